@@ -1,0 +1,206 @@
+/*
+ * pgr_hip.h -- C ABI of libpgrhip.so: MI355X (gfx950) SHIMMER minimizer indexing and
+ * sparse hit chaining.  This is the drop-in boundary for ONE hot path of GeneDx/pgr-tk
+ * (SURVEY.md section 8b).  Plain pointers and sizes only; no C++/torch types.
+ *
+ * Conventions
+ *   - every function returns PGR_OK (0) or a negative pgr_status; the message of the last
+ *     failure is available from pgr_last_error(ctx).  Nothing aborts or throws across the
+ *     boundary (the reference panics / asserts instead: shmmrutils.rs:443-445).
+ *   - inputs are borrowed for the duration of the call.  Host outputs are allocated by the
+ *     library and released with pgr_free() (the reference's only existing C-ABI precedent,
+ *     the AGC FFI, uses the same pattern: pgr-db/src/agc_io.rs:76-116, agc_list_destroy).
+ *   - a context is bound to one GPU and is NOT thread safe: one context per (thread, GPU).
+ *     The reference calls sequence_to_shmmrs once per contig from a rayon par_iter
+ *     (pgr-db/src/seq_db.rs:456-469); the replacement takes the whole batch in one call.
+ *   - there is no CPU fallback: without a usable gfx950 device pgr_ctx_create fails.
+ *
+ * All structs are POD, little endian, layout-identical to the Rust types they stand for.
+ */
+#ifndef PGR_HIP_H
+#define PGR_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    PGR_OK = 0,
+    PGR_ERR_INVALID_ARG = -1, /* NULL pointer, bad size ...                                   */
+    PGR_ERR_BAD_SPEC = -2,    /* k>56, w>128, r not in 1..12 (reference: assert!)             */
+    PGR_ERR_DEVICE = -3,      /* HIP runtime error / no gfx950 device                         */
+    PGR_ERR_NOMEM = -4,
+    PGR_ERR_TOO_LONG = -5,    /* contig length >= 2^31 (MM128.y holds pos in 31 bits)         */
+    PGR_ERR_STATE = -6,       /* call order / handle misuse                                   */
+    PGR_ERR_INTERNAL = -7
+} pgr_status;
+
+/* ShmmrSpec: pgr-db/src/shmmrutils.rs:20-27 (serialised as 5 x u32 in .mdb, seq_db.rs:1302-1306) */
+typedef struct {
+    uint32_t w, k, r, min_span;
+    uint32_t sketch; /* bool */
+} pgr_spec;
+
+/* MM128: pgr-db/src/shmmrutils.rs:225-269.  x = hash<<8 | k ; y = rid<<32 | pos<<1 | strand */
+typedef struct {
+    uint64_t x, y;
+} pgr_mm128;
+
+/* one shimmer-pair record = key + FragmentSignature
+ * ((u64,u64),u32,u32,u8) of seq_db.rs:381-400 + (frg_id, sid) of seq_db.rs:605-612 */
+typedef struct {
+    uint64_t h0, h1;  /* ShmmrPair key, h0 <= h1                         */
+    uint32_t frg_id;  /* pair ordinal within the contig (index-only path) */
+    uint32_t sid;     /* sequence id                                      */
+    uint32_t bgn, end;
+    uint32_t orient;  /* 0: hash(s0) <= hash(s1) (index side) / < (query side) */
+    uint32_t _pad;
+} pgr_frag_rec;
+
+/* HitPair: pgr-db/src/aln.rs:10 */
+typedef struct {
+    uint32_t qb, qe, qo;
+    uint32_t tb, te, to;
+} pgr_hitpair;
+
+typedef struct pgr_ctx pgr_ctx;
+typedef struct pgr_batch pgr_batch;   /* a batch of contigs resident on the GPU, 2-bit packed */
+typedef struct pgr_shmmrs pgr_shmmrs; /* device-resident result of one sequence_to_shmmrs pass */
+typedef struct pgr_index pgr_index;   /* ShmmrToFrags as a GPU/host CSR                        */
+
+/* ------------------------------------------------------------------ context */
+int pgr_ctx_create(int device, pgr_ctx **out);
+void pgr_ctx_destroy(pgr_ctx *ctx);
+const char *pgr_last_error(const pgr_ctx *ctx); /* ctx may be NULL: last create error */
+void pgr_free(void *p);
+const char *pgr_version(void);
+
+/* ------------------------------------------------------------------ B1: sequence_to_shmmrs
+ * Replaces shmmrutils::sequence_to_shmmrs (pgr-db/src/shmmrutils.rs:657-669) as called
+ * batched from CompactSeqDB::get_shmmrs_from_seqs (pgr-db/src/seq_db.rs:456-469):
+ *   seqs[i]  ASCII bytes of contig i (same byte semantics as shmmrutils.rs:426-436)
+ *   rids[i]  value placed in MM128.y >> 32 (NULL: rid = i)
+ *   padding  as the reference's `padding` argument (only Python get_shmmr_pairs_from_seq
+ *            passes true, pgr-tk/src/lib.rs:1597)
+ * out:  *out_mm    concatenated MM128 of all contigs (pgr_free)
+ *       *out_off   n_seqs+1 offsets into *out_mm    (pgr_free)                            */
+int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n_seqs,
+                    const uint8_t *const *seqs, const uint64_t *lens, const uint32_t *rids,
+                    int padding, pgr_mm128 **out_mm, uint64_t **out_off);
+
+/* Fused B1 + pair_shmmrs/seq_to_index (pgr-db/src/seq_db.rs:102-111, 360-418): one record
+ * per adjacent shimmer pair, frg_id = pair ordinal in the contig, sid = sids[i] (NULL: i).
+ * query_side != 0 uses the strict `<` of raw_query_fragment (seq_db.rs:1213).             */
+int pgr_frag_recs_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n_seqs,
+                        const uint8_t *const *seqs, const uint64_t *lens, const uint32_t *sids,
+                        int query_side, pgr_frag_rec **out_recs, uint64_t **out_off);
+
+/* ------------------------------------------------------------------ device-resident path
+ * (what bench.py times: inputs already in HBM, results left in HBM)                        */
+
+/* H2D + ASCII -> 2-bit planes (+ validity plane) */
+int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n_seqs, const uint8_t *const *seqs,
+                         const uint64_t *lens, pgr_batch **out);
+/* counter-based synthetic contigs generated on the device:
+ * base(c,i) = (splitmix64(seed ^ c*0x9E3779B97F4A7C15 ^ (i>>5)) >> (2*(i&31))) & 3,
+ * c = contig0 + index.  Identical to oracle orc_synth_contig.                              */
+int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n_seqs, const uint64_t *lens, uint64_t seed,
+                        uint64_t contig0, pgr_batch **out);
+void pgr_batch_destroy(pgr_batch *b);
+uint64_t pgr_batch_total_bases(const pgr_batch *b);
+
+/* the hot path on a resident batch; result stays on the device.  rids may be NULL (rid=i). */
+int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec,
+                       const uint32_t *rids, int padding, pgr_shmmrs **out);
+uint64_t pgr_shmmrs_count(const pgr_shmmrs *s);
+/* device pointers (valid until pgr_shmmrs_destroy): MM128[count], u64 offsets[n_seqs+1] */
+const pgr_mm128 *pgr_shmmrs_device_ptr(const pgr_shmmrs *s);
+const uint64_t *pgr_shmmrs_device_offsets(const pgr_shmmrs *s);
+int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 **out_mm, uint64_t **out_off);
+void pgr_shmmrs_destroy(pgr_shmmrs *s);
+
+/* device pair records from a resident result; d_out must hold count - n_nonempty records;
+ * returns the number written in *n_out.  sids may be NULL.  d_out is a DEVICE pointer
+ * (e.g. a torch tensor's data_ptr) so that per-GPU buffers can be all-gathered by RCCL.   */
+uint64_t pgr_shmmrs_n_pairs(const pgr_shmmrs *s);
+int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids,
+                                   int query_side, pgr_frag_rec *d_out, uint64_t capacity,
+                                   uint64_t *n_out);
+
+/* ------------------------------------------------------------------ profiling hooks
+ * HIP-event timing of the kernels of the LAST pgr_shmmrs_compute on the context's stream. */
+typedef struct {
+    float level1_ms;     /* dominant kernel (level1_tile_kernel): k-mer hash + windowed minimizers */
+    float level1_aux_ms; /* tail kernel + serial (exact state machine) kernel                       */
+    float level2_ms;     /* gather + reduce x2 + min_span filter                                    */
+    float total_ms;      /* first launch to last kernel of pgr_shmmrs_compute (incl. host syncs)    */
+    uint64_t n_level1;   /* level-1 minimizers emitted                                              */
+    uint64_t n_tiles;    /* workgroups of the dominant kernel                                       */
+    uint64_t n_serial_contigs; /* contigs routed to the serial GPU kernel                           */
+    uint64_t bases_tiled;      /* bases covered by the dominant kernel                              */
+} pgr_prof;
+int pgr_ctx_last_prof(const pgr_ctx *ctx, pgr_prof *out);
+int pgr_ctx_synchronize(pgr_ctx *ctx);
+
+/* ------------------------------------------------------------------ index (ShmmrToFrags)
+ * frag_map: FxHashMap<(u64,u64), Vec<FragmentSignature>> (pgr-db/src/seq_db.rs:75-76) as a
+ * CSR sorted by key; within a key the records keep (sid, frg_id) insertion order
+ * (seq_db.rs:605-612).                                                                      */
+int pgr_index_create(pgr_ctx *ctx, const pgr_spec *spec, pgr_index **out);
+void pgr_index_destroy(pgr_index *ix);
+/* load_index_from_seq_vec (seq_db.rs:573-615): append contigs; sids[i] NULL -> running id */
+int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *ix, uint32_t n_seqs, const uint8_t *const *seqs,
+                        const uint64_t *lens, const uint32_t *sids);
+int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_batch *b, const uint32_t *sids);
+/* merge pair records computed elsewhere (other GPUs, after the RCCL all-gather) */
+int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs, uint64_t n,
+                          int recs_on_device);
+int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix); /* sort -> CSR (GPU) */
+uint64_t pgr_index_n_keys(const pgr_index *ix);
+uint64_t pgr_index_n_records(const pgr_index *ix);
+/* host copy of the sorted records (pgr_free) */
+int pgr_index_download(pgr_ctx *ctx, const pgr_index *ix, pgr_frag_rec **out, uint64_t *n);
+
+/* ------------------------------------------------------------------ B2: query_fragment_to_hps
+ * Replaces SeqIndexDB::query_fragment_to_hps (pgr-db/src/ext.rs:252-282) =
+ * raw_query_fragment (seq_db.rs:1200-1228) + aln::query_fragment_to_hps (aln.rs:147-242) +
+ * aln::sparse_aln (aln.rs:12-142) for a whole batch of queries (the reference loops over
+ * queries with rayon, pgr-bin/src/bin/pgr-query.rs:135-165).
+ * Result layout (flat, all arrays pgr_free'd through pgr_hps_result_free):
+ *   query q owns targets  [q_off[q], q_off[q+1])
+ *   target t: sid = t_sid[t], owns chains [t_off[t], t_off[t+1])      (sorted by sid)
+ *   chain c: score = c_score[c], owns hit pairs [c_off[c], c_off[c+1])                      */
+typedef struct {
+    uint32_t n_queries;
+    uint64_t *q_off;
+    uint64_t n_targets;
+    uint32_t *t_sid;
+    uint64_t *t_off;
+    uint64_t n_chains;
+    float *c_score;
+    uint64_t *c_off;
+    uint64_t n_hps;
+    pgr_hitpair *hps;
+} pgr_hps_result;
+
+int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries,
+                        const uint8_t *const *seqs, const uint64_t *lens, float penalty,
+                        uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
+                        uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
+                        pgr_hps_result *out);
+void pgr_hps_result_free(pgr_hps_result *r);
+
+/* aln::sparse_aln on caller-provided hit pairs (pgr-tk/src/lib.rs:1539 `sparse_aln`):
+ * n_groups groups, group g = hits[g_off[g], g_off[g+1]).  Output as above with one
+ * "query" and one target per group (t_sid = group index).                                  */
+int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_hitpair *hits,
+                         const uint64_t *g_off, uint32_t max_span, float penalty, int has_max_gap,
+                         uint32_t max_gap, int oriented, pgr_hps_result *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGR_HIP_H */

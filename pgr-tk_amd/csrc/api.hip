@@ -1,0 +1,688 @@
+// api.hip -- host side of libpgrhip.so: context, resident batches, orchestration of the
+// sequence_to_shmmrs pipeline, and the C ABI declared in include/pgr_hip.h.
+//
+// Pipeline of one pgr_shmmrs_compute:
+//   level1_tile_kernel  (dominant)  -> unordered per-tile segments of level-1 minimizers
+//   level1_tail_kernel              -> per-contig tail segment (rescan-only positions)
+//   level1_serial_kernel            -> whole-contig segment for contigs the closed form cannot do
+//   scan(seg counts) + gather       -> ordered per-contig level-1 lists
+//   select(reduce) x2, select(min_span) -> final MM128 lists (+ rid patch)
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+
+#include "pgr_ctx.h"
+
+using namespace pgr;
+
+static std::string g_create_error;
+
+extern "C" const char *pgr_version(void) { return "pgr-hip 0.1.0 (gfx950)"; }
+
+extern "C" const char *pgr_last_error(const pgr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+extern "C" void pgr_free(void *p) { free(p); }
+
+extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
+    if (!out) return PGR_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n_dev = 0;
+    hipError_t e = hipGetDeviceCount(&n_dev);
+    if (e != hipSuccess || n_dev <= 0) {
+        g_create_error = std::string("no HIP device available: ") + hipGetErrorString(e) +
+                         " (libpgrhip has no CPU fallback)";
+        return PGR_ERR_DEVICE;
+    }
+    if (device < 0 || device >= n_dev) {
+        g_create_error = "device index out of range";
+        return PGR_ERR_INVALID_ARG;
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) {
+        g_create_error = std::string("hipGetDeviceProperties: ") + hipGetErrorString(e);
+        return PGR_ERR_DEVICE;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_error = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return PGR_ERR_DEVICE;
+    }
+    pgr_ctx *ctx = new pgr_ctx();
+    ctx->device = device;
+    e = hipSetDevice(device);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
+    if (e != hipSuccess) {
+        g_create_error = std::string("context setup: ") + hipGetErrorString(e);
+        delete ctx;
+        return PGR_ERR_DEVICE;
+    }
+    *out = ctx;
+    return PGR_OK;
+}
+
+extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    ctx->release_all();
+    for (auto &ev : ctx->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int pgr_ctx_synchronize(pgr_ctx *ctx) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return PGR_OK;
+}
+
+extern "C" int pgr_ctx_last_prof(const pgr_ctx *ctx, pgr_prof *out) {
+    if (!ctx || !out) return PGR_ERR_INVALID_ARG;
+    *out = ctx->prof;
+    return PGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batches
+static int batch_alloc(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, pgr_batch **out) {
+    pgr_batch *b = new pgr_batch();
+    b->ctx = ctx;
+    b->n = n;
+    b->h_word_off.resize((size_t)n + 1);
+    b->h_len.resize(n);
+    b->h_n_invalid.assign(n, 0);
+    uint64_t words = 0, bases = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (lens[i] >= (1ull << 31)) {
+            delete b;
+            return ctx->fail(PGR_ERR_TOO_LONG, "contig length >= 2^31 (MM128 position field is 31 bits)");
+        }
+        b->h_word_off[i] = words;
+        b->h_len[i] = (uint32_t)lens[i];
+        words += (lens[i] + 31) / 32;
+        bases += lens[i];
+    }
+    b->h_word_off[n] = words;
+    b->total_words = words;
+    b->total_bases = bases;
+    int rc;
+    if ((rc = ctx->dmalloc((void **)&b->d.planes, std::max<uint64_t>(words, 1) * sizeof(uint2))) ||
+        (rc = ctx->dmalloc((void **)&b->d.valid, std::max<uint64_t>(words, 1) * sizeof(uint32_t))) ||
+        (rc = ctx->dmalloc((void **)&b->d.word_off, ((size_t)n + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->dmalloc((void **)&b->d.len, std::max<uint32_t>(n, 1) * sizeof(uint32_t))) ||
+        (rc = ctx->dmalloc((void **)&b->d.n_invalid, std::max<uint32_t>(n, 1) * sizeof(uint32_t)))) {
+        pgr_batch_destroy(b);
+        return rc;
+    }
+    PGR_HIP(ctx, hipMemcpyAsync(b->d.word_off, b->h_word_off.data(), ((size_t)n + 1) * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, ctx->stream));
+    if (n)
+        PGR_HIP(ctx, hipMemcpyAsync(b->d.len, b->h_len.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice,
+                                    ctx->stream));
+    PGR_HIP(ctx, hipMemsetAsync(b->d.n_invalid, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), ctx->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out = b;
+    return PGR_OK;
+}
+
+extern "C" void pgr_batch_destroy(pgr_batch *b) {
+    if (!b) return;
+    pgr_ctx *ctx = b->ctx;
+    ctx->dfree(b->d.planes);
+    ctx->dfree(b->d.valid);
+    ctx->dfree(b->d.word_off);
+    ctx->dfree(b->d.len);
+    ctx->dfree(b->d.n_invalid);
+    delete b;
+}
+
+extern "C" uint64_t pgr_batch_total_bases(const pgr_batch *b) { return b ? b->total_bases : 0; }
+
+extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                                    pgr_batch **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out || (n && (!seqs || !lens))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
+    pgr_batch *b = nullptr;
+    int rc = batch_alloc(ctx, n, lens, &b);
+    if (rc) return rc;
+    // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Staged through a pinned window.
+    const uint64_t WIN_WORDS = 4ull << 20;  // 128 MiB of ASCII per window
+    const uint64_t win_words = std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
+    if ((rc = ctx->ensure_pinned(win_words * 32)) || (rc = ctx->ws_ascii.ensure(ctx, win_words * 32))) {
+        pgr_batch_destroy(b);
+        return rc;
+    }
+    uint32_t c = 0;
+    for (uint64_t w0 = 0; w0 < b->total_words; w0 += win_words) {
+        const uint64_t w1 = std::min(b->total_words, w0 + win_words);
+        uint8_t *stage = (uint8_t *)ctx->pinned;
+        while (c < n && b->h_word_off[c + 1] <= w0) ++c;
+        for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1; ++cc) {
+            const uint64_t cw0 = b->h_word_off[cc], cw1 = b->h_word_off[cc + 1];
+            const uint64_t lo = std::max(cw0, w0), hi = std::min(cw1, w1);
+            if (lo >= hi) continue;
+            const uint64_t b_lo = (lo - cw0) * 32, b_hi = std::min<uint64_t>((hi - cw0) * 32, lens[cc]);
+            if (b_hi > b_lo) memcpy(stage + (lo - w0) * 32, seqs[cc] + b_lo, b_hi - b_lo);
+        }
+        if (hipMemcpyAsync(ctx->ws_ascii.p, stage, (w1 - w0) * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            pgr_batch_destroy(b);
+            return ctx->fail(PGR_ERR_DEVICE, "H2D copy of the ASCII window failed");
+        }
+        launch_pack_ascii(ctx->stream, (const uint8_t *)ctx->ws_ascii.p, w0, b->d, n, w1);
+        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+            pgr_batch_destroy(b);
+            return ctx->fail(PGR_ERR_DEVICE, "pack kernel failed");
+        }
+    }
+    if (n) {
+        if (hipMemcpy(b->h_n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) !=
+            hipSuccess) {
+            pgr_batch_destroy(b);
+            return ctx->fail(PGR_ERR_DEVICE, "D2H of the invalid-base counts failed");
+        }
+    }
+    *out = b;
+    return PGR_OK;
+}
+
+extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint64_t seed, uint64_t contig0,
+                                   pgr_batch **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out || (n && !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    pgr_batch *b = nullptr;
+    int rc = batch_alloc(ctx, n, lens, &b);
+    if (rc) return rc;
+    launch_synth(ctx->stream, b->d, n, b->total_words, seed, contig0);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        pgr_batch_destroy(b);
+        return ctx->fail(PGR_ERR_DEVICE, "synthetic generator kernel failed");
+    }
+    *out = b;
+    return PGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ordered segmented select: in/off_in -> out/off_out; returns the number of survivors
+static int run_select(pgr_ctx *ctx, SelArgs a, DevBuf &out_buf, uint64_t *d_off_out, uint64_t *n_out) {
+    hipStream_t st = ctx->stream;
+    const uint32_t n_blocks = (uint32_t)((a.n + SEL_BLOCK_ELEMS - 1) / SEL_BLOCK_ELEMS);
+    int rc;
+    if ((rc = ctx->ws_blk_cnt.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_blk_base.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_start_rank.ensure(ctx, std::max<uint32_t>(a.n_contigs, 1) * sizeof(uint64_t))))
+        return rc;
+    uint32_t *blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
+    uint64_t *blk_base = (uint64_t *)ctx->ws_blk_base.p;
+    PGR_HIP(ctx, hipMemsetAsync(blk_cnt + n_blocks, 0, sizeof(uint32_t), st));
+    launch_select_count(st, a, blk_cnt, n_blocks);
+    const size_t tb = scan_counts_temp_bytes(n_blocks + 1);
+    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, blk_cnt, blk_base, n_blocks + 1));
+    uint64_t total = 0;
+    PGR_HIP(ctx, hipMemcpyAsync(&total, blk_base + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = out_buf.ensure(ctx, std::max<uint64_t>(total, 1) * sizeof(pgr_mm128)))) return rc;
+    launch_select_scatter(st, a, blk_base, n_blocks, (pgr_mm128 *)out_buf.p, (uint64_t *)ctx->ws_start_rank.p);
+    launch_fill_offsets(st, a.off_in, (const uint64_t *)ctx->ws_start_rank.p, a.n_contigs, blk_base + n_blocks,
+                        d_off_out);
+    PGR_HIP(ctx, hipGetLastError());
+    *n_out = total;
+    return PGR_OK;
+}
+
+static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
+    if (!spec) return ctx->fail(PGR_ERR_INVALID_ARG, "null spec");
+    // shmmrutils.rs:443-445 / :575-576
+    if (spec->k == 0 || spec->k > 56) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.k must be in 1..56");
+    if (spec->r == 0 || spec->r > 12) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.r must be in 1..12");
+    if (!spec->sketch && (spec->w == 0 || spec->w > 128)) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.w must be in 1..128");
+    return PGR_OK;
+}
+
+extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *rids,
+                                  int padding, pgr_shmmrs **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!b || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    int rc = check_spec(ctx, spec);
+    if (rc) return rc;
+    if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t n = b->n;
+    const bool sketch = spec->sketch != 0;
+    const bool tiled = sketch || spec->w >= (uint32_t)L1_MIN_W;
+    const uint32_t w_eff = sketch ? 1u : spec->w;
+    const uint32_t tc = L1_EXT - 2 * (w_eff - 1);
+
+    // ---- host plan: tiles for the closed form, list for the serial kernel
+    std::vector<uint32_t> tile_first((size_t)n + 1);
+    std::vector<uint32_t> serial;
+    uint64_t n_tiles64 = 0, bases_tiled = 0;
+    for (uint32_t c = 0; c < n; ++c) {
+        tile_first[c] = (uint32_t)n_tiles64;
+        const uint64_t L = b->h_len[c];
+        if (L == 0) continue;
+        if (tiled && b->h_n_invalid[c] == 0) {
+            n_tiles64 += (L + tc - 1) / tc;
+            bases_tiled += L;
+        } else {
+            serial.push_back(c);
+        }
+    }
+    if (n_tiles64 + n + 1 >= (1ull << 31)) return ctx->fail(PGR_ERR_INVALID_ARG, "batch too large (tile count)");
+    tile_first[n] = (uint32_t)n_tiles64;
+    const uint32_t n_tiles = (uint32_t)n_tiles64;
+    const uint32_t n_segs = n_tiles + n;
+
+    // capacity of the cursor-allocated region: expected density 2/(w+1) (sketch: 2^-(4+r)) + slack
+    const double dens = sketch ? 1.0 / (double)(1ull << (4 + spec->r)) : 2.0 / (double)(spec->w + 1);
+    uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 1.25) + 65536 + 4ull * n;
+    auto serial_cap = [&](uint32_t c, bool full) -> uint64_t {
+        const uint64_t L = b->h_len[c];
+        return full ? L : std::min<uint64_t>(L, L / 4 + 4096);
+    };
+
+    if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_cursor.ensure(ctx, 2 * sizeof(unsigned long long))) ||
+        (rc = ctx->ws_flags.ensure(ctx, std::max<uint32_t>(n, 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_off_b.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))))
+        return rc;
+    PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t),
+                                hipMemcpyHostToDevice, st));
+    uint32_t *d_rids = nullptr;
+    if (rids && n) {
+        if ((rc = ctx->ws_rids.ensure(ctx, (size_t)n * sizeof(uint32_t)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rids.p, rids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        d_rids = (uint32_t *)ctx->ws_rids.p;
+    }
+
+    L1Args a;
+    a.b = b->d;
+    a.n_contigs = n;
+    a.n_tiles = n_tiles;
+    a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
+    a.w = w_eff;
+    a.k = spec->k;
+    a.r = spec->r;
+    a.tc = tc;
+    a.sketch = sketch ? 1u : 0u;
+    a.cursor = (unsigned long long *)ctx->ws_cursor.p;
+    a.seg_off = (uint64_t *)ctx->ws_seg_off.p;
+    a.seg_cnt = (uint32_t *)ctx->ws_seg_cnt.p;
+    a.contig_flags = (uint32_t *)ctx->ws_flags.p;
+
+    pgr_prof prof;
+    memset(&prof, 0, sizeof(prof));
+    prof.n_tiles = n_tiles;
+    prof.bases_tiled = bases_tiled;
+    std::vector<uint32_t> flags(n);
+    std::vector<char> in_serial(n, 0);
+    for (uint32_t c : serial) in_serial[c] = 1;
+
+    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    uint64_t serial_base = 0;  // first element of the serial regions inside the level-1 buffer
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 4) return ctx->fail(PGR_ERR_INTERNAL, "level-1 buffer kept overflowing");
+        uint64_t serial_total = 0;
+        for (uint32_t c : serial) serial_total += serial_cap(c, false);
+        if ((rc = ctx->ws_l1.ensure(ctx, (cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return rc;
+        a.out = (pgr_mm128 *)ctx->ws_l1.p;
+        a.cap = cap_par;
+        serial_base = cap_par;
+        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), st));
+        PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
+        PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        launch_level1_tiles(st, a);
+        PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
+        launch_level1_tails(st, a);
+        unsigned long long cur[2] = {0, 0};
+        PGR_HIP(ctx, hipMemcpyAsync(cur, ctx->ws_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
+        if (n) PGR_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->ws_flags.p, (size_t)n * sizeof(uint32_t),
+                                           hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        PGR_HIP(ctx, hipGetLastError());
+        if (cur[1] || cur[0] > cap_par) {  // cursor region too small: grow and redo
+            cap_par = (uint64_t)((double)cur[0] * 1.1) + 65536;
+            continue;
+        }
+        prof.n_level1 = cur[0];
+        break;
+    }
+    // contigs with palindromic k-mers (skipped pushes) join the serial list
+    if (!sketch)
+        for (uint32_t c = 0; c < n; ++c)
+            if ((flags[c] & 1u) && !in_serial[c]) {
+                serial.push_back(c);
+                in_serial[c] = 1;
+            }
+    prof.n_serial_contigs = serial.size();
+    if (!serial.empty()) {
+        std::sort(serial.begin(), serial.end());
+        std::vector<char> full(serial.size(), 0);
+        for (int attempt = 0;; ++attempt) {
+            if (attempt > 2) return ctx->fail(PGR_ERR_INTERNAL, "serial kernel kept overflowing");
+            const size_t ns = serial.size();
+            std::vector<uint64_t> roff(ns), rcap(ns);
+            uint64_t o = serial_base;
+            for (size_t i = 0; i < ns; ++i) {
+                roff[i] = o;
+                rcap[i] = serial_cap(serial[i], full[i] != 0);
+                o += rcap[i];
+            }
+            if ((rc = ctx->ws_l1.ensure_keep(ctx, (o + 1) * sizeof(pgr_mm128), st))) return rc;
+            a.out = (pgr_mm128 *)ctx->ws_l1.p;
+            if ((rc = ctx->ws_serial.ensure(ctx, ns * (sizeof(uint32_t) * 2 + sizeof(uint64_t) * 2)))) return rc;
+            uint64_t *d_roff = (uint64_t *)ctx->ws_serial.p;
+            uint64_t *d_rcap = d_roff + ns;
+            uint32_t *d_list = (uint32_t *)(d_rcap + ns);
+            uint32_t *d_ovf = d_list + ns;
+            PGR_HIP(ctx, hipMemcpyAsync(d_roff, roff.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            PGR_HIP(ctx, hipMemcpyAsync(d_rcap, rcap.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+            PGR_HIP(ctx, hipMemcpyAsync(d_list, serial.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            PGR_HIP(ctx, hipMemsetAsync(d_ovf, 0, ns * sizeof(uint32_t), st));
+            L1Args as = a;
+            as.w = spec->w;  // the serial kernel follows the spec literally (sketch ignores w)
+            launch_level1_serial(st, as, d_list, (uint32_t)ns, d_roff, d_rcap, d_ovf);
+            std::vector<uint32_t> ovf(ns);
+            PGR_HIP(ctx, hipMemcpyAsync(ovf.data(), d_ovf, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PGR_HIP(ctx, hipStreamSynchronize(st));
+            PGR_HIP(ctx, hipGetLastError());
+            bool again = false;
+            for (size_t i = 0; i < ns; ++i)
+                if (ovf[i]) {
+                    full[i] = 1;
+                    again = true;
+                }
+            if (!again) break;
+        }
+    }
+    PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+
+    // ---- ordered per-contig level-1 lists
+    const size_t tb = scan_counts_temp_bytes(n_segs + 1);
+    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, (const uint32_t *)ctx->ws_seg_cnt.p,
+                             (uint64_t *)ctx->ws_seg_dst.p, n_segs + 1));
+    uint64_t total1 = 0;
+    PGR_HIP(ctx, hipMemcpyAsync(&total1, (uint64_t *)ctx->ws_seg_dst.p + n_segs, sizeof(uint64_t),
+                                hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    prof.n_level1 = total1;
+    if ((rc = ctx->ws_list_a.ensure(ctx, std::max<uint64_t>(total1, 1) * sizeof(pgr_mm128)))) return rc;
+    launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_l1.p, (const uint64_t *)ctx->ws_seg_off.p,
+                           (const uint32_t *)ctx->ws_seg_cnt.p, (const uint64_t *)ctx->ws_seg_dst.p, n_segs,
+                           (pgr_mm128 *)ctx->ws_list_a.p);
+    launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
+                          (uint64_t *)ctx->ws_off_a.p);
+
+    // ---- reduce x2 (shmmrutils.rs:533-535), min_span filter (:536-555)
+    DevBuf *cur_list = &ctx->ws_list_a, *nxt_list = &ctx->ws_list_b;
+    DevBuf *cur_off = &ctx->ws_off_a, *nxt_off = &ctx->ws_off_b;
+    uint64_t cur_n = total1;
+    std::vector<uint64_t> l1_off;  // only needed for the padding artefact
+    const bool pad_fix = padding && !sketch && spec->r > 1;
+    if (pad_fix) {
+        l1_off.resize((size_t)n + 1);
+        PGR_HIP(ctx, hipMemcpyAsync(l1_off.data(), cur_off->p, ((size_t)n + 1) * sizeof(uint64_t),
+                                    hipMemcpyDeviceToHost, st));
+    }
+    if (!sketch && spec->r > 1) {
+        for (int round = 0; round < 2; ++round) {
+            SelArgs s;
+            s.in = (const pgr_mm128 *)cur_list->p;
+            s.n = cur_n;
+            s.off_in = (const uint64_t *)cur_off->p;
+            s.n_contigs = n;
+            s.mode = 0;
+            s.r = spec->r;
+            s.padding = padding ? 1u : 0u;
+            s.min_span = 0;
+            s.rids = nullptr;
+            uint64_t n_out = 0;
+            if ((rc = run_select(ctx, s, *nxt_list, (uint64_t *)nxt_off->p, &n_out))) return rc;
+            std::swap(cur_list, nxt_list);
+            std::swap(cur_off, nxt_off);
+            cur_n = n_out;
+        }
+    }
+    pgr_shmmrs *res = new pgr_shmmrs();
+    res->ctx = ctx;
+    res->n = n;
+    res->h_off.assign((size_t)n + 1, 0);
+    {
+        SelArgs s;
+        s.in = (const pgr_mm128 *)cur_list->p;
+        s.n = cur_n;
+        s.off_in = (const uint64_t *)cur_off->p;
+        s.n_contigs = n;
+        s.mode = 1;
+        s.r = spec->r;
+        s.padding = 0;
+        s.min_span = spec->min_span;
+        s.rids = d_rids;
+        uint64_t n_out = 0;
+        if ((rc = run_select(ctx, s, *nxt_list, (uint64_t *)nxt_off->p, &n_out))) {
+            delete res;
+            return rc;
+        }
+        std::swap(cur_list, nxt_list);
+        std::swap(cur_off, nxt_off);
+        cur_n = n_out;
+    }
+    auto bail = [&](int code) {
+        pgr_shmmrs_destroy(res);
+        return code;
+    };
+    if (hipMemcpyAsync(res->h_off.data(), cur_off->p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st) !=
+            hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return bail(ctx->fail(PGR_ERR_DEVICE, "D2H of the result offsets failed"));
+
+    std::vector<uint64_t> final_off = res->h_off;
+    bool need_sentinels = false;
+    if (pad_fix) {
+        uint64_t add = 0;
+        for (uint32_t c = 0; c < n; ++c) {
+            final_off[c] = res->h_off[c] + add;
+            if (l1_off[c + 1] == l1_off[c]) {  // empty level-1 list -> two {MAX,MAX} (reference artefact)
+                add += 2;
+                need_sentinels = true;
+            }
+        }
+        final_off[n] = res->h_off[n] + add;
+    }
+    res->count = final_off[n];
+    if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(res->count, 1) * sizeof(pgr_mm128))) ||
+        (rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t))))
+        return bail(rc);
+    if (hipMemcpyAsync(res->d_off, final_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) !=
+        hipSuccess)
+        return bail(ctx->fail(PGR_ERR_DEVICE, "H2D of the result offsets failed"));
+    if (need_sentinels) {
+        launch_copy_or_sentinel(st, (const pgr_mm128 *)cur_list->p, (const uint64_t *)cur_off->p, res->d_off, n,
+                                res->d_mm);
+    } else if (cur_n) {
+        if (hipMemcpyAsync(res->d_mm, cur_list->p, cur_n * sizeof(pgr_mm128), hipMemcpyDeviceToDevice, st) != hipSuccess)
+            return bail(ctx->fail(PGR_ERR_DEVICE, "D2D copy of the result failed"));
+    }
+    res->h_off = final_off;
+    hipEvent_t ev_end = ctx->ev_end;
+    if (hipEventRecord(ev_end, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
+        hipGetLastError() != hipSuccess)
+        return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
+    (void)hipEventElapsedTime(&prof.level1_ms, ctx->ev[1], ctx->ev[2]);
+    (void)hipEventElapsedTime(&prof.level1_aux_ms, ctx->ev[2], ctx->ev[3]);
+    (void)hipEventElapsedTime(&prof.level2_ms, ctx->ev[3], ev_end);
+    (void)hipEventElapsedTime(&prof.total_ms, ctx->ev[0], ev_end);
+    ctx->prof = prof;
+    *out = res;
+    return PGR_OK;
+}
+
+extern "C" uint64_t pgr_shmmrs_count(const pgr_shmmrs *s) { return s ? s->count : 0; }
+extern "C" const pgr_mm128 *pgr_shmmrs_device_ptr(const pgr_shmmrs *s) { return s ? s->d_mm : nullptr; }
+extern "C" const uint64_t *pgr_shmmrs_device_offsets(const pgr_shmmrs *s) { return s ? s->d_off : nullptr; }
+
+extern "C" void pgr_shmmrs_destroy(pgr_shmmrs *s) {
+    if (!s) return;
+    s->ctx->dfree(s->d_mm);
+    s->ctx->dfree(s->d_off);
+    delete s;
+}
+
+extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 **out_mm, uint64_t **out_off) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!s || !out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out_mm = nullptr;
+    *out_off = nullptr;
+    pgr_mm128 *mm = (pgr_mm128 *)malloc(std::max<uint64_t>(s->count, 1) * sizeof(pgr_mm128));
+    uint64_t *off = (uint64_t *)malloc(((size_t)s->n + 1) * sizeof(uint64_t));
+    if (!mm || !off) {
+        free(mm);
+        free(off);
+        return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    }
+    memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * sizeof(uint64_t));
+    if (s->count) {
+        hipError_t e = hipMemcpyAsync(mm, s->d_mm, s->count * sizeof(pgr_mm128), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            free(mm);
+            free(off);
+            return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+        }
+    }
+    *out_mm = mm;
+    *out_off = off;
+    return PGR_OK;
+}
+
+extern "C" uint64_t pgr_shmmrs_n_pairs(const pgr_shmmrs *s) {
+    if (!s) return 0;
+    uint64_t np = 0;
+    for (uint32_t c = 0; c < s->n; ++c) {
+        const uint64_t cnt = s->h_off[c + 1] - s->h_off[c];
+        if (cnt > 1) np += cnt - 1;
+    }
+    return np;
+}
+
+extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
+                                              pgr_frag_rec *d_out, uint64_t capacity, uint64_t *n_out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!s || !n_out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    const uint32_t n = s->n;
+    std::vector<uint64_t> rec_off((size_t)n + 1);
+    uint64_t np = 0;
+    for (uint32_t c = 0; c < n; ++c) {
+        rec_off[c] = np;
+        const uint64_t cnt = s->h_off[c + 1] - s->h_off[c];
+        if (cnt > 1) np += cnt - 1;
+    }
+    rec_off[n] = np;
+    *n_out = np;
+    if (np == 0) return PGR_OK;
+    if (!d_out || capacity < np) return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the pair records");
+    hipStream_t st = ctx->stream;
+    int rc;
+    if ((rc = ctx->ws_rec_off.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t)))) return rc;
+    PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rec_off.p, rec_off.data(), ((size_t)n + 1) * sizeof(uint64_t),
+                                hipMemcpyHostToDevice, st));
+    uint32_t *d_sids = nullptr;
+    if (sids) {
+        if ((rc = ctx->ws_rids.ensure(ctx, (size_t)n * sizeof(uint32_t)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rids.p, sids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        d_sids = (uint32_t *)ctx->ws_rids.p;
+    }
+    launch_frag_recs(st, s->d_mm, s->d_off, (const uint64_t *)ctx->ws_rec_off.p, n, s->count, d_sids, query_side, d_out);
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    PGR_HIP(ctx, hipGetLastError());
+    return PGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-buffer conveniences (the B1 drop-in)
+extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
+                               const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
+                               uint64_t **out_off) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null output pointer");
+    int rc = check_spec(ctx, spec);
+    if (rc) return rc;
+    pgr_batch *b = nullptr;
+    if ((rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b))) return rc;
+    pgr_shmmrs *s = nullptr;
+    rc = pgr_shmmrs_compute(ctx, b, spec, rids, padding, &s);
+    pgr_batch_destroy(b);
+    if (rc) return rc;
+    rc = pgr_shmmrs_download(ctx, s, out_mm, out_off);
+    pgr_shmmrs_destroy(s);
+    return rc;
+}
+
+extern "C" int pgr_frag_recs_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
+                                   const uint64_t *lens, const uint32_t *sids, int query_side, pgr_frag_rec **out_recs,
+                                   uint64_t **out_off) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out_recs || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null output pointer");
+    *out_recs = nullptr;
+    *out_off = nullptr;
+    int rc = check_spec(ctx, spec);
+    if (rc) return rc;
+    pgr_batch *b = nullptr;
+    if ((rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b))) return rc;
+    pgr_shmmrs *s = nullptr;
+    rc = pgr_shmmrs_compute(ctx, b, spec, nullptr, 0, &s);
+    pgr_batch_destroy(b);
+    if (rc) return rc;
+    const uint64_t np = pgr_shmmrs_n_pairs(s);
+    DevBuf tmp;
+    if ((rc = tmp.ensure(ctx, std::max<uint64_t>(np, 1) * sizeof(pgr_frag_rec)))) {
+        pgr_shmmrs_destroy(s);
+        return rc;
+    }
+    uint64_t n_out = 0;
+    rc = pgr_shmmrs_to_frag_recs_device(ctx, s, sids, query_side, (pgr_frag_rec *)tmp.p, np, &n_out);
+    uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    pgr_frag_rec *recs = (pgr_frag_rec *)malloc(std::max<uint64_t>(np, 1) * sizeof(pgr_frag_rec));
+    if (!rc && (!off || !recs)) rc = ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    if (!rc) {
+        uint64_t acc = 0;
+        for (uint32_t c = 0; c < n; ++c) {
+            off[c] = acc;
+            const uint64_t cnt = s->h_off[c + 1] - s->h_off[c];
+            if (cnt > 1) acc += cnt - 1;
+        }
+        off[n] = acc;
+        if (np && hipMemcpy(recs, tmp.p, np * sizeof(pgr_frag_rec), hipMemcpyDeviceToHost) != hipSuccess)
+            rc = ctx->fail(PGR_ERR_DEVICE, "D2H of the pair records failed");
+    }
+    tmp.release(ctx);
+    pgr_shmmrs_destroy(s);
+    if (rc) {
+        free(off);
+        free(recs);
+        return rc;
+    }
+    *out_recs = recs;
+    *out_off = off;
+    return PGR_OK;
+}

@@ -1,0 +1,132 @@
+// ctx.hip -- context memory management (workspaces, pinned staging, caching device allocator).
+#include <algorithm>
+
+#include "pgr_ctx.h"
+
+namespace pgr {
+
+int DevBuf::ensure(pgr_ctx *ctx, size_t bytes) {
+    if (bytes <= cap && p) return PGR_OK;
+    if (p) {
+        (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    // grow with head-room so that repeated calls with slightly different sizes do not reallocate
+    size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) {
+        want = std::max<size_t>(bytes, 256);
+        e = hipMalloc(&p, want);
+    }
+    if (e != hipSuccess) {
+        p = nullptr;
+        return ctx->fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    }
+    cap = want;
+    return PGR_OK;
+}
+
+int DevBuf::ensure_keep(pgr_ctx *ctx, size_t bytes, hipStream_t st) {
+    if (bytes <= cap && p) return PGR_OK;
+    void *np = nullptr;
+    const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
+    hipError_t e = hipMalloc(&np, want);
+    if (e != hipSuccess)
+        return ctx->fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+    if (p && cap) {
+        e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) {
+            (void)hipFree(np);
+            return ctx->fail(PGR_ERR_DEVICE, std::string("workspace grow copy: ") + hipGetErrorString(e));
+        }
+        (void)hipFree(p);
+    }
+    p = np;
+    cap = want;
+    return PGR_OK;
+}
+
+void DevBuf::release(pgr_ctx *) {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+
+}  // namespace pgr
+
+int pgr_ctx::dmalloc(void **out, size_t bytes) {
+    *out = nullptr;
+    bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
+    // best fit within 1.5x from the cache
+    auto it = free_blocks.lower_bound(bytes);
+    if (it != free_blocks.end() && it->first <= bytes + bytes / 2 + 4096) {
+        *out = it->second;
+        live_blocks[it->second] = it->first;
+        cached_bytes -= it->first;
+        free_blocks.erase(it);
+        return PGR_OK;
+    }
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess && !free_blocks.empty()) {  // drop the cache and retry
+        for (auto &kv : free_blocks) (void)hipFree(kv.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+        e = hipMalloc(&p, bytes);
+    }
+    if (e != hipSuccess)
+        return fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    live_blocks[p] = bytes;
+    *out = p;
+    return PGR_OK;
+}
+
+void pgr_ctx::dfree(void *p) {
+    if (!p) return;
+    auto it = live_blocks.find(p);
+    if (it == live_blocks.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    const size_t bytes = it->second;
+    live_blocks.erase(it);
+    // keep at most 64 GiB cached (288 GB of HBM3E per GPU)
+    if (cached_bytes + bytes > (64ull << 30)) {
+        (void)hipFree(p);
+        return;
+    }
+    free_blocks.emplace(bytes, p);
+    cached_bytes += bytes;
+}
+
+int pgr_ctx::ensure_pinned(size_t bytes) {
+    if (bytes <= pinned_cap && pinned) return PGR_OK;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_cap = 0;
+    hipError_t e = hipHostMalloc(&pinned, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        pinned = nullptr;
+        return fail(PGR_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    pinned_cap = bytes;
+    return PGR_OK;
+}
+
+void pgr_ctx::release_all() {
+    pgr::DevBuf *bufs[] = {&ws_ascii,    &ws_tile_first, &ws_seg_off,    &ws_seg_cnt, &ws_seg_dst,
+                           &ws_cursor,   &ws_flags,      &ws_l1,         &ws_serial,  &ws_scan_tmp,
+                           &ws_list_a,   &ws_list_b,     &ws_off_a,      &ws_off_b,   &ws_blk_cnt,
+                           &ws_blk_base, &ws_start_rank, &ws_rids,       &ws_rec_off};
+    for (auto *b : bufs) b->release(this);
+    for (auto &kv : free_blocks) (void)hipFree(kv.second);
+    free_blocks.clear();
+    for (auto &kv : live_blocks) (void)hipFree(kv.first);
+    live_blocks.clear();
+    cached_bytes = 0;
+    if (pinned) (void)hipHostFree(pinned);
+    pinned = nullptr;
+    pinned_cap = 0;
+}

@@ -1,0 +1,575 @@
+// level1.hip -- gfx950 kernels for the level-1 SHIMMER selection (k-mer hash + windowed minimizers).
+//
+// Replaces the per-base loop of shmmrutils::sequence_to_shmmrs1 (pgr-db/src/shmmrutils.rs:454-530)
+// and the sketch loop of sequence_to_shmmrs2 (:580-630).
+//
+// Three kernels:
+//   level1_tile_kernel   position-parallel closed form: one workgroup of 256
+//                        lanes per tile of 4096 positions (core + 2*(w-1) halo); every lane owns 16
+//                        consecutive positions in registers.
+//   level1_tail_kernel   the last (w-k) positions of a contig, where the reference only rescans
+//                        (branch 2 disabled, shmmrutils.rs:516-520): one wavefront per contig.
+//   level1_serial_kernel the exact ring-buffer state machine, event driven, one wavefront per contig.
+//                        Used for contigs the closed form does not cover: non-ACGT bytes, reverse-
+//                        complement-palindromic k-mers (skipped pushes, shmmrutils.rs:477-480), w < 17.
+//
+// Integer / byte work only: no MFMA.  The tile kernel is VALU bound (two 64-bit mix hashes per position).
+#include "pgr_device.h"
+#include "pgr_internal.h"
+
+namespace pgr {
+
+namespace {
+
+__device__ __forceinline__ uint32_t find_contig(const uint32_t *__restrict__ tile_first, uint32_t n, uint32_t tile) {
+    // largest c with tile_first[c] <= tile
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (tile_first[mid] <= tile) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+struct ContigGeom {
+    long long L;       // contig length
+    long long jstart;  // first window end (position) handled by the closed form
+    long long jend;    // last window end handled by the closed form (jend < jstart: none)
+};
+
+// gap-free contig whose first pushed position is k (all bases valid)
+__device__ __forceinline__ ContigGeom contig_geom(uint32_t len, uint32_t w, uint32_t k) {
+    ContigGeom g;
+    g.L = len;
+    g.jstart = (long long)k + w - 1;
+    if (g.L - (long long)k < (long long)w) {  // fewer than w pushed k-mers: no rescan ever happens
+        g.jend = g.jstart - 1;
+    } else {
+        // branch 2 enabled for w+k <= pos < L-w+k (shmmrutils.rs:516-519)
+        const long long lb = g.L - (long long)w + (long long)k;
+        long long je = lb - 1;
+        if (je > g.L - 1) je = g.L - 1;
+        if (je < g.jstart) je = g.jstart;
+        g.jend = je;
+    }
+    return g;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
+    __shared__ uint64_t s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
+    __shared__ uint64_t s_row[L1_BLOCK];        // row min, later row max
+    __shared__ uint2 s_words[136];
+    __shared__ uint32_t s_wsum[L1_BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    __shared__ int s_skip;
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
+    const uint32_t tile_local = tile - a.tile_first[c];
+    const uint32_t w = a.w, k = a.k;
+    const ContigGeom g = contig_geom(a.b.len[c], w, k);
+    const long long c0 = (long long)tile_local * a.tc;
+    long long c1 = c0 + a.tc;
+    if (c1 > g.L) c1 = g.L;
+    const long long e0 = c0 - (long long)(w - 1);  // first extended position (may be negative)
+
+    // ---- stage the 2-bit planes of the tile (+ k-mer look-back) in LDS
+    const long long wbase = (e0 - 96) >> 5;  // floor
+    const long long nwords = (g.L + 31) >> 5;
+    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
+    if (t < 136) {
+        const long long wi = wbase + t;
+        uint2 v = make_uint2(0u, 0u);
+        if (wi >= 0 && wi < nwords) v = planes[wi];
+        s_words[t] = v;
+    }
+    if (t == 0) s_skip = 0;
+    __syncthreads();
+
+    // ---- per-lane 96-bit windows of both planes ending at this lane's last position
+    const long long q = e0 + (long long)L1_G * t;
+    const long long e = q + (L1_G - 1);
+    const int jl = (int)((e >> 5) - wbase);
+    const uint32_t s = 31u - (uint32_t)(e & 31);
+    const uint2 W0 = s_words[jl], W1 = s_words[jl - 1], W2 = s_words[jl - 2], W3 = s_words[jl - 3];
+    const uint32_t a0 = funnel(W1.x, W0.x, s), a1 = funnel(W2.x, W1.x, s), a2 = funnel(W3.x, W2.x, s);
+    const uint32_t b0 = funnel(W1.y, W0.y, s), b1 = funnel(W2.y, W1.y, s), b2 = funnel(W3.y, W2.y, s);
+    const uint64_t kmask = U64MAX >> (64 - k);
+    const uint64_t sketch_thr = (U64MAX >> 4) >> a.r;  // shmmrutils.rs:621
+
+    uint64_t x[L1_G];
+    uint32_t strand_bits = 0, emit = 0;
+    bool saw_skip = false;
+#pragma unroll
+    for (int u = 0; u < L1_G; ++u) {
+        const uint32_t sh = (uint32_t)(L1_G - 1 - u);
+        const uint64_t f0 = (((uint64_t)funnel(a2, a1, sh) << 32) | funnel(a1, a0, sh)) & kmask;
+        const uint64_t f1 = (((uint64_t)funnel(b2, b1, sh) << 32) | funnel(b1, b0, sh)) & kmask;
+        const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
+        const long long p = q + u;
+        const bool valid = (p >= (long long)k) && (p < g.L);
+        const bool skip = (f0 == r0) && (f1 == r1);  // shmmrutils.rs:477-480
+        uint32_t st;
+        uint64_t h;
+        const uint64_t xv = kmer_x(f0, f1, r0, r1, k, st, h);
+        x[u] = (valid && !skip) ? xv : U64MAX;
+        strand_bits |= st << u;
+        saw_skip |= (valid && skip);
+        if (a.sketch) {
+            if (valid && !skip && h < sketch_thr && p >= c0 && p < c1) emit |= 1u << u;
+        }
+    }
+
+    if (!a.sketch) {
+        if (saw_skip) s_skip = 1;  // benign race: all writers store 1
+
+        // ---- pass 1: M[j] = min(x[j-w+1 .. j])  (van Herk / Gil-Werman with 16-wide rows in registers)
+        {
+            uint64_t run = U64MAX;
+#pragma unroll
+            for (int u = L1_G - 1; u >= 0; --u) {
+                run = umin64(run, x[u]);
+                s_suf[u][t] = run;
+            }
+            s_row[t] = run;
+        }
+        __syncthreads();
+        const int wm1 = (int)w - 1;
+        uint64_t M[L1_G];
+        {
+            const int rs_lo = (-wm1) >> 4;  // floor(-(w-1)/16)
+            const int nb = -rs_lo - 1;      // whole rows between the window start row and this row (u small)
+            uint64_t acc = U64MAX, qlo = U64MAX;
+            for (int i = 1; i <= nb; ++i) {
+                if (i == nb) qlo = acc;
+                const int ti = (int)t - i;
+                acc = umin64(acc, s_row[ti < 0 ? 0 : ti]);
+            }
+            uint64_t pre = U64MAX;
+#pragma unroll
+            for (int u = 0; u < L1_G; ++u) {
+                pre = umin64(pre, x[u]);
+                const int d = u - wm1;
+                const int rs = d >> 4;
+                const int off = d & 15;
+                int ts = (int)t + rs;
+                ts = ts < 0 ? 0 : ts;
+                uint64_t m = umin64(pre, s_suf[off][ts]);
+                m = umin64(m, rs == rs_lo ? acc : qlo);
+                const long long pj = q + u;
+                M[u] = (pj >= g.jstart && pj <= g.jend) ? m : 0ull;
+            }
+        }
+        __syncthreads();
+        // ---- pass 2: E[i] = max(M[i .. i+w-1]); i is selected iff x[i] == E[i]
+        {
+            uint64_t pm = 0;
+#pragma unroll
+            for (int u = 0; u < L1_G; ++u) {
+                pm = umax64(pm, M[u]);
+                s_suf[u][t] = pm;
+            }
+            s_row[t] = pm;
+        }
+        __syncthreads();
+        {
+            const int re_lo = wm1 >> 4;
+            uint64_t acc = 0, qlo = 0;
+            for (int i = 1; i <= re_lo; ++i) {
+                if (i == re_lo) qlo = acc;
+                const int ti = (int)t + i;
+                acc = umax64(acc, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
+            }
+            uint64_t sm = 0;
+#pragma unroll
+            for (int u = L1_G - 1; u >= 0; --u) {
+                sm = umax64(sm, M[u]);
+                const int d = u + wm1;
+                const int re = d >> 4;
+                const int off = d & 15;
+                int te = (int)t + re;
+                te = te > L1_BLOCK - 1 ? L1_BLOCK - 1 : te;
+                uint64_t ev = umax64(sm, s_suf[off][te]);
+                ev = umax64(ev, re == re_lo ? qlo : acc);
+                const long long p = q + u;
+                if (p >= c0 && p < c1 && x[u] != U64MAX && x[u] == ev) emit |= 1u << u;
+            }
+        }
+    }
+
+    // ---- ordered compaction: block scan of per-lane counts, one cursor bump per tile
+    const uint32_t cnt = __popc(emit);
+    const uint32_t incl = wave_incl_sum(cnt);
+    const uint32_t lane = t & 63, wv = t >> 6;
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t wave_base = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < L1_BLOCK / 64; ++i) {
+        const uint32_t v = s_wsum[i];
+        if (i < (int)wv) wave_base += v;
+        total += v;
+    }
+    if (t == 0) {
+        unsigned long long base = 0;
+        if (total) base = atomicAdd(a.cursor, (unsigned long long)total);
+        s_base = base;
+        const uint32_t sidx = tile + c;  // one tail segment per preceding contig
+        a.seg_off[sidx] = base;
+        a.seg_cnt[sidx] = (base + total <= a.cap) ? total : 0u;
+        if (base + total > a.cap) atomicExch(a.cursor + 1, 1ull);
+        if (s_skip) atomicOr(a.contig_flags + c, 1u);
+    }
+    __syncthreads();
+    if (cnt) {
+        const unsigned long long base = s_base;
+        if (base + total <= a.cap) {
+            uint64_t o = base + wave_base + (incl - cnt);
+#pragma unroll
+            for (int u = 0; u < L1_G; ++u) {
+                if (emit & (1u << u)) {
+                    const uint64_t p = (uint64_t)(q + u);
+                    pgr_mm128 m;
+                    m.x = x[u];
+                    m.y = ((uint64_t)c << 32) | (p << 1) | ((strand_bits >> u) & 1u);
+                    a.out[o++] = m;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k-mer planes at an arbitrary position straight from global memory (all k bases valid, p >= k-1)
+__device__ __forceinline__ void kmer_at(const uint2 *__restrict__ planes, long long nwords, long long p, uint32_t k,
+                                        uint64_t &f0, uint64_t &f1) {
+    const long long j = p >> 5;
+    const uint32_t s = 31u - (uint32_t)(p & 31);
+    uint2 w0 = make_uint2(0, 0), w1 = w0, w2 = w0;
+    if (j >= 0 && j < nwords) w0 = planes[j];
+    if (j - 1 >= 0 && j - 1 < nwords) w1 = planes[j - 1];
+    if (j - 2 >= 0 && j - 2 < nwords) w2 = planes[j - 2];
+    const uint64_t kmask = U64MAX >> (64 - k);
+    f0 = (((uint64_t)funnel(w2.x, w1.x, s) << 32) | funnel(w1.x, w0.x, s)) & kmask;
+    f1 = (((uint64_t)funnel(w2.y, w1.y, s) << 32) | funnel(w1.y, w0.y, s)) & kmask;
+}
+
+// one wavefront per contig: positions after jend, rescans only (shmmrutils.rs:503-515 with :516-520 false)
+__global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
+    __shared__ uint64_t s_x[256];
+    __shared__ uint32_t s_st[256];
+    __shared__ uint32_t s_emit[256];
+    __shared__ unsigned long long s_base;
+
+    const uint32_t c = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t sidx = a.tile_first[c + 1] + c;
+    const uint32_t w = a.w, k = a.k;
+    const ContigGeom g = contig_geom(a.b.len[c], w, k);
+    const long long n_tail = (a.sketch || g.jend < g.jstart) ? 0 : (g.L - 1 - g.jend);
+    if (n_tail <= 0) {
+        if (lane == 0) {
+            a.seg_off[sidx] = 0;
+            a.seg_cnt[sidx] = 0;
+        }
+        return;
+    }
+    const long long lo = g.jend - (long long)w + 1;  // first position of the window ending at jend (>= k)
+    const int n = (int)(g.L - lo);                   // <= w + (w-k) <= 256
+    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
+    const long long nwords = (g.L + 31) >> 5;
+    for (int i = lane; i < n; i += 64) {
+        uint64_t f0, f1;
+        kmer_at(planes, nwords, lo + i, k, f0, f1);
+        const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
+        uint32_t st;
+        uint64_t h;
+        const uint64_t xv = kmer_x(f0, f1, r0, r1, k, st, h);
+        // a palindromic k-mer here means the contig is re-done by the serial kernel anyway
+        s_x[i] = (f0 == r0 && f1 == r1) ? U64MAX : xv;
+        s_st[i] = st;
+    }
+    __syncthreads();
+    // every lane runs the same (uniform) tiny machine; lane 0 records the emissions
+    int n_emit = 0;
+    {
+        uint64_t mn = U64MAX;
+        int mi = 0;
+        for (int i = 0; i < (int)w; ++i) {
+            const uint64_t v = s_x[i];
+            if (v <= mn) {  // right-most arg-min of the window ending at jend
+                mn = v;
+                mi = i;
+            }
+        }
+        int mdist = (int)w - 1 - mi;
+        for (int j = (int)w; j < n; ++j) {
+            if (mdist == (int)w - 1) {
+                const int wl = j - (int)w + 1;
+                uint64_t m2 = U64MAX;
+                for (int i = wl; i <= j; ++i) m2 = umin64(m2, s_x[i]);
+                int last = wl;
+                for (int i = wl; i <= j; ++i) {
+                    if (s_x[i] == m2) {
+                        if (lane == 0 && n_emit < 256) s_emit[n_emit] = (uint32_t)i;
+                        if (n_emit < 256) ++n_emit;
+                        last = i;
+                    }
+                }
+                mdist = j - last;
+            } else {
+                ++mdist;
+            }
+        }
+    }
+    if (lane == 0) {
+        unsigned long long base = 0;
+        if (n_emit) base = atomicAdd(a.cursor, (unsigned long long)n_emit);
+        s_base = base;
+        a.seg_off[sidx] = base;
+        a.seg_cnt[sidx] = (base + n_emit <= a.cap) ? (uint32_t)n_emit : 0u;
+        if (base + n_emit > a.cap) atomicExch(a.cursor + 1, 1ull);
+    }
+    __syncthreads();
+    const unsigned long long base = s_base;
+    if (base + n_emit <= a.cap) {
+        for (int i = lane; i < n_emit; i += 64) {
+            const uint32_t idx = s_emit[i];
+            pgr_mm128 m;
+            m.x = s_x[idx];
+            m.y = ((uint64_t)c << 32) | ((uint64_t)(lo + idx) << 1) | (s_st[idx] & 1u);
+            a.out[base + i] = m;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact state machine (shmmrutils.rs:438-530), one wavefront per contig, event driven:
+// positions are hashed 64 at a time, the machine jumps from event to event (rescan R when
+// mdist == w-1, or branch-2 emission B when x <= min_mer.x); between events mdist just counts pushes.
+__global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint32_t *__restrict__ list,
+                                                           const uint64_t *__restrict__ region_off,
+                                                           const uint64_t *__restrict__ region_cap,
+                                                           uint32_t *__restrict__ overflow) {
+    __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
+    const uint32_t lane = threadIdx.x;
+    const uint32_t c = list[blockIdx.x];
+    const uint32_t w = a.w, k = a.k;
+    const long long L = a.b.len[c];
+    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
+    const uint32_t *__restrict__ vplane = a.b.valid + a.b.word_off[c];
+    const long long nwords = (L + 31) >> 5;
+    pgr_mm128 *__restrict__ out = a.out + region_off[blockIdx.x];
+    const uint64_t cap = region_cap[blockIdx.x];
+    const uint64_t kmask = U64MAX >> (64 - k);
+    const uint32_t shift = k - 1;
+    const uint64_t sketch_thr = (U64MAX >> 4) >> a.r;
+    // branch 2 enabled for w+k <= pos < Lb; Rust usize arithmetic wraps in release builds
+    const uint64_t Lb = (uint64_t)L - (uint64_t)w + (uint64_t)k;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+
+    s_rx[lane] = U64MAX;
+    s_rx[lane + 64] = U64MAX;
+    s_ry[lane] = U64MAX;
+    s_ry[lane + 64] = U64MAX;
+    __syncthreads();
+
+    uint64_t F0 = 0, F1 = 0, R0 = 0, R1 = 0;  // rolling k-mer planes (uniform)
+    uint32_t rlen = 0, rstart = 0, rend = 0;  // ring state (uniform)
+    uint64_t min_x = U64MAX, min_y = U64MAX;
+    uint64_t mdist = 0;
+    uint64_t n_out = 0;
+
+    for (long long base = 0; base < L; base += 64) {
+        const long long wj = base >> 5;
+        uint2 p_hi = planes[wj], p_lo = make_uint2(0, 0);
+        uint32_t v_hi = vplane[wj], v_lo = 0;
+        if (wj + 1 < nwords) {
+            p_lo = planes[wj + 1];
+            v_lo = vplane[wj + 1];
+        }
+        const uint64_t P0 = ((uint64_t)p_hi.x << 32) | p_lo.x;  // position base+i at bit 63-i
+        const uint64_t P1 = ((uint64_t)p_hi.y << 32) | p_lo.y;
+        const uint64_t V = ((uint64_t)v_hi << 32) | v_lo;
+        const long long pos = base + lane;
+        uint64_t f0, f1, r0, r1;
+        if (V == U64MAX) {
+            // all 64 bases valid: lane i's state = carried state advanced by i+1 bases, in closed form
+            f0 = (((F0 << lane) << 1) | (P0 >> (63 - lane))) & kmask;
+            f1 = (((F1 << lane) << 1) | (P1 >> (63 - lane))) & kmask;
+            r0 = (((R0 >> lane) >> 1) | (__brevll((~P0) >> (63 - lane)) >> (64 - k))) & kmask;
+            r1 = (((R1 >> lane) >> 1) | (__brevll((~P1) >> (63 - lane)) >> (64 - k))) & kmask;
+            F0 = __shfl((uint32_t)f0, 63, 64) | ((uint64_t)__shfl((uint32_t)(f0 >> 32), 63, 64) << 32);
+            F1 = __shfl((uint32_t)f1, 63, 64) | ((uint64_t)__shfl((uint32_t)(f1 >> 32), 63, 64) << 32);
+            R0 = __shfl((uint32_t)r0, 63, 64) | ((uint64_t)__shfl((uint32_t)(r0 >> 32), 63, 64) << 32);
+            R1 = __shfl((uint32_t)r1, 63, 64) | ((uint64_t)__shfl((uint32_t)(r1 >> 32), 63, 64) << 32);
+        } else {
+            // bytes outside ACGT do not touch the k-mer (shmmrutils.rs:461-476): roll uniformly
+            f0 = f1 = r0 = r1 = 0;
+            for (uint32_t i = 0; i < 64; ++i) {
+                const uint32_t bit = 63 - i;
+                if ((V >> bit) & 1) {
+                    const uint64_t c0b = (P0 >> bit) & 1, c1b = (P1 >> bit) & 1;
+                    F0 = ((F0 << 1) | c0b) & kmask;
+                    F1 = ((F1 << 1) | c1b) & kmask;
+                    R0 = ((R0 >> 1) | ((c0b ^ 1) << shift)) & kmask;
+                    R1 = ((R1 >> 1) | ((c1b ^ 1) << shift)) & kmask;
+                }
+                if (lane == i) {
+                    f0 = F0;
+                    f1 = F1;
+                    r0 = R0;
+                    r1 = R1;
+                }
+            }
+        }
+        const bool skip = (f0 == r0) && (f1 == r1);
+        const bool pushed = !skip && pos >= (long long)k && pos < L;
+        uint32_t st;
+        uint64_t h;
+        const uint64_t x = kmer_x(f0, f1, r0, r1, k, st, h);
+        const uint64_t y = ((uint64_t)c << 32) | ((uint64_t)pos << 1) | st;
+
+        if (a.sketch) {  // shmmrutils.rs:621-628
+            const bool em = pushed && h < sketch_thr;
+            const uint64_t m = __ballot(em);
+            if (em) {
+                const uint64_t o = n_out + __popcll(m & lt_mask);
+                if (o < cap) {
+                    pgr_mm128 mm;
+                    mm.x = x;
+                    mm.y = y;
+                    out[o] = mm;
+                }
+            }
+            n_out += __popcll(m);
+            continue;
+        }
+
+        const uint64_t pmask = __ballot(pushed);
+        const bool b_en = (uint64_t)pos >= (uint64_t)(w + k) && (uint64_t)pos < Lb && pos < L;
+        uint32_t cur = 0;  // first unprocessed lane of this chunk
+        for (;;) {
+            const uint64_t rest = (cur >= 64) ? 0ull : (pmask & (U64MAX << cur));
+            if (rest == 0) break;
+            // R: the (w-1-mdist+1)-th remaining push, if mdist <= w-1
+            uint64_t mR = 0;
+            if (mdist <= (uint64_t)(w - 1)) {
+                const uint32_t tsteps = (uint32_t)((uint64_t)(w - 1) - mdist);
+                const uint32_t rank = __popcll(rest & lt_mask);
+                mR = __ballot(pushed && lane >= cur && rank == tsteps);
+            }
+            const uint64_t mB = __ballot(pushed && lane >= cur && b_en && x <= min_x);
+            const int iR = mR ? (int)__ffsll((unsigned long long)mR) - 1 : 64;
+            const int iB = mB ? (int)__ffsll((unsigned long long)mB) - 1 : 64;
+            const int iE = (iB < iR) ? iB : iR;  // B only when strictly before R (R is tested first)
+            const uint64_t range = (iE >= 63) ? rest : (rest & ((2ull << iE) - 1));
+            // push every pushed position in [cur, iE] (or to the end of the chunk) into the ring
+            const uint32_t tot = __popcll(range);
+            if ((range >> lane) & 1) {
+                const uint32_t rk = __popcll(range & lt_mask);
+                if (tot - rk <= w) {
+                    const uint32_t slot = (rend + rk) % w;
+                    s_rx[slot] = x;
+                    s_ry[slot] = y;
+                }
+            }
+            rend = (rend + tot) % w;
+            if (rlen + tot >= w) {
+                rlen = w;
+                rstart = rend;
+            } else {
+                rlen += tot;
+            }
+            __syncthreads();
+            if (iE == 64) {  // no event in the rest of the chunk
+                mdist += tot;
+                break;
+            }
+            if (iB < iR) {  // branch 2 (shmmrutils.rs:516-527)
+                const uint64_t ex = shfl64(x, iB), ey = shfl64(y, iB);
+                if (lane == 0 && n_out < cap) {
+                    pgr_mm128 mm;
+                    mm.x = ex;
+                    mm.y = ey;
+                    out[n_out] = mm;
+                }
+                n_out += 1;
+                min_x = ex;
+                min_y = ey;
+                mdist = 0;
+            } else {  // rescan (shmmrutils.rs:503-515)
+                const uint32_t q0 = lane, q1 = lane + 64;
+                const uint32_t s0 = (rstart + q0) % w, s1 = (rstart + q1) % w;
+                const uint64_t x0 = (q0 < w) ? s_rx[s0] : U64MAX;
+                const uint64_t x1 = (q1 < w) ? s_rx[s1] : U64MAX;
+                const uint64_t mn = wave_min64(umin64(x0, x1));
+                const bool e0 = (q0 < w) && x0 == mn, e1 = (q1 < w) && x1 == mn;
+                const uint64_t m0 = __ballot(e0), m1 = __ballot(e1);
+                const uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
+                if (e0) {
+                    const uint64_t o = n_out + __popcll(m0 & lt_mask);
+                    if (o < cap) {
+                        pgr_mm128 mm;
+                        mm.x = x0;
+                        mm.y = s_ry[s0];
+                        out[o] = mm;
+                    }
+                }
+                if (e1) {
+                    const uint64_t o = n_out + n0 + __popcll(m1 & lt_mask);
+                    if (o < cap) {
+                        pgr_mm128 mm;
+                        mm.x = x1;
+                        mm.y = s_ry[s1];
+                        out[o] = mm;
+                    }
+                }
+                n_out += n0 + n1;
+                const uint32_t qlast = m1 ? (64 + 63 - (uint32_t)__clzll((long long)m1)) : (63 - (uint32_t)__clzll((long long)m0));
+                min_x = mn;
+                min_y = s_ry[(rstart + qlast) % w];
+                const uint64_t ppos = (uint64_t)(base + iR);
+                mdist = ppos - ((min_y & 0xFFFFFFFFull) >> 1);
+            }
+            cur = (uint32_t)iE + 1;
+            __syncthreads();
+        }
+    }
+    // this contig's tile segments are void; the whole list lives in the tail segment
+    const uint32_t t0 = a.tile_first[c], t1 = a.tile_first[c + 1];
+    for (uint32_t ti = t0 + lane; ti < t1; ti += 64) a.seg_cnt[ti + c] = 0;
+    if (lane == 0) {
+        const uint32_t sidx = t1 + c;
+        a.seg_off[sidx] = region_off[blockIdx.x];
+        if (n_out > cap || n_out > 0xFFFFFFFFull) {
+            overflow[blockIdx.x] = 1;
+            a.seg_cnt[sidx] = 0;
+        } else {
+            a.seg_cnt[sidx] = (uint32_t)n_out;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+void launch_level1_tiles(hipStream_t st, const L1Args &a) {
+    if (a.n_tiles == 0) return;
+    hipLaunchKernelGGL(level1_tile_kernel, dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+}
+void launch_level1_tails(hipStream_t st, const L1Args &a) {
+    if (a.n_contigs == 0) return;
+    hipLaunchKernelGGL(level1_tail_kernel, dim3(a.n_contigs), dim3(64), 0, st, a);
+}
+void launch_level1_serial(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list,
+                          const uint64_t *d_region_off, const uint64_t *d_region_cap, uint32_t *d_overflow) {
+    if (n_list == 0) return;
+    hipLaunchKernelGGL(level1_serial_kernel, dim3(n_list), dim3(64), 0, st, a, d_list, d_region_off, d_region_cap,
+                       d_overflow);
+}
+
+}  // namespace pgr

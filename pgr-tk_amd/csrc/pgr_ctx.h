@@ -1,0 +1,56 @@
+// pgr_ctx.h -- the context object behind the C ABI: one GPU, one stream, grow-only workspaces and a
+// small caching device allocator (so the steady state of repeated calls does no hipMalloc/hipFree).
+#pragma once
+#include <map>
+#include <string>
+
+#include "pgr_internal.h"
+
+namespace pgr {
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(pgr_ctx *ctx, size_t bytes);                        // contents NOT preserved
+    int ensure_keep(pgr_ctx *ctx, size_t bytes, hipStream_t st);   // contents preserved
+    void release(pgr_ctx *ctx);
+};
+}  // namespace pgr
+
+struct pgr_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_end = nullptr;
+    std::string err;
+    pgr_prof prof = {};
+
+    // pinned staging for H2D
+    void *pinned = nullptr;
+    size_t pinned_cap = 0;
+
+    // workspaces
+    pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
+        ws_scan_tmp, ws_list_a, ws_list_b, ws_off_a, ws_off_b, ws_blk_cnt, ws_blk_base, ws_start_rank, ws_rids,
+        ws_rec_off;
+
+    // caching allocator for result buffers: size -> free blocks
+    std::multimap<size_t, void *> free_blocks;
+    std::map<void *, size_t> live_blocks;
+    size_t cached_bytes = 0;
+
+    int fail(int code, const std::string &msg) {
+        err = msg;
+        return code;
+    }
+    int dmalloc(void **out, size_t bytes);
+    void dfree(void *p);
+    int ensure_pinned(size_t bytes);
+    void release_all();
+};
+
+#define PGR_HIP(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t _e = (expr);                                                                              \
+        if (_e != hipSuccess)                                                                                \
+            return (ctx)->fail(PGR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e));          \
+    } while (0)

@@ -1,0 +1,76 @@
+// pgr_device.h -- device-side helpers shared by the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgr {
+
+// Thomas Wang / minimap2 hash64 with a full 64-bit mask -- reference: pgr-db/src/shmmrutils.rs:271-280
+__device__ __forceinline__ uint64_t u64hash(uint64_t key) {
+    key = (~key) + (key << 21);
+    key = key ^ (key >> 24);
+    key = (key + (key << 3)) + (key << 8);
+    key = key ^ (key >> 14);
+    key = (key + (key << 2)) + (key << 4);
+    key = key ^ (key >> 28);
+    key = key + (key << 31);
+    return key;
+}
+
+// ((hi:lo) >> s) & 0xffffffff, s in 0..31  (v_alignbit_b32)
+__device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s) {
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+}
+
+__device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
+__device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
+
+// canonical k-mer -> (x, strand).  f/r: forward / reverse-complement bit planes
+// (shmmrutils.rs:485-500): strand decided on the LOW plane only; x = hash << 8 | k.
+__device__ __forceinline__ uint64_t kmer_x(uint64_t f0, uint64_t f1, uint64_t r0, uint64_t r1, uint32_t k,
+                                           uint32_t &strand, uint64_t &hash) {
+    const bool rev = r0 < f0;
+    const uint64_t m0 = rev ? r0 : f0;
+    const uint64_t m1 = rev ? r1 : f1;
+    const uint64_t h = u64hash(m0) ^ u64hash(m1 ^ 0xAD12CF59ull);
+    strand = rev ? 1u : 0u;
+    hash = h;
+    return (h << 8) | (uint64_t)k;
+}
+
+// reverse-complement plane of a forward plane value (all k bases valid):
+// r bit (k-1-m) = ~f bit m  (shmmrutils.rs:469-475 applied k times)
+__device__ __forceinline__ uint64_t rc_plane(uint64_t f, uint32_t k) { return __brevll(~f) >> (64 - k); }
+
+// wave64 helpers ---------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+__device__ __forceinline__ uint64_t shfl64(uint64_t v, int src) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl(lo, src, 64);
+    hi = __shfl(hi, src, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    lo = __shfl_xor(lo, m, 64);
+    hi = __shfl_xor(hi, m, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = umin64(v, shfl_xor64(v, m));
+    return v;
+}
+// inclusive prefix sum over the wave
+__device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
+    const uint32_t lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+}  // namespace pgr

@@ -1,0 +1,125 @@
+// pgr_internal.h -- shared between the HIP translation units of libpgrhip.so (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/pgr_hip.h"
+
+namespace pgr {
+
+// ------------------------------------------------------------------ geometry of the level-1 kernel
+constexpr int L1_BLOCK = 256;            // threads per workgroup (4 wavefronts of 64)
+constexpr int L1_G = 16;                 // consecutive positions owned by one lane
+constexpr int L1_EXT = L1_BLOCK * L1_G;  // 4096 positions per tile including both halos
+constexpr int L1_MIN_W = 17;             // window sizes below this use the serial kernel
+constexpr uint64_t U64MAX = 0xFFFFFFFFFFFFFFFFull;
+
+// ------------------------------------------------------------------ device-resident batch
+// Contig c occupies words [word_off[c], word_off[c] + ceil(len/32)) of the plane arrays.
+// Word j of a contig holds bases 32j .. 32j+31, base i at bit (31 - i%32)  (MSB first), so a
+// run of consecutive bases ending at base e is a contiguous bit field whose LSB is base e:
+// exactly the k-mer bit-plane layout of shmmrutils.rs:459-476 (fmmer.0 = low bits, fmmer.1 =
+// high bits of the 2-bit codes).  planes[j] = {low-bit plane, high-bit plane}.
+// valid[j]: bit set = the byte was one of ACGTacgt\0\1\2\3 (shmmrutils.rs:426-436).
+struct BatchDev {
+    uint2 *planes = nullptr;
+    uint32_t *valid = nullptr;
+    uint64_t *word_off = nullptr;  // [n+1]
+    uint32_t *len = nullptr;       // [n]
+    uint32_t *n_invalid = nullptr; // [n] number of non-ACGT bytes
+};
+
+}  // namespace pgr
+
+struct pgr_batch {
+    pgr_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    uint64_t total_bases = 0;
+    uint64_t total_words = 0;
+    pgr::BatchDev d;
+    std::vector<uint64_t> h_word_off;  // [n+1]
+    std::vector<uint32_t> h_len;       // [n]
+    std::vector<uint32_t> h_n_invalid; // [n]
+};
+
+struct pgr_shmmrs {
+    pgr_ctx *ctx = nullptr;
+    uint32_t n = 0;
+    uint64_t count = 0;
+    pgr_mm128 *d_mm = nullptr;   // [count]
+    uint64_t *d_off = nullptr;   // [n+1]
+    std::vector<uint64_t> h_off; // [n+1]
+};
+
+namespace pgr {
+
+// ------------------------------------------------------------------ kernel launch wrappers
+// pack.hip
+void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, const BatchDev &b, uint32_t n,
+                       uint64_t w1);
+void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_words, uint64_t seed,
+                  uint64_t contig0);
+
+// level1.hip
+struct L1Args {
+    BatchDev b;
+    uint32_t n_contigs;
+    uint32_t n_tiles;
+    const uint32_t *tile_first;  // [n+1] device
+    uint32_t w, k, r, tc, sketch;
+    pgr_mm128 *out;              // unordered level-1 segments
+    uint64_t cap;
+    unsigned long long *cursor;  // [0] elements allocated, [1] overflow flag
+    uint64_t *seg_off;           // [n_tiles + n_contigs]
+    uint32_t *seg_cnt;           // [n_tiles + n_contigs]
+    uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the serial kernel)
+};
+void launch_level1_tiles(hipStream_t st, const L1Args &a);
+void launch_level1_tails(hipStream_t st, const L1Args &a);
+// serial (exact state machine) kernel for the contigs listed in d_list
+void launch_level1_serial(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list,
+                          const uint64_t *d_region_off /*[n_list] element offset into out*/,
+                          const uint64_t *d_region_cap /*[n_list]*/, uint32_t *d_overflow /*[n_list]*/);
+
+// level2.hip
+void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,
+                            const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst);
+struct SelArgs {
+    const pgr_mm128 *in;
+    uint64_t n;
+    const uint64_t *off_in;  // [n_contigs+1]
+    uint32_t n_contigs;
+    int mode;                // 0 reduce (window r), 1 min_span stencil
+    uint32_t r, padding, min_span;
+    const uint32_t *rids;    // patch y>>32 on output when non-null
+};
+// pass 1: per-block counts
+void launch_select_count(hipStream_t st, const SelArgs &a, uint32_t *blk_cnt, uint32_t n_blocks);
+// pass 2: scatter; blk_base = exclusive scan of blk_cnt
+void launch_select_scatter(hipStream_t st, const SelArgs &a, const uint64_t *blk_base, uint32_t n_blocks,
+                           pgr_mm128 *out, uint64_t *start_rank /*[n_contigs]*/);
+void launch_fill_offsets(hipStream_t st, const uint64_t *off_in, const uint64_t *start_rank, uint32_t n_contigs,
+                         const uint64_t *d_total, uint64_t *off_out);
+constexpr uint32_t SEL_BLOCK_ELEMS = 1024;
+void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, const uint64_t *rec_off,
+                      uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, pgr_frag_rec *out);
+
+void launch_contig_offsets(hipStream_t st, const uint64_t *seg_dst, const uint32_t *tile_first, uint32_t n,
+                           uint32_t n_segs, uint64_t *off);
+void launch_copy_or_sentinel(hipStream_t st, const pgr_mm128 *in, const uint64_t *off_in, const uint64_t *off_out,
+                             uint32_t n, pgr_mm128 *out);
+
+// scan.hip (rocPRIM device scans / sorts: plain library primitives, not the hot path)
+// exclusive scan of n+1 u32 counts (in[n] must be 0) into n+1 u64 offsets: out[n] = total
+size_t scan_counts_temp_bytes(uint32_t n_plus_1);
+hipError_t scan_counts(hipStream_t st, void *temp, size_t temp_bytes, const uint32_t *in, uint64_t *out,
+                       uint32_t n_plus_1);
+size_t sort_pairs_temp_bytes(uint64_t n);
+hipError_t sort_pairs(hipStream_t st, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
+                      const uint32_t *vals_in, uint32_t *vals_out, uint64_t n);
+
+}  // namespace pgr

@@ -1,0 +1,11 @@
+"""pgrtk_amd -- MI355X-native SHIMMER indexing / query engine (host side mirror of pgr-tk's `pgrtk`).
+
+All compute happens in libpgrhip.so (hand-written gfx950 HIP kernels behind the C ABI of
+include/pgr_hip.h).  There is no CPU path: without the built library and a gfx950 device the
+calls raise.
+"""
+from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PgrError, Spec, default_context  # noqa: F401
+from .engine import (Batch, Shmmrs, frag_recs_batch, make_spec, sequence_to_shmmrs,  # noqa: F401
+                     sequence_to_shmmrs_batch)
+
+__version__ = "0.1.0"

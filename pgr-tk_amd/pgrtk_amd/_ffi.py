@@ -1,0 +1,182 @@
+"""ctypes binding of libpgrhip.so (include/pgr_hip.h).
+
+The product has no CPU path: if the shared library is missing or no gfx950 device is
+usable, importing is fine but creating a context raises loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpgrhip.so")
+
+MM128 = np.dtype([("x", "<u8"), ("y", "<u8")])
+FRAG_REC = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("frg_id", "<u4"), ("sid", "<u4"), ("bgn", "<u4"),
+                     ("end", "<u4"), ("orient", "<u4"), ("_pad", "<u4")])
+HITPAIR = np.dtype([("qb", "<u4"), ("qe", "<u4"), ("qo", "<u4"), ("tb", "<u4"), ("te", "<u4"), ("to", "<u4")])
+
+
+class PgrError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("libpgrhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Spec(C.Structure):
+    """ShmmrSpec (pgr-db/src/shmmrutils.rs:20-27)"""
+    _fields_ = [("w", C.c_uint32), ("k", C.c_uint32), ("r", C.c_uint32), ("min_span", C.c_uint32),
+                ("sketch", C.c_uint32)]
+
+    def as_tuple(self):
+        return (self.w, self.k, self.r, self.min_span, bool(self.sketch))
+
+
+class Prof(C.Structure):
+    _fields_ = [("level1_ms", C.c_float), ("level1_aux_ms", C.c_float), ("level2_ms", C.c_float),
+                ("total_ms", C.c_float), ("n_level1", C.c_uint64), ("n_tiles", C.c_uint64),
+                ("n_serial_contigs", C.c_uint64), ("bases_tiled", C.c_uint64)]
+
+
+class HpsResult(C.Structure):
+    _fields_ = [("n_queries", C.c_uint32), ("q_off", C.POINTER(C.c_uint64)), ("n_targets", C.c_uint64),
+                ("t_sid", C.POINTER(C.c_uint32)), ("t_off", C.POINTER(C.c_uint64)), ("n_chains", C.c_uint64),
+                ("c_score", C.POINTER(C.c_float)), ("c_off", C.POINTER(C.c_uint64)), ("n_hps", C.c_uint64),
+                ("hps", C.c_void_p)]
+
+
+# every symbol declared in include/pgr_hip.h: (name, restype, argtypes)
+_VP = C.c_void_p
+_PVP = C.POINTER(C.c_void_p)
+_SIGS = [
+    ("pgr_ctx_create", C.c_int, [C.c_int, _PVP]),
+    ("pgr_ctx_destroy", None, [_VP]),
+    ("pgr_last_error", C.c_char_p, [_VP]),
+    ("pgr_free", None, [_VP]),
+    ("pgr_version", C.c_char_p, []),
+    ("pgr_shmmr_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
+                                  C.POINTER(C.c_uint32), C.c_int, _PVP, _PVP]),
+    ("pgr_frag_recs_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
+                                      C.POINTER(C.c_uint32), C.c_int, _PVP, _PVP]),
+    ("pgr_batch_from_ascii", C.c_int, [_VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), _PVP]),
+    ("pgr_batch_synthetic", C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, _PVP]),
+    ("pgr_batch_destroy", None, [_VP]),
+    ("pgr_batch_total_bases", C.c_uint64, [_VP]),
+    ("pgr_shmmrs_compute", C.c_int, [_VP, _VP, C.POINTER(Spec), C.POINTER(C.c_uint32), C.c_int, _PVP]),
+    ("pgr_shmmrs_count", C.c_uint64, [_VP]),
+    ("pgr_shmmrs_device_ptr", _VP, [_VP]),
+    ("pgr_shmmrs_device_offsets", _VP, [_VP]),
+    ("pgr_shmmrs_download", C.c_int, [_VP, _VP, _PVP, _PVP]),
+    ("pgr_shmmrs_destroy", None, [_VP]),
+    ("pgr_shmmrs_n_pairs", C.c_uint64, [_VP]),
+    ("pgr_shmmrs_to_frag_recs_device", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.c_int, _VP, C.c_uint64,
+                                                 C.POINTER(C.c_uint64)]),
+    ("pgr_ctx_last_prof", C.c_int, [_VP, C.POINTER(Prof)]),
+    ("pgr_ctx_synchronize", C.c_int, [_VP]),
+    ("pgr_index_create", C.c_int, [_VP, C.POINTER(Spec), _PVP]),
+    ("pgr_index_destroy", None, [_VP]),
+    ("pgr_index_add_batch", C.c_int, [_VP, _VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
+    ("pgr_index_add_resident", C.c_int, [_VP, _VP, _VP, C.POINTER(C.c_uint32)]),
+    ("pgr_index_add_records", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
+    ("pgr_index_finalize", C.c_int, [_VP, _VP]),
+    ("pgr_index_n_keys", C.c_uint64, [_VP]),
+    ("pgr_index_n_records", C.c_uint64, [_VP]),
+    ("pgr_index_download", C.c_int, [_VP, _VP, _PVP, C.POINTER(C.c_uint64)]),
+    ("pgr_query_hps_batch", C.c_int, [_VP, _VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.c_float, C.c_uint32,
+                                      C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
+                                      C.POINTER(HpsResult)]),
+    ("pgr_hps_result_free", None, [C.POINTER(HpsResult)]),
+    ("pgr_sparse_aln_batch", C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64), C.c_uint32, C.c_float, C.c_int,
+                                       C.c_uint32, C.c_int, C.POINTER(HpsResult)]),
+]
+SYMBOLS = [s[0] for s in _SIGS]
+
+_lib = None
+
+
+def lib():
+    """load libpgrhip.so; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libpgrhip.so not built: run `python __graft_entry__.py build` "
+                              "(make -C pgr-tk_amd); expected at " + LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, res, args in _SIGS:
+            f = getattr(L, name)  # AttributeError if a declared symbol is missing
+            f.restype = res
+            f.argtypes = args
+        _lib = L
+    return _lib
+
+
+def seq_array(seq):
+    if isinstance(seq, np.ndarray):
+        return np.ascontiguousarray(seq, dtype=np.uint8)
+    if isinstance(seq, str):
+        seq = seq.encode()
+    return np.frombuffer(bytes(seq), dtype=np.uint8)
+
+
+def seq_ptrs(seqs):
+    """-> (keepalive arrays, void** , uint64* lens, n)"""
+    arrs = [seq_array(s) for s in seqs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
+    lens = (C.c_uint64 * max(n, 1))(*[a.size for a in arrs])
+    return arrs, ptrs, lens, n
+
+
+def take(ptr, n, dtype):
+    """copy n records out of a library-allocated host buffer, then pgr_free it"""
+    out = np.zeros(n, dtype=dtype)
+    if ptr.value:
+        if n:
+            C.memmove(out.ctypes.data, ptr.value, n * dtype.itemsize)
+        lib().pgr_free(ptr)
+    return out
+
+
+class Context:
+    """one GPU, one stream (pgr_ctx).  Not thread safe."""
+
+    def __init__(self, device=0):
+        self._h = C.c_void_p()
+        rc = lib().pgr_ctx_create(device, C.byref(self._h))
+        if rc != 0:
+            msg = lib().pgr_last_error(None)
+            raise PgrError(rc, msg.decode() if msg else "pgr_ctx_create failed")
+
+    def close(self):
+        if self._h:
+            lib().pgr_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self):
+        return self._h
+
+    def check(self, rc):
+        if rc != 0:
+            msg = lib().pgr_last_error(self._h)
+            raise PgrError(rc, msg.decode() if msg else "?")
+
+    def last_prof(self):
+        p = Prof()
+        self.check(lib().pgr_ctx_last_prof(self._h, C.byref(p)))
+        return p
+
+
+_default_ctx = {}
+
+
+def default_context(device=0):
+    if device not in _default_ctx:
+        _default_ctx[device] = Context(device)
+    return _default_ctx[device]

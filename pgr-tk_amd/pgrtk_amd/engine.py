@@ -1,0 +1,148 @@
+"""Thin Python objects over the C ABI: resident batches and the sequence_to_shmmrs hot path.
+
+Names follow the reference (pgr-db/src/shmmrutils.rs, seq_db.rs); the compute is entirely in
+libpgrhip.so -- nothing here computes a hash or a minimizer.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import FRAG_REC, MM128, Spec, default_context, lib
+
+
+def make_spec(w=80, k=56, r=4, min_span=64, sketch=False):
+    return Spec(w, k, r, min_span, 1 if sketch else 0)
+
+
+def _u32_array(vals, n):
+    if vals is None:
+        return None, None
+    a = np.ascontiguousarray(vals, dtype=np.uint32)
+    if a.size != n:
+        raise ValueError("expected %d ids, got %d" % (n, a.size))
+    return a, a.ctypes.data_as(C.POINTER(C.c_uint32))
+
+
+class Batch:
+    """contigs resident on the GPU as 2-bit planes (pgr_batch)."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx = ctx
+        self._h = handle
+        self.n = n
+
+    @classmethod
+    def from_seqs(cls, seqs, ctx=None):
+        ctx = ctx or default_context()
+        arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+        h = C.c_void_p()
+        ctx.check(lib().pgr_batch_from_ascii(ctx.handle, n, ptrs, lens, C.byref(h)))
+        return cls(ctx, h, n)
+
+    @classmethod
+    def synthetic(cls, lens, seed, contig0=0, ctx=None):
+        ctx = ctx or default_context()
+        n = len(lens)
+        la = (C.c_uint64 * max(n, 1))(*[int(v) for v in lens])
+        h = C.c_void_p()
+        ctx.check(lib().pgr_batch_synthetic(ctx.handle, n, la, int(seed), int(contig0), C.byref(h)))
+        return cls(ctx, h, n)
+
+    @property
+    def total_bases(self):
+        return int(lib().pgr_batch_total_bases(self._h))
+
+    def shmmrs(self, spec, rids=None, padding=False):
+        keep, rp = _u32_array(rids, self.n)
+        h = C.c_void_p()
+        self.ctx.check(lib().pgr_shmmrs_compute(self.ctx.handle, self._h, C.byref(spec), rp, int(padding), C.byref(h)))
+        return Shmmrs(self.ctx, h, self.n)
+
+    def close(self):
+        if self._h:
+            lib().pgr_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Shmmrs:
+    """device-resident result of one sequence_to_shmmrs pass over a batch (pgr_shmmrs)."""
+
+    def __init__(self, ctx, handle, n):
+        self.ctx = ctx
+        self._h = handle
+        self.n = n
+
+    @property
+    def count(self):
+        return int(lib().pgr_shmmrs_count(self._h))
+
+    @property
+    def n_pairs(self):
+        return int(lib().pgr_shmmrs_n_pairs(self._h))
+
+    @property
+    def device_ptr(self):
+        return lib().pgr_shmmrs_device_ptr(self._h)
+
+    def download(self):
+        """-> (MM128 array, offsets[n+1])"""
+        pm, po = C.c_void_p(), C.c_void_p()
+        cnt = self.count
+        self.ctx.check(lib().pgr_shmmrs_download(self.ctx.handle, self._h, C.byref(pm), C.byref(po)))
+        return _ffi.take(pm, cnt, MM128), _ffi.take(po, self.n + 1, np.dtype("<u8"))
+
+    def frag_recs_into(self, device_ptr, capacity, sids=None, query_side=False):
+        """write the shimmer-pair records into caller-owned DEVICE memory (e.g. a torch tensor)"""
+        keep, sp = _u32_array(sids, self.n)
+        n_out = C.c_uint64()
+        self.ctx.check(lib().pgr_shmmrs_to_frag_recs_device(self.ctx.handle, self._h, sp, int(query_side),
+                                                            C.c_void_p(device_ptr), capacity, C.byref(n_out)))
+        return int(n_out.value)
+
+    def close(self):
+        if self._h:
+            lib().pgr_shmmrs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def sequence_to_shmmrs_batch(seqs, spec, rids=None, padding=False, ctx=None):
+    """batched shmmrutils::sequence_to_shmmrs (shmmrutils.rs:657-669) -> list of MM128 arrays"""
+    ctx = ctx or default_context()
+    arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+    keep, rp = _u32_array(rids, n)
+    pm, po = C.c_void_p(), C.c_void_p()
+    ctx.check(lib().pgr_shmmr_batch(ctx.handle, C.byref(spec), n, ptrs, lens, rp, int(padding), C.byref(pm),
+                                    C.byref(po)))
+    off = _ffi.take(po, n + 1, np.dtype("<u8"))
+    mm = _ffi.take(pm, int(off[n]) if n else 0, MM128)
+    return [mm[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+def sequence_to_shmmrs(rid, seq, spec, padding=False, ctx=None):
+    return sequence_to_shmmrs_batch([seq], spec, rids=[rid], padding=padding, ctx=ctx)[0]
+
+
+def frag_recs_batch(seqs, spec, sids=None, query_side=False, ctx=None):
+    """sequence_to_shmmrs + pair_shmmrs/seq_to_index records (seq_db.rs:360-418) -> list of FRAG_REC arrays"""
+    ctx = ctx or default_context()
+    arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+    keep, sp = _u32_array(sids, n)
+    pr, po = C.c_void_p(), C.c_void_p()
+    ctx.check(lib().pgr_frag_recs_batch(ctx.handle, C.byref(spec), n, ptrs, lens, sp, int(query_side), C.byref(pr),
+                                        C.byref(po)))
+    off = _ffi.take(po, n + 1, np.dtype("<u8"))
+    recs = _ffi.take(pr, int(off[n]) if n else 0, FRAG_REC)
+    return [recs[int(off[i]):int(off[i + 1])] for i in range(n)]

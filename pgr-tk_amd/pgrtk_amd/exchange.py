@@ -1,0 +1,53 @@
+"""Multi-GPU exchange step: contigs are sharded across ranks (one process per GPU); every rank
+computes the shimmer-pair records of its own contigs, then the per-rank record buffers are
+all-gathered (RCCL over xGMI via torch.distributed, backend "nccl"; "gloo" on CPU in the tests)
+so that every rank -- in particular the one that owns the host-side ShmmrToFrags map -- holds
+the full record set in global (rank, sid, frg_id) order.
+
+torch is plumbing here (device memory + the collective); no compute.
+"""
+import torch
+import torch.distributed as dist
+
+REC_WORDS = 5  # one pgr_frag_rec = 40 bytes = 5 x int64
+
+
+def shard_contigs(lens, world_size):
+    """greedy length-balanced assignment of contigs to ranks.
+    Returns a list of index lists, one per rank; ids inside a rank stay in file order."""
+    order = sorted(range(len(lens)), key=lambda i: (-int(lens[i]), i))
+    load = [0] * world_size
+    shards = [[] for _ in range(world_size)]
+    for i in order:
+        r = min(range(world_size), key=lambda q: (load[q], q))
+        shards[r].append(i)
+        load[r] += int(lens[i])
+    for s in shards:
+        s.sort()
+    return shards
+
+
+def allgather_records(local, group=None):
+    """local: int64 tensor [n_local, 5] (40-byte records) on this rank's device.
+    Returns (gathered [sum n, 5] in rank order, counts list).  Two collectives: the counts
+    (8 bytes per rank) and one padded all-gather of the payload."""
+    world = dist.get_world_size(group)
+    assert local.dtype == torch.int64 and local.dim() == 2 and local.shape[1] == REC_WORDS
+    n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+    counts = torch.empty(world, dtype=torch.int64, device=local.device)
+    dist.all_gather_into_tensor(counts, n_local, group=group)
+    counts_h = [int(v) for v in counts.cpu()]
+    n_max = max(counts_h) if counts_h else 0
+    if n_max == 0:
+        return local.new_zeros((0, REC_WORDS)), counts_h
+    if local.shape[0] == n_max:
+        padded = local.contiguous()
+    else:
+        padded = local.new_zeros((n_max, REC_WORDS))
+        padded[: local.shape[0]] = local
+    out = local.new_empty((world * n_max, REC_WORDS))
+    dist.all_gather_into_tensor(out, padded, group=group)
+    if all(c == n_max for c in counts_h):
+        return out, counts_h
+    parts = [out[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
+    return torch.cat(parts, dim=0), counts_h
