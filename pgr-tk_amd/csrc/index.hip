@@ -1,26 +1,809 @@
-// index.hip -- ShmmrToFrags index + query entry points (under construction in this commit).
+// index.hip -- ShmmrToFrags index (frag_map) and the query path on the GPU.
+//
+// Index  : FxHashMap<(u64,u64), Vec<FragmentSignature>> of pgr-db/src/seq_db.rs:75-76, built by
+//          load_index_from_seq_vec (seq_db.rs:573-615), as a CSR: records sorted by (h0, h1, sid, frg_id)
+//          (= the reference's per-key Vec order, which is insertion order = ascending (sid, frg_id)),
+//          key_off[] = first record of every distinct key.
+// Query  : raw_query_fragment (seq_db.rs:1200-1228) + aln::query_fragment_to_hps (aln.rs:147-242) +
+//          aln::sparse_aln (aln.rs:12-142) for a whole batch of queries.
+//
+// Sorting / scans are rocPRIM library calls; lookups, count filters, hit expansion and the chaining DP
+// are hand-written kernels.  f32 arithmetic in the DP is IEEE without contraction (-ffp-contract=off),
+// in the reference's operation order.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
 #include "pgr_ctx.h"
+#include "pgr_device.h"
+
+using namespace pgr;
 
 struct pgr_index {
     pgr_ctx *ctx = nullptr;
+    pgr_spec spec = {};
+    pgr_frag_rec *raw = nullptr;  // appended records (device)
+    uint64_t n_raw = 0, cap_raw = 0;
+    pgr_frag_rec *recs = nullptr;  // sorted records (device), valid when finalized
+    uint64_t n = 0;
+    uint64_t *key_off = nullptr;  // [n_keys + 1]
+    uint64_t n_keys = 0;
+    bool finalized = false;
+    uint32_t next_sid = 0;
 };
 
-#define NOT_YET(ctx) ((ctx) ? (ctx)->fail(PGR_ERR_STATE, "not implemented yet") : PGR_ERR_INVALID_ARG)
+namespace {
 
-extern "C" int pgr_index_create(pgr_ctx *ctx, const pgr_spec *, pgr_index **) { return NOT_YET(ctx); }
-extern "C" void pgr_index_destroy(pgr_index *ix) { delete ix; }
-extern "C" int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *, uint32_t, const uint8_t *const *, const uint64_t *,
-                                   const uint32_t *) { return NOT_YET(ctx); }
-extern "C" int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *, const pgr_batch *, const uint32_t *) { return NOT_YET(ctx); }
-extern "C" int pgr_index_add_records(pgr_ctx *ctx, pgr_index *, const pgr_frag_rec *, uint64_t, int) { return NOT_YET(ctx); }
-extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *) { return NOT_YET(ctx); }
-extern "C" uint64_t pgr_index_n_keys(const pgr_index *) { return 0; }
-extern "C" uint64_t pgr_index_n_records(const pgr_index *) { return 0; }
-extern "C" int pgr_index_download(pgr_ctx *ctx, const pgr_index *, pgr_frag_rec **, uint64_t *) { return NOT_YET(ctx); }
-extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *, uint32_t, const uint8_t *const *, const uint64_t *,
-                                   float, uint32_t, uint32_t, uint32_t, uint32_t, int, uint32_t, int, pgr_hps_result *) {
-    return NOT_YET(ctx);
+// ------------------------------------------------------------------ small RAII device temp
+struct Tmp {
+    pgr_ctx *ctx;
+    void *p = nullptr;
+    explicit Tmp(pgr_ctx *c) : ctx(c) {}
+    ~Tmp() { ctx->dfree(p); }
+    int alloc(size_t bytes) { return ctx->dmalloc(&p, std::max<size_t>(bytes, 16)); }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+    Tmp(const Tmp &) = delete;
+    Tmp &operator=(const Tmp &) = delete;
+};
+
+__global__ void iota_kernel(uint32_t *idx, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = (uint32_t)i;
 }
-extern "C" void pgr_hps_result_free(pgr_hps_result *) {}
-extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t, const pgr_hitpair *, const uint64_t *, uint32_t, float, int,
-                                    uint32_t, int, pgr_hps_result *) { return NOT_YET(ctx); }
+
+// field: 0 frg_id, 1 sid, 2 h1, 3 h0, 4 bgn
+__global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint32_t *__restrict__ idx, int field,
+                               uint64_t *__restrict__ keys, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pgr_frag_rec &r = recs[idx[i]];
+    uint64_t k;
+    switch (field) {
+    case 0: k = r.frg_id; break;
+    case 1: k = r.sid; break;
+    case 2: k = r.h1; break;
+    case 3: k = r.h0; break;
+    default: k = r.bgn; break;
+    }
+    keys[i] = k;
+}
+
+__global__ void gather_recs_kernel(const pgr_frag_rec *__restrict__ in, const uint32_t *__restrict__ idx,
+                                   pgr_frag_rec *__restrict__ out, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+
+__global__ void key_flags_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n, uint32_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        flags[i] = 0;
+        return;
+    }
+    flags[i] = (i == 0 || recs[i].h0 != recs[i - 1].h0 || recs[i].h1 != recs[i - 1].h1) ? 1u : 0u;
+}
+
+__global__ void scatter_starts_kernel(const uint32_t *__restrict__ flags, const uint64_t *__restrict__ rank, uint64_t n,
+                                      uint64_t *__restrict__ starts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        starts[rank[n]] = n;
+        return;
+    }
+    if (flags[i]) starts[rank[i]] = i;
+}
+
+inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
+
+// multi-pass stable LSD sort of a permutation; fields are sorted in the given order (least significant first)
+int sort_perm(pgr_ctx *ctx, const pgr_frag_rec *recs, uint64_t n, const int *fields, const unsigned *bits, int n_fields,
+              uint32_t *idx_a /*in: perm, out: sorted perm*/, uint32_t *idx_b, uint64_t *keys_a, uint64_t *keys_b) {
+    hipStream_t st = ctx->stream;
+    const size_t tb = sort_pairs_temp_bytes(n);
+    int rc;
+    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+    uint32_t *cur = idx_a, *nxt = idx_b;
+    for (int f = 0; f < n_fields; ++f) {
+        hipLaunchKernelGGL(rec_key_kernel, grid_for(n), dim3(256), 0, st, recs, cur, fields[f], keys_a, n);
+        PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a, keys_b, cur, nxt, n, bits[f]));
+        std::swap(cur, nxt);
+    }
+    if (cur != idx_a) PGR_HIP(ctx, hipMemcpyAsync(idx_a, cur, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+    return PGR_OK;
+}
+
+int grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) {
+    if (need <= ix->cap_raw) return PGR_OK;
+    const uint64_t cap = std::max<uint64_t>(need + need / 2, 1024);
+    pgr_frag_rec *np = nullptr;
+    int rc = ctx->dmalloc((void **)&np, cap * sizeof(pgr_frag_rec));
+    if (rc) return rc;
+    if (ix->n_raw) {
+        hipError_t e = hipMemcpyAsync(np, ix->raw, ix->n_raw * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->dfree(np);
+            return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+        }
+    }
+    ctx->dfree(ix->raw);
+    ix->raw = np;
+    ix->cap_raw = cap;
+    return PGR_OK;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int pgr_index_create(pgr_ctx *ctx, const pgr_spec *spec, pgr_index **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!spec || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (spec->k == 0 || spec->k > 56) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.k must be in 1..56");
+    if (spec->r == 0 || spec->r > 12) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.r must be in 1..12");
+    if (!spec->sketch && (spec->w == 0 || spec->w > 128)) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.w must be in 1..128");
+    pgr_index *ix = new pgr_index();
+    ix->ctx = ctx;
+    ix->spec = *spec;
+    *out = ix;
+    return PGR_OK;
+}
+
+extern "C" void pgr_index_destroy(pgr_index *ix) {
+    if (!ix) return;
+    ix->ctx->dfree(ix->raw);
+    ix->ctx->dfree(ix->recs);
+    ix->ctx->dfree(ix->key_off);
+    delete ix;
+}
+
+extern "C" uint64_t pgr_index_n_keys(const pgr_index *ix) { return ix ? ix->n_keys : 0; }
+extern "C" uint64_t pgr_index_n_records(const pgr_index *ix) { return ix ? (ix->finalized ? ix->n : ix->n_raw) : 0; }
+
+extern "C" int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs, uint64_t n, int on_device) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || (n && !recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (n == 0) return PGR_OK;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = grow_raw(ctx, ix, ix->n_raw + n);
+    if (rc) return rc;
+    PGR_HIP(ctx, hipMemcpyAsync(ix->raw + ix->n_raw, recs, n * sizeof(pgr_frag_rec),
+                                on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, ctx->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ix->n_raw += n;
+    ix->finalized = false;
+    return PGR_OK;
+}
+
+extern "C" int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_batch *b, const uint32_t *sids) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || !b) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    pgr_shmmrs *s = nullptr;
+    int rc = pgr_shmmrs_compute(ctx, b, &ix->spec, nullptr, 0, &s);  // index path: padding = false (seq_db.rs:462)
+    if (rc) return rc;
+    const uint64_t np = pgr_shmmrs_n_pairs(s);
+    std::vector<uint32_t> auto_sids;
+    if (!sids) {  // load_index_from_reader: running sid (seq_db.rs:543-553)
+        auto_sids.resize(b->n);
+        for (uint32_t i = 0; i < b->n; ++i) auto_sids[i] = ix->next_sid + i;
+        sids = auto_sids.data();
+    }
+    rc = grow_raw(ctx, ix, ix->n_raw + np);
+    uint64_t n_out = 0;
+    if (!rc) rc = pgr_shmmrs_to_frag_recs_device(ctx, s, sids, 0, ix->raw + ix->n_raw, ix->cap_raw - ix->n_raw, &n_out);
+    pgr_shmmrs_destroy(s);
+    if (rc) return rc;
+    ix->n_raw += n_out;
+    uint32_t mx = ix->next_sid;
+    for (uint32_t i = 0; i < b->n; ++i) mx = std::max(mx, sids[i] + 1);
+    ix->next_sid = mx;
+    ix->finalized = false;
+    return PGR_OK;
+}
+
+extern "C" int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                                   const uint32_t *sids) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
+    pgr_batch *b = nullptr;
+    int rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b);
+    if (rc) return rc;
+    rc = pgr_index_add_resident(ctx, ix, b, sids);
+    pgr_batch_destroy(b);
+    return rc;
+}
+
+extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
+    if (ix->finalized) return PGR_OK;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint64_t n = ix->n_raw;
+    if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "index holds more than 2^32-1 records per GPU");
+    ctx->dfree(ix->recs);
+    ctx->dfree(ix->key_off);
+    ix->recs = nullptr;
+    ix->key_off = nullptr;
+    ix->n = n;
+    ix->n_keys = 0;
+    int rc;
+    if ((rc = ctx->dmalloc((void **)&ix->recs, std::max<uint64_t>(n, 1) * sizeof(pgr_frag_rec)))) return rc;
+    if (n == 0) {
+        if ((rc = ctx->dmalloc((void **)&ix->key_off, sizeof(uint64_t)))) return rc;
+        PGR_HIP(ctx, hipMemsetAsync(ix->key_off, 0, sizeof(uint64_t), st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        ix->finalized = true;
+        return PGR_OK;
+    }
+    Tmp idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), flags(ctx), rank(ctx);
+    if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)))
+        return rc;
+    hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
+    const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
+    const unsigned bits[4] = {32, 32, 56, 56};
+    if ((rc = sort_perm(ctx, ix->raw, n, fields, bits, 4, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+                        keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
+        return rc;
+    hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, ix->raw, idx_a.as<uint32_t>(), ix->recs, n);
+    // distinct keys -> key_off
+    if ((rc = flags.alloc((n + 1) * 4)) || (rc = rank.alloc((n + 1) * 8))) return rc;
+    hipLaunchKernelGGL(key_flags_kernel, grid_for(n + 1), dim3(256), 0, st, ix->recs, n, flags.as<uint32_t>());
+    const size_t tb = scan_counts_temp_bytes((uint32_t)(n + 1));
+    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, flags.as<uint32_t>(), rank.as<uint64_t>(), (uint32_t)(n + 1)));
+    uint64_t n_keys = 0;
+    PGR_HIP(ctx, hipMemcpyAsync(&n_keys, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = ctx->dmalloc((void **)&ix->key_off, (n_keys + 1) * sizeof(uint64_t)))) return rc;
+    hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(),
+                       rank.as<uint64_t>(), n, ix->key_off);
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    PGR_HIP(ctx, hipGetLastError());
+    ix->n_keys = n_keys;
+    ix->finalized = true;
+    return PGR_OK;
+}
+
+extern "C" int pgr_index_download(pgr_ctx *ctx, const pgr_index *ix, pgr_frag_rec **out, uint64_t *n) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || !out || !n) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized");
+    *out = (pgr_frag_rec *)malloc(std::max<uint64_t>(ix->n, 1) * sizeof(pgr_frag_rec));
+    if (!*out) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    *n = ix->n;
+    if (ix->n) {
+        hipError_t e = hipMemcpy(*out, ix->recs, ix->n * sizeof(pgr_frag_rec), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            free(*out);
+            *out = nullptr;
+            return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+        }
+    }
+    return PGR_OK;
+}
+
+// ================================================================================================
+// query path
+namespace {
+
+// raw_query_fragment lookup: [lo, hi) = records of the query pair's key (empty when absent)
+__global__ void lookup_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, const pgr_frag_rec *__restrict__ recs,
+                              const uint64_t *__restrict__ key_off, uint64_t n_keys, uint64_t *__restrict__ lo_out,
+                              uint64_t *__restrict__ hi_out) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nq) return;
+    const uint64_t h0 = q[p].h0, h1 = q[p].h1;
+    uint64_t lo = 0, hi = n_keys;  // first key >= (h0,h1)
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const pgr_frag_rec &r = recs[key_off[mid]];
+        if (r.h0 < h0 || (r.h0 == h0 && r.h1 < h1)) lo = mid + 1;
+        else hi = mid;
+    }
+    uint64_t a = 0, b = 0;
+    if (lo < n_keys) {
+        const pgr_frag_rec &r = recs[key_off[lo]];
+        if (r.h0 == h0 && r.h1 == h1) {
+            a = key_off[lo];
+            b = key_off[lo + 1];
+        }
+    }
+    lo_out[p] = a;
+    hi_out[p] = b;
+}
+
+// shmmr_pair_hash_count (aln.rs:180-181): number of pairs of the same query with the same key.
+// sorted: permutation of the query pairs ordered by (query, h0, h1); one thread per run start.
+__global__ void run_count_kernel(const pgr_frag_rec *__restrict__ q, const uint32_t *__restrict__ sorted, uint64_t nq,
+                                 uint32_t *__restrict__ count) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nq) return;
+    const pgr_frag_rec &a = q[sorted[i]];
+    if (i > 0) {
+        const pgr_frag_rec &p = q[sorted[i - 1]];
+        if (p.sid == a.sid && p.h0 == a.h0 && p.h1 == a.h1) return;  // not a run start
+    }
+    uint64_t j = i + 1;
+    while (j < nq) {
+        const pgr_frag_rec &b = q[sorted[j]];
+        if (b.sid != a.sid || b.h0 != a.h0 || b.h1 != a.h1) break;
+        ++j;
+    }
+    const uint32_t len = (uint32_t)(j - i);
+    for (uint64_t t = i; t < j; ++t) count[sorted[t]] = len;
+}
+
+struct QParams {
+    uint32_t max_count, max_count_query, max_count_target;
+};
+
+// aln.rs:197-228: number of hits a query pair contributes (mode 0) or the hits themselves (mode 1).
+// Records of one key are sorted by sid, so target_shmer_pair_count[(key,sid)] = count * run length.
+__global__ void hits_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, const uint32_t *__restrict__ count,
+                            const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
+                            const pgr_frag_rec *__restrict__ recs, QParams prm, int mode, uint32_t *__restrict__ n_hits,
+                            const uint64_t *__restrict__ hit_off, uint64_t *__restrict__ hit_key,
+                            pgr_hitpair *__restrict__ hit_hp) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p > nq) return;
+    if (p == nq) {
+        if (mode == 0) n_hits[nq] = 0;
+        return;
+    }
+    const uint32_t c = count[p];
+    uint32_t n = 0;
+    uint64_t o = mode ? hit_off[p] : 0;
+    if (c <= prm.max_count && c <= prm.max_count_query) {
+        const pgr_frag_rec qp = q[p];
+        uint64_t s = lo[p];
+        const uint64_t e = hi[p];
+        while (s < e) {
+            const uint32_t sid = recs[s].sid;
+            uint64_t t = s + 1;
+            while (t < e && recs[t].sid == sid) ++t;
+            const uint64_t tcount = (uint64_t)(t - s) * c;
+            if (tcount <= prm.max_count_target) {
+                if (mode) {
+                    for (uint64_t u = s; u < t; ++u) {
+                        pgr_hitpair h;
+                        h.qb = qp.bgn;
+                        h.qe = qp.end;
+                        h.qo = qp.orient;
+                        h.tb = recs[u].bgn;
+                        h.te = recs[u].end;
+                        h.to = recs[u].orient;
+                        hit_hp[o] = h;
+                        hit_key[o] = ((uint64_t)qp.sid << 32) | sid;  // (query, target)
+                        ++o;
+                    }
+                }
+                n += (uint32_t)(t - s);
+            }
+            s = t;
+        }
+    }
+    if (mode == 0) n_hits[p] = n;
+}
+
+// field 0: qb, 1: (query<<32 | sid)
+__global__ void hit_key_kernel(const uint64_t *__restrict__ hit_key, const pgr_hitpair *__restrict__ hp,
+                               const uint32_t *__restrict__ idx, int field, uint64_t *__restrict__ keys, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t j = idx[i];
+    keys[i] = field == 0 ? (uint64_t)hp[j].qb : hit_key[j];
+}
+
+__global__ void gather_hits_kernel(const uint64_t *__restrict__ hit_key, const pgr_hitpair *__restrict__ hp,
+                                   const uint32_t *__restrict__ idx, uint64_t n, uint64_t *__restrict__ key_out,
+                                   pgr_hitpair *__restrict__ hp_out, uint32_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    if (i == n) {
+        flags[n] = 0;
+        return;
+    }
+    const uint32_t j = idx[i];
+    const uint64_t k = hit_key[j];
+    key_out[i] = k;
+    hp_out[i] = hp[j];
+    flags[i] = (i == 0 || hit_key[idx[i - 1]] != k) ? 1u : 0u;
+}
+
+struct AlnParams {
+    uint32_t max_span;
+    float penalty;
+    int has_max_gap;
+    uint32_t max_gap;
+    int oriented;
+};
+
+__device__ __forceinline__ bool same_q(const pgr_hitpair &a, const pgr_hitpair &b) {
+    return a.qb == b.qb && a.qe == b.qe && a.qo == b.qo;
+}
+__device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair &b) {
+    return same_q(a, b) && a.tb == b.tb && a.te == b.te && a.to == b.to;
+}
+__device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
+
+constexpr uint32_t MAX_SPAN_CAP = 64;
+
+// aln::sparse_aln (aln.rs:12-142), one thread per (query, target) group.  The hits of a group are
+// already stably sorted by query bgn (aln.rs:21).  v_s / best_pre_v are FxHashMaps keyed by the
+// HitPair VALUE in the reference, so identical hit pairs share one slot: slot[i] = first index with
+// the same value.  Tie-break of the chain extraction (FxHashSet order in the reference, unspecified):
+// lowest sorted index.  Outputs are written into the group's own range [gs, gs+n).
+__global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start,
+                                  uint64_t n_groups, AlnParams prm, float *__restrict__ v_s, int *__restrict__ pre,
+                                  int *__restrict__ slot, pgr_hitpair *__restrict__ out_hp,
+                                  uint32_t *__restrict__ chain_len, float *__restrict__ chain_score,
+                                  uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
+                                  uint32_t *__restrict__ err) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n_groups) return;
+    const uint64_t gs = g_start[g];
+    const int n = (int)(g_start[g + 1] - gs);
+    g_nchains[g] = 0;
+    g_nhp[g] = 0;
+    if (n < 2) return;  // aln.rs:234: targets with a single hit are dropped
+    const pgr_hitpair *h = hp + gs;
+    float *vs = v_s + gs;
+    int *pv = pre + gs;
+    int *sl = slot + gs;
+    for (int i = 0; i < n; ++i) {
+        int s = i;
+        for (int j = i - 1; j >= 0 && h[j].qb == h[i].qb; --j)
+            if (same_hp(h[j], h[i])) {
+                s = sl[j];
+                break;
+            }
+        sl[i] = s;
+    }
+    vs[sl[0]] = (float)h[0].qe - (float)h[0].qb;  // aln.rs:25-27
+    pv[sl[0]] = -1;
+    uint32_t span_q[MAX_SPAN_CAP][3];
+    for (int i = 1; i < n; ++i) {  // aln.rs:29-103
+        const pgr_hitpair cur = h[i];
+        int best_v = -1;
+        float best_s = 0.0f;
+        uint32_t span_n = 0;
+        for (int j = i - 1; j >= 0; --j) {
+            const pgr_hitpair p = h[j];
+            if (prm.oriented && ((p.qo ^ p.to) != (cur.qo ^ cur.to))) continue;  // :43-50
+            float a = (float)cur.qb - (float)p.qe;
+            float b = (cur.qo == cur.to) ? ((float)cur.tb - (float)p.te) : ((float)cur.te - (float)p.tb);
+            a = absf(a);
+            b = absf(b);
+            if (prm.has_max_gap) {  // :52-65
+                const float mg = (float)prm.max_gap;
+                if (a > mg || b > mg) continue;
+            }
+            if (same_q(p, cur)) continue;  // :67
+            bool found = false;            // :70
+            for (uint32_t t = 0; t < span_n; ++t)
+                if (span_q[t][0] == p.qb && span_q[t][1] == p.qe && span_q[t][2] == p.qo) {
+                    found = true;
+                    break;
+                }
+            if (!found) {
+                span_q[span_n][0] = p.qb;
+                span_q[span_n][1] = p.qe;
+                span_q[span_n][2] = p.qo;
+                ++span_n;
+            }
+            const float p_s = vs[sl[j]];                             // :71
+            float s = p_s + ((float)cur.qe - (float)cur.qb);         // :72
+            const float sum = a + b;                                 // :74-84
+            const float pen = prm.penalty * sum;
+            s = s - pen;
+            if (s > best_s) {  // :86-89
+                best_s = s;
+                best_v = sl[j];
+            }
+            if (span_n >= prm.max_span) break;  // :91
+        }
+        if (best_s > 0.0f) {  // :96-102
+            vs[sl[i]] = best_s;
+            pv[sl[i]] = best_v;
+        } else {
+            vs[sl[i]] = (float)cur.qe - (float)cur.qb;
+            pv[sl[i]] = -1;
+        }
+    }
+    // extraction (aln.rs:105-140).  A visited value-slot is marked by sl[v] = -1 - v (the DP is done,
+    // so sl is free to carry the flag); unvisited representatives have sl[i] == i.
+    uint32_t n_ch = 0, n_out = 0;
+    int n_unvisited = 0;
+    for (int i = 0; i < n; ++i) n_unvisited += (sl[i] == i);
+    while (n_unvisited > 0) {
+        float best_s = 0.0f;
+        int best_v = -1;
+        for (int i = 0; i < n; ++i)
+            if (sl[i] == i && vs[i] > best_s) {  // strict >, first (lowest sorted index) wins
+                best_s = vs[i];
+                best_v = i;
+            }
+        if (best_v < 0) {  // aln.rs:129-131 would spin forever (non-positive scores)
+            atomicExch(err, 1u);
+            break;
+        }
+        uint32_t len = 0;
+        int v = best_v, first_v = best_v;
+        while (v >= 0 && sl[v] == v) {  // :121-128
+            out_hp[gs + n_out + len] = h[v];
+            ++len;
+            first_v = v;
+            const int nv = pv[v];
+            sl[v] = -1 - v;  // :133-137
+            --n_unvisited;
+            v = nv;
+        }
+        for (uint32_t a = 0, b = len - 1; a < b; ++a, --b) {  // :132 reverse
+            const pgr_hitpair t = out_hp[gs + n_out + a];
+            out_hp[gs + n_out + a] = out_hp[gs + n_out + b];
+            out_hp[gs + n_out + b] = t;
+        }
+        chain_len[gs + n_ch] = len;
+        chain_score[gs + n_ch] = best_s - vs[first_v];  // :138-139
+        ++n_ch;
+        n_out += len;
+    }
+    g_nchains[g] = n_ch;
+    g_nhp[g] = n_out;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host orchestration of the chaining stage: hits (key = group id, hp) -> per-group chains
+namespace {
+
+struct ChainOut {
+    std::vector<uint64_t> g_key;      // key of every group with >= 2 hits that produced chains
+    std::vector<uint32_t> g_nchains;  // chains per such group
+    std::vector<float> c_score;
+    std::vector<uint32_t> c_len;
+    std::vector<pgr_hitpair> hps;
+};
+
+// d_key/d_hp: n hits in arbitrary order; groups = equal keys.  Sorts (stable by qb, then by key), runs the DP.
+int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uint64_t n, const AlnParams &prm,
+               ChainOut &out) {
+    if (n == 0) return PGR_OK;
+    if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 hits in one batch");
+    hipStream_t st = ctx->stream;
+    int rc;
+    Tmp idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), skey(ctx), shp(ctx), flags(ctx), rank(ctx), gstart(ctx);
+    if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)) ||
+        (rc = skey.alloc(n * 8)) || (rc = shp.alloc(n * sizeof(pgr_hitpair))) || (rc = flags.alloc((n + 1) * 4)) ||
+        (rc = rank.alloc((n + 1) * 8)))
+        return rc;
+    hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
+    const size_t tb = sort_pairs_temp_bytes(n);
+    if ((rc = ctx->ws_scan_tmp.ensure(ctx, std::max(tb, scan_counts_temp_bytes((uint32_t)(n + 1)))))) return rc;
+    uint32_t *cur = idx_a.as<uint32_t>(), *nxt = idx_b.as<uint32_t>();
+    for (int f = 0; f < 2; ++f) {  // stable: by qb (aln.rs:21), then by group
+        hipLaunchKernelGGL(hit_key_kernel, grid_for(n), dim3(256), 0, st, d_key, d_hp, cur, f, keys_a.as<uint64_t>(), n);
+        PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), cur, nxt, n,
+                                f == 0 ? 32u : 64u));
+        std::swap(cur, nxt);
+    }
+    hipLaunchKernelGGL(gather_hits_kernel, grid_for(n + 1), dim3(256), 0, st, d_key, d_hp, cur, n, skey.as<uint64_t>(),
+                       shp.as<pgr_hitpair>(), flags.as<uint32_t>());
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, scan_counts_temp_bytes((uint32_t)(n + 1)), flags.as<uint32_t>(),
+                             rank.as<uint64_t>(), (uint32_t)(n + 1)));
+    uint64_t n_groups = 0;
+    PGR_HIP(ctx, hipMemcpyAsync(&n_groups, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = gstart.alloc((n_groups + 1) * 8))) return rc;
+    hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(), rank.as<uint64_t>(),
+                       n, gstart.as<uint64_t>());
+    Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx);
+    if ((rc = v_s.alloc(n * 4)) || (rc = pre.alloc(n * 4)) || (rc = slot.alloc(n * 4)) ||
+        (rc = o_hp.alloc(n * sizeof(pgr_hitpair))) || (rc = c_len.alloc(n * 4)) || (rc = c_score.alloc(n * 4)) ||
+        (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(4)))
+        return rc;
+    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 4, st));
+    hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n_groups, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
+                       gstart.as<uint64_t>(), n_groups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
+                       o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(), g_nch.as<uint32_t>(),
+                       g_nhp.as<uint32_t>(), err.as<uint32_t>());
+    // D2H and compaction on the host (output assembly only)
+    std::vector<uint64_t> h_gstart(n_groups + 1), h_skey(n);
+    std::vector<uint32_t> h_nch(n_groups), h_nhp(n_groups), h_clen(n);
+    std::vector<float> h_cscore(n);
+    std::vector<pgr_hitpair> h_hp(n);
+    uint32_t h_err = 0;
+    PGR_HIP(ctx, hipMemcpyAsync(h_gstart.data(), gstart.p, (n_groups + 1) * 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(h_skey.data(), skey.p, n * 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(h_nch.data(), g_nch.p, n_groups * 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(h_nhp.data(), g_nhp.p, n_groups * 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(h_clen.data(), c_len.p, n * 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(h_cscore.data(), c_score.p, n * 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(h_hp.data(), o_hp.p, n * sizeof(pgr_hitpair), hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    PGR_HIP(ctx, hipGetLastError());
+    if (h_err)
+        return ctx->fail(PGR_ERR_INVALID_ARG,
+                         "sparse_aln: a hit pair with end <= bgn (non-positive score); the reference never terminates "
+                         "on such input (aln.rs:129-131)");
+    for (uint64_t g = 0; g < n_groups; ++g) {
+        if (h_gstart[g + 1] - h_gstart[g] < 2) continue;  // aln.rs:234
+        const uint64_t gs = h_gstart[g];
+        out.g_key.push_back(h_skey[gs]);
+        out.g_nchains.push_back(h_nch[g]);
+        uint64_t o = gs;
+        for (uint32_t c = 0; c < h_nch[g]; ++c) {
+            out.c_score.push_back(h_cscore[gs + c]);
+            out.c_len.push_back(h_clen[gs + c]);
+            out.hps.insert(out.hps.end(), h_hp.begin() + o, h_hp.begin() + o + h_clen[gs + c]);
+            o += h_clen[gs + c];
+        }
+    }
+    return PGR_OK;
+}
+
+template <class T>
+T *dup_vec(const std::vector<T> &v) {
+    T *p = (T *)malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
+    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
+    return p;
+}
+
+// groups are sorted by key = (query << 32 | sid): flat result
+int fill_result(pgr_ctx *ctx, uint32_t n_queries, const ChainOut &co, pgr_hps_result *out) {
+    std::vector<uint64_t> q_off((size_t)n_queries + 1, 0), t_off, c_off;
+    std::vector<uint32_t> t_sid;
+    uint64_t n_chains = 0, n_hp = 0;
+    size_t gi = 0;
+    for (uint32_t q = 0; q < n_queries; ++q) {
+        q_off[q] = t_sid.size();
+        while (gi < co.g_key.size() && (uint32_t)(co.g_key[gi] >> 32) == q) {
+            t_sid.push_back((uint32_t)(co.g_key[gi] & 0xFFFFFFFFull));
+            t_off.push_back(n_chains);
+            for (uint32_t c = 0; c < co.g_nchains[gi]; ++c) {
+                c_off.push_back(n_hp);
+                n_hp += co.c_len[n_chains];
+                ++n_chains;
+            }
+            ++gi;
+        }
+    }
+    q_off[n_queries] = t_sid.size();
+    t_off.push_back(n_chains);
+    c_off.push_back(n_hp);
+    out->n_queries = n_queries;
+    out->q_off = dup_vec(q_off);
+    out->n_targets = t_sid.size();
+    out->t_sid = dup_vec(t_sid);
+    out->t_off = dup_vec(t_off);
+    out->n_chains = n_chains;
+    out->c_score = dup_vec(co.c_score);
+    out->c_off = dup_vec(c_off);
+    out->n_hps = n_hp;
+    out->hps = dup_vec(co.hps);
+    if (!out->q_off || !out->t_sid || !out->t_off || !out->c_score || !out->c_off || !out->hps) {
+        pgr_hps_result_free(out);
+        return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    }
+    return PGR_OK;
+}
+
+}  // namespace
+
+extern "C" void pgr_hps_result_free(pgr_hps_result *r) {
+    if (!r) return;
+    free(r->q_off);
+    free(r->t_sid);
+    free(r->t_off);
+    free(r->c_score);
+    free(r->c_off);
+    free(r->hps);
+    memset(r, 0, sizeof(*r));
+}
+
+extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries, const uint8_t *const *seqs,
+                                   const uint64_t *lens, float penalty, uint32_t max_count, uint32_t max_count_query,
+                                   uint32_t max_count_target, uint32_t max_aln_span, int has_max_gap, uint32_t max_gap,
+                                   int oriented, pgr_hps_result *out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
+    if (max_aln_span == 0 || max_aln_span > MAX_SPAN_CAP)
+        return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be in 1..64");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // queries -> shimmer-pair records, query side (strict <, seq_db.rs:1213); sid field = query index
+    pgr_batch *b = nullptr;
+    int rc = pgr_batch_from_ascii(ctx, n_queries, seqs, lens, &b);
+    if (rc) return rc;
+    pgr_shmmrs *s = nullptr;
+    rc = pgr_shmmrs_compute(ctx, b, &ix->spec, nullptr, 0, &s);
+    pgr_batch_destroy(b);
+    if (rc) return rc;
+    const uint64_t nq = pgr_shmmrs_n_pairs(s);
+    ChainOut co;
+    if (nq && ix->n) {
+        Tmp qrec(ctx), lo(ctx), hi(ctx), cnt(ctx), idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), nh(ctx), hoff(ctx);
+        if ((rc = qrec.alloc(nq * sizeof(pgr_frag_rec)))) {
+            pgr_shmmrs_destroy(s);
+            return rc;
+        }
+        uint64_t n_out = 0;
+        rc = pgr_shmmrs_to_frag_recs_device(ctx, s, nullptr, 1, qrec.as<pgr_frag_rec>(), nq, &n_out);
+        pgr_shmmrs_destroy(s);
+        s = nullptr;
+        if (rc) return rc;
+        if ((rc = lo.alloc(nq * 8)) || (rc = hi.alloc(nq * 8)) || (rc = cnt.alloc(nq * 4)) || (rc = idx_a.alloc(nq * 4)) ||
+            (rc = idx_b.alloc(nq * 4)) || (rc = keys_a.alloc(nq * 8)) || (rc = keys_b.alloc(nq * 8)) ||
+            (rc = nh.alloc((nq + 1) * 4)) || (rc = hoff.alloc((nq + 1) * 8)))
+            return rc;
+        hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
+                           ix->key_off, ix->n_keys, lo.as<uint64_t>(), hi.as<uint64_t>());
+        // per-query key multiplicities: sort the pairs by (query, h0, h1), count runs
+        hipLaunchKernelGGL(iota_kernel, grid_for(nq), dim3(256), 0, st, idx_a.as<uint32_t>(), nq);
+        const int fields[3] = {2, 3, 1};  // h1, h0, sid(=query)
+        const unsigned bits[3] = {56, 56, 32};
+        if ((rc = sort_perm(ctx, qrec.as<pgr_frag_rec>(), nq, fields, bits, 3, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+                            keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
+            return rc;
+        hipLaunchKernelGGL(run_count_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(),
+                           idx_a.as<uint32_t>(), nq, cnt.as<uint32_t>());
+        QParams qp{max_count, max_count_query, max_count_target};
+        hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
+                           cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qp, 0, nh.as<uint32_t>(),
+                           (const uint64_t *)nullptr, (uint64_t *)nullptr, (pgr_hitpair *)nullptr);
+        const size_t tb = scan_counts_temp_bytes((uint32_t)(nq + 1));
+        if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, nh.as<uint32_t>(), hoff.as<uint64_t>(), (uint32_t)(nq + 1)));
+        uint64_t n_hits = 0;
+        PGR_HIP(ctx, hipMemcpyAsync(&n_hits, hoff.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        if (n_hits) {
+            Tmp hkey(ctx), hhp(ctx);
+            if ((rc = hkey.alloc(n_hits * 8)) || (rc = hhp.alloc(n_hits * sizeof(pgr_hitpair)))) return rc;
+            hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
+                               cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qp, 1,
+                               (uint32_t *)nullptr, hoff.as<uint64_t>(), hkey.as<uint64_t>(), hhp.as<pgr_hitpair>());
+            AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
+            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, co))) return rc;
+        }
+    } else {
+        pgr_shmmrs_destroy(s);
+    }
+    return fill_result(ctx, n_queries, co, out);
+}
+
+extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_hitpair *hits, const uint64_t *g_off,
+                                    uint32_t max_span, float penalty, int has_max_gap, uint32_t max_gap, int oriented,
+                                    pgr_hps_result *out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out || (n_groups && (!hits || !g_off))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (max_span == 0 || max_span > MAX_SPAN_CAP) return ctx->fail(PGR_ERR_INVALID_ARG, "max_span must be in 1..64");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = n_groups ? g_off[n_groups] : 0;
+    for (uint32_t g = 0; g < n_groups; ++g)
+        if (g_off[g + 1] - g_off[g] < 2)  // aln.rs:24 assert!(sp_hits.len() > 1)
+            return ctx->fail(PGR_ERR_INVALID_ARG, "sparse_aln needs at least 2 hit pairs per group");
+    ChainOut co;
+    if (n) {
+        std::vector<uint64_t> keys(n);
+        for (uint32_t g = 0; g < n_groups; ++g)
+            for (uint64_t i = g_off[g]; i < g_off[g + 1]; ++i) keys[i] = (uint64_t)g;  // query 0, "sid" = group
+        Tmp dk(ctx), dh(ctx);
+        int rc;
+        if ((rc = dk.alloc(n * 8)) || (rc = dh.alloc(n * sizeof(pgr_hitpair)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(dk.p, keys.data(), n * 8, hipMemcpyHostToDevice, ctx->stream));
+        PGR_HIP(ctx, hipMemcpyAsync(dh.p, hits, n * sizeof(pgr_hitpair), hipMemcpyHostToDevice, ctx->stream));
+        PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AlnParams ap{max_span, penalty, has_max_gap, max_gap, oriented};
+        if ((rc = chain_hits(ctx, dk.as<uint64_t>(), dh.as<pgr_hitpair>(), n, ap, co))) return rc;
+    }
+    return fill_result(ctx, 1, co, out);
+}

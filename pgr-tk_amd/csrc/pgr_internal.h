@@ -120,6 +120,6 @@ hipError_t scan_counts(hipStream_t st, void *temp, size_t temp_bytes, const uint
                        uint32_t n_plus_1);
 size_t sort_pairs_temp_bytes(uint64_t n);
 hipError_t sort_pairs(hipStream_t st, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                      const uint32_t *vals_in, uint32_t *vals_out, uint64_t n);
+                      const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit);
 
 }  // namespace pgr

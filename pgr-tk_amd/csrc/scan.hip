@@ -33,18 +33,17 @@ hipError_t scan_counts(hipStream_t st, void *temp, size_t temp_bytes, const uint
                                    rocprim::plus<uint64_t>(), st);
 }
 
-// stable LSD radix sort of 64-bit keys with a 32-bit payload (used twice: by h1 then by h0)
+// stable LSD radix sort of 64-bit keys (bits [0, end_bit)) with a 32-bit payload
 size_t sort_pairs_temp_bytes(uint64_t n) {
     size_t bytes = 0;
     (void)rocprim::radix_sort_pairs(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr,
-                                    (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 56);
+                                    (const uint32_t *)nullptr, (uint32_t *)nullptr, (size_t)n, 0, 64);
     return bytes;
 }
 
 hipError_t sort_pairs(hipStream_t st, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
-                      const uint32_t *vals_in, uint32_t *vals_out, uint64_t n) {
-    // hashes are 56-bit (x >> 8 of a (hash << 8 | k) word): sort bits [0, 56)
-    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, 56, st);
+                      const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit) {
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, end_bit, st);
 }
 
 }  // namespace pgr

@@ -1,0 +1,275 @@
+"""SeqIndexDB -- host-side mirror of pgr-tk's `pgrtk.SeqIndexDB` (pgr-tk/src/lib.rs:58-1404) for the
+index / query subset.  Same method names, argument meaning and
+defaults; the shimmer computation, the frag_map (as a sorted CSR) and the chaining run on the
+GPU through libpgrhip.so.  Sequence iteration (FASTA) and the name tables stay on the host, as in
+the reference.
+"""
+import ctypes as C
+import gzip
+import os
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import FRAG_REC, HITPAIR, HpsResult, default_context, lib
+from .engine import frag_recs_batch, make_spec
+
+
+def read_fastx(filepath):
+    """FASTA / FASTQ (.gz ok) with the reference reader's record semantics (pgr-db/src/fasta_io.rs:
+    id = header up to the first space :94-101, sequence bytes kept as they are, newlines dropped
+    :102-106).  Returns [(name: str, seq: bytes)]."""
+    opener = gzip.open if filepath.endswith(".gz") else open
+    recs = []
+    with opener(filepath, "rb") as f:
+        data = f.read()
+    if not data:
+        return recs
+    if data[:1] == b">":
+        for chunk in data.split(b"\n>"):
+            chunk = chunk[1:] if chunk[:1] == b">" else chunk
+            nl = chunk.find(b"\n")
+            head = chunk if nl < 0 else chunk[:nl]
+            body = b"" if nl < 0 else chunk[nl + 1:]
+            name = head.rstrip(b"\r").split(b" ")[0]
+            recs.append((name.decode("utf-8", "replace"), body.replace(b"\n", b"").replace(b"\r", b"")))
+    elif data[:1] == b"@":
+        lines = data.split(b"\n")
+        for i in range(0, len(lines) - 3, 4):
+            recs.append((lines[i][1:].rstrip(b"\r").split(b" ")[0].decode("utf-8", "replace"),
+                         lines[i + 1].rstrip(b"\r")))
+    else:
+        raise ValueError("not a FASTA/FASTQ file: " + filepath)
+    return recs
+
+
+def _unpack_hps(res, n_queries):
+    """pgr_hps_result -> per query: [(sid, [(score, [hitpair tuples])])]"""
+    q_off = np.ctypeslib.as_array(res.q_off, shape=(n_queries + 1,)).copy()
+    nt, nc, nh = int(res.n_targets), int(res.n_chains), int(res.n_hps)
+    t_sid = np.ctypeslib.as_array(res.t_sid, shape=(max(nt, 1),))[:nt].copy()
+    t_off = np.ctypeslib.as_array(res.t_off, shape=(nt + 1,)).copy()
+    c_score = np.ctypeslib.as_array(res.c_score, shape=(max(nc, 1),))[:nc].copy()
+    c_off = np.ctypeslib.as_array(res.c_off, shape=(nc + 1,)).copy()
+    hps = np.zeros(nh, dtype=HITPAIR)
+    if nh:
+        C.memmove(hps.ctypes.data, res.hps, nh * HITPAIR.itemsize)
+    out = []
+    for q in range(n_queries):
+        targets = []
+        for t in range(int(q_off[q]), int(q_off[q + 1])):
+            chains = []
+            for c in range(int(t_off[t]), int(t_off[t + 1])):
+                hp = hps[int(c_off[c]):int(c_off[c + 1])]
+                chains.append((float(c_score[c]),
+                               [((int(h["qb"]), int(h["qe"]), int(h["qo"])), (int(h["tb"]), int(h["te"]), int(h["to"])))
+                                for h in hp]))
+            targets.append((int(t_sid[t]), chains))
+        out.append(targets)
+    return out
+
+
+def sparse_aln(sp_hits, max_span, penalty, max_gap=None, orientated=False, ctx=None):
+    """pgrtk.sparse_aln (pgr-tk/src/lib.rs:1539-1550 -> aln::sparse_aln, aln.rs:12-142).
+    sp_hits: [((qb,qe,qo),(tb,te,to))] -> [(score, [hit pairs])]"""
+    ctx = ctx or default_context()
+    a = np.array([(h[0][0], h[0][1], h[0][2], h[1][0], h[1][1], h[1][2]) for h in sp_hits], dtype=HITPAIR)
+    if a.size < 2:
+        raise ValueError("sparse_aln needs at least 2 hit pairs")  # aln.rs:24 assert
+    off = (C.c_uint64 * 2)(0, a.size)
+    res = HpsResult()
+    ctx.check(lib().pgr_sparse_aln_batch(ctx.handle, 1, a.ctypes.data, off, max_span, penalty,
+                                         int(max_gap is not None), int(max_gap or 0), int(bool(orientated)),
+                                         C.byref(res)))
+    out = _unpack_hps(res, 1)
+    lib().pgr_hps_result_free(C.byref(res))
+    return out[0][0][1] if out[0] else []
+
+
+def get_shmmr_pairs_from_seq(seq, w=80, k=56, r=4, min_span=16, padding=False, ctx=None):
+    """pgrtk.get_shmmr_pairs_from_seq (pgr-tk/src/lib.rs:1581-1613): [(h0, h1, p0, p1, orientation)]"""
+    from .engine import sequence_to_shmmrs
+    mm = sequence_to_shmmrs(0, seq, make_spec(w, k, r, min_span), padding=padding, ctx=ctx)
+    out = []
+    for a, b in zip(mm[:-1], mm[1:]):
+        s0, s1 = int(a["x"]) >> 8, int(b["x"]) >> 8
+        p0 = ((int(a["y"]) & 0xFFFFFFFF) >> 1) + 1
+        p1 = ((int(b["y"]) & 0xFFFFFFFF) >> 1) + 1
+        out.append((s0, s1, p0, p1, 0) if s0 < s1 else (s1, s0, p0, p1, 1))
+    return out
+
+
+class SeqIndexDB:
+    """FASTX / MEMORY backends of the reference's SeqIndexDB (pgr-db/src/ext.rs:152-249)."""
+
+    def __init__(self, ctx=None, device=0):
+        self.ctx = ctx or default_context(device)
+        self._ix = C.c_void_p()
+        self._spec = None
+        self.backend = "UNKNOWN"
+        self.seq_index = None  # {(name, source): (sid, len)}   (lib.rs:215 getter)
+        self.seq_info = None   # {sid: (name, source, len)}     (lib.rs:223 getter)
+        self._n_seqs = 0
+        self._host = None      # lazily downloaded sorted records + key table
+
+    # ------------------------------------------------------------------ loading
+    def _reset(self, w, k, r, min_span):
+        self.close()
+        self._spec = make_spec(w, k, r, min_span, False)
+        self._ix = C.c_void_p()
+        self.ctx.check(lib().pgr_index_create(self.ctx.handle, C.byref(self._spec), C.byref(self._ix)))
+        self.seq_index, self.seq_info, self._n_seqs, self._host = {}, {}, 0, None
+
+    def _append(self, named_seqs, source):
+        seqs = [s for _, s in named_seqs]
+        arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+        sids = np.arange(self._n_seqs, self._n_seqs + n, dtype=np.uint32)
+        self.ctx.check(lib().pgr_index_add_batch(self.ctx.handle, self._ix, n, ptrs, lens,
+                                                 sids.ctypes.data_as(C.POINTER(C.c_uint32))))
+        for i, (name, s) in enumerate(named_seqs):
+            sid = self._n_seqs + i
+            self.seq_index[(name, source)] = (sid, len(s))
+            self.seq_info[sid] = (name, source, len(s))
+        self._n_seqs += n
+        self.ctx.check(lib().pgr_index_finalize(self.ctx.handle, self._ix))
+        self._host = None
+
+    def load_from_fastx(self, filepath, w=80, k=56, r=4, min_span=64):
+        """lib.rs:142-155 / ext.rs:152-181"""
+        self._reset(w, k, r, min_span)
+        self.backend = "FASTX"
+        self._append(read_fastx(filepath), filepath)
+
+    def append_from_fastx(self, filepath):
+        """lib.rs:157-165"""
+        assert self.backend == "FASTX", "Only DB created with load_from_fastx() can add data from another fastx file"
+        self._append(read_fastx(filepath), filepath)
+
+    def load_from_seq_list(self, seq_list, source="Memory", w=80, k=56, r=4, min_span=8):
+        """lib.rs:196-213 / ext.rs:208-249: seq_list = [(name, bytes)]"""
+        self._reset(w, k, r, min_span)
+        self.backend = "MEMORY"
+        self._append([(n, bytes(s)) for n, s in seq_list], source)
+
+    def close(self):
+        if getattr(self, "_ix", None):
+            lib().pgr_index_destroy(self._ix)
+            self._ix = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ frag_map views
+    def _records(self):
+        """host copy of the CSR: (records sorted by key/sid/frg_id with GLOBAL fragment ids, {key: (lo, hi)})"""
+        if self._host is None:
+            p, n = C.c_void_p(), C.c_uint64()
+            self.ctx.check(lib().pgr_index_download(self.ctx.handle, self._ix, C.byref(p), C.byref(n)))
+            recs = _ffi.take(p, int(n.value), FRAG_REC)
+            # FASTX/MEMORY backends number fragments globally (seq_db.rs:189-357): per sequence
+            # Prefix +1, one per pair, Suffix +1; a sequence without pairs takes 2 ids.
+            pairs = np.bincount(recs["sid"], minlength=self._n_seqs).astype(np.int64)
+            base = np.concatenate([[0], np.cumsum(np.where(pairs == 0, 2, pairs + 2))])[:-1]
+            recs["frg_id"] = (base[recs["sid"]] + 1 + recs["frg_id"]).astype(np.uint32)
+            keys = {}
+            if len(recs):
+                chg = np.flatnonzero((recs["h0"][1:] != recs["h0"][:-1]) | (recs["h1"][1:] != recs["h1"][:-1])) + 1
+                starts = np.concatenate([[0], chg])
+                ends = np.concatenate([chg, [len(recs)]])
+                for s, e in zip(starts, ends):
+                    keys[(int(recs["h0"][s]), int(recs["h1"][s]))] = (int(s), int(e))
+            self._host = (recs, keys)
+        return self._host
+
+    @staticmethod
+    def _sig(r):
+        return (int(r["frg_id"]), int(r["sid"]), int(r["bgn"]), int(r["end"]), int(r["orient"]))
+
+    def get_shmmr_spec(self):
+        """lib.rs:729-735"""
+        return None if self._spec is None else self._spec.as_tuple()
+
+    def get_shmmr_map(self):
+        """lib.rs:752-762: {(h0,h1): [(frg_id, sid, bgn, end, orientation)]}"""
+        recs, keys = self._records()
+        return {k: [self._sig(r) for r in recs[s:e]] for k, (s, e) in keys.items()}
+
+    def get_shmmr_pair_list(self):
+        """lib.rs:774-790: [(h0, h1, sid, bgn, end, orientation)] (order unspecified in the reference)"""
+        recs, _ = self._records()
+        return [(int(r["h0"]), int(r["h1"]), int(r["sid"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in recs]
+
+    def get_shmmr_pair_count(self, shmmr_pair):
+        """lib.rs:636-648"""
+        _, keys = self._records()
+        s, e = keys.get((int(shmmr_pair[0]), int(shmmr_pair[1])), (0, 0))
+        return e - s
+
+    # ------------------------------------------------------------------ queries
+    def query_fragment(self, seq):
+        """lib.rs:249-306 -> raw_query_fragment (seq_db.rs:1200-1228):
+        [((h0,h1), (p0,p1,orientation), [fragment signatures])] in query order"""
+        recs, keys = self._records()
+        q = frag_recs_batch([seq], self._spec, query_side=True, ctx=self.ctx)[0]
+        out = []
+        for r in q:
+            key = (int(r["h0"]), int(r["h1"]))
+            s, e = keys.get(key, (0, 0))
+            out.append((key, (int(r["bgn"]), int(r["end"]), int(r["orient"])), [self._sig(x) for x in recs[s:e]]))
+        return out
+
+    def get_match_positions_with_fragment(self, seq):
+        """lib.rs:308-326 -> seq_db.rs:1271-1289: {sid: sorted [(bgn, end, direction)]}"""
+        res = {}
+        for _, (_, _, qo), sigs in self.query_fragment(seq):
+            for (_, sid, p0, p1, d) in sigs:
+                res.setdefault(sid, []).append((p0, p1, 0 if d == qo else 1))
+        for v in res.values():
+            v.sort()
+        return res
+
+    def query_fragments_to_hps(self, seqs, penalty, max_count=None, max_count_query=None, max_count_target=None,
+                               max_aln_span=None, max_gap=None, orientated=False):
+        """batched query_fragment_to_hps (the reference loops over queries with rayon,
+        pgr-bin/src/bin/pgr-query.rs:135-165).  Defaults of the Option arguments: aln.rs:204-230."""
+        arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+        res = HpsResult()
+        self.ctx.check(lib().pgr_query_hps_batch(
+            self.ctx.handle, self._ix, n, ptrs, lens, float(penalty),
+            128 if max_count is None else max_count, 128 if max_count_query is None else max_count_query,
+            128 if max_count_target is None else max_count_target, 8 if max_aln_span is None else max_aln_span,
+            int(max_gap is not None), int(max_gap or 0), int(bool(orientated)), C.byref(res)))
+        out = _unpack_hps(res, n)
+        lib().pgr_hps_result_free(C.byref(res))
+        return out
+
+    def query_fragment_to_hps(self, seq, penalty, max_count=None, max_count_query=None, max_count_target=None,
+                              max_aln_span=None, max_gap=None, orientated=False):
+        """lib.rs:365-420 -> ext.rs:252-282: [(sid, [(score, [((qb,qe,qo),(tb,te,to))])])]
+        (target order: ascending sid; the reference's order is hash-map iteration order)"""
+        return self.query_fragments_to_hps([seq], penalty, max_count, max_count_query, max_count_target, max_aln_span,
+                                           max_gap, orientated)[0]
+
+    # ------------------------------------------------------------------ .mdb / .midx (seq_db.rs:790-810, 1291-1326)
+    def write_shmmr_map_index(self, prefix):
+        recs, keys = self._records()
+        w, k, r, ms, sk = self._spec.as_tuple()
+        with open(prefix + ".mdb", "wb") as f:
+            f.write(b"mdb")
+            f.write(np.array([w, k, r, ms, int(sk)], dtype="<u4").tobytes())
+            f.write(np.array([len(keys)], dtype="<u8").tobytes())
+            sig = np.dtype([("frg_id", "<u4"), ("sid", "<u4"), ("bgn", "<u4"), ("end", "<u4"), ("orient", "u1")])
+            for (h0, h1), (s, e) in keys.items():
+                f.write(np.array([h0, h1, e - s], dtype="<u8").tobytes())
+                blk = np.zeros(e - s, dtype=sig)
+                for name in ("frg_id", "sid", "bgn", "end"):
+                    blk[name] = recs[name][s:e]
+                blk["orient"] = recs["orient"][s:e]
+                f.write(blk.tobytes())
+        with open(prefix + ".midx", "w") as f:
+            for sid in range(self._n_seqs):
+                name, source, ln = self.seq_info[sid]
+                f.write("%d\t%d\t%s\t%s\n" % (sid, ln, name, source if source is not None else "-"))

@@ -1,0 +1,213 @@
+"""GPU parity: ShmmrToFrags index, raw query, count filters and sparse hit chaining vs the CPU oracle.
+
+Reference path: load_index_from_seq_vec (pgr-db/src/seq_db.rs:573-615), raw_query_fragment
+(seq_db.rs:1200-1228), aln::query_fragment_to_hps (aln.rs:147-242), aln::sparse_aln (aln.rs:12-142),
+through the SeqIndexDB surface of pgr-tk/src/lib.rs.
+Chaining has no expected output in the reference (aln.rs:484): parity here is oracle <-> GPU.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import seqgen
+
+pytestmark = pytest.mark.gpu
+
+COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgtN", b"TGCAtgcaN"):
+    COMP[_a] = _b
+
+
+def revcomp(s):
+    return COMP[np.frombuffer(s, dtype=np.uint8)][::-1].tobytes()
+
+
+def _oracle_hps_to_tuples(res):
+    return [(sid, [(sc, [((h[0], h[1], h[2]), (h[3], h[4], h[5])) for h in hps]) for sc, hps in chains])
+            for sid, chains in res]
+
+
+def test_seqindexdb_golden_mdb(oracle, gpu_ctx, golden_dir, tmp_path):
+    """G1 through the public API, exactly like gen_frag_db.py: load_from_fastx('test_seqs.fa') ->
+    frag_map == test_seqs_frag.mdb (820 signatures, 55 keys, global fragment ids, per-key order);
+    written .mdb/.midx round-trip to the same content."""
+    import pgrtk_amd as P
+    fa = os.path.join(golden_dir, "test_seqs.fa")
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_fastx(fa)
+    gspec, g = oracle.read_mdb(os.path.join(golden_dir, "test_seqs_frag.mdb"))
+    assert sdb.get_shmmr_spec() == (80, 56, 4, 64, False)
+    assert sdb.get_shmmr_map() == g
+    assert sorted(sdb.get_shmmr_pair_list()) == sorted((k[0], k[1], s[1], s[2], s[3], s[4]) for k, v in g.items() for s in v)
+    k0 = next(iter(g))
+    assert sdb.get_shmmr_pair_count(k0) == len(g[k0]) and sdb.get_shmmr_pair_count((1, 2)) == 0
+    sdb.write_shmmr_map_index(str(tmp_path / "out"))
+    spec2, g2 = oracle.read_mdb(str(tmp_path / "out.mdb"))
+    assert spec2 == gspec and g2 == g
+    assert os.path.getsize(str(tmp_path / "out.mdb")) == 15291
+    ref_midx = [l.split("\t")[:3] for l in open(os.path.join(golden_dir, "test_seqs_frag.midx")).read().splitlines()]
+    got_midx = [l.split("\t") for l in open(str(tmp_path / "out.midx")).read().splitlines()]
+    assert [g[:3] for g in got_midx] == ref_midx and all(g[3] == fa for g in got_midx)
+    assert len(sdb.seq_info) == 66 and sdb.seq_info[0][2] == 3385
+
+
+def _build_pair(oracle, gpu_ctx, seqs, spec_t=(80, 56, 4, 64)):
+    import pgrtk_amd as P
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_seq_list([("s%d" % i, s) for i, s in enumerate(seqs)], w=spec_t[0], k=spec_t[1], r=spec_t[2],
+                           min_span=spec_t[3])
+    oix = oracle.Index(oracle.spec(*spec_t))
+    for i, s in enumerate(seqs):
+        oix.add_seq(i, s)
+    oix.finalize()
+    return sdb, oix
+
+
+def _make_db_seqs(rng, n=12, L=120000):
+    """contigs sharing segments (so that queries hit several targets) + an exact duplicate"""
+    core = [seqgen.rnd(rng, 30000) for _ in range(4)]
+    seqs = []
+    for i in range(n):
+        parts = [seqgen.rnd(rng, int(rng.integers(1000, 20000)))]
+        for j in rng.permutation(4)[: int(rng.integers(1, 4))]:
+            c = core[j]
+            parts.append(c if rng.random() < 0.6 else revcomp(c))
+            parts.append(seqgen.rnd(rng, int(rng.integers(500, 8000))))
+        seqs.append(b"".join(parts)[:L])
+    seqs.append(seqs[0])
+    seqs.append(b"")
+    seqs.append(seqgen.rnd(rng, 100))
+    return seqs, core
+
+
+def test_index_records_vs_oracle(oracle, gpu_ctx):
+    rng = np.random.default_rng(21)
+    seqs, _ = _make_db_seqs(rng)
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    ref = oix.records()
+    import ctypes as C
+    from pgrtk_amd import _ffi
+    p, n = C.c_void_p(), C.c_uint64()
+    gpu_ctx.check(_ffi.lib().pgr_index_download(gpu_ctx.handle, sdb._ix, C.byref(p), C.byref(n)))
+    got = _ffi.take(p, int(n.value), _ffi.FRAG_REC)
+    assert len(got) == len(ref) and _ffi.lib().pgr_index_n_keys(sdb._ix) == oix.n_keys()
+    for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+        assert np.array_equal(ref[f], got[f]), f
+
+
+@pytest.mark.parametrize("variant", ["default", "max_gap", "oriented", "tight_counts", "span2"])
+def test_query_fragment_to_hps_vs_oracle(oracle, gpu_ctx, variant):
+    rng = np.random.default_rng(22)
+    seqs, core = _make_db_seqs(rng)
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    kw = dict(penalty=0.025, max_count=128, max_count_query=128, max_count_target=128, max_aln_span=8, max_gap=None,
+              orientated=False)
+    if variant == "max_gap":
+        kw["max_gap"] = 2000
+    elif variant == "oriented":
+        kw["orientated"] = True
+    elif variant == "tight_counts":
+        kw.update(max_count=1, max_count_query=1, max_count_target=1)
+    elif variant == "span2":
+        kw.update(max_aln_span=2, penalty=0.5)
+    queries = []
+    for i in range(40):
+        src = seqs[int(rng.integers(0, 12))]
+        a = int(rng.integers(0, max(1, len(src) - 12000)))
+        q = src[a:a + int(rng.integers(2000, 12000))]
+        if i % 2:
+            q = revcomp(q)
+        if i % 5 == 0:  # a few SNPs
+            qa = bytearray(q)
+            for p in rng.integers(0, len(qa), 5):
+                qa[p] = ord("ACGT"[int(rng.integers(0, 4))])
+            q = bytes(qa)
+        queries.append(q)
+    queries += [core[0] + core[1], core[2] * 3, b"", seqgen.rnd(rng, 50), seqgen.rnd(rng, 5000)]
+    got = sdb.query_fragments_to_hps(queries, kw["penalty"], kw["max_count"], kw["max_count_query"],
+                                     kw["max_count_target"], kw["max_aln_span"], kw["max_gap"], kw["orientated"])
+    n_chains = 0
+    for q, g in zip(queries, got):
+        ref = _oracle_hps_to_tuples(oix.query_fragment_to_hps(
+            q, kw["penalty"], kw["max_count"], kw["max_count_query"], kw["max_count_target"], kw["max_aln_span"],
+            kw["max_gap"], kw["orientated"]))
+        assert [t[0] for t in ref] == [t[0] for t in g]
+        for (sid, rc), (_, gc) in zip(ref, g):
+            assert len(rc) == len(gc), (variant, sid)
+            for (rs, rh), (gs, gh) in zip(rc, gc):
+                assert rs == gs, (variant, sid, rs, gs)  # f32, bit exact
+                assert rh == gh
+            n_chains += len(rc)
+    assert n_chains > 20
+    # single-query entry point == batched
+    one = sdb.query_fragment_to_hps(queries[1], kw["penalty"], kw["max_count"], kw["max_count_query"],
+                                    kw["max_count_target"], kw["max_aln_span"], kw["max_gap"], kw["orientated"])
+    assert one == got[1]
+
+
+def test_raw_query_fragment_vs_oracle(oracle, gpu_ctx):
+    rng = np.random.default_rng(23)
+    seqs, core = _make_db_seqs(rng)
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    q = core[1][2000:20000]
+    raw = sdb.query_fragment(q)
+    sh = oracle.sequence_to_shmmrs(0, q, oracle.spec())
+    qr = oracle.frag_recs(sh, 0, query_side=True)
+    assert len(raw) == len(qr) > 10
+    recs = oix.records()
+    n_sig = 0
+    for r, (key, pos, sigs) in zip(qr, raw):
+        assert key == (int(r["h0"]), int(r["h1"])) and pos == (int(r["bgn"]), int(r["end"]), int(r["orient"]))
+        m = recs[(recs["h0"] == r["h0"]) & (recs["h1"] == r["h1"])]
+        assert [(s[1], s[2], s[3], s[4]) for s in sigs] == [(int(x["sid"]), int(x["bgn"]), int(x["end"]), int(x["orient"])) for x in m]
+        n_sig += len(sigs)
+    assert n_sig > 10
+    mp = sdb.get_match_positions_with_fragment(q)
+    assert all(v == sorted(v) for v in mp.values()) and len(mp) >= 1
+
+
+def test_sparse_aln_test_hits(oracle, gpu_ctx, golden_dir):
+    """the reference's own input for sparse_aln (aln.rs:458-485: test_hits, max_span 8, penalty 0.5)"""
+    import pgrtk_amd as P
+    h = np.loadtxt(os.path.join(golden_dir, "test_hits"), dtype=np.uint32)
+    hits = [((int(r[0]), int(r[1]), int(r[2])), (int(r[3]), int(r[4]), int(r[5]))) for r in h]
+    for (span, pen, gap, ori) in [(8, 0.5, None, False), (8, 0.025, None, False), (3, 0.5, 5000, False), (8, 0.5, None, True)]:
+        got = P.sparse_aln(hits, span, pen, gap, ori, ctx=gpu_ctx)
+        ref = oracle.sparse_aln([(a[0], a[1], a[2], b[0], b[1], b[2]) for a, b in hits], span, pen, gap, ori)
+        ref = [(sc, [((x[0], x[1], x[2]), (x[3], x[4], x[5])) for x in hp]) for sc, hp in ref]
+        assert len(got) == len(ref)
+        assert got == ref
+
+
+def test_sparse_aln_duplicates_and_small(oracle, gpu_ctx):
+    """identical hit pairs share one map slot in the reference (FxHashMap keyed by value)"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(5)
+    for trial in range(20):
+        n = int(rng.integers(2, 40))
+        hits = []
+        q = 0
+        for i in range(n):
+            q += int(rng.integers(0, 300))
+            ln = int(rng.integers(50, 400))
+            t = int(rng.integers(0, 5000))
+            hits.append(((q, q + ln, int(rng.integers(0, 2))), (t, t + ln, int(rng.integers(0, 2)))))
+        hits += [hits[int(i)] for i in rng.integers(0, n, 3)]  # duplicates
+        order = rng.permutation(len(hits))
+        hits = [hits[int(i)] for i in order]
+        got = P.sparse_aln(hits, 4, 0.1, None, False, ctx=gpu_ctx)
+        ref = oracle.sparse_aln([(a[0], a[1], a[2], b[0], b[1], b[2]) for a, b in hits], 4, 0.1, None, False)
+        ref = [(sc, [((x[0], x[1], x[2]), (x[3], x[4], x[5])) for x in hp]) for sc, hp in ref]
+        assert got == ref, trial
+
+
+def test_get_shmmr_pairs_from_seq(oracle, gpu_ctx):
+    import pgrtk_amd as P
+    rng = np.random.default_rng(6)
+    s = seqgen.rnd(rng, 30000)
+    for pad in (False, True):
+        got = P.get_shmmr_pairs_from_seq(s, 80, 56, 4, 16, pad, ctx=gpu_ctx)
+        sh = oracle.sequence_to_shmmrs(0, s, oracle.spec(80, 56, 4, 16), pad)
+        ref = oracle.frag_recs(sh, 0, query_side=True)
+        assert got == [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in ref]
