@@ -59,9 +59,64 @@ __device__ __forceinline__ ContigGeom contig_geom(uint32_t len, uint32_t w, uint
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
+// level1_tile_kernel.  Measured op costs on gfx950 (tools/ubench_valu.hip): add/xor/or/and/not/lshr ~2.7
+// cycles per wave64 instruction, everything else ~4.2, and a v_cndmask_b32 that is not fed by the
+// immediately preceding v_cmp ~20.  So the kernel is written select-free:
+//   * window minima / maxima run on v_min_f64 / v_max_f64: a 56-bit hash with bit 62 set is a positive
+//     normal double whose order equals the integer order (one 4.3-cycle op instead of cmp + 2 cndmask);
+//   * validity / core / window-range tests are 16-bit per-lane masks applied with v_bfe_i32 + v_bfi_b32;
+//   * the canonical strand is chosen with a sign mask of (r0 - f0) and v_bfi_b32.
+namespace {
+
+__device__ __forceinline__ double dmin(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double dmax(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {  // (mask & a) | (~mask & b)
+    uint32_t r;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
+    return r;
+}
+// bit u of bits -> 0 / 0xffffffff.  Inline asm on purpose: written with __builtin_amdgcn_sbfe the optimiser
+// turns "value & mask" back into v_cmp + v_cndmask, the slow pattern this kernel avoids.
+__device__ __forceinline__ uint32_t bit_to_mask(uint32_t bits, uint32_t u) {
+    uint32_t r;
+    asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(r) : "v"(bits), "s"(u));
+    return r;
+}
+// acc = 2*acc + (a < b): v_cmp_lt_f64 feeds the carry-in of v_addc_co_u32 (8.4 cycles for both)
+__device__ __forceinline__ void shift_in_lt(uint32_t &acc, double a, double b) {
+    asm("v_cmp_lt_f64 vcc, %1, %2\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ double mk_double(uint32_t lo, uint32_t hi) {
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+// bits u (0..15) with lo <= 16*t + u < hi  (all in tile-extended coordinates)
+__device__ __forceinline__ uint32_t lane_range_mask(int t16, int lo, int hi) {
+    int a = lo - t16, b = hi - t16;
+    a = a < 0 ? 0 : (a > 16 ? 16 : a);
+    b = b < 0 ? 0 : (b > 16 ? 16 : b);
+    return (b > a) ? (((1u << b) - 1u) & ~((1u << a) - 1u)) : 0u;
+}
+__device__ __forceinline__ int clamp_rel(long long v) { return v < 0 ? 0 : (v > L1_EXT ? L1_EXT : (int)v); }
+
+constexpr uint32_t KEY_EXP = 0x40000000u;   // bit 62: keys are positive normal doubles
+constexpr uint32_t KEY_INF = 0x7FE00000u;   // hi word of the "not a k-mer" sentinel (finite, above every key)
+
+}  // namespace
+
+// TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
+// instantiated with constants so that every row offset, shift and mask is an immediate.
+template <int TW, int TK, bool SKETCH>
 __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
-    __shared__ uint64_t s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
-    __shared__ uint64_t s_row[L1_BLOCK];        // row min, later row max
+    __shared__ double s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
+    __shared__ double s_row[L1_BLOCK];        // row min, later row max
     __shared__ uint2 s_words[136];
     __shared__ uint32_t s_wsum[L1_BLOCK / 64];
     __shared__ unsigned long long s_base;
@@ -71,7 +126,7 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     const uint32_t tile = blockIdx.x;
     const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
     const uint32_t tile_local = tile - a.tile_first[c];
-    const uint32_t w = a.w, k = a.k;
+    const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
     const ContigGeom g = contig_geom(a.b.len[c], w, k);
     const long long c0 = (long long)tile_local * a.tc;
     long long c1 = c0 + a.tc;
@@ -91,8 +146,14 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     if (t == 0) s_skip = 0;
     __syncthreads();
 
+    // ---- per-lane masks over this lane's 16 positions (tile-extended coordinates 16t .. 16t+15)
+    const int t16 = (int)t * L1_G;
+    const uint32_t valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
+    const uint32_t core_mask = lane_range_mask(t16, clamp_rel(c0 - e0), clamp_rel(c1 - e0));
+    const uint32_t mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
+
     // ---- per-lane 96-bit windows of both planes ending at this lane's last position
-    const long long q = e0 + (long long)L1_G * t;
+    const long long q = e0 + (long long)t16;
     const long long e = q + (L1_G - 1);
     const int jl = (int)((e >> 5) - wbase);
     const uint32_t s = 31u - (uint32_t)(e & 31);
@@ -102,76 +163,91 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     const uint64_t kmask = U64MAX >> (64 - k);
     const uint64_t sketch_thr = (U64MAX >> 4) >> a.r;  // shmmrutils.rs:621
 
-    uint64_t x[L1_G];
+    double x[L1_G];  // ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
     uint32_t strand_bits = 0, emit = 0;
-    bool saw_skip = false;
+    uint32_t pal_min = 0xFFFFFFFFu;  // 0 iff some position may hold a palindromic k-mer
 #pragma unroll
     for (int u = 0; u < L1_G; ++u) {
         const uint32_t sh = (uint32_t)(L1_G - 1 - u);
         const uint64_t f0 = (((uint64_t)funnel(a2, a1, sh) << 32) | funnel(a1, a0, sh)) & kmask;
         const uint64_t f1 = (((uint64_t)funnel(b2, b1, sh) << 32) | funnel(b1, b0, sh)) & kmask;
         const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
-        const long long p = q + u;
-        const bool valid = (p >= (long long)k) && (p < g.L);
-        const bool skip = (f0 == r0) && (f1 == r1);  // shmmrutils.rs:477-480
-        uint32_t st;
-        uint64_t h;
-        const uint64_t xv = kmer_x(f0, f1, r0, r1, k, st, h);
-        x[u] = (valid && !skip) ? xv : U64MAX;
-        strand_bits |= st << u;
-        saw_skip |= (valid && skip);
-        if (a.sketch) {
-            if (valid && !skip && h < sketch_thr && p >= c0 && p < c1) emit |= 1u << u;
+        // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488); both < 2^56
+        const uint32_t rev = (uint32_t)((int32_t)((uint32_t)((r0 - f0) >> 32)) >> 31);  // 0 / ~0
+        const uint32_t m0l = bfi(rev, (uint32_t)r0, (uint32_t)f0), m0h = bfi(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
+        const uint32_t m1l = bfi(rev, (uint32_t)r1, (uint32_t)f1), m1h = bfi(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
+        const uint64_t h = u64hash_sa(((uint64_t)m0h << 32) | m0l) ^ u64hash_sa((((uint64_t)m1h << 32) | m1l) ^ 0xAD12CF59ull);
+        strand_bits = bfi(1u << u, rev, strand_bits);
+        const uint32_t inval = bit_to_mask(~valid_mask, u);
+        const uint64_t key = (h & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)KEY_EXP << 32);
+        const uint64_t iv = (uint64_t)inval << 32;  // sentinel: only the high word decides
+        x[u] = __longlong_as_double((long long)((key & ~iv) | (((uint64_t)KEY_INF << 32) & iv)));
+        if (SKETCH) {
+            // exact skip test (shmmrutils.rs:603-606) and the sketch threshold on the full 64-bit hash (:621)
+            const bool skip = (f0 == r0) && (f1 == r1);
+            if (!skip && h < sketch_thr) emit |= 1u << u;
+        } else {
+            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480) => low words equal: cheap necessary
+            // test; a hit only routes the contig to the exact serial kernel
+            const uint32_t d = (((uint32_t)f0 ^ (uint32_t)r0) | ((uint32_t)f1 ^ (uint32_t)r1)) | inval;
+            pal_min = pal_min < d ? pal_min : d;
         }
     }
 
-    if (!a.sketch) {
-        if (saw_skip) s_skip = 1;  // benign race: all writers store 1
+    if (SKETCH) {
+        emit &= valid_mask & core_mask;
+    } else {
+        if (pal_min == 0) s_skip = 1;  // benign race: all writers store 1
 
         // ---- pass 1: M[j] = min(x[j-w+1 .. j])  (van Herk / Gil-Werman with 16-wide rows in registers)
         {
-            uint64_t run = U64MAX;
+            double run = x[L1_G - 1];
+            s_suf[L1_G - 1][t] = run;
 #pragma unroll
-            for (int u = L1_G - 1; u >= 0; --u) {
-                run = umin64(run, x[u]);
+            for (int u = L1_G - 2; u >= 0; --u) {
+                run = dmin(run, x[u]);
                 s_suf[u][t] = run;
             }
             s_row[t] = run;
         }
         __syncthreads();
         const int wm1 = (int)w - 1;
-        uint64_t M[L1_G];
+        const double big = mk_double(0u, KEY_INF);
+        double M[L1_G];
         {
             const int rs_lo = (-wm1) >> 4;  // floor(-(w-1)/16)
             const int nb = -rs_lo - 1;      // whole rows between the window start row and this row (u small)
-            uint64_t acc = U64MAX, qlo = U64MAX;
+            double acc = big, qlo = big;
             for (int i = 1; i <= nb; ++i) {
                 if (i == nb) qlo = acc;
                 const int ti = (int)t - i;
-                acc = umin64(acc, s_row[ti < 0 ? 0 : ti]);
+                acc = dmin(acc, s_row[ti < 0 ? 0 : ti]);
             }
-            uint64_t pre = U64MAX;
+            double pre = big;
 #pragma unroll
             for (int u = 0; u < L1_G; ++u) {
-                pre = umin64(pre, x[u]);
+                pre = dmin(pre, x[u]);
                 const int d = u - wm1;
                 const int rs = d >> 4;
                 const int off = d & 15;
                 int ts = (int)t + rs;
                 ts = ts < 0 ? 0 : ts;
-                uint64_t m = umin64(pre, s_suf[off][ts]);
-                m = umin64(m, rs == rs_lo ? acc : qlo);
-                const long long pj = q + u;
-                M[u] = (pj >= g.jstart && pj <= g.jend) ? m : 0ull;
+                double m = dmin(pre, s_suf[off][ts]);
+                m = dmin(m, rs == rs_lo ? acc : qlo);
+                // window ends outside [jstart, jend] do not select anything: M = +0 (below every key)
+                const uint64_t mb = (uint64_t)__double_as_longlong(m);
+                const uint64_t keep = (uint64_t)(int64_t)(int32_t)bit_to_mask(mwin_mask, u);
+                M[u] = __longlong_as_double((long long)(mb & keep));
             }
         }
         __syncthreads();
         // ---- pass 2: E[i] = max(M[i .. i+w-1]); i is selected iff x[i] == E[i]
         {
-            uint64_t pm = 0;
+            double pm = M[0];
+            s_suf[0][t] = pm;
 #pragma unroll
-            for (int u = 0; u < L1_G; ++u) {
-                pm = umax64(pm, M[u]);
+            for (int u = 1; u < L1_G; ++u) {
+                pm = dmax(pm, M[u]);
                 s_suf[u][t] = pm;
             }
             s_row[t] = pm;
@@ -179,26 +255,27 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         __syncthreads();
         {
             const int re_lo = wm1 >> 4;
-            uint64_t acc = 0, qlo = 0;
+            double acc = 0.0, qlo = 0.0;
             for (int i = 1; i <= re_lo; ++i) {
                 if (i == re_lo) qlo = acc;
                 const int ti = (int)t + i;
-                acc = umax64(acc, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
+                acc = dmax(acc, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
             }
-            uint64_t sm = 0;
+            double sm = 0.0;
+            uint32_t neq = 0;  // bit u set iff E[u] < x[u]  (E <= x always: every window minimum is <= x)
 #pragma unroll
             for (int u = L1_G - 1; u >= 0; --u) {
-                sm = umax64(sm, M[u]);
+                sm = dmax(sm, M[u]);
                 const int d = u + wm1;
                 const int re = d >> 4;
                 const int off = d & 15;
                 int te = (int)t + re;
                 te = te > L1_BLOCK - 1 ? L1_BLOCK - 1 : te;
-                uint64_t ev = umax64(sm, s_suf[off][te]);
-                ev = umax64(ev, re == re_lo ? qlo : acc);
-                const long long p = q + u;
-                if (p >= c0 && p < c1 && x[u] != U64MAX && x[u] == ev) emit |= 1u << u;
+                double ev = dmax(sm, s_suf[off][te]);
+                ev = dmax(ev, re == re_lo ? qlo : acc);
+                shift_in_lt(neq, ev, x[u]);  // u runs 15..0, so bit u ends up at position u
             }
+            emit = ~neq & valid_mask & core_mask;
         }
     }
 
@@ -234,8 +311,9 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
             for (int u = 0; u < L1_G; ++u) {
                 if (emit & (1u << u)) {
                     const uint64_t p = (uint64_t)(q + u);
+                    const uint64_t kb = (uint64_t)__double_as_longlong(x[u]);
                     pgr_mm128 m;
-                    m.x = x[u];
+                    m.x = (kb << 8) | (uint64_t)k;  // drops bit 62, keeps the low 56 hash bits
                     m.y = ((uint64_t)c << 32) | (p << 1) | ((strand_bits >> u) & 1u);
                     a.out[o++] = m;
                 }
@@ -559,7 +637,14 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
 // ------------------------------------------------------------------------------------------------
 void launch_level1_tiles(hipStream_t st, const L1Args &a) {
     if (a.n_tiles == 0) return;
-    hipLaunchKernelGGL(level1_tile_kernel, dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+    if (a.sketch)
+        hipLaunchKernelGGL((level1_tile_kernel<0, 0, true>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+    else if (a.w == 80 && a.k == 56)
+        hipLaunchKernelGGL((level1_tile_kernel<80, 56, false>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+    else if (a.w == 48 && a.k == 56)
+        hipLaunchKernelGGL((level1_tile_kernel<48, 56, false>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+    else
+        hipLaunchKernelGGL((level1_tile_kernel<0, 0, false>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
 }
 void launch_level1_tails(hipStream_t st, const L1Args &a) {
     if (a.n_contigs == 0) return;

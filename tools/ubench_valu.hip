@@ -50,6 +50,11 @@ KERNEL(k_cmp_lt_u64_only, DECL64, REP8_64("v_cmp_lt_u64 vcc, %0, %1\n v_lshl_add
 KERNEL(k_cmp_eq_u64_only, DECL64, REP8_64("v_cmp_eq_u64 vcc, %0, %1\n v_lshl_add_u64 %0, %0, 1, %1") FIN64)
 KERNEL(k_cmp_lt_f64_only, DECL64, REP8_64("v_cmp_lt_f64 vcc, %0, %1\n v_lshl_add_u64 %0, %0, 1, %1") FIN64)
 KERNEL(k_cmp_eq_f64_only, DECL64, REP8_64("v_cmp_eq_f64 vcc, %0, %1\n v_lshl_add_u64 %0, %0, 1, %1") FIN64)
+KERNEL(k_cmp_cnd2, DECL32, REP8_32("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc") FIN32)
+KERNEL(k_cmp_cnd4, DECL32, REP8_32("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc\n v_cndmask_b32 %0, %0, %1, vcc\n v_cndmask_b32 %0, %1, %0, vcc") FIN32)
+KERNEL(k_cmp_sgpr_cnd2, DECL32, REP8_32("v_cmp_lt_u32 s[20:21], %0, %1\n v_cndmask_b32 %0, %0, %1, s[20:21]\n v_cndmask_b32 %0, %1, %0, s[20:21]") FIN32)
+KERNEL(k_cmp_addc, DECL32, REP8_32("v_cmp_lt_u32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc") FIN32)
+KERNEL(k_cmpf64_addc, DECL64; uint32_t acc2 = 0, REP8_64("v_cmp_lt_f64 vcc, %0, %1\n v_lshl_add_u64 %0, %0, 1, %1") asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc2) :: "vcc"); FIN64 acc ^= acc2;)
 KERNEL(k_min_u32, DECL32, REP8_32("v_min_u32 %0, %0, %1") FIN32)
 KERNEL(k_min3_u32, DECL32, REP8_32("v_min3_u32 %0, %0, %1, %1") FIN32)
 KERNEL(k_alignbit, DECL32, REP8_32("v_alignbit_b32 %0, %0, %1, 7") FIN32)
@@ -135,6 +140,8 @@ int main() {
         {"v_cmp_eq_u32 + v_addc (pair)", k_cmp_eq_u32, 8}, {"v_add_co_u32", k_add_co_only, 8},
         {"v_cmp_lt_u64 + lshl_add_u64 (pair)", k_cmp_lt_u64_only, 8}, {"v_cmp_eq_u64 + lshl_add_u64 (pair)", k_cmp_eq_u64_only, 8},
         {"v_cmp_lt_f64 + lshl_add_u64 (pair)", k_cmp_lt_f64_only, 8}, {"v_cmp_eq_f64 + lshl_add_u64 (pair)", k_cmp_eq_f64_only, 8},
+        {"cmp_u32 + 2 cndmask (vcc)", k_cmp_cnd2, 8}, {"cmp_u32 + 4 cndmask (vcc)", k_cmp_cnd4, 8},
+        {"cmp_u32->sgpr + 2 cndmask_e64", k_cmp_sgpr_cnd2, 8}, {"cmp_u32 + v_addc (bit accumulate)", k_cmp_addc, 8},
         {"v_min_u32", k_min_u32, 8}, {"v_min3_u32", k_min3_u32, 8},
         {"v_alignbit_b32", k_alignbit, 8}, {"v_bfrev_b32", k_bfrev, 8}, {"v_mul_lo_u32", k_mul_lo_u32, 8},
         {"v_mul_u32_u24", k_mul_u32_u24, 8}, {"v_mad_u32_u24", k_mad_u32_u24, 8}, {"v_add3_u32", k_add3_u32, 8},
