@@ -214,34 +214,6 @@ extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *len
 }
 
 // ------------------------------------------------------------------------------------------------
-// ordered segmented select: in/off_in -> out/off_out; returns the number of survivors
-static int run_select(pgr_ctx *ctx, SelArgs a, DevBuf &out_buf, uint64_t *d_off_out, uint64_t *n_out) {
-    hipStream_t st = ctx->stream;
-    const uint32_t n_blocks = (uint32_t)((a.n + SEL_BLOCK_ELEMS - 1) / SEL_BLOCK_ELEMS);
-    int rc;
-    if ((rc = ctx->ws_blk_cnt.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))) ||
-        (rc = ctx->ws_blk_base.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_start_rank.ensure(ctx, std::max<uint32_t>(a.n_contigs, 1) * sizeof(uint64_t))))
-        return rc;
-    uint32_t *blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
-    uint64_t *blk_base = (uint64_t *)ctx->ws_blk_base.p;
-    PGR_HIP(ctx, hipMemsetAsync(blk_cnt + n_blocks, 0, sizeof(uint32_t), st));
-    launch_select_count(st, a, blk_cnt, n_blocks);
-    const size_t tb = scan_counts_temp_bytes(n_blocks + 1);
-    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
-    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, blk_cnt, blk_base, n_blocks + 1));
-    uint64_t total = 0;
-    PGR_HIP(ctx, hipMemcpyAsync(&total, blk_base + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipStreamSynchronize(st));
-    if ((rc = out_buf.ensure(ctx, std::max<uint64_t>(total, 1) * sizeof(pgr_mm128)))) return rc;
-    launch_select_scatter(st, a, blk_base, n_blocks, (pgr_mm128 *)out_buf.p, (uint64_t *)ctx->ws_start_rank.p);
-    launch_fill_offsets(st, a.off_in, (const uint64_t *)ctx->ws_start_rank.p, a.n_contigs, blk_base + n_blocks,
-                        d_off_out);
-    PGR_HIP(ctx, hipGetLastError());
-    *n_out = total;
-    return PGR_OK;
-}
-
 static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
     if (!spec) return ctx->fail(PGR_ERR_INVALID_ARG, "null spec");
     // shmmrutils.rs:443-445 / :575-576
@@ -416,7 +388,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     }
     PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 
-    // ---- ordered per-contig level-1 lists
+    // ---- level-1 segment scan: logical (ordered) position of every segment
     const size_t tb = scan_counts_temp_bytes(n_segs + 1);
     if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
     PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, (const uint32_t *)ctx->ws_seg_cnt.p,
@@ -424,106 +396,122 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     uint64_t total1 = 0;
     PGR_HIP(ctx, hipMemcpyAsync(&total1, (uint64_t *)ctx->ws_seg_dst.p + n_segs, sizeof(uint64_t),
                                 hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipStreamSynchronize(st));
-    prof.n_level1 = total1;
-    if ((rc = ctx->ws_list_a.ensure(ctx, std::max<uint64_t>(total1, 1) * sizeof(pgr_mm128)))) return rc;
-    launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_l1.p, (const uint64_t *)ctx->ws_seg_off.p,
-                           (const uint32_t *)ctx->ws_seg_cnt.p, (const uint64_t *)ctx->ws_seg_dst.p, n_segs,
-                           (pgr_mm128 *)ctx->ws_list_a.p);
-    launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
-                          (uint64_t *)ctx->ws_off_a.p);
-
-    // ---- reduce x2 (shmmrutils.rs:533-535), min_span filter (:536-555)
-    DevBuf *cur_list = &ctx->ws_list_a, *nxt_list = &ctx->ws_list_b;
-    DevBuf *cur_off = &ctx->ws_off_a, *nxt_off = &ctx->ws_off_b;
-    uint64_t cur_n = total1;
-    std::vector<uint64_t> l1_off;  // only needed for the padding artefact
     const bool pad_fix = padding && !sketch && spec->r > 1;
+    std::vector<uint64_t> l1_off;  // only needed for the padding artefact
     if (pad_fix) {
         l1_off.resize((size_t)n + 1);
-        PGR_HIP(ctx, hipMemcpyAsync(l1_off.data(), cur_off->p, ((size_t)n + 1) * sizeof(uint64_t),
+        launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
+                              (uint64_t *)ctx->ws_off_a.p);
+        PGR_HIP(ctx, hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
                                     hipMemcpyDeviceToHost, st));
     }
-    if (!sketch && spec->r > 1) {
-        for (int round = 0; round < 2; ++round) {
-            SelArgs s;
-            s.in = (const pgr_mm128 *)cur_list->p;
-            s.n = cur_n;
-            s.off_in = (const uint64_t *)cur_off->p;
-            s.n_contigs = n;
-            s.mode = 0;
-            s.r = spec->r;
-            s.padding = padding ? 1u : 0u;
-            s.min_span = 0;
-            s.rids = nullptr;
-            uint64_t n_out = 0;
-            if ((rc = run_select(ctx, s, *nxt_list, (uint64_t *)nxt_off->p, &n_out))) return rc;
-            std::swap(cur_list, nxt_list);
-            std::swap(cur_off, nxt_off);
-            cur_n = n_out;
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    prof.n_level1 = total1;
+
+    // ---- fused reduce x2 (shmmrutils.rs:533-535) + min_span filter (:536-555) straight from the segments
+    const bool do_reduce = !sketch && spec->r > 1;
+    const uint32_t halo = do_reduce ? 2 * spec->r * spec->r : 1;
+    const uint32_t n_blocks = (uint32_t)((total1 + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
+    if ((rc = ctx->ws_blk_cnt.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_blk_base.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_blk_off.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_start_rank.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))))
+        return rc;
+    uint64_t cap2 = (uint64_t)((double)total1 * (do_reduce ? 0.20 : 0.6)) + 65536;
+    uint64_t n_final = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 3) return ctx->fail(PGR_ERR_INTERNAL, "fused select buffer kept overflowing");
+        if ((rc = ctx->ws_list_a.ensure(ctx, std::max<uint64_t>(cap2, 1) * sizeof(pgr_mm128)))) return rc;
+        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+        PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p + n_blocks, 0, sizeof(uint32_t), st));
+        FusedArgsPub fa;
+        fa.l1 = (const pgr_mm128 *)ctx->ws_l1.p;
+        fa.seg_off = (const uint64_t *)ctx->ws_seg_off.p;
+        fa.seg_cnt = (const uint32_t *)ctx->ws_seg_cnt.p;
+        fa.seg_dst = (const uint64_t *)ctx->ws_seg_dst.p;
+        fa.n_segs = n_segs;
+        fa.total = total1;
+        fa.r = spec->r;
+        fa.padding = padding ? 1u : 0u;
+        fa.min_span = spec->min_span;
+        fa.do_reduce = do_reduce ? 1u : 0u;
+        fa.halo = halo;
+        fa.out = (pgr_mm128 *)ctx->ws_list_a.p;
+        fa.cap = cap2;
+        fa.cursor = (unsigned long long *)ctx->ws_cursor.p;
+        fa.blk_off = (uint64_t *)ctx->ws_blk_off.p;
+        fa.blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
+        fa.blk_first_seg = (uint32_t *)ctx->ws_start_rank.p;
+        launch_fused_select_pub(st, fa, n_blocks);
+        unsigned long long cur[2] = {0, 0};
+        PGR_HIP(ctx, hipMemcpyAsync(cur, ctx->ws_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        PGR_HIP(ctx, hipGetLastError());
+        if (cur[1] || cur[0] > cap2) {
+            cap2 = (uint64_t)((double)cur[0] * 1.05) + 65536;
+            continue;
         }
+        n_final = cur[0];
+        break;
     }
     pgr_shmmrs *res = new pgr_shmmrs();
     res->ctx = ctx;
     res->n = n;
     res->h_off.assign((size_t)n + 1, 0);
-    {
-        SelArgs s;
-        s.in = (const pgr_mm128 *)cur_list->p;
-        s.n = cur_n;
-        s.off_in = (const uint64_t *)cur_off->p;
-        s.n_contigs = n;
-        s.mode = 1;
-        s.r = spec->r;
-        s.padding = 0;
-        s.min_span = spec->min_span;
-        s.rids = d_rids;
-        uint64_t n_out = 0;
-        if ((rc = run_select(ctx, s, *nxt_list, (uint64_t *)nxt_off->p, &n_out))) {
-            delete res;
-            return rc;
-        }
-        std::swap(cur_list, nxt_list);
-        std::swap(cur_off, nxt_off);
-        cur_n = n_out;
-    }
     auto bail = [&](int code) {
         pgr_shmmrs_destroy(res);
         return code;
     };
-    if (hipMemcpyAsync(res->h_off.data(), cur_off->p, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st) !=
+    // ---- order the block segments: scan + gather, then per-contig offsets from the (internal) rid
+    {
+        const size_t tb2 = scan_counts_temp_bytes(n_blocks + 1);
+        if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb2))) return bail(rc);
+        hipError_t e = scan_counts(st, ctx->ws_scan_tmp.p, tb2, (const uint32_t *)ctx->ws_blk_cnt.p,
+                                   (uint64_t *)ctx->ws_blk_base.p, n_blocks + 1);
+        if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e)));
+    }
+    pgr_mm128 *d_list = nullptr;  // ordered final list (before the padding artefact)
+    uint64_t *d_loff = nullptr;
+    if (!pad_fix) {  // common case: gather straight into the result buffers
+        if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(n_final, 1) * sizeof(pgr_mm128))) ||
+            (rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t))))
+            return bail(rc);
+        d_list = res->d_mm;
+        d_loff = res->d_off;
+    } else {
+        if ((rc = ctx->ws_list_b.ensure(ctx, std::max<uint64_t>(n_final, 1) * sizeof(pgr_mm128)))) return bail(rc);
+        d_list = (pgr_mm128 *)ctx->ws_list_b.p;
+        d_loff = (uint64_t *)ctx->ws_off_b.p;
+    }
+    launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_list_a.p, (const uint64_t *)ctx->ws_blk_off.p,
+                           (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list);
+    launch_offsets_by_rid(st, d_list, n_final, n, d_loff);
+    if (d_rids) launch_patch_rid(st, d_list, n_final, d_rids);
+    if (hipMemcpyAsync(res->h_off.data(), d_loff, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st) !=
             hipSuccess ||
         hipStreamSynchronize(st) != hipSuccess)
         return bail(ctx->fail(PGR_ERR_DEVICE, "D2H of the result offsets failed"));
-
-    std::vector<uint64_t> final_off = res->h_off;
-    bool need_sentinels = false;
+    res->count = n_final;
     if (pad_fix) {
+        // reference artefact: reduce_shmmr on an EMPTY list with padding emits its sentinels
+        // (shmmrutils.rs:367-380), which survive as exactly two {MAX,MAX} after the second pass + filter
+        std::vector<uint64_t> final_off((size_t)n + 1);
         uint64_t add = 0;
         for (uint32_t c = 0; c < n; ++c) {
             final_off[c] = res->h_off[c] + add;
-            if (l1_off[c + 1] == l1_off[c]) {  // empty level-1 list -> two {MAX,MAX} (reference artefact)
-                add += 2;
-                need_sentinels = true;
-            }
+            if (l1_off[c + 1] == l1_off[c]) add += 2;
         }
         final_off[n] = res->h_off[n] + add;
+        res->count = final_off[n];
+        if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(res->count, 1) * sizeof(pgr_mm128))) ||
+            (rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t))))
+            return bail(rc);
+        if (hipMemcpyAsync(res->d_off, final_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
+                           st) != hipSuccess)
+            return bail(ctx->fail(PGR_ERR_DEVICE, "H2D of the result offsets failed"));
+        launch_copy_or_sentinel(st, d_list, d_loff, res->d_off, n, res->d_mm);
+        res->h_off = final_off;
     }
-    res->count = final_off[n];
-    if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(res->count, 1) * sizeof(pgr_mm128))) ||
-        (rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t))))
-        return bail(rc);
-    if (hipMemcpyAsync(res->d_off, final_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st) !=
-        hipSuccess)
-        return bail(ctx->fail(PGR_ERR_DEVICE, "H2D of the result offsets failed"));
-    if (need_sentinels) {
-        launch_copy_or_sentinel(st, (const pgr_mm128 *)cur_list->p, (const uint64_t *)cur_off->p, res->d_off, n,
-                                res->d_mm);
-    } else if (cur_n) {
-        if (hipMemcpyAsync(res->d_mm, cur_list->p, cur_n * sizeof(pgr_mm128), hipMemcpyDeviceToDevice, st) != hipSuccess)
-            return bail(ctx->fail(PGR_ERR_DEVICE, "D2D copy of the result failed"));
-    }
-    res->h_off = final_off;
     hipEvent_t ev_end = ctx->ev_end;
     if (hipEventRecord(ev_end, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
         hipGetLastError() != hipSuccess)

@@ -2,10 +2,9 @@
 // the two hierarchical reductions (reduce_shmmr, pgr-db/src/shmmrutils.rs:359-415), the min_span
 // stencil (:536-555) and the shimmer-pair records (pgr-db/src/seq_db.rs:381-400, 1205-1217).
 //
-// Every stage is an order-preserving segmented select over a concatenated per-contig list:
-//   count kernel -> exclusive scan of per-block counts -> scatter kernel.
-// The lists are ~2.5 % of the positions, so all of this is a few % of the level-1 kernel's time; the
-// kernels are plain HBM streaming code (16 B per element, coalesced).
+// The level-1 list is ~2.5 % of the positions (16 B each).  It is read ONCE, straight from the unordered
+// per-tile segments, by fused_select_kernel (reduce x2 + min_span in LDS); only the survivors (~12 %) are
+// written, ordered by a scan + gather_segments_kernel.  Plain HBM streaming code, no MFMA.
 #include "pgr_device.h"
 #include "pgr_internal.h"
 
@@ -34,9 +33,7 @@ void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t
                        n_segs, dst);
 }
 
-// ------------------------------------------------------------------ select predicates
 namespace {
-
 __device__ __forceinline__ uint32_t find_seg(const uint64_t *__restrict__ off, uint32_t n, uint64_t i) {
     uint32_t lo = 0, hi = n;  // largest c with off[c] <= i
     while (hi - lo > 1) {
@@ -46,146 +43,7 @@ __device__ __forceinline__ uint32_t find_seg(const uint64_t *__restrict__ off, u
     }
     return lo;
 }
-
-// reduce_shmmr in closed form: element i survives iff it is a minimum (ties included) of some full
-// window of r consecutive list elements; with `padding` the list is virtually extended by r-1
-// {MAX,MAX} sentinels on both sides (shmmrutils.rs:367-380).
-__device__ __forceinline__ bool reduce_keep(const pgr_mm128 *__restrict__ in, uint64_t i, uint64_t S, uint64_t E,
-                                            uint32_t r, uint32_t padding) {
-    const uint64_t xi = in[i].x;
-    uint32_t a = 0, b = 0;
-    for (uint32_t d = 1; d < r; ++d) {
-        if (i < S + d) {
-            if (padding) a = r - 1;
-            break;
-        }
-        if (in[i - d].x >= xi) ++a;
-        else break;
-    }
-    for (uint32_t d = 1; d < r; ++d) {
-        if (i + d >= E) {
-            if (padding) b = r - 1;
-            break;
-        }
-        if (in[i + d].x >= xi) ++b;
-        else break;
-    }
-    return a + b + 1 >= r;
-}
-
-// min_span stencil on the unfiltered neighbours (shmmrutils.rs:541-553)
-__device__ __forceinline__ bool span_keep(const pgr_mm128 *__restrict__ in, uint64_t i, uint64_t S, uint64_t E,
-                                          uint32_t min_span) {
-    if (i == S || i + 1 == E) return true;
-    const pgr_mm128 p = in[i - 1], m = in[i], n = in[i + 1];
-    const uint32_t pp = (uint32_t)((p.y & 0xFFFFFFFFull) >> 1), mp = (uint32_t)((m.y & 0xFFFFFFFFull) >> 1),
-                   np = (uint32_t)((n.y & 0xFFFFFFFFull) >> 1);
-    return (uint32_t)(mp - pp) > min_span && (uint32_t)(np - mp) > min_span && p.x != m.x && m.x != n.x;
-}
-
-__device__ __forceinline__ bool sel_keep(const SelArgs &a, uint64_t i, uint32_t &cid, uint64_t &S) {
-    cid = (uint32_t)(a.in[i].y >> 32);  // internal rid = contig index until the last stage
-    S = a.off_in[cid];
-    const uint64_t E = a.off_in[cid + 1];
-    return a.mode == 0 ? reduce_keep(a.in, i, S, E, a.r, a.padding) : span_keep(a.in, i, S, E, a.min_span);
-}
-
 }  // namespace
-
-__global__ __launch_bounds__(256) void select_count_kernel(SelArgs a, uint32_t *__restrict__ blk_cnt) {
-    __shared__ uint32_t s_w[4];
-    const uint64_t base = (uint64_t)blockIdx.x * SEL_BLOCK_ELEMS + threadIdx.x * 4;
-    uint32_t cnt = 0;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint64_t i = base + j;
-        if (i < a.n) {
-            uint32_t cid;
-            uint64_t S;
-            cnt += sel_keep(a, i, cid, S) ? 1u : 0u;
-        }
-    }
-    const uint32_t incl = wave_incl_sum(cnt);
-    if ((threadIdx.x & 63) == 63) s_w[threadIdx.x >> 6] = incl;
-    __syncthreads();
-    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
-}
-
-__global__ __launch_bounds__(256) void select_scatter_kernel(SelArgs a, const uint64_t *__restrict__ blk_base,
-                                                             pgr_mm128 *__restrict__ out,
-                                                             uint64_t *__restrict__ start_rank) {
-    __shared__ uint32_t s_w[4];
-    const uint64_t base = (uint64_t)blockIdx.x * SEL_BLOCK_ELEMS + threadIdx.x * 4;
-    uint32_t flags = 0, firsts = 0;
-    uint32_t cids[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const uint64_t i = base + j;
-        cids[j] = 0;
-        if (i < a.n) {
-            uint64_t S;
-            if (sel_keep(a, i, cids[j], S)) flags |= 1u << j;
-            if (i == S) firsts |= 1u << j;
-        }
-    }
-    const uint32_t cnt = __popc(flags);
-    const uint32_t incl = wave_incl_sum(cnt);
-    const uint32_t wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 63) s_w[wv] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t i = 0; i < wv; ++i) wbase += s_w[i];
-    uint64_t o = blk_base[blockIdx.x] + wbase + (incl - cnt);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (firsts & (1u << j)) start_rank[cids[j]] = o;
-        if (flags & (1u << j)) {
-            pgr_mm128 m = a.in[base + j];
-            if (a.rids) m.y = ((uint64_t)a.rids[cids[j]] << 32) | (m.y & 0xFFFFFFFFull);
-            out[o++] = m;
-        }
-    }
-}
-
-// offsets of the selected list: contigs with an empty input list inherit the rank of the next element
-__global__ void fill_offsets_kernel(const uint64_t *__restrict__ off_in, const uint64_t *__restrict__ start_rank,
-                                    uint32_t n, const uint64_t *__restrict__ d_total, uint64_t *__restrict__ off_out) {
-    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > n) return;
-    const uint64_t total = *d_total;
-    if (c == n) {
-        off_out[n] = total;
-        return;
-    }
-    const uint64_t me = off_in[c];
-    if (off_in[c + 1] > me) {
-        off_out[c] = start_rank[c];
-        return;
-    }
-    // smallest m in (c, n] with off_in[m] > me
-    uint32_t lo = c, hi = n + 1;  // off_in[lo] <= me ; hi = n+1 means "none"
-    while (hi - lo > 1) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (off_in[mid] > me) hi = mid;
-        else lo = mid;
-    }
-    off_out[c] = (hi == n + 1) ? total : start_rank[hi - 1];
-}
-
-void launch_select_count(hipStream_t st, const SelArgs &a, uint32_t *blk_cnt, uint32_t n_blocks) {
-    if (n_blocks == 0) return;
-    hipLaunchKernelGGL(select_count_kernel, dim3(n_blocks), dim3(256), 0, st, a, blk_cnt);
-}
-void launch_select_scatter(hipStream_t st, const SelArgs &a, const uint64_t *blk_base, uint32_t n_blocks,
-                           pgr_mm128 *out, uint64_t *start_rank) {
-    if (n_blocks == 0) return;
-    hipLaunchKernelGGL(select_scatter_kernel, dim3(n_blocks), dim3(256), 0, st, a, blk_base, out, start_rank);
-}
-void launch_fill_offsets(hipStream_t st, const uint64_t *off_in, const uint64_t *start_rank, uint32_t n_contigs,
-                         const uint64_t *d_total, uint64_t *off_out) {
-    hipLaunchKernelGGL(fill_offsets_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, off_in, start_rank,
-                       n_contigs, d_total, off_out);
-}
 
 // ------------------------------------------------------------------ shimmer-pair records
 // off: list offsets per contig; rec_off: record offsets per contig (count-1 per non-empty contig)
@@ -259,4 +117,267 @@ void launch_copy_or_sentinel(hipStream_t st, const pgr_mm128 *in, const uint64_t
     if (n == 0) return;
     hipLaunchKernelGGL(copy_or_sentinel_kernel, dim3(n), dim3(256), 0, st, in, off_in, off_out, n, out);
 }
+}  // namespace pgr
+
+// ================================================================================================
+// Fused list stage: reduce_shmmr x2 + min_span stencil in ONE pass over the level-1 segments.
+//
+// A workgroup owns FUSED_B consecutive elements of the (logically ordered) level-1 stream plus a halo of
+// H = 2 r^2 elements on each side.  H bounds the dependency radius of the final decision:
+//   - consecutive survivors of a reduction are at most r list elements apart (every full r-window
+//     contains its own minimum), so the r-1 reduced neighbours an element needs for the second
+//     reduction lie within r(r-1) level-1 elements, and the previous / next twice-reduced element the
+//     min_span stencil needs lies within r^2; each of those needs its own +-(r-1) context.
+// The stream is read straight from the unordered per-tile segments (seg_off / seg_cnt / seg_dst = scan of
+// seg_cnt): no ordered copy of the level-1 list is ever materialised.  Survivors of the core range go to a
+// cursor-allocated block segment; a scan + gather_segments_kernel orders them afterwards.
+namespace pgr {
+
+namespace {
+
+constexpr int FUSED_T = 256;
+constexpr int FUSED_B = 1024;
+constexpr int FUSED_EMAX = FUSED_B + 2 * 288;  // r = 12
+
+struct FusedLds {
+    uint64_t x[FUSED_EMAX];
+    uint64_t y[FUSED_EMAX];
+    uint16_t s1[FUSED_EMAX];
+    uint16_t s2[FUSED_EMAX];
+    uint32_t wsum[FUSED_T / 64];
+    unsigned long long base;
+};
+
+// ordered compaction helper: thread t owns items [t*C, (t+1)*C); returns exclusive rank of its first item,
+// total through *total.  All threads must call.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t cnt, uint32_t *wsum, uint32_t *total) {
+    const uint32_t incl = wave_incl_sum(cnt);
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __syncthreads();  // wsum reuse
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < FUSED_T / 64; ++i) {
+        const uint32_t v = wsum[i];
+        if (i < (int)wv) base += v;
+        tot += v;
+    }
+    *total = tot;
+    return base + incl - cnt;
+}
+
+// reduce predicate on an indexed LDS list: list[k] -> element index e; neighbours must share the contig id
+__device__ __forceinline__ bool reduce_keep_lds(const FusedLds &L, const uint16_t *list, int n, int k, uint32_t r,
+                                                uint32_t padding, bool lo_is_start, bool hi_is_end) {
+    const int e = list ? list[k] : k;
+    const uint64_t xi = L.x[e];
+    const uint32_t cid = (uint32_t)(L.y[e] >> 32);
+    uint32_t a = 0, b = 0;
+    for (uint32_t d = 1; d < r; ++d) {
+        const int kk = k - (int)d;
+        bool boundary = kk < 0;
+        int ee = 0;
+        if (!boundary) {
+            ee = list ? list[kk] : kk;
+            boundary = (uint32_t)(L.y[ee] >> 32) != cid;
+        }
+        if (boundary) {
+            // a true list / contig boundary: with padding the virtual sentinels are >= everything.
+            // (kk < 0 with !lo_is_start is a loading edge: only reached by far-halo elements)
+            if (padding && (kk >= 0 || lo_is_start)) a = r - 1;
+            break;
+        }
+        if (L.x[ee] >= xi) ++a;
+        else break;
+    }
+    for (uint32_t d = 1; d < r; ++d) {
+        const int kk = k + (int)d;
+        bool boundary = kk >= n;
+        int ee = 0;
+        if (!boundary) {
+            ee = list ? list[kk] : kk;
+            boundary = (uint32_t)(L.y[ee] >> 32) != cid;
+        }
+        if (boundary) {
+            if (padding && (kk < n || hi_is_end)) b = r - 1;
+            break;
+        }
+        if (L.x[ee] >= xi) ++b;
+        else break;
+    }
+    return a + b + 1 >= r;
+}
+
+}  // namespace
+
+// FusedArgsPub (pgr_internal.h): l1 = unordered level-1 segments; seg_dst = exclusive scan of seg_cnt
+// ([n_segs+1]); out = cursor-allocated block segments; cursor[0] allocated, [1] overflow.
+using FusedArgs = FusedArgsPub;
+
+__global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
+    __shared__ FusedLds L;
+    const uint32_t t = threadIdx.x;
+    const uint64_t core_lo = (uint64_t)blockIdx.x * FUSED_B;
+    uint64_t core_hi = core_lo + FUSED_B;
+    if (core_hi > a.total) core_hi = a.total;
+    const uint64_t lo = core_lo >= a.halo ? core_lo - a.halo : 0;
+    uint64_t hi = core_hi + a.halo;
+    if (hi > a.total) hi = a.total;
+    const int ne = (int)(hi - lo);
+    const bool lo_is_start = (lo == 0), hi_is_end = (hi == a.total);
+
+    // ---- stream the segments of [lo, hi) into LDS; the segment holding `lo` was located by
+    // block_first_seg_kernel (a 22-step dependent binary search per workgroup here would dominate)
+    {
+        const uint32_t wv = t >> 6, lane = t & 63;
+        const uint32_t first_seg = a.blk_first_seg[blockIdx.x];
+        for (uint32_t s = first_seg + wv; s < a.n_segs; s += FUSED_T / 64) {
+            const uint64_t d0 = a.seg_dst[s];
+            if (d0 >= hi) break;
+            const uint32_t cnt = a.seg_cnt[s];
+            if (cnt == 0) continue;
+            const uint64_t b0 = d0 > lo ? d0 : lo;                  // logical range of this segment inside [lo, hi)
+            const uint64_t b1 = (d0 + cnt) < hi ? (d0 + cnt) : hi;
+            const pgr_mm128 *src = a.l1 + a.seg_off[s] + (b0 - d0);
+            const int dst = (int)(b0 - lo);
+            for (int i = lane; i < (int)(b1 - b0); i += 64) {
+                const pgr_mm128 m = src[i];
+                L.x[dst + i] = m.x;
+                L.y[dst + i] = m.y;
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- reduce x2 (shmmrutils.rs:533-535) on index lists, then the min_span stencil (:536-555)
+    const uint16_t *cur = nullptr;  // nullptr = identity list over [0, ne)
+    int n_cur = ne;
+    if (a.do_reduce) {
+        for (int round = 0; round < 2; ++round) {
+            uint16_t *dstl = round == 0 ? L.s1 : L.s2;
+            const int C = (n_cur + FUSED_T - 1) / FUSED_T;
+            const int k0 = (int)t * C;
+            uint32_t flags = 0, cnt = 0;  // C <= 7
+            for (int j = 0; j < C; ++j) {
+                const int k = k0 + j;
+                if (k < n_cur && reduce_keep_lds(L, cur, n_cur, k, a.r, a.padding, lo_is_start, hi_is_end)) {
+                    flags |= 1u << j;
+                    ++cnt;
+                }
+            }
+            uint32_t tot;
+            uint32_t o = block_excl_scan(cnt, L.wsum, &tot);
+            for (int j = 0; j < C; ++j)
+                if (flags & (1u << j)) dstl[o++] = (uint16_t)(cur ? cur[k0 + j] : (k0 + j));
+            __syncthreads();
+            cur = dstl;
+            n_cur = (int)tot;
+        }
+    }
+    // span filter over `cur`; survivors that are core elements are emitted in order
+    const int c_lo = (int)(core_lo - lo), c_hi = (int)(core_hi - lo);
+    uint32_t flags = 0, cnt = 0;
+    const int C = (n_cur + FUSED_T - 1) / FUSED_T;
+    const int k0 = (int)t * C;
+    for (int j = 0; j < C; ++j) {
+        const int k = k0 + j;
+        if (k >= n_cur) break;
+        const int e = cur ? cur[k] : k;
+        if (e < c_lo || e >= c_hi) continue;
+        const uint64_t ye = L.y[e];
+        const uint32_t cid = (uint32_t)(ye >> 32);
+        bool keep = true;
+        const bool has_p = k > 0, has_n = k + 1 < n_cur;
+        const int ep = has_p ? (cur ? cur[k - 1] : k - 1) : 0;
+        const int en = has_n ? (cur ? cur[k + 1] : k + 1) : 0;
+        const bool first = !has_p || (uint32_t)(L.y[ep] >> 32) != cid;
+        const bool last = !has_n || (uint32_t)(L.y[en] >> 32) != cid;
+        if (!first && !last) {
+            const uint32_t pp = (uint32_t)((L.y[ep] & 0xFFFFFFFFull) >> 1), mp = (uint32_t)((ye & 0xFFFFFFFFull) >> 1),
+                           np = (uint32_t)((L.y[en] & 0xFFFFFFFFull) >> 1);
+            keep = (uint32_t)(mp - pp) > a.min_span && (uint32_t)(np - mp) > a.min_span && L.x[ep] != L.x[e] &&
+                   L.x[e] != L.x[en];
+        }
+        if (keep) {
+            flags |= 1u << j;
+            ++cnt;
+        }
+    }
+    uint32_t tot;
+    const uint32_t o0 = block_excl_scan(cnt, L.wsum, &tot);
+    if (t == 0) {
+        unsigned long long base = 0;
+        if (tot) base = atomicAdd(a.cursor, (unsigned long long)tot);
+        L.base = base;
+        a.blk_off[blockIdx.x] = base;
+        a.blk_cnt[blockIdx.x] = (base + tot <= a.cap) ? tot : 0u;
+        if (base + tot > a.cap) atomicExch(a.cursor + 1, 1ull);
+    }
+    __syncthreads();
+    const unsigned long long base = L.base;
+    if (cnt && base + tot <= a.cap) {
+        uint64_t o = base + o0;
+        for (int j = 0; j < C; ++j)
+            if (flags & (1u << j)) {
+                const int e = cur ? cur[k0 + j] : (k0 + j);
+                pgr_mm128 m;
+                m.x = L.x[e];
+                m.y = L.y[e];
+                a.out[o++] = m;
+            }
+    }
+}
+
+// first segment of every fused workgroup: largest s with seg_dst[s] <= max(0, b*FUSED_B - halo)
+__global__ void block_first_seg_kernel(const uint64_t *__restrict__ seg_dst, uint32_t n_segs, uint32_t n_blocks,
+                                       uint32_t halo, uint32_t *__restrict__ blk_first_seg) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= n_blocks) return;
+    const uint64_t core_lo = (uint64_t)b * FUSED_B;
+    const uint64_t lo = core_lo >= halo ? core_lo - halo : 0;
+    uint32_t s_lo = 0, s_hi = n_segs;
+    while (s_hi - s_lo > 1) {
+        const uint32_t mid = (s_lo + s_hi) >> 1;
+        if (seg_dst[mid] <= lo) s_lo = mid;
+        else s_hi = mid;
+    }
+    blk_first_seg[b] = s_lo;
+}
+
+// offsets of the final ordered list: off[c] = first element whose (internal) rid >= c
+__global__ void offsets_by_rid_kernel(const pgr_mm128 *__restrict__ mm, uint64_t n, uint32_t n_contigs,
+                                      uint64_t *__restrict__ off) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n_contigs) return;
+    uint64_t lo = 0, hi = n;  // first j with rid(j) >= c
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if ((uint32_t)(mm[mid].y >> 32) < c) lo = mid + 1;
+        else hi = mid;
+    }
+    off[c] = lo;
+}
+
+__global__ void patch_rid_kernel(pgr_mm128 *__restrict__ mm, uint64_t n, const uint32_t *__restrict__ rids) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t y = mm[i].y;
+    mm[i].y = ((uint64_t)rids[(uint32_t)(y >> 32)] << 32) | (y & 0xFFFFFFFFull);
+}
+
+void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks) {
+    if (n_blocks == 0) return;
+    hipLaunchKernelGGL(block_first_seg_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, a.seg_dst, a.n_segs,
+                       n_blocks, a.halo, a.blk_first_seg);
+    hipLaunchKernelGGL(fused_select_kernel, dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+}
+void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off) {
+    hipLaunchKernelGGL(offsets_by_rid_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, mm, n, n_contigs, off);
+}
+void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, uint64_t n, const uint32_t *rids) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(patch_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, mm, n, rids);
+}
+
 }  // namespace pgr

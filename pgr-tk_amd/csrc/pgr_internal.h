@@ -88,23 +88,6 @@ void launch_level1_serial(hipStream_t st, const L1Args &a, const uint32_t *d_lis
 // level2.hip
 void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,
                             const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst);
-struct SelArgs {
-    const pgr_mm128 *in;
-    uint64_t n;
-    const uint64_t *off_in;  // [n_contigs+1]
-    uint32_t n_contigs;
-    int mode;                // 0 reduce (window r), 1 min_span stencil
-    uint32_t r, padding, min_span;
-    const uint32_t *rids;    // patch y>>32 on output when non-null
-};
-// pass 1: per-block counts
-void launch_select_count(hipStream_t st, const SelArgs &a, uint32_t *blk_cnt, uint32_t n_blocks);
-// pass 2: scatter; blk_base = exclusive scan of blk_cnt
-void launch_select_scatter(hipStream_t st, const SelArgs &a, const uint64_t *blk_base, uint32_t n_blocks,
-                           pgr_mm128 *out, uint64_t *start_rank /*[n_contigs]*/);
-void launch_fill_offsets(hipStream_t st, const uint64_t *off_in, const uint64_t *start_rank, uint32_t n_contigs,
-                         const uint64_t *d_total, uint64_t *off_out);
-constexpr uint32_t SEL_BLOCK_ELEMS = 1024;
 void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, const uint64_t *rec_off,
                       uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, pgr_frag_rec *out);
 
@@ -112,6 +95,28 @@ void launch_contig_offsets(hipStream_t st, const uint64_t *seg_dst, const uint32
                            uint32_t n_segs, uint64_t *off);
 void launch_copy_or_sentinel(hipStream_t st, const pgr_mm128 *in, const uint64_t *off_in, const uint64_t *off_out,
                              uint32_t n, pgr_mm128 *out);
+
+// fused reduce x2 + min_span over the unordered level-1 segments (level2.hip)
+
+constexpr uint32_t FUSED_BLOCK_ELEMS = 1024;
+struct FusedArgsPub {
+    const pgr_mm128 *l1;
+    const uint64_t *seg_off;
+    const uint32_t *seg_cnt;
+    const uint64_t *seg_dst;
+    uint32_t n_segs;
+    uint64_t total;
+    uint32_t r, padding, min_span, do_reduce, halo;
+    pgr_mm128 *out;
+    uint64_t cap;
+    unsigned long long *cursor;
+    uint64_t *blk_off;
+    uint32_t *blk_cnt;
+    uint32_t *blk_first_seg;  // [n_blocks] scratch
+};
+void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);
+void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off);
+void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, uint64_t n, const uint32_t *rids);
 
 // scan.hip (rocPRIM device scans / sorts: plain library primitives, not the hot path)
 // exclusive scan of n+1 u32 counts (in[n] must be 0) into n+1 u64 offsets: out[n] = total
