@@ -259,9 +259,12 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint32_t n_tiles = (uint32_t)n_tiles64;
     const uint32_t n_segs = n_tiles + n;
 
-    // capacity of the cursor-allocated region: expected density 2/(w+1) (sketch: 2^-(4+r)) + slack
+    // level-1 buffer: one fixed slot per tile (2x the expected count: density 2/(w+1), sketch 2^-(4+r)) and
+    // a cursor-allocated overflow region for dense tiles and the per-contig tails
     const double dens = sketch ? 1.0 / (double)(1ull << (4 + spec->r)) : 2.0 / (double)(spec->w + 1);
-    uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 1.25) + 65536 + 4ull * n;
+    const uint32_t slot = std::min<uint32_t>(tc, (((uint32_t)((double)tc * dens * 2.0) + 64 + 63) / 64) * 64);
+    const uint64_t slots_total = (uint64_t)n_tiles * slot;
+    uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 300ull * n;
     auto serial_cap = [&](uint32_t c, bool full) -> uint64_t {
         const uint64_t L = b->h_len[c];
         return full ? L : std::min<uint64_t>(L, L / 4 + 4096);
@@ -314,10 +317,12 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (attempt > 4) return ctx->fail(PGR_ERR_INTERNAL, "level-1 buffer kept overflowing");
         uint64_t serial_total = 0;
         for (uint32_t c : serial) serial_total += serial_cap(c, false);
-        if ((rc = ctx->ws_l1.ensure(ctx, (cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return rc;
+        if ((rc = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return rc;
         a.out = (pgr_mm128 *)ctx->ws_l1.p;
+        a.slot = slot;
+        a.ovf_base = slots_total;
         a.cap = cap_par;
-        serial_base = cap_par;
+        serial_base = slots_total + cap_par;
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), st));
         PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
@@ -417,11 +422,15 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         (rc = ctx->ws_blk_off.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_start_rank.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))))
         return rc;
-    uint64_t cap2 = (uint64_t)((double)total1 * (do_reduce ? 0.20 : 0.6)) + 65536;
+    // fixed output slot per fused workgroup (expected survivors: ~12 % after two reductions + min_span), plus
+    // a cursor-allocated overflow region
+    const uint32_t slot2 = do_reduce ? 256u : FUSED_BLOCK_ELEMS;
+    const uint64_t slots2 = (uint64_t)n_blocks * slot2;
+    uint64_t cap2 = (uint64_t)((double)total1 * 0.01) + 65536;
     uint64_t n_final = 0;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 3) return ctx->fail(PGR_ERR_INTERNAL, "fused select buffer kept overflowing");
-        if ((rc = ctx->ws_list_a.ensure(ctx, std::max<uint64_t>(cap2, 1) * sizeof(pgr_mm128)))) return rc;
+        if ((rc = ctx->ws_list_a.ensure(ctx, (slots2 + cap2 + 1) * sizeof(pgr_mm128)))) return rc;
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
         PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p + n_blocks, 0, sizeof(uint32_t), st));
         FusedArgsPub fa;
@@ -437,6 +446,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         fa.do_reduce = do_reduce ? 1u : 0u;
         fa.halo = halo;
         fa.out = (pgr_mm128 *)ctx->ws_list_a.p;
+        fa.slot = slot2;
+        fa.ovf_base = slots2;
         fa.cap = cap2;
         fa.cursor = (unsigned long long *)ctx->ws_cursor.p;
         fa.blk_off = (uint64_t *)ctx->ws_blk_off.p;
@@ -451,7 +462,6 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
             cap2 = (uint64_t)((double)cur[0] * 1.05) + 65536;
             continue;
         }
-        n_final = cur[0];
         break;
     }
     pgr_shmmrs *res = new pgr_shmmrs();
@@ -469,6 +479,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         hipError_t e = scan_counts(st, ctx->ws_scan_tmp.p, tb2, (const uint32_t *)ctx->ws_blk_cnt.p,
                                    (uint64_t *)ctx->ws_blk_base.p, n_blocks + 1);
         if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e)));
+        if (hipMemcpyAsync(&n_final, (uint64_t *)ctx->ws_blk_base.p + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost,
+                           st) != hipSuccess ||
+            hipStreamSynchronize(st) != hipSuccess)
+            return bail(ctx->fail(PGR_ERR_DEVICE, "D2H of the survivor count failed"));
     }
     pgr_mm128 *d_list = nullptr;  // ordered final list (before the padding artefact)
     uint64_t *d_loff = nullptr;

@@ -17,6 +17,10 @@
 #include "pgr_device.h"
 #include "pgr_internal.h"
 
+#ifndef PGR_ABLATE
+#define PGR_ABLATE 0  // timing experiments only (1: no window passes, 2: no u64hash); results are wrong when set
+#endif
+
 namespace pgr {
 
 namespace {
@@ -111,49 +115,15 @@ constexpr uint32_t KEY_INF = 0x7FE00000u;   // hi word of the "not a k-mer" sent
 
 }  // namespace
 
-// TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
-// instantiated with constants so that every row offset, shift and mask is an immediate.
-template <int TW, int TK, bool SKETCH>
-__global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
-    __shared__ double s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
-    __shared__ double s_row[L1_BLOCK];        // row min, later row max
-    __shared__ uint2 s_words[136];
-    __shared__ uint32_t s_wsum[L1_BLOCK / 64];
-    __shared__ unsigned long long s_base;
-    __shared__ int s_skip;
-
-    const uint32_t t = threadIdx.x;
-    const uint32_t tile = blockIdx.x;
-    const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
-    const uint32_t tile_local = tile - a.tile_first[c];
-    const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
-    const ContigGeom g = contig_geom(a.b.len[c], w, k);
-    const long long c0 = (long long)tile_local * a.tc;
-    long long c1 = c0 + a.tc;
-    if (c1 > g.L) c1 = g.L;
-    const long long e0 = c0 - (long long)(w - 1);  // first extended position (may be negative)
-
-    // ---- stage the 2-bit planes of the tile (+ k-mer look-back) in LDS
-    const long long wbase = (e0 - 96) >> 5;  // floor
-    const long long nwords = (g.L + 31) >> 5;
-    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
-    if (t < 136) {
-        const long long wi = wbase + t;
-        uint2 v = make_uint2(0u, 0u);
-        if (wi >= 0 && wi < nwords) v = planes[wi];
-        s_words[t] = v;
-    }
-    if (t == 0) s_skip = 0;
-    __syncthreads();
-
-    // ---- per-lane masks over this lane's 16 positions (tile-extended coordinates 16t .. 16t+15)
-    const int t16 = (int)t * L1_G;
-    const uint32_t valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
-    const uint32_t core_mask = lane_range_mask(t16, clamp_rel(c0 - e0), clamp_rel(c1 - e0));
-    const uint32_t mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
-
+// Hash and select this lane's 16 positions.  MASKED = false: every position of the wave is a real k-mer
+// and every window end is inside [jstart, jend] (interior of a contig) -> no masking instructions.
+template <int TW, int TK, bool SKETCH, bool MASKED>
+__device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_t k, uint32_t t, long long q,
+                                            long long wbase, const uint2 *s_words, double (*s_suf)[L1_BLOCK],
+                                            double *s_row, int *s_skip, uint32_t valid_mask, uint32_t mwin_mask,
+                                            uint32_t core_mask, double (&x)[L1_G], uint32_t &strand_bits,
+                                            uint32_t &emit) {
     // ---- per-lane 96-bit windows of both planes ending at this lane's last position
-    const long long q = e0 + (long long)t16;
     const long long e = q + (L1_G - 1);
     const int jl = (int)((e >> 5) - wbase);
     const uint32_t s = 31u - (uint32_t)(e & 31);
@@ -162,26 +132,52 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     const uint32_t b0 = funnel(W1.y, W0.y, s), b1 = funnel(W2.y, W1.y, s), b2 = funnel(W3.y, W2.y, s);
     const uint64_t kmask = U64MAX >> (64 - k);
     const uint64_t sketch_thr = (U64MAX >> 4) >> a.r;  // shmmrutils.rs:621
+    // bit-reversed complement windows: Rv bit i = ~base[e - 95 + i]; with a compile-time k the reverse-
+    // complement planes (shmmrutils.rs:469-475) are static bit fields of Rv, like the forward planes of A
+    const uint32_t ra0 = __brev(~a2), ra1 = __brev(~a1), ra2 = __brev(~a0);
+    const uint32_t rb0 = __brev(~b2), rb1 = __brev(~b1), rb2 = __brev(~b0);
 
-    double x[L1_G];  // ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
-    uint32_t strand_bits = 0, emit = 0;
+    // x[]: ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
     uint32_t pal_min = 0xFFFFFFFFu;  // 0 iff some position may hold a palindromic k-mer
 #pragma unroll
     for (int u = 0; u < L1_G; ++u) {
         const uint32_t sh = (uint32_t)(L1_G - 1 - u);
         const uint64_t f0 = (((uint64_t)funnel(a2, a1, sh) << 32) | funnel(a1, a0, sh)) & kmask;
         const uint64_t f1 = (((uint64_t)funnel(b2, b1, sh) << 32) | funnel(b1, b0, sh)) & kmask;
-        const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
+        uint64_t r0, r1;
+        if (TK) {
+            constexpr int rsh0 = 81 - (TK ? TK : 1);  // r = (Rv >> (81 + u - k)) & kmask
+            const int rsh = rsh0 + u;
+            if (rsh < 32) {
+                r0 = (((uint64_t)funnel(ra2, ra1, rsh) << 32) | funnel(ra1, ra0, rsh)) & kmask;
+                r1 = (((uint64_t)funnel(rb2, rb1, rsh) << 32) | funnel(rb1, rb0, rsh)) & kmask;
+            } else {
+                r0 = (((uint64_t)(ra2 >> (rsh - 32)) << 32) | funnel(ra2, ra1, rsh - 32)) & kmask;
+                r1 = (((uint64_t)(rb2 >> (rsh - 32)) << 32) | funnel(rb2, rb1, rsh - 32)) & kmask;
+            }
+        } else {
+            r0 = rc_plane(f0, k);
+            r1 = rc_plane(f1, k);
+        }
         // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488); both < 2^56
         const uint32_t rev = (uint32_t)((int32_t)((uint32_t)((r0 - f0) >> 32)) >> 31);  // 0 / ~0
         const uint32_t m0l = bfi(rev, (uint32_t)r0, (uint32_t)f0), m0h = bfi(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
         const uint32_t m1l = bfi(rev, (uint32_t)r1, (uint32_t)f1), m1h = bfi(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
+#if PGR_ABLATE == 2
+        const uint64_t h = (((uint64_t)m0h << 32) | m0l) * 0x9E3779B97F4A7C15ull ^ ((((uint64_t)m1h << 32) | m1l) << 7);
+#else
         const uint64_t h = u64hash_sa(((uint64_t)m0h << 32) | m0l) ^ u64hash_sa((((uint64_t)m1h << 32) | m1l) ^ 0xAD12CF59ull);
+#endif
         strand_bits = bfi(1u << u, rev, strand_bits);
-        const uint32_t inval = bit_to_mask(~valid_mask, u);
         const uint64_t key = (h & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)KEY_EXP << 32);
-        const uint64_t iv = (uint64_t)inval << 32;  // sentinel: only the high word decides
-        x[u] = __longlong_as_double((long long)((key & ~iv) | (((uint64_t)KEY_INF << 32) & iv)));
+        uint32_t inval = 0;
+        if (MASKED) {
+            inval = bit_to_mask(~valid_mask, u);
+            const uint64_t iv = (uint64_t)inval << 32;  // sentinel: only the high word decides
+            x[u] = __longlong_as_double((long long)((key & ~iv) | (((uint64_t)KEY_INF << 32) & iv)));
+        } else {
+            x[u] = __longlong_as_double((long long)key);
+        }
         if (SKETCH) {
             // exact skip test (shmmrutils.rs:603-606) and the sketch threshold on the full 64-bit hash (:621)
             const bool skip = (f0 == r0) && (f1 == r1);
@@ -194,10 +190,17 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         }
     }
 
+#if PGR_ABLATE == 1
+    if (true) {
+#pragma unroll
+        for (int u = 0; u < L1_G; ++u) emit |= (((uint32_t)__double_as_longlong(x[u]) & 0x3Fu) == 0u) ? (1u << u) : 0u;
+        emit &= valid_mask & core_mask;
+    } else
+#endif
     if (SKETCH) {
         emit &= valid_mask & core_mask;
     } else {
-        if (pal_min == 0) s_skip = 1;  // benign race: all writers store 1
+        if (pal_min == 0) *s_skip = 1;  // benign race: all writers store 1
 
         // ---- pass 1: M[j] = min(x[j-w+1 .. j])  (van Herk / Gil-Werman with 16-wide rows in registers)
         {
@@ -235,9 +238,13 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
                 double m = dmin(pre, s_suf[off][ts]);
                 m = dmin(m, rs == rs_lo ? acc : qlo);
                 // window ends outside [jstart, jend] do not select anything: M = +0 (below every key)
-                const uint64_t mb = (uint64_t)__double_as_longlong(m);
-                const uint64_t keep = (uint64_t)(int64_t)(int32_t)bit_to_mask(mwin_mask, u);
-                M[u] = __longlong_as_double((long long)(mb & keep));
+                if (MASKED) {
+                    const uint64_t mb = (uint64_t)__double_as_longlong(m);
+                    const uint64_t keep = (uint64_t)(int64_t)(int32_t)bit_to_mask(mwin_mask, u);
+                    M[u] = __longlong_as_double((long long)(mb & keep));
+                } else {
+                    M[u] = m;
+                }
             }
         }
         __syncthreads();
@@ -279,6 +286,62 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         }
     }
 
+}
+
+// TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
+// instantiated with constants so that every row offset, shift and mask is an immediate.
+template <int TW, int TK, bool SKETCH>
+__global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
+    __shared__ double s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
+    __shared__ double s_row[L1_BLOCK];        // row min, later row max
+    __shared__ uint2 s_words[136];
+    __shared__ uint32_t s_wsum[L1_BLOCK / 64];
+    __shared__ unsigned long long s_base;
+    __shared__ int s_skip;
+
+    const uint32_t t = threadIdx.x;
+    const uint32_t tile = blockIdx.x;
+    const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
+    const uint32_t tile_local = tile - a.tile_first[c];
+    const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
+    const ContigGeom g = contig_geom(a.b.len[c], w, k);
+    const long long c0 = (long long)tile_local * a.tc;
+    long long c1 = c0 + a.tc;
+    if (c1 > g.L) c1 = g.L;
+    const long long e0 = c0 - (long long)(w - 1);  // first extended position (may be negative)
+
+    // ---- stage the 2-bit planes of the tile (+ k-mer look-back) in LDS
+    const long long wbase = (e0 - 96) >> 5;  // floor
+    const long long nwords = (g.L + 31) >> 5;
+    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
+    if (t < 136) {
+        const long long wi = wbase + t;
+        uint2 v = make_uint2(0u, 0u);
+        if (wi >= 0 && wi < nwords) v = planes[wi];
+        s_words[t] = v;
+    }
+    if (t == 0) s_skip = 0;
+    __syncthreads();
+
+    // ---- per-lane masks over this lane's 16 positions (tile-extended coordinates 16t .. 16t+15)
+    const int t16 = (int)t * L1_G;
+    const uint32_t valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
+    const uint32_t core_mask = lane_range_mask(t16, clamp_rel(c0 - e0), clamp_rel(c1 - e0));
+    const uint32_t mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
+
+    // ---- hash + select.  Waves whose 64x16 positions are all inside the contig and inside the window-end
+    // range skip every masking instruction (uniform branch; both variants hit the same barriers).
+    double x[L1_G];
+    uint32_t strand_bits = 0, emit = 0;
+    const long long q = e0 + (long long)t16;
+    const bool wave_full = __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
+    if (wave_full)
+        tile_select<TW, TK, SKETCH, false>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
+                                          core_mask, x, strand_bits, emit);
+    else
+        tile_select<TW, TK, SKETCH, true>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
+                                         core_mask, x, strand_bits, emit);
+
     // ---- ordered compaction: block scan of per-lane counts, one cursor bump per tile
     const uint32_t cnt = __popc(emit);
     const uint32_t incl = wave_incl_sum(cnt);
@@ -293,19 +356,27 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         total += v;
     }
     if (t == 0) {
-        unsigned long long base = 0;
-        if (total) base = atomicAdd(a.cursor, (unsigned long long)total);
-        s_base = base;
+        // Every tile owns a fixed slot of a.slot elements (no atomics: one shared cursor saturates at ~88
+        // same-address atomics/us, which would cap the kernel at ~29 ms for 2.5 M tiles).  Only tiles denser
+        // than the slot (low-complexity sequence: ties emit every position) allocate from the overflow cursor.
+        unsigned long long base = (unsigned long long)tile * a.slot;
+        bool ok = true;
+        if (total > a.slot) {
+            const unsigned long long ob = atomicAdd(a.cursor, (unsigned long long)total);
+            base = a.ovf_base + ob;
+            ok = ob + total <= a.cap;
+            if (!ok) atomicExch(a.cursor + 1, 1ull);
+        }
+        s_base = ok ? base : ~0ull;
         const uint32_t sidx = tile + c;  // one tail segment per preceding contig
         a.seg_off[sidx] = base;
-        a.seg_cnt[sidx] = (base + total <= a.cap) ? total : 0u;
-        if (base + total > a.cap) atomicExch(a.cursor + 1, 1ull);
+        a.seg_cnt[sidx] = ok ? total : 0u;
         if (s_skip) atomicOr(a.contig_flags + c, 1u);
     }
     __syncthreads();
     if (cnt) {
         const unsigned long long base = s_base;
-        if (base + total <= a.cap) {
+        if (base != ~0ull) {
             uint64_t o = base + wave_base + (incl - cnt);
 #pragma unroll
             for (int u = 0; u < L1_G; ++u) {
@@ -406,16 +477,17 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
         }
     }
     if (lane == 0) {
-        unsigned long long base = 0;
-        if (n_emit) base = atomicAdd(a.cursor, (unsigned long long)n_emit);
-        s_base = base;
-        a.seg_off[sidx] = base;
-        a.seg_cnt[sidx] = (base + n_emit <= a.cap) ? (uint32_t)n_emit : 0u;
-        if (base + n_emit > a.cap) atomicExch(a.cursor + 1, 1ull);
+        unsigned long long ob = 0;
+        if (n_emit) ob = atomicAdd(a.cursor, (unsigned long long)n_emit);  // one per contig: no contention
+        const bool ok = ob + n_emit <= a.cap;
+        s_base = ok ? a.ovf_base + ob : ~0ull;
+        a.seg_off[sidx] = a.ovf_base + ob;
+        a.seg_cnt[sidx] = ok ? (uint32_t)n_emit : 0u;
+        if (!ok) atomicExch(a.cursor + 1, 1ull);
     }
     __syncthreads();
     const unsigned long long base = s_base;
-    if (base + n_emit <= a.cap) {
+    if (base != ~0ull) {
         for (int i = lane; i < n_emit; i += 64) {
             const uint32_t idx = s_emit[i];
             pgr_mm128 m;

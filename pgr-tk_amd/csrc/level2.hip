@@ -307,16 +307,23 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     uint32_t tot;
     const uint32_t o0 = block_excl_scan(cnt, L.wsum, &tot);
     if (t == 0) {
-        unsigned long long base = 0;
-        if (tot) base = atomicAdd(a.cursor, (unsigned long long)tot);
-        L.base = base;
+        // fixed slot per workgroup; only blocks with more survivors than the slot use the shared cursor
+        // (same-address atomics saturate at ~88/us on gfx950)
+        unsigned long long base = (unsigned long long)blockIdx.x * a.slot;
+        bool ok = true;
+        if (tot > a.slot) {
+            const unsigned long long ob = atomicAdd(a.cursor, (unsigned long long)tot);
+            base = a.ovf_base + ob;
+            ok = ob + tot <= a.cap;
+            if (!ok) atomicExch(a.cursor + 1, 1ull);
+        }
+        L.base = ok ? base : ~0ull;
         a.blk_off[blockIdx.x] = base;
-        a.blk_cnt[blockIdx.x] = (base + tot <= a.cap) ? tot : 0u;
-        if (base + tot > a.cap) atomicExch(a.cursor + 1, 1ull);
+        a.blk_cnt[blockIdx.x] = ok ? tot : 0u;
     }
     __syncthreads();
     const unsigned long long base = L.base;
-    if (cnt && base + tot <= a.cap) {
+    if (cnt && base != ~0ull) {
         uint64_t o = base + o0;
         for (int j = 0; j < C; ++j)
             if (flags & (1u << j)) {

@@ -71,9 +71,11 @@ struct L1Args {
     uint32_t n_tiles;
     const uint32_t *tile_first;  // [n+1] device
     uint32_t w, k, r, tc, sketch;
-    pgr_mm128 *out;              // unordered level-1 segments
-    uint64_t cap;
-    unsigned long long *cursor;  // [0] elements allocated, [1] overflow flag
+    pgr_mm128 *out;              // level-1 segments: [0, n_tiles*slot) fixed tile slots, then the overflow region
+    uint32_t slot;               // elements per tile slot
+    uint64_t ovf_base;           // first element of the overflow region (= n_tiles * slot)
+    uint64_t cap;                // capacity of the overflow region (elements)
+    unsigned long long *cursor;  // [0] overflow elements allocated, [1] overflow-of-the-overflow flag
     uint64_t *seg_off;           // [n_tiles + n_contigs]
     uint32_t *seg_cnt;           // [n_tiles + n_contigs]
     uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the serial kernel)
@@ -107,8 +109,10 @@ struct FusedArgsPub {
     uint32_t n_segs;
     uint64_t total;
     uint32_t r, padding, min_span, do_reduce, halo;
-    pgr_mm128 *out;
-    uint64_t cap;
+    pgr_mm128 *out;            // [0, n_blocks*slot) fixed block slots, then the overflow region
+    uint32_t slot;
+    uint64_t ovf_base;
+    uint64_t cap;              // overflow capacity
     unsigned long long *cursor;
     uint64_t *blk_off;
     uint32_t *blk_cnt;
