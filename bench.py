@@ -25,6 +25,19 @@ ALGO_BYTES_PER_BP = 0.2986  # 0.25 B packed input + 16 B 
 HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 
 
+def measured_traffic(bp_per_launch):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by tools/summarize_profile.py: 2 x FETCH_SIZE + WRITE_SIZE, the gfx950
+    correction of MI355X_MICROARCH.md); None when no profile of this workload is committed."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        if t.get("bp_per_launch") == bp_per_launch:
+            return t["hbm_bytes_per_launch"]
+    except Exception:
+        pass
+    return None
+
+
 def cpu_baseline(spec_t, n_contigs, contig_len, seed, contig0, gpu_counts):
     """the oracle (CPU restatement of the reference, one task per contig like rayon par_iter) on a
     bounded sample of the same workload, all host cores.  Checker + baseline only."""
@@ -87,26 +100,35 @@ def main():
     batch = P.Batch.synthetic(lens, seed=args.seed, contig0=contig0, ctx=ctx)  # inputs resident in HBM
     bp_per_step = batch.total_bases
 
-    rec_buf = None
-    state = {}
+    rec_bufs = [None, None]  # double buffered: the all-gather of step i overlaps the kernels of step i+1
+    state = {"i": 0, "pending": None}
+
+    def finish_pending():
+        if state["pending"] is not None:
+            gathered, counts = state["pending"].wait()
+            state["n_gathered"] = int(gathered.shape[0])
+            state["pending"] = None
 
     def step():
         sh = batch.shmmrs(spec)
-        nonlocal rec_buf
+        slot = state["i"] & 1
+        state["i"] += 1
         n_pairs = sh.n_pairs
-        if rec_buf is None or rec_buf.shape[0] < n_pairs:
-            rec_buf = torch.empty((int(n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64,
-                                  device="cuda:%d" % local_rank)
+        if rec_bufs[slot] is None or rec_bufs[slot].shape[0] < n_pairs:
+            rec_bufs[slot] = torch.empty((int(n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64,
+                                         device="cuda:%d" % local_rank)
+        rec_buf = rec_bufs[slot]
         n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=sids)
         if world > 1 and not args.no_exchange:
-            gathered, counts = exchange.allgather_records(rec_buf[:n])
-            state["n_gathered"] = int(gathered.shape[0])
+            finish_pending()  # step i-1's records have arrived everywhere
+            state["pending"] = exchange.PendingAllgather(rec_buf[:n])
         p = ctx.last_prof()
         state["sh"] = sh
         state["n_pairs"] = n
         return p.level1_ms, p.level1_aux_ms, p.level2_ms, p.total_ms, p.bases_tiled, p.n_level1
 
     def sync():
+        finish_pending()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -155,7 +177,7 @@ def main():
             "roofline": {
                 "bound": "hbm", "kernel": "level1_tile_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
+                "traffic": measured_traffic(bases_tiled),
                 "algorithmic_bytes_per_bp": ALGO_BYTES_PER_BP, "bp_per_launch": bases_tiled,
                 "avg_launch_ms": l1_ms,
                 "note": "integer hashing: the kernel is VALU bound (~2 x 64-bit mix hashes per position), "

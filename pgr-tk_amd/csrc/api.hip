@@ -272,6 +272,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
 
     if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_tile_desc.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(TileDesc))) ||
         (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_cursor.ensure(ctx, 2 * sizeof(unsigned long long))) ||
@@ -293,6 +294,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.n_contigs = n;
     a.n_tiles = n_tiles;
     a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
+    a.desc = (TileDesc *)ctx->ws_tile_desc.p;
     a.w = w_eff;
     a.k = spec->k;
     a.r = spec->r;

@@ -301,10 +301,11 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
 
     const uint32_t t = threadIdx.x;
     const uint32_t tile = blockIdx.x;
-    const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
-    const uint32_t tile_local = tile - a.tile_first[c];
+    const TileDesc td = a.desc[tile];
+    const uint32_t c = td.contig;
+    const uint32_t tile_local = td.tile_local;
     const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
-    const ContigGeom g = contig_geom(a.b.len[c], w, k);
+    const ContigGeom g = contig_geom(td.len, w, k);
     const long long c0 = (long long)tile_local * a.tc;
     long long c1 = c0 + a.tc;
     if (c1 > g.L) c1 = g.L;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     // ---- stage the 2-bit planes of the tile (+ k-mer look-back) in LDS
     const long long wbase = (e0 - 96) >> 5;  // floor
     const long long nwords = (g.L + 31) >> 5;
-    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
+    const uint2 *__restrict__ planes = a.b.planes + td.word_off;
     if (t < 136) {
         const long long wi = wbase + t;
         uint2 v = make_uint2(0u, 0u);
@@ -707,8 +708,22 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
 }
 
 // ------------------------------------------------------------------------------------------------
+__global__ void tile_desc_kernel(L1Args a) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= a.n_tiles) return;
+    const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
+    TileDesc d;
+    d.word_off = a.b.word_off[c];
+    d.len = a.b.len[c];
+    d.contig = c;
+    d.tile_local = tile - a.tile_first[c];
+    d._pad[0] = d._pad[1] = d._pad[2] = 0;
+    a.desc[tile] = d;
+}
+
 void launch_level1_tiles(hipStream_t st, const L1Args &a) {
     if (a.n_tiles == 0) return;
+    hipLaunchKernelGGL(tile_desc_kernel, dim3((a.n_tiles + 255) / 256), dim3(256), 0, st, a);
     if (a.sketch)
         hipLaunchKernelGGL((level1_tile_kernel<0, 0, true>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
     else if (a.w == 80 && a.k == 56)

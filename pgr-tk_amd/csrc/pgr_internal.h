@@ -65,11 +65,19 @@ void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_
                   uint64_t contig0);
 
 // level1.hip
+struct TileDesc {  // one per tile, written by tile_desc_kernel (saves every workgroup a 10-step dependent search)
+    uint64_t word_off;    // first plane word of the contig
+    uint32_t len;         // contig length
+    uint32_t contig;      // contig index
+    uint32_t tile_local;  // tile ordinal inside the contig
+    uint32_t _pad[3];
+};
 struct L1Args {
     BatchDev b;
     uint32_t n_contigs;
     uint32_t n_tiles;
     const uint32_t *tile_first;  // [n+1] device
+    TileDesc *desc;              // [n_tiles] scratch, filled by launch_level1_tiles
     uint32_t w, k, r, tc, sketch;
     pgr_mm128 *out;              // level-1 segments: [0, n_tiles*slot) fixed tile slots, then the overflow region
     uint32_t slot;               // elements per tile slot

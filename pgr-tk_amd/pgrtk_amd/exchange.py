@@ -27,6 +27,45 @@ def shard_contigs(lens, world_size):
     return shards
 
 
+class PendingAllgather:
+    """an all-gather of one rank-local record tensor in flight (collective on the process group's own
+    stream, so the next batch's kernels overlap with it); wait() returns (gathered, counts)."""
+
+    def __init__(self, local, group=None):
+        world = dist.get_world_size(group)
+        assert local.dtype == torch.int64 and local.dim() == 2 and local.shape[1] == REC_WORDS
+        self.local = local
+        n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
+        counts = torch.empty(world, dtype=torch.int64, device=local.device)
+        dist.all_gather_into_tensor(counts, n_local, group=group)
+        self.counts = [int(v) for v in counts.cpu()]
+        self.n_max = max(self.counts) if self.counts else 0
+        self.out = None
+        self.work = None
+        if self.n_max:
+            if local.shape[0] == self.n_max:
+                padded = local.contiguous()
+            else:
+                padded = local.new_zeros((self.n_max, REC_WORDS))
+                padded[: local.shape[0]] = local
+            self.padded = padded
+            self.out = local.new_empty((world * self.n_max, REC_WORDS))
+            self.work = dist.all_gather_into_tensor(self.out, padded, group=group, async_op=True)
+
+    def wait(self):
+        if self.work is None:
+            return self.local.new_zeros((0, REC_WORDS)), self.counts
+        self.work.wait()
+        if self.out.is_cuda:
+            # the record buffers are rewritten by kernels on libpgrhip's own stream, which torch does not
+            # order against: make the completion visible to the host before the caller reuses them
+            torch.cuda.current_stream(self.out.device).synchronize()
+        if all(c == self.n_max for c in self.counts):
+            return self.out, self.counts
+        parts = [self.out[r * self.n_max: r * self.n_max + c] for r, c in enumerate(self.counts)]
+        return torch.cat(parts, dim=0), self.counts
+
+
 def allgather_records(local, group=None):
     """local: int64 tensor [n_local, 5] (40-byte records) on this rank's device.
     Returns (gathered [sum n, 5] in rank order, counts list).  Two collectives: the counts

@@ -39,6 +39,9 @@ def _worker(rank, world, port, counts, q):
             local[:, 3] = 7
             local[:, 4] = 9
         out, cnts = exchange.allgather_records(local)
+        pend = exchange.PendingAllgather(local)  # the overlapped form bench.py uses must agree
+        out2, cnts2 = pend.wait()
+        assert cnts2 == cnts and out2.shape == out.shape and bool((out2 == out).all())
         q.put((rank, out.numpy().copy(), cnts))
     finally:
         dist.destroy_process_group()
