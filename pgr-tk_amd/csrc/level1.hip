@@ -110,6 +110,20 @@ __device__ __forceinline__ uint32_t lane_range_mask(int t16, int lo, int hi) {
 }
 __device__ __forceinline__ int clamp_rel(long long v) { return v < 0 ? 0 : (v > L1_EXT ? L1_EXT : (int)v); }
 
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {  // (a & m) | o
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(o));
+    return r;
+}
+// low 64 bits of the 96-bit value (w2:w1:w0) >> S, S a compile-time constant in 0..63
+template <int S>
+__device__ __forceinline__ uint64_t shr96_lo64(uint32_t w2, uint32_t w1, uint32_t w0) {
+    if (S == 0) return ((uint64_t)w1 << 32) | w0;
+    if (S < 32) return ((uint64_t)funnel(w2, w1, S) << 32) | funnel(w1, w0, S);
+    if (S == 32) return ((uint64_t)w2 << 32) | w1;
+    return ((uint64_t)(w2 >> ((S - 32) & 31)) << 32) | funnel(w2, w1, (S - 32) & 31);
+}
+
 constexpr uint32_t KEY_EXP = 0x40000000u;   // bit 62: keys are positive normal doubles
 constexpr uint32_t KEY_INF = 0x7FE00000u;   // hi word of the "not a k-mer" sentinel (finite, above every key)
 
@@ -132,35 +146,36 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
     const uint32_t b0 = funnel(W1.y, W0.y, s), b1 = funnel(W2.y, W1.y, s), b2 = funnel(W3.y, W2.y, s);
     const uint64_t kmask = U64MAX >> (64 - k);
     const uint64_t sketch_thr = (U64MAX >> 4) >> a.r;  // shmmrutils.rs:621
-    // bit-reversed complement windows: Rv bit i = ~base[e - 95 + i]; with a compile-time k the reverse-
-    // complement planes (shmmrutils.rs:469-475) are static bit fields of Rv, like the forward planes of A
+    // Two 64-bit anchors per plane so that every position's k-mer plane is ONE 64-bit shift (by 0..7) + mask:
+    //   FA = window ending at position q+15 (positions u = 8..15), FB = window ending at q+7 (u = 0..7).
+    const uint64_t fa0 = ((uint64_t)a1 << 32) | a0, fb0 = ((uint64_t)funnel(a2, a1, 8) << 32) | funnel(a1, a0, 8);
+    const uint64_t fa1 = ((uint64_t)b1 << 32) | b0, fb1 = ((uint64_t)funnel(b2, b1, 8) << 32) | funnel(b1, b0, 8);
+    // bit-reversed complement windows: Rv bit i = ~base[q + 15 - 95 + i]; with a compile-time k the reverse-
+    // complement planes (shmmrutils.rs:469-475) are r = (Rv >> (81 + u - k)) & kmask: anchors at shift
+    // 81-k (u = 0..7) and 89-k (u = 8..15)
     const uint32_t ra0 = __brev(~a2), ra1 = __brev(~a1), ra2 = __brev(~a0);
     const uint32_t rb0 = __brev(~b2), rb1 = __brev(~b1), rb2 = __brev(~b0);
+    constexpr int RS1 = 81 - (TK ? TK : 56), RS0 = RS1 + 8;
+    const uint64_t rA0 = shr96_lo64<RS1>(ra2, ra1, ra0), rB0 = shr96_lo64<RS0>(ra2, ra1, ra0);
+    const uint64_t rA1 = shr96_lo64<RS1>(rb2, rb1, rb0), rB1 = shr96_lo64<RS0>(rb2, rb1, rb0);
 
     // x[]: ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
     uint32_t pal_min = 0xFFFFFFFFu;  // 0 iff some position may hold a palindromic k-mer
 #pragma unroll
     for (int u = 0; u < L1_G; ++u) {
-        const uint32_t sh = (uint32_t)(L1_G - 1 - u);
-        const uint64_t f0 = (((uint64_t)funnel(a2, a1, sh) << 32) | funnel(a1, a0, sh)) & kmask;
-        const uint64_t f1 = (((uint64_t)funnel(b2, b1, sh) << 32) | funnel(b1, b0, sh)) & kmask;
+        const uint64_t f0 = ((u >= 8 ? fa0 : fb0) >> ((L1_G - 1 - u) & 7)) & kmask;
+        const uint64_t f1 = ((u >= 8 ? fa1 : fb1) >> ((L1_G - 1 - u) & 7)) & kmask;
         uint64_t r0, r1;
         if (TK) {
-            constexpr int rsh0 = 81 - (TK ? TK : 1);  // r = (Rv >> (81 + u - k)) & kmask
-            const int rsh = rsh0 + u;
-            if (rsh < 32) {
-                r0 = (((uint64_t)funnel(ra2, ra1, rsh) << 32) | funnel(ra1, ra0, rsh)) & kmask;
-                r1 = (((uint64_t)funnel(rb2, rb1, rsh) << 32) | funnel(rb1, rb0, rsh)) & kmask;
-            } else {
-                r0 = (((uint64_t)(ra2 >> (rsh - 32)) << 32) | funnel(ra2, ra1, rsh - 32)) & kmask;
-                r1 = (((uint64_t)(rb2 >> (rsh - 32)) << 32) | funnel(rb2, rb1, rsh - 32)) & kmask;
-            }
+            r0 = ((u >= 8 ? rB0 : rA0) >> (u & 7)) & kmask;
+            r1 = ((u >= 8 ? rB1 : rA1) >> (u & 7)) & kmask;
         } else {
             r0 = rc_plane(f0, k);
             r1 = rc_plane(f1, k);
         }
         // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488); both < 2^56
-        const uint32_t rev = (uint32_t)((int32_t)((uint32_t)((r0 - f0) >> 32)) >> 31);  // 0 / ~0
+        const uint64_t dfr = r0 - f0;
+        const uint32_t rev = (uint32_t)((int32_t)((uint32_t)(dfr >> 32)) >> 31);  // 0 / ~0
         const uint32_t m0l = bfi(rev, (uint32_t)r0, (uint32_t)f0), m0h = bfi(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
         const uint32_t m1l = bfi(rev, (uint32_t)r1, (uint32_t)f1), m1h = bfi(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
 #if PGR_ABLATE == 2
@@ -169,7 +184,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         const uint64_t h = u64hash_sa(((uint64_t)m0h << 32) | m0l) ^ u64hash_sa((((uint64_t)m1h << 32) | m1l) ^ 0xAD12CF59ull);
 #endif
         strand_bits = bfi(1u << u, rev, strand_bits);
-        const uint64_t key = (h & 0x00FFFFFFFFFFFFFFull) | ((uint64_t)KEY_EXP << 32);
+        const uint64_t key = ((uint64_t)and_or((uint32_t)(h >> 32), 0x00FFFFFFu, KEY_EXP) << 32) | (uint32_t)h;
         uint32_t inval = 0;
         if (MASKED) {
             inval = bit_to_mask(~valid_mask, u);
@@ -183,9 +198,10 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             const bool skip = (f0 == r0) && (f1 == r1);
             if (!skip && h < sketch_thr) emit |= 1u << u;
         } else {
-            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480) => low words equal: cheap necessary
-            // test; a hit only routes the contig to the exact serial kernel
-            const uint32_t d = (((uint32_t)f0 ^ (uint32_t)r0) | ((uint32_t)f1 ^ (uint32_t)r1)) | inval;
+            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480) => r0 - f0 == 0 (already computed for
+            // the strand; alone it fires with probability 2^-(k/2) on random sequence) and the low words of the
+            // high plane agree: a cheap necessary test, a hit only routes the contig to the exact serial kernel
+            const uint32_t d = (uint32_t)dfr | (uint32_t)(dfr >> 32) | ((uint32_t)f1 ^ (uint32_t)r1) | inval;
             pal_min = pal_min < d ? pal_min : d;
         }
     }
@@ -326,16 +342,21 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
 
     // ---- per-lane masks over this lane's 16 positions (tile-extended coordinates 16t .. 16t+15)
     const int t16 = (int)t * L1_G;
-    const uint32_t valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
     const uint32_t core_mask = lane_range_mask(t16, clamp_rel(c0 - e0), clamp_rel(c1 - e0));
-    const uint32_t mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
+    // interior tile (uniform): all 4096 extended positions are real k-mers and every window end is in range
+    const bool interior = e0 >= (long long)k && e0 + L1_EXT <= g.L && e0 >= g.jstart && e0 + L1_EXT - 1 <= g.jend;
+    uint32_t valid_mask = 0xFFFFu, mwin_mask = 0xFFFFu;
+    if (!interior) {
+        valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
+        mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
+    }
 
     // ---- hash + select.  Waves whose 64x16 positions are all inside the contig and inside the window-end
     // range skip every masking instruction (uniform branch; both variants hit the same barriers).
     double x[L1_G];
     uint32_t strand_bits = 0, emit = 0;
     const long long q = e0 + (long long)t16;
-    const bool wave_full = __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
+    const bool wave_full = interior || __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
     if (wave_full)
         tile_select<TW, TK, SKETCH, false>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
                                           core_mask, x, strand_bits, emit);
@@ -374,21 +395,24 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         a.seg_cnt[sidx] = ok ? total : 0u;
         if (s_skip) atomicOr(a.contig_flags + c, 1u);
     }
-    __syncthreads();
-    if (cnt) {
-        const unsigned long long base = s_base;
-        if (base != ~0ull) {
-            uint64_t o = base + wave_base + (incl - cnt);
+    // selected keys go through LDS (s_suf is free now; each lane re-reads only its own column, so no barrier
+    // is needed for the data): a loop over the ~0.4 set bits per lane instead of 16 predicated stores
 #pragma unroll
-            for (int u = 0; u < L1_G; ++u) {
-                if (emit & (1u << u)) {
-                    const uint64_t p = (uint64_t)(q + u);
-                    const uint64_t kb = (uint64_t)__double_as_longlong(x[u]);
-                    pgr_mm128 m;
-                    m.x = (kb << 8) | (uint64_t)k;  // drops bit 62, keeps the low 56 hash bits
-                    m.y = ((uint64_t)c << 32) | (p << 1) | ((strand_bits >> u) & 1u);
-                    a.out[o++] = m;
-                }
+    for (int u = 0; u < L1_G; ++u) s_suf[u][t] = x[u];
+    __syncthreads();
+    {
+        const unsigned long long base = s_base;
+        if (cnt && base != ~0ull) {
+            uint64_t o = base + wave_base + (incl - cnt);
+            uint32_t em = emit;
+            while (em) {
+                const uint32_t u = (uint32_t)__builtin_ctz(em);
+                em &= em - 1;
+                const uint64_t kb = (uint64_t)__double_as_longlong(s_suf[u][t]);
+                pgr_mm128 m;
+                m.x = (kb << 8) | (uint64_t)k;  // drops bit 62, keeps the low 56 hash bits
+                m.y = ((uint64_t)c << 32) | ((uint64_t)(q + u) << 1) | ((strand_bits >> u) & 1u);
+                a.out[o++] = m;
             }
         }
     }
