@@ -38,6 +38,72 @@ def measured_traffic(bp_per_launch):
     return None
 
 
+def synth_substrings(seed, contigs, offsets, length):
+    """the BASELINE.md section 4 generator restated with numpy, for arbitrary (contig, offset) windows:
+    base(c,i) = (splitmix64(seed ^ c*0x9E3779B97F4A7C15 ^ (i>>5)) >> (2*(i&31))) & 3 -> ACGT bytes"""
+    import numpy as np
+    M = np.uint64(0xFFFFFFFFFFFFFFFF)
+    out = []
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    with np.errstate(over="ignore"):
+        for c, o in zip(contigs, offsets):
+            i = np.arange(o, o + length, dtype=np.uint64)
+            z = (np.uint64(seed) ^ (np.uint64(c) * np.uint64(0x9E3779B97F4A7C15)) ^ (i >> np.uint64(5))) & M
+            z = z + np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            code = (z >> (np.uint64(2) * (i & np.uint64(31)))) & np.uint64(3)
+            out.append(acgt[code.astype(np.int64)])
+    return out
+
+
+def query_bench(P, ctx, batch, spec, args, contig0):
+    """BASELINE.json configs[2]: index = the resident contigs; 10 000 x 10 kbp substrings at random
+    (contig, offset), half of them reverse-complemented; pgr-query defaults (penalty 0.025, counts 128, span 8)."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    nq, qlen = args.queries, 10_000
+    t0 = time.perf_counter()
+    ix = P.Index(spec, ctx=ctx)
+    ix.add_resident(batch, sids=list(range(contig0, contig0 + args.contigs)))
+    ix.finalize()
+    t_build = time.perf_counter() - t0
+    cs = rng.integers(0, args.contigs, nq)
+    offs = rng.integers(0, max(1, args.contig_len - qlen), nq)
+    qs = synth_substrings(args.seed, contig0 + cs, offs, qlen)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    qs = [comp[q][::-1].copy() if i & 1 else q for i, q in enumerate(qs)]
+    ix.query_hps_raw(qs[:64], 0.025)  # warm-up
+    t0 = time.perf_counter()
+    r = ix.query_hps_raw(qs, 0.025)
+    t_q = time.perf_counter() - t0
+    # self-consistency: the best chain of every query lies on its source contig at its source offset
+    ok = 0
+    for qi in range(nq):
+        best = None
+        for t in range(int(r["q_off"][qi]), int(r["q_off"][qi + 1])):
+            for c in range(int(r["t_off"][t]), int(r["t_off"][t + 1])):
+                n_hp = int(r["c_off"][c + 1] - r["c_off"][c])
+                if best is None or n_hp > best[0]:
+                    best = (n_hp, int(r["t_sid"][t]), c)
+        if best is not None and best[1] == contig0 + int(cs[qi]):
+            h = r["hps"][int(r["c_off"][best[2]])]
+            tb = int(h["tb"])
+            if offs[qi] <= tb <= offs[qi] + qlen:
+                ok += 1
+    return {
+        "workload": "BASELINE.json configs[2]: %d x %d bp queries (50%% reverse complement) against the %d x %d bp index, "
+                    "penalty 0.025, max counts 128, max_aln_span 8" % (nq, qlen, args.contigs, args.contig_len),
+        "index_build_s": t_build, "index_records": ix.n_records, "index_keys": ix.n_keys,
+        "query_s": t_q, "queries_per_s": nq / t_q, "hit_pairs": int(len(r["hps"])),
+        "hit_pairs_per_s": len(r["hps"]) / t_q, "chains": int(len(r["c_score"])),
+        "queries_with_best_chain_on_source": ok,
+    }
+
+
 def cpu_baseline(spec_t, n_contigs, contig_len, seed, contig0, gpu_counts):
     """the oracle (CPU restatement of the reference, one task per contig like rayon par_iter) on a
     bounded sample of the same workload, all host cores.  Checker + baseline only."""
@@ -71,6 +137,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the RCCL all-gather of pair records")
+    ap.add_argument("--queries", type=int, default=10_000, help="query leg (after the timed region, N=1 only); 0 = off")
     args = ap.parse_args()
 
     import torch
@@ -185,6 +252,8 @@ def main():
             },
             "stage_ms": {"level1_tile": l1_ms, "level1_tail_serial": aux_ms, "level2": l2_ms, "compute_total": tot_ms},
         }
+        if world == 1 and args.queries > 0:
+            out["query"] = query_bench(P, ctx, batch, spec, args, contig0)
         if not args.no_cpu_baseline:
             import numpy as np  # noqa: F401
             mm, off = sh.download()

@@ -146,3 +146,81 @@ def frag_recs_batch(seqs, spec, sids=None, query_side=False, ctx=None):
     off = _ffi.take(po, n + 1, np.dtype("<u8"))
     recs = _ffi.take(pr, int(off[n]) if n else 0, FRAG_REC)
     return [recs[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+class Index:
+    """ShmmrToFrags on the GPU (pgr_index): sorted CSR of fragment signatures + the query entry point."""
+
+    def __init__(self, spec, ctx=None):
+        self.ctx = ctx or default_context()
+        self.spec = spec
+        self._h = C.c_void_p()
+        self.ctx.check(lib().pgr_index_create(self.ctx.handle, C.byref(spec), C.byref(self._h)))
+
+    def add_resident(self, batch, sids=None):
+        keep, sp = _u32_array(sids, batch.n)
+        self.ctx.check(lib().pgr_index_add_resident(self.ctx.handle, self._h, batch._h, sp))
+
+    def add_seqs(self, seqs, sids=None):
+        arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+        keep, sp = _u32_array(sids, n)
+        self.ctx.check(lib().pgr_index_add_batch(self.ctx.handle, self._h, n, ptrs, lens, sp))
+
+    def add_records(self, recs=None, device_ptr=None, n=None):
+        """merge pair records computed elsewhere: a host FRAG_REC array, or n records at a DEVICE pointer
+        (e.g. the all-gathered torch tensor of the multi-GPU exchange)"""
+        if recs is not None:
+            a = np.ascontiguousarray(recs, dtype=FRAG_REC)
+            self.ctx.check(lib().pgr_index_add_records(self.ctx.handle, self._h, a.ctypes.data, a.size, 0))
+        else:
+            self.ctx.check(lib().pgr_index_add_records(self.ctx.handle, self._h, C.c_void_p(device_ptr), int(n), 1))
+
+    def finalize(self):
+        self.ctx.check(lib().pgr_index_finalize(self.ctx.handle, self._h))
+
+    @property
+    def n_keys(self):
+        return int(lib().pgr_index_n_keys(self._h))
+
+    @property
+    def n_records(self):
+        return int(lib().pgr_index_n_records(self._h))
+
+    def download(self):
+        p, n = C.c_void_p(), C.c_uint64()
+        self.ctx.check(lib().pgr_index_download(self.ctx.handle, self._h, C.byref(p), C.byref(n)))
+        return _ffi.take(p, int(n.value), FRAG_REC)
+
+    def query_hps_raw(self, seqs, penalty, max_count=128, max_count_query=128, max_count_target=128, max_aln_span=8,
+                      max_gap=None, oriented=False):
+        """pgr_query_hps_batch -> flat numpy arrays (q_off, t_sid, t_off, c_score, c_off, hps)"""
+        arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+        res = _ffi.HpsResult()
+        self.ctx.check(lib().pgr_query_hps_batch(self.ctx.handle, self._h, n, ptrs, lens, float(penalty), max_count,
+                                                 max_count_query, max_count_target, max_aln_span,
+                                                 int(max_gap is not None), int(max_gap or 0), int(bool(oriented)),
+                                                 C.byref(res)))
+        nt, nc, nh = int(res.n_targets), int(res.n_chains), int(res.n_hps)
+        out = {
+            "q_off": np.ctypeslib.as_array(res.q_off, shape=(n + 1,)).copy(),
+            "t_sid": np.ctypeslib.as_array(res.t_sid, shape=(max(nt, 1),))[:nt].copy(),
+            "t_off": np.ctypeslib.as_array(res.t_off, shape=(nt + 1,)).copy(),
+            "c_score": np.ctypeslib.as_array(res.c_score, shape=(max(nc, 1),))[:nc].copy(),
+            "c_off": np.ctypeslib.as_array(res.c_off, shape=(nc + 1,)).copy(),
+            "hps": np.zeros(nh, dtype=_ffi.HITPAIR),
+        }
+        if nh:
+            C.memmove(out["hps"].ctypes.data, res.hps, nh * _ffi.HITPAIR.itemsize)
+        lib().pgr_hps_result_free(C.byref(res))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().pgr_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
