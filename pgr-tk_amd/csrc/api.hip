@@ -4,7 +4,8 @@
 // Pipeline of one pgr_shmmrs_compute:
 //   level1_tile_kernel  (dominant)  -> unordered per-tile segments of level-1 minimizers
 //   level1_tail_kernel              -> per-contig tail segment (rescan-only positions)
-//   level1_serial_kernel            -> whole-contig segment for contigs the closed form cannot do
+//   level1_chunk_kernel             -> exact state machine (chunked, verified seams) for contigs the
+//                                      closed form cannot do
 //   scan(seg counts) + gather       -> ordered per-contig level-1 lists
 //   select(reduce) x2, select(min_span) -> final MM128 lists (+ rid patch)
 #include <algorithm>
@@ -16,6 +17,16 @@
 #include "pgr_ctx.h"
 
 using namespace pgr;
+
+namespace {
+struct Tmp_list {  // small RAII device allocation from the context's caching allocator
+    pgr_ctx *ctx;
+    void *p = nullptr;
+    explicit Tmp_list(pgr_ctx *c) : ctx(c) {}
+    ~Tmp_list() { ctx->dfree(p); }
+    int alloc(size_t bytes) { return ctx->dmalloc(&p, bytes < 16 ? 16 : bytes); }
+};
+}  // namespace
 
 static std::string g_create_error;
 
@@ -214,6 +225,142 @@ extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *len
 }
 
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Exact state machine over the listed contigs, parallel over 32 kbp chunks with verified seams
+// (level1_chunk_kernel).  A seam whose warmed-up state differs from the previous chunk's true end state is
+// re-run with that state installed; if even that cannot be done the contig is re-run as ONE chunk.
+static int run_exact_chunks(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, const std::vector<uint32_t> &contigs,
+                            const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base) {
+    hipStream_t st = ctx->stream;
+    constexpr uint64_t CS = 32768;
+    struct HChunk {
+        ChunkDesc d;
+        bool full_cap = false;
+        bool whole = false;
+    };
+    std::vector<HChunk> ch;
+    auto cap_of = [&](uint64_t len, bool full) -> uint64_t {
+        return full ? len + a.w + 64 : std::min<uint64_t>(len + a.w + 64, len / 4 + 1024);
+    };
+    auto add_contig = [&](uint32_t c, bool whole) {
+        const uint64_t L = b->h_len[c];
+        const uint32_t nt = tile_first[c + 1] - tile_first[c];
+        const uint64_t nch = whole ? 1 : (L + CS - 1) / CS;
+        for (uint64_t j = 0; j < nch; ++j) {
+            HChunk h;
+            memset(&h.d, 0, sizeof(h.d));
+            h.d.contig = c;
+            h.d.cs = whole ? 0 : j * CS;
+            h.d.ce = whole ? L : std::min<uint64_t>(L, (j + 1) * CS);
+            const uint64_t tl = std::min<uint64_t>(nt ? nt - 1 : 0, (j * CS) / tc);
+            h.d.seg = tile_first[c] + c + (uint32_t)tl;
+            h.d.warm = 256;
+            h.whole = whole;
+            ch.push_back(h);
+        }
+    };
+    for (uint32_t c : contigs) add_contig(c, false);
+
+    int rc;
+    Tmp_list d_list(ctx);
+    if ((rc = d_list.alloc(contigs.size() * sizeof(uint32_t)))) return rc;
+    PGR_HIP(ctx, hipMemcpyAsync(d_list.p, contigs.data(), contigs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    launch_zero_contig_segs(st, a, (const uint32_t *)d_list.p, (uint32_t)contigs.size());
+
+    uint64_t next_region = region_base;
+    std::vector<ChunkState> s_in, s_out;
+    std::vector<uint32_t> status;
+    std::vector<size_t> todo(ch.size());
+    for (size_t i = 0; i < ch.size(); ++i) todo[i] = i;
+    for (int round = 0; !todo.empty(); ++round) {
+        if (round > 64) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine chunks did not converge");
+        // regions for the chunks of this round (appended; earlier regions of re-run chunks are abandoned)
+        std::vector<ChunkDesc> descs(todo.size());
+        for (size_t q = 0; q < todo.size(); ++q) {
+            HChunk &h = ch[todo[q]];
+            h.d.region_off = next_region;
+            h.d.region_cap = cap_of(h.d.ce - h.d.cs, h.full_cap);
+            next_region += h.d.region_cap;
+            descs[q] = h.d;
+        }
+        if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(pgr_mm128), st))) return rc;
+        a.out = (pgr_mm128 *)ctx->ws_l1.p;
+        const size_t nq = todo.size();
+        if ((rc = ctx->ws_serial.ensure(ctx, nq * (sizeof(ChunkDesc) + 2 * sizeof(ChunkState) + sizeof(uint32_t)))))
+            return rc;
+        ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
+        ChunkState *d_in = (ChunkState *)(d_desc + nq);
+        ChunkState *d_out = d_in + nq;
+        uint32_t *d_stat = (uint32_t *)(d_out + nq);
+        PGR_HIP(ctx, hipMemcpyAsync(d_desc, descs.data(), nq * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
+        PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
+        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat);
+        std::vector<ChunkState> r_in(nq), r_out(nq);
+        std::vector<uint32_t> r_stat(nq);
+        PGR_HIP(ctx, hipMemcpyAsync(r_in.data(), d_in, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipMemcpyAsync(r_out.data(), d_out, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipMemcpyAsync(r_stat.data(), d_stat, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        PGR_HIP(ctx, hipGetLastError());
+        if (s_in.size() < ch.size()) {
+            s_in.resize(ch.size());
+            s_out.resize(ch.size());
+            status.resize(ch.size());
+        }
+        for (size_t q = 0; q < nq; ++q) {
+            s_in[todo[q]] = r_in[q];
+            s_out[todo[q]] = r_out[q];
+            status[todo[q]] = r_stat[q];
+        }
+        // ---- verify every seam; collect the chunks that must run again
+        std::vector<size_t> next;
+        std::vector<uint32_t> whole_contigs;
+        for (size_t i = 0; i < ch.size(); ++i) {
+            HChunk &h = ch[i];
+            if (h.d.contig == 0xFFFFFFFFu) continue;  // retired (its contig is re-run as one chunk)
+            bool again = false;
+            if (status[i] & 1u) {  // region overflow
+                h.full_cap = true;
+                again = true;
+            }
+            if (status[i] & 2u) {  // the true state could not be installed: whole contig, one chunk
+                whole_contigs.push_back(h.d.contig);
+                continue;
+            }
+            if (!h.whole && h.d.cs > 0 && i > 0 && ch[i - 1].d.contig == h.d.contig) {
+                if (memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
+                    h.d.override_state = 1;
+                    h.d.in_state = s_out[i - 1];
+                    h.d.warm = 1024;
+                    again = true;
+                }
+            }
+            if (again) next.push_back(i);
+        }
+        if (!whole_contigs.empty()) {
+            std::sort(whole_contigs.begin(), whole_contigs.end());
+            whole_contigs.erase(std::unique(whole_contigs.begin(), whole_contigs.end()), whole_contigs.end());
+            for (auto &h : ch)
+                if (std::binary_search(whole_contigs.begin(), whole_contigs.end(), h.d.contig)) h.d.contig = 0xFFFFFFFFu;
+            next.erase(std::remove_if(next.begin(), next.end(), [&](size_t i) { return ch[i].d.contig == 0xFFFFFFFFu; }),
+                       next.end());
+            // their chunk segments must be emptied again before the single-chunk run
+            Tmp_list d_wl(ctx);
+            if ((rc = d_wl.alloc(whole_contigs.size() * sizeof(uint32_t)))) return rc;
+            PGR_HIP(ctx, hipMemcpyAsync(d_wl.p, whole_contigs.data(), whole_contigs.size() * sizeof(uint32_t),
+                                        hipMemcpyHostToDevice, st));
+            launch_zero_contig_segs(st, a, (const uint32_t *)d_wl.p, (uint32_t)whole_contigs.size());
+            PGR_HIP(ctx, hipStreamSynchronize(st));
+            for (uint32_t c : whole_contigs) {
+                add_contig(c, true);
+                next.push_back(ch.size() - 1);
+            }
+        }
+        todo.swap(next);
+    }
+    return PGR_OK;
+}
+
 static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
     if (!spec) return ctx->fail(PGR_ERR_INVALID_ARG, "null spec");
     // shmmrutils.rs:443-445 / :575-576
@@ -247,12 +394,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         tile_first[c] = (uint32_t)n_tiles64;
         const uint64_t L = b->h_len[c];
         if (L == 0) continue;
-        if (tiled && b->h_n_invalid[c] == 0) {
-            n_tiles64 += (L + tc - 1) / tc;
-            bases_tiled += L;
-        } else {
-            serial.push_back(c);
-        }
+        n_tiles64 += (L + tc - 1) / tc;  // every contig owns tile segments (the chunk kernel reuses them)
+        if (tiled && b->h_n_invalid[c] == 0) bases_tiled += L;
+        else serial.push_back(c);
     }
     if (n_tiles64 + n + 1 >= (1ull << 31)) return ctx->fail(PGR_ERR_INVALID_ARG, "batch too large (tile count)");
     tile_first[n] = (uint32_t)n_tiles64;
@@ -265,10 +409,6 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint32_t slot = std::min<uint32_t>(tc, (((uint32_t)((double)tc * dens * 2.0) + 64 + 63) / 64) * 64);
     const uint64_t slots_total = (uint64_t)n_tiles * slot;
     uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 300ull * n;
-    auto serial_cap = [&](uint32_t c, bool full) -> uint64_t {
-        const uint64_t L = b->h_len[c];
-        return full ? L : std::min<uint64_t>(L, L / 4 + 4096);
-    };
 
     if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
@@ -318,7 +458,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     for (int attempt = 0;; ++attempt) {
         if (attempt > 4) return ctx->fail(PGR_ERR_INTERNAL, "level-1 buffer kept overflowing");
         uint64_t serial_total = 0;
-        for (uint32_t c : serial) serial_total += serial_cap(c, false);
+        for (uint32_t c : serial) serial_total += (uint64_t)b->h_len[c] / 4 + 4096;
         if ((rc = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return rc;
         a.out = (pgr_mm128 *)ctx->ws_l1.p;
         a.slot = slot;
@@ -329,7 +469,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), st));
         PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-        launch_level1_tiles(st, a);
+        if (tiled && bases_tiled) launch_level1_tiles(st, a);
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         launch_level1_tails(st, a);
         unsigned long long cur[2] = {0, 0};
@@ -355,43 +495,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     prof.n_serial_contigs = serial.size();
     if (!serial.empty()) {
         std::sort(serial.begin(), serial.end());
-        std::vector<char> full(serial.size(), 0);
-        for (int attempt = 0;; ++attempt) {
-            if (attempt > 2) return ctx->fail(PGR_ERR_INTERNAL, "serial kernel kept overflowing");
-            const size_t ns = serial.size();
-            std::vector<uint64_t> roff(ns), rcap(ns);
-            uint64_t o = serial_base;
-            for (size_t i = 0; i < ns; ++i) {
-                roff[i] = o;
-                rcap[i] = serial_cap(serial[i], full[i] != 0);
-                o += rcap[i];
-            }
-            if ((rc = ctx->ws_l1.ensure_keep(ctx, (o + 1) * sizeof(pgr_mm128), st))) return rc;
-            a.out = (pgr_mm128 *)ctx->ws_l1.p;
-            if ((rc = ctx->ws_serial.ensure(ctx, ns * (sizeof(uint32_t) * 2 + sizeof(uint64_t) * 2)))) return rc;
-            uint64_t *d_roff = (uint64_t *)ctx->ws_serial.p;
-            uint64_t *d_rcap = d_roff + ns;
-            uint32_t *d_list = (uint32_t *)(d_rcap + ns);
-            uint32_t *d_ovf = d_list + ns;
-            PGR_HIP(ctx, hipMemcpyAsync(d_roff, roff.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-            PGR_HIP(ctx, hipMemcpyAsync(d_rcap, rcap.data(), ns * sizeof(uint64_t), hipMemcpyHostToDevice, st));
-            PGR_HIP(ctx, hipMemcpyAsync(d_list, serial.data(), ns * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-            PGR_HIP(ctx, hipMemsetAsync(d_ovf, 0, ns * sizeof(uint32_t), st));
-            L1Args as = a;
-            as.w = spec->w;  // the serial kernel follows the spec literally (sketch ignores w)
-            launch_level1_serial(st, as, d_list, (uint32_t)ns, d_roff, d_rcap, d_ovf);
-            std::vector<uint32_t> ovf(ns);
-            PGR_HIP(ctx, hipMemcpyAsync(ovf.data(), d_ovf, ns * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            PGR_HIP(ctx, hipStreamSynchronize(st));
-            PGR_HIP(ctx, hipGetLastError());
-            bool again = false;
-            for (size_t i = 0; i < ns; ++i)
-                if (ovf[i]) {
-                    full[i] = 1;
-                    again = true;
-                }
-            if (!again) break;
-        }
+        L1Args as = a;
+        as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
+        if ((rc = run_exact_chunks(ctx, b, as, serial, tile_first, tc, serial_base))) return rc;
+        a.out = as.out;
     }
     PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 

@@ -9,9 +9,10 @@
 //                        consecutive positions in registers.
 //   level1_tail_kernel   the last (w-k) positions of a contig, where the reference only rescans
 //                        (branch 2 disabled, shmmrutils.rs:516-520): one wavefront per contig.
-//   level1_serial_kernel the exact ring-buffer state machine, event driven, one wavefront per contig.
-//                        Used for contigs the closed form does not cover: non-ACGT bytes, reverse-
-//                        complement-palindromic k-mers (skipped pushes, shmmrutils.rs:477-480), w < 17.
+//   level1_chunk_kernel  the exact ring-buffer state machine, event driven, one wavefront per 32 kbp chunk
+//                        with verified seams.  Used for contigs the closed form does not cover: non-ACGT
+//                        bytes, reverse-complement-palindromic k-mers (skipped pushes, shmmrutils.rs:477-480),
+//                        w < 17.
 //
 // Integer / byte work only: no MFMA.  The tile kernel is VALU bound (two 64-bit mix hashes per position).
 #include "pgr_device.h"
@@ -318,6 +319,7 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     const uint32_t t = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const TileDesc td = a.desc[tile];
+    if (td.skip) return;  // this contig goes through the exact chunk kernel (non-ACGT bytes): uniform exit
     const uint32_t c = td.contig;
     const uint32_t tile_local = td.tile_local;
     const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
@@ -524,29 +526,51 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact state machine (shmmrutils.rs:438-530), one wavefront per contig, event driven:
+// Exact state machine (shmmrutils.rs:438-530), event driven, one wavefront per CHUNK of a contig:
 // positions are hashed 64 at a time, the machine jumps from event to event (rescan R when
 // mdist == w-1, or branch-2 emission B when x <= min_mer.x); between events mdist just counts pushes.
-__global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint32_t *__restrict__ list,
-                                                           const uint64_t *__restrict__ region_off,
-                                                           const uint64_t *__restrict__ region_cap,
-                                                           uint32_t *__restrict__ overflow) {
+//
+// Chunking: a chunk [cs, ce) that does not start at 0 first rebuilds the rolling
+// k-mer (looking back until k valid bases have been seen) and then runs the machine from an empty ring
+// over a warm-up of `warm` positions WITHOUT emitting.  After w pushes the warmed-up state equals the
+// true state whenever the true machine is in its regular regime (min_mer = right-most minimum of the last
+// w pushes); the state at cs is recorded next to the previous chunk's state at its ce so that the host can
+// verify every seam and re-run the rare chunk whose assumption failed with the true state (`override`).
+// Emissions are attributed by the step (position) at which the reference emits them.
+__device__ __forceinline__ uint64_t ring_signature(const uint64_t *s_rx, uint32_t rstart, uint32_t rlen, uint32_t w,
+                                                   uint32_t lane) {
+    uint64_t sig = 0;
+    for (uint32_t q = lane; q < w; q += 64) {
+        const uint64_t v = s_rx[(rstart + q) % w];
+        sig ^= (v + 0x9E3779B97F4A7C15ull * (q + 1)) * (2ull * q + 1);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) sig ^= shfl_xor64(sig, m);
+    return sig + rlen;
+}
+
+__global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkDesc *__restrict__ descs,
+                                                          ChunkState *__restrict__ st_in,
+                                                          ChunkState *__restrict__ st_out,
+                                                          uint32_t *__restrict__ status) {
     __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
     const uint32_t lane = threadIdx.x;
-    const uint32_t c = list[blockIdx.x];
+    const ChunkDesc cd = descs[blockIdx.x];
+    const uint32_t c = cd.contig;
     const uint32_t w = a.w, k = a.k;
     const long long L = a.b.len[c];
     const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
     const uint32_t *__restrict__ vplane = a.b.valid + a.b.word_off[c];
     const long long nwords = (L + 31) >> 5;
-    pgr_mm128 *__restrict__ out = a.out + region_off[blockIdx.x];
-    const uint64_t cap = region_cap[blockIdx.x];
+    pgr_mm128 *__restrict__ out = a.out + cd.region_off;
+    const uint64_t cap = cd.region_cap;
     const uint64_t kmask = U64MAX >> (64 - k);
     const uint32_t shift = k - 1;
     const uint64_t sketch_thr = (U64MAX >> 4) >> a.r;
     // branch 2 enabled for w+k <= pos < Lb; Rust usize arithmetic wraps in release builds
     const uint64_t Lb = (uint64_t)L - (uint64_t)w + (uint64_t)k;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+    const long long cs = (long long)cd.cs, ce = (long long)cd.ce;
 
     s_rx[lane] = U64MAX;
     s_rx[lane + 64] = U64MAX;
@@ -554,23 +578,75 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
     s_ry[lane + 64] = U64MAX;
     __syncthreads();
 
+    // ---- where to start: pm = first position the machine sees, pk = first position the k-mer roll sees
+    long long pm = cs - (long long)cd.warm;
+    if (pm < 0) pm = 0;
+    long long pk = pm;
+    if (pm > 0) {
+        // look back (64 blocks of 64 positions per step) until k valid bases precede pm
+        uint32_t have = 0;
+        long long hi = pm;  // blocks [hi - 64(lane+1), hi - 64 lane)
+        while (have < k && hi > 0) {
+            const long long b0 = hi - 64ll * (lane + 1);
+            uint32_t cnt = 0;
+            if (b0 >= 0) cnt = __popc(vplane[b0 >> 5]) + __popc(vplane[(b0 >> 5) + 1]);
+            const uint32_t incl = wave_incl_sum(cnt);
+            const uint64_t enough = __ballot(have + incl >= k);
+            if (enough) {
+                const int l0 = (int)__ffsll((unsigned long long)enough) - 1;
+                pk = hi - 64ll * (l0 + 1);
+                have = k;
+            } else {
+                have += __shfl(incl, 63, 64);
+                hi -= 64ll * 64;
+                pk = hi > 0 ? hi : 0;
+            }
+        }
+        if (pk < 0) pk = 0;
+    }
+
     uint64_t F0 = 0, F1 = 0, R0 = 0, R1 = 0;  // rolling k-mer planes (uniform)
     uint32_t rlen = 0, rstart = 0, rend = 0;  // ring state (uniform)
     uint64_t min_x = U64MAX, min_y = U64MAX;
     uint64_t mdist = 0;
     uint64_t n_out = 0;
+    uint32_t stat = 0;
 
-    for (long long base = 0; base < L; base += 64) {
-        const long long wj = base >> 5;
-        uint2 p_hi = planes[wj], p_lo = make_uint2(0, 0);
-        uint32_t v_hi = vplane[wj], v_lo = 0;
-        if (wj + 1 < nwords) {
-            p_lo = planes[wj + 1];
-            v_lo = vplane[wj + 1];
+    for (long long base = pk; base < ce; base += 64) {
+        if (base == cs && cs > 0) {
+            // seam: record the warmed-up state, or install the true state handed over by the host
+            const uint64_t sig = ring_signature(s_rx, rstart, rlen, w, lane);
+            if (cd.override_state) {
+                const ChunkState t = cd.in_state;
+                if (t.F0 != F0 || t.F1 != F1 || t.R0 != R0 || t.R1 != R1 || (!a.sketch && t.ring_sig != sig))
+                    stat |= 2u;  // warm-up could not even rebuild the k-mer / ring: whole-contig re-run
+                min_x = t.min_x;
+                min_y = t.min_y;
+                mdist = t.mdist;
+            }
+            if (lane == 0) {
+                ChunkState o;
+                o.min_x = a.sketch ? 0 : min_x;
+                o.min_y = a.sketch ? 0 : min_y;
+                o.mdist = a.sketch ? 0 : mdist;
+                o.F0 = F0;
+                o.F1 = F1;
+                o.R0 = R0;
+                o.R1 = R1;
+                o.ring_sig = a.sketch ? 0 : sig;
+                st_in[blockIdx.x] = o;
+            }
         }
+        const long long wj = base >> 5;
+        uint32_t v_hi = vplane[wj], v_lo = 0;
+        if (wj + 1 < nwords) v_lo = vplane[wj + 1];
+        const uint64_t V = ((uint64_t)v_hi << 32) | v_lo;
+        const bool kmer_only = base < pm;
+        if (kmer_only && V == 0) continue;  // nothing touches the k-mer here (shmmrutils.rs:461-476)
+        uint2 p_hi = planes[wj], p_lo = make_uint2(0, 0);
+        if (wj + 1 < nwords) p_lo = planes[wj + 1];
         const uint64_t P0 = ((uint64_t)p_hi.x << 32) | p_lo.x;  // position base+i at bit 63-i
         const uint64_t P1 = ((uint64_t)p_hi.y << 32) | p_lo.y;
-        const uint64_t V = ((uint64_t)v_hi << 32) | v_lo;
         const long long pos = base + lane;
         uint64_t f0, f1, r0, r1;
         if (V == U64MAX) {
@@ -579,10 +655,10 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
             f1 = (((F1 << lane) << 1) | (P1 >> (63 - lane))) & kmask;
             r0 = (((R0 >> lane) >> 1) | (__brevll((~P0) >> (63 - lane)) >> (64 - k))) & kmask;
             r1 = (((R1 >> lane) >> 1) | (__brevll((~P1) >> (63 - lane)) >> (64 - k))) & kmask;
-            F0 = __shfl((uint32_t)f0, 63, 64) | ((uint64_t)__shfl((uint32_t)(f0 >> 32), 63, 64) << 32);
-            F1 = __shfl((uint32_t)f1, 63, 64) | ((uint64_t)__shfl((uint32_t)(f1 >> 32), 63, 64) << 32);
-            R0 = __shfl((uint32_t)r0, 63, 64) | ((uint64_t)__shfl((uint32_t)(r0 >> 32), 63, 64) << 32);
-            R1 = __shfl((uint32_t)r1, 63, 64) | ((uint64_t)__shfl((uint32_t)(r1 >> 32), 63, 64) << 32);
+            F0 = shfl64(f0, 63);
+            F1 = shfl64(f1, 63);
+            R0 = shfl64(r0, 63);
+            R1 = shfl64(r1, 63);
         } else {
             // bytes outside ACGT do not touch the k-mer (shmmrutils.rs:461-476): roll uniformly
             f0 = f1 = r0 = r1 = 0;
@@ -603,6 +679,8 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
                 }
             }
         }
+        if (kmer_only) continue;
+        const bool emit_on = base >= cs;
         const bool skip = (f0 == r0) && (f1 == r1);
         const bool pushed = !skip && pos >= (long long)k && pos < L;
         uint32_t st;
@@ -611,7 +689,7 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
         const uint64_t y = ((uint64_t)c << 32) | ((uint64_t)pos << 1) | st;
 
         if (a.sketch) {  // shmmrutils.rs:621-628
-            const bool em = pushed && h < sketch_thr;
+            const bool em = emit_on && pushed && h < sketch_thr;
             const uint64_t m = __ballot(em);
             if (em) {
                 const uint64_t o = n_out + __popcll(m & lt_mask);
@@ -628,7 +706,7 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
 
         const uint64_t pmask = __ballot(pushed);
         const bool b_en = (uint64_t)pos >= (uint64_t)(w + k) && (uint64_t)pos < Lb && pos < L;
-        uint32_t cur = 0;  // first unprocessed lane of this chunk
+        uint32_t cur = 0;  // first unprocessed lane of this step
         for (;;) {
             const uint64_t rest = (cur >= 64) ? 0ull : (pmask & (U64MAX << cur));
             if (rest == 0) break;
@@ -644,7 +722,7 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
             const int iB = mB ? (int)__ffsll((unsigned long long)mB) - 1 : 64;
             const int iE = (iB < iR) ? iB : iR;  // B only when strictly before R (R is tested first)
             const uint64_t range = (iE >= 63) ? rest : (rest & ((2ull << iE) - 1));
-            // push every pushed position in [cur, iE] (or to the end of the chunk) into the ring
+            // push every pushed position in [cur, iE] (or to the end of the step) into the ring
             const uint32_t tot = __popcll(range);
             if ((range >> lane) & 1) {
                 const uint32_t rk = __popcll(range & lt_mask);
@@ -662,19 +740,21 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
                 rlen += tot;
             }
             __syncthreads();
-            if (iE == 64) {  // no event in the rest of the chunk
+            if (iE == 64) {  // no event in the rest of the step
                 mdist += tot;
                 break;
             }
             if (iB < iR) {  // branch 2 (shmmrutils.rs:516-527)
                 const uint64_t ex = shfl64(x, iB), ey = shfl64(y, iB);
-                if (lane == 0 && n_out < cap) {
-                    pgr_mm128 mm;
-                    mm.x = ex;
-                    mm.y = ey;
-                    out[n_out] = mm;
+                if (emit_on) {
+                    if (lane == 0 && n_out < cap) {
+                        pgr_mm128 mm;
+                        mm.x = ex;
+                        mm.y = ey;
+                        out[n_out] = mm;
+                    }
+                    n_out += 1;
                 }
-                n_out += 1;
                 min_x = ex;
                 min_y = ey;
                 mdist = 0;
@@ -687,25 +767,27 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
                 const bool e0 = (q0 < w) && x0 == mn, e1 = (q1 < w) && x1 == mn;
                 const uint64_t m0 = __ballot(e0), m1 = __ballot(e1);
                 const uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
-                if (e0) {
-                    const uint64_t o = n_out + __popcll(m0 & lt_mask);
-                    if (o < cap) {
-                        pgr_mm128 mm;
-                        mm.x = x0;
-                        mm.y = s_ry[s0];
-                        out[o] = mm;
+                if (emit_on) {
+                    if (e0) {
+                        const uint64_t o = n_out + __popcll(m0 & lt_mask);
+                        if (o < cap) {
+                            pgr_mm128 mm;
+                            mm.x = x0;
+                            mm.y = s_ry[s0];
+                            out[o] = mm;
+                        }
                     }
-                }
-                if (e1) {
-                    const uint64_t o = n_out + n0 + __popcll(m1 & lt_mask);
-                    if (o < cap) {
-                        pgr_mm128 mm;
-                        mm.x = x1;
-                        mm.y = s_ry[s1];
-                        out[o] = mm;
+                    if (e1) {
+                        const uint64_t o = n_out + n0 + __popcll(m1 & lt_mask);
+                        if (o < cap) {
+                            pgr_mm128 mm;
+                            mm.x = x1;
+                            mm.y = s_ry[s1];
+                            out[o] = mm;
+                        }
                     }
+                    n_out += n0 + n1;
                 }
-                n_out += n0 + n1;
                 const uint32_t qlast = m1 ? (64 + 63 - (uint32_t)__clzll((long long)m1)) : (63 - (uint32_t)__clzll((long long)m0));
                 min_x = mn;
                 min_y = s_ry[(rstart + qlast) % w];
@@ -716,19 +798,35 @@ __global__ __launch_bounds__(64) void level1_serial_kernel(L1Args a, const uint3
             __syncthreads();
         }
     }
-    // this contig's tile segments are void; the whole list lives in the tail segment
-    const uint32_t t0 = a.tile_first[c], t1 = a.tile_first[c + 1];
-    for (uint32_t ti = t0 + lane; ti < t1; ti += 64) a.seg_cnt[ti + c] = 0;
+    // ---- state at the end of the chunk (the next chunk's seam) and the segment entry
+    const uint64_t sig_out = ring_signature(s_rx, rstart, rlen, w, lane);
     if (lane == 0) {
-        const uint32_t sidx = t1 + c;
-        a.seg_off[sidx] = region_off[blockIdx.x];
+        ChunkState o;
+        o.min_x = a.sketch ? 0 : min_x;
+        o.min_y = a.sketch ? 0 : min_y;
+        o.mdist = a.sketch ? 0 : mdist;
+        o.F0 = F0;
+        o.F1 = F1;
+        o.R0 = R0;
+        o.R1 = R1;
+        o.ring_sig = a.sketch ? 0 : sig_out;
+        st_out[blockIdx.x] = o;
+        a.seg_off[cd.seg] = cd.region_off;
         if (n_out > cap || n_out > 0xFFFFFFFFull) {
-            overflow[blockIdx.x] = 1;
-            a.seg_cnt[sidx] = 0;
+            stat |= 1u;  // region too small: the host re-runs this chunk with a full-size region
+            a.seg_cnt[cd.seg] = 0;
         } else {
-            a.seg_cnt[sidx] = (uint32_t)n_out;
+            a.seg_cnt[cd.seg] = (uint32_t)n_out;
         }
+        status[blockIdx.x] = stat;
     }
+}
+
+// every segment (tiles + tail) of the listed contigs becomes empty: their lists come from the chunk kernel
+__global__ void zero_contig_segs_kernel(L1Args a, const uint32_t *__restrict__ list, uint32_t n_list) {
+    const uint32_t c = list[blockIdx.x];
+    const uint32_t s0 = a.tile_first[c] + c, s1 = a.tile_first[c + 1] + c + 1;  // incl. the tail segment
+    for (uint32_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) a.seg_cnt[s] = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -741,7 +839,8 @@ __global__ void tile_desc_kernel(L1Args a) {
     d.len = a.b.len[c];
     d.contig = c;
     d.tile_local = tile - a.tile_first[c];
-    d._pad[0] = d._pad[1] = d._pad[2] = 0;
+    d.skip = a.b.n_invalid[c] ? 1u : 0u;
+    d._pad[0] = d._pad[1] = 0;
     a.desc[tile] = d;
 }
 
@@ -761,11 +860,14 @@ void launch_level1_tails(hipStream_t st, const L1Args &a) {
     if (a.n_contigs == 0) return;
     hipLaunchKernelGGL(level1_tail_kernel, dim3(a.n_contigs), dim3(64), 0, st, a);
 }
-void launch_level1_serial(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list,
-                          const uint64_t *d_region_off, const uint64_t *d_region_cap, uint32_t *d_overflow) {
+void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
+                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status) {
+    if (n_chunks == 0) return;
+    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status);
+}
+void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list) {
     if (n_list == 0) return;
-    hipLaunchKernelGGL(level1_serial_kernel, dim3(n_list), dim3(64), 0, st, a, d_list, d_region_off, d_region_cap,
-                       d_overflow);
+    hipLaunchKernelGGL(zero_contig_segs_kernel, dim3(n_list), dim3(256), 0, st, a, d_list, n_list);
 }
 
 }  // namespace pgr

@@ -70,7 +70,23 @@ struct TileDesc {  // one per tile, written by tile_desc_kernel (saves every wor
     uint32_t len;         // contig length
     uint32_t contig;      // contig index
     uint32_t tile_local;  // tile ordinal inside the contig
-    uint32_t _pad[3];
+    uint32_t skip;        // 1: the contig is handled by the exact chunk kernel, the tile kernel exits
+    uint32_t _pad[2];
+};
+// exact-machine chunks (level1_chunk_kernel)
+struct ChunkState {
+    uint64_t min_x, min_y, mdist;  // min_mer and the distance counter (shmmrutils.rs:450-453, 441)
+    uint64_t F0, F1, R0, R1;       // rolling k-mer planes (fmmer / rmmer)
+    uint64_t ring_sig;             // order-sensitive signature of the ring buffer + its fill
+};
+struct ChunkDesc {
+    uint32_t contig;
+    uint32_t seg;             // segment-table entry this chunk's list goes to
+    uint64_t cs, ce;          // positions [cs, ce), cs a multiple of 64
+    uint64_t region_off, region_cap;
+    uint32_t warm;            // machine warm-up positions before cs (multiple of 64)
+    uint32_t override_state;  // 1: install in_state at cs instead of trusting the warm-up
+    ChunkState in_state;
 };
 struct L1Args {
     BatchDev b;
@@ -90,10 +106,10 @@ struct L1Args {
 };
 void launch_level1_tiles(hipStream_t st, const L1Args &a);
 void launch_level1_tails(hipStream_t st, const L1Args &a);
-// serial (exact state machine) kernel for the contigs listed in d_list
-void launch_level1_serial(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list,
-                          const uint64_t *d_region_off /*[n_list] element offset into out*/,
-                          const uint64_t *d_region_cap /*[n_list]*/, uint32_t *d_overflow /*[n_list]*/);
+// exact state machine, one wavefront per chunk; status bit0 = region overflow, bit1 = override impossible
+void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
+                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status);
+void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list);
 
 // level2.hip
 void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,

@@ -148,6 +148,40 @@ def test_serial_kernel_cases(oracle, gpu_ctx):
     _check_batch(oracle, gpu_ctx, seqs[::5], (80, 56, 4, 64, True), what="serial-sketch")
 
 
+def test_chunked_exact_machine_seams(oracle, gpu_ctx):
+    """long contigs on the exact-machine path: the 32 kbp chunks must agree with the sequential oracle across
+    every seam (N runs over seams, palindromes next to seams, N-only chunks, scattered N, low complexity)"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(17)
+    CS = 32768
+    base = seqgen.rnd(rng, 300000)
+    seqs = []
+    s = bytearray(base)  # single N far from any seam: everything else must be unaffected
+    s[1000] = ord("N")
+    seqs.append(bytes(s))
+    for at in (CS - 1, CS, CS + 1, CS - 56, CS - 80, CS - 136, 2 * CS - 300, 3 * CS + 7):  # N at / around seams
+        s = bytearray(base)
+        s[at] = ord("N")
+        seqs.append(bytes(s))
+    for run, at in ((500, CS - 250), (70000, 20000), (3 * CS, CS // 2), (40, 2 * CS - 20), (CS, CS)):  # N runs over seams
+        seqs.append(base[:at] + b"N" * run + base[at:200000])
+    seqs.append(b"N" * 100000 + base[:50000])  # leading N run longer than 3 chunks
+    seqs.append(base[:50000] + b"N" * 100000)  # trailing
+    for at in (CS - 60, CS - 10, CS + 30, 2 * CS - 100):  # palindromic 56-mers ((AT)n) next to seams
+        seqs.append(base[:at] + b"AT" * 45 + base[at:150000])
+    s = bytearray(base)  # scattered N every ~5 kbp
+    for p in range(777, len(s), 5003):
+        s[p] = ord("n")
+    seqs.append(bytes(s))
+    seqs.append((b"ACGTTGCA" * 20000)[:150000])  # tandem repeat: ties everywhere (tile path, dense slots)
+    seqs.append(b"A" * 70000 + base[:70000] + b"N" + b"C" * 70000)  # homopolymers + N
+    for spec_t in [(80, 56, 4, 64, False), (48, 56, 4, 12, False), (16, 8, 2, 0, False), (80, 56, 4, 64, True)]:
+        sub = seqs if spec_t[0] == 80 and not spec_t[4] else seqs[::3]
+        _check_batch(oracle, gpu_ctx, sub, spec_t, what="chunked")
+    prof = gpu_ctx.last_prof()
+    assert prof.n_serial_contigs > 0
+
+
 def test_ragged_and_empty(oracle, gpu_ctx):
     import pgrtk_amd as P
     sp = P.make_spec()
