@@ -163,6 +163,12 @@ uint64_t pgr_index_n_keys(const pgr_index *ix);
 uint64_t pgr_index_n_records(const pgr_index *ix);
 /* host copy of the sorted records (pgr_free) */
 int pgr_index_download(pgr_ctx *ctx, const pgr_index *ix, pgr_frag_rec **out, uint64_t *n);
+/* .mdb files: write_shmmr_map_file / read_mdb_file (pgr-db/src/seq_db.rs:1291-1326, 1328-1407).  Keys are
+ * written sorted (the reference writes hash-map order; its readers are order agnostic).  load returns a
+ * finalized index carrying the spec stored in the file. */
+int pgr_index_write_mdb(pgr_ctx *ctx, const pgr_index *ix, const char *path);
+int pgr_index_load_mdb(pgr_ctx *ctx, const char *path, pgr_index **out);
+int pgr_index_spec(const pgr_index *ix, pgr_spec *out);
 
 /* ------------------------------------------------------------------ B2: query_fragment_to_hps
  * Replaces SeqIndexDB::query_fragment_to_hps (pgr-db/src/ext.rs:252-282) =

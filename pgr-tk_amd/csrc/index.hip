@@ -807,3 +807,125 @@ extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_h
     }
     return fill_result(ctx, 1, co, out);
 }
+
+// ------------------------------------------------------------------------------------------------
+// .mdb on-disk format (pgr-db/src/seq_db.rs:1291-1326 writer, :1328-1471 readers):
+//   "mdb" | w,k,r,min_span,flags : 5 x u32 LE | n_keys : u64 | n_keys x { h0,h1,n : u64 ; n x {frg_id,sid,bgn,end : u32 ; orient : u8} }
+// The reference writes keys in FxHashMap order (unspecified); here keys are written sorted.  Readers are
+// order agnostic, and so is pgr_index_load_mdb.
+extern "C" int pgr_index_write_mdb(pgr_ctx *ctx, const pgr_index *ix, const char *path) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || !path) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    pgr_frag_rec *recs = nullptr;
+    uint64_t n = 0;
+    int rc = pgr_index_download(ctx, ix, &recs, &n);
+    if (rc) return rc;
+    FILE *f = fopen(path, "wb");
+    if (!f) {
+        free(recs);
+        return ctx->fail(PGR_ERR_INVALID_ARG, std::string("cannot open for writing: ") + path);
+    }
+    std::vector<uint8_t> buf;
+    buf.reserve(1 << 20);
+    auto put = [&](const void *p, size_t len) {
+        const uint8_t *b = (const uint8_t *)p;
+        buf.insert(buf.end(), b, b + len);
+        if (buf.size() >= (1 << 20)) {
+            fwrite(buf.data(), 1, buf.size(), f);
+            buf.clear();
+        }
+    };
+    put("mdb", 3);
+    const uint32_t hdr[5] = {ix->spec.w, ix->spec.k, ix->spec.r, ix->spec.min_span, ix->spec.sketch ? 1u : 0u};
+    put(hdr, sizeof(hdr));
+    const uint64_t nk = ix->n_keys;
+    put(&nk, 8);
+    for (uint64_t i = 0; i < n;) {
+        uint64_t j = i;
+        while (j < n && recs[j].h0 == recs[i].h0 && recs[j].h1 == recs[i].h1) ++j;
+        const uint64_t head[3] = {recs[i].h0, recs[i].h1, j - i};
+        put(head, sizeof(head));
+        for (uint64_t t = i; t < j; ++t) {
+            const uint32_t q[4] = {recs[t].frg_id, recs[t].sid, recs[t].bgn, recs[t].end};
+            put(q, sizeof(q));
+            const uint8_t o = (uint8_t)recs[t].orient;
+            put(&o, 1);
+        }
+        i = j;
+    }
+    if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
+    const bool ok = fclose(f) == 0;
+    free(recs);
+    return ok ? PGR_OK : ctx->fail(PGR_ERR_INVALID_ARG, std::string("write failed: ") + path);
+}
+
+extern "C" int pgr_index_load_mdb(pgr_ctx *ctx, const char *path, pgr_index **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!path || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    FILE *f = fopen(path, "rb");
+    if (!f) return ctx->fail(PGR_ERR_INVALID_ARG, std::string("cannot open: ") + path);
+    fseek(f, 0, SEEK_END);
+    const long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    std::vector<uint8_t> d((size_t)std::max<long>(sz, 0));
+    const size_t got = d.empty() ? 0 : fread(d.data(), 1, d.size(), f);
+    fclose(f);
+    if (got != d.size() || d.size() < 31 || memcmp(d.data(), "mdb", 3) != 0)
+        return ctx->fail(PGR_ERR_INVALID_ARG, std::string("not an .mdb file: ") + path);
+    uint32_t hdr[5];
+    memcpy(hdr, d.data() + 3, 20);
+    uint64_t nk;
+    memcpy(&nk, d.data() + 23, 8);
+    pgr_spec spec = {hdr[0], hdr[1], hdr[2], hdr[3], hdr[4] & 1u};
+    pgr_index *ix = nullptr;
+    int rc = pgr_index_create(ctx, &spec, &ix);
+    if (rc) return rc;
+    std::vector<pgr_frag_rec> recs;
+    size_t off = 31;
+    for (uint64_t kx = 0; kx < nk; ++kx) {
+        if (off + 24 > d.size()) {
+            pgr_index_destroy(ix);
+            return ctx->fail(PGR_ERR_INVALID_ARG, "truncated .mdb");
+        }
+        uint64_t head[3];
+        memcpy(head, d.data() + off, 24);
+        off += 24;
+        if (off + head[2] * 17 > d.size()) {
+            pgr_index_destroy(ix);
+            return ctx->fail(PGR_ERR_INVALID_ARG, "truncated .mdb");
+        }
+        for (uint64_t t = 0; t < head[2]; ++t) {
+            uint32_t q[4];
+            memcpy(q, d.data() + off, 16);
+            pgr_frag_rec r;
+            r.h0 = head[0];
+            r.h1 = head[1];
+            r.frg_id = q[0];
+            r.sid = q[1];
+            r.bgn = q[2];
+            r.end = q[3];
+            r.orient = d[off + 16];
+            r._pad = 0;
+            recs.push_back(r);
+            off += 17;
+        }
+    }
+    rc = pgr_index_add_records(ctx, ix, recs.data(), recs.size(), 0);
+    if (!rc) rc = pgr_index_finalize(ctx, ix);
+    if (rc) {
+        pgr_index_destroy(ix);
+        return rc;
+    }
+    uint32_t mx = 0;
+    for (const auto &r : recs) mx = std::max(mx, r.sid + 1);
+    ix->next_sid = mx;
+    *out = ix;
+    return PGR_OK;
+}
+
+extern "C" int pgr_index_spec(const pgr_index *ix, pgr_spec *out) {
+    if (!ix || !out) return PGR_ERR_INVALID_ARG;
+    *out = ix->spec;
+    return PGR_OK;
+}

@@ -82,6 +82,9 @@ _SIGS = [
     ("pgr_index_n_keys", C.c_uint64, [_VP]),
     ("pgr_index_n_records", C.c_uint64, [_VP]),
     ("pgr_index_download", C.c_int, [_VP, _VP, _PVP, C.POINTER(C.c_uint64)]),
+    ("pgr_index_write_mdb", C.c_int, [_VP, _VP, C.c_char_p]),
+    ("pgr_index_load_mdb", C.c_int, [_VP, C.c_char_p, _PVP]),
+    ("pgr_index_spec", C.c_int, [_VP, C.POINTER(Spec)]),
     ("pgr_query_hps_batch", C.c_int, [_VP, _VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.c_float, C.c_uint32,
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                       C.POINTER(HpsResult)]),

@@ -1,0 +1,194 @@
+"""Command-line counterparts of the reference's callers of the hot path:
+
+  python -m pgrtk_amd.cli mdb   <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch]
+        pgr-mdb (pgr-bin/src/bin/pgr-mdb.rs:26-111): builds <prefix>.mdb + <prefix>.midx.  The reference reads
+        AGC archives; AGC is not available here, so <filelist> lists FASTA/FASTQ(.gz) files.  Index-only path
+        (seq_db.rs:541-615): fragment id = pair ordinal in the contig.
+  python -m pgrtk_amd.cli query <db> <query.fa> <out_prefix> [--fastx_file | (default) .mdb/.midx prefix] ...
+        pgr-query (pgr-bin/src/bin/pgr-query.rs:17-409): chains -> per-target regions -> <out>.NNN.hit[.bed]
+        (and <out>.NNN.fa with --fastx_file unless --only_summary).
+
+Sequence iteration, range merging and file writing are host code, as in the reference; shimmers, the
+frag_map and the chaining run on the GPU.
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+from .engine import Index, make_spec
+from .seqindexdb import SeqIndexDB, read_fastx
+
+_COMP = np.zeros(256, dtype=np.uint8)
+_COMP[:] = np.arange(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
+    _COMP[_a] = _b
+
+
+def reverse_complement(seq):
+    """pgr-db/src/fasta_io.rs:26-44"""
+    return _COMP[np.frombuffer(seq, dtype=np.uint8)][::-1].tobytes()
+
+
+# ----------------------------------------------------------------------------- pgr-mdb
+def cmd_mdb(args):
+    spec = make_spec(args.w, args.k, args.r, args.min_span, args.sketch)
+    ix = Index(spec)
+    paths = [l.strip() for l in open(args.filepath) if l.strip()]
+    midx = []
+    sid = 0
+    for path in paths:
+        recs = read_fastx(path)
+        if args.reference_sid_quirk:
+            sid = 0  # load_index_from_reader restarts at 0 for every input (seq_db.rs:543)
+        # the reference feeds batches of <= 129 contigs (seq_db.rs:549-564); one GPU batch per ~2 Gbp here
+        i = 0
+        while i < len(recs):
+            j, tot = i, 0
+            while j < len(recs) and (j == i or tot + len(recs[j][1]) <= args.batch_bp):
+                tot += len(recs[j][1])
+                j += 1
+            ix.add_seqs([s for _, s in recs[i:j]], sids=list(range(sid, sid + (j - i))))
+            for name, s in recs[i:j]:
+                midx.append((sid, len(s), name, path))
+                sid += 1
+            i = j
+    ix.finalize()
+    ix.ctx.check(__import__("pgrtk_amd")._ffi.lib().pgr_index_write_mdb(ix.ctx.handle, ix._h, (args.prefix + ".mdb").encode()))
+    with open(args.prefix + ".midx", "w") as f:  # seq_db.rs:798-805
+        for sid_, ln, name, src in midx:
+            f.write("%d\t%d\t%s\t%s\n" % (sid_, ln, name, src))
+    print("%d sequences, %d shimmer pairs, %d keys -> %s.mdb / .midx" % (len(midx), ix.n_records, ix.n_keys, args.prefix),
+          file=sys.stderr)
+
+
+# ----------------------------------------------------------------------------- pgr-query post-processing
+def chains_to_regions(query_result, merge_range_tol):
+    """pgr-query.rs:167-285 for ONE query: [(sid, [(score, [hit pairs])])] -> {sid: [(bgn, end, len, orientation, aln)]}.
+    Keeps the reference's quirks: only chains with more than 2 hit pairs; the forward / reverse counters are
+    NOT reset between the chains of a target (:171-183); regions are merged per orientation when the gap to
+    the previous region is below merge_range_tol."""
+    sid_to_alns = {}
+    for sid, alns in query_result:
+        f_count = r_count = 0
+        for _score, aln in alns:
+            if len(aln) > 2:
+                for hp in aln:
+                    if hp[0][2] == hp[1][2]:
+                        f_count += 1
+                    else:
+                        r_count += 1
+                orientation = 0 if f_count > r_count else 1
+                sid_to_alns.setdefault(sid, []).append((aln, orientation))
+    out = {}
+    for sid, alns in sid_to_alns.items():
+        rgns = []
+        for aln, orientation in alns:
+            tc = sorted((hp[1][0], hp[1][1]) for hp in aln)
+            bgn, end = tc[0][0], tc[-1][1]
+            rgns.append((bgn, end, end - bgn, orientation, list(aln)))
+        merged = []
+        for ori in (0, 1):
+            last = None
+            for r in sorted((x for x in rgns if x[3] == ori), key=lambda x: (x[0], x[1], x[2], x[3], x[4])):
+                if last is None:
+                    last = r
+                elif r[0] - last[1] < merge_range_tol:
+                    end = max(r[1], last[1])
+                    last = (last[0], end, end - last[0], last[3], last[4] + r[4])
+                else:
+                    merged.append(last)
+                    last = r
+            if last is not None and last[2] > 0:
+                merged.append(last)
+        out[sid] = merged
+    return out
+
+
+def cmd_query(args):
+    sdb = SeqIndexDB()
+    seqs_by_sid = None
+    if args.fastx_file:
+        sdb.load_from_fastx(args.pgr_db_prefix, args.w, args.k, args.r, args.min_span)
+        if not args.only_summary:
+            seqs_by_sid = {i: s for i, (_, s) in enumerate(read_fastx(args.pgr_db_prefix))}
+    else:
+        sdb.load_from_mdb_index(args.pgr_db_prefix)
+    queries = read_fastx(args.query_fastx_path)
+    results = sdb.query_fragments_to_hps([s for _, s in queries], args.gap_penalty_factor, args.max_count,
+                                         args.max_query_count, args.max_target_count, args.max_aln_chain_span, None, False)
+    for idx, ((q_name, q_seq), qr) in enumerate(zip(queries, results)):
+        regions = chains_to_regions(qr, args.merge_range_tol)
+        ext = "%03d.hit.bed" % idx if args.bed_summary else "%03d.hit" % idx
+        fa_recs = []
+        with open(args.output_prefix + "." + ext, "w") as hit:
+            if args.bed_summary:
+                hit.write("#" + "\t".join(["target", "bgn", "end", "query", "color", "orientation", "q_len",
+                                           "aln_anchor_count", "q_idx", "src", "ctg_bgn", "ctg_end"]) + "\n")
+            else:
+                hit.write("#" + "\t".join(["idx", "q_ctg_name", "q_ctg_bgn", "q_ctg_end", "q_ctg_len", "aln_anchor_count",
+                                           "src", "ctg", "ctg_bgn", "ctg_end", "orientation", "ctg_name"]) + "\n")
+            for sid in sorted(regions):
+                ctg, src, _ = sdb.seq_info[sid]
+                src = src if src is not None else "N/A"
+                base = os.path.splitext(os.path.basename(src))[0]
+                for b, e, _, orientation, aln in regions[sid]:
+                    aln = sorted(aln)
+                    q_bgn, q_end = aln[0][0][0], aln[-1][0][1]
+                    tname = "%s::%s_%d_%d_%d" % (base, ctg, b, e, orientation)
+                    if args.bed_summary:
+                        hit.write("\t".join(str(v) for v in [ctg, b, e, q_name, "#AAAAAA", orientation, len(q_seq), len(aln),
+                                                             idx, src, q_bgn, q_end, tname]) + "\n")
+                    else:
+                        hit.write("\t".join(str(v) for v in ["%03d" % idx, q_name, q_bgn, q_end, len(q_seq), len(aln), src,
+                                                             ctg, b, e, orientation, tname]) + "\n")
+                    fa_recs.append((sid, b, e, orientation, tname))
+        if seqs_by_sid is not None:
+            with open(args.output_prefix + ".%03d.fa" % idx, "w") as fa:
+                for sid, b, e, orientation, tname in fa_recs:
+                    t = seqs_by_sid[sid][b:e]
+                    if orientation == 1:
+                        t = reverse_complement(t)
+                    fa.write(">%s\n%s\n" % (tname, t.decode("ascii", "replace")))
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="pgrtk_amd.cli")
+    sub = ap.add_subparsers(dest="cmd", required=True)
+    m = sub.add_parser("mdb", help="pgr-mdb counterpart: FASTA list -> .mdb/.midx")
+    m.add_argument("filepath")
+    m.add_argument("prefix")
+    m.add_argument("-w", type=int, default=80)
+    m.add_argument("-k", type=int, default=56)
+    m.add_argument("-r", type=int, default=4)
+    m.add_argument("-m", "--min-span", dest="min_span", type=int, default=64)
+    m.add_argument("--sketch", action="store_true")
+    m.add_argument("--batch-bp", type=int, default=2_000_000_000)
+    m.add_argument("--reference-sid-quirk", action="store_true",
+                   help="restart sequence ids at 0 for every input file, like load_index_from_reader (seq_db.rs:543)")
+    m.set_defaults(fn=cmd_mdb)
+    q = sub.add_parser("query", help="pgr-query counterpart")
+    q.add_argument("pgr_db_prefix")
+    q.add_argument("query_fastx_path")
+    q.add_argument("output_prefix")
+    q.add_argument("--fastx_file", action="store_true")
+    q.add_argument("-w", type=int, default=80)
+    q.add_argument("-k", type=int, default=56)
+    q.add_argument("-r", type=int, default=4)
+    q.add_argument("-m", "--min-span", dest="min_span", type=int, default=64)
+    q.add_argument("-g", "--gap-penalty-factor", dest="gap_penalty_factor", type=float, default=0.025)
+    q.add_argument("--merge-range-tol", dest="merge_range_tol", type=int, default=100000)
+    q.add_argument("--max-count", dest="max_count", type=int, default=128)
+    q.add_argument("--max-query-count", dest="max_query_count", type=int, default=128)
+    q.add_argument("--max-target-count", dest="max_target_count", type=int, default=128)
+    q.add_argument("--max-aln-chain-span", dest="max_aln_chain_span", type=int, default=8)
+    q.add_argument("--only-summary", dest="only_summary", action="store_true")
+    q.add_argument("--bed-summary", dest="bed_summary", action="store_true")
+    q.set_defaults(fn=cmd_query)
+    args = ap.parse_args(argv)
+    args.fn(args)
+
+
+if __name__ == "__main__":
+    main()

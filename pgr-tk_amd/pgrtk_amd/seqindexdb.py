@@ -151,6 +151,26 @@ class SeqIndexDB:
         self.backend = "MEMORY"
         self._append([(n, bytes(s)) for n, s in seq_list], source)
 
+    def load_from_mdb_index(self, prefix):
+        """index-file backend (the reference's AGC / FRG backends load the same `.mdb` + `.midx` pair:
+        ext.rs:87-150, seq_db.rs:1328-1471): the frag_map goes to the GPU, names come from the .midx.
+        Fragment ids are the ones stored in the file."""
+        self.close()
+        self._ix = C.c_void_p()
+        self.ctx.check(lib().pgr_index_load_mdb(self.ctx.handle, (prefix + ".mdb").encode(), C.byref(self._ix)))
+        sp = _ffi.Spec()
+        lib().pgr_index_spec(self._ix, C.byref(sp))
+        self._spec = sp
+        self.backend = "MDB"
+        self.seq_index, self.seq_info, self._host = {}, {}, None
+        with open(prefix + ".midx") as f:
+            for line in f:
+                sid, ln, name, source = line.rstrip("\n").split("\t")
+                source = None if source == "-" else source
+                self.seq_index[(name, source)] = (int(sid), int(ln))
+                self.seq_info[int(sid)] = (name, source, int(ln))
+        self._n_seqs = (max(self.seq_info) + 1) if self.seq_info else 0
+
     def close(self):
         if getattr(self, "_ix", None):
             lib().pgr_index_destroy(self._ix)
@@ -169,11 +189,12 @@ class SeqIndexDB:
             p, n = C.c_void_p(), C.c_uint64()
             self.ctx.check(lib().pgr_index_download(self.ctx.handle, self._ix, C.byref(p), C.byref(n)))
             recs = _ffi.take(p, int(n.value), FRAG_REC)
-            # FASTX/MEMORY backends number fragments globally (seq_db.rs:189-357): per sequence
-            # Prefix +1, one per pair, Suffix +1; a sequence without pairs takes 2 ids.
-            pairs = np.bincount(recs["sid"], minlength=self._n_seqs).astype(np.int64)
-            base = np.concatenate([[0], np.cumsum(np.where(pairs == 0, 2, pairs + 2))])[:-1]
-            recs["frg_id"] = (base[recs["sid"]] + 1 + recs["frg_id"]).astype(np.uint32)
+            if self.backend in ("FASTX", "MEMORY"):
+                # FASTX/MEMORY backends number fragments globally (seq_db.rs:189-357): per sequence
+                # Prefix +1, one per pair, Suffix +1; a sequence without pairs takes 2 ids.
+                pairs = np.bincount(recs["sid"], minlength=self._n_seqs).astype(np.int64)
+                base = np.concatenate([[0], np.cumsum(np.where(pairs == 0, 2, pairs + 2))])[:-1]
+                recs["frg_id"] = (base[recs["sid"]] + 1 + recs["frg_id"]).astype(np.uint32)
             keys = {}
             if len(recs):
                 chg = np.flatnonzero((recs["h0"][1:] != recs["h0"][:-1]) | (recs["h1"][1:] != recs["h1"][:-1])) + 1

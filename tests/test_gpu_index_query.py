@@ -211,3 +211,50 @@ def test_get_shmmr_pairs_from_seq(oracle, gpu_ctx):
         sh = oracle.sequence_to_shmmrs(0, s, oracle.spec(80, 56, 4, 16), pad)
         ref = oracle.frag_recs(sh, 0, query_side=True)
         assert got == [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in ref]
+
+
+def test_cli_mdb_and_query(oracle, gpu_ctx, golden_dir, tmp_path):
+    """pgr-mdb / pgr-query counterparts end to end: index-only .mdb (per-contig fragment ids) == the golden
+    frag_map after undoing the FASTX-backend renumbering; the index file round-trips through the GPU; a query
+    cut out of a contig is reported on that contig at the right place."""
+    import pgrtk_amd as P
+    from pgrtk_amd import cli
+    fa = os.path.join(golden_dir, "test_seqs.fa")
+    lst = tmp_path / "list.txt"
+    lst.write_text(fa + "\n")
+    prefix = str(tmp_path / "idx")
+    cli.main(["mdb", str(lst), prefix])
+    spec_t, m = oracle.read_mdb(prefix + ".mdb")
+    _, g = oracle.read_mdb(os.path.join(golden_dir, "test_seqs_frag.mdb"))
+    assert spec_t == (80, 56, 4, 64, 0) and set(m) == set(g)
+    # golden ids are global (Prefix +1, pairs, Suffix +1 per sequence); the index-only path numbers per contig
+    recs = oracle.read_fasta(fa)
+    pairs = [0] * len(recs)
+    for v in g.values():
+        for s in v:
+            pairs[s[1]] += 1
+    base, acc = [], 0
+    for c in pairs:
+        base.append(acc)
+        acc += 2 if c == 0 else c + 2
+    for key, sigs in g.items():
+        assert [(s[0] - base[s[1]] - 1, s[1], s[2], s[3], s[4]) for s in sigs] == m[key]
+    assert open(prefix + ".midx").read().splitlines()[0].split("\t")[:3] == ["0", "3385", recs[0][0].decode()]
+    # query through the index file
+    qfa = tmp_path / "q.fa"
+    src = recs[5][1]
+    qfa.write_text(">q0 some comment\n%s\n>q1\n%s\n" % (src[200:3000].decode(), P.cli.reverse_complement(src[100:3300]).decode()))
+    out = str(tmp_path / "res")
+    cli.main(["query", prefix, str(qfa), out, "--only-summary"])
+    for i in (0, 1):
+        lines = [l.split("\t") for l in open(out + ".%03d.hit" % i).read().splitlines() if not l.startswith("#")]
+        assert any(l[7] == recs[5][0].decode() for l in lines)  # the source contig is among the targets
+    # same query against the FASTA directly (FASTX backend) + sequences of the hit regions
+    cli.main(["query", fa, str(qfa), out + "_fx", "--fastx_file"])
+    a = [l.split("\t")[1:11] for l in open(out + ".000.hit").read().splitlines() if not l.startswith("#")]
+    b = [l.split("\t")[1:11] for l in open(out + "_fx.000.hit").read().splitlines() if not l.startswith("#")]
+    assert [x[:5] + x[6:] for x in a] == [x[:5] + x[6:] for x in b]  # identical but for the src column
+    assert os.path.getsize(out + "_fx.000.fa") > 0
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_mdb_index(prefix)
+    assert sdb.get_shmmr_map() == m and sdb.get_shmmr_spec() == (80, 56, 4, 64, False)
