@@ -8,6 +8,10 @@
 #include "pgr_device.h"
 #include "pgr_internal.h"
 
+#ifndef PGR_ABLATE_L2
+#define PGR_ABLATE_L2 0  // timing experiments only
+#endif
+
 namespace pgr {
 
 // ------------------------------------------------------------------ ordered gather
@@ -137,74 +141,96 @@ namespace {
 
 constexpr int FUSED_T = 256;
 constexpr int FUSED_B = 1024;
-constexpr int FUSED_EMAX = FUSED_B + 2 * 288;  // r = 12
+constexpr int FUSED_EMAX_BIG = FUSED_B + 2 * 288;   // r <= 12
+constexpr int FUSED_EMAX_SMALL = FUSED_B + 2 * 32;  // r <= 4 (the common spec): 22 KB of LDS, 7 workgroups / CU
 
-struct FusedLds {
-    uint64_t x[FUSED_EMAX];
-    uint64_t y[FUSED_EMAX];
-    uint16_t s1[FUSED_EMAX];
-    uint16_t s2[FUSED_EMAX];
-    uint32_t wsum[FUSED_T / 64];
-    unsigned long long base;
+constexpr int FUSED_SEGS = 64;  // segment descriptors staged per round
+
+template <int EMAX>
+struct FusedLdsT {
+    static constexpr int CMAX = (EMAX + FUSED_T - 1) / FUSED_T;  // items per lane, lane-strided (k = j*256 + t)
+    uint64_t x[EMAX];
+    uint64_t y[EMAX];
+    uint16_t s1[EMAX];
+    uint16_t s2[EMAX];
+    uint32_t cnt[CMAX][FUSED_T / 64];   // per (j, wave) survivor counts
+    uint32_t base[CMAX][FUSED_T / 64];  // their exclusive prefix in (j, wave) order
+    uint32_t total;
+    uint64_t sdst[FUSED_SEGS + 1];  // logical start of the staged segments (+ sentinel)
+    uint64_t soff[FUSED_SEGS];      // physical offset
+    uint32_t n_seg;
+    unsigned long long base_out;
 };
 
-// ordered compaction helper: thread t owns items [t*C, (t+1)*C); returns exclusive rank of its first item,
-// total through *total.  All threads must call.
-__device__ __forceinline__ uint32_t block_excl_scan(uint32_t cnt, uint32_t *wsum, uint32_t *total) {
-    const uint32_t incl = wave_incl_sum(cnt);
+// Ordered compaction for lane-strided items k = j*256 + t (consecutive lanes <-> consecutive elements, so
+// the neighbour reads of the predicates are LDS-conflict free).  keep[j] per lane -> rank of every kept item
+// in k order.  Two barriers per call; `ballots` come back for the caller's popcount.
+template <int CM, class FusedLds>
+__device__ __forceinline__ void strided_ranks(FusedLds &L, const bool (&keep)[CM], int C, uint32_t (&rank)[CM],
+                                              uint32_t *total) {
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    __syncthreads();  // wsum reuse
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    uint32_t base = 0, tot = 0;
+    const uint64_t lt = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+    uint64_t bal[CM];
 #pragma unroll
-    for (int i = 0; i < FUSED_T / 64; ++i) {
-        const uint32_t v = wsum[i];
-        if (i < (int)wv) base += v;
-        tot += v;
+    for (int j = 0; j < CM; ++j) {
+        bal[j] = (j < C) ? __ballot(keep[j]) : 0ull;
+        if (j < C && lane == 0) L.cnt[j][wv] = (uint32_t)__popcll(bal[j]);
     }
-    *total = tot;
-    return base + incl - cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t acc = 0;
+        for (int j = 0; j < C; ++j)
+            for (int v = 0; v < FUSED_T / 64; ++v) {
+                L.base[j][v] = acc;
+                acc += L.cnt[j][v];
+            }
+        L.total = acc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CM; ++j) rank[j] = (j < C) ? L.base[j][wv] + (uint32_t)__popcll(bal[j] & lt) : 0u;
+    *total = L.total;
 }
 
-// reduce predicate on an indexed LDS list: list[k] -> element index e; neighbours must share the contig id
-__device__ __forceinline__ bool reduce_keep_lds(const FusedLds &L, const uint16_t *list, int n, int k, uint32_t r,
+// reduce predicate on an indexed LDS list: list[k] -> element index e; neighbours must share the contig id.
+// Branch-free over the 2(r-1) neighbours: all LDS reads are issued up front (a loop with an early exit is a
+// chain of dependent ~100-cycle LDS round trips and made this kernel latency bound).  TR = compile-time r
+// (0: runtime).
+template <int TR, class FusedLds>
+__device__ __forceinline__ bool reduce_keep_lds(const FusedLds &L, const uint16_t *list, int n, int k, uint32_t r_rt,
                                                 uint32_t padding, bool lo_is_start, bool hi_is_end) {
+    const uint32_t r = TR ? (uint32_t)TR : r_rt;
     const int e = list ? list[k] : k;
     const uint64_t xi = L.x[e];
     const uint32_t cid = (uint32_t)(L.y[e] >> 32);
     uint32_t a = 0, b = 0;
-    for (uint32_t d = 1; d < r; ++d) {
-        const int kk = k - (int)d;
-        bool boundary = kk < 0;
-        int ee = 0;
-        if (!boundary) {
-            ee = list ? list[kk] : kk;
-            boundary = (uint32_t)(L.y[ee] >> 32) != cid;
-        }
-        if (boundary) {
-            // a true list / contig boundary: with padding the virtual sentinels are >= everything.
+    bool run_a = true, run_b = true;
+#pragma unroll
+    for (uint32_t d = 1; d < (TR ? (uint32_t)TR : 12u); ++d) {
+        if (!TR && d >= r) break;
+        // left neighbour
+        {
+            const int kk = k - (int)d;
+            const bool inside = kk >= 0;
+            const int ee = inside ? (list ? list[kk] : kk) : e;
+            const bool same = inside && (uint32_t)(L.y[ee] >> 32) == cid;
+            // a true list / contig boundary: with padding the virtual sentinels are >= everything
             // (kk < 0 with !lo_is_start is a loading edge: only reached by far-halo elements)
-            if (padding && (kk >= 0 || lo_is_start)) a = r - 1;
-            break;
+            const bool virt = !same && padding && (inside || lo_is_start);
+            const bool ge = same ? (L.x[ee] >= xi) : virt;
+            run_a = run_a && ge;
+            a += run_a ? 1u : 0u;
         }
-        if (L.x[ee] >= xi) ++a;
-        else break;
-    }
-    for (uint32_t d = 1; d < r; ++d) {
-        const int kk = k + (int)d;
-        bool boundary = kk >= n;
-        int ee = 0;
-        if (!boundary) {
-            ee = list ? list[kk] : kk;
-            boundary = (uint32_t)(L.y[ee] >> 32) != cid;
+        {
+            const int kk = k + (int)d;
+            const bool inside = kk < n;
+            const int ee = inside ? (list ? list[kk] : kk) : e;
+            const bool same = inside && (uint32_t)(L.y[ee] >> 32) == cid;
+            const bool virt = !same && padding && (inside || hi_is_end);
+            const bool ge = same ? (L.x[ee] >= xi) : virt;
+            run_b = run_b && ge;
+            b += run_b ? 1u : 0u;
         }
-        if (boundary) {
-            if (padding && (kk < n || hi_is_end)) b = r - 1;
-            break;
-        }
-        if (L.x[ee] >= xi) ++b;
-        else break;
     }
     return a + b + 1 >= r;
 }
@@ -212,10 +238,13 @@ __device__ __forceinline__ bool reduce_keep_lds(const FusedLds &L, const uint16_
 }  // namespace
 
 // FusedArgsPub (pgr_internal.h): l1 = unordered level-1 segments; seg_dst = exclusive scan of seg_cnt
-// ([n_segs+1]); out = cursor-allocated block segments; cursor[0] allocated, [1] overflow.
+// ([n_segs+1]); out = fixed block slots + overflow region; cursor[0] overflow allocated, [1] overflow flag.
 using FusedArgs = FusedArgsPub;
 
+template <int EMAX>
 __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
+    using FusedLds = FusedLdsT<EMAX>;
+    constexpr int FUSED_CMAX = FusedLds::CMAX;
     __shared__ FusedLds L;
     const uint32_t t = threadIdx.x;
     const uint64_t core_lo = (uint64_t)blockIdx.x * FUSED_B;
@@ -227,29 +256,44 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     const int ne = (int)(hi - lo);
     const bool lo_is_start = (lo == 0), hi_is_end = (hi == a.total);
 
-    // ---- stream the segments of [lo, hi) into LDS; the segment holding `lo` was located by
-    // block_first_seg_kernel (a 22-step dependent binary search per workgroup here would dominate)
-    {
-        const uint32_t wv = t >> 6, lane = t & 63;
-        const uint32_t first_seg = a.blk_first_seg[blockIdx.x];
-        for (uint32_t s = first_seg + wv; s < a.n_segs; s += FUSED_T / 64) {
-            const uint64_t d0 = a.seg_dst[s];
-            if (d0 >= hi) break;
-            const uint32_t cnt = a.seg_cnt[s];
-            if (cnt == 0) continue;
-            const uint64_t b0 = d0 > lo ? d0 : lo;                  // logical range of this segment inside [lo, hi)
-            const uint64_t b1 = (d0 + cnt) < hi ? (d0 + cnt) : hi;
-            const pgr_mm128 *src = a.l1 + a.seg_off[s] + (b0 - d0);
-            const int dst = (int)(b0 - lo);
-            for (int i = lane; i < (int)(b1 - b0); i += 64) {
-                const pgr_mm128 m = src[i];
-                L.x[dst + i] = m.x;
-                L.y[dst + i] = m.y;
-            }
+    // ---- stream [lo, hi) of the logical level-1 list into LDS.  Segment descriptors are staged 64 at a time
+    // (the segment holding `lo` was located by block_first_seg_kernel); then every lane fetches its own
+    // elements (k = j*256 + t) independently: ~5 outstanding 16-byte loads per lane.
+    uint32_t seg0 = a.blk_first_seg[blockIdx.x];
+    uint64_t done = lo;  // logical elements below `done` are loaded
+    while (done < hi) {
+        if (t < FUSED_SEGS + 1) {
+            const uint32_t sg = seg0 + t;
+            const uint64_t d = (sg <= a.n_segs) ? a.seg_dst[sg] : a.total;  // seg_dst[n_segs] = total
+            L.sdst[t] = d;
+            if (t < FUSED_SEGS) L.soff[t] = (sg < a.n_segs) ? a.seg_off[sg] : 0;
         }
+        __syncthreads();
+        // elements covered by the staged descriptors: [sdst[0], sdst[64]) intersected with [done, hi)
+        const uint64_t cover_hi = L.sdst[FUSED_SEGS] < hi ? L.sdst[FUSED_SEGS] : hi;
+        for (uint64_t g = done + t; g < cover_hi; g += FUSED_T) {
+            int s_lo = 0, s_hi = FUSED_SEGS;  // largest s with sdst[s] <= g
+            while (s_hi - s_lo > 1) {
+                const int mid = (s_lo + s_hi) >> 1;
+                if (L.sdst[mid] <= g) s_lo = mid;
+                else s_hi = mid;
+            }
+            const pgr_mm128 m = a.l1[L.soff[s_lo] + (g - L.sdst[s_lo])];
+            L.x[g - lo] = m.x;
+            L.y[g - lo] = m.y;
+        }
+        done = cover_hi > done ? cover_hi : done;
+        seg0 += FUSED_SEGS;
+        __syncthreads();
+        if (seg0 >= a.n_segs && done < hi) break;  // cannot happen: seg_dst[n_segs] == total >= hi
     }
-    __syncthreads();
 
+#if PGR_ABLATE_L2 == 1
+    if (L.x[t] != 0x1234567ull) {  // load only
+        if (t == 0) { a.blk_off[blockIdx.x] = 0; a.blk_cnt[blockIdx.x] = 0; }
+        return;
+    }
+#endif
     // ---- reduce x2 (shmmrutils.rs:533-535) on index lists, then the min_span stencil (:536-555)
     const uint16_t *cur = nullptr;  // nullptr = identity list over [0, ne)
     int n_cur = ne;
@@ -257,19 +301,23 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
         for (int round = 0; round < 2; ++round) {
             uint16_t *dstl = round == 0 ? L.s1 : L.s2;
             const int C = (n_cur + FUSED_T - 1) / FUSED_T;
-            const int k0 = (int)t * C;
-            uint32_t flags = 0, cnt = 0;  // C <= 7
-            for (int j = 0; j < C; ++j) {
-                const int k = k0 + j;
-                if (k < n_cur && reduce_keep_lds(L, cur, n_cur, k, a.r, a.padding, lo_is_start, hi_is_end)) {
-                    flags |= 1u << j;
-                    ++cnt;
-                }
+            bool keep[FUSED_CMAX];
+            uint32_t rank[FUSED_CMAX];
+#pragma unroll
+            for (int j = 0; j < FUSED_CMAX; ++j) {
+                const int k = j * FUSED_T + (int)t;
+                keep[j] = (j < C) && k < n_cur &&
+                          (a.r == 4 ? reduce_keep_lds<4, FusedLds>(L, cur, n_cur, k, 4, a.padding, lo_is_start, hi_is_end)
+                                    : reduce_keep_lds<0, FusedLds>(L, cur, n_cur, k, a.r, a.padding, lo_is_start, hi_is_end));
             }
             uint32_t tot;
-            uint32_t o = block_excl_scan(cnt, L.wsum, &tot);
-            for (int j = 0; j < C; ++j)
-                if (flags & (1u << j)) dstl[o++] = (uint16_t)(cur ? cur[k0 + j] : (k0 + j));
+            strided_ranks<FUSED_CMAX, FusedLds>(L, keep, C, rank, &tot);
+#pragma unroll
+            for (int j = 0; j < FUSED_CMAX; ++j)
+                if (keep[j]) {
+                    const int k = j * FUSED_T + (int)t;
+                    dstl[rank[j]] = (uint16_t)(cur ? cur[k] : k);
+                }
             __syncthreads();
             cur = dstl;
             n_cur = (int)tot;
@@ -277,35 +325,37 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     }
     // span filter over `cur`; survivors that are core elements are emitted in order
     const int c_lo = (int)(core_lo - lo), c_hi = (int)(core_hi - lo);
-    uint32_t flags = 0, cnt = 0;
     const int C = (n_cur + FUSED_T - 1) / FUSED_T;
-    const int k0 = (int)t * C;
-    for (int j = 0; j < C; ++j) {
-        const int k = k0 + j;
-        if (k >= n_cur) break;
-        const int e = cur ? cur[k] : k;
-        if (e < c_lo || e >= c_hi) continue;
-        const uint64_t ye = L.y[e];
-        const uint32_t cid = (uint32_t)(ye >> 32);
-        bool keep = true;
-        const bool has_p = k > 0, has_n = k + 1 < n_cur;
-        const int ep = has_p ? (cur ? cur[k - 1] : k - 1) : 0;
-        const int en = has_n ? (cur ? cur[k + 1] : k + 1) : 0;
-        const bool first = !has_p || (uint32_t)(L.y[ep] >> 32) != cid;
-        const bool last = !has_n || (uint32_t)(L.y[en] >> 32) != cid;
-        if (!first && !last) {
-            const uint32_t pp = (uint32_t)((L.y[ep] & 0xFFFFFFFFull) >> 1), mp = (uint32_t)((ye & 0xFFFFFFFFull) >> 1),
-                           np = (uint32_t)((L.y[en] & 0xFFFFFFFFull) >> 1);
-            keep = (uint32_t)(mp - pp) > a.min_span && (uint32_t)(np - mp) > a.min_span && L.x[ep] != L.x[e] &&
-                   L.x[e] != L.x[en];
+    bool keep[FUSED_CMAX];
+    uint32_t rank[FUSED_CMAX];
+#pragma unroll
+    for (int j = 0; j < FUSED_CMAX; ++j) {
+        const int k = j * FUSED_T + (int)t;
+        bool kp = false;
+        if (j < C && k < n_cur) {
+            const int e = cur ? cur[k] : k;
+            if (e >= c_lo && e < c_hi) {
+                const uint64_t ye = L.y[e];
+                const uint32_t cid = (uint32_t)(ye >> 32);
+                const bool has_p = k > 0, has_n = k + 1 < n_cur;
+                const int ep = has_p ? (cur ? cur[k - 1] : k - 1) : 0;
+                const int en = has_n ? (cur ? cur[k + 1] : k + 1) : 0;
+                const bool first = !has_p || (uint32_t)(L.y[ep] >> 32) != cid;
+                const bool last = !has_n || (uint32_t)(L.y[en] >> 32) != cid;
+                kp = true;
+                if (!first && !last) {
+                    const uint32_t pp = (uint32_t)((L.y[ep] & 0xFFFFFFFFull) >> 1),
+                                   mp = (uint32_t)((ye & 0xFFFFFFFFull) >> 1),
+                                   np = (uint32_t)((L.y[en] & 0xFFFFFFFFull) >> 1);
+                    kp = (uint32_t)(mp - pp) > a.min_span && (uint32_t)(np - mp) > a.min_span && L.x[ep] != L.x[e] &&
+                         L.x[e] != L.x[en];
+                }
+            }
         }
-        if (keep) {
-            flags |= 1u << j;
-            ++cnt;
-        }
+        keep[j] = kp;
     }
     uint32_t tot;
-    const uint32_t o0 = block_excl_scan(cnt, L.wsum, &tot);
+    strided_ranks<FUSED_CMAX, FusedLds>(L, keep, C, rank, &tot);
     if (t == 0) {
         // fixed slot per workgroup; only blocks with more survivors than the slot use the shared cursor
         // (same-address atomics saturate at ~88/us on gfx950)
@@ -317,21 +367,22 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
             ok = ob + tot <= a.cap;
             if (!ok) atomicExch(a.cursor + 1, 1ull);
         }
-        L.base = ok ? base : ~0ull;
+        L.base_out = ok ? base : ~0ull;
         a.blk_off[blockIdx.x] = base;
         a.blk_cnt[blockIdx.x] = ok ? tot : 0u;
     }
     __syncthreads();
-    const unsigned long long base = L.base;
-    if (cnt && base != ~0ull) {
-        uint64_t o = base + o0;
-        for (int j = 0; j < C; ++j)
-            if (flags & (1u << j)) {
-                const int e = cur ? cur[k0 + j] : (k0 + j);
+    const unsigned long long base = L.base_out;
+    if (base != ~0ull) {
+#pragma unroll
+        for (int j = 0; j < FUSED_CMAX; ++j)
+            if (keep[j]) {
+                const int k = j * FUSED_T + (int)t;
+                const int e = cur ? cur[k] : k;
                 pgr_mm128 m;
                 m.x = L.x[e];
                 m.y = L.y[e];
-                a.out[o++] = m;
+                a.out[base + rank[j]] = m;
             }
     }
 }
@@ -377,7 +428,10 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
     if (n_blocks == 0) return;
     hipLaunchKernelGGL(block_first_seg_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, a.seg_dst, a.n_segs,
                        n_blocks, a.halo, a.blk_first_seg);
-    hipLaunchKernelGGL(fused_select_kernel, dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+    if (a.halo <= 32)
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+    else
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
 }
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off) {
     hipLaunchKernelGGL(offsets_by_rid_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, mm, n, n_contigs, off);
