@@ -138,6 +138,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the RCCL all-gather of pair records")
     ap.add_argument("--queries", type=int, default=10_000, help="query leg (after the timed region, N=1 only); 0 = off")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
+    ap.add_argument("--single-device", action="store_true",
+                    help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     args = ap.parse_args()
 
     import torch
@@ -149,12 +152,17 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" %
                   (args.gpus, world), file=sys.stderr)
         sys.exit(2)
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     import pgrtk_amd as P
     from pgrtk_amd import exchange
@@ -188,7 +196,7 @@ def main():
         n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=sids)
         if world > 1 and not args.no_exchange:
             finish_pending()  # step i-1's records have arrived everywhere
-            state["pending"] = exchange.PendingAllgather(rec_buf[:n])
+            state["pending"] = exchange.PendingAllgather(rec_buf[:n] if args.backend == "nccl" else rec_buf[:n].cpu())
         p = ctx.last_prof()
         state["sh"] = sh
         state["n_pairs"] = n
@@ -209,7 +217,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
+        t = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % local_rank) if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 

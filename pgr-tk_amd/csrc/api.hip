@@ -662,6 +662,7 @@ extern "C" void pgr_shmmrs_destroy(pgr_shmmrs *s) {
 extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 **out_mm, uint64_t **out_off) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!s || !out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
     *out_mm = nullptr;
     *out_off = nullptr;
     pgr_mm128 *mm = (pgr_mm128 *)malloc(std::max<uint64_t>(s->count, 1) * sizeof(pgr_mm128));
@@ -700,6 +701,7 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
                                               pgr_frag_rec *d_out, uint64_t capacity, uint64_t *n_out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!s || !n_out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t n = s->n;
     std::vector<uint64_t> rec_off((size_t)n + 1);
     uint64_t np = 0;

@@ -311,7 +311,7 @@ template <int TW, int TK, bool SKETCH>
 __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     __shared__ double s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
     __shared__ double s_row[L1_BLOCK];        // row min, later row max
-    __shared__ uint2 s_words[136];
+    __shared__ uint2 s_words[L1_WORDS];
     __shared__ uint32_t s_wsum[L1_BLOCK / 64];
     __shared__ unsigned long long s_base;
     __shared__ int s_skip;
@@ -333,7 +333,7 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     const long long wbase = (e0 - 96) >> 5;  // floor
     const long long nwords = (g.L + 31) >> 5;
     const uint2 *__restrict__ planes = a.b.planes + td.word_off;
-    if (t < 136) {
+    if (t < L1_WORDS) {
         const long long wi = wbase + t;
         uint2 v = make_uint2(0u, 0u);
         if (wi >= 0 && wi < nwords) v = planes[wi];

@@ -12,9 +12,10 @@
 namespace pgr {
 
 // ------------------------------------------------------------------ geometry of the level-1 kernel
-constexpr int L1_BLOCK = 256;            // threads per workgroup (4 wavefronts of 64)
+constexpr int L1_BLOCK = 512;            // threads per workgroup (8 wavefronts of 64)
 constexpr int L1_G = 16;                 // consecutive positions owned by one lane
-constexpr int L1_EXT = L1_BLOCK * L1_G;  // 4096 positions per tile including both halos
+constexpr int L1_EXT = L1_BLOCK * L1_G;  // positions per tile including both halos
+constexpr int L1_WORDS = (L1_EXT + 96) / 32 + 5;  // plane words staged per tile (tile + k-mer look-back)
 constexpr int L1_MIN_W = 17;             // window sizes below this use the serial kernel
 constexpr uint64_t U64MAX = 0xFFFFFFFFFFFFFFFFull;
 

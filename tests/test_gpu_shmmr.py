@@ -115,12 +115,13 @@ def test_tile_boundaries(oracle, gpu_ctx):
     """contig lengths around multiples of the tile core (4096 - 2(w-1)) and of the 64-position chunks"""
     rng = np.random.default_rng(5)
     for (w, k, r, ms) in [(80, 56, 4, 64), (48, 56, 4, 12), (128, 56, 4, 64), (17, 17, 2, 4)]:
-        tc = 4096 - 2 * (w - 1)
         lens = []
-        for m in (1, 2, 3, 5):
-            for d in (-w - k, -w, -k, -2, -1, 0, 1, 2, k, w, w + k):
-                lens.append(m * tc + d)
-        lens += [4096, 8192, 4095, 4097, 64 * 100, 64 * 100 + 1, 64 * 100 - 1]
+        for ext in (4096, 8192):  # tile = 16 positions x 256 or 512 lanes, core = ext - 2(w-1)
+            tc = ext - 2 * (w - 1)
+            for m in (1, 2, 3):
+                for d in (-w - k, -w, -k, -2, -1, 0, 1, 2, k, w, w + k):
+                    lens.append(m * tc + d)
+        lens += [4096, 8192, 4095, 4097, 8191, 8193, 16384, 64 * 100, 64 * 100 + 1, 64 * 100 - 1]
         seqs = [seqgen.rnd(rng, L) for L in lens]
         _check_batch(oracle, gpu_ctx, seqs, (w, k, r, ms, False), what="tiles")
 
