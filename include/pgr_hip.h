@@ -139,8 +139,9 @@ typedef struct {
     float total_ms;      /* first launch to last kernel of pgr_shmmrs_compute (incl. host syncs)    */
     uint64_t n_level1;   /* level-1 minimizers emitted                                              */
     uint64_t n_tiles;    /* workgroups of the dominant kernel                                       */
-    uint64_t n_serial_contigs; /* contigs routed to the serial GPU kernel                           */
+    uint64_t n_serial_contigs; /* contigs with at least one island of exact (state machine) tiles   */
     uint64_t bases_tiled;      /* bases covered by the dominant kernel                              */
+    uint64_t exact_bases;      /* bases re-done by the exact state-machine kernel (islands)         */
 } pgr_prof;
 int pgr_ctx_last_prof(const pgr_ctx *ctx, pgr_prof *out);
 int pgr_ctx_synchronize(pgr_ctx *ctx);

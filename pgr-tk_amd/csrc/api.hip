@@ -226,66 +226,97 @@ extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *len
 
 // ------------------------------------------------------------------------------------------------
 // ------------------------------------------------------------------------------------------------
-// Exact state machine over the listed contigs, parallel over 32 kbp chunks with verified seams
-// (level1_chunk_kernel).  A seam whose warmed-up state differs from the previous chunk's true end state is
-// re-run with that state installed; if even that cannot be done the contig is re-run as ONE chunk.
-static int run_exact_chunks(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, const std::vector<uint32_t> &contigs,
-                            const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base) {
+// Exact state machine (level1_chunk_kernel) over ISLANDS: position ranges [B, E) of a contig (tile aligned, or
+// the whole contig) that replace the closed-form tiles near an irregularity (non-ACGT byte, palindromic
+// k-mer) or everything when the spec has no tile path (w < 17).  Inside an island the chunks of 32 kbp are
+// seamed by emission step and every seam is verified against the previous chunk's end state; the island's
+// left edge trusts the warm-up (everything before it is regular by construction: islands keep a clean tile
+// on both sides), its right edge is verified with a probe (warm-up only) at E and the island grows when the
+// machine has not yet returned to its regular regime there.
+struct Island {
+    uint32_t contig;
+    uint64_t B, E;
+    bool whole;  // one chunk for the whole contig (last resort)
+};
+
+static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
+                             const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base) {
     hipStream_t st = ctx->stream;
     constexpr uint64_t CS = 32768;
     struct HChunk {
         ChunkDesc d;
-        bool full_cap = false;
-        bool whole = false;
+        size_t island;
+        bool full_cap = false, probe = false, retired = false;
     };
     std::vector<HChunk> ch;
+    std::vector<ChunkState> s_in, s_out;
+    std::vector<uint32_t> status;
+    std::vector<size_t> todo;
     auto cap_of = [&](uint64_t len, bool full) -> uint64_t {
-        return full ? len + a.w + 64 : std::min<uint64_t>(len + a.w + 64, len / 4 + 1024);
+        return full ? len + a.w + 320 : std::min<uint64_t>(len + a.w + 320, len / 4 + 1024);
     };
-    auto add_contig = [&](uint32_t c, bool whole) {
+    int rc;
+    // (re)build the chunks of one island; its tile (and tail) segments become empty first
+    auto build = [&](size_t ii) -> int {
+        const Island &is = islands[ii];
+        const uint32_t c = is.contig;
         const uint64_t L = b->h_len[c];
         const uint32_t nt = tile_first[c + 1] - tile_first[c];
-        const uint64_t nch = whole ? 1 : (L + CS - 1) / CS;
+        const uint32_t seg0 = tile_first[c] + c;
+        uint32_t rng[2] = {seg0 + (uint32_t)(is.B / tc), seg0 + (uint32_t)((is.E + tc - 1) / tc)};
+        if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
+        Tmp_list d_r(ctx);
+        if ((rc = d_r.alloc(sizeof(rng)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(d_r.p, rng, sizeof(rng), hipMemcpyHostToDevice, st));
+        launch_zero_seg_ranges(st, a, (const uint32_t *)d_r.p, 1);
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
         for (uint64_t j = 0; j < nch; ++j) {
             HChunk h;
             memset(&h.d, 0, sizeof(h.d));
+            h.island = ii;
             h.d.contig = c;
-            h.d.cs = whole ? 0 : j * CS;
-            h.d.ce = whole ? L : std::min<uint64_t>(L, (j + 1) * CS);
-            const uint64_t tl = std::min<uint64_t>(nt ? nt - 1 : 0, (j * CS) / tc);
-            h.d.seg = tile_first[c] + c + (uint32_t)tl;
+            h.d.cs = is.whole ? 0 : is.B + j * CS;
+            h.d.ce = is.whole ? L : std::min<uint64_t>(is.E, is.B + (j + 1) * CS);
+            h.d.emit_lo_pos = (j == 0) ? is.B : 0;
+            h.d.drain_end = h.d.ce;
+            if (j + 1 == nch && is.E < L) h.d.drain_end = std::min<uint64_t>(L, is.E + 320);
+            h.d.seg = seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, h.d.cs / tc);
             h.d.warm = 256;
-            h.whole = whole;
+            todo.push_back(ch.size());
             ch.push_back(h);
         }
+        if (is.E < L) {  // probe: what a warmed-up (regular) machine looks like at E
+            HChunk h;
+            memset(&h.d, 0, sizeof(h.d));
+            h.island = ii;
+            h.probe = true;
+            h.d.contig = c;
+            h.d.cs = h.d.ce = h.d.drain_end = is.E;
+            h.d.seg = 0xFFFFFFFFu;
+            h.d.warm = 256;
+            todo.push_back(ch.size());
+            ch.push_back(h);
+        }
+        return PGR_OK;
     };
-    for (uint32_t c : contigs) add_contig(c, false);
-
-    int rc;
-    Tmp_list d_list(ctx);
-    if ((rc = d_list.alloc(contigs.size() * sizeof(uint32_t)))) return rc;
-    PGR_HIP(ctx, hipMemcpyAsync(d_list.p, contigs.data(), contigs.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    launch_zero_contig_segs(st, a, (const uint32_t *)d_list.p, (uint32_t)contigs.size());
+    for (size_t ii = 0; ii < islands.size(); ++ii)
+        if ((rc = build(ii))) return rc;
 
     uint64_t next_region = region_base;
-    std::vector<ChunkState> s_in, s_out;
-    std::vector<uint32_t> status;
-    std::vector<size_t> todo(ch.size());
-    for (size_t i = 0; i < ch.size(); ++i) todo[i] = i;
     for (int round = 0; !todo.empty(); ++round) {
-        if (round > 64) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine chunks did not converge");
-        // regions for the chunks of this round (appended; earlier regions of re-run chunks are abandoned)
-        std::vector<ChunkDesc> descs(todo.size());
-        for (size_t q = 0; q < todo.size(); ++q) {
+        if (round > 200) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
+        const size_t nq = todo.size();
+        std::vector<ChunkDesc> descs(nq);
+        for (size_t q = 0; q < nq; ++q) {
             HChunk &h = ch[todo[q]];
             h.d.region_off = next_region;
-            h.d.region_cap = cap_of(h.d.ce - h.d.cs, h.full_cap);
+            h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
             next_region += h.d.region_cap;
             descs[q] = h.d;
         }
         if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(pgr_mm128), st))) return rc;
         a.out = (pgr_mm128 *)ctx->ws_l1.p;
-        const size_t nq = todo.size();
         if ((rc = ctx->ws_serial.ensure(ctx, nq * (sizeof(ChunkDesc) + 2 * sizeof(ChunkState) + sizeof(uint32_t)))))
             return rc;
         ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
@@ -302,32 +333,57 @@ static int run_exact_chunks(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, const s
         PGR_HIP(ctx, hipMemcpyAsync(r_stat.data(), d_stat, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));
         PGR_HIP(ctx, hipGetLastError());
-        if (s_in.size() < ch.size()) {
-            s_in.resize(ch.size());
-            s_out.resize(ch.size());
-            status.resize(ch.size());
-        }
+        s_in.resize(ch.size());
+        s_out.resize(ch.size());
+        status.resize(ch.size());
         for (size_t q = 0; q < nq; ++q) {
             s_in[todo[q]] = r_in[q];
             s_out[todo[q]] = r_out[q];
             status[todo[q]] = r_stat[q];
         }
-        // ---- verify every seam; collect the chunks that must run again
+        if (getenv("PGR_DEBUG"))
+            fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu\n", round, nq,
+                    islands.size(), (unsigned long long)next_region);
+        // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last)
         std::vector<size_t> next;
-        std::vector<uint32_t> whole_contigs;
+        std::vector<size_t> rebuild;  // islands to rebuild (grown or turned into one whole-contig chunk)
         for (size_t i = 0; i < ch.size(); ++i) {
             HChunk &h = ch[i];
-            if (h.d.contig == 0xFFFFFFFFu) continue;  // retired (its contig is re-run as one chunk)
+            if (h.retired) continue;
+            Island &is = islands[h.island];
+            if (status[i] & 2u) {  // the true state could not be installed: the contig as one chunk
+                if (!is.whole) {
+                    is.whole = true;
+                    is.B = 0;
+                    is.E = b->h_len[is.contig];
+                    rebuild.push_back(h.island);
+                }
+                continue;
+            }
             bool again = false;
             if (status[i] & 1u) {  // region overflow
                 h.full_cap = true;
                 again = true;
             }
-            if (status[i] & 2u) {  // the true state could not be installed: whole contig, one chunk
-                whole_contigs.push_back(h.d.contig);
-                continue;
-            }
-            if (!h.whole && h.d.cs > 0 && i > 0 && ch[i - 1].d.contig == h.d.contig) {
+            const bool has_prev = i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island;
+            if (h.probe) {
+                if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
+                    if (getenv("PGR_DEBUG")) {
+                        const ChunkState &p = s_in[i], &q = s_out[i - 1];
+                        fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
+                                "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
+                                (unsigned long long)p.min_x, (unsigned long long)q.min_x, (unsigned long long)p.min_y,
+                                (unsigned long long)q.min_y, (unsigned long long)p.mdist, (unsigned long long)q.mdist,
+                                (unsigned long long)p.F0, (unsigned long long)q.F0, (unsigned long long)p.R0,
+                                (unsigned long long)q.R0, (unsigned long long)p.ring_sig, (unsigned long long)q.ring_sig);
+                    }
+                    // the machine is not back in its regular regime at E: grow the island
+                    const uint64_t L = b->h_len[is.contig];
+                    is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
+                    if (L - is.E < 2ull * tc) is.E = L;
+                    rebuild.push_back(h.island);
+                }
+            } else if (!is.whole && h.d.cs > is.B && has_prev) {
                 if (memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
                     h.d.override_state = 1;
                     h.d.in_state = s_out[i - 1];
@@ -337,26 +393,30 @@ static int run_exact_chunks(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, const s
             }
             if (again) next.push_back(i);
         }
-        if (!whole_contigs.empty()) {
-            std::sort(whole_contigs.begin(), whole_contigs.end());
-            whole_contigs.erase(std::unique(whole_contigs.begin(), whole_contigs.end()), whole_contigs.end());
+        if (!rebuild.empty()) {
+            std::sort(rebuild.begin(), rebuild.end());
+            rebuild.erase(std::unique(rebuild.begin(), rebuild.end()), rebuild.end());
             for (auto &h : ch)
-                if (std::binary_search(whole_contigs.begin(), whole_contigs.end(), h.d.contig)) h.d.contig = 0xFFFFFFFFu;
-            next.erase(std::remove_if(next.begin(), next.end(), [&](size_t i) { return ch[i].d.contig == 0xFFFFFFFFu; }),
-                       next.end());
-            // their chunk segments must be emptied again before the single-chunk run
-            Tmp_list d_wl(ctx);
-            if ((rc = d_wl.alloc(whole_contigs.size() * sizeof(uint32_t)))) return rc;
-            PGR_HIP(ctx, hipMemcpyAsync(d_wl.p, whole_contigs.data(), whole_contigs.size() * sizeof(uint32_t),
-                                        hipMemcpyHostToDevice, st));
-            launch_zero_contig_segs(st, a, (const uint32_t *)d_wl.p, (uint32_t)whole_contigs.size());
-            PGR_HIP(ctx, hipStreamSynchronize(st));
-            for (uint32_t c : whole_contigs) {
-                add_contig(c, true);
-                next.push_back(ch.size() - 1);
+                if (std::binary_search(rebuild.begin(), rebuild.end(), h.island)) h.retired = true;
+            next.erase(std::remove_if(next.begin(), next.end(), [&](size_t i) { return ch[i].retired; }), next.end());
+            todo.swap(next);
+            for (size_t ii : rebuild) {
+                // merge with later islands of the same contig that the grown island now touches
+                for (size_t jj = 0; jj < islands.size(); ++jj)
+                    if (jj != ii && islands[jj].contig == islands[ii].contig && islands[jj].B < islands[ii].E + tc &&
+                        islands[jj].B >= islands[ii].B && islands[jj].E > islands[ii].B && !islands[jj].whole &&
+                        islands[jj].E != 0) {
+                        islands[ii].E = std::max(islands[ii].E, islands[jj].E);
+                        for (auto &h : ch)
+                            if (h.island == jj) h.retired = true;
+                        islands[jj].E = islands[jj].B = 0;  // absorbed
+                    }
+                todo.erase(std::remove_if(todo.begin(), todo.end(), [&](size_t i) { return ch[i].retired; }), todo.end());
+                if ((rc = build(ii))) return rc;
             }
+        } else {
+            todo.swap(next);
         }
-        todo.swap(next);
     }
     return PGR_OK;
 }
@@ -384,7 +444,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const bool sketch = spec->sketch != 0;
     const bool tiled = sketch || spec->w >= (uint32_t)L1_MIN_W;
     const uint32_t w_eff = sketch ? 1u : spec->w;
-    const uint32_t tc = L1_EXT - 2 * (w_eff - 1);
+    // tile core: extended tile minus both halos, rounded down to the 64-position step of the exact kernel so
+    // that islands of exact tiles start and end on step boundaries
+    const uint32_t tc = ((L1_EXT - 2 * (w_eff - 1)) / 64) * 64;
 
     // ---- host plan: tiles for the closed form, list for the serial kernel
     std::vector<uint32_t> tile_first((size_t)n + 1);
@@ -395,8 +457,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         const uint64_t L = b->h_len[c];
         if (L == 0) continue;
         n_tiles64 += (L + tc - 1) / tc;  // every contig owns tile segments (the chunk kernel reuses them)
-        if (tiled && b->h_n_invalid[c] == 0) bases_tiled += L;
-        else serial.push_back(c);
+        if (tiled) bases_tiled += L;  // contigs with non-ACGT bytes too: only islands around them are replaced
+        else serial.push_back(c);     // w < 17: the whole contig goes through the exact kernel
     }
     if (n_tiles64 + n + 1 >= (1ull << 31)) return ctx->fail(PGR_ERR_INVALID_ARG, "batch too large (tile count)");
     tile_first[n] = (uint32_t)n_tiles64;
@@ -413,6 +475,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_tile_desc.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(TileDesc))) ||
+        (rc = ctx->ws_tile_flags.ensure(ctx, (size_t)n_tiles + 16)) ||
         (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_cursor.ensure(ctx, 2 * sizeof(unsigned long long))) ||
@@ -435,6 +498,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.n_tiles = n_tiles;
     a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
     a.desc = (TileDesc *)ctx->ws_tile_desc.p;
+    a.tile_flags = (uint8_t *)ctx->ws_tile_flags.p;
     a.w = w_eff;
     a.k = spec->k;
     a.r = spec->r;
@@ -450,8 +514,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     prof.n_tiles = n_tiles;
     prof.bases_tiled = bases_tiled;
     std::vector<uint32_t> flags(n);
-    std::vector<char> in_serial(n, 0);
-    for (uint32_t c : serial) in_serial[c] = 1;
+    bool any_invalid = false;
+    for (uint32_t c = 0; c < n; ++c) any_invalid |= b->h_n_invalid[c] != 0;
 
     PGR_HIP(ctx, hipEventRecord(ctx->ev[0], st));
     uint64_t serial_base = 0;  // first element of the serial regions inside the level-1 buffer
@@ -468,10 +532,12 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), st));
         PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
+        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_tile_flags.p, 0, (size_t)n_tiles + 16, st));
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         if (tiled && bases_tiled) launch_level1_tiles(st, a);
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         launch_level1_tails(st, a);
+        if (tiled && bases_tiled && any_invalid) launch_mark_invalid_tiles(st, a);
         unsigned long long cur[2] = {0, 0};
         PGR_HIP(ctx, hipMemcpyAsync(cur, ctx->ws_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
         if (n) PGR_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->ws_flags.p, (size_t)n * sizeof(uint32_t),
@@ -485,20 +551,60 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         prof.n_level1 = cur[0];
         break;
     }
-    // contigs with palindromic k-mers (skipped pushes) join the serial list
-    if (!sketch)
-        for (uint32_t c = 0; c < n; ++c)
-            if ((flags[c] & 1u) && !in_serial[c]) {
-                serial.push_back(c);
-                in_serial[c] = 1;
+    // ---- islands of exact tiles: around palindromic k-mers (skipped pushes, flagged by the tile kernel) and
+    // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path
+    std::vector<Island> islands;
+    for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false});
+    if (tiled && bases_tiled) {
+        bool need = false;
+        for (uint32_t c = 0; c < n; ++c) need |= (b->h_n_invalid[c] != 0) || (!sketch && (flags[c] & 1u));
+        if (need) {
+            std::vector<uint8_t> tf(n_tiles);
+            PGR_HIP(ctx, hipMemcpyAsync(tf.data(), ctx->ws_tile_flags.p, n_tiles, hipMemcpyDeviceToHost, st));
+            PGR_HIP(ctx, hipStreamSynchronize(st));
+            for (uint32_t c = 0; c < n; ++c) {
+                if (b->h_n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
+                const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
+                const uint64_t L = b->h_len[c];
+                uint32_t n_flag = 0;
+                for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
+                if (n_flag == 0) continue;
+                if (sketch && b->h_n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
+                if (3ull * n_flag > nt) {  // mostly irregular: one island
+                    islands.push_back(Island{c, 0, L, false});
+                    continue;
+                }
+                for (uint32_t t = 0; t < nt;) {
+                    if (!tf[t0 + t]) {
+                        ++t;
+                        continue;
+                    }
+                    uint32_t ta = t > 0 ? t - 1 : 0, tb = t;
+                    while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
+                    if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
+                    Island is{c, (uint64_t)ta * tc, std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false};
+                    if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
+                    if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B)
+                        islands.back().E = std::max(islands.back().E, is.E);
+                    else
+                        islands.push_back(is);
+                    t = tb + 1;
+                }
             }
-    prof.n_serial_contigs = serial.size();
-    if (!serial.empty()) {
-        std::sort(serial.begin(), serial.end());
+        }
+    }
+    {
+        std::vector<uint32_t> cs;
+        for (const auto &is : islands) cs.push_back(is.contig);
+        std::sort(cs.begin(), cs.end());
+        prof.n_serial_contigs = std::unique(cs.begin(), cs.end()) - cs.begin();
+    }
+    if (!islands.empty()) {
         L1Args as = a;
         as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
-        if ((rc = run_exact_chunks(ctx, b, as, serial, tile_first, tc, serial_base))) return rc;
+        if ((rc = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base))) return rc;
         a.out = as.out;
+        for (const auto &is : islands) prof.exact_bases += is.E - is.B;  // final extents (islands may have grown)
     }
     PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
 

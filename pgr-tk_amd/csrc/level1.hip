@@ -395,7 +395,10 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         const uint32_t sidx = tile + c;  // one tail segment per preceding contig
         a.seg_off[sidx] = base;
         a.seg_cnt[sidx] = ok ? total : 0u;
-        if (s_skip) atomicOr(a.contig_flags + c, 1u);
+        if (s_skip) {
+            atomicOr(a.contig_flags + c, 1u);
+            a.tile_flags[tile] = 1;
+        }
     }
     // selected keys go through LDS (s_suf is free now; each lane re-reads only its own column, so no barrier
     // is needed for the data): a loop over the ~0.4 set bits per lane instead of 16 predicated stores
@@ -612,8 +615,12 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     uint64_t n_out = 0;
     uint32_t stat = 0;
 
-    for (long long base = pk; base < ce; base += 64) {
-        if (base == cs && cs > 0) {
+    const long long drain_end = (long long)cd.drain_end > ce ? (long long)cd.drain_end : ce;
+    const uint64_t emit_lo = cd.emit_lo_pos;
+    bool out_captured = false;
+    uint64_t sig_out = 0;
+    ChunkState o_out;
+    auto seam = [&]() {
             // seam: record the warmed-up state, or install the true state handed over by the host
             const uint64_t sig = ring_signature(s_rx, rstart, rlen, w, lane);
             if (cd.override_state) {
@@ -636,7 +643,23 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 o.ring_sig = a.sketch ? 0 : sig;
                 st_in[blockIdx.x] = o;
             }
+        };
+    for (long long base = pk; base < drain_end; base += 64) {
+        if (base >= ce && !out_captured) {
+            // end of the by-step range: this is the state the next chunk / the island-end probe must match
+            sig_out = ring_signature(s_rx, rstart, rlen, w, lane);
+            o_out.min_x = a.sketch ? 0 : min_x;
+            o_out.min_y = a.sketch ? 0 : min_y;
+            o_out.mdist = a.sketch ? 0 : mdist;
+            o_out.F0 = F0;
+            o_out.F1 = F1;
+            o_out.R0 = R0;
+            o_out.R1 = R1;
+            o_out.ring_sig = a.sketch ? 0 : sig_out;
+            out_captured = true;
         }
+        const bool draining = base >= ce;  // island end: only elements below ce are still ours
+        if (base == cs && cs > 0) seam();
         const long long wj = base >> 5;
         uint32_t v_hi = vplane[wj], v_lo = 0;
         if (wj + 1 < nwords) v_lo = vplane[wj + 1];
@@ -681,6 +704,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         }
         if (kmer_only) continue;
         const bool emit_on = base >= cs;
+        const uint64_t pos_lo = emit_lo, pos_hi = draining ? (uint64_t)ce : ~0ull;  // position filter
         const bool skip = (f0 == r0) && (f1 == r1);
         const bool pushed = !skip && pos >= (long long)k && pos < L;
         uint32_t st;
@@ -689,7 +713,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         const uint64_t y = ((uint64_t)c << 32) | ((uint64_t)pos << 1) | st;
 
         if (a.sketch) {  // shmmrutils.rs:621-628
-            const bool em = emit_on && pushed && h < sketch_thr;
+            const bool em = emit_on && !draining && pushed && h < sketch_thr;
             const uint64_t m = __ballot(em);
             if (em) {
                 const uint64_t o = n_out + __popcll(m & lt_mask);
@@ -707,6 +731,58 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         const uint64_t pmask = __ballot(pushed);
         const bool b_en = (uint64_t)pos >= (uint64_t)(w + k) && (uint64_t)pos < Lb && pos < L;
         uint32_t cur = 0;  // first unprocessed lane of this step
+        // Tie runs (N runs, homopolymers: every push is a branch-2 event because x <= min_mer.x keeps holding)
+        // are taken in one shot: if EVERY pushed lane of the step is a record low with respect to the running
+        // minimum and no rescan is due at the first push, all of them emit in order, the last one becomes
+        // min_mer and mdist = 0 -- exactly what 64 single-event iterations would do.
+        if (pmask && mdist != (uint64_t)(w - 1)) {
+            uint64_t pm = pushed ? x : U64MAX;  // exclusive prefix minimum over the pushed lanes
+            {
+                uint64_t incl = pm;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint64_t o = shfl64(incl, (int)lane - d < 0 ? (int)lane : (int)lane - d);
+                    if ((int)lane >= d) incl = umin64(incl, o);
+                }
+                const uint64_t prev = shfl64(incl, lane == 0 ? 0 : (int)lane - 1);
+                pm = lane == 0 ? U64MAX : prev;
+            }
+            const bool rec = pushed && b_en && x <= umin64(pm, min_x);
+            if (__ballot(rec) == pmask) {
+                const uint32_t tot = __popcll(pmask);
+                if (pushed) {
+                    const uint32_t rk = __popcll(pmask & lt_mask);
+                    if (tot - rk <= w) {
+                        const uint32_t slot = (rend + rk) % w;
+                        s_rx[slot] = x;
+                        s_ry[slot] = y;
+                    }
+                    if (emit_on && !draining) {
+                        const uint64_t o = n_out + rk;
+                        if (o < cap) {
+                            pgr_mm128 mm;
+                            mm.x = x;
+                            mm.y = y;
+                            out[o] = mm;
+                        }
+                    }
+                }
+                if (emit_on && !draining) n_out += tot;
+                rend = (rend + tot) % w;
+                if (rlen + tot >= w) {
+                    rlen = w;
+                    rstart = rend;
+                } else {
+                    rlen += tot;
+                }
+                const int last = 63 - (int)__clzll((long long)pmask);
+                min_x = shfl64(x, last);
+                min_y = shfl64(y, last);
+                mdist = 0;
+                cur = 64;
+                __syncthreads();
+            }
+        }
         for (;;) {
             const uint64_t rest = (cur >= 64) ? 0ull : (pmask & (U64MAX << cur));
             if (rest == 0) break;
@@ -746,7 +822,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             }
             if (iB < iR) {  // branch 2 (shmmrutils.rs:516-527)
                 const uint64_t ex = shfl64(x, iB), ey = shfl64(y, iB);
-                if (emit_on) {
+                if (emit_on && !draining) {  // the element of a B event sits at the step itself
                     if (lane == 0 && n_out < cap) {
                         pgr_mm128 mm;
                         mm.x = ex;
@@ -766,23 +842,27 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 const uint64_t mn = wave_min64(umin64(x0, x1));
                 const bool e0 = (q0 < w) && x0 == mn, e1 = (q1 < w) && x1 == mn;
                 const uint64_t m0 = __ballot(e0), m1 = __ballot(e1);
-                const uint32_t n0 = __popcll(m0), n1 = __popcll(m1);
                 if (emit_on) {
-                    if (e0) {
-                        const uint64_t o = n_out + __popcll(m0 & lt_mask);
+                    const uint64_t y0 = e0 ? s_ry[s0] : 0, y1 = e1 ? s_ry[s1] : 0;
+                    const uint64_t p0 = (y0 & 0xFFFFFFFFull) >> 1, p1 = (y1 & 0xFFFFFFFFull) >> 1;
+                    const bool w0 = e0 && p0 >= pos_lo && p0 < pos_hi, w1 = e1 && p1 >= pos_lo && p1 < pos_hi;
+                    const uint64_t wm0 = __ballot(w0), wm1 = __ballot(w1);
+                    const uint32_t n0 = __popcll(wm0), n1 = __popcll(wm1);
+                    if (w0) {
+                        const uint64_t o = n_out + __popcll(wm0 & lt_mask);
                         if (o < cap) {
                             pgr_mm128 mm;
                             mm.x = x0;
-                            mm.y = s_ry[s0];
+                            mm.y = y0;
                             out[o] = mm;
                         }
                     }
-                    if (e1) {
-                        const uint64_t o = n_out + n0 + __popcll(m1 & lt_mask);
+                    if (w1) {
+                        const uint64_t o = n_out + n0 + __popcll(wm1 & lt_mask);
                         if (o < cap) {
                             pgr_mm128 mm;
                             mm.x = x1;
-                            mm.y = s_ry[s1];
+                            mm.y = y1;
                             out[o] = mm;
                         }
                     }
@@ -798,25 +878,29 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             __syncthreads();
         }
     }
-    // ---- state at the end of the chunk (the next chunk's seam) and the segment entry
-    const uint64_t sig_out = ring_signature(s_rx, rstart, rlen, w, lane);
+    if (cs > 0 && cs >= drain_end) seam();  // probe: nothing to emit, only the warmed-up state at cs
+    // ---- state at the end of the by-step range (the next chunk's seam) and the segment entry
+    if (!out_captured) {
+        sig_out = ring_signature(s_rx, rstart, rlen, w, lane);
+        o_out.min_x = a.sketch ? 0 : min_x;
+        o_out.min_y = a.sketch ? 0 : min_y;
+        o_out.mdist = a.sketch ? 0 : mdist;
+        o_out.F0 = F0;
+        o_out.F1 = F1;
+        o_out.R0 = R0;
+        o_out.R1 = R1;
+        o_out.ring_sig = a.sketch ? 0 : sig_out;
+    }
     if (lane == 0) {
-        ChunkState o;
-        o.min_x = a.sketch ? 0 : min_x;
-        o.min_y = a.sketch ? 0 : min_y;
-        o.mdist = a.sketch ? 0 : mdist;
-        o.F0 = F0;
-        o.F1 = F1;
-        o.R0 = R0;
-        o.R1 = R1;
-        o.ring_sig = a.sketch ? 0 : sig_out;
-        st_out[blockIdx.x] = o;
-        a.seg_off[cd.seg] = cd.region_off;
-        if (n_out > cap || n_out > 0xFFFFFFFFull) {
-            stat |= 1u;  // region too small: the host re-runs this chunk with a full-size region
-            a.seg_cnt[cd.seg] = 0;
-        } else {
-            a.seg_cnt[cd.seg] = (uint32_t)n_out;
+        st_out[blockIdx.x] = o_out;
+        if (cd.seg != 0xFFFFFFFFu) {
+            a.seg_off[cd.seg] = cd.region_off;
+            if (n_out > cap || n_out > 0xFFFFFFFFull) {
+                stat |= 1u;  // region too small: the host re-runs this chunk with a full-size region
+                a.seg_cnt[cd.seg] = 0;
+            } else {
+                a.seg_cnt[cd.seg] = (uint32_t)n_out;
+            }
         }
         status[blockIdx.x] = stat;
     }
@@ -829,6 +913,36 @@ __global__ void zero_contig_segs_kernel(L1Args a, const uint32_t *__restrict__ l
     for (uint32_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) a.seg_cnt[s] = 0;
 }
 
+__global__ void zero_seg_ranges_kernel(L1Args a, const uint32_t *__restrict__ ranges, uint32_t n_ranges) {
+    const uint32_t s0 = ranges[2 * blockIdx.x], s1 = ranges[2 * blockIdx.x + 1];
+    for (uint32_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) a.seg_cnt[s] = 0;
+}
+
+// one lane per tile (of contigs that contain non-ACGT bytes): does the tile's extended range (core +- (w-1),
+// k-mer look-back, one 64-position step of slack) contain a byte that is not a base?
+__global__ void mark_invalid_tiles_kernel(L1Args a) {
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile >= a.n_tiles) return;
+    const TileDesc td = a.desc[tile];
+    const uint32_t c = td.contig;
+    if (a.b.n_invalid[c] == 0) return;
+    const long long L = td.len;
+    const uint32_t *__restrict__ v = a.b.valid + td.word_off;
+    long long lo = (long long)td.tile_local * a.tc - (long long)(a.w - 1) - (long long)(a.k - 1) - 64;
+    long long hi = (long long)(td.tile_local + 1) * a.tc + (long long)(a.w - 1) + 64;
+    if (lo < 0) lo = 0;
+    if (hi > L) hi = L;
+    bool bad = false;
+    for (long long wj = lo >> 5; wj <= (hi - 1) >> 5 && !bad; ++wj) {
+        uint32_t m = 0xFFFFFFFFu;  // bits of this word inside [lo, hi)
+        const long long w0 = wj << 5;
+        if (w0 < lo) m &= 0xFFFFFFFFu >> (uint32_t)(lo - w0);
+        if (w0 + 32 > hi) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - hi);
+        bad = (v[wj] & m) != m;
+    }
+    if (bad) a.tile_flags[tile] = 1;
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ void tile_desc_kernel(L1Args a) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
@@ -839,7 +953,7 @@ __global__ void tile_desc_kernel(L1Args a) {
     d.len = a.b.len[c];
     d.contig = c;
     d.tile_local = tile - a.tile_first[c];
-    d.skip = a.b.n_invalid[c] ? 1u : 0u;
+    d.skip = 0u;  // contigs with non-ACGT bytes run too: only the tiles near such bytes are replaced (islands)
     d._pad[0] = d._pad[1] = 0;
     a.desc[tile] = d;
 }
@@ -864,6 +978,14 @@ void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_de
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status) {
     if (n_chunks == 0) return;
     hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status);
+}
+void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges) {
+    if (n_ranges == 0) return;
+    hipLaunchKernelGGL(zero_seg_ranges_kernel, dim3(n_ranges), dim3(256), 0, st, a, d_ranges, n_ranges);
+}
+void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a) {
+    if (a.n_tiles == 0) return;
+    hipLaunchKernelGGL(mark_invalid_tiles_kernel, dim3((a.n_tiles + 255) / 256), dim3(256), 0, st, a);
 }
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list) {
     if (n_list == 0) return;

@@ -82,8 +82,10 @@ struct ChunkState {
 };
 struct ChunkDesc {
     uint32_t contig;
-    uint32_t seg;             // segment-table entry this chunk's list goes to
-    uint64_t cs, ce;          // positions [cs, ce), cs a multiple of 64
+    uint32_t seg;             // segment-table entry this chunk's list goes to (0xFFFFFFFF: probe, writes nothing)
+    uint64_t cs, ce;          // emission steps [cs, ce), cs a multiple of 64
+    uint64_t emit_lo_pos;     // elements below this position belong to the tile before an island: suppressed
+    uint64_t drain_end;       // > ce: keep stepping to here, emitting only elements with position < ce
     uint64_t region_off, region_cap;
     uint32_t warm;            // machine warm-up positions before cs (multiple of 64)
     uint32_t override_state;  // 1: install in_state at cs instead of trusting the warm-up
@@ -103,7 +105,8 @@ struct L1Args {
     unsigned long long *cursor;  // [0] overflow elements allocated, [1] overflow-of-the-overflow flag
     uint64_t *seg_off;           // [n_tiles + n_contigs]
     uint32_t *seg_cnt;           // [n_tiles + n_contigs]
-    uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the serial kernel)
+    uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the exact kernel)
+    uint8_t *tile_flags;         // [n_tiles] 1: the tile's extended range holds a palindromic k-mer / non-ACGT byte
 };
 void launch_level1_tiles(hipStream_t st, const L1Args &a);
 void launch_level1_tails(hipStream_t st, const L1Args &a);
@@ -111,6 +114,10 @@ void launch_level1_tails(hipStream_t st, const L1Args &a);
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status);
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list);
+// seg_cnt[s] = 0 for s in [ranges[2i], ranges[2i+1])
+void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges);
+// tile_flags |= 1 for tiles (of the listed contigs) whose extended range contains a non-ACGT byte
+void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // needs a.desc (after launch_level1_tiles)
 
 // level2.hip
 void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,

@@ -35,7 +35,7 @@ class Spec(C.Structure):
 class Prof(C.Structure):
     _fields_ = [("level1_ms", C.c_float), ("level1_aux_ms", C.c_float), ("level2_ms", C.c_float),
                 ("total_ms", C.c_float), ("n_level1", C.c_uint64), ("n_tiles", C.c_uint64),
-                ("n_serial_contigs", C.c_uint64), ("bases_tiled", C.c_uint64)]
+                ("n_serial_contigs", C.c_uint64), ("bases_tiled", C.c_uint64), ("exact_bases", C.c_uint64)]
 
 
 class HpsResult(C.Structure):

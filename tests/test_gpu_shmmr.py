@@ -183,6 +183,36 @@ def test_chunked_exact_machine_seams(oracle, gpu_ctx):
     assert prof.n_serial_contigs > 0
 
 
+def test_exact_islands_are_local(oracle, gpu_ctx):
+    """a few irregular spots in long contigs: only islands of tiles around them take the exact kernel, the rest
+    stays on the closed-form tile kernel, and the stitched lists are bit exact (island edges by position,
+    inner seams by emission step, right edge verified by a probe)"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(23)
+    L = 1_000_000
+    seqs = []
+    for spots in ([500_000], [10], [L - 5], [7990, 8010], [100_000, 108_050, 116_100], [250_000, 750_000],
+                  list(range(50_000, 950_000, 90_000))):
+        s = bytearray(seqgen.rnd(rng, L))
+        for p in spots:
+            s[p] = ord("N")
+        seqs.append(bytes(s))
+    s = bytearray(seqgen.rnd(rng, L))  # an N run of 3 tiles + a palindromic (AT)n + a lower-case stretch
+    s[300_000:325_000] = b"N" * 25_000
+    s[600_000:600_090] = b"AT" * 45
+    s[700_000:710_000] = bytes(s[700_000:710_000]).lower()
+    seqs.append(bytes(s))
+    seqs.append(seqgen.rnd(rng, L))  # a clean contig in the same batch
+    s = bytearray(seqgen.rnd(rng, 30_000))  # short contigs: island == whole contig
+    s[15_000] = ord("N")
+    seqs.append(bytes(s))
+    for spec_t in [(80, 56, 4, 64, False), (48, 56, 4, 12, False), (80, 56, 4, 64, True)]:
+        _check_batch(oracle, gpu_ctx, seqs, spec_t, what="islands")
+        prof = gpu_ctx.last_prof()
+        assert prof.n_serial_contigs >= 9
+        assert prof.exact_bases < 0.2 * sum(len(x) for x in seqs), prof.exact_bases  # islands, not whole contigs
+
+
 def test_ragged_and_empty(oracle, gpu_ctx):
     import pgrtk_amd as P
     sp = P.make_spec()

@@ -2,7 +2,8 @@ import sys, time
 sys.path.insert(0, "/root/repo/pgr-tk_amd"); sys.path.insert(0, "/root/repo/oracle")
 import numpy as np, pgrtk_amd as P, oracle as O
 ctx = P.default_context(0)
-n, L = 64, 10_000_000
+import os
+n, L = int(os.environ.get("NCONTIG", "64")), 10_000_000
 seqs = []
 for i in range(n):
     s = O.synth_contig(9, i, L).copy()
