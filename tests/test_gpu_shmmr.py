@@ -213,6 +213,43 @@ def test_exact_islands_are_local(oracle, gpu_ctx):
         assert prof.exact_bases < 0.2 * sum(len(x) for x in seqs), prof.exact_bases  # islands, not whole contigs
 
 
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_island_fuzz(oracle, gpu_ctx, seed):
+    """random irregularities (single N, N runs of random length, (AT)n / (CG)n palindromes, homopolymers, lower case,
+    bytes 0..3) at random places of 300 kbp contigs, random specs: tile kernel + exact islands == oracle"""
+    rng = np.random.default_rng(1000 + seed)
+    seqs = []
+    for _ in range(14):
+        L = int(rng.integers(60_000, 300_000))
+        s = bytearray(seqgen.rnd(rng, L))
+        for _ in range(int(rng.integers(0, 7))):
+            kind = int(rng.integers(0, 6))
+            p = int(rng.integers(0, L))
+            if kind == 0:
+                s[p] = ord("N")
+            elif kind == 1:
+                n = int(rng.choice([2, 60, 200, 5000, 20000, 70000]))
+                s[p:p + n] = b"N" * len(s[p:p + n])
+            elif kind == 2:
+                rep = (b"AT" if rng.random() < 0.5 else b"CG") * int(rng.integers(28, 90))
+                s[p:p + len(rep)] = rep[:len(s[p:p + len(rep)])]
+            elif kind == 3:
+                n = int(rng.integers(100, 3000))
+                s[p:p + n] = bytes([int(rng.choice(list(b"ACGT")))]) * len(s[p:p + n])
+            elif kind == 4:
+                n = int(rng.integers(10, 5000))
+                s[p:p + n] = bytes(s[p:p + n]).lower()
+            else:
+                n = int(rng.integers(1, 200))
+                s[p:p + n] = bytes(int(v) for v in rng.integers(0, 4, len(s[p:p + n])))
+        seqs.append(bytes(s))
+    specs = [(80, 56, 4, 64, False), (48, 56, 4, 12, False), (31, 24, 3, 8, False), (128, 56, 12, 64, False),
+             (80, 56, 4, 64, True)]
+    for spec_t in (specs[seed % len(specs)], specs[0]):
+        _check_batch(oracle, gpu_ctx, seqs, spec_t, what="island-fuzz seed %d" % seed)
+        _check_batch(oracle, gpu_ctx, seqs[:5], spec_t, padding=not spec_t[4], what="island-fuzz+pad")
+
+
 def test_ragged_and_empty(oracle, gpu_ctx):
     import pgrtk_amd as P
     sp = P.make_spec()
