@@ -9,6 +9,8 @@
 //   scan(seg counts) + gather       -> ordered per-contig level-1 lists
 //   select(reduce) x2, select(min_span) -> final MM128 lists (+ rid patch)
 #include <algorithm>
+#include <atomic>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -166,34 +168,71 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
     pgr_batch *b = nullptr;
     int rc = batch_alloc(ctx, n, lens, &b);
     if (rc) return rc;
-    // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Staged through a pinned window.
-    const uint64_t WIN_WORDS = 4ull << 20;  // 128 MiB of ASCII per window
+    // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Two pinned windows of 32 MiB: while window
+    // i is on its way to the GPU (H2D + pack kernel on the context's stream) the host threads fill window i+1.
+    const uint64_t WIN_WORDS = 1ull << 20;  // 32 MiB of ASCII per window
     const uint64_t win_words = std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
-    if ((rc = ctx->ensure_pinned(win_words * 32)) || (rc = ctx->ws_ascii.ensure(ctx, win_words * 32))) {
+    if ((rc = ctx->ensure_pinned(2 * win_words * 32)) || (rc = ctx->ws_ascii.ensure(ctx, 2 * win_words * 32))) {
         pgr_batch_destroy(b);
         return rc;
     }
+    hipEvent_t done[2] = {ctx->ev[0], ctx->ev[1]};
+    bool used[2] = {false, false};
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
     uint32_t c = 0;
-    for (uint64_t w0 = 0; w0 < b->total_words; w0 += win_words) {
+    int slot = 0;
+    for (uint64_t w0 = 0; w0 < b->total_words; w0 += win_words, slot ^= 1) {
         const uint64_t w1 = std::min(b->total_words, w0 + win_words);
-        uint8_t *stage = (uint8_t *)ctx->pinned;
+        uint8_t *stage = (uint8_t *)ctx->pinned + (size_t)slot * win_words * 32;
+        uint8_t *d_stage = (uint8_t *)ctx->ws_ascii.p + (size_t)slot * win_words * 32;
+        if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess) {  // this window's previous trip is over
+            pgr_batch_destroy(b);
+            return ctx->fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+        }
         while (c < n && b->h_word_off[c + 1] <= w0) ++c;
+        // copy jobs of this window: (dst, src, len), split into <= 4 MiB pieces and spread over the threads
+        struct Job {
+            uint8_t *dst;
+            const uint8_t *src;
+            size_t len;
+        };
+        std::vector<Job> jobs;
         for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1; ++cc) {
             const uint64_t cw0 = b->h_word_off[cc], cw1 = b->h_word_off[cc + 1];
             const uint64_t lo = std::max(cw0, w0), hi = std::min(cw1, w1);
             if (lo >= hi) continue;
             const uint64_t b_lo = (lo - cw0) * 32, b_hi = std::min<uint64_t>((hi - cw0) * 32, lens[cc]);
-            if (b_hi > b_lo) memcpy(stage + (lo - w0) * 32, seqs[cc] + b_lo, b_hi - b_lo);
+            for (uint64_t o = b_lo; o < b_hi; o += (4u << 20))
+                jobs.push_back(Job{stage + (lo - w0) * 32 + (o - b_lo), seqs[cc] + o,
+                                   (size_t)std::min<uint64_t>(4u << 20, b_hi - o)});
         }
-        if (hipMemcpyAsync(ctx->ws_ascii.p, stage, (w1 - w0) * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+        if (jobs.size() <= 1 || n_thr == 1) {
+            for (const Job &j : jobs) memcpy(j.dst, j.src, j.len);
+        } else {
+            std::atomic<size_t> next{0};
+            auto work = [&]() {
+                for (size_t i; (i = next.fetch_add(1)) < jobs.size();) memcpy(jobs[i].dst, jobs[i].src, jobs[i].len);
+            };
+            std::vector<std::thread> th;
+            for (unsigned t = 1; t < std::min<size_t>(n_thr, jobs.size()); ++t) th.emplace_back(work);
+            work();
+            for (auto &t : th) t.join();
+        }
+        if (hipMemcpyAsync(d_stage, stage, (w1 - w0) * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
             pgr_batch_destroy(b);
             return ctx->fail(PGR_ERR_DEVICE, "H2D copy of the ASCII window failed");
         }
-        launch_pack_ascii(ctx->stream, (const uint8_t *)ctx->ws_ascii.p, w0, b->d, n, w1);
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
+        launch_pack_ascii(ctx->stream, d_stage, w0, b->d, n, w1);
+        if (hipEventRecord(done[slot], ctx->stream) != hipSuccess) {
             pgr_batch_destroy(b);
-            return ctx->fail(PGR_ERR_DEVICE, "pack kernel failed");
+            return ctx->fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         }
+        used[slot] = true;
+    }
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+        pgr_batch_destroy(b);
+        return ctx->fail(PGR_ERR_DEVICE, "pack kernel failed");
     }
     if (n) {
         if (hipMemcpy(b->h_n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) !=
