@@ -760,6 +760,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         hipStreamSynchronize(st) != hipSuccess)
         return bail(ctx->fail(PGR_ERR_DEVICE, "D2H of the result offsets failed"));
     res->count = n_final;
+    res->rid_is_index = (d_rids == nullptr) && !pad_fix;
     if (pad_fix) {
         // reference artefact: reduce_shmmr on an EMPTY list with padding emits its sentinels
         // (shmmrutils.rs:367-380), which survive as exactly two {MAX,MAX} after the second pass + filter
@@ -870,7 +871,8 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
         PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rids.p, sids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         d_sids = (uint32_t *)ctx->ws_rids.p;
     }
-    launch_frag_recs(st, s->d_mm, s->d_off, (const uint64_t *)ctx->ws_rec_off.p, n, s->count, d_sids, query_side, d_out);
+    launch_frag_recs(st, s->d_mm, s->d_off, (const uint64_t *)ctx->ws_rec_off.p, n, s->count, d_sids, query_side,
+                     s->rid_is_index ? 1 : 0, d_out);
     PGR_HIP(ctx, hipStreamSynchronize(st));
     PGR_HIP(ctx, hipGetLastError());
     return PGR_OK;

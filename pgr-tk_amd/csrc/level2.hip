@@ -55,10 +55,11 @@ __global__ __launch_bounds__(256) void frag_recs_kernel(const pgr_mm128 *__restr
                                                         const uint64_t *__restrict__ off,
                                                         const uint64_t *__restrict__ rec_off, uint32_t n, uint64_t total,
                                                         const uint32_t *__restrict__ sids, int query_side,
-                                                        pgr_frag_rec *__restrict__ out) {
+                                                        int rid_is_index, pgr_frag_rec *__restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= total) return;
-    const uint32_t c = find_seg(off, n, i);
+    // contig of element i: the rid field itself when the caller did not override rids, else a search
+    const uint32_t c = rid_is_index ? (uint32_t)(mm[i].y >> 32) : find_seg(off, n, i);
     if (i + 1 >= off[c + 1]) return;  // last shimmer of the contig starts no pair
     const pgr_mm128 s0 = mm[i], s1 = mm[i + 1];
     const uint64_t h0 = s0.x >> 8, h1 = s1.x >> 8;
@@ -76,10 +77,11 @@ __global__ __launch_bounds__(256) void frag_recs_kernel(const pgr_mm128 *__restr
 }
 
 void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, const uint64_t *rec_off,
-                      uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, pgr_frag_rec *out) {
+                      uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, int rid_is_index,
+                      pgr_frag_rec *out) {
     if (n == 0) return;
     hipLaunchKernelGGL(frag_recs_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, mm, off, rec_off,
-                       n_contigs, n, sids, query_side, out);
+                       n_contigs, n, sids, query_side, rid_is_index, out);
 }
 
 }  // namespace pgr

@@ -54,6 +54,7 @@ struct pgr_shmmrs {
     pgr_mm128 *d_mm = nullptr;   // [count]
     uint64_t *d_off = nullptr;   // [n+1]
     std::vector<uint64_t> h_off; // [n+1]
+    bool rid_is_index = false;   // MM128.y >> 32 is the contig index (no rids given, no padding sentinels)
 };
 
 namespace pgr {
@@ -123,7 +124,8 @@ void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // needs a.des
 void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,
                             const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst);
 void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, const uint64_t *rec_off,
-                      uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, pgr_frag_rec *out);
+                      uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, int rid_is_index,
+                      pgr_frag_rec *out);
 
 void launch_contig_offsets(hipStream_t st, const uint64_t *seg_dst, const uint32_t *tile_first, uint32_t n,
                            uint32_t n_segs, uint64_t *off);

@@ -1,0 +1,18 @@
+"""breakdown of the query leg (configs[2] shape at reduced index size): where the time of
+pgr_query_hps_batch goes.  Run under rocprofv3 --kernel-trace --stats for the kernel view."""
+import sys, time
+sys.path.insert(0, "/root/repo/pgr-tk_amd"); sys.path.insert(0, "/root/repo")
+import numpy as np, pgrtk_amd as P
+from bench import synth_substrings
+ctx = P.default_context(0)
+n, L, nq, ql = 1000, 10_000_000, 10_000, 10_000
+sp = P.make_spec()
+batch = P.Batch.synthetic([L] * n, seed=2, ctx=ctx)
+ix = P.Index(sp, ctx=ctx); ix.add_resident(batch); ix.finalize()
+rng = np.random.default_rng(3)
+cs = rng.integers(0, n, nq); offs = rng.integers(0, L - ql, nq)
+qs = synth_substrings(2, cs, offs, ql)
+ix.query_hps_raw(qs[:100], 0.025)
+for rep in range(3):
+    t0 = time.perf_counter(); r = ix.query_hps_raw(qs, 0.025); dt = time.perf_counter() - t0
+    print("query batch: %d x %d bp in %.1f ms (%.0f q/s, %d hit pairs)" % (nq, ql, dt * 1e3, nq / dt, len(r["hps"])))
