@@ -175,7 +175,8 @@ def main():
     batch = P.Batch.synthetic(lens, seed=args.seed, contig0=contig0, ctx=ctx)  # inputs resident in HBM
     bp_per_step = batch.total_bases
 
-    rec_bufs = [None, None]  # double buffered: the all-gather of step i overlaps the kernels of step i+1
+    rec_buf = [None]         # local shimmer-pair records (the per-GPU index shard)
+    mm_bufs = [None, None]   # double buffered exchange buffers: the all-gather of step i overlaps step i+1
     state = {"i": 0, "pending": None}
 
     def finish_pending():
@@ -189,14 +190,21 @@ def main():
         slot = state["i"] & 1
         state["i"] += 1
         n_pairs = sh.n_pairs
-        if rec_bufs[slot] is None or rec_bufs[slot].shape[0] < n_pairs:
-            rec_bufs[slot] = torch.empty((int(n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64,
-                                         device="cuda:%d" % local_rank)
-        rec_buf = rec_bufs[slot]
-        n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=sids)
+        if rec_buf[0] is None or rec_buf[0].shape[0] < n_pairs:
+            rec_buf[0] = torch.empty((int(n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64,
+                                     device="cuda:%d" % local_rank)
+        n = sh.frag_recs_into(rec_buf[0].data_ptr(), rec_buf[0].shape[0], sids=sids)
         if world > 1 and not args.no_exchange:
-            finish_pending()  # step i-1's records have arrived everywhere
-            state["pending"] = exchange.PendingAllgather(rec_buf[:n] if args.backend == "nccl" else rec_buf[:n].cpu())
+            # what travels: the final MM128 lists with global sequence ids (16 B per shimmer; the pair records
+            # are adjacent shimmers and are re-derived by the receiver, pgr_index_add_shmmrs)
+            cnt = sh.count
+            if mm_bufs[slot] is None or mm_bufs[slot].shape[0] < cnt:
+                mm_bufs[slot] = torch.empty((int(cnt * 1.05) + 16, exchange.MM_WORDS), dtype=torch.int64,
+                                            device="cuda:%d" % local_rank)
+            finish_pending()  # step i-1's lists have arrived everywhere (and its buffer slot is free again)
+            sh.copy_into(mm_bufs[slot].data_ptr(), mm_bufs[slot].shape[0], rid_add=contig0)
+            local = mm_bufs[slot][:cnt]
+            state["pending"] = exchange.PendingAllgather(local if args.backend == "nccl" else local.cpu())
         p = ctx.last_prof()
         state["sh"] = sh
         state["n_pairs"] = n
@@ -244,7 +252,7 @@ def main():
                             "per GPU (seed %d), ShmmrSpec k=56 w=80 r=4 min_span=64, 2-bit packed input resident "
                             "in HBM, output = final MM128 lists + shimmer-pair records%s" %
                             (args.contigs, args.contig_len, args.seed,
-                             "" if world == 1 else (", pair records all-gathered over RCCL" if not args.no_exchange
+                             "" if world == 1 else (", per-GPU shimmer lists (pair endpoints, 16 B each) all-gathered over RCCL" if not args.no_exchange
                                                     else ", no exchange")),
                 "bp_per_gpu_per_step": bp_per_step, "parallelism": "contig-sharded x%d" % world,
                 "final_shimmers_per_gpu": mm_count, "pair_records_per_gpu": state["n_pairs"],

@@ -122,6 +122,12 @@ const uint64_t *pgr_shmmrs_device_offsets(const pgr_shmmrs *s);
 int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 **out_mm, uint64_t **out_off);
 void pgr_shmmrs_destroy(pgr_shmmrs *s);
 
+/* copy the MM128 list of a resident result into caller-owned DEVICE memory (e.g. a torch tensor that is then
+ * all-gathered over RCCL: 16 B per shimmer instead of 40 B per pair record). capacity in elements; rid_add is
+ * added to every rid (MM128.y >> 32), turning rank-local contig indices into global sequence ids. */
+int pgr_shmmrs_copy_to_device(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 *d_out, uint64_t capacity,
+                              uint32_t rid_add);
+
 /* device pair records from a resident result; d_out must hold count - n_nonempty records;
  * returns the number written in *n_out.  sids may be NULL.  d_out is a DEVICE pointer
  * (e.g. a torch tensor's data_ptr) so that per-GPU buffers can be all-gathered by RCCL.   */
@@ -159,6 +165,10 @@ int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_batch *b, cons
 /* merge pair records computed elsewhere (other GPUs, after the RCCL all-gather) */
 int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs, uint64_t n,
                           int recs_on_device);
+/* merge shimmer lists computed elsewhere: MM128 with y>>32 = sequence id; the shimmers of one sequence must be
+ * contiguous and in position order (what pgr_shmmrs_compute produces with rids = global ids); the pair records
+ * (seq_db.rs:381-400) are derived on the GPU.  mm is a host or a DEVICE pointer. */
+int pgr_index_add_shmmrs(pgr_ctx *ctx, pgr_index *ix, const pgr_mm128 *mm, uint64_t n, int mm_on_device);
 int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix); /* sort -> CSR (GPU) */
 uint64_t pgr_index_n_keys(const pgr_index *ix);
 uint64_t pgr_index_n_records(const pgr_index *ix);

@@ -833,6 +833,20 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
     return PGR_OK;
 }
 
+extern "C" int pgr_shmmrs_copy_to_device(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 *d_out, uint64_t capacity,
+                                         uint32_t rid_add) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!s || (s->count && !d_out)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (capacity < s->count) return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the shimmer list");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->count) {
+        launch_copy_add_rid(ctx->stream, s->d_mm, s->count, rid_add, d_out);
+        PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGR_HIP(ctx, hipGetLastError());
+    }
+    return PGR_OK;
+}
+
 extern "C" uint64_t pgr_shmmrs_n_pairs(const pgr_shmmrs *s) {
     if (!s) return 0;
     uint64_t np = 0;

@@ -177,6 +177,77 @@ extern "C" int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag
     return PGR_OK;
 }
 
+namespace {
+// pair records from a concatenation of per-sequence shimmer lists (y >> 32 = sequence id):
+// flags[i] = 1 iff (i, i+1) is a pair; rank = exclusive scan; run_start = first index of i's sequence
+__global__ void mm_pair_flags_kernel(const pgr_mm128 *__restrict__ mm, uint64_t n, uint32_t *__restrict__ flags) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    flags[i] = (i + 1 < n && (mm[i].y >> 32) == (mm[i + 1].y >> 32)) ? 1u : 0u;
+}
+__global__ void mm_to_recs_kernel(const pgr_mm128 *__restrict__ mm, uint64_t n, const uint32_t *__restrict__ flags,
+                                  const uint64_t *__restrict__ rank, pgr_frag_rec *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    const pgr_mm128 s0 = mm[i], s1 = mm[i + 1];
+    // ordinal of the pair in its sequence = number of pairs of the same sequence before it: walk back over
+    // the run start with the ranks (pairs of one sequence are consecutive ranks)
+    uint64_t lo = 0, hi = i;  // first index of the run of this sid: binary search on the sid field
+    const uint64_t sid = s0.y >> 32;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        // runs are contiguous: every element in [run_start, i] has this sid; elements before have another
+        if ((mm[mid].y >> 32) == sid && rank[i] - rank[mid] == i - mid) hi = mid;
+        else lo = mid + 1;
+    }
+    const uint64_t h0 = s0.x >> 8, h1 = s1.x >> 8;
+    const bool keep = h0 <= h1;  // index side (seq_db.rs:391)
+    pgr_frag_rec r;
+    r.h0 = keep ? h0 : h1;
+    r.h1 = keep ? h1 : h0;
+    r.frg_id = (uint32_t)(i - lo);
+    r.sid = (uint32_t)sid;
+    r.bgn = (uint32_t)((s0.y & 0xFFFFFFFFull) >> 1) + 1;
+    r.end = (uint32_t)((s1.y & 0xFFFFFFFFull) >> 1) + 1;
+    r.orient = keep ? 0u : 1u;
+    r._pad = 0;
+    out[rank[i]] = r;
+}
+}  // namespace
+
+extern "C" int pgr_index_add_shmmrs(pgr_ctx *ctx, pgr_index *ix, const pgr_mm128 *mm, uint64_t n, int on_device) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || (n && !mm)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (n < 2) return PGR_OK;
+    if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 shimmers in one call");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    int rc;
+    Tmp d_mm(ctx), flags(ctx), rank(ctx);
+    const pgr_mm128 *dm = mm;
+    if (!on_device) {
+        if ((rc = d_mm.alloc(n * sizeof(pgr_mm128)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(d_mm.p, mm, n * sizeof(pgr_mm128), hipMemcpyHostToDevice, st));
+        dm = d_mm.as<pgr_mm128>();
+    }
+    if ((rc = flags.alloc((n + 1) * 4)) || (rc = rank.alloc((n + 1) * 8))) return rc;
+    hipLaunchKernelGGL(mm_pair_flags_kernel, grid_for(n + 1), dim3(256), 0, st, dm, n, flags.as<uint32_t>());
+    const size_t tb = scan_counts_temp_bytes((uint32_t)(n + 1));
+    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, flags.as<uint32_t>(), rank.as<uint64_t>(), (uint32_t)(n + 1)));
+    uint64_t np = 0;
+    PGR_HIP(ctx, hipMemcpyAsync(&np, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = grow_raw(ctx, ix, ix->n_raw + np))) return rc;
+    hipLaunchKernelGGL(mm_to_recs_kernel, grid_for(n), dim3(256), 0, st, dm, n, flags.as<uint32_t>(), rank.as<uint64_t>(),
+                       ix->raw + ix->n_raw);
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    PGR_HIP(ctx, hipGetLastError());
+    ix->n_raw += np;
+    ix->finalized = false;
+    return PGR_OK;
+}
+
 extern "C" int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_batch *b, const uint32_t *sids) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix || !b) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");

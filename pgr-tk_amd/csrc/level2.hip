@@ -438,6 +438,18 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off) {
     hipLaunchKernelGGL(offsets_by_rid_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, mm, n, n_contigs, off);
 }
+__global__ void copy_add_rid_kernel(const pgr_mm128 *__restrict__ in, uint64_t n, uint32_t rid_add,
+                                    pgr_mm128 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pgr_mm128 m = in[i];
+    m.y += (uint64_t)rid_add << 32;
+    out[i] = m;
+}
+void launch_copy_add_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, uint32_t rid_add, pgr_mm128 *out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(copy_add_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, n, rid_add, out);
+}
 void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, uint64_t n, const uint32_t *rids) {
     if (n == 0) return;
     hipLaunchKernelGGL(patch_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, mm, n, rids);

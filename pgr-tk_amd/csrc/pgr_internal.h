@@ -155,6 +155,7 @@ struct FusedArgsPub {
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off);
 void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, uint64_t n, const uint32_t *rids);
+void launch_copy_add_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, uint32_t rid_add, pgr_mm128 *out);
 
 // scan.hip (rocPRIM device scans / sorts: plain library primitives, not the hot path)
 // exclusive scan of n+1 u32 counts (in[n] must be 0) into n+1 u64 offsets: out[n] = total

@@ -69,6 +69,8 @@ _SIGS = [
     ("pgr_shmmrs_download", C.c_int, [_VP, _VP, _PVP, _PVP]),
     ("pgr_shmmrs_destroy", None, [_VP]),
     ("pgr_shmmrs_n_pairs", C.c_uint64, [_VP]),
+    ("pgr_shmmrs_copy_to_device", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint32]),
+    ("pgr_index_add_shmmrs", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
     ("pgr_shmmrs_to_frag_recs_device", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.c_int, _VP, C.c_uint64,
                                                  C.POINTER(C.c_uint64)]),
     ("pgr_ctx_last_prof", C.c_int, [_VP, C.POINTER(Prof)]),

@@ -98,6 +98,13 @@ class Shmmrs:
         self.ctx.check(lib().pgr_shmmrs_download(self.ctx.handle, self._h, C.byref(pm), C.byref(po)))
         return _ffi.take(pm, cnt, MM128), _ffi.take(po, self.n + 1, np.dtype("<u8"))
 
+    def copy_into(self, device_ptr, capacity, rid_add=0):
+        """copy the MM128 list into caller-owned DEVICE memory (e.g. a torch tensor for the RCCL all-gather);
+        rid_add turns rank-local contig indices into global sequence ids"""
+        self.ctx.check(lib().pgr_shmmrs_copy_to_device(self.ctx.handle, self._h, C.c_void_p(device_ptr), capacity,
+                                                       int(rid_add)))
+        return self.count
+
     def frag_recs_into(self, device_ptr, capacity, sids=None, query_side=False):
         """write the shimmer-pair records into caller-owned DEVICE memory (e.g. a torch tensor)"""
         keep, sp = _u32_array(sids, self.n)
@@ -174,6 +181,15 @@ class Index:
             self.ctx.check(lib().pgr_index_add_records(self.ctx.handle, self._h, a.ctypes.data, a.size, 0))
         else:
             self.ctx.check(lib().pgr_index_add_records(self.ctx.handle, self._h, C.c_void_p(device_ptr), int(n), 1))
+
+    def add_shmmrs(self, mm=None, device_ptr=None, n=None):
+        """merge shimmer lists (MM128, rid = sequence id, one sequence's shimmers contiguous): a host array or
+        n elements at a DEVICE pointer (the all-gathered tensor); pair records are derived on the GPU"""
+        if mm is not None:
+            a = np.ascontiguousarray(mm, dtype=MM128)
+            self.ctx.check(lib().pgr_index_add_shmmrs(self.ctx.handle, self._h, a.ctypes.data, a.size, 0))
+        else:
+            self.ctx.check(lib().pgr_index_add_shmmrs(self.ctx.handle, self._h, C.c_void_p(device_ptr), int(n), 1))
 
     def finalize(self):
         self.ctx.check(lib().pgr_index_finalize(self.ctx.handle, self._h))

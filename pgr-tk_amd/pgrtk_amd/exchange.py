@@ -1,8 +1,11 @@
 """Multi-GPU exchange step: contigs are sharded across ranks (one process per GPU); every rank
-computes the shimmer-pair records of its own contigs, then the per-rank record buffers are
-all-gathered (RCCL over xGMI via torch.distributed, backend "nccl"; "gloo" on CPU in the tests)
-so that every rank -- in particular the one that owns the host-side ShmmrToFrags map -- holds
-the full record set in global (rank, sid, frg_id) order.
+computes the shimmers of its own contigs, then the per-rank buffers are all-gathered (RCCL over
+xGMI via torch.distributed, backend "nccl"; "gloo" on CPU in the tests) so that every rank -- in
+particular the one that owns the host-side ShmmrToFrags map -- holds the full set in global
+(rank, sid, position) order.  What travels is the final MM128 list (16 B per shimmer, rid =
+global sequence id); the shimmer-pair records (40 B per pair) are adjacent shimmers and are
+derived on the receiving GPU (pgr_index_add_shmmrs), 2.5x less traffic than shipping records.
+Rows are int64 tensors [n, words] (MM_WORDS or REC_WORDS).
 
 torch is plumbing here (device memory + the collective); no compute.
 """
@@ -10,6 +13,7 @@ import torch
 import torch.distributed as dist
 
 REC_WORDS = 5  # one pgr_frag_rec = 40 bytes = 5 x int64
+MM_WORDS = 2   # one MM128 = 16 bytes = 2 x int64 (what the ranks exchange: pairs are adjacent shimmers)
 
 
 def shard_contigs(lens, world_size):
@@ -33,7 +37,8 @@ class PendingAllgather:
 
     def __init__(self, local, group=None):
         world = dist.get_world_size(group)
-        assert local.dtype == torch.int64 and local.dim() == 2 and local.shape[1] == REC_WORDS
+        assert local.dtype == torch.int64 and local.dim() == 2
+        words = local.shape[1]
         self.local = local
         n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
         counts = torch.empty(world, dtype=torch.int64, device=local.device)
@@ -46,15 +51,15 @@ class PendingAllgather:
             if local.shape[0] == self.n_max:
                 padded = local.contiguous()
             else:
-                padded = local.new_zeros((self.n_max, REC_WORDS))
+                padded = local.new_zeros((self.n_max, words))
                 padded[: local.shape[0]] = local
             self.padded = padded
-            self.out = local.new_empty((world * self.n_max, REC_WORDS))
+            self.out = local.new_empty((world * self.n_max, words))
             self.work = dist.all_gather_into_tensor(self.out, padded, group=group, async_op=True)
 
     def wait(self):
         if self.work is None:
-            return self.local.new_zeros((0, REC_WORDS)), self.counts
+            return self.local.new_zeros((0, self.local.shape[1])), self.counts
         self.work.wait()
         if self.out.is_cuda:
             # the record buffers are rewritten by kernels on libpgrhip's own stream, which torch does not
@@ -71,20 +76,21 @@ def allgather_records(local, group=None):
     Returns (gathered [sum n, 5] in rank order, counts list).  Two collectives: the counts
     (8 bytes per rank) and one padded all-gather of the payload."""
     world = dist.get_world_size(group)
-    assert local.dtype == torch.int64 and local.dim() == 2 and local.shape[1] == REC_WORDS
+    assert local.dtype == torch.int64 and local.dim() == 2
+    words = local.shape[1]
     n_local = torch.tensor([local.shape[0]], dtype=torch.int64, device=local.device)
     counts = torch.empty(world, dtype=torch.int64, device=local.device)
     dist.all_gather_into_tensor(counts, n_local, group=group)
     counts_h = [int(v) for v in counts.cpu()]
     n_max = max(counts_h) if counts_h else 0
     if n_max == 0:
-        return local.new_zeros((0, REC_WORDS)), counts_h
+        return local.new_zeros((0, words)), counts_h
     if local.shape[0] == n_max:
         padded = local.contiguous()
     else:
-        padded = local.new_zeros((n_max, REC_WORDS))
+        padded = local.new_zeros((n_max, words))
         padded[: local.shape[0]] = local
-    out = local.new_empty((world * n_max, REC_WORDS))
+    out = local.new_empty((world * n_max, words))
     dist.all_gather_into_tensor(out, padded, group=group)
     if all(c == n_max for c in counts_h):
         return out, counts_h

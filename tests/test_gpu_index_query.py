@@ -258,3 +258,39 @@ def test_cli_mdb_and_query(oracle, gpu_ctx, golden_dir, tmp_path):
     sdb = P.SeqIndexDB(ctx=gpu_ctx)
     sdb.load_from_mdb_index(prefix)
     assert sdb.get_shmmr_map() == m and sdb.get_shmmr_spec() == (80, 56, 4, 64, False)
+
+
+def test_index_from_exchanged_shimmer_lists(oracle, gpu_ctx):
+    """multi-GPU merge path on one GPU: two "ranks" index disjoint contig shards, copy their MM128 lists with
+    global sequence ids (what the RCCL all-gather moves), and an index built from the concatenated lists
+    (pgr_index_add_shmmrs) equals the index built from all sequences directly"""
+    import ctypes as C
+    import torch
+    import pgrtk_amd as P
+    rng = np.random.default_rng(31)
+    seqs = [seqgen.rnd(rng, int(L)) for L in (50_000, 120_000, 100, 0, 80_000, 30_000, 64_000)]
+    sp = P.make_spec()
+    shards = [(0, seqs[:3]), (3, seqs[3:])]
+    parts = []
+    for contig0, sub in shards:
+        b = P.Batch.from_seqs(sub, ctx=gpu_ctx)
+        sh = b.shmmrs(sp)
+        t = torch.empty((sh.count + 4, 2), dtype=torch.int64, device="cuda:0")
+        n = sh.copy_into(t.data_ptr(), t.shape[0], rid_add=contig0)
+        parts.append(t[:n])
+    gathered = torch.cat(parts[::-1], dim=0)  # rank order does not matter
+    ix = P.Index(sp, ctx=gpu_ctx)
+    ix.add_shmmrs(device_ptr=gathered.data_ptr(), n=gathered.shape[0])
+    ix.finalize()
+    ref = P.Index(sp, ctx=gpu_ctx)
+    ref.add_seqs(seqs)
+    ref.finalize()
+    a, b2 = ix.download(), ref.download()
+    assert len(a) == len(b2) > 100 and ix.n_keys == ref.n_keys
+    for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+        assert np.array_equal(a[f], b2[f]), f
+    # host-array form
+    ix2 = P.Index(sp, ctx=gpu_ctx)
+    ix2.add_shmmrs(mm=np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=P.MM128))
+    ix2.finalize()
+    assert np.array_equal(ix2.download()["bgn"], b2["bgn"])
