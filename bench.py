@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only for plumbing tests)")
     ap.add_argument("--single-device", action="store_true",
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="plumbing test: run the process group + exchange code path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -156,9 +158,13 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -194,7 +200,7 @@ def main():
             rec_buf[0] = torch.empty((int(n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64,
                                      device="cuda:%d" % local_rank)
         n = sh.frag_recs_into(rec_buf[0].data_ptr(), rec_buf[0].shape[0], sids=sids)
-        if world > 1 and not args.no_exchange:
+        if use_dist and not args.no_exchange:
             # what travels: the final MM128 lists with global sequence ids (16 B per shimmer; the pair records
             # are adjacent shimmers and are re-derived by the receiver, pgr_index_add_shmmrs)
             cnt = sh.count
@@ -213,7 +219,7 @@ def main():
     def sync():
         finish_pending()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -224,7 +230,7 @@ def main():
     profs = [step() for _ in range(args.steps)]
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=("cuda:%d" % local_rank) if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -276,7 +282,7 @@ def main():
             gpu_counts = [int(off[i + 1] - off[i]) for i in range(args.contigs)]
             out["cpu_baseline"] = cpu_baseline(spec_t, args.contigs, args.contig_len, args.seed, contig0, gpu_counts)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -29,3 +29,22 @@ def adversarial(rng, mode, L):
 
 
 N_MODES = 8
+
+
+def amy1a_like(seed=4, n_hap=96, L=200_000, unit=10_000, snp_rate=0.001):
+    """BASELINE.json configs[3]: one random ancestor + per-haplotype
+    0.1 % SNPs and 3..10 tandem copies of a 10 kbp unit (AMY1A-like copy-number variation)."""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    anc = rng.choice(acgt, L)
+    u0 = L // 2
+    left, rep, right = anc[:u0], anc[u0:u0 + unit], anc[u0 + unit:]
+    haps = []
+    for _ in range(n_hap):
+        copies = int(rng.integers(3, 11))
+        h = np.concatenate([left] + [rep] * copies + [right]).copy()
+        n_snp = int(len(h) * snp_rate)
+        pos = rng.choice(len(h), n_snp, replace=False)
+        h[pos] = acgt[(np.searchsorted(acgt, h[pos]) + rng.integers(1, 4, n_snp)) % 4]
+        haps.append(h.tobytes())
+    return haps

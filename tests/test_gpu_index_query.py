@@ -294,3 +294,32 @@ def test_index_from_exchanged_shimmer_lists(oracle, gpu_ctx):
     ix2.add_shmmrs(mm=np.frombuffer(gathered.cpu().numpy().tobytes(), dtype=P.MM128))
     ix2.finalize()
     assert np.array_equal(ix2.download()["bgn"], b2["bgn"])
+
+
+def test_pangenome_config4_index_and_query(oracle, gpu_ctx):
+    """BASELINE.json configs[3] input (96 AMY1A-like haplotypes, tandem 10 kbp copies, 0.1 % SNPs) at the
+    pgr-pbundle-decomp spec (48,56,4,12): frag_map records and hit chains equal the oracle's.  Repeats
+    make every key occur ~96 x copies times, which is what the count filters of aln.rs:203-222 cut on."""
+    import ctypes as C
+    from pgrtk_amd import _ffi
+    haps = seqgen.amy1a_like(seed=4, n_hap=96, L=200_000)
+    spec_t = (48, 56, 4, 12)
+    sdb, oix = _build_pair(oracle, gpu_ctx, haps, spec_t)
+    ref = oix.records()
+    p, n = C.c_void_p(), C.c_uint64()
+    gpu_ctx.check(_ffi.lib().pgr_index_download(gpu_ctx.handle, sdb._ix, C.byref(p), C.byref(n)))
+    got = _ffi.take(p, int(n.value), _ffi.FRAG_REC)
+    assert len(got) == len(ref) > 96 * 1000
+    for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+        assert np.array_equal(ref[f], got[f]), f
+    # queries: a unique flank, the repeat unit, and a reverse-complemented slice across the repeat boundary
+    h0 = haps[0]
+    queries = [h0[20_000:45_000], h0[100_000:112_000], revcomp(h0[90_000:125_000])]
+    n_chains = 0
+    for q in queries:
+        for cap in (128, 4096):
+            got_h = sdb.query_fragment_to_hps(q, 0.025, cap, cap, cap, 8)
+            ref_h = _oracle_hps_to_tuples(oix.query_fragment_to_hps(q, 0.025, cap, cap, cap, 8))
+            assert got_h == ref_h
+            n_chains += sum(len(c) for _, c in ref_h)
+    assert n_chains > 96
