@@ -217,6 +217,92 @@ int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_hitpair *hit
                          const uint64_t *g_off, uint32_t max_span, float penalty, int has_max_gap,
                          uint32_t max_gap, int oriented, pgr_hps_result *out);
 
+/* ------------------------------------------------------------------ next: MAP-graph + principal bundles
+ * Consumers of the frag_map (BASELINE.json configs[3], pgr-pbundle-decomp).  The data-parallel parts run on
+ * the GPU (adjacency list = one sort + a 2-point stencil over all records; bundle lookup of every shimmer pair);
+ * the graph walks are small serial host code inside the library, like the reference's.                       */
+
+/* ShmmrGraphNode (pgr-db/src/graph_utils.rs:47) + its weight = frag_map[(h0,h1)].len() (seq_db.rs:1038-1043) */
+typedef struct {
+    uint64_t h0, h1;
+    uint32_t orient;
+    uint32_t count;
+} pgr_vertex;
+
+/* AdjPair (graph_utils.rs:49): (sid, v, w) */
+typedef struct {
+    uint32_t sid, _pad;
+    pgr_vertex v, w;
+} pgr_adj_pair;
+
+/* seq_db::frag_map_to_adj_list (pgr-db/src/seq_db.rs:876-945) on a finalized index.
+ * keeps == NULL <=> None.  *out is pgr_free'd by the caller.                                                  */
+int pgr_index_adj_list(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count, const uint32_t *keeps,
+                       uint32_t n_keeps, pgr_adj_pair **out, uint64_t *n_out);
+
+/* frag_map[(h0,h1)].len() for n keys (pgr-tk/src/lib.rs:636 get_shmmr_pair_count, batched); keys = n x {h0,h1} */
+int pgr_index_key_counts(pgr_ctx *ctx, const pgr_index *ix, uint64_t n, const uint64_t *keys,
+                         uint32_t *counts);
+
+/* one element of seq_db::sort_adj_list_by_weighted_dfs (seq_db.rs:1006-1062):
+ * (node, Option<previous node>, node weight = node.count, is_leaf, global_rank, branch, branch_rank)          */
+typedef struct {
+    pgr_vertex node, parent;
+    uint32_t has_parent, is_leaf, rank, branch, branch_rank, _pad;
+} pgr_dfs_node;
+int pgr_sort_adj_list_by_weighted_dfs(pgr_ctx *ctx, const pgr_adj_pair *adj, uint64_t n,
+                                      const pgr_vertex *start, pgr_dfs_node **out, uint64_t *n_out);
+
+/* principal bundles: bundle b = vertices[b_off[b], b_off[b+1]);  bundle_id / mean_ord are filled by the
+ * "with id" entry points (ext.rs:552-650: bundles re-ordered by mean position along the sequences,
+ * reversed by direction vote), otherwise bundle_id[b] = b and mean_ord[b] = 0.                               */
+typedef struct {
+    uint64_t n_bundles;
+    uint64_t *b_off;
+    uint64_t *bundle_id;
+    uint64_t *mean_ord;
+    uint64_t n_vertices;
+    pgr_vertex *vertices;
+} pgr_bundles;
+void pgr_bundles_free(pgr_bundles *b);
+
+/* SeqIndexDB::get_principal_bundles (ext.rs:491-510) = frag_map_to_adj_list +
+ * get_principal_bundles_from_adj_list (seq_db.rs:1064-1186) */
+int pgr_principal_bundles(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count, uint32_t path_len_cutoff,
+                          const uint32_t *keeps, uint32_t n_keeps, pgr_bundles *out);
+/* the same from a caller-provided adjacency list (seq_db.rs:1064) */
+int pgr_principal_bundles_from_adj_list(pgr_ctx *ctx, const pgr_adj_pair *adj, uint64_t n,
+                                        uint32_t path_len_cutoff, pgr_bundles *out);
+
+/* one shimmer pair of a sequence annotated with its principal bundle
+ * ((h0,h1,p0,p1,orient), Option<(bundle_id, direction, position)>)  ext.rs:976-1014 */
+typedef struct {
+    uint64_t h0, h1;
+    uint32_t bgn, end;
+    uint32_t orient;     /* query-side orientation (strict <, ext.rs:534-548) */
+    uint32_t sid;
+    int32_t bundle_id;   /* -1: None */
+    uint32_t bundle_dir;
+    uint32_t bundle_pos;
+    uint32_t _pad;
+} pgr_smp_bundle;
+
+/* get_principal_bundle_decomposition (pgr-tk/src/lib.rs:1066-1100, ext.rs:552-650 + 976-1014) over the
+ * index's own sequences: bundles with id + every shimmer pair annotated, grouped by sequence in
+ * ascending sid (smps of sequence j = smps[seq_off[j], seq_off[j+1]), its id seq_sid[j]).
+ * Outputs are pgr_free'd / pgr_bundles_free'd by the caller.                                                  */
+int pgr_principal_bundle_decomposition(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count,
+                                       uint32_t path_len_cutoff, const uint32_t *keeps, uint32_t n_keeps,
+                                       pgr_bundles *bundles, pgr_smp_bundle **smps, uint64_t *n_smps,
+                                       uint32_t **seq_sid, uint64_t **seq_off, uint32_t *n_seqs);
+/* get_principal_bundle_projection (pgr-tk/src/lib.rs:1128-1146): the same for caller-provided sequences
+ * (ASCII, host), which also vote on bundle order and direction.                                              */
+int pgr_principal_bundle_projection(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count,
+                                    uint32_t path_len_cutoff, const uint32_t *keeps, uint32_t n_keeps,
+                                    uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                                    const uint32_t *sids, pgr_bundles *bundles, pgr_smp_bundle **smps,
+                                    uint64_t *n_smps, uint64_t **seq_off);
+
 #ifdef __cplusplus
 }
 #endif

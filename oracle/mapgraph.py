@@ -173,7 +173,7 @@ class BinaryHeap:
             pos = 0
             hole = d[0]
             child = 1
-            while child <= max(end, 2) - 2 and child + 1 < end + 0 or (end >= 2 and child <= end - 2):
+            while child <= max(end - 2, 0):  # end.saturating_sub(2)
                 if d[child][0] <= d[child + 1][0]:
                     child += 1
                 d[pos] = d[child]

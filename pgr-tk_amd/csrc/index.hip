@@ -14,45 +14,19 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "pgr_ctx.h"
+#include "pgr_index.h"
 #include "pgr_device.h"
 
 using namespace pgr;
 
-struct pgr_index {
-    pgr_ctx *ctx = nullptr;
-    pgr_spec spec = {};
-    pgr_frag_rec *raw = nullptr;  // appended records (device)
-    uint64_t n_raw = 0, cap_raw = 0;
-    pgr_frag_rec *recs = nullptr;  // sorted records (device), valid when finalized
-    uint64_t n = 0;
-    uint64_t *key_off = nullptr;  // [n_keys + 1]
-    uint64_t n_keys = 0;
-    bool finalized = false;
-    uint32_t next_sid = 0;
-};
-
 namespace {
-
-// ------------------------------------------------------------------ small RAII device temp
-struct Tmp {
-    pgr_ctx *ctx;
-    void *p = nullptr;
-    explicit Tmp(pgr_ctx *c) : ctx(c) {}
-    ~Tmp() { ctx->dfree(p); }
-    int alloc(size_t bytes) { return ctx->dmalloc(&p, std::max<size_t>(bytes, 16)); }
-    template <class T>
-    T *as() const { return reinterpret_cast<T *>(p); }
-    Tmp(const Tmp &) = delete;
-    Tmp &operator=(const Tmp &) = delete;
-};
 
 __global__ void iota_kernel(uint32_t *idx, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (uint32_t)i;
 }
 
-// field: 0 frg_id, 1 sid, 2 h1, 3 h0, 4 bgn
+// field: pgr::RecField
 __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint32_t *__restrict__ idx, int field,
                                uint64_t *__restrict__ keys, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -64,7 +38,9 @@ __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint
     case 1: k = r.sid; break;
     case 2: k = r.h1; break;
     case 3: k = r.h0; break;
-    default: k = r.bgn; break;
+    case 4: k = r.bgn; break;
+    case 5: k = r.end; break;
+    default: k = r.orient; break;
     }
     keys[i] = k;
 }
@@ -96,11 +72,11 @@ __global__ void scatter_starts_kernel(const uint32_t *__restrict__ flags, const 
     if (flags[i]) starts[rank[i]] = i;
 }
 
-inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
-
 // multi-pass stable LSD sort of a permutation; fields are sorted in the given order (least significant first)
-int sort_perm(pgr_ctx *ctx, const pgr_frag_rec *recs, uint64_t n, const int *fields, const unsigned *bits, int n_fields,
-              uint32_t *idx_a /*in: perm, out: sorted perm*/, uint32_t *idx_b, uint64_t *keys_a, uint64_t *keys_b) {
+}  // namespace
+
+int pgr::sort_perm(pgr_ctx *ctx, const pgr_frag_rec *recs, uint64_t n, const int *fields, const unsigned *bits, int n_fields,
+                   uint32_t *idx_a /*in: perm, out: sorted perm*/, uint32_t *idx_b, uint64_t *keys_a, uint64_t *keys_b) {
     hipStream_t st = ctx->stream;
     const size_t tb = sort_pairs_temp_bytes(n);
     int rc;
@@ -114,6 +90,15 @@ int sort_perm(pgr_ctx *ctx, const pgr_frag_rec *recs, uint64_t n, const int *fie
     if (cur != idx_a) PGR_HIP(ctx, hipMemcpyAsync(idx_a, cur, n * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
     return PGR_OK;
 }
+
+void pgr::launch_iota(hipStream_t st, uint32_t *idx, uint64_t n) {
+    if (n) hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx, n);
+}
+void pgr::launch_gather_recs(hipStream_t st, const pgr_frag_rec *in, const uint32_t *idx, pgr_frag_rec *out, uint64_t n) {
+    if (n) hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, in, idx, out, n);
+}
+
+namespace {
 
 int grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) {
     if (need <= ix->cap_raw) return PGR_OK;

@@ -1,0 +1,48 @@
+// pgr_index.h -- the GPU-resident ShmmrToFrags index object shared by index.hip (build / query) and
+// mapgraph.hip (MAP-graph adjacency list, principal bundles).
+#pragma once
+#include <algorithm>
+
+#include "pgr_ctx.h"
+
+struct pgr_index {
+    pgr_ctx *ctx = nullptr;
+    pgr_spec spec = {};
+    pgr_frag_rec *raw = nullptr;  // appended records (device)
+    uint64_t n_raw = 0, cap_raw = 0;
+    pgr_frag_rec *recs = nullptr;  // sorted records (device), valid when finalized
+    uint64_t n = 0;
+    uint64_t *key_off = nullptr;  // [n_keys + 1]
+    uint64_t n_keys = 0;
+    bool finalized = false;
+    uint32_t next_sid = 0;
+};
+
+namespace pgr {
+
+// small RAII device temp (from the context's caching allocator)
+struct Tmp {
+    pgr_ctx *ctx;
+    void *p = nullptr;
+    explicit Tmp(pgr_ctx *c) : ctx(c) {}
+    ~Tmp() { ctx->dfree(p); }
+    int alloc(size_t bytes) { return ctx->dmalloc(&p, std::max<size_t>(bytes, 16)); }
+    template <class T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+    Tmp(const Tmp &) = delete;
+    Tmp &operator=(const Tmp &) = delete;
+};
+
+inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
+
+// record fields usable as sort keys
+enum RecField { F_FRG_ID = 0, F_SID = 1, F_H1 = 2, F_H0 = 3, F_BGN = 4, F_END = 5, F_ORIENT = 6 };
+
+// multi-pass stable LSD radix sort of a permutation of recs; fields are given least significant first.
+// idx_a: in = initial permutation, out = sorted permutation
+int sort_perm(pgr_ctx *ctx, const pgr_frag_rec *recs, uint64_t n, const int *fields, const unsigned *bits, int n_fields,
+              uint32_t *idx_a, uint32_t *idx_b, uint64_t *keys_a, uint64_t *keys_b);
+void launch_iota(hipStream_t st, uint32_t *idx, uint64_t n);
+void launch_gather_recs(hipStream_t st, const pgr_frag_rec *in, const uint32_t *idx, pgr_frag_rec *out, uint64_t n);
+
+}  // namespace pgr

@@ -15,6 +15,12 @@ MM128 = np.dtype([("x", "<u8"), ("y", "<u8")])
 FRAG_REC = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("frg_id", "<u4"), ("sid", "<u4"), ("bgn", "<u4"),
                      ("end", "<u4"), ("orient", "<u4"), ("_pad", "<u4")])
 HITPAIR = np.dtype([("qb", "<u4"), ("qe", "<u4"), ("qo", "<u4"), ("tb", "<u4"), ("te", "<u4"), ("to", "<u4")])
+VERTEX = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("orient", "<u4"), ("count", "<u4")])
+ADJ_PAIR = np.dtype([("sid", "<u4"), ("_pad", "<u4"), ("v", VERTEX), ("w", VERTEX)])
+DFS_NODE = np.dtype([("node", VERTEX), ("parent", VERTEX), ("has_parent", "<u4"), ("is_leaf", "<u4"), ("rank", "<u4"),
+                     ("branch", "<u4"), ("branch_rank", "<u4"), ("_pad", "<u4")])
+SMP_BUNDLE = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("bgn", "<u4"), ("end", "<u4"), ("orient", "<u4"), ("sid", "<u4"),
+                       ("bundle_id", "<i4"), ("bundle_dir", "<u4"), ("bundle_pos", "<u4"), ("_pad", "<u4")])
 
 
 class PgrError(RuntimeError):
@@ -43,6 +49,11 @@ class HpsResult(C.Structure):
                 ("t_sid", C.POINTER(C.c_uint32)), ("t_off", C.POINTER(C.c_uint64)), ("n_chains", C.c_uint64),
                 ("c_score", C.POINTER(C.c_float)), ("c_off", C.POINTER(C.c_uint64)), ("n_hps", C.c_uint64),
                 ("hps", C.c_void_p)]
+
+
+class Bundles(C.Structure):
+    _fields_ = [("n_bundles", C.c_uint64), ("b_off", C.POINTER(C.c_uint64)), ("bundle_id", C.POINTER(C.c_uint64)),
+                ("mean_ord", C.POINTER(C.c_uint64)), ("n_vertices", C.c_uint64), ("vertices", C.c_void_p)]
 
 
 # every symbol declared in include/pgr_hip.h: (name, restype, argtypes)
@@ -93,6 +104,20 @@ _SIGS = [
     ("pgr_hps_result_free", None, [C.POINTER(HpsResult)]),
     ("pgr_sparse_aln_batch", C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64), C.c_uint32, C.c_float, C.c_int,
                                        C.c_uint32, C.c_int, C.POINTER(HpsResult)]),
+    ("pgr_index_adj_list", C.c_int, [_VP, _VP, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, _PVP,
+                                     C.POINTER(C.c_uint64)]),
+    ("pgr_index_key_counts", C.c_int, [_VP, _VP, C.c_uint64, _VP, _VP]),
+    ("pgr_sort_adj_list_by_weighted_dfs", C.c_int, [_VP, _VP, C.c_uint64, _VP, _PVP, C.POINTER(C.c_uint64)]),
+    ("pgr_bundles_free", None, [C.POINTER(Bundles)]),
+    ("pgr_principal_bundles", C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
+                                        C.POINTER(Bundles)]),
+    ("pgr_principal_bundles_from_adj_list", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, C.POINTER(Bundles)]),
+    ("pgr_principal_bundle_decomposition", C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
+                                                     C.POINTER(Bundles), _PVP, C.POINTER(C.c_uint64), _PVP, _PVP,
+                                                     C.POINTER(C.c_uint32)]),
+    ("pgr_principal_bundle_projection", C.c_int, [_VP, _VP, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32,
+                                                  C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32),
+                                                  C.POINTER(Bundles), _PVP, C.POINTER(C.c_uint64), _PVP]),
 ]
 SYMBOLS = [s[0] for s in _SIGS]
 

@@ -8,6 +8,10 @@
         pgr-query (pgr-bin/src/bin/pgr-query.rs:17-409): chains -> per-target regions -> <out>.NNN.hit[.bed]
         (and <out>.NNN.fa with --fastx_file unless --only_summary).
 
+  python -m pgrtk_amd.cli pbundle-decomp <fastx> <out_prefix> [-w 48 -k 56 -r 4 --min-span 12 --min-cov 0 ...]
+        pgr-pbundle-decomp (pgr-bin/src/bin/pgr-pbundle-decomp.rs:139-531): MAP-graph principal bundles of the
+        sequences of <fastx> and the bundle decomposition of every contig -> <out>.bed + <out>.ctg.summary.tsv.
+
 Sequence iteration, range merging and file writing are host code, as in the reference; shimmers, the
 frag_map and the chaining run on the GPU.
 """
@@ -153,6 +157,132 @@ def cmd_query(args):
                     fa.write(">%s\n%s\n" % (tname, t.decode("ascii", "replace")))
 
 
+# ----------------------------------------------------------------------------- pgr-pbundle-decomp
+def group_smps_by_principle_bundle_id(smps, bundle_length_cutoff, bundle_merge_distance):
+    """pgr-pbundle-decomp.rs:61-137: runs of shimmer pairs on the same (bundle, direction) longer than
+    bundle_length_cutoff, neighbouring runs of the same bundle merged when closer than bundle_merge_distance.
+    smps = [((h0,h1,p0,p1,o), (bundle id, direction, position) | None)] -> [[(smp, bid, direction, bpos)]]"""
+    parts, cur = [], []
+    pre = None
+    for smp, info in smps:
+        if info is None:
+            continue
+        key = (info[0], 0 if smp[4] == info[1] else 1)
+        if pre is not None and key != pre:
+            if cur[-1][0][3] - cur[0][0][2] > bundle_length_cutoff:
+                parts.append(cur)
+            cur = []
+        pre = key
+        cur.append((smp, key[0], key[1], info[2]))
+    if cur and cur[-1][0][3] - cur[0][0][2] > bundle_length_cutoff:
+        parts.append(cur)
+    merged = []
+    for p in parts:
+        if merged and merged[-1][-1][1] == p[0][1] and merged[-1][-1][2] == p[0][2] and \
+                abs(p[0][0][2] - merged[-1][-1][0][3]) < bundle_merge_distance:
+            merged[-1] = merged[-1] + p
+        else:
+            merged.append(p)
+    return merged
+
+
+def pbundle_partitions(seq_names, decomposition, bundle_length_cutoff, bundle_merge_distance):
+    """per contig in name order (rs:343): [(sid, name, partitions, {bid: count})]"""
+    by_sid = dict(decomposition)
+    out = []
+    for sid, name in sorted(seq_names.items(), key=lambda t: t[1]):
+        parts = group_smps_by_principle_bundle_id(by_sid.get(sid, []), bundle_length_cutoff, bundle_merge_distance)
+        cnt = {}
+        for p in parts:
+            cnt[p[0][1]] = cnt.get(p[0][1], 0) + 1
+        out.append((sid, name, parts, cnt))
+    return out
+
+
+def pbundle_bed_lines(seq_names, decomposition, bundles_with_id, k, bundle_length_cutoff=2500, bundle_merge_distance=10000):
+    """the body of <out>.bed (rs:355-394): ctg, bgn, end, bid:bundle size:direction:first pos:last pos:R|U"""
+    size = {b[0]: len(b[2]) for b in bundles_with_id}
+    lines = []
+    for _sid, name, parts, cnt in pbundle_partitions(seq_names, decomposition, bundle_length_cutoff, bundle_merge_distance):
+        for p in parts:
+            bid = p[0][1]
+            lines.append("%s\t%d\t%d\t%d:%d:%d:%d:%d:%s" % (name, p[0][0][2], p[-1][0][3] + k, bid, size[bid], p[0][2], p[0][3],
+                                                            p[-1][3], "R" if cnt[bid] > 1 else "U"))
+    return lines
+
+
+def _f32(x):
+    """Rust `{}` of an f32: shortest decimal that round-trips, no exponent, no trailing .0"""
+    x = np.float32(x)
+    if np.isnan(x):
+        return "NaN"
+    if np.isinf(x):
+        return "inf" if x > 0 else "-inf"
+    return np.format_float_positional(x, unique=True, trim="-")
+
+
+def pbundle_summary_lines(seq_info, partitions, k):
+    """<out>.ctg.summary.tsv (rs:396-530); seq_info = {sid: (name, source, len)}"""
+    hdr = ["ctg", "length", "repeat_bundle_count", "repeat_bundle_sum", "repeat_bundle_percentage", "repeat_bundle_mean",
+           "repeat_bundle_min", "repeat_bundle_max", "non_repeat_bundle_count", "non_repeat_bundle_sum",
+           "non_repeat_bundle_percentage", "non_repeat_bundle_mean", "non_repeat_bundle_min", "non_repeat_bundle_max",
+           "total_bundle_count", "total_bundle_coverage_percentage"]
+    lines = ["#" + "\t".join(hdr)]
+    f32 = np.float32
+    for sid, name, parts, cnt in partitions:
+        ln = seq_info[sid][2]
+        rep, non = [], []
+        for p in parts:
+            # e - b - k with e = last end + k (rs:362-372)
+            (rep if cnt[p[0][1]] > 1 else non).append(p[-1][0][3] - p[0][0][2])
+        rs, ns = sum(rep) & 0xFFFFFFFF, sum(non) & 0xFFFFFFFF
+
+        def stats(v, total):
+            if not v:
+                return ["NA", "NA", "NA"]
+            return [_f32(f32(total) / f32(len(v))), str(min(v)), str(max(v))]
+        rmean, rmin, rmax = stats(rep, rs)
+        nmean, nmin, nmax = stats(non, ns)
+        lines.append("\t".join([name, str(ln), str(len(rep)), str(rs), _f32(f32(100.0) * f32(rs) / f32(ln)), rmean, rmin, rmax,
+                                str(len(non)), str(ns), _f32(f32(100.0) * f32(ns) / f32(ln)), nmean, nmin, nmax,
+                                str(len(rep) + len(non)), _f32(f32(100.0) * f32((rs + ns) & 0xFFFFFFFF) / f32(ln))]))
+    return lines
+
+
+def cmd_pbundle_decomp(args):
+    sdb = SeqIndexDB()
+    sdb.load_from_fastx(args.fastx_path, args.w, args.k, args.r, args.min_span)
+    bundles, dec = sdb.get_principal_bundle_decomposition(args.min_cov, args.min_branch_size)
+    seq_info = sdb.seq_info
+    if args.decomp_fastx_path or args.include:
+        # decomposition of other sequences with the vertex map voted by <fastx_path>'s own sequences
+        # (rs:247-292 + ext.rs:976-1014): every bundle vertex is a shimmer pair of those sequences, so the map is
+        # exactly the annotation of their pairs
+        vmap = {(smp[0], smp[1]): info for _, smps in dec for smp, info in smps if info is not None}
+        recs = read_fastx(args.decomp_fastx_path or args.fastx_path)
+        if args.include:
+            want = set(l.strip() for l in open(args.include) if l.strip())
+            recs = [r for r in recs if r[0] in want]
+        seq_info = {i: (name, args.decomp_fastx_path or args.fastx_path, len(s)) for i, (name, s) in enumerate(recs)}
+        from .engine import frag_recs_batch
+        q = frag_recs_batch([s for _, s in recs], sdb._spec, query_side=True, ctx=sdb.ctx)
+        dec = []
+        for i, rr in enumerate(q):
+            smps = [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in rr]
+            dec.append((i, [(v, vmap.get((v[0], v[1]))) for v in smps]))
+    names = {sid: v[0] for sid, v in seq_info.items()}
+    parts = pbundle_partitions(names, dec, args.bundle_length_cutoff, args.bundle_merge_distance)
+    with open(args.output_prefix + ".bed", "w") as f:
+        f.write("# cmd: %s\n" % " ".join(sys.argv))
+        for line in pbundle_bed_lines(names, dec, bundles, args.k, args.bundle_length_cutoff, args.bundle_merge_distance):
+            f.write(line + "\n")
+    with open(args.output_prefix + ".ctg.summary.tsv", "w") as f:
+        for line in pbundle_summary_lines(seq_info, parts, args.k):
+            f.write(line + "\n")
+    print("%d sequences, %d principal bundles -> %s.bed / .ctg.summary.tsv" % (len(seq_info), len(bundles),
+                                                                               args.output_prefix), file=sys.stderr)
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="pgrtk_amd.cli")
     sub = ap.add_subparsers(dest="cmd", required=True)
@@ -186,6 +316,20 @@ def main(argv=None):
     q.add_argument("--only-summary", dest="only_summary", action="store_true")
     q.add_argument("--bed-summary", dest="bed_summary", action="store_true")
     q.set_defaults(fn=cmd_query)
+    b = sub.add_parser("pbundle-decomp", help="pgr-pbundle-decomp counterpart")
+    b.add_argument("fastx_path")
+    b.add_argument("output_prefix")
+    b.add_argument("-i", "--include", default=None)
+    b.add_argument("-d", "--decomp-fastx-path", dest="decomp_fastx_path", default=None)
+    b.add_argument("-w", type=int, default=48)
+    b.add_argument("-k", type=int, default=56)
+    b.add_argument("-r", type=int, default=4)
+    b.add_argument("--min-span", dest="min_span", type=int, default=12)
+    b.add_argument("--min-cov", dest="min_cov", type=int, default=0)
+    b.add_argument("--min-branch-size", dest="min_branch_size", type=int, default=8)
+    b.add_argument("--bundle-length-cutoff", dest="bundle_length_cutoff", type=int, default=2500)
+    b.add_argument("--bundle-merge-distance", dest="bundle_merge_distance", type=int, default=10000)
+    b.set_defaults(fn=cmd_pbundle_decomp)
     args = ap.parse_args(argv)
     args.fn(args)
 

@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-from . import _ffi
+from . import _ffi, mapgraph
 from ._ffi import FRAG_REC, HITPAIR, HpsResult, default_context, lib
 from .engine import frag_recs_batch, make_spec
 
@@ -111,6 +111,7 @@ class SeqIndexDB:
         self.seq_info = None   # {sid: (name, source, len)}     (lib.rs:223 getter)
         self._n_seqs = 0
         self._host = None      # lazily downloaded sorted records + key table
+        self._seqs = {}        # sid -> bytes (FASTX / MEMORY backends keep the sequences, ext.rs:344-489)
 
     # ------------------------------------------------------------------ loading
     def _reset(self, w, k, r, min_span):
@@ -118,7 +119,7 @@ class SeqIndexDB:
         self._spec = make_spec(w, k, r, min_span, False)
         self._ix = C.c_void_p()
         self.ctx.check(lib().pgr_index_create(self.ctx.handle, C.byref(self._spec), C.byref(self._ix)))
-        self.seq_index, self.seq_info, self._n_seqs, self._host = {}, {}, 0, None
+        self.seq_index, self.seq_info, self._n_seqs, self._host, self._seqs = {}, {}, 0, None, {}
 
     def _append(self, named_seqs, source):
         seqs = [s for _, s in named_seqs]
@@ -130,6 +131,7 @@ class SeqIndexDB:
             sid = self._n_seqs + i
             self.seq_index[(name, source)] = (sid, len(s))
             self.seq_info[sid] = (name, source, len(s))
+            self._seqs[sid] = bytes(s)
         self._n_seqs += n
         self.ctx.check(lib().pgr_index_finalize(self.ctx.handle, self._ix))
         self._host = None
@@ -273,6 +275,47 @@ class SeqIndexDB:
         (target order: ascending sid; the reference's order is hash-map iteration order)"""
         return self.query_fragments_to_hps([seq], penalty, max_count, max_count_query, max_count_target, max_aln_span,
                                            max_gap, orientated)[0]
+
+    # ------------------------------------------------------------------ sequences (lib.rs:809-890)
+    def get_seq_by_id(self, sid):
+        if sid not in self._seqs:
+            raise KeyError("sequence %r is not held by this database (backend %s)" % (sid, self.backend))
+        return self._seqs[sid]
+
+    def get_seq(self, sample_name, ctg_name):
+        return self.get_seq_by_id(self.seq_index[(ctg_name, sample_name)][0])
+
+    def get_sub_seq_by_id(self, sid, bgn, end):
+        return self.get_seq_by_id(sid)[bgn:end]
+
+    def get_sub_seq(self, sample_name, ctg_name, bgn, end):
+        return self.get_seq(sample_name, ctg_name)[bgn:end]
+
+    # ------------------------------------------------------------------ MAP-graph / principal bundles (lib.rs:893-1300)
+    def get_smp_adj_list(self, min_count, keeps=None):
+        """lib.rs:893-919 -> seq_db::frag_map_to_adj_list: [(sid, (h0,h1,o), (h0,h1,o))]"""
+        a = mapgraph.adj_list_records(self.ctx, self._ix, min_count, keeps)
+        return [(int(r["sid"]), mapgraph._vtuple(r["v"]), mapgraph._vtuple(r["w"])) for r in a]
+
+    def sort_adj_list_by_weighted_dfs(self, adj_list, start):
+        """lib.rs:938-985: [(node, parent, weight, is_leaf, global_rank, branch, branch_rank)]"""
+        a = mapgraph.adj_records_from_tuples(self.ctx, self._ix, adj_list)
+        return mapgraph.weighted_dfs(self.ctx, a, start, self.get_shmmr_pair_count((start[0], start[1])))
+
+    def get_principal_bundles(self, min_count, path_len_cutoff, keeps=None):
+        """lib.rs:1002-1013 -> ext.rs:491-510: [[(h0,h1,orientation)]] longest first"""
+        return mapgraph.principal_bundles(self.ctx, self._ix, min_count, path_len_cutoff, keeps)
+
+    def get_principal_bundle_decomposition(self, min_count, path_len_cutoff, keeps=None):
+        """lib.rs:1066-1100: (principal_bundles [(id, mean order, [(h0,h1,dir)])],
+        [(sid, [((h0,h1,p0,p1,o), (bundle id, direction, position) | None)])]) -- sequences in ascending sid
+        (the reference's order is hash-map iteration order)"""
+        bundles, by_sid = mapgraph.bundle_decomposition(self.ctx, self._ix, min_count, path_len_cutoff, keeps)
+        return bundles, [(sid, by_sid.get(sid, [])) for sid in sorted(self.seq_info)]
+
+    def get_principal_bundle_projection(self, min_count, path_len_cutoff, sequence, keeps=None):
+        """lib.rs:1128-1146: like the decomposition for caller-provided [(sid, seq)]"""
+        return mapgraph.bundle_projection(self.ctx, self._ix, min_count, path_len_cutoff, sequence, keeps)
 
     # ------------------------------------------------------------------ .mdb / .midx (seq_db.rs:790-810, 1291-1326)
     def write_shmmr_map_index(self, prefix):

@@ -1,0 +1,142 @@
+"""GPU parity: MAP-graph adjacency list, weighted DFS, principal bundles and the bundle decomposition
+(BASELINE.json configs[3]) vs the CPU oracle (oracle/mapgraph.py).
+
+Reference path: frag_map_to_adj_list (pgr-db/src/seq_db.rs:876-945), sort_adj_list_by_weighted_dfs (:1006-1062),
+get_principal_bundles_from_adj_list (:1064-1186), get_principal_bundles_with_id (ext.rs:552-650),
+get_principal_bundle_decomposition (ext.rs:976-1014), pgr-pbundle-decomp's .bed (rs:61-137, 340-395).
+The reference has no expected output for any of these: parity is oracle <-> product (unpinned).
+"""
+import numpy as np
+import pytest
+
+import seqgen
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_side(oracle, seqs, spec_t):
+    import mapgraph as og
+    sp = oracle.spec(*spec_t)
+    oix = oracle.Index(sp)
+    for i, s in enumerate(seqs):
+        oix.add_seq(i, s)
+    oix.finalize()
+    fm = {}
+    for r in oix.records():
+        fm.setdefault((int(r["h0"]), int(r["h1"])), []).append(
+            (int(r["frg_id"]), int(r["sid"]), int(r["bgn"]), int(r["end"]), int(r["orient"])))
+    smps = []
+    for i, s in enumerate(seqs):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), i, query_side=True)
+        smps.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    return og, fm, smps
+
+
+def _gpu_side(gpu_ctx, seqs, spec_t):
+    import pgrtk_amd as P
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_seq_list([("h%03d" % i, s) for i, s in enumerate(seqs)], w=spec_t[0], k=spec_t[1], r=spec_t[2],
+                           min_span=spec_t[3])
+    return sdb
+
+
+def _check_all(oracle, gpu_ctx, seqs, spec_t, min_count, cutoff, keeps=None, bed_args=(2500, 10000)):
+    og, fm, smps = _oracle_side(oracle, seqs, spec_t)
+    sdb = _gpu_side(gpu_ctx, seqs, spec_t)
+    # adjacency list: same edges in the same order
+    ref_adj = og.frag_map_to_adj_list(fm, min_count, keeps)
+    got_adj = sdb.get_smp_adj_list(min_count, keeps)
+    assert got_adj == ref_adj
+    if not ref_adj:
+        assert sdb.get_principal_bundles(min_count, cutoff, keeps) == []
+        return 0
+    # weighted DFS from the first vertex
+    start = ref_adj[0][1]
+    ref_dfs = og.sort_adj_list_by_weighted_dfs(fm, ref_adj, start)
+    got_dfs = sdb.sort_adj_list_by_weighted_dfs(got_adj, start)
+    assert got_dfs == ref_dfs
+    # principal bundles
+    ref_pb = og.get_principal_bundles(fm, min_count, cutoff, keeps)
+    got_pb = sdb.get_principal_bundles(min_count, cutoff, keeps)
+    assert got_pb == ref_pb
+    # bundles with id + decomposition of every sequence
+    ref_with_id, vmap = og.get_principal_bundles_with_id(fm, smps, min_count, cutoff, keeps)
+    ref_dec = og.get_principal_bundle_decomposition(vmap, smps)
+    got_with_id, got_dec = sdb.get_principal_bundle_decomposition(min_count, cutoff, keeps)
+    assert got_with_id == ref_with_id
+    assert got_dec == ref_dec
+    # the .bed body pgr-pbundle-decomp writes
+    from pgrtk_amd import cli
+    names = {sid: v[0] for sid, v in sdb.seq_info.items()}
+    ref_bed = og.bed_lines(names, ref_dec, ref_with_id, spec_t[1], *bed_args)
+    got_bed = cli.pbundle_bed_lines(names, got_dec, got_with_id, spec_t[1], *bed_args)
+    assert got_bed == ref_bed
+    return len(ref_pb)
+
+
+def test_config4_amy1a_like(oracle, gpu_ctx):
+    """BASELINE.json configs[3]: 96 haplotypes x ~250 kbp, pgr-pbundle-decomp defaults (48,56,4,12), min_cov 0,
+    min_branch_size 8"""
+    haps = seqgen.amy1a_like(seed=4, n_hap=96, L=200_000)
+    n = _check_all(oracle, gpu_ctx, haps, (48, 56, 4, 12), 0, 8)
+    assert n > 10
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14])
+def test_small_pangenomes(oracle, gpu_ctx, seed):
+    """structural variation: inversions, deletions, duplications, private insertions; min_count filter and keeps"""
+    rng = np.random.default_rng(seed)
+    comp = bytes.maketrans(b"ACGT", b"TGCA")
+    anc = seqgen.rnd(rng, 60_000)
+    haps = []
+    for h in range(int(rng.integers(4, 10))):
+        s = bytearray(anc)
+        for _ in range(int(rng.integers(1, 5))):
+            a = int(rng.integers(0, len(s) - 8000))
+            ln = int(rng.integers(500, 7000))
+            op = int(rng.integers(0, 4))
+            seg = bytes(s[a:a + ln])
+            if op == 0:
+                s[a:a + ln] = seg.translate(comp)[::-1]       # inversion
+            elif op == 1:
+                del s[a:a + ln]                                # deletion
+            elif op == 2:
+                s[a:a] = seg * int(rng.integers(1, 4))         # tandem duplication
+            else:
+                s[a:a] = seqgen.rnd(rng, ln)                   # private insertion
+        haps.append(bytes(s))
+    haps.append(haps[0].translate(comp)[::-1])                 # one haplotype given as its reverse complement
+    for (mc, cutoff, keeps) in [(0, 2, None), (2, 3, None), (3, 1, [0, len(haps) - 1]), (1, 0, [])]:
+        _check_all(oracle, gpu_ctx, haps, (24, 24, 2, 8), mc, cutoff, keeps, bed_args=(200, 2000))
+
+
+def test_projection_and_edge_cases(oracle, gpu_ctx):
+    import mapgraph as og
+    rng = np.random.default_rng(5)
+    haps = seqgen.amy1a_like(seed=6, n_hap=8, L=40_000, unit=3000)
+    spec_t = (24, 24, 2, 8)
+    _, fm, _ = _oracle_side(oracle, haps, spec_t)
+    sdb = _gpu_side(gpu_ctx, haps, spec_t)
+    ext = [(7, haps[1][5000:30000]), (3, seqgen.rnd(rng, 5000)), (9, b""), (1, haps[2])]
+    sp = oracle.spec(*spec_t)
+    smps = []
+    for sid, s in ext:
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), sid, query_side=True)
+        smps.append((sid, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    ref_with_id, vmap = og.get_principal_bundles_with_id(fm, smps, 0, 2)
+    ref_dec = og.get_principal_bundle_decomposition(vmap, smps)
+    got_with_id, got_dec = sdb.get_principal_bundle_projection(0, 2, ext)
+    assert got_with_id == ref_with_id and got_dec == ref_dec
+    # an index without any adjacent pair: no edges, no bundles
+    import pgrtk_amd as P
+    e = P.SeqIndexDB(ctx=gpu_ctx)
+    e.load_from_seq_list([("a", seqgen.rnd(rng, 40)), ("b", b"")], w=24, k=24, r=2, min_span=8)
+    assert e.get_smp_adj_list(0) == [] and e.get_principal_bundles(0, 0) == []
+    b, d = e.get_principal_bundle_decomposition(0, 0)
+    assert b == [] and all(bi is None for _, smp in d for _, bi in smp)
+    # min_count above every multiplicity: empty
+    assert sdb.get_smp_adj_list(10_000) == []
+    # weighted DFS from a vertex that is not in the list is an error, not a crash
+    adj = sdb.get_smp_adj_list(0)
+    with pytest.raises(P.PgrError):
+        sdb.sort_adj_list_by_weighted_dfs(adj, (1, 2, 0))
