@@ -486,3 +486,81 @@ def bed_lines(seq_names, decomposition, with_id, k, bundle_length_cutoff=2500, b
             lines.append("%s\t%d\t%d\t%d:%d:%d:%d:%d:%s" % (name, b, e, bid, bid_to_size[bid], p[0][2], p[0][3], p[-1][3],
                                                             "R" if cnt[bid] > 1 else "U"))
     return lines
+
+
+def gfa_lines(frag_map, adj_list, k, vertex_map=None):
+    """generate_mapg_gfa / generate_principal_mapg_gfa bodies (ext.rs:727-788, 905-957)"""
+    overlaps, frag_id = {}, {}
+    for sid, v, w in adj_list:
+        if v[0] <= w[0]:
+            overlaps.setdefault((v, w), []).append((sid, v[2], w[2]))
+            for n in (v, w):
+                if (n[0], n[1]) not in frag_id:
+                    frag_id[(n[0], n[1])] = len(frag_id)
+    lines = ["H\tVN:Z:1.0\tCM:Z:Sparse Genome Graph Generated By pgr-tk"]
+    for smp, i in frag_id.items():
+        hits = frag_map[smp]
+        ave_len = (sum(h[3] - h[2] for h in hits) & 0xFFFFFFFF) // len(hits)
+        line = "S\t%d\t*\tLN:i:%d\tSN:Z:%016x_%016x" % (i, ave_len + k, smp[0], smp[1])
+        if vertex_map is not None and smp in vertex_map:
+            line += "\tBN:i:%d\tBP:i:%d" % (vertex_map[smp][0], vertex_map[smp][2])
+        lines.append(line)
+    for (v, w), vs in overlaps.items():
+        lines.append("L\t%d\t%s\t%d\t%s\t%dM\tSC:i:%d" % (frag_id[(v[0], v[1])], "+" if v[2] == 0 else "-",
+                                                          frag_id[(w[0], w[1])], "+" if w[2] == 0 else "-", k, len(vs)))
+    return lines
+
+
+def smp_adj_list_for_seq(smps, sid, frag_map, min_count):
+    """generate_smp_adj_list_for_seq (seq_db.rs:947-1002); smps = get_smps of the sequence"""
+    out = []
+    for i in range(len(smps) - 1):
+        v, w = smps[i], smps[i + 1]
+        fv, fw = frag_map.get((v[0], v[1])), frag_map.get((w[0], w[1]))
+        if fv is None or fw is None or len(fv) < min_count or len(fw) < min_count or v[3] != w[2]:
+            continue
+        out.append((sid, (v[0], v[1], v[4]), (w[0], w[1], w[4])))
+        out.append((sid, (w[0], w[1], 1 - w[4]), (v[0], v[1], 1 - v[4])))
+    return out
+
+
+def _rust_f32(x):
+    """Rust Display of an f32"""
+    x = np.float32(x)
+    if np.isnan(x):
+        return "NaN"
+    if np.isinf(x):
+        return "inf" if x > 0 else "-inf"
+    return np.format_float_positional(x, unique=True, trim="-")
+
+
+def ctg_summary_lines(seq_info, decomposition, k, bundle_length_cutoff=2500, bundle_merge_distance=10000):
+    """<prefix>.ctg.summary.tsv of pgr-pbundle-decomp (rs:340-530); seq_info = {sid: (name, source, len)}"""
+    sid_smps = dict(decomposition)
+    order = sorted(seq_info.items(), key=lambda t: t[1][0])
+    repeat, non_repeat = {}, {}
+    for sid, (_name, _src, _len) in order:
+        parts = group_smps_by_principle_bundle_id(sid_smps[sid], bundle_length_cutoff, bundle_merge_distance)
+        cnt = {}
+        for p in parts:
+            cnt[p[0][1]] = cnt.get(p[0][1], 0) + 1
+        for p in parts:
+            b = p[0][0][2]
+            e = p[-1][0][3] + k
+            (repeat if cnt[p[0][1]] > 1 else non_repeat).setdefault(sid, []).append(e - b - k)
+    cols = ["ctg", "length", "repeat_bundle_count", "repeat_bundle_sum", "repeat_bundle_percentage", "repeat_bundle_mean",
+            "repeat_bundle_min", "repeat_bundle_max", "non_repeat_bundle_count", "non_repeat_bundle_sum",
+            "non_repeat_bundle_percentage", "non_repeat_bundle_mean", "non_repeat_bundle_min", "non_repeat_bundle_max",
+            "total_bundle_count", "total_bundle_coverage_percentage"]
+    lines = ["#" + "\t".join(cols)]
+    f = np.float32
+    for sid, (name, _src, ln) in order:
+        r, n = repeat.get(sid, []), non_repeat.get(sid, [])
+        rs, ns = sum(r), sum(n)
+        row = [name, str(ln), str(len(r)), str(rs), _rust_f32(f(100.0) * f(rs) / f(ln)),
+               _rust_f32(f(rs) / f(len(r))) if r else "NA", str(min(r)) if r else "NA", str(max(r)) if r else "NA",
+               str(len(n)), str(ns), _rust_f32(f(100.0) * f(ns) / f(ln)),
+               _rust_f32(f(ns) / f(len(n))) if n else "NA", str(min(n)) if n else "NA", str(max(n)) if n else "NA",
+               str(len(r) + len(n)), _rust_f32(f(100.0) * f(rs + ns) / f(ln))]
+        lines.append("\t".join(row))
+    return lines

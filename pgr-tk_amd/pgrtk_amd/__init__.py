@@ -8,6 +8,6 @@ from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PgrError, Spec, default_con
 from .engine import (Batch, Index, Shmmrs, frag_recs_batch, make_spec, sequence_to_shmmrs,  # noqa: F401
                      sequence_to_shmmrs_batch)
 from .seqindexdb import SeqIndexDB, get_shmmr_pairs_from_seq, read_fastx, sparse_aln  # noqa: F401
-from . import cli  # noqa: F401
+from . import cli, mapgraph  # noqa: F401
 
 __version__ = "0.1.0"

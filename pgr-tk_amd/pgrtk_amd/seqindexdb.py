@@ -317,6 +317,86 @@ class SeqIndexDB:
         """lib.rs:1128-1146: like the decomposition for caller-provided [(sid, seq)]"""
         return mapgraph.bundle_projection(self.ctx, self._ix, min_count, path_len_cutoff, sequence, keeps)
 
+    # ------------------------------------------------------------------ GFA / index text writers (ext.rs:652-960)
+    def _gfa_lines(self, adj_list, vertex_map=None):
+        """S / L lines of generate_mapg_gfa (ext.rs:727-788): segment ids in order of first appearance in the
+        adjacency list, LN = mean pair span + k, SC = number of sequences supporting the link"""
+        recs, keys = self._records()
+        k = self._spec.k
+        overlaps, frag_id = {}, {}
+        for sid, v, w in adj_list:
+            if v[0] <= w[0]:
+                overlaps.setdefault((v, w), []).append((sid, v[2], w[2]))
+                frag_id.setdefault((v[0], v[1]), len(frag_id))
+                frag_id.setdefault((w[0], w[1]), len(frag_id))
+        lines = ["H\tVN:Z:1.0\tCM:Z:Sparse Genome Graph Generated By pgr-tk"]
+        for smp, i in frag_id.items():
+            s, e = keys[smp]
+            span = (recs["end"][s:e].astype(np.uint64) - recs["bgn"][s:e]).sum()
+            ave_len = (int(span) & 0xFFFFFFFF) // (e - s)
+            line = "S\t%d\t*\tLN:i:%d\tSN:Z:%016x_%016x" % (i, ave_len + k, smp[0], smp[1])
+            if vertex_map is not None and smp in vertex_map:
+                line += "\tBN:i:%d\tBP:i:%d" % (vertex_map[smp][0], vertex_map[smp][2])
+            lines.append(line)
+        for (v, w), vs in overlaps.items():
+            lines.append("L\t%d\t%s\t%d\t%s\t%dM\tSC:i:%d" % (frag_id[(v[0], v[1])], "+" if v[2] == 0 else "-",
+                                                              frag_id[(w[0], w[1])], "+" if w[2] == 0 else "-", k, len(vs)))
+        return lines
+
+    def _smp_adj_list_from_seqs(self, min_count, keeps):
+        """seq_db::generate_smp_adj_list_for_seq (seq_db.rs:947-1002) for every sequence of the database"""
+        recs, keys = self._records()
+        order = np.lexsort((recs["frg_id"], recs["sid"]))
+        keeps = set(keeps) if keeps is not None else None
+        out = []
+        prev = None
+        for r in recs[order]:
+            key = (int(r["h0"]), int(r["h1"]))
+            o = int(r["orient"]) | int(key[0] == key[1])  # get_smps orientation (strict '<')
+            cur = (int(r["sid"]), key, int(r["bgn"]), int(r["end"]), o, keys[key][1] - keys[key][0])
+            if prev is not None and prev[0] == cur[0]:
+                mc = 0 if (keeps is not None and cur[0] in keeps) else min_count
+                if prev[5] >= mc and cur[5] >= mc and prev[3] == cur[2]:
+                    out.append((cur[0], (prev[1][0], prev[1][1], prev[4]), (key[0], key[1], o)))
+                    out.append((cur[0], (key[0], key[1], 1 - o), (prev[1][0], prev[1][1], 1 - prev[4])))
+            prev = cur
+        return out
+
+    def generate_mapg_gfa(self, min_count, filepath, method="from_fragmap", keeps=None):
+        """lib.rs:1304-1335 -> ext.rs:652-789 (line order inside the S and L blocks is hash-map order there)"""
+        adj = self.get_smp_adj_list(min_count, keeps) if method == "from_fragmap" else \
+            self._smp_adj_list_from_seqs(min_count, keeps)
+        with open(filepath, "w") as f:
+            f.write("\n".join(self._gfa_lines(adj)) + "\n")
+
+    def generate_principal_mapg_gfa(self, min_count, path_len_cutoff, filepath, keeps=None):
+        """lib.rs:1357-1384 -> ext.rs:849-960: the MAP-graph restricted to principal-bundle vertices, segments
+        tagged with bundle id (BN) and position (BP)"""
+        adj = self.get_smp_adj_list(min_count, keeps)
+        pb = self.get_principal_bundles(min_count, path_len_cutoff, keeps) if adj else []
+        vmap = {}
+        for bid, path in enumerate(pb):
+            for p, v in enumerate(path):
+                vmap[(v[0], v[1])] = (bid, v[2], p)
+        # filtered_adj_list (seq_db.rs:1097-1111): both ends on long DFS paths == both ends in some bundle
+        filtered = [(sid, v, w) for sid, v, w in adj if (v[0], v[1]) in vmap and (w[0], w[1]) in vmap]
+        with open(filepath, "w") as f:
+            f.write("\n".join(self._gfa_lines(filtered, vmap)) + "\n")
+
+    def write_mapg_idx(self, filepath):
+        """ext.rs:791-847: K (spec), C (contigs), F (fragment signatures) lines"""
+        recs, keys = self._records()
+        w, k, r, ms, sk = self._spec.as_tuple()
+        with open(filepath, "w") as f:
+            f.write("K\t%d\t%d\t%d\t%d\t%s\n" % (w, k, r, ms, "true" if sk else "false"))
+            for sid in sorted(self.seq_info):
+                name, source, ln = self.seq_info[sid]
+                f.write("C\t%d\t%s\t%s\t%d\n" % (sid, name, source if source is not None else "NA", ln))
+            for (h0, h1), (s, e) in keys.items():
+                for x in recs[s:e]:
+                    f.write("F\t%016x_%016x\t%d\t%d\t%d\t%d\t%d\n" % (h0, h1, x["frg_id"], x["sid"], x["bgn"], x["end"],
+                                                                      x["orient"]))
+
     # ------------------------------------------------------------------ .mdb / .midx (seq_db.rs:790-810, 1291-1326)
     def write_shmmr_map_index(self, prefix):
         recs, keys = self._records()

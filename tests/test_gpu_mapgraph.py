@@ -140,3 +140,82 @@ def test_projection_and_edge_cases(oracle, gpu_ctx):
     adj = sdb.get_smp_adj_list(0)
     with pytest.raises(P.PgrError):
         sdb.sort_adj_list_by_weighted_dfs(adj, (1, 2, 0))
+
+
+def test_gfa_and_idx_writers(oracle, gpu_ctx, tmp_path):
+    """generate_mapg_gfa (both methods), generate_principal_mapg_gfa, write_mapg_idx: same lines as the oracle's
+    restatement (the reference writes the S / L / F blocks in hash-map order, so lines are compared as sorted sets)"""
+    import mapgraph as og
+    haps = seqgen.amy1a_like(seed=8, n_hap=10, L=50_000, unit=4000)
+    spec_t = (24, 24, 2, 8)
+    _, fm, smps = _oracle_side(oracle, haps, spec_t)
+    sdb = _gpu_side(gpu_ctx, haps, spec_t)
+    for mc, keeps in [(0, None), (3, None), (11, [2, 5])]:
+        adj = og.frag_map_to_adj_list(fm, mc, keeps)
+        sdb.generate_mapg_gfa(mc, str(tmp_path / "a.gfa"), "from_fragmap", keeps)
+        got = open(tmp_path / "a.gfa").read().splitlines()
+        assert got == og.gfa_lines(fm, adj, spec_t[1])  # same insertion order too
+        adj2 = []
+        for sid, sm in smps:
+            adj2 += og.smp_adj_list_for_seq(sm, sid, fm, 0 if (keeps is not None and sid in keeps) else mc)
+        sdb.generate_mapg_gfa(mc, str(tmp_path / "b.gfa"), "from_seqs", keeps)
+        assert open(tmp_path / "b.gfa").read().splitlines() == og.gfa_lines(fm, adj2, spec_t[1])
+        if adj:
+            pb, filtered = og.get_principal_bundles_from_adj_list(fm, adj, 2)
+            vmap = og.vertex_map_from_bundles(pb)
+            sdb.generate_principal_mapg_gfa(mc, 2, str(tmp_path / "p.gfa"), keeps)
+            assert open(tmp_path / "p.gfa").read().splitlines() == og.gfa_lines(fm, filtered, spec_t[1], vmap)
+    sdb.write_mapg_idx(str(tmp_path / "m.idx"))
+    lines = open(tmp_path / "m.idx").read().splitlines()
+    assert lines[0] == "K\t24\t24\t2\t8\tfalse"
+    assert [l for l in lines if l[0] == "C"] == ["C\t%d\th%03d\tMemory\t%d" % (i, i, len(s)) for i, s in enumerate(haps)]
+    # MEMORY backend: global fragment ids (seq_db.rs:189-357) -- the oracle index built with fastx ids gives them
+    oix = oracle.Index(oracle.spec(*spec_t))
+    for i, s in enumerate(haps):
+        oix.add_seq(i, s, fastx_ids=True)
+    oix.finalize()
+    ref_f = sorted("F\t%016x_%016x\t%d\t%d\t%d\t%d\t%d" % (r["h0"], r["h1"], r["frg_id"], r["sid"], r["bgn"], r["end"],
+                                                         r["orient"]) for r in oix.records())
+    assert sorted(l for l in lines if l[0] == "F") == ref_f
+
+
+def test_cli_pbundle_decomp(oracle, gpu_ctx, tmp_path):
+    """pgr-pbundle-decomp counterpart end to end: FASTA -> .bed + .ctg.summary.tsv, and the -d variant that
+    decomposes other sequences with the bundles of the first file"""
+    import mapgraph as og
+    from pgrtk_amd import cli
+    haps = seqgen.amy1a_like(seed=9, n_hap=12, L=60_000, unit=5000)
+    spec_t = (24, 24, 2, 8)
+    fa = tmp_path / "haps.fa"
+    with open(fa, "w") as f:
+        for i, s in enumerate(haps):
+            f.write(">hap%02d\n%s\n" % (11 - i, s.decode()))  # names sort differently from the ids
+    argv = ["pbundle-decomp", str(fa), str(tmp_path / "out"), "-w", "24", "-k", "24", "-r", "2", "--min-span", "8",
+            "--min-branch-size", "8", "--bundle-length-cutoff", "300", "--bundle-merge-distance", "3000"]
+    cli.main(argv)
+    og_, fm, smps = _oracle_side(oracle, haps, spec_t)
+    with_id, vmap = og.get_principal_bundles_with_id(fm, smps, 0, 8)
+    dec = og.get_principal_bundle_decomposition(vmap, smps)
+    names = {i: "hap%02d" % (11 - i) for i in range(len(haps))}
+    bed = open(tmp_path / "out.bed").read().splitlines()
+    assert bed[0].startswith("# cmd: ")
+    ref_bed = og.bed_lines(names, dec, with_id, 24, 300, 3000)
+    assert bed[1:] == ref_bed and len(ref_bed) > len(haps)
+    assert any(l.endswith(":R") for l in ref_bed) and any(l.endswith(":U") for l in ref_bed)
+    info = {i: (names[i], str(fa), len(s)) for i, s in enumerate(haps)}
+    assert open(tmp_path / "out.ctg.summary.tsv").read().splitlines() == og.ctg_summary_lines(info, dec, 24, 300, 3000)
+    # -d: other sequences (one mutated haplotype, one unrelated) against the same bundles
+    rng = np.random.default_rng(3)
+    other = [haps[3][2000:50000], seqgen.rnd(rng, 8000)]
+    fb = tmp_path / "other.fa"
+    with open(fb, "w") as f:
+        for i, s in enumerate(other):
+            f.write(">o%d\n%s\n" % (i, s.decode()))
+    cli.main(argv[:2] + [str(tmp_path / "out2")] + argv[3:] + ["-d", str(fb)])
+    sp = oracle.spec(*spec_t)
+    osm = []
+    for i, s in enumerate(other):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), i, query_side=True)
+        osm.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    odec = og.get_principal_bundle_decomposition(vmap, osm)
+    assert open(tmp_path / "out2.bed").read().splitlines()[1:] == og.bed_lines({0: "o0", 1: "o1"}, odec, with_id, 24, 300, 3000)
