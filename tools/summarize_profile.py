@@ -41,6 +41,8 @@ if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
     t = {"kernel": "level1_tile_kernel", "profile": name, "bp_per_launch": bench.get("roofline", {}).get("bp_per_launch"),
          "fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
          "correction": "2 x FETCH_SIZE (gfx950 wide-read undercount) + WRITE_SIZE"}
+    if "SQ_INSTS_VALU" in out[dom[0]]:
+        t["valu_wave_insts_per_launch"] = out[dom[0]]["SQ_INSTS_VALU"]["mean_per_launch"]
     json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(t))
 for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
