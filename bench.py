@@ -93,11 +93,14 @@ def query_bench(P, ctx, batch, spec, args, contig0):
     comp = np.zeros(256, dtype=np.uint8)
     for a, b in zip(b"ACGT", b"TGCA"):
         comp[a] = b
-    qs = [comp[q][::-1].copy() if i & 1 else q for i, q in enumerate(qs)]
+    qs = P.PackedSeqs.from_list([comp[q][::-1] if i & 1 else q for i, q in enumerate(qs)])  # one host buffer
     ix.query_hps_raw(qs, 0.025)  # warm-up (grows the workspaces once)
-    t0 = time.perf_counter()
-    r = ix.query_hps_raw(qs, 0.025)
-    t_q = time.perf_counter() - t0
+    reps = []
+    for _ in range(3):  # the batch is a few ms: report the median of three
+        t0 = time.perf_counter()
+        r = ix.query_hps_raw(qs, 0.025)
+        reps.append(time.perf_counter() - t0)
+    t_q = sorted(reps)[1]
     # self-consistency: the best chain of every query lies on its source contig at its source offset
     ok = 0
     for qi in range(nq):
@@ -116,7 +119,7 @@ def query_bench(P, ctx, batch, spec, args, contig0):
         "workload": "BASELINE.json configs[2]: %d x %d bp queries (50%% reverse complement) against the %d x %d bp index, "
                     "penalty 0.025, max counts 128, max_aln_span 8" % (nq, qlen, args.contigs, args.contig_len),
         "index_build_s": t_build, "index_records": ix.n_records, "index_keys": ix.n_keys,
-        "query_s": t_q, "queries_per_s": nq / t_q, "hit_pairs": int(len(r["hps"])),
+        "query_s": t_q, "query_s_reps": reps, "queries_per_s": nq / t_q, "hit_pairs": int(len(r["hps"])),
         "hit_pairs_per_s": len(r["hps"]) / t_q, "chains": int(len(r["c_score"])),
         "queries_with_best_chain_on_source": ok,
     }

@@ -9,6 +9,7 @@
 //   scan(seg counts) + gather       -> ordered per-contig level-1 lists
 //   select(reduce) x2, select(min_span) -> final MM128 lists (+ rid patch)
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <thread>
 #include <cstdio>
@@ -166,8 +167,16 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
     for (uint32_t i = 0; i < n; ++i)
         if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
     pgr_batch *b = nullptr;
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
+    double t_copy = 0, t_wait = 0;
     int rc = batch_alloc(ctx, n, lens, &b);
     if (rc) return rc;
+    const auto t1 = now();
     // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Two pinned windows of 32 MiB: while window
     // i is on its way to the GPU (H2D + pack kernel on the context's stream) the host threads fill window i+1.
     const uint64_t WIN_WORDS = 1ull << 20;  // 32 MiB of ASCII per window
@@ -186,10 +195,13 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
         const uint64_t w1 = std::min(b->total_words, w0 + win_words);
         uint8_t *stage = (uint8_t *)ctx->pinned + (size_t)slot * win_words * 32;
         uint8_t *d_stage = (uint8_t *)ctx->ws_ascii.p + (size_t)slot * win_words * 32;
+        const auto tw0 = now();
         if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess) {  // this window's previous trip is over
             pgr_batch_destroy(b);
             return ctx->fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         }
+        const auto tw1 = now();
+        t_wait += ms(tw0, tw1);
         while (c < n && b->h_word_off[c + 1] <= w0) ++c;
         // copy jobs of this window: (dst, src, len), split into <= 4 MiB pieces and spread over the threads
         struct Job {
@@ -219,6 +231,7 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
             work();
             for (auto &t : th) t.join();
         }
+        t_copy += ms(tw1, now());
         if (hipMemcpyAsync(d_stage, stage, (w1 - w0) * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
             pgr_batch_destroy(b);
             return ctx->fail(PGR_ERR_DEVICE, "H2D copy of the ASCII window failed");
@@ -241,6 +254,9 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
             return ctx->fail(PGR_ERR_DEVICE, "D2H of the invalid-base counts failed");
         }
     }
+    if (dbg)
+        fprintf(stderr, "[pgr] batch_from_ascii %u seqs, %.1f MB: alloc %.2f ms, staging memcpy %.2f, window waits %.2f, total %.2f\n",
+                n, b->total_bases / 1e6, ms(t0, t1), t_copy, t_wait, ms(t0, now()));
     *out = b;
     return PGR_OK;
 }

@@ -11,6 +11,8 @@
 // are hand-written kernels.  f32 arithmetic in the DP is IEEE without contraction (-ffp-contract=off),
 // in the reference's operation order.
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -774,14 +776,23 @@ extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n
         return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be in 1..64");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
+        return std::chrono::duration<double, std::milli>(b - a).count();
+    };
+    const auto t0 = now();
     // queries -> shimmer-pair records, query side (strict <, seq_db.rs:1213); sid field = query index
     pgr_batch *b = nullptr;
     int rc = pgr_batch_from_ascii(ctx, n_queries, seqs, lens, &b);
     if (rc) return rc;
+    const auto t1 = now();
     pgr_shmmrs *s = nullptr;
     rc = pgr_shmmrs_compute(ctx, b, &ix->spec, nullptr, 0, &s);
     pgr_batch_destroy(b);
     if (rc) return rc;
+    const auto t2 = now();
+    auto t3 = t2, t4 = t2;
     const uint64_t nq = pgr_shmmrs_n_pairs(s);
     ChainOut co;
     if (nq && ix->n) {
@@ -820,6 +831,7 @@ extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n
         uint64_t n_hits = 0;
         PGR_HIP(ctx, hipMemcpyAsync(&n_hits, hoff.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));
+        t3 = now();
         if (n_hits) {
             Tmp hkey(ctx), hhp(ctx);
             if ((rc = hkey.alloc(n_hits * 8)) || (rc = hhp.alloc(n_hits * sizeof(pgr_hitpair)))) return rc;
@@ -829,10 +841,15 @@ extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n
             AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
             if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, co))) return rc;
         }
+        t4 = now();
     } else {
         pgr_shmmrs_destroy(s);
     }
-    return fill_result(ctx, n_queries, co, out);
+    rc = fill_result(ctx, n_queries, co, out);
+    if (dbg)
+        fprintf(stderr, "[pgr] query batch %u: stage+pack %.2f ms, shimmers %.2f, lookup+counts %.2f, hits+chain %.2f, result %.2f\n",
+                n_queries, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+    return rc;
 }
 
 extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_hitpair *hits, const uint64_t *g_off,

@@ -4,7 +4,7 @@ All compute happens in libpgrhip.so (hand-written gfx950 HIP kernels behind the 
 include/pgr_hip.h).  There is no CPU path: without the built library and a gfx950 device the
 calls raise.
 """
-from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PgrError, Spec, default_context  # noqa: F401
+from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PackedSeqs, PgrError, Spec, default_context  # noqa: F401
 from .engine import (Batch, Index, Shmmrs, frag_recs_batch, make_spec, sequence_to_shmmrs,  # noqa: F401
                      sequence_to_shmmrs_batch)
 from .seqindexdb import SeqIndexDB, get_shmmr_pairs_from_seq, read_fastx, sparse_aln  # noqa: F401

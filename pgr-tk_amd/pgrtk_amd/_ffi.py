@@ -148,13 +148,49 @@ def seq_array(seq):
     return np.frombuffer(bytes(seq), dtype=np.uint8)
 
 
+class PackedSeqs:
+    """n sequences back to back in ONE uint8 buffer: sequence i = buf[off[i]:off[i+1]].  The pointer array the
+    C ABI wants is then base + off, computed vectorised (a list of 10 000 Python objects costs milliseconds)."""
+
+    def __init__(self, buf, off):
+        self.buf = np.ascontiguousarray(buf, dtype=np.uint8)
+        self.off = np.ascontiguousarray(off, dtype=np.uint64)
+        assert self.off.ndim == 1 and len(self.off) >= 1 and int(self.off[-1]) <= self.buf.size
+
+    @classmethod
+    def from_list(cls, seqs):
+        arrs = [seq_array(s) for s in seqs]
+        off = np.zeros(len(arrs) + 1, dtype=np.uint64)
+        if arrs:
+            off[1:] = np.cumsum([a.size for a in arrs], dtype=np.uint64)
+        return cls(np.concatenate(arrs) if arrs else np.zeros(0, dtype=np.uint8), off)
+
+    def __len__(self):
+        return len(self.off) - 1
+
+
 def seq_ptrs(seqs):
-    """-> (keepalive arrays, void** , uint64* lens, n)"""
+    """-> (keepalive objects, void**, uint64* lens, n).  PackedSeqs: vectorised; bytes go through a c_char_p
+    array (converted at C speed); numpy arrays through their data pointers."""
+    n = len(seqs)
+    if isinstance(seqs, PackedSeqs):
+        base = seqs.buf.__array_interface__["data"][0]
+        addr = np.zeros(max(n, 1), dtype=np.uint64)
+        lens_np = np.zeros(max(n, 1), dtype=np.uint64)
+        addr[:n] = np.uint64(base) + seqs.off[:-1]
+        lens_np[:n] = seqs.off[1:] - seqs.off[:-1]
+        return (seqs, addr, lens_np), addr.ctypes.data_as(_PVP), lens_np.ctypes.data_as(C.POINTER(C.c_uint64)), n
+    if n and all(type(s) is bytes for s in seqs):
+        ptrs = C.cast((C.c_char_p * n)(*seqs), _PVP)
+        lens_np = np.fromiter(map(len, seqs), dtype=np.uint64, count=n)
+        return (seqs, lens_np), ptrs, lens_np.ctypes.data_as(C.POINTER(C.c_uint64)), n
     arrs = [seq_array(s) for s in seqs]
-    n = len(arrs)
-    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data if a.size else None for a in arrs])
-    lens = (C.c_uint64 * max(n, 1))(*[a.size for a in arrs])
-    return arrs, ptrs, lens, n
+    addr = np.zeros(max(n, 1), dtype=np.uint64)
+    lens_np = np.zeros(max(n, 1), dtype=np.uint64)
+    for i, a in enumerate(arrs):
+        lens_np[i] = a.size
+        addr[i] = a.__array_interface__["data"][0] if a.size else 0
+    return (arrs, addr, lens_np), addr.ctypes.data_as(_PVP), lens_np.ctypes.data_as(C.POINTER(C.c_uint64)), n
 
 
 def take(ptr, n, dtype):
