@@ -219,3 +219,29 @@ def test_cli_pbundle_decomp(oracle, gpu_ctx, tmp_path):
         osm.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
     odec = og.get_principal_bundle_decomposition(vmap, osm)
     assert open(tmp_path / "out2.bed").read().splitlines()[1:] == og.bed_lines({0: "o0", 1: "o1"}, odec, with_id, 24, 300, 3000)
+
+
+def test_golden_fixture_graph(oracle, gpu_ctx, golden_dir):
+    """the reference's own fixture (test_seqs.fa -> test_seqs_frag.mdb): the MAP-graph of the golden frag_map,
+    loaded from the .mdb/.midx pair, vs the oracle fed with the same file"""
+    import os
+    import mapgraph as og
+    import pgrtk_amd as P
+    spec, fm = oracle.read_mdb(os.path.join(golden_dir, "test_seqs_frag.mdb"))
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_mdb_index(os.path.join(golden_dir, "test_seqs_frag"))
+    seqs = oracle.read_fasta(os.path.join(golden_dir, "test_seqs.fa"))
+    sp = oracle.spec(*spec[:4])
+    smps = []
+    for i, (_name, s) in enumerate(seqs):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), i, query_side=True)
+        smps.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    for mc, cutoff in [(0, 0), (2, 1), (4, 2)]:
+        adj = og.frag_map_to_adj_list(fm, mc)
+        assert sdb.get_smp_adj_list(mc) == adj and len(adj) > 100
+        assert sdb.sort_adj_list_by_weighted_dfs(adj, adj[0][1]) == og.sort_adj_list_by_weighted_dfs(fm, adj, adj[0][1])
+        assert sdb.get_principal_bundles(mc, cutoff) == og.get_principal_bundles(fm, mc, cutoff)
+        with_id, vmap = og.get_principal_bundles_with_id(fm, smps, mc, cutoff)
+        got_with_id, got_dec = sdb.get_principal_bundle_decomposition(mc, cutoff)
+        assert got_with_id == with_id
+        assert got_dec == og.get_principal_bundle_decomposition(vmap, smps)
