@@ -182,7 +182,9 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
 #if PGR_ABLATE == 2
         const uint64_t h = (((uint64_t)m0h << 32) | m0l) * 0x9E3779B97F4A7C15ull ^ ((((uint64_t)m1h << 32) | m1l) << 7);
 #else
-        const uint64_t h = u64hash_sa(((uint64_t)m0h << 32) | m0l) ^ u64hash_sa((((uint64_t)m1h << 32) | m1l) ^ 0xAD12CF59ull);
+        uint32_t m1x = m1l ^ 0xAD12CF59u;
+        asm("" : "+v"(m1x));  // keep the constant out of the hash's first step (the optimiser would distribute it)
+        const uint64_t h = u64hash_sa(((uint64_t)m0h << 32) | m0l) ^ u64hash_sa(((uint64_t)m1h << 32) | m1x);
 #endif
         strand_bits = bfi(1u << u, rev, strand_bits);
         const uint64_t key = ((uint64_t)and_or((uint32_t)(h >> 32), 0x00FFFFFFu, KEY_EXP) << 32) | (uint32_t)h;
@@ -369,17 +371,18 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     // ---- ordered compaction: block scan of per-lane counts, one cursor bump per tile
     const uint32_t cnt = __popc(emit);
     const uint32_t incl = wave_incl_sum(cnt);
-    const uint32_t lane = t & 63, wv = t >> 6;
+    const uint32_t lane = t & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));  // wave-uniform: scalar compares below
     if (lane == 63) s_wsum[wv] = incl;
     __syncthreads();
-    uint32_t wave_base = 0, total = 0;
+    uint32_t wave_base = 0;
 #pragma unroll
-    for (int i = 0; i < L1_BLOCK / 64; ++i) {
-        const uint32_t v = s_wsum[i];
-        if (i < (int)wv) wave_base += v;
-        total += v;
-    }
+    for (int i = 0; i < L1_BLOCK / 64 - 1; ++i)
+        if ((uint32_t)i < wv) wave_base += s_wsum[i];
     if (t == 0) {
+        uint32_t total = 0;
+#pragma unroll
+        for (int i = 0; i < L1_BLOCK / 64; ++i) total += s_wsum[i];
         // Every tile owns a fixed slot of a.slot elements (no atomics: one shared cursor saturates at ~88
         // same-address atomics/us, which would cap the kernel at ~29 ms for 2.5 M tiles).  Only tiles denser
         // than the slot (low-complexity sequence: ties emit every position) allocate from the overflow cursor.
@@ -408,7 +411,8 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     {
         const unsigned long long base = s_base;
         if (cnt && base != ~0ull) {
-            uint64_t o = base + wave_base + (incl - cnt);
+            pgr_mm128 *__restrict__ o = a.out + (base + wave_base + (incl - cnt));
+            const uint32_t q32 = (uint32_t)q;  // core positions are >= 0 and < 2^31
             uint32_t em = emit;
             while (em) {
                 const uint32_t u = (uint32_t)__builtin_ctz(em);
@@ -416,8 +420,8 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
                 const uint64_t kb = (uint64_t)__double_as_longlong(s_suf[u][t]);
                 pgr_mm128 m;
                 m.x = (kb << 8) | (uint64_t)k;  // drops bit 62, keeps the low 56 hash bits
-                m.y = ((uint64_t)c << 32) | ((uint64_t)(q + u) << 1) | ((strand_bits >> u) & 1u);
-                a.out[o++] = m;
+                m.y = ((uint64_t)c << 32) | (((q32 + u) << 1) | ((strand_bits >> u) & 1u));
+                *o++ = m;
             }
         }
     }

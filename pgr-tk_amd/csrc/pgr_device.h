@@ -40,6 +40,8 @@ __device__ __forceinline__ uint64_t shl31(uint64_t a) {  // opaque: "key + (key 
     asm("v_lshlrev_b64 %0, 31, %1" : "=v"(r) : "v"(a));
     return r;
 }
+// (measured and rejected: "(key << 21) - key - 1" with the -1 on a preset borrow, 2 x v_subb_co_u32 -- the vcc
+// dependency makes it slower than 2 x v_not_b32 + v_lshl_add_u64: 22.5 vs 22.2 ms per 10 Gbp)
 __device__ __forceinline__ uint64_t u64hash_sa(uint64_t key) {
     key = (~key) + (key << 21);
     key = key ^ (key >> 24);
@@ -96,14 +98,15 @@ __device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
     for (int m = 32; m >= 1; m >>= 1) v = umin64(v, shfl_xor64(v, m));
     return v;
 }
-// inclusive prefix sum over the wave
+// inclusive prefix sum over the wave: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts
+// (6 v_add_u32_dpp instead of 6 x (ds_bpermute + compare + select + add))
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
-    const uint32_t lane = lane_id();
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
-    }
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
     return v;
 }
 
