@@ -70,7 +70,8 @@ __device__ __forceinline__ ContigGeom contig_geom(uint32_t len, uint32_t w, uint
 //   * window minima / maxima run on v_min_f64 / v_max_f64: a 56-bit hash with bit 62 set is a positive
 //     normal double whose order equals the integer order (one 4.3-cycle op instead of cmp + 2 cndmask);
 //   * validity / core / window-range tests are 16-bit per-lane masks applied with v_bfe_i32 + v_bfi_b32;
-//   * the canonical strand is chosen with a sign mask of (r0 - f0) and v_bfi_b32.
+//   * the canonical strand is chosen with a sign mask of (r0 - f0) and v_bfi_b32 (measured alternatives with the
+//     same run time: v_cmp_lt_u64 + 4 x v_cndmask_b32 + v_addc; v_cmp_lt_u64 + v_subb mask + v_bfi).
 namespace {
 
 __device__ __forceinline__ double dmin(double a, double b) {
@@ -317,6 +318,10 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     __shared__ uint32_t s_wsum[L1_BLOCK / 64];
     __shared__ unsigned long long s_base;
     __shared__ int s_skip;
+#ifdef PGR_LDS_PAD
+    __shared__ uint32_t s_pad[PGR_LDS_PAD / 4];  // occupancy experiment only
+    if (a.w == 0xdead) s_pad[threadIdx.x] = 1;
+#endif
 
     const uint32_t t = threadIdx.x;
     const uint32_t tile = blockIdx.x;
