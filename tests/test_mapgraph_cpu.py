@@ -1,0 +1,114 @@
+"""CPU tests of the MAP-graph host logic: the oracle's container models (petgraph GraphMap / IndexMap, std BinaryHeap),
+structural properties of its outputs, and the product's host-side post-processing (pgrtk_amd.cli pbundle functions)
+against the oracle's restatement of pgr-pbundle-decomp (rs:61-137, 340-530).  No GPU needed."""
+import numpy as np
+
+import seqgen
+
+
+def _small_pangenome(oracle, seed=1, n_hap=6, spec_t=(24, 24, 2, 8)):
+    import mapgraph as og
+    haps = seqgen.amy1a_like(seed=seed, n_hap=n_hap, L=30_000, unit=2500)
+    sp = oracle.spec(*spec_t)
+    oix = oracle.Index(sp)
+    for i, s in enumerate(haps):
+        oix.add_seq(i, s)
+    oix.finalize()
+    fm = {}
+    for r in oix.records():
+        fm.setdefault((int(r["h0"]), int(r["h1"])), []).append(
+            (int(r["frg_id"]), int(r["sid"]), int(r["bgn"]), int(r["end"]), int(r["orient"])))
+    smps = []
+    for i, s in enumerate(haps):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), i, query_side=True)
+        smps.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    return og, haps, fm, smps
+
+
+def test_container_models():
+    import mapgraph as og
+    # IndexMap: insertion order, swap_remove moves the last entry into the hole
+    m = og.IndexMap()
+    for k in "abcde":
+        assert m.insert(k, k.upper())
+    assert not m.insert("b", "B2") and m.get("b") == "B2"
+    assert m.swap_remove("b") == "B2" and m.keys == ["a", "e", "c", "d"] and m.pos["e"] == 1
+    assert m.swap_remove("d") == "D" and m.keys == ["a", "e", "c"] and m.swap_remove("zz") is None
+    # GraphMap: neighbour order = edge insertion order; self loops have no Incoming entry but count as both
+    g = og.DiGraphMap()
+    for a, b in [(1, 2), (1, 3), (2, 3), (3, 3), (4, 1), (1, 2)]:
+        g.add_edge(a, b)
+    assert g.node_list() == [1, 2, 3, 4] and g.all_edges() == [(1, 2), (1, 3), (2, 3), (3, 3), (4, 1)]
+    assert g.neighbors_directed(1, og.OUT) == [2, 3] and g.neighbors_directed(1, og.IN) == [4]
+    assert g.neighbors_directed(3, og.OUT) == [3] and g.neighbors_directed(3, og.IN) == [1, 2, 3]
+    g.remove_node(1)
+    assert g.node_list() == [4, 2, 3] and g.neighbors_directed(2, og.IN) == [] and g.neighbors_directed(4, og.OUT) == []
+    assert g.all_edges() == [(2, 3), (3, 3)]  # three swap_removes: (1,2)<-(4,1), (1,3)<-(3,3), (4,1)<-(2,3)
+    # BinaryHeap: pops a maximum every time; equal weights come out in the order fixed by the sift mechanics
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        h = og.BinaryHeap()
+        items = [(int(w), i) for i, w in enumerate(rng.integers(0, 5, int(rng.integers(1, 40))))]
+        for it in items:
+            h.push(it)
+            d = h.d
+            assert all(d[(i - 1) // 2][0] >= d[i][0] for i in range(1, len(d)))
+        out = [h.pop() for _ in range(len(items))]
+        assert [w for w, _ in out] == sorted((w for w, _ in items), reverse=True) and sorted(out) == sorted(items)
+    h = og.BinaryHeap()
+    for it in [(1, "a"), (1, "b"), (1, "c"), (1, "d")]:
+        h.push(it)
+    # hand simulation of std's sift_down_to_bottom + sift_up with all weights equal: [a,b,c,d] -> a; [c,b,d] -> c;
+    # [b,d] -> b; [d] -> d   (the right child wins "<=" ties on the way down)
+    assert [h.pop()[1] for _ in range(4)] == ["a", "c", "b", "d"]
+
+
+def test_adj_list_and_bundle_properties(oracle):
+    og, haps, fm, smps = _small_pangenome(oracle)
+    adj = og.frag_map_to_adj_list(fm, 0)
+    assert adj and len(adj) % 2 == 0
+    # every edge comes with its reverse-complement twin; edges connect pairs adjacent on the sequence
+    for i in range(0, len(adj), 2):
+        sid, v, w = adj[i]
+        assert adj[i + 1] == (sid, og.rev(w), og.rev(v))
+        ev = [s for s in fm[(v[0], v[1])] if s[1] == sid and s[4] == v[2]]
+        ew = [s for s in fm[(w[0], w[1])] if s[1] == sid and s[4] == w[2]]
+        assert any(a[3] == b[2] for a in ev for b in ew)
+    # min_count keeps a subset; keeps=all sequences restores everything
+    sub = og.frag_map_to_adj_list(fm, 4)
+    assert set(sub) <= set(adj) and len(sub) < len(adj)
+    assert og.frag_map_to_adj_list(fm, 10 ** 6, keeps=list(range(len(haps)))) == adj
+    # weighted DFS visits every vertex key reachable once (a vertex and its reverse share the visit)
+    dfs = og.sort_adj_list_by_weighted_dfs(fm, adj, adj[0][1])
+    keys = [(n[0][0], n[0][1]) for n in dfs]
+    assert len(keys) == len(set(keys)) and dfs[0][0] == adj[0][1] and dfs[0][1] is None
+    assert all(n[2] == len(fm[(n[0][0], n[0][1])]) for n in dfs)
+    # principal bundles: longest first, every vertex key in at most one bundle position, all from the graph
+    pb = og.get_principal_bundles(fm, 0, 2)
+    assert pb and [len(p) for p in pb] == sorted((len(p) for p in pb), reverse=True)
+    allk = [(v[0], v[1]) for p in pb for v in p]
+    assert len(allk) == len(set(allk)) and set(allk) <= {(v[0], v[1]) for _, v, _ in adj} | {(w[0], w[1]) for _, _, w in adj}
+    with_id, vmap = og.get_principal_bundles_with_id(fm, smps, 0, 2)
+    assert sorted(b[0] for b in with_id) == list(range(len(pb)))
+    assert [b[1] for b in with_id] == sorted(b[1] for b in with_id)
+    for bid, _ord, bundle in with_id:  # a bundle is kept or reverse-complemented as a whole
+        assert bundle == pb[bid] or bundle == [(v[0], v[1], 1 - v[2]) for v in reversed(pb[bid])]
+
+
+def test_pbundle_postprocessing_vs_oracle(oracle):
+    """product host code (cli.py) == oracle restatement on the same decomposition"""
+    import sys, os
+    from pgrtk_amd import cli
+    og, haps, fm, smps = _small_pangenome(oracle, seed=3, n_hap=8)
+    with_id, vmap = og.get_principal_bundles_with_id(fm, smps, 0, 4)
+    dec = og.get_principal_bundle_decomposition(vmap, smps)
+    names = {i: "ctg%02d" % (7 - i) for i in range(len(haps))}
+    info = {i: (names[i], "x.fa", len(s)) for i, s in enumerate(haps)}
+    for cutoff, dist in [(100, 1000), (300, 3000), (2500, 10000), (0, 0)]:
+        for sid, sm in dec:
+            assert cli.group_smps_by_principle_bundle_id(sm, cutoff, dist) == og.group_smps_by_principle_bundle_id(sm, cutoff, dist)
+        assert cli.pbundle_bed_lines(names, dec, with_id, 24, cutoff, dist) == og.bed_lines(names, dec, with_id, 24, cutoff, dist)
+        parts = cli.pbundle_partitions(names, dec, cutoff, dist)
+        assert cli.pbundle_summary_lines(info, parts, 24) == og.ctg_summary_lines(info, dec, 24, cutoff, dist)
+    assert any(l.split("\t")[2] != "0" for l in og.ctg_summary_lines(info, dec, 24, 100, 1000)[1:])  # repeats found
+    assert cli._f32(100.0) == "100" and cli._f32(0.1) == "0.1" and cli._f32(1.0 / 3.0) == "0.33333334"
