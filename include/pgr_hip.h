@@ -250,6 +250,7 @@ typedef struct {
     pgr_vertex node, parent;
     uint32_t has_parent, is_leaf, rank, branch, branch_rank, _pad;
 } pgr_dfs_node;
+/* (host only: ctx may be NULL, then errors come back as codes without a message) */
 int pgr_sort_adj_list_by_weighted_dfs(pgr_ctx *ctx, const pgr_adj_pair *adj, uint64_t n,
                                       const pgr_vertex *start, pgr_dfs_node **out, uint64_t *n_out);
 
@@ -270,7 +271,7 @@ void pgr_bundles_free(pgr_bundles *b);
  * get_principal_bundles_from_adj_list (seq_db.rs:1064-1186) */
 int pgr_principal_bundles(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count, uint32_t path_len_cutoff,
                           const uint32_t *keeps, uint32_t n_keeps, pgr_bundles *out);
-/* the same from a caller-provided adjacency list (seq_db.rs:1064) */
+/* the same from a caller-provided adjacency list (seq_db.rs:1064); host only, ctx may be NULL */
 int pgr_principal_bundles_from_adj_list(pgr_ctx *ctx, const pgr_adj_pair *adj, uint64_t n,
                                         uint32_t path_len_cutoff, pgr_bundles *out);
 

@@ -477,6 +477,9 @@ void principal_bundles_host(const pgr_adj_pair *adj, uint64_t n, uint32_t path_l
 
 void bundles_clear(pgr_bundles *b) { memset(b, 0, sizeof(*b)); }
 
+// the host-only entry points (graph walks on caller-provided edges) work without a context / GPU
+int host_fail(pgr_ctx *ctx, int code, const char *msg) { return ctx ? ctx->fail(code, msg) : code; }
+
 int bundles_export(pgr_ctx *ctx, const NodeTable &nt, const std::vector<std::vector<uint32_t>> &bundles,
                    const std::vector<uint64_t> *ids, const std::vector<uint64_t> *ords, pgr_bundles *out) {
     bundles_clear(out);
@@ -489,7 +492,7 @@ int bundles_export(pgr_ctx *ctx, const NodeTable &nt, const std::vector<std::vec
     out->vertices = (pgr_vertex *)malloc(std::max<size_t>(nv, 1) * sizeof(pgr_vertex));
     if (!out->b_off || !out->bundle_id || !out->mean_ord || !out->vertices) {
         pgr_bundles_free(out);
-        return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+        return host_fail(ctx, PGR_ERR_NOMEM, "host allocation failed");
     }
     size_t o = 0;
     for (size_t b = 0; b < nb; ++b) {
@@ -734,21 +737,20 @@ extern "C" int pgr_index_key_counts(pgr_ctx *ctx, const pgr_index *ix, uint64_t 
 
 extern "C" int pgr_sort_adj_list_by_weighted_dfs(pgr_ctx *ctx, const pgr_adj_pair *adj, uint64_t n,
                                                  const pgr_vertex *start, pgr_dfs_node **out, uint64_t *n_out) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!out || !n_out || !start || (n && !adj)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (!out || !n_out || !start || (n && !adj)) return host_fail(ctx, PGR_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     *n_out = 0;
     NodeTable nt;
     AdjIds ids;
     intern_adj(adj, n, nt, ids);
     const int64_t s = nt.find_node(*start);
-    if (s < 0) return ctx->fail(PGR_ERR_INVALID_ARG, "start node is not in the adjacency list");  // reference: expect()
+    if (s < 0) return host_fail(ctx, PGR_ERR_INVALID_ARG, "start node is not in the adjacency list");  // reference: expect()
     GraphMap g(nt.n_nodes());
     for (uint64_t i = 0; i < n; ++i) g.add_edge(ids.v[i], ids.w[i]);
     std::vector<DfsOut> order;
     weighted_dfs(g, nt, (uint32_t)s, order);
     pgr_dfs_node *h = (pgr_dfs_node *)malloc(std::max<size_t>(order.size(), 1) * sizeof(pgr_dfs_node));
-    if (!h) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    if (!h) return host_fail(ctx, PGR_ERR_NOMEM, "host allocation failed");
     for (size_t i = 0; i < order.size(); ++i) {
         pgr_dfs_node &o = h[i];
         memset(&o, 0, sizeof(o));
@@ -767,8 +769,7 @@ extern "C" int pgr_sort_adj_list_by_weighted_dfs(pgr_ctx *ctx, const pgr_adj_pai
 
 extern "C" int pgr_principal_bundles_from_adj_list(pgr_ctx *ctx, const pgr_adj_pair *adj, uint64_t n,
                                                    uint32_t path_len_cutoff, pgr_bundles *out) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!out || (n && !adj)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (!out || (n && !adj)) return host_fail(ctx, PGR_ERR_INVALID_ARG, "null argument");
     NodeTable nt;
     std::vector<std::vector<uint32_t>> pb;
     principal_bundles_host(adj, n, path_len_cutoff, nt, pb);

@@ -112,3 +112,46 @@ def test_pbundle_postprocessing_vs_oracle(oracle):
         assert cli.pbundle_summary_lines(info, parts, 24) == og.ctg_summary_lines(info, dec, 24, cutoff, dist)
     assert any(l.split("\t")[2] != "0" for l in og.ctg_summary_lines(info, dec, 24, 100, 1000)[1:])  # repeats found
     assert cli._f32(100.0) == "100" and cli._f32(0.1) == "0.1" and cli._f32(1.0 / 3.0) == "0.33333334"
+
+
+def test_product_graph_walks_on_cpu(oracle):
+    """the library's host-only graph entry points (weighted DFS, principal bundles from an adjacency list) need no
+    GPU: run them here against the oracle on the oracle's adjacency list"""
+    import ctypes as C
+    from pgrtk_amd import _ffi
+    og, haps, fm, smps = _small_pangenome(oracle, seed=5, n_hap=7)
+    L = _ffi.lib()
+    for mc, cutoff in [(0, 0), (0, 3), (3, 1), (7, 2)]:
+        adj = og.frag_map_to_adj_list(fm, mc)
+        a = np.zeros(len(adj), dtype=_ffi.ADJ_PAIR)
+        for i, (sid, v, w) in enumerate(adj):
+            a[i]["sid"] = sid
+            for side, n in (("v", v), ("w", w)):
+                a[i][side]["h0"], a[i][side]["h1"], a[i][side]["orient"] = n
+                a[i][side]["count"] = len(fm[(n[0], n[1])])
+        if not adj:
+            continue
+        # weighted DFS
+        sv = a[:1]["v"].copy()
+        p, n = C.c_void_p(), C.c_uint64()
+        assert L.pgr_sort_adj_list_by_weighted_dfs(None, a.ctypes.data, len(a), sv.ctypes.data, C.byref(p), C.byref(n)) == 0
+        d = _ffi.take(p, int(n.value), _ffi.DFS_NODE)
+        got = [((int(r["node"]["h0"]), int(r["node"]["h1"]), int(r["node"]["orient"])),
+                (int(r["parent"]["h0"]), int(r["parent"]["h1"]), int(r["parent"]["orient"])) if r["has_parent"] else None,
+                int(r["node"]["count"]), bool(r["is_leaf"]), int(r["rank"]), int(r["branch"]), int(r["branch_rank"])) for r in d]
+        assert got == og.sort_adj_list_by_weighted_dfs(fm, adj, adj[0][1])
+        # principal bundles
+        b = _ffi.Bundles()
+        assert L.pgr_principal_bundles_from_adj_list(None, a.ctypes.data, len(a), cutoff, C.byref(b)) == 0
+        nb = int(b.n_bundles)
+        verts = np.zeros(int(b.n_vertices), dtype=_ffi.VERTEX)
+        if b.n_vertices:
+            C.memmove(verts.ctypes.data, b.vertices, verts.nbytes)
+        got_pb = [[(int(v["h0"]), int(v["h1"]), int(v["orient"])) for v in verts[int(b.b_off[i]):int(b.b_off[i + 1])]]
+                  for i in range(nb)]
+        L.pgr_bundles_free(C.byref(b))
+        assert got_pb == og.get_principal_bundles_from_adj_list(fm, adj, cutoff)[0]
+    # a start vertex outside the graph is an error code, not a crash (reference: expect("Node not found"))
+    bad = np.zeros(1, dtype=_ffi.VERTEX)
+    bad["h0"] = 1
+    assert L.pgr_sort_adj_list_by_weighted_dfs(None, a.ctypes.data, len(a), bad.ctypes.data, C.byref(p), C.byref(n)) < 0
