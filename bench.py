@@ -125,13 +125,32 @@ def query_bench(P, ctx, batch, spec, args, contig0):
     }
 
 
+def effective_cpus():
+    """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota (a container that sees
+    256 CPUs but has a 16-CPU quota runs 16 threads' worth of work)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, (q + per // 2) // per))
+        except Exception:
+            pass
+    return max(1, n)
+
+
 def cpu_baseline(spec_t, n_contigs, contig_len, seed, contig0, gpu_counts):
     """the oracle (CPU restatement of the reference, one task per contig like rayon par_iter) on a
     bounded sample of the same workload, all host cores.  Checker + baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import oracle as O
-    cores = os.cpu_count() or 1
-    n_s = min(n_contigs, max(8, 2 * cores))
+    cores = effective_cpus()
+    n_s = min(n_contigs, max(8, 4 * cores))  # ~10 s of CPU work at ~65 Mbp/s per thread
     while n_s > 1 and n_s * contig_len > 4_000_000_000:  # bound host memory
         n_s //= 2
     seqs = [O.synth_contig(seed, contig0 + i, contig_len) for i in range(n_s)]
@@ -142,8 +161,10 @@ def cpu_baseline(spec_t, n_contigs, contig_len, seed, contig0, gpu_counts):
     ok = all(int(counts[i]) == int(gpu_counts[i]) for i in range(n_s))
     return {
         "value": n_s * contig_len / dt / 1e9, "unit": "Gbp/s", "cores": cores, "kind": "port",
-        "sample": "%d x %d bp of the same synthetic contigs, %.1f s wall, one task per contig on %d threads; "
-                  "per-contig shimmer counts %s the GPU's" % (n_s, contig_len, dt, cores, "==" if ok else "!="),
+        "sample": "%d x %d bp of the same synthetic contigs, %.1f s wall, one task per contig on %d threads "
+                  "(= the CPUs this container may use: affinity capped by the cgroup quota; the host shows %d); "
+                  "per-contig shimmer counts %s the GPU's" % (n_s, contig_len, dt, cores, os.cpu_count() or 0,
+                                                              "==" if ok else "!="),
         "counts_match_gpu": ok,
     }
 
