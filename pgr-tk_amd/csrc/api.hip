@@ -836,12 +836,11 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
     }
     memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * sizeof(uint64_t));
     if (s->count) {
-        hipError_t e = hipMemcpyAsync(mm, s->d_mm, s->count * sizeof(pgr_mm128), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) {
+        const int rc = ctx->d2h(mm, s->d_mm, s->count * sizeof(pgr_mm128));
+        if (rc) {
             free(mm);
             free(off);
-            return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+            return rc;
         }
     }
     *out_mm = mm;
@@ -962,8 +961,7 @@ extern "C" int pgr_frag_recs_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t 
             if (cnt > 1) acc += cnt - 1;
         }
         off[n] = acc;
-        if (np && hipMemcpy(recs, tmp.p, np * sizeof(pgr_frag_rec), hipMemcpyDeviceToHost) != hipSuccess)
-            rc = ctx->fail(PGR_ERR_DEVICE, "D2H of the pair records failed");
+        if (np) rc = ctx->d2h(recs, tmp.p, np * sizeof(pgr_frag_rec));
     }
     tmp.release(ctx);
     pgr_shmmrs_destroy(s);

@@ -1,5 +1,8 @@
 // ctx.hip -- context memory management (workspaces, pinned staging, caching device allocator).
 #include <algorithm>
+#include <cstring>
+#include <thread>
+#include <vector>
 
 #include "pgr_ctx.h"
 
@@ -112,6 +115,63 @@ int pgr_ctx::ensure_pinned(size_t bytes) {
         return fail(PGR_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     }
     pinned_cap = bytes;
+    return PGR_OK;
+}
+
+int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
+    if (bytes == 0) return PGR_OK;
+    if (bytes < (4u << 20)) {  // stream ordered like the pipelined path (the context's stream is non-blocking)
+        hipError_t e = hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(stream);
+        return e == hipSuccess ? PGR_OK : fail(PGR_ERR_DEVICE, std::string("D2H copy: ") + hipGetErrorString(e));
+    }
+    const size_t WIN = 16u << 20;
+    int rc = ensure_pinned(2 * WIN);
+    if (rc) return rc;
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_thr = std::max(1u, std::min(4u, hw ? hw / 2 : 1u));
+    auto host_copy = [&](uint8_t *d, const uint8_t *s, size_t len) {
+        if (n_thr == 1 || len < (2u << 20)) {
+            memcpy(d, s, len);
+            return;
+        }
+        const size_t part = (len + n_thr - 1) / n_thr;
+        std::vector<std::thread> th;
+        for (unsigned i = 1; i < n_thr; ++i) {
+            const size_t o = std::min(len, (size_t)i * part), l = std::min(part, len - o);
+            if (l) th.emplace_back([=] { memcpy(d + o, s + o, l); });
+        }
+        memcpy(d, s, std::min(part, len));
+        for (auto &t : th) t.join();
+    };
+    const uint8_t *sd = (const uint8_t *)src_dev;
+    uint8_t *dh = (uint8_t *)dst, *pin = (uint8_t *)pinned;
+    size_t issued = 0, copied = 0;
+    int slot = 0;
+    hipError_t e = hipSuccess;
+    // prime window 0, then: issue window i+1, wait for window i, copy it out
+    auto issue = [&](int sl) {
+        const size_t len = std::min(WIN, bytes - issued);
+        e = hipMemcpyAsync(pin + (size_t)sl * WIN, sd + issued, len, hipMemcpyDeviceToHost, stream);
+        if (e == hipSuccess) e = hipEventRecord(ev[2 + sl], stream);
+        issued += len;
+    };
+    issue(0);
+    while (e == hipSuccess && copied < bytes) {
+        const int cur = slot;
+        slot ^= 1;
+        if (issued < bytes) issue(slot);
+        if (e != hipSuccess) break;
+        e = hipEventSynchronize(ev[2 + cur]);
+        if (e != hipSuccess) break;
+        const size_t len = std::min(WIN, bytes - copied);
+        host_copy(dh + copied, pin + (size_t)cur * WIN, len);
+        copied += len;
+    }
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(stream);
+        return fail(PGR_ERR_DEVICE, std::string("D2H copy: ") + hipGetErrorString(e));
+    }
     return PGR_OK;
 }
 

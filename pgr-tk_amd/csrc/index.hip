@@ -333,11 +333,11 @@ extern "C" int pgr_index_download(pgr_ctx *ctx, const pgr_index *ix, pgr_frag_re
     if (!*out) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     *n = ix->n;
     if (ix->n) {
-        hipError_t e = hipMemcpy(*out, ix->recs, ix->n * sizeof(pgr_frag_rec), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
+        const int rc = ctx->d2h(*out, ix->recs, ix->n * sizeof(pgr_frag_rec));
+        if (rc) {
             free(*out);
             *out = nullptr;
-            return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+            return rc;
         }
     }
     return PGR_OK;

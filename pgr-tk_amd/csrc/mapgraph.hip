@@ -554,12 +554,11 @@ int adj_list_device(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count, const
                        rank.as<uint64_t>(), dout.as<pgr_adj_pair>());
     pgr_adj_pair *h = (pgr_adj_pair *)malloc(2 * n_edges * sizeof(pgr_adj_pair));
     if (!h) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
-    hipError_t e = hipMemcpyAsync(h, dout.p, 2 * n_edges * sizeof(pgr_adj_pair), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) {
+    rc = ctx->d2h(h, dout.p, 2 * n_edges * sizeof(pgr_adj_pair));  // ordered after the kernel on the context's stream
+    if (!rc && hipGetLastError() != hipSuccess) rc = ctx->fail(PGR_ERR_DEVICE, "adjacency kernels failed");
+    if (rc) {
         free(h);
-        return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+        return rc;
     }
     *out = h;
     *n_out = 2 * n_edges;
@@ -602,8 +601,7 @@ int lookup_smps(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uint64_t n, int index_
     hipStream_t st = ctx->stream;
     hipLaunchKernelGGL(bundle_lookup_kernel, grid_for(n), dim3(256), 0, st, d_recs, n, index_side, dtab.as<VEntry>(), n_tab,
                        d_out);
-    PGR_HIP(ctx, hipMemcpyAsync(h_out, d_out, n * sizeof(pgr_smp_bundle), hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipStreamSynchronize(st));
+    if ((rc = ctx->d2h(h_out, d_out, n * sizeof(pgr_smp_bundle)))) return rc;
     PGR_HIP(ctx, hipGetLastError());
     return PGR_OK;
 }

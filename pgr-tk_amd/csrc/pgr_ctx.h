@@ -45,6 +45,9 @@ struct pgr_ctx {
     int dmalloc(void **out, size_t bytes);
     void dfree(void *p);
     int ensure_pinned(size_t bytes);
+    // device -> pageable host memory through the pinned buffer (two windows, D2H of window i+1 overlaps the host
+    // copy of window i, which is spread over a few threads); small transfers go straight through hipMemcpy
+    int d2h(void *dst, const void *src_dev, size_t bytes);
     void release_all();
 };
 
