@@ -676,14 +676,21 @@ static int sparse_aln_impl(orc_hitpair *hits, size_t n, uint32_t max_span, float
         }
         size_t tn = 0;
         long v = best_v;
+        int cycle = 0;
         while (v >= 0) { /* :121-128 */
             if (!unvisited[v]) break;
+            if (tn == n_ids) { /* best_pre has a cycle (only possible with exact duplicate hit pairs: a value
+                                * slot re-scored after a later node chose it): the reference pushes to `track`
+                                * forever here */
+                cycle = 1;
+                break;
+            }
             track[tn] = hits[first_idx[v]];
             track_id[tn] = v;
             tn++;
             v = best_pre[v];
         }
-        if (tn == 0) { /* :129-131 `continue` -> the reference would spin forever */
+        if (tn == 0 || cycle) { /* :129-131 `continue` -> the reference would spin forever */
             rc = -1;
             break;
         }

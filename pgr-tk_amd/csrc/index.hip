@@ -488,6 +488,8 @@ __device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair 
 __device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
 
 constexpr uint32_t MAX_SPAN_CAP = 64;
+constexpr int ALN_WAVE_MIN = 65;    // groups with at least this many hits are chained by a whole wavefront
+constexpr int ALN_LDS_MAX = 3584;   // ... and held in LDS while they are at most this long (36 B per hit)
 
 // aln::sparse_aln (aln.rs:12-142), one thread per (query, target) group.  The hits of a group are
 // already stably sorted by query bgn (aln.rs:21).  v_s / best_pre_v are FxHashMaps keyed by the
@@ -499,7 +501,8 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
                                   int *__restrict__ slot, pgr_hitpair *__restrict__ out_hp,
                                   uint32_t *__restrict__ chain_len, float *__restrict__ chain_score,
                                   uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
-                                  uint32_t *__restrict__ err) {
+                                  uint32_t *__restrict__ err, uint32_t *__restrict__ big_list,
+                                  uint32_t *__restrict__ n_big) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const uint64_t gs = g_start[g];
@@ -507,6 +510,10 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
     g_nchains[g] = 0;
     g_nhp[g] = 0;
     if (n < 2) return;  // aln.rs:234: targets with a single hit are dropped
+    if (n >= ALN_WAVE_MIN) {  // long groups: one wavefront each (sparse_aln_wave_kernel)
+        big_list[atomicAdd(n_big, 1u)] = (uint32_t)g;
+        return;
+    }
     const pgr_hitpair *h = hp + gs;
     float *vs = v_s + gs;
     int *pv = pre + gs;
@@ -613,6 +620,212 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
     g_nhp[g] = n_out;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// sparse_aln for ONE long group per wavefront.  Same recurrence, same f32 operation order and the same tie
+// rules as sparse_aln_kernel; what changes is where the latency goes: the look-back of a hit evaluates 64
+// candidates per step in parallel (the "stop after max_span distinct query intervals" rule becomes ballots in
+// candidate order), the arg-max scans of the extraction are lane-strided, and groups of up to ALN_LDS_MAX hits
+// live in LDS for the whole computation (a serial thread pays ~1 us of HBM/L2 latency per dependent access).
+struct AlnWaveLds {
+    pgr_hitpair h[ALN_LDS_MAX];
+    float vs[ALN_LDS_MAX];
+    int sl[ALN_LDS_MAX];
+    int pv[ALN_LDS_MAX];
+    uint32_t span_q[MAX_SPAN_CAP][3];
+};
+
+__device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders LDS and global accesses of the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+__global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
+    const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start, const uint32_t *__restrict__ big_list,
+    const uint32_t *__restrict__ n_big, AlnParams prm, float *v_s, int *pre, int *slot, pgr_hitpair *out_hp,
+    uint32_t *__restrict__ chain_len, float *__restrict__ chain_score, uint32_t *__restrict__ g_nchains,
+    uint32_t *__restrict__ g_nhp, uint32_t *__restrict__ err) {
+    __shared__ AlnWaveLds L;
+    if (blockIdx.x >= *n_big) return;
+    const uint32_t g = big_list[blockIdx.x];
+    const uint64_t gs = g_start[g];
+    const int n = (int)(g_start[g + 1] - gs);
+    const int lane = (int)threadIdx.x;
+    const bool in_lds = n <= ALN_LDS_MAX;
+    const pgr_hitpair *h = hp + gs;
+    float *vs = v_s + gs;
+    int *sl = slot + gs, *pv = pre + gs;
+    if (in_lds) {
+        for (int i = lane; i < n; i += 64) L.h[i] = hp[gs + i];
+        h = L.h;
+        vs = L.vs;
+        sl = L.sl;
+        pv = L.pv;
+    }
+    wave_sync();
+    // value slots: the earliest identical hit pair of the (equal qb) run
+    for (int i = lane; i < n; i += 64) {
+        int s = i;
+        const pgr_hitpair hi = h[i];
+        for (int j = i - 1; j >= 0 && h[j].qb == hi.qb; --j)
+            if (same_hp(h[j], hi)) s = j;
+        sl[i] = s;
+    }
+    wave_sync();
+    if (lane == 0) {
+        vs[sl[0]] = (float)h[0].qe - (float)h[0].qb;  // aln.rs:25-27
+        pv[sl[0]] = -1;
+    }
+    wave_sync();
+    for (int i = 1; i < n; ++i) {  // aln.rs:29-103
+        const pgr_hitpair cur = h[i];
+        const float cur_len = (float)cur.qe - (float)cur.qb;
+        float best_s = 0.0f;
+        int best_v = -1;
+        uint32_t span_n = 0;
+        bool stop = false;
+        for (int jb = i - 1; jb >= 0 && !stop; jb -= 64) {
+            const int j = jb - lane;
+            bool cons = j >= 0;
+            const pgr_hitpair p = cons ? h[j] : cur;
+            float a = 0.0f, b = 0.0f;
+            if (cons) {
+                if (prm.oriented && ((p.qo ^ p.to) != (cur.qo ^ cur.to))) cons = false;  // :43-50
+                a = (float)cur.qb - (float)p.qe;
+                b = (cur.qo == cur.to) ? ((float)cur.tb - (float)p.te) : ((float)cur.te - (float)p.tb);
+                a = absf(a);
+                b = absf(b);
+                if (prm.has_max_gap) {  // :52-65
+                    const float mg = (float)prm.max_gap;
+                    if (a > mg || b > mg) cons = false;
+                }
+                if (same_q(p, cur)) cons = false;  // :67
+            }
+            const uint64_t cm = __ballot(cons);
+            if (!cm) continue;
+            // span_set (:70, :91) in candidate order: intervals already seen in earlier batches, then new ones
+            uint64_t rem = cm;
+            for (uint32_t t = 0; t < span_n; ++t) {
+                const uint32_t q0 = L.span_q[t][0], q1 = L.span_q[t][1], q2 = L.span_q[t][2];
+                rem &= ~__ballot(cons && p.qb == q0 && p.qe == q1 && p.qo == q2);
+            }
+            int stop_lane = 64;
+            while (rem) {
+                const int l0 = __builtin_ctzll(rem);
+                const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)p.qb, l0);
+                const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)p.qe, l0);
+                const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)p.qo, l0);
+                if (lane == 0) {
+                    L.span_q[span_n][0] = q0;
+                    L.span_q[span_n][1] = q1;
+                    L.span_q[span_n][2] = q2;
+                }
+                ++span_n;
+                rem &= ~__ballot(cons && p.qb == q0 && p.qe == q1 && p.qo == q2);
+                if (span_n >= prm.max_span) {  // the candidate that completes the span set is still scored
+                    stop_lane = l0;
+                    break;
+                }
+            }
+            wave_sync();  // span_q is read back by every lane in the next batch
+            const bool proc = cons && lane <= stop_lane;
+            float s = 0.0f;
+            int slj = 0;
+            if (proc) {
+                slj = sl[j];
+                const float p_s = vs[slj];      // :71
+                s = p_s + cur_len;              // :72
+                const float sum = a + b;        // :74-84
+                const float pen = prm.penalty * sum;
+                s = s - pen;
+            }
+            uint64_t pm = __ballot(proc);
+            while (pm) {  // strict >, candidates in look-back order (:86-89)
+                const int l = __builtin_ctzll(pm);
+                pm &= pm - 1;
+                const float s_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), l));
+                if (s_l > best_s) {
+                    best_s = s_l;
+                    best_v = __builtin_amdgcn_readlane(slj, l);
+                }
+            }
+            if (stop_lane < 64) stop = true;
+        }
+        if (lane == 0) {  // :96-102
+            const int si = sl[i];
+            if (best_s > 0.0f) {
+                vs[si] = best_s;
+                pv[si] = best_v;
+            } else {
+                vs[si] = cur_len;
+                pv[si] = -1;
+            }
+        }
+        wave_sync();
+    }
+    // extraction (aln.rs:105-140); a visited value slot is marked by sl[v] = -1 - v
+    int n_unvisited = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        n_unvisited += (int)__popcll(__ballot(i < n && sl[i] == i));
+    }
+    uint32_t n_ch = 0, n_out = 0;
+    while (n_unvisited > 0) {
+        float bs = 0.0f;
+        int bv = -1;
+        for (int i = lane; i < n; i += 64)
+            if (sl[i] == i && vs[i] > bs) {  // strict >: the lowest index of this lane's maxima
+                bs = vs[i];
+                bv = i;
+            }
+        for (int off = 32; off; off >>= 1) {  // wave arg-max: highest score, ties to the lowest sorted index
+            const float os = __shfl_xor(bs, off, 64);
+            const int ov = __shfl_xor(bv, off, 64);
+            if (ov >= 0 && (bv < 0 || os > bs || (os == bs && ov < bv))) {
+                bs = os;
+                bv = ov;
+            }
+        }
+        if (bv < 0) {  // aln.rs:129-131 would spin forever (non-positive scores)
+            if (lane == 0) atomicExch(err, 1u);
+            break;
+        }
+        int len = 0, first_v = bv;
+        if (lane == 0) {
+            int v = bv;
+            while (v >= 0 && sl[v] == v) {  // :121-128
+                out_hp[gs + n_out + len] = h[v];
+                ++len;
+                first_v = v;
+                const int nv = pv[v];
+                sl[v] = -1 - v;  // :133-137
+                v = nv;
+            }
+        }
+        len = __builtin_amdgcn_readfirstlane(len);
+        first_v = __builtin_amdgcn_readfirstlane(first_v);
+        wave_sync();
+        for (int a = lane; a < len / 2; a += 64) {  // :132 reverse
+            const pgr_hitpair t = out_hp[gs + n_out + a];
+            out_hp[gs + n_out + a] = out_hp[gs + n_out + len - 1 - a];
+            out_hp[gs + n_out + len - 1 - a] = t;
+        }
+        if (lane == 0) {
+            chain_len[gs + n_ch] = (uint32_t)len;
+            chain_score[gs + n_ch] = bs - vs[first_v];  // :138-139
+        }
+        ++n_ch;
+        n_out += (uint32_t)len;
+        n_unvisited -= len;
+        wave_sync();
+    }
+    if (lane == 0) {
+        g_nchains[g] = n_ch;
+        g_nhp[g] = n_out;
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -659,16 +872,23 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     if ((rc = gstart.alloc((n_groups + 1) * 8))) return rc;
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(), rank.as<uint64_t>(),
                        n, gstart.as<uint64_t>());
-    Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx);
+    Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx), big(ctx);
+    const uint64_t max_big = n / ALN_WAVE_MIN + 1;  // a long group has at least ALN_WAVE_MIN hits
     if ((rc = v_s.alloc(n * 4)) || (rc = pre.alloc(n * 4)) || (rc = slot.alloc(n * 4)) ||
         (rc = o_hp.alloc(n * sizeof(pgr_hitpair))) || (rc = c_len.alloc(n * 4)) || (rc = c_score.alloc(n * 4)) ||
-        (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(4)))
+        (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(8)) ||
+        (rc = big.alloc(max_big * 4)))
         return rc;
-    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 4, st));
+    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 8, st));  // [0] error flag, [1] number of long groups
     hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n_groups, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
                        gstart.as<uint64_t>(), n_groups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
                        o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(), g_nch.as<uint32_t>(),
-                       g_nhp.as<uint32_t>(), err.as<uint32_t>());
+                       g_nhp.as<uint32_t>(), err.as<uint32_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1);
+    // long groups, one wavefront each; the grid is the upper bound, surplus workgroups exit on the device-side count
+    hipLaunchKernelGGL(sparse_aln_wave_kernel, dim3((uint32_t)max_big), dim3(64), 0, st, shp.as<pgr_hitpair>(),
+                       gstart.as<uint64_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1, prm, v_s.as<float>(),
+                       pre.as<int>(), slot.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(),
+                       g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
     // D2H and compaction on the host (output assembly only)
     std::vector<uint64_t> h_gstart(n_groups + 1), h_skey(n);
     std::vector<uint32_t> h_nch(n_groups), h_nhp(n_groups), h_clen(n);

@@ -3,6 +3,14 @@ import sys
 
 import pytest
 
+try:
+    # torch bundles its own copy of the HIP runtime; it has to initialise BEFORE libpgrhip.so pulls in the system
+    # runtime (/opt/rocm), or torch.cuda finds no device later in the same process (the other order is fine).
+    # Tests that use torch (multi-GPU exchange) therefore need it imported first.
+    import torch  # noqa: F401
+except ImportError:
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests"), ROOT):
     if p not in sys.path:

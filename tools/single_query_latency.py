@@ -1,0 +1,24 @@
+"""latency of ONE query through the Python API (SeqIndexDB.query_fragment_to_hps), index of 100 x 1 Mbp"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "oracle")]
+import oracle as O  # noqa: E402
+import pgrtk_amd as P  # noqa: E402
+
+seqs = [O.synth_contig(11, i, 1_000_000) for i in range(100)]
+sdb = P.SeqIndexDB()
+sdb.load_from_seq_list([("c%d" % i, s) for i, s in enumerate(seqs)], w=80, k=56, r=4, min_span=64)
+for ql in (10_000, 100_000, 1_000_000):
+    q = seqs[5][1000:1000 + ql]
+    sdb.query_fragment_to_hps(q, 0.025)
+    ts = []
+    for _ in range(9):
+        t0 = time.perf_counter()
+        r = sdb.query_fragment_to_hps(q, 0.025)
+        ts.append(time.perf_counter() - t0)
+    ts.sort()
+    print("query %8d bp: median %.3f ms, min %.3f ms, %d targets, %d hit pairs in the best chain" %
+          (ql, ts[4] * 1e3, ts[0] * 1e3, len(r), max((len(c[1]) for _, cs in r for c in cs), default=0)))
