@@ -488,8 +488,9 @@ __device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair 
 __device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
 
 constexpr uint32_t MAX_SPAN_CAP = 64;
-constexpr int ALN_WAVE_MIN = 65;    // groups with at least this many hits are chained by a whole wavefront
-constexpr int ALN_LDS_MAX = 3584;   // ... and held in LDS while they are at most this long (36 B per hit)
+constexpr int ALN_WAVE_MIN = 16;    // groups with at least this many hits are chained by a whole wavefront
+constexpr int ALN_LDS_SMALL = 256;  // ... in a 9 KB LDS image (many workgroups per CU) up to this many hits,
+constexpr int ALN_LDS_MAX = 3584;   // in a 129 KB image up to this many (36 B per hit), in global memory above
 
 // aln::sparse_aln (aln.rs:12-142), one thread per (query, target) group.  The hits of a group are
 // already stably sorted by query bgn (aln.rs:21).  v_s / best_pre_v are FxHashMaps keyed by the
@@ -502,7 +503,7 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
                                   uint32_t *__restrict__ chain_len, float *__restrict__ chain_score,
                                   uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
                                   uint32_t *__restrict__ err, uint32_t *__restrict__ big_list,
-                                  uint32_t *__restrict__ n_big) {
+                                  uint32_t *__restrict__ n_big, uint32_t cls_stride) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= n_groups) return;
     const uint64_t gs = g_start[g];
@@ -510,8 +511,9 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
     g_nchains[g] = 0;
     g_nhp[g] = 0;
     if (n < 2) return;  // aln.rs:234: targets with a single hit are dropped
-    if (n >= ALN_WAVE_MIN) {  // long groups: one wavefront each (sparse_aln_wave_kernel)
-        big_list[atomicAdd(n_big, 1u)] = (uint32_t)g;
+    if (n >= ALN_WAVE_MIN) {  // one wavefront each (sparse_aln_wave_kernel), two size classes
+        const int cls = n > ALN_LDS_SMALL ? 1 : 0;
+        big_list[(size_t)cls * cls_stride + atomicAdd(n_big + cls, 1u)] = (uint32_t)g;
         return;
     }
     const pgr_hitpair *h = hp + gs;
@@ -627,11 +629,12 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
 // candidates per step in parallel (the "stop after max_span distinct query intervals" rule becomes ballots in
 // candidate order), the arg-max scans of the extraction are lane-strided, and groups of up to ALN_LDS_MAX hits
 // live in LDS for the whole computation (a serial thread pays ~1 us of HBM/L2 latency per dependent access).
+template <int NMAX>
 struct AlnWaveLds {
-    pgr_hitpair h[ALN_LDS_MAX];
-    float vs[ALN_LDS_MAX];
-    int sl[ALN_LDS_MAX];
-    int pv[ALN_LDS_MAX];
+    pgr_hitpair h[NMAX];
+    float vs[NMAX];
+    int sl[NMAX];
+    int pv[NMAX];
     uint32_t span_q[MAX_SPAN_CAP][3];
 };
 
@@ -641,18 +644,19 @@ __device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
+template <int NMAX>
 __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
     const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start, const uint32_t *__restrict__ big_list,
     const uint32_t *__restrict__ n_big, AlnParams prm, float *v_s, int *pre, int *slot, pgr_hitpair *out_hp,
     uint32_t *__restrict__ chain_len, float *__restrict__ chain_score, uint32_t *__restrict__ g_nchains,
     uint32_t *__restrict__ g_nhp, uint32_t *__restrict__ err) {
-    __shared__ AlnWaveLds L;
+    __shared__ AlnWaveLds<NMAX> L;
     if (blockIdx.x >= *n_big) return;
     const uint32_t g = big_list[blockIdx.x];
     const uint64_t gs = g_start[g];
     const int n = (int)(g_start[g + 1] - gs);
     const int lane = (int)threadIdx.x;
-    const bool in_lds = n <= ALN_LDS_MAX;
+    const bool in_lds = n <= NMAX;
     const pgr_hitpair *h = hp + gs;
     float *vs = v_s + gs;
     int *sl = slot + gs, *pv = pre + gs;
@@ -873,22 +877,28 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(), rank.as<uint64_t>(),
                        n, gstart.as<uint64_t>());
     Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx), big(ctx);
-    const uint64_t max_big = n / ALN_WAVE_MIN + 1;  // a long group has at least ALN_WAVE_MIN hits
+    const uint64_t max_big = n / ALN_WAVE_MIN + 1;  // a wave-chained group has at least ALN_WAVE_MIN hits
     if ((rc = v_s.alloc(n * 4)) || (rc = pre.alloc(n * 4)) || (rc = slot.alloc(n * 4)) ||
         (rc = o_hp.alloc(n * sizeof(pgr_hitpair))) || (rc = c_len.alloc(n * 4)) || (rc = c_score.alloc(n * 4)) ||
-        (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(8)) ||
-        (rc = big.alloc(max_big * 4)))
+        (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(16)) ||
+        (rc = big.alloc(2 * max_big * 4)))
         return rc;
-    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 8, st));  // [0] error flag, [1] number of long groups
+    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 16, st));  // [0] error flag, [1], [2] number of groups per wave class
     hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n_groups, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
                        gstart.as<uint64_t>(), n_groups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
                        o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(), g_nch.as<uint32_t>(),
-                       g_nhp.as<uint32_t>(), err.as<uint32_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1);
-    // long groups, one wavefront each; the grid is the upper bound, surplus workgroups exit on the device-side count
-    hipLaunchKernelGGL(sparse_aln_wave_kernel, dim3((uint32_t)max_big), dim3(64), 0, st, shp.as<pgr_hitpair>(),
-                       gstart.as<uint64_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1, prm, v_s.as<float>(),
-                       pre.as<int>(), slot.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(),
-                       g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
+                       g_nhp.as<uint32_t>(), err.as<uint32_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1,
+                       (uint32_t)max_big);
+    // one wavefront per longer group; the grids are upper bounds, surplus workgroups exit on the device-side counts
+    hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_SMALL>, dim3((uint32_t)max_big), dim3(64), 0, st,
+                       shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1, prm,
+                       v_s.as<float>(), pre.as<int>(), slot.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
+                       c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
+    const uint64_t max_long = n / (ALN_LDS_SMALL + 1) + 1;
+    hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_MAX>, dim3((uint32_t)max_long), dim3(64), 0, st,
+                       shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>() + max_big, err.as<uint32_t>() + 2,
+                       prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
+                       c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
     // D2H and compaction on the host (output assembly only)
     std::vector<uint64_t> h_gstart(n_groups + 1), h_skey(n);
     std::vector<uint32_t> h_nch(n_groups), h_nhp(n_groups), h_clen(n);

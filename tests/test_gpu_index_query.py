@@ -202,9 +202,10 @@ def test_sparse_aln_duplicates_and_small(oracle, gpu_ctx):
         assert got == ref, trial
 
 
-@pytest.mark.parametrize("n", [64, 65, 66, 129, 700, 3584, 3585, 6000])
+@pytest.mark.parametrize("n", [15, 16, 17, 64, 129, 256, 257, 700, 3584, 3585, 6000])
 def test_sparse_aln_long_groups(oracle, gpu_ctx, n):
-    """long groups take the wavefront-per-group kernel (>= 65 hits; in LDS up to 3584 hits, in global memory above):
+    """groups of >= 16 hits take the wavefront-per-group kernel (9 KB LDS image up to 256 hits, 129 KB up to 3584, global
+    memory above; shorter groups one thread each):
     collinear runs with noise, ties in qb, equal query intervals on different targets, duplicates, both orientations"""
     import pgrtk_amd as P
     rng = np.random.default_rng(1000 + n)
