@@ -306,6 +306,54 @@ def test_cli_mdb_and_query(oracle, gpu_ctx, golden_dir, tmp_path):
     assert sdb.get_shmmr_map() == m and sdb.get_shmmr_spec() == (80, 56, 4, 64, False)
 
 
+def test_cpp_host_programs_match_python_cli(oracle, gpu_ctx, golden_dir, tmp_path):
+    """the C++ host programs above the C ABI (pgr-tk_amd/bin/pgr-mdb, pgr-query: the reference's callers are compiled
+    code too) write the same files as the Python counterparts: .mdb / .midx byte for byte, every .hit / .hit.bed / .fa"""
+    import subprocess
+    from pgrtk_amd import cli
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    bindir = os.path.join(root, "pgr-tk_amd", "bin")
+    assert os.path.exists(os.path.join(bindir, "pgr-mdb")), "host programs not built: python __graft_entry__.py build"
+    fa = os.path.join(golden_dir, "test_seqs.fa")
+    fq = tmp_path / "extra.fq"   # a FASTQ input next to the FASTA one
+    recs = oracle.read_fasta(fa)
+    fq.write_text("".join("@r%d x\n%s\n+\n%s\n" % (i, recs[i][1][:2500].decode(), "I" * len(recs[i][1][:2500])) for i in (3, 9)))
+    lst = tmp_path / "list.txt"
+    lst.write_text(fa + "\n" + str(fq) + "\n")
+    py, cc = str(tmp_path / "py"), str(tmp_path / "cc")
+    for args in ([], ["-w", "48", "-k", "56", "-r", "4", "-m", "12"], ["--reference-sid-quirk"]):
+        cli.main(["mdb", str(lst), py] + args)
+        subprocess.run([os.path.join(bindir, "pgr-mdb"), str(lst), cc] + args, check=True)
+        assert open(py + ".mdb", "rb").read() == open(cc + ".mdb", "rb").read()
+        assert open(py + ".midx").read() == open(cc + ".midx").read()
+    cli.main(["mdb", str(lst), py])
+    subprocess.run([os.path.join(bindir, "pgr-mdb"), str(lst), cc], check=True)
+    # queries: forward, reverse complement, one spanning two contigs, one without hits
+    rng = np.random.default_rng(4)
+    src = recs[5][1]
+    qfa = tmp_path / "q.fa"
+    qfa.write_text(">q0 c\n%s\n>q1\n%s\n>q2\n%s\n>q3\n%s\n" % (
+        src[200:3000].decode(), cli.reverse_complement(src[100:3300]).decode(),
+        (recs[7][1][:1500] + recs[11][1][:1800]).decode(), seqgen.rnd(rng, 3000).decode()))
+    for db_py, db_cc, extra in ((py, cc, []), (py, cc, ["--bed-summary"]), (fa, fa, ["--fastx_file"]),
+                                (py, cc, ["--merge-range-tol", "10", "--max-aln-chain-span", "2", "-g", "0.5"])):
+        for f in os.listdir(tmp_path):
+            if f.startswith(("opy.", "occ.")):
+                os.remove(tmp_path / f)
+        cli.main(["query", db_py, str(qfa), str(tmp_path / "opy")] + extra)
+        subprocess.run([os.path.join(bindir, "pgr-query"), db_cc, str(qfa), str(tmp_path / "occ")] + extra, check=True)
+        outs_py = sorted(f[4:] for f in os.listdir(tmp_path) if f.startswith("opy."))
+        outs_cc = sorted(f[4:] for f in os.listdir(tmp_path) if f.startswith("occ."))
+        assert outs_py == outs_cc and len(outs_py) >= 4
+        for f in outs_py:
+            a = open(tmp_path / ("opy." + f)).read()
+            b = open(tmp_path / ("occ." + f)).read()
+            if db_py != db_cc:
+                pass
+            assert a.replace(py, "DB") == b.replace(cc, "DB"), f
+    assert any(len(open(tmp_path / ("occ." + f)).read().splitlines()) > 1 for f in outs_cc)
+
+
 def test_index_from_exchanged_shimmer_lists(oracle, gpu_ctx):
     """multi-GPU merge path on one GPU: two "ranks" index disjoint contig shards, copy their MM128 lists with
     global sequence ids (what the RCCL all-gather moves), and an index built from the concatenated lists
