@@ -219,6 +219,24 @@ def test_cli_pbundle_decomp(oracle, gpu_ctx, tmp_path):
         osm.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
     odec = og.get_principal_bundle_decomposition(vmap, osm)
     assert open(tmp_path / "out2.bed").read().splitlines()[1:] == og.bed_lines({0: "o0", 1: "o1"}, odec, with_id, 24, 300, 3000)
+    # the C++ host program above the C ABI writes the same files
+    import os
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgr-tk_amd", "bin", "pgr-pbundle-decomp")
+    assert os.path.exists(exe), "host programs not built: python __graft_entry__.py build"
+    subprocess.run([exe, str(fa), str(tmp_path / "cc")] + argv[3:], check=True)
+    assert open(tmp_path / "cc.bed").read().splitlines()[1:] == bed[1:]
+    assert open(tmp_path / "cc.ctg.summary.tsv").read() == open(tmp_path / "out.ctg.summary.tsv").read()
+    subprocess.run([exe, str(fa), str(tmp_path / "cc2")] + argv[3:] + ["-d", str(fb)], check=True)
+    assert open(tmp_path / "cc2.bed").read().splitlines()[1:] == open(tmp_path / "out2.bed").read().splitlines()[1:]
+    assert open(tmp_path / "cc2.ctg.summary.tsv").read() == open(tmp_path / "out2.ctg.summary.tsv").read()
+    inc = tmp_path / "inc.txt"
+    inc.write_text("hap03\nhap07\n")
+    cli.main(argv[:2] + [str(tmp_path / "out3")] + argv[3:] + ["-i", str(inc)])
+    subprocess.run([exe, str(fa), str(tmp_path / "cc3")] + argv[3:] + ["-i", str(inc)], check=True)
+    assert open(tmp_path / "cc3.bed").read().splitlines()[1:] == open(tmp_path / "out3.bed").read().splitlines()[1:]
+    assert len(open(tmp_path / "cc3.ctg.summary.tsv").read().splitlines()) == 3
+    assert open(tmp_path / "cc3.ctg.summary.tsv").read() == open(tmp_path / "out3.ctg.summary.tsv").read()
 
 
 def test_golden_fixture_graph(oracle, gpu_ctx, golden_dir):
