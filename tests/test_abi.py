@@ -55,3 +55,23 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")) or f == "Makefile":
                 txt = open(os.path.join(d, f), errors="ignore").read()
                 assert "oracle" not in txt.lower() or f == "_never_", os.path.join(d, f)
+
+
+def test_host_programs_built_and_fail_loudly_without_gpu(tmp_path):
+    """the C++ host programs above the C ABI exist (built by __graft_entry__.build / make), print their usage, and --
+    in a container without a GPU -- report the missing device instead of computing anything on the host"""
+    import subprocess
+    import torch
+    bindir = os.path.join(ROOT, "pgr-tk_amd", "bin")
+    for exe in ("pgr-mdb", "pgr-query", "pgr-pbundle-decomp"):
+        path = os.path.join(bindir, exe)
+        assert os.path.exists(path), "build first: python __graft_entry__.py build"
+        r = subprocess.run([path], capture_output=True, text=True)
+        assert r.returncode == 2 and "usage" in r.stderr
+    if torch.cuda.is_available():
+        return
+    lst = tmp_path / "l.txt"
+    lst.write_text("")
+    r = subprocess.run([os.path.join(bindir, "pgr-mdb"), str(lst), str(tmp_path / "x")], capture_output=True, text=True)
+    assert r.returncode == 1 and "pgr_ctx_create failed" in r.stderr
+    assert not os.path.exists(str(tmp_path / "x.mdb"))
