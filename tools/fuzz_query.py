@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Randomised parity campaign for the index / query path (GPU box): random repeat-rich databases, random queries
+(substrings, reverse complements, chimeras, mutated, unrelated), random count filters / span / gap / orientation
+parameters; SeqIndexDB.query_fragments_to_hps compared with the oracle's query_fragment_to_hps, chains and f32 scores
+bit exact.   usage: fuzz_query.py [iterations] [seed0]"""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")]
+import numpy as np  # noqa: E402
+import oracle as O  # noqa: E402
+import pgrtk_amd as P  # noqa: E402
+import seqgen  # noqa: E402
+
+COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def rc(s):
+    return s.translate(COMP)[::-1]
+
+
+def one_case(seed, ctx):
+    rng = np.random.default_rng(seed)
+    spec_t = [(80, 56, 4, 64), (48, 56, 4, 12), (24, 24, 2, 8), (31, 21, 3, 16)][int(rng.integers(0, 4))]
+    cores = [seqgen.rnd(rng, int(rng.integers(2000, 40000))) for _ in range(int(rng.integers(2, 6)))]
+    seqs = []
+    for _ in range(int(rng.integers(2, 14))):
+        parts = [seqgen.rnd(rng, int(rng.integers(0, 20000)))]
+        for j in rng.permutation(len(cores))[: int(rng.integers(1, len(cores) + 1))]:
+            c = cores[j]
+            c = c if rng.random() < 0.6 else rc(c)
+            parts.append(c * int(rng.integers(1, 4)) if rng.random() < 0.2 else c)  # tandem copies
+            parts.append(seqgen.rnd(rng, int(rng.integers(0, 6000))))
+        seqs.append(b"".join(parts))
+    if rng.random() < 0.3:
+        seqs.append(seqs[0])
+    sdb = P.SeqIndexDB(ctx=ctx)
+    sdb.load_from_seq_list([("s%d" % i, s) for i, s in enumerate(seqs)], w=spec_t[0], k=spec_t[1], r=spec_t[2], min_span=spec_t[3])
+    oix = O.Index(O.spec(*spec_t))
+    for i, s in enumerate(seqs):
+        oix.add_seq(i, s)
+    oix.finalize()
+    queries = []
+    for _ in range(int(rng.integers(3, 12))):
+        kind = rng.random()
+        src = seqs[int(rng.integers(0, len(seqs)))]
+        if kind < 0.5 and len(src) > 100:
+            a = int(rng.integers(0, len(src) - 50))
+            q = src[a:a + int(rng.integers(50, 60000))]
+        elif kind < 0.7:
+            q = cores[int(rng.integers(0, len(cores)))] + cores[int(rng.integers(0, len(cores)))]
+        elif kind < 0.8:
+            q = seqgen.rnd(rng, int(rng.integers(0, 5000)))
+        else:
+            q = src
+        if rng.random() < 0.5:
+            q = rc(q)
+        if rng.random() < 0.3 and len(q) > 10:
+            qa = bytearray(q)
+            for p in rng.integers(0, len(qa), max(1, len(qa) // 2000)):
+                qa[p] = b"ACGT"[int(rng.integers(0, 4))]
+            q = bytes(qa)
+        queries.append(q)
+    pen = float(rng.choice([0.025, 0.5, 0.1, 0.0, 1.0]))
+    mc, mq, mt = [int(rng.choice([1, 2, 8, 128, 100000])) for _ in range(3)]
+    span = int(rng.choice([1, 2, 8, 16, 64]))
+    gap = None if rng.random() < 0.6 else int(rng.choice([0, 500, 5000, 100000]))
+    ori = bool(rng.random() < 0.3)
+    got = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
+    n_chains = 0
+    for qi, q in enumerate(queries):
+        try:
+            ref = oix.query_fragment_to_hps(q, pen, mc, mq, mt, span, gap, ori)
+        except RuntimeError:
+            continue  # the reference would not terminate on this input (cyclic predecessor map)
+        ref = [(sid, [(sc, [((h[0], h[1], h[2]), (h[3], h[4], h[5])) for h in hps]) for sc, hps in chains]) for sid, chains in ref]
+        if ref != got[qi]:
+            return "seed %d: spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s query %d (len %d)" % (
+                seed, spec_t, pen, mc, mq, mt, span, gap, ori, qi, len(q))
+        n_chains += sum(len(c) for _, c in ref)
+    sdb.close()
+    return None, n_chains
+
+
+def main():
+    iters = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    ctx = P.default_context(0)
+    fails, chains = [], 0
+    t0 = time.time()
+    for it in range(iters):
+        r = one_case(seed0 + it, ctx)
+        if isinstance(r, str):
+            fails.append(r)
+            print("FAIL", r, flush=True)
+        else:
+            chains += r[1]
+    print("fuzz_query: %d cases (seeds %d..%d), %d chains compared, %d failures, %.0f s" % (iters, seed0, seed0 + iters - 1, chains,
+                                                                                         len(fails), time.time() - t0))
+    sys.exit(1 if fails else 0)
+
+
+if __name__ == "__main__":
+    main()
