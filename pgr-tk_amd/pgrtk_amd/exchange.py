@@ -43,7 +43,9 @@ class PendingAllgather:
     """an all-gather of one rank-local record tensor in flight (collective on the process group's own
     stream, so the next batch's kernels overlap with it); wait() returns (gathered, counts)."""
 
-    def __init__(self, local, group=None):
+    def __init__(self, local, group=None, out=None):
+        """out: optional preallocated [>= world * n_max, words] tensor to gather into (callers that exchange every
+        step keep two and alternate, so the steady state allocates nothing)"""
         world = dist.get_world_size(group)
         assert local.dtype == torch.int64 and local.dim() == 2
         words = local.shape[1]
@@ -62,7 +64,11 @@ class PendingAllgather:
                 padded = local.new_zeros((self.n_max, words))
                 padded[: local.shape[0]] = local
             self.padded = padded
-            self.out = local.new_empty((world * self.n_max, words))
+            if out is not None and out.shape[0] >= world * self.n_max and out.shape[1] == words and out.dtype == local.dtype \
+                    and out.device == local.device:
+                self.out = out[: world * self.n_max]
+            else:
+                self.out = local.new_empty((world * self.n_max, words))
             self.work = dist.all_gather_into_tensor(self.out, padded, group=group, async_op=True)
 
     def wait(self):
