@@ -9,5 +9,6 @@ from .engine import (Batch, Index, Shmmrs, frag_recs_batch, make_spec, sequence_
                      sequence_to_shmmrs_batch)
 from .seqindexdb import SeqIndexDB, get_shmmr_pairs_from_seq, read_fastx, sparse_aln  # noqa: F401
 from . import cli, mapgraph  # noqa: F401
+from .helpers import merge_regions, query_sdb, string_to_u8, u8_to_string  # noqa: F401
 
 __version__ = "0.1.0"

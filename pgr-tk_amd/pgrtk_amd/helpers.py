@@ -1,0 +1,69 @@
+"""Python-level helpers of the reference package that sit on top of SeqIndexDB.query_fragment_to_hps
+(pgr-tk/pgrtk/__init__.py: string_to_u8 / u8_to_string :93-127, query_sdb :130-221, merge_regions :270-328).
+Host logic only; pinned on vectors generated from the reference's own functions (tests/golden/query_sdb_cases.json).
+"""
+
+
+def string_to_u8(s):
+    """DNA string -> list of byte values"""
+    return list(s.encode("utf-8"))
+
+
+def u8_to_string(u8):
+    """list of byte values -> DNA string"""
+    return bytes(u8).decode("utf-8")
+
+
+def merge_regions(rgns, tol=1000):
+    """rgns: [(bgn, end, length, orientation, aln_records)].  Sorted, then per orientation a region that starts less
+    than `tol` after the END of the current merged region is folded into it (its end replaces the end, lengths and
+    records add up); a region ending before the current end is dropped.  Returns forward regions, then reverse ones,
+    as lists."""
+    out = []
+    ordered = sorted(rgns)
+    for orientation in (0, 1):
+        group = []
+        for r in ordered:
+            if r[3] != orientation:
+                continue
+            r = list(r)
+            if not group:
+                group.append(r)
+                continue
+            cur = group[-1]
+            if r[1] < cur[1]:
+                continue
+            if r[0] - cur[1] < tol:
+                cur[1] = r[1]
+                cur[2] += r[2]
+                cur[4] += r[4]
+            else:
+                group.append(r)
+        out += group
+    return out
+
+
+def query_sdb(seq_index_db, query_seq, gap_penalty_factor=0.25, merge_range_tol=12, max_count=128, max_query_count=128,
+              max_target_count=128, max_aln_span=8):
+    """{target sid: [(start, end, length, orientation, hit pairs)]} for one query: chains with more than two hit
+    pairs, orientation by the running forward / reverse vote of the target (the counters are not reset between the
+    chains of a target, as in the reference), regions merged with merge_regions when merge_range_tol > 0."""
+    res = seq_index_db.query_fragment_to_hps(query_seq, gap_penalty_factor, max_count, max_query_count, max_target_count,
+                                             max_aln_span)
+    ranges = {}
+    for sid, chains in res:
+        fwd = rev = 0
+        for _score, aln in chains:
+            if len(aln) <= 2:
+                continue
+            same = sum(1 for hp in aln if hp[0][2] == hp[1][2])
+            fwd += same
+            rev += len(aln) - same
+            first = min((hp[1][0], hp[1][1]) for hp in aln)
+            last = max((hp[1][0], hp[1][1]) for hp in aln)
+            bgn, end = min(first), max(last)
+            ranges.setdefault(sid, []).append((bgn, end, end - bgn, 0 if fwd > rev else 1, aln))
+    if merge_range_tol > 0:
+        for sid in ranges:
+            ranges[sid] = merge_regions(ranges[sid], tol=merge_range_tol)
+    return ranges

@@ -32,3 +32,39 @@ def test_chains_to_regions_merge_and_quirks():
 def test_reverse_complement():
     from pgrtk_amd.cli import reverse_complement
     assert reverse_complement(b"ACGTNacgt") == b"acgtNACGT"
+
+
+def _norm(x):
+    """JSON round trip: tuples become lists"""
+    if isinstance(x, (list, tuple)):
+        return [_norm(v) for v in x]
+    return x
+
+
+def test_query_sdb_and_merge_regions_golden():
+    """pgrtk.query_sdb / merge_regions (pgr-tk/pgrtk/__init__.py:130-221, 270-328): vectors generated from the
+    reference's own functions by tests/golden/make_query_sdb_fixture.py"""
+    import json
+    import pgrtk_amd as P
+    cases = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "query_sdb_cases.json")))
+    assert len(cases["merge_regions"]) == 60 and len(cases["query_sdb"]) == 40
+    for c in cases["merge_regions"]:
+        rgns = [(r[0], r[1], r[2], r[3], list(r[4])) for r in c["rgns"]]
+        assert _norm(P.merge_regions(rgns, tol=c["tol"])) == c["out"]
+
+    class Canned:
+        def __init__(self, r):
+            self.r = r
+
+        def query_fragment_to_hps(self, *a):
+            return self.r
+
+    n_regions = 0
+    for c in cases["query_sdb"]:
+        r = [(sid, [(sc, [((h[0][0], h[0][1], h[0][2]), (h[1][0], h[1][1], h[1][2])) for h in aln]) for sc, aln in alns])
+             for sid, alns in c["r"]]
+        got = P.query_sdb(Canned(r), b"ACGT", merge_range_tol=c["tol"])
+        assert _norm([[sid, v] for sid, v in got.items()]) == c["out"]
+        n_regions += sum(len(v) for v in got.values())
+    assert n_regions > 40
+    assert P.u8_to_string(P.string_to_u8("ACGTN")) == "ACGTN"
