@@ -4,6 +4,31 @@ Host logic only; pinned on vectors generated from the reference's own functions 
 """
 
 
+# byte complement table (pgrtk/__init__.py:36-37) and the string one (:75), whose lower-case half pairs
+# a->t, c->g, t->c, g->a in the reference: kept as is, the golden vectors pin it
+_BYTE_RC = dict(zip(b"ACGTNnacgt", b"TGCANntgca"))
+_STR_RC = dict(zip("ACGTNnactg", "TGCANntgca"))
+
+
+def rc_byte_seq(seq):
+    """reverse complement of a sequence given as a list of byte values"""
+    return [_BYTE_RC[b] for b in reversed(seq)]
+
+
+rc_u8_seq = rc_byte_seq
+
+
+def rc(seq):
+    """reverse complement of a sequence given as a str"""
+    return "".join(_STR_RC[c] for c in reversed(seq))
+
+
+def group_smps_by_principle_bundle_id(smps, len_cutoff=2500, merge_length=5000):
+    """pgrtk/__init__.py:391-467 (the Python twin of pgr-pbundle-decomp.rs:61-137)"""
+    from .cli import group_smps_by_principle_bundle_id as g
+    return g(smps, len_cutoff, merge_length)
+
+
 def string_to_u8(s):
     """DNA string -> list of byte values"""
     return list(s.encode("utf-8"))

@@ -57,7 +57,9 @@ def random_chains(rng, n_targets):
 
 
 def main():
-    ns = load_functions({"merge_regions", "query_sdb"})
+    ns = load_functions({"merge_regions", "query_sdb", "group_smps_by_principle_bundle_id", "rc", "rc_byte_seq"})
+    ns["rc_map"] = dict(zip("ACGTNnactg", "TGCANntgca"))           # module-level tables of the reference (:36-37, :75)
+    ns["byte_rc_map"] = dict(zip([ord(c) for c in "ACGTNnacgt"], [ord(c) for c in "TGCANntgca"]))
     rng = random.Random(20240917)
     merge_cases = []
     for _ in range(60):
@@ -75,9 +77,29 @@ def main():
         tol = rng.choice([0, 12, 1000, 100000])
         got = ns["query_sdb"](CannedDB(copy.deepcopy(r)), b"ACGT", merge_range_tol=tol)
         sdb_cases.append({"r": r, "tol": tol, "out": [[sid, v] for sid, v in got.items()]})
+    group_cases = []
+    for _ in range(60):
+        smps, pos = [], rng.randrange(0, 1000)
+        bid, d_run = rng.randrange(6), rng.randrange(2)
+        for _ in range(rng.randrange(0, 60)):
+            if rng.random() < 0.25:
+                bid, d_run = rng.randrange(6), rng.randrange(2)
+            ln = rng.randrange(30, 900)
+            o = rng.randrange(2)
+            smp = (rng.getrandbits(50), rng.getrandbits(50), pos, pos + ln, o)
+            info = None if rng.random() < 0.15 else (bid, o if d_run == 0 else 1 - o, rng.randrange(500))
+            smps.append((smp, info))
+            pos += ln + (rng.randrange(0, 12000) if rng.random() < 0.1 else 0)
+        cutoff, merge = rng.choice([0, 50, 500, 2500]), rng.choice([0, 100, 5000, 100000])
+        got = ns["group_smps_by_principle_bundle_id"](copy.deepcopy(smps), cutoff, merge)
+        group_cases.append({"smps": smps, "len_cutoff": cutoff, "merge_length": merge, "out": got})
+    rc_cases = []
+    for _ in range(10):
+        sq = "".join(rng.choice("ACGTNnacgt") for _ in range(rng.randrange(0, 60)))
+        rc_cases.append({"seq": sq, "rc": ns["rc"](sq), "rc_bytes": ns["rc_byte_seq"](list(sq.encode()))})
     with open(os.path.join(HERE, "query_sdb_cases.json"), "w") as f:
-        json.dump({"merge_regions": merge_cases, "query_sdb": sdb_cases}, f)
-    print(len(merge_cases), "merge_regions cases,", len(sdb_cases), "query_sdb cases")
+        json.dump({"merge_regions": merge_cases, "query_sdb": sdb_cases, "group_smps": group_cases, "rc": rc_cases}, f)
+    print(len(merge_cases), "merge_regions cases,", len(sdb_cases), "query_sdb cases,", len(group_cases), "group_smps cases")
 
 
 if __name__ == "__main__":

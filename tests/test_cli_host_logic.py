@@ -68,3 +68,18 @@ def test_query_sdb_and_merge_regions_golden():
         n_regions += sum(len(v) for v in got.values())
     assert n_regions > 40
     assert P.u8_to_string(P.string_to_u8("ACGTN")) == "ACGTN"
+    # group_smps_by_principle_bundle_id (:391-467): the product's and the oracle's restatements against the
+    # reference's own function
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mapgraph as og
+    n_parts = 0
+    for c in cases["group_smps"]:
+        smps = [((s[0][0], s[0][1], s[0][2], s[0][3], s[0][4]), None if s[1] is None else (s[1][0], s[1][1], s[1][2]))
+                for s in c["smps"]]
+        got = P.group_smps_by_principle_bundle_id(smps, c["len_cutoff"], c["merge_length"])
+        assert _norm(got) == c["out"]
+        assert _norm(og.group_smps_by_principle_bundle_id(smps, c["len_cutoff"], c["merge_length"])) == c["out"]
+        n_parts += len(got)
+    assert n_parts > 60
+    for c in cases["rc"]:
+        assert P.rc(c["seq"]) == c["rc"] and P.rc_byte_seq(list(c["seq"].encode())) == c["rc_bytes"]
