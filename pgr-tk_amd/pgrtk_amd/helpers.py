@@ -92,3 +92,22 @@ def query_sdb(seq_index_db, query_seq, gap_penalty_factor=0.25, merge_range_tol=
         for sid in ranges:
             ranges[sid] = merge_regions(ranges[sid], tol=merge_range_tol)
     return ranges
+
+
+def get_principle_bundle_bed_file_for_query(seqs, w=64, k=56, r=4, min_span=32, min_cov=2, min_branch_length=8, ctx=None):
+    """pgrtk/__init__.py:470-508: principal-bundle layout of a set of hit sequences whose names end in
+    `_<bgn>_<end>_<direction>` (the names pgr-query / query_sdb give to fetched regions): [(ctg, bgn, end,
+    "bundle:direction:first_pos:last_pos")] in contig-name order, partitions of a contig from last to first."""
+    from .seqindexdb import SeqIndexDB
+    sdb = SeqIndexDB(ctx=ctx)
+    sdb.load_from_seq_list(seqs, "memory", w, k, r, min_span)
+    _bundles, sid_smps = sdb.get_principal_bundle_decomposition(min_cov, min_branch_length)
+    sid_smps = dict(sid_smps)
+    layout = []
+    for sid, (ctg, _src, _len) in sorted(sdb.seq_info.items(), key=lambda kv: kv[1][0]):
+        ctg_bgn = int(ctg.split("_")[-3])
+        for p in reversed(group_smps_by_principle_bundle_id(sid_smps[sid], 50, 100000)):
+            layout.append((ctg, ctg_bgn + p[0][0][2], ctg_bgn + p[-1][0][3] + k,
+                           "{}:{}:{}:{}".format(p[0][1], p[0][2], p[0][3], p[-1][3])))
+    sdb.close()
+    return layout

@@ -263,3 +263,21 @@ def test_golden_fixture_graph(oracle, gpu_ctx, golden_dir):
         got_with_id, got_dec = sdb.get_principal_bundle_decomposition(mc, cutoff)
         assert got_with_id == with_id
         assert got_dec == og.get_principal_bundle_decomposition(vmap, smps)
+
+
+def test_bundle_bed_for_query_helper(oracle, gpu_ctx):
+    """pgrtk.get_principle_bundle_bed_file_for_query (pgrtk/__init__.py:470-508) composed from the oracle's pieces"""
+    import mapgraph as og
+    import pgrtk_amd as P
+    haps = seqgen.amy1a_like(seed=12, n_hap=7, L=40_000, unit=3000)
+    spec_t = (24, 24, 2, 8)
+    names = ["src::ctg%d_%d_%d_%d" % (6 - i, 1000 * i, 1000 * i + len(h), i % 2) for i, h in enumerate(haps)]
+    got = P.get_principle_bundle_bed_file_for_query(list(zip(names, haps)), 24, 24, 2, 8, 2, 3, ctx=gpu_ctx)
+    _, fm, smps = _oracle_side(oracle, haps, spec_t)
+    with_id, vmap = og.get_principal_bundles_with_id(fm, smps, 2, 3)
+    dec = dict(og.get_principal_bundle_decomposition(vmap, smps))
+    ref = []
+    for sid in sorted(range(len(haps)), key=lambda i: names[i]):
+        for p in reversed(og.group_smps_by_principle_bundle_id(dec[sid], 50, 100000)):
+            ref.append((names[sid], 1000 * sid + p[0][0][2], 1000 * sid + p[-1][0][3] + 24, "%d:%d:%d:%d" % (p[0][1], p[0][2], p[0][3], p[-1][3])))
+    assert got == ref and len(ref) >= len(haps)
