@@ -99,6 +99,24 @@ def get_shmmr_pairs_from_seq(seq, w=80, k=56, r=4, min_span=16, padding=False, c
     return out
 
 
+def get_shmmr_dots(seq0, seq1, w=80, k=56, r=4, min_span=16, ctx=None):
+    """lib.rs:1649-1697: shimmer matches between two sequences for a dot plot: (x, y) = positions in seq0 / seq1 of
+    every pair of shimmers with the same hash, ordered by seq1 position, then by seq0 position"""
+    from .engine import sequence_to_shmmrs_batch
+    a, b = sequence_to_shmmrs_batch([seq0, seq1], make_spec(w, k, r, min_span, False), ctx=ctx or default_context())
+    ha, pa = a["x"] >> np.uint64(8), ((a["y"] & np.uint64(0xFFFFFFFF)) >> np.uint64(1)).astype(np.uint32)
+    hb, pb = b["x"] >> np.uint64(8), ((b["y"] & np.uint64(0xFFFFFFFF)) >> np.uint64(1)).astype(np.uint32)
+    by_hash = {}
+    for h, p in zip(ha.tolist(), pa.tolist()):
+        by_hash.setdefault(h, []).append(p)
+    x, y = [], []
+    for h, p in zip(hb.tolist(), pb.tolist()):
+        for px in by_hash.get(h, ()):
+            x.append(px)
+            y.append(p)
+    return x, y
+
+
 class SeqIndexDB:
     """FASTX / MEMORY backends of the reference's SeqIndexDB (pgr-db/src/ext.rs:152-249)."""
 
@@ -230,6 +248,17 @@ class SeqIndexDB:
         _, keys = self._records()
         s, e = keys.get((int(shmmr_pair[0]), int(shmmr_pair[1])), (0, 0))
         return e - s
+
+    def get_shmmr_pair_source_count(self, shmmr_pair, max_unique_count=None):
+        """lib.rs:669-727: [(source name, count)] of the pair's fragment signatures per source file, sources with
+        count >= max_unique_count dropped (order unspecified in the reference; sorted here)"""
+        recs, keys = self._records()
+        s, e = keys.get((int(shmmr_pair[0]), int(shmmr_pair[1])), (0, 0))
+        count = {}
+        for sid in recs["sid"][s:e].tolist():
+            src = self.seq_info[sid][1] or ""
+            count[src] = count.get(src, 0) + 1
+        return sorted((k, v) for k, v in count.items() if max_unique_count is None or v < max_unique_count)
 
     # ------------------------------------------------------------------ queries
     def query_fragment(self, seq):

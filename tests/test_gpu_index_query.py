@@ -259,6 +259,38 @@ def test_get_shmmr_pairs_from_seq(oracle, gpu_ctx):
         assert got == [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in ref]
 
 
+def test_shmmr_dots_and_source_count(oracle, gpu_ctx, golden_dir, tmp_path):
+    """get_shmmr_dots (lib.rs:1649-1697) and get_shmmr_pair_source_count (lib.rs:669-727) from oracle shimmers"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(8)
+    a = seqgen.rnd(rng, 30000)
+    b = a[5000:20000] + revcomp(a[1000:9000]) + seqgen.rnd(rng, 4000) + a[5000:9000]
+    for (w, k, r, ms) in [(80, 56, 4, 16), (24, 24, 2, 8)]:
+        x, y = P.get_shmmr_dots(a, b, w, k, r, ms, ctx=gpu_ctx)
+        sp = oracle.spec(w, k, r, ms)
+        s0, s1 = oracle.sequence_to_shmmrs(0, a, sp), oracle.sequence_to_shmmrs(1, b, sp)
+        base = {}
+        for m in s0:
+            base.setdefault(int(m["x"]) >> 8, []).append((int(m["y"]) & 0xFFFFFFFF) >> 1)
+        rx, ry = [], []
+        for m in s1:
+            for px in base.get(int(m["x"]) >> 8, ()):
+                rx.append(px)
+                ry.append((int(m["y"]) & 0xFFFFFFFF) >> 1)
+        assert (x, y) == (rx, ry) and len(x) > 20
+    # two FASTA sources with shared content
+    f1, f2 = tmp_path / "one.fa", tmp_path / "two.fa"
+    f1.write_text(">a\n%s\n>b\n%s\n" % (a.decode(), a[2000:25000].decode()))
+    f2.write_text(">c\n%s\n" % a[:28000].decode())
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_fastx(str(f1))
+    sdb.append_from_fastx(str(f2))
+    key = next(k for k, v in sdb.get_shmmr_map().items() if len(v) == 3)
+    assert sdb.get_shmmr_pair_source_count(key) == sorted([(str(f1), 2), (str(f2), 1)])
+    assert sdb.get_shmmr_pair_source_count(key, 2) == [(str(f2), 1)]
+    assert sdb.get_shmmr_pair_source_count((1, 2)) == []
+
+
 def test_cli_mdb_and_query(oracle, gpu_ctx, golden_dir, tmp_path):
     """pgr-mdb / pgr-query counterparts end to end: index-only .mdb (per-contig fragment ids) == the golden
     frag_map after undoing the FASTX-backend renumbering; the index file round-trips through the GPU; a query
