@@ -636,7 +636,20 @@ struct AlnWaveLds {
     int sl[NMAX];
     int pv[NMAX];
     uint32_t span_q[MAX_SPAN_CAP][3];
+    uint32_t cand[4][64];  // qb, qe, qo, considered-flag of the 64 candidates of the current look-back batch
 };
+
+// maximum over the wavefront (DPP row shifts + row broadcasts; lanes without a source see -inf)
+__device__ __forceinline__ float wave_max_f32(float v) {
+    const int ninf = __float_as_int(-INFINITY);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x111, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x112, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x114, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x118, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x142, 0xa, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x143, 0xc, 0xf, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
 
 __device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders LDS and global accesses of the wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -647,43 +660,76 @@ __device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders 
 template <int NMAX>
 __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
     const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start, const uint32_t *__restrict__ big_list,
-    const uint32_t *__restrict__ n_big, AlnParams prm, float *v_s, int *pre, int *slot, pgr_hitpair *out_hp,
+    const uint32_t *__restrict__ n_big, AlnParams prm, float *v_s, int *pre, int *slot, int *track, pgr_hitpair *out_hp,
     uint32_t *__restrict__ chain_len, float *__restrict__ chain_score, uint32_t *__restrict__ g_nchains,
     uint32_t *__restrict__ g_nhp, uint32_t *__restrict__ err) {
+    static_assert(NMAX % 64 == 0, "the LDS image is also used as a ring of 64-hit blocks");
     __shared__ AlnWaveLds<NMAX> L;
     if (blockIdx.x >= *n_big) return;
     const uint32_t g = big_list[blockIdx.x];
     const uint64_t gs = g_start[g];
     const int n = (int)(g_start[g + 1] - gs);
     const int lane = (int)threadIdx.x;
+    // in_lds: the whole group lives in LDS.  Otherwise the arrays stay in global memory and LDS is a RING over the
+    // last NMAX hits (blocks of 64 are loaded as the DP reaches them): the look-back of a hit almost always stays
+    // inside it; index k is in the ring iff k >= ring_lo.
     const bool in_lds = n <= NMAX;
-    const pgr_hitpair *h = hp + gs;
-    float *vs = v_s + gs;
-    int *sl = slot + gs, *pv = pre + gs;
-    if (in_lds) {
-        for (int i = lane; i < n; i += 64) L.h[i] = hp[gs + i];
-        h = L.h;
-        vs = L.vs;
-        sl = L.sl;
-        pv = L.pv;
-    }
+    const pgr_hitpair *gh = hp + gs;
+    float *gvs = v_s + gs;
+    int *gsl = slot + gs, *gpv = pre + gs, *gtrack = track + gs;
+    int ring_lo = 0;
+    auto H = [&](int k) -> pgr_hitpair { return (in_lds || k >= ring_lo) ? L.h[in_lds ? k : k % NMAX] : gh[k]; };
+    auto SL = [&](int k) -> int { return (in_lds || k >= ring_lo) ? L.sl[in_lds ? k : k % NMAX] : gsl[k]; };
+    auto VS = [&](int k) -> float { return (in_lds || k >= ring_lo) ? L.vs[in_lds ? k : k % NMAX] : gvs[k]; };
+    auto load_block = [&](int blk) {  // hits [blk, blk + 64) -> ring; everything below blk + 64 - NMAX drops out
+        const int k = blk + lane;
+        if (k < n) {
+            L.h[k % NMAX] = gh[k];
+            L.sl[k % NMAX] = gsl[k];
+        }
+        ring_lo = blk + 64 > NMAX ? blk + 64 - NMAX : 0;
+    };
+
+    if (in_lds)
+        for (int i = lane; i < n; i += 64) L.h[i] = gh[i];
     wave_sync();
     // value slots: the earliest identical hit pair of the (equal qb) run
     for (int i = lane; i < n; i += 64) {
         int s = i;
-        const pgr_hitpair hi = h[i];
-        for (int j = i - 1; j >= 0 && h[j].qb == hi.qb; --j)
-            if (same_hp(h[j], hi)) s = j;
-        sl[i] = s;
+        const pgr_hitpair hi = in_lds ? L.h[i] : gh[i];
+        for (int j = i - 1; j >= 0; --j) {
+            const pgr_hitpair hj = in_lds ? L.h[j] : gh[j];
+            if (hj.qb != hi.qb) break;
+            if (same_hp(hj, hi)) s = j;
+        }
+        if (in_lds) L.sl[i] = s;
+        else gsl[i] = s;
     }
     wave_sync();
-    if (lane == 0) {
-        vs[sl[0]] = (float)h[0].qe - (float)h[0].qb;  // aln.rs:25-27
-        pv[sl[0]] = -1;
+    if (!in_lds) {
+        load_block(0);
+        wave_sync();
+    }
+    if (lane == 0) {  // aln.rs:25-27
+        const pgr_hitpair h0 = H(0);
+        const int s0 = SL(0);
+        const float v0 = (float)h0.qe - (float)h0.qb;
+        if (in_lds) {
+            L.vs[s0] = v0;
+            L.pv[s0] = -1;
+        } else {
+            L.vs[s0 % NMAX] = v0;
+            gvs[s0] = v0;
+            gpv[s0] = -1;
+        }
     }
     wave_sync();
     for (int i = 1; i < n; ++i) {  // aln.rs:29-103
-        const pgr_hitpair cur = h[i];
+        if (!in_lds && (i & 63) == 0) {
+            load_block(i);
+            wave_sync();
+        }
+        const pgr_hitpair cur = H(i);
         const float cur_len = (float)cur.qe - (float)cur.qb;
         float best_s = 0.0f;
         int best_v = -1;
@@ -692,7 +738,7 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
         for (int jb = i - 1; jb >= 0 && !stop; jb -= 64) {
             const int j = jb - lane;
             bool cons = j >= 0;
-            const pgr_hitpair p = cons ? h[j] : cur;
+            const pgr_hitpair p = cons ? H(j) : cur;
             float a = 0.0f, b = 0.0f;
             if (cons) {
                 if (prm.oriented && ((p.qo ^ p.to) != (cur.qo ^ cur.to))) cons = false;  // :43-50
@@ -708,79 +754,90 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
             }
             const uint64_t cm = __ballot(cons);
             if (!cm) continue;
-            // span_set (:70, :91) in candidate order: intervals already seen in earlier batches, then new ones
-            uint64_t rem = cm;
-            for (uint32_t t = 0; t < span_n; ++t) {
-                const uint32_t q0 = L.span_q[t][0], q1 = L.span_q[t][1], q2 = L.span_q[t][2];
-                rem &= ~__ballot(cons && p.qb == q0 && p.qe == q1 && p.qo == q2);
+            // span_set (:70, :91) in candidate order, lane parallel.  A candidate opens a new distinct query interval
+            // unless an earlier batch (span_q) or an earlier considered lane of this batch has the same interval;
+            // equal intervals share their qb, and the candidates are sorted by qb, so the lanes to look at are the
+            // run of equal qb right before this lane.
+            L.cand[0][lane] = p.qb;
+            L.cand[1][lane] = p.qe;
+            L.cand[2][lane] = p.qo;
+            L.cand[3][lane] = cons ? 1u : 0u;
+            wave_sync();
+            bool fresh = cons;
+            for (uint32_t t = 0; t < span_n; ++t)  // only in the second and later batches of a look-back
+                if (p.qb == L.span_q[t][0] && p.qe == L.span_q[t][1] && p.qo == L.span_q[t][2]) fresh = false;
+            if (fresh)
+                for (int l = lane - 1; l >= 0 && L.cand[0][l] == p.qb; --l)
+                    if (L.cand[3][l] && L.cand[1][l] == p.qe && L.cand[2][l] == p.qo) {
+                        fresh = false;
+                        break;
+                    }
+            const uint64_t lt = lane ? (U64MAX >> (64 - lane)) : 0ull;
+            const uint64_t nm = __ballot(fresh);
+            const uint32_t before = (uint32_t)__popcll(nm & lt);  // distinct intervals opened by earlier lanes
+            const uint32_t need = prm.max_span - span_n;           // >= 1: the look-back has not stopped yet
+            const uint64_t sm = __ballot(fresh && before + 1 == need);
+            const int stop_lane = sm ? __builtin_ctzll(sm) : 64;  // the candidate completing the span set is scored
+            if (fresh && lane <= stop_lane) {
+                L.span_q[span_n + before][0] = p.qb;
+                L.span_q[span_n + before][1] = p.qe;
+                L.span_q[span_n + before][2] = p.qo;
             }
-            int stop_lane = 64;
-            while (rem) {
-                const int l0 = __builtin_ctzll(rem);
-                const uint32_t q0 = (uint32_t)__builtin_amdgcn_readlane((int)p.qb, l0);
-                const uint32_t q1 = (uint32_t)__builtin_amdgcn_readlane((int)p.qe, l0);
-                const uint32_t q2 = (uint32_t)__builtin_amdgcn_readlane((int)p.qo, l0);
-                if (lane == 0) {
-                    L.span_q[span_n][0] = q0;
-                    L.span_q[span_n][1] = q1;
-                    L.span_q[span_n][2] = q2;
-                }
-                ++span_n;
-                rem &= ~__ballot(cons && p.qb == q0 && p.qe == q1 && p.qo == q2);
-                if (span_n >= prm.max_span) {  // the candidate that completes the span set is still scored
-                    stop_lane = l0;
-                    break;
-                }
-            }
-            wave_sync();  // span_q is read back by every lane in the next batch
+            span_n += (uint32_t)__popcll(stop_lane < 63 ? nm & (U64MAX >> (63 - stop_lane)) : nm);
+            wave_sync();  // span_q is read back in the next batch
             const bool proc = cons && lane <= stop_lane;
-            float s = 0.0f;
+            float s = -INFINITY;
             int slj = 0;
             if (proc) {
-                slj = sl[j];
-                const float p_s = vs[slj];      // :71
+                slj = SL(j);
+                const float p_s = VS(slj);      // :71
                 s = p_s + cur_len;              // :72
                 const float sum = a + b;        // :74-84
                 const float pen = prm.penalty * sum;
                 s = s - pen;
             }
-            uint64_t pm = __ballot(proc);
-            while (pm) {  // strict >, candidates in look-back order (:86-89)
-                const int l = __builtin_ctzll(pm);
-                pm &= pm - 1;
-                const float s_l = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(s), l));
-                if (s_l > best_s) {
-                    best_s = s_l;
-                    best_v = __builtin_amdgcn_readlane(slj, l);
-                }
+            // strict >, candidates in look-back order (:86-89): the batch maximum replaces the running best only
+            // when strictly larger; among equal maxima the first lane (= nearest candidate) wins
+            const float m = wave_max_f32(s);
+            if (m > best_s) {
+                const int l = __builtin_ctzll(__ballot(proc && s == m));
+                best_s = m;
+                best_v = __builtin_amdgcn_readlane(slj, l);
             }
             if (stop_lane < 64) stop = true;
         }
         if (lane == 0) {  // :96-102
-            const int si = sl[i];
-            if (best_s > 0.0f) {
-                vs[si] = best_s;
-                pv[si] = best_v;
+            const int si = SL(i);
+            const float v = best_s > 0.0f ? best_s : cur_len;
+            const int pvv = best_s > 0.0f ? best_v : -1;
+            if (in_lds) {
+                L.vs[si] = v;
+                L.pv[si] = pvv;
             } else {
-                vs[si] = cur_len;
-                pv[si] = -1;
+                if (si >= ring_lo) L.vs[si % NMAX] = v;
+                gvs[si] = v;
+                gpv[si] = pvv;
             }
         }
         wave_sync();
     }
-    // extraction (aln.rs:105-140); a visited value slot is marked by sl[v] = -1 - v
+    // extraction (aln.rs:105-140); a visited value slot is marked by sl[v] = -1 - v.  From here on the global-mode
+    // arrays are read from global memory (the ring is no longer meaningful).
+    const float *xvs = in_lds ? L.vs : gvs;
+    int *xsl = in_lds ? L.sl : gsl;
+    const int *xpv = in_lds ? L.pv : gpv;
     int n_unvisited = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
-        n_unvisited += (int)__popcll(__ballot(i < n && sl[i] == i));
+        n_unvisited += (int)__popcll(__ballot(i < n && xsl[i] == i));
     }
     uint32_t n_ch = 0, n_out = 0;
     while (n_unvisited > 0) {
         float bs = 0.0f;
         int bv = -1;
         for (int i = lane; i < n; i += 64)
-            if (sl[i] == i && vs[i] > bs) {  // strict >: the lowest index of this lane's maxima
-                bs = vs[i];
+            if (xsl[i] == i && xvs[i] > bs) {  // strict >: the lowest index of this lane's maxima
+                bs = xvs[i];
                 bv = i;
             }
         for (int off = 32; off; off >>= 1) {  // wave arg-max: highest score, ties to the lowest sorted index
@@ -796,28 +853,55 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
             break;
         }
         int len = 0, first_v = bv;
-        if (lane == 0) {
-            int v = bv;
-            while (v >= 0 && sl[v] == v) {  // :121-128
-                out_hp[gs + n_out + len] = h[v];
+        if (in_lds) {
+            if (lane == 0) {
+                int v = bv;
+                while (v >= 0 && L.sl[v] == v) {  // :121-128
+                    out_hp[gs + n_out + len] = L.h[v];
+                    ++len;
+                    first_v = v;
+                    const int nv = L.pv[v];
+                    L.sl[v] = -1 - v;  // :133-137
+                    v = nv;
+                }
+            }
+            len = __builtin_amdgcn_readfirstlane(len);
+            first_v = __builtin_amdgcn_readfirstlane(first_v);
+            wave_sync();
+            for (int a = lane; a < len / 2; a += 64) {  // :132 reverse
+                const pgr_hitpair t = out_hp[gs + n_out + a];
+                out_hp[gs + n_out + a] = out_hp[gs + n_out + len - 1 - a];
+                out_hp[gs + n_out + len - 1 - a] = t;
+            }
+        } else {
+            // the walk is a pointer chase (a serial thread pays a memory round trip per step): predecessors are
+            // almost always a few positions back, so the wave keeps 64 consecutive (pv, sl) entries in registers
+            // and steps through them with readlane; visited indices go to `track`, the hit pairs are gathered in
+            // parallel afterwards (already in reversed = chain order)
+            int v = bv, base = -1, pvb = -1, slb = -2;
+            while (v >= 0) {
+                if (base < 0 || v < base || v >= base + 64) {
+                    base = v >= 63 ? v - 63 : 0;
+                    const int k = base + lane;
+                    pvb = k < n ? gpv[k] : -1;
+                    slb = k < n ? gsl[k] : -2;
+                }
+                const int o = v - base;
+                if (__builtin_amdgcn_readlane(slb, o) != v) break;  // :121-128: stop at a visited node
+                if (lane == 0) {
+                    gtrack[len] = v;
+                    gsl[v] = -1 - v;  // :133-137
+                }
                 ++len;
                 first_v = v;
-                const int nv = pv[v];
-                sl[v] = -1 - v;  // :133-137
-                v = nv;
+                v = __builtin_amdgcn_readlane(pvb, o);
             }
-        }
-        len = __builtin_amdgcn_readfirstlane(len);
-        first_v = __builtin_amdgcn_readfirstlane(first_v);
-        wave_sync();
-        for (int a = lane; a < len / 2; a += 64) {  // :132 reverse
-            const pgr_hitpair t = out_hp[gs + n_out + a];
-            out_hp[gs + n_out + a] = out_hp[gs + n_out + len - 1 - a];
-            out_hp[gs + n_out + len - 1 - a] = t;
+            wave_sync();
+            for (int a = lane; a < len; a += 64) out_hp[gs + n_out + (len - 1 - a)] = gh[gtrack[a]];  // :132
         }
         if (lane == 0) {
             chain_len[gs + n_ch] = (uint32_t)len;
-            chain_score[gs + n_ch] = bs - vs[first_v];  // :138-139
+            chain_score[gs + n_ch] = bs - xvs[first_v];  // :138-139
         }
         ++n_ch;
         n_out += (uint32_t)len;
@@ -876,12 +960,13 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     if ((rc = gstart.alloc((n_groups + 1) * 8))) return rc;
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(), rank.as<uint64_t>(),
                        n, gstart.as<uint64_t>());
-    Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx), big(ctx);
+    Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx), big(ctx),
+        trk(ctx);
     const uint64_t max_big = n / ALN_WAVE_MIN + 1;  // a wave-chained group has at least ALN_WAVE_MIN hits
     if ((rc = v_s.alloc(n * 4)) || (rc = pre.alloc(n * 4)) || (rc = slot.alloc(n * 4)) ||
         (rc = o_hp.alloc(n * sizeof(pgr_hitpair))) || (rc = c_len.alloc(n * 4)) || (rc = c_score.alloc(n * 4)) ||
         (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(16)) ||
-        (rc = big.alloc(2 * max_big * 4)))
+        (rc = big.alloc(2 * max_big * 4)) || (rc = trk.alloc(n * 4)))
         return rc;
     PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 16, st));  // [0] error flag, [1], [2] number of groups per wave class
     hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n_groups, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
@@ -892,12 +977,12 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     // one wavefront per longer group; the grids are upper bounds, surplus workgroups exit on the device-side counts
     hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_SMALL>, dim3((uint32_t)max_big), dim3(64), 0, st,
                        shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1, prm,
-                       v_s.as<float>(), pre.as<int>(), slot.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
+                       v_s.as<float>(), pre.as<int>(), slot.as<int>(), trk.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
                        c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
     const uint64_t max_long = n / (ALN_LDS_SMALL + 1) + 1;
     hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_MAX>, dim3((uint32_t)max_long), dim3(64), 0, st,
                        shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>() + max_big, err.as<uint32_t>() + 2,
-                       prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
+                       prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(), trk.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
                        c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
     // D2H and compaction on the host (output assembly only)
     std::vector<uint64_t> h_gstart(n_groups + 1), h_skey(n);

@@ -202,7 +202,7 @@ def test_sparse_aln_duplicates_and_small(oracle, gpu_ctx):
         assert got == ref, trial
 
 
-@pytest.mark.parametrize("n", [15, 16, 17, 64, 129, 256, 257, 700, 3584, 3585, 6000])
+@pytest.mark.parametrize("n", [15, 16, 17, 64, 129, 256, 257, 700, 3584, 3585, 6000, 20000])
 def test_sparse_aln_long_groups(oracle, gpu_ctx, n):
     """groups of >= 16 hits take the wavefront-per-group kernel (9 KB LDS image up to 256 hits, 129 KB up to 3584, global
     memory above; shorter groups one thread each):
@@ -246,6 +246,37 @@ def test_sparse_aln_long_groups(oracle, gpu_ctx, n):
         assert got == ref, (n, span, pen, gap, ori)
         compared += 1
     assert compared >= 4
+
+
+def test_sparse_aln_look_back_beyond_the_lds_ring(oracle, gpu_ctx):
+    """groups above 3584 hits keep the last 3584 hits in an LDS ring; an `oriented` look-back that has to skip
+    thousands of hits of the other orientation class reaches below the ring and reads global memory"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(77)
+    hits, q, t = [], 0, 1000
+
+    def run(n, cls):
+        nonlocal q, t
+        for _ in range(n):
+            q += int(rng.integers(1, 300))
+            t += int(rng.integers(1, 300))
+            ln = int(rng.integers(60, 300))
+            qo = int(rng.integers(0, 2))
+            hits.append(((q, q + ln, qo), (t, t + ln, qo ^ cls)))
+    run(150, 0)
+    run(5200, 1)
+    run(150, 0)
+    run(4100, 1)
+    run(60, 0)
+    flat = [(a[0], a[1], a[2], b[0], b[1], b[2]) for a, b in hits]
+    for (span, pen, gap, ori) in [(8, 0.001, None, True), (3, 0.01, None, True), (8, 0.001, None, False)]:
+        got = P.sparse_aln(hits, span, pen, gap, ori, ctx=gpu_ctx)
+        ref = oracle.sparse_aln(flat, span, pen, gap, ori)
+        ref = [(sc, [((x[0], x[1], x[2]), (x[3], x[4], x[5])) for x in hp]) for sc, hp in ref]
+        assert got == ref, (span, pen, gap, ori)
+    # with orientation the three class-0 runs chain across the class-1 blocks
+    got = P.sparse_aln(hits, 8, 0.001, None, True, ctx=gpu_ctx)
+    assert max(len(hp) for _, hp in got) > 5200
 
 
 def test_get_shmmr_pairs_from_seq(oracle, gpu_ctx):
