@@ -914,6 +914,47 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// dense outputs: the chaining kernels leave chains / hit pairs at their group's offset in hit-sized arrays;
+// pack them by group (chain_off / hp_off = exclusive scans of the per-group counts) so that the host receives
+// exactly what it returns
+__global__ void group_counts_kernel(const uint64_t *__restrict__ g_start, uint64_t n_groups,
+                                    const uint32_t *__restrict__ g_nch, const uint32_t *__restrict__ g_nhp,
+                                    const uint64_t *__restrict__ skey, uint32_t *__restrict__ nch_out,
+                                    uint32_t *__restrict__ nhp_out, uint64_t *__restrict__ gkey_out) {
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > n_groups) return;
+    if (g == n_groups) {  // scan sentinels
+        nch_out[g] = 0;
+        nhp_out[g] = 0;
+        return;
+    }
+    const uint64_t gs = g_start[g];
+    const bool real = g_start[g + 1] - gs >= 2;  // aln.rs:234: targets with a single hit are dropped
+    nch_out[g] = real ? g_nch[g] : 0u;
+    nhp_out[g] = real ? g_nhp[g] : 0u;
+    gkey_out[g] = skey[gs];
+}
+
+__global__ void pack_chains_kernel(const uint64_t *__restrict__ g_start, uint64_t n_groups, uint64_t n,
+                                   const uint32_t *__restrict__ flags, const uint64_t *__restrict__ rank,
+                                   const uint32_t *__restrict__ nch, const uint32_t *__restrict__ nhp,
+                                   const uint64_t *__restrict__ chain_off, const uint64_t *__restrict__ hp_off,
+                                   const uint32_t *__restrict__ c_len, const float *__restrict__ c_score,
+                                   const pgr_hitpair *__restrict__ o_hp, uint32_t *__restrict__ d_clen,
+                                   float *__restrict__ d_cscore, pgr_hitpair *__restrict__ d_hp) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t g = rank[i] - (flags[i] ? 0u : 1u);  // rank = exclusive scan of the group-start flags
+    const uint64_t k = i - g_start[g];
+    if (k < nhp[g]) d_hp[hp_off[g] + k] = o_hp[i];
+    if (k < nch[g]) {
+        d_clen[chain_off[g] + k] = c_len[i];
+        d_cscore[chain_off[g] + k] = c_score[i];
+    }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -921,20 +962,37 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
 namespace {
 
 struct ChainOut {
-    std::vector<uint64_t> g_key;      // key of every group with >= 2 hits that produced chains
+    std::vector<uint64_t> g_key;      // key of every group with >= 2 hits
     std::vector<uint32_t> g_nchains;  // chains per such group
-    std::vector<float> c_score;
-    std::vector<uint32_t> c_len;
-    std::vector<pgr_hitpair> hps;
+    // dense per-chain / per-hit-pair outputs, malloc'd: fill_result hands c_score and hps to the caller as they are
+    float *c_score = nullptr;
+    uint32_t *c_len = nullptr;
+    pgr_hitpair *hps = nullptr;
+    uint64_t n_chains = 0, n_hps = 0;
+    ChainOut() = default;
+    ChainOut(const ChainOut &) = delete;
+    ChainOut &operator=(const ChainOut &) = delete;
+    ~ChainOut() {
+        free(c_score);
+        free(c_len);
+        free(hps);
+    }
 };
 
-// d_key/d_hp: n hits in arbitrary order; groups = equal keys.  Sorts (stable by qb, then by key), runs the DP.
 int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uint64_t n, const AlnParams &prm,
                ChainOut &out) {
     if (n == 0) return PGR_OK;
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 hits in one batch");
     hipStream_t st = ctx->stream;
     int rc;
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const auto c0 = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        (void)hipStreamSynchronize(st);
+        fprintf(stderr, "[pgr]   chain_hits %-18s at %.2f ms\n", what,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - c0).count());
+    };
     Tmp idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), skey(ctx), shp(ctx), flags(ctx), rank(ctx), gstart(ctx);
     if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)) ||
         (rc = skey.alloc(n * 8)) || (rc = shp.alloc(n * sizeof(pgr_hitpair))) || (rc = flags.alloc((n + 1) * 4)) ||
@@ -954,6 +1012,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
                        shp.as<pgr_hitpair>(), flags.as<uint32_t>());
     PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, scan_counts_temp_bytes((uint32_t)(n + 1)), flags.as<uint32_t>(),
                              rank.as<uint64_t>(), (uint32_t)(n + 1)));
+    lap("sorted + grouped");
     uint64_t n_groups = 0;
     PGR_HIP(ctx, hipMemcpyAsync(&n_groups, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
@@ -984,19 +1043,23 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
                        shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>() + max_big, err.as<uint32_t>() + 2,
                        prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(), trk.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
                        c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
-    // D2H and compaction on the host (output assembly only)
-    std::vector<uint64_t> h_gstart(n_groups + 1), h_skey(n);
-    std::vector<uint32_t> h_nch(n_groups), h_nhp(n_groups), h_clen(n);
-    std::vector<float> h_cscore(n);
-    std::vector<pgr_hitpair> h_hp(n);
+    lap("chained");
+    // pack on the device, then download straight into the buffers that are handed to the caller
+    Tmp d_nch(ctx), d_nhp(ctx), d_gkey(ctx), d_choff(ctx), d_hpoff(ctx);
+    if ((rc = d_nch.alloc((n_groups + 1) * 4)) || (rc = d_nhp.alloc((n_groups + 1) * 4)) || (rc = d_gkey.alloc(n_groups * 8)) ||
+        (rc = d_choff.alloc((n_groups + 1) * 8)) || (rc = d_hpoff.alloc((n_groups + 1) * 8)))
+        return rc;
+    hipLaunchKernelGGL(group_counts_kernel, grid_for(n_groups + 1), dim3(256), 0, st, gstart.as<uint64_t>(), n_groups,
+                       g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), skey.as<uint64_t>(), d_nch.as<uint32_t>(),
+                       d_nhp.as<uint32_t>(), d_gkey.as<uint64_t>());
+    const size_t tbg = scan_counts_temp_bytes((uint32_t)(n_groups + 1));
+    if ((rc = ctx->ws_scan_tmp.ensure_keep(ctx, tbg, st))) return rc;
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nch.as<uint32_t>(), d_choff.as<uint64_t>(), (uint32_t)(n_groups + 1)));
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nhp.as<uint32_t>(), d_hpoff.as<uint64_t>(), (uint32_t)(n_groups + 1)));
+    uint64_t totals[2] = {0, 0};
     uint32_t h_err = 0;
-    PGR_HIP(ctx, hipMemcpyAsync(h_gstart.data(), gstart.p, (n_groups + 1) * 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(h_skey.data(), skey.p, n * 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(h_nch.data(), g_nch.p, n_groups * 4, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(h_nhp.data(), g_nhp.p, n_groups * 4, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(h_clen.data(), c_len.p, n * 4, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(h_cscore.data(), c_score.p, n * 4, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(h_hp.data(), o_hp.p, n * sizeof(pgr_hitpair), hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(&totals[0], d_choff.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(&totals[1], d_hpoff.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
     PGR_HIP(ctx, hipGetLastError());
@@ -1004,19 +1067,38 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
         return ctx->fail(PGR_ERR_INVALID_ARG,
                          "sparse_aln: a hit pair with end <= bgn (non-positive score); the reference never terminates "
                          "on such input (aln.rs:129-131)");
+    const uint64_t n_chains = totals[0], n_hps = totals[1];
+    Tmp p_clen(ctx), p_cscore(ctx), p_hp(ctx);
+    if ((rc = p_clen.alloc(std::max<uint64_t>(n_chains, 1) * 4)) || (rc = p_cscore.alloc(std::max<uint64_t>(n_chains, 1) * 4)) ||
+        (rc = p_hp.alloc(std::max<uint64_t>(n_hps, 1) * sizeof(pgr_hitpair))))
+        return rc;
+    hipLaunchKernelGGL(pack_chains_kernel, grid_for(n), dim3(256), 0, st, gstart.as<uint64_t>(), n_groups, n,
+                       flags.as<uint32_t>(), rank.as<uint64_t>(), d_nch.as<uint32_t>(), d_nhp.as<uint32_t>(),
+                       d_choff.as<uint64_t>(), d_hpoff.as<uint64_t>(), c_len.as<uint32_t>(), c_score.as<float>(),
+                       o_hp.as<pgr_hitpair>(), p_clen.as<uint32_t>(), p_cscore.as<float>(), p_hp.as<pgr_hitpair>());
+    out.c_score = (float *)malloc(std::max<uint64_t>(n_chains, 1) * sizeof(float));
+    out.c_len = (uint32_t *)malloc(std::max<uint64_t>(n_chains, 1) * sizeof(uint32_t));
+    out.hps = (pgr_hitpair *)malloc(std::max<uint64_t>(n_hps, 1) * sizeof(pgr_hitpair));
+    std::vector<uint64_t> h_gstart(n_groups + 1), h_gkey(n_groups);
+    std::vector<uint32_t> h_nch(n_groups + 1);
+    if (!out.c_score || !out.c_len || !out.hps) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    if ((rc = ctx->d2h(out.c_score, p_cscore.p, n_chains * 4)) || (rc = ctx->d2h(out.c_len, p_clen.p, n_chains * 4)) ||
+        (rc = ctx->d2h(out.hps, p_hp.p, n_hps * sizeof(pgr_hitpair))) ||
+        (rc = ctx->d2h(h_gstart.data(), gstart.p, (n_groups + 1) * 8)) || (rc = ctx->d2h(h_gkey.data(), d_gkey.p, n_groups * 8)) ||
+        (rc = ctx->d2h(h_nch.data(), d_nch.p, (n_groups + 1) * 4)))
+        return rc;
+    PGR_HIP(ctx, hipGetLastError());
+    out.n_chains = n_chains;
+    out.n_hps = n_hps;
+    lap("downloaded");
+    out.g_key.reserve(n_groups);
+    out.g_nchains.reserve(n_groups);
     for (uint64_t g = 0; g < n_groups; ++g) {
         if (h_gstart[g + 1] - h_gstart[g] < 2) continue;  // aln.rs:234
-        const uint64_t gs = h_gstart[g];
-        out.g_key.push_back(h_skey[gs]);
+        out.g_key.push_back(h_gkey[g]);
         out.g_nchains.push_back(h_nch[g]);
-        uint64_t o = gs;
-        for (uint32_t c = 0; c < h_nch[g]; ++c) {
-            out.c_score.push_back(h_cscore[gs + c]);
-            out.c_len.push_back(h_clen[gs + c]);
-            out.hps.insert(out.hps.end(), h_hp.begin() + o, h_hp.begin() + o + h_clen[gs + c]);
-            o += h_clen[gs + c];
-        }
     }
+    lap("assembled");
     return PGR_OK;
 }
 
@@ -1028,41 +1110,49 @@ T *dup_vec(const std::vector<T> &v) {
 }
 
 // groups are sorted by key = (query << 32 | sid): flat result
-int fill_result(pgr_ctx *ctx, uint32_t n_queries, const ChainOut &co, pgr_hps_result *out) {
-    std::vector<uint64_t> q_off((size_t)n_queries + 1, 0), t_off, c_off;
+int fill_result(pgr_ctx *ctx, uint32_t n_queries, ChainOut &co, pgr_hps_result *out) {
+    std::vector<uint64_t> q_off((size_t)n_queries + 1, 0), t_off;
     std::vector<uint32_t> t_sid;
-    uint64_t n_chains = 0, n_hp = 0;
+    t_off.reserve(co.g_key.size() + 1);
+    t_sid.reserve(co.g_key.size());
+    uint64_t n_chains = 0;
     size_t gi = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
         q_off[q] = t_sid.size();
         while (gi < co.g_key.size() && (uint32_t)(co.g_key[gi] >> 32) == q) {
             t_sid.push_back((uint32_t)(co.g_key[gi] & 0xFFFFFFFFull));
             t_off.push_back(n_chains);
-            for (uint32_t c = 0; c < co.g_nchains[gi]; ++c) {
-                c_off.push_back(n_hp);
-                n_hp += co.c_len[n_chains];
-                ++n_chains;
-            }
+            n_chains += co.g_nchains[gi];
             ++gi;
         }
     }
     q_off[n_queries] = t_sid.size();
     t_off.push_back(n_chains);
-    c_off.push_back(n_hp);
+    uint64_t *c_off = (uint64_t *)malloc((n_chains + 1) * sizeof(uint64_t));
     out->n_queries = n_queries;
     out->q_off = dup_vec(q_off);
     out->n_targets = t_sid.size();
     out->t_sid = dup_vec(t_sid);
     out->t_off = dup_vec(t_off);
     out->n_chains = n_chains;
-    out->c_score = dup_vec(co.c_score);
-    out->c_off = dup_vec(c_off);
-    out->n_hps = n_hp;
-    out->hps = dup_vec(co.hps);
-    if (!out->q_off || !out->t_sid || !out->t_off || !out->c_score || !out->c_off || !out->hps) {
+    out->c_off = c_off;
+    out->n_hps = co.n_hps;
+    // the dense chain scores / hit pairs go to the caller as they came from the device
+    out->c_score = co.c_score ? co.c_score : (float *)malloc(sizeof(float));
+    out->hps = co.hps ? co.hps : (pgr_hitpair *)malloc(sizeof(pgr_hitpair));
+    co.c_score = nullptr;
+    co.hps = nullptr;
+    if (!out->q_off || !out->t_sid || !out->t_off || !out->c_score || !out->c_off || !out->hps || n_chains != co.n_chains) {
         pgr_hps_result_free(out);
-        return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+        return ctx->fail(n_chains != co.n_chains ? PGR_ERR_INTERNAL : PGR_ERR_NOMEM,
+                         n_chains != co.n_chains ? "chain bookkeeping mismatch" : "host allocation failed");
     }
+    uint64_t n_hp = 0;
+    for (uint64_t c = 0; c < n_chains; ++c) {
+        c_off[c] = n_hp;
+        n_hp += co.c_len[c];
+    }
+    c_off[n_chains] = n_hp;
     return PGR_OK;
 }
 
