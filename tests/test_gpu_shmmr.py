@@ -339,3 +339,28 @@ def test_size_independent_properties(oracle, gpu_ctx):
     rc = comp[s][::-1].copy()
     f, r = P.sequence_to_shmmrs_batch([s, rc], P.make_spec(sketch=True), ctx=gpu_ctx)
     assert list(f["x"]) == list(r["x"][::-1])
+
+
+def test_batch_beyond_2_pow_32_bases(gpu_ctx):
+    """one resident batch of 6 Gbp (> 2^32 positions): a contig's shimmers do not depend on where it sits in the batch
+    (64-bit word / position arithmetic in every kernel): the last contigs equal a small batch of the same contig ids"""
+    import pgrtk_amd as P
+    spec = P.make_spec()
+    n = 600
+    b = P.Batch.synthetic([10_000_000] * n, seed=2, ctx=gpu_ctx)
+    assert b.total_bases > 2 ** 32
+    s = b.shmmrs(spec)
+    mm, off = s.download()
+    b.close()
+    s.close()
+    for c0 in (0, 428, n - 3):  # first, the ones straddling base 2^32, last
+        b2 = P.Batch.synthetic([10_000_000] * 3, seed=2, contig0=c0, ctx=gpu_ctx)
+        s2 = b2.shmmrs(spec)
+        mm2, off2 = s2.download()
+        lo, hi = int(off[c0]), int(off[c0 + 3])
+        assert hi - lo == len(mm2) and np.array_equal(off[c0:c0 + 4] - off[c0], off2)
+        assert np.array_equal(mm["x"][lo:hi], mm2["x"])
+        assert np.array_equal(mm["y"][lo:hi] & np.uint64(0xFFFFFFFF), mm2["y"] & np.uint64(0xFFFFFFFF))
+        assert np.array_equal(mm["y"][lo:hi] >> np.uint64(32), (mm2["y"] >> np.uint64(32)) + np.uint64(c0))
+        b2.close()
+        s2.close()
