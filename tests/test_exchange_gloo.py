@@ -42,6 +42,17 @@ def _worker(rank, world, port, counts, q):
         pend = exchange.PendingAllgather(local)  # the overlapped form bench.py uses must agree
         out2, cnts2 = pend.wait()
         assert cnts2 == cnts and out2.shape == out.shape and bool((out2 == out).all())
+        # the MM128 form (2 words per row) with caller-provided gather buffers, as bench.py exchanges every step:
+        # a big enough buffer is used in place, a too small one is replaced
+        mm = local[:, :exchange.MM_WORDS].contiguous()
+        big = torch.full((world * (max(counts) + 3), exchange.MM_WORDS), -1, dtype=torch.int64)
+        g3, c3 = exchange.PendingAllgather(mm, out=big).wait()
+        assert c3 == cnts and bool((g3 == out[:, :exchange.MM_WORDS]).all())
+        if max(counts):
+            assert g3.data_ptr() == big.data_ptr() or len(set(counts)) > 1  # gathered in place (ragged: re-packed)
+            small = torch.empty((1, exchange.MM_WORDS), dtype=torch.int64)
+            g4, _ = exchange.PendingAllgather(mm, out=small).wait()
+            assert bool((g4 == g3).all())
         q.put((rank, out.numpy().copy(), cnts))
     finally:
         dist.destroy_process_group()
