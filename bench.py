@@ -125,6 +125,60 @@ def query_bench(P, ctx, batch, spec, args, contig0):
     }
 
 
+def query_bench_dist(P, ctx, spec, args, gathered, world, rank, dist, torch, local_rank):
+    """BASELINE.json configs[2] on N GPUs: every rank builds the (replicated) index of ALL ranks' contigs from the
+    all-gathered MM128 lists (pgr_index_add_shmmrs derives the pair records), the 10 000 queries are sharded round
+    robin, every rank chains its own share; value = all queries / slowest rank."""
+    import numpy as np
+    rng = np.random.default_rng(3)
+    nq, qlen = args.queries, 10_000
+    n_contigs = args.contigs * world
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ix = P.Index(spec, ctx=ctx)
+    ix.add_shmmrs(device_ptr=gathered.data_ptr(), n=int(gathered.shape[0]))
+    ix.finalize()
+    t_build = time.perf_counter() - t0
+    cs = rng.integers(0, n_contigs, nq)
+    offs = rng.integers(0, max(1, args.contig_len - qlen), nq)
+    mine = np.arange(rank, nq, world)
+    qs = synth_substrings(args.seed, cs[mine], offs[mine], qlen)
+    comp = np.zeros(256, dtype=np.uint8)
+    for a, b in zip(b"ACGT", b"TGCA"):
+        comp[a] = b
+    qs = P.PackedSeqs.from_list([comp[q][::-1] if int(mine[i]) & 1 else q for i, q in enumerate(qs)])
+    ix.query_hps_raw(qs, 0.025)
+    reps = []
+    for _ in range(3):
+        dist.barrier()
+        t0 = time.perf_counter()
+        r = ix.query_hps_raw(qs, 0.025)
+        reps.append(time.perf_counter() - t0)
+    ok = 0
+    for i in range(len(mine)):
+        best = None
+        for t in range(int(r["q_off"][i]), int(r["q_off"][i + 1])):
+            for c in range(int(r["t_off"][t]), int(r["t_off"][t + 1])):
+                n_hp = int(r["c_off"][c + 1] - r["c_off"][c])
+                if best is None or n_hp > best[0]:
+                    best = (n_hp, int(r["t_sid"][t]))
+        ok += int(best is not None and best[1] == int(cs[mine[i]]))
+    dev = ("cuda:%d" % local_rank) if args.backend == "nccl" else "cpu"
+    t = torch.tensor([sorted(reps)[1], t_build], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    agg = torch.tensor([float(len(r["hps"])), float(ok)], dtype=torch.float64, device=dev)
+    dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+    t_q = float(t[0].item())
+    return {
+        "workload": "BASELINE.json configs[2] on %d GPUs: %d x %d bp queries sharded round robin, every rank holds the index "
+                    "of all %d x %d bp contigs built from the all-gathered shimmer lists" % (world, nq, qlen, n_contigs,
+                                                                                          args.contig_len),
+        "index_build_s": float(t[1].item()), "index_records": ix.n_records, "query_s": t_q, "queries_per_s": nq / t_q,
+        "hit_pairs": int(agg[0].item()), "hit_pairs_per_s": float(agg[0].item()) / t_q,
+        "queries_with_best_chain_on_source": int(agg[1].item()),
+    }
+
+
 def effective_cpus():
     """CPUs this process may really use: scheduler affinity capped by the cgroup CPU quota (a container that sees
     256 CPUs but has a 16-CPU quota runs 16 threads' worth of work)"""
@@ -244,6 +298,7 @@ def main():
         if state["pending"] is not None:
             gathered, counts = state["pending"].wait()
             state["n_gathered"] = int(gathered.shape[0])
+            state["gathered"] = gathered
             state["pending"] = None
 
     def step():
@@ -284,6 +339,15 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # query leg on N GPUs (after the timed region; a failure here must not cost the headline line)
+    dist_query = None
+    if use_dist and args.queries > 0 and state.get("gathered") is not None:
+        try:
+            g = state["gathered"]
+            g = g if g.is_cuda else g.to("cuda:%d" % local_rank)
+            dist_query = query_bench_dist(P, ctx, spec, args, g.contiguous(), world, rank, dist, torch, local_rank)
+        except Exception as e:  # noqa: BLE001
+            dist_query = {"error": repr(e)[:300]}
     if rank == 0:
         k = max(1, args.steps)
         l1_ms = sum(p[0] for p in profs) / k
@@ -324,7 +388,9 @@ def main():
             },
             "stage_ms": {"level1_tile": l1_ms, "level1_tail_serial": aux_ms, "level2": l2_ms, "compute_total": tot_ms},
         }
-        if world == 1 and args.queries > 0:
+        if dist_query is not None:
+            out["query"] = dist_query
+        elif world == 1 and args.queries > 0:
             out["query"] = query_bench(P, ctx, batch, spec, args, contig0)
         if not args.no_cpu_baseline:
             import numpy as np  # noqa: F401
