@@ -391,12 +391,17 @@ def main():
         if dist_query is not None:
             out["query"] = dist_query
         elif world == 1 and args.queries > 0:
-            out["query"] = query_bench(P, ctx, batch, spec, args, contig0)
+            try:
+                out["query"] = query_bench(P, ctx, batch, spec, args, contig0)
+            except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                out["query"] = {"error": repr(e)[:300]}
         if not args.no_cpu_baseline:
-            import numpy as np  # noqa: F401
-            mm, off = sh.download()
-            gpu_counts = [int(off[i + 1] - off[i]) for i in range(args.contigs)]
-            out["cpu_baseline"] = cpu_baseline(spec_t, args.contigs, args.contig_len, args.seed, contig0, gpu_counts)
+            try:
+                mm, off = sh.download()
+                gpu_counts = [int(off[i + 1] - off[i]) for i in range(args.contigs)]
+                out["cpu_baseline"] = cpu_baseline(spec_t, args.contigs, args.contig_len, args.seed, contig0, gpu_counts)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": repr(e)[:300]}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
