@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <thread>
 #include <cstdio>
 #include <cstdlib>
@@ -67,7 +69,9 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     ctx->device = device;
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->cev[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
     if (e != hipSuccess) {
         g_create_error = std::string("context setup: ") + hipGetErrorString(e);
@@ -86,6 +90,9 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    for (auto &ev : ctx->cev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -158,34 +165,22 @@ extern "C" void pgr_batch_destroy(pgr_batch *b) {
 
 extern "C" uint64_t pgr_batch_total_bases(const pgr_batch *b) { return b ? b->total_bases : 0; }
 
-extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
-                                    pgr_batch **out) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!out || (n && (!seqs || !lens))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    *out = nullptr;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
-    for (uint32_t i = 0; i < n; ++i)
-        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
-    pgr_batch *b = nullptr;
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
+// Stage the ASCII bytes of an allocated batch: host threads fill two pinned windows, H2D + pack kernel on `st`.
+// Thread-compatible with a compute call running on ctx->stream: touches only the batch, ctx->pinned, ctx->ws_ascii and
+// the two events it is given.  Errors come back as a code + message (the caller owns ctx->err).
+static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, std::string &err) {
+    auto fail = [&](int code, const std::string &m) {
+        err = m;
+        return code;
     };
-    const auto t0 = now();
-    double t_copy = 0, t_wait = 0;
-    int rc = batch_alloc(ctx, n, lens, &b);
-    if (rc) return rc;
-    const auto t1 = now();
     // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Two pinned windows of 32 MiB: while window
-    // i is on its way to the GPU (H2D + pack kernel on the context's stream) the host threads fill window i+1.
+    // i is on its way to the GPU (H2D + pack kernel) the host threads fill window i+1.
     const uint64_t WIN_WORDS = 1ull << 20;  // 32 MiB of ASCII per window
     const uint64_t win_words = std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
-    if ((rc = ctx->ensure_pinned(2 * win_words * 32)) || (rc = ctx->ws_ascii.ensure(ctx, 2 * win_words * 32))) {
-        pgr_batch_destroy(b);
-        return rc;
-    }
-    hipEvent_t done[2] = {ctx->ev[0], ctx->ev[1]};
+    if (ctx->ensure_pinned(2 * win_words * 32) || ctx->ws_ascii.ensure(ctx, 2 * win_words * 32))
+        return fail(PGR_ERR_NOMEM, "staging buffers: " + ctx->err);
+    hipEvent_t done[2] = {ev0, ev1};
     bool used[2] = {false, false};
     const unsigned hw = std::thread::hardware_concurrency();
     const unsigned n_thr = std::max(1u, std::min(8u, hw ? hw / 2 : 1u));
@@ -195,13 +190,8 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
         const uint64_t w1 = std::min(b->total_words, w0 + win_words);
         uint8_t *stage = (uint8_t *)ctx->pinned + (size_t)slot * win_words * 32;
         uint8_t *d_stage = (uint8_t *)ctx->ws_ascii.p + (size_t)slot * win_words * 32;
-        const auto tw0 = now();
-        if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess) {  // this window's previous trip is over
-            pgr_batch_destroy(b);
-            return ctx->fail(PGR_ERR_DEVICE, "H2D pipeline failed");
-        }
-        const auto tw1 = now();
-        t_wait += ms(tw0, tw1);
+        if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess)  // this window's previous trip is over
+            return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         while (c < n && b->h_word_off[c + 1] <= w0) ++c;
         // copy jobs of this window: (dst, src, len), split into <= 4 MiB pieces and spread over the threads
         struct Job {
@@ -231,32 +221,41 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
             work();
             for (auto &t : th) t.join();
         }
-        t_copy += ms(tw1, now());
-        if (hipMemcpyAsync(d_stage, stage, (w1 - w0) * 32, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
-            pgr_batch_destroy(b);
-            return ctx->fail(PGR_ERR_DEVICE, "H2D copy of the ASCII window failed");
-        }
-        launch_pack_ascii(ctx->stream, d_stage, w0, b->d, n, w1);
-        if (hipEventRecord(done[slot], ctx->stream) != hipSuccess) {
-            pgr_batch_destroy(b);
-            return ctx->fail(PGR_ERR_DEVICE, "H2D pipeline failed");
-        }
+        if (hipMemcpyAsync(d_stage, stage, (w1 - w0) * 32, hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(PGR_ERR_DEVICE, "H2D copy of the ASCII window failed");
+        launch_pack_ascii(st, d_stage, w0, b->d, n, w1);
+        if (hipEventRecord(done[slot], st) != hipSuccess) return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         used[slot] = true;
     }
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess) {
+    if (n && hipMemcpyAsync(b->h_n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st) !=
+                 hipSuccess)
+        return fail(PGR_ERR_DEVICE, "D2H of the invalid-base counts failed");
+    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+        return fail(PGR_ERR_DEVICE, "pack kernel failed");
+    return PGR_OK;
+}
+
+extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                                    pgr_batch **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out || (n && (!seqs || !lens))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
+    pgr_batch *b = nullptr;
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = batch_alloc(ctx, n, lens, &b);
+    if (rc) return rc;
+    std::string err;
+    if ((rc = batch_stage(ctx, b, n, seqs, lens, ctx->stream, ctx->ev[0], ctx->ev[1], err))) {
         pgr_batch_destroy(b);
-        return ctx->fail(PGR_ERR_DEVICE, "pack kernel failed");
-    }
-    if (n) {
-        if (hipMemcpy(b->h_n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost) !=
-            hipSuccess) {
-            pgr_batch_destroy(b);
-            return ctx->fail(PGR_ERR_DEVICE, "D2H of the invalid-base counts failed");
-        }
+        return ctx->fail(rc, err);
     }
     if (dbg)
-        fprintf(stderr, "[pgr] batch_from_ascii %u seqs, %.1f MB: alloc %.2f ms, staging memcpy %.2f, window waits %.2f, total %.2f\n",
-                n, b->total_bases / 1e6, ms(t0, t1), t_copy, t_wait, ms(t0, now()));
+        fprintf(stderr, "[pgr] batch_from_ascii %u seqs, %.1f MB: %.2f ms\n", n, b->total_bases / 1e6,
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     *out = b;
     return PGR_OK;
 }
@@ -909,13 +908,146 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
 
 // ------------------------------------------------------------------------------------------------
 // host-buffer conveniences (the B1 drop-in)
+// Large host inputs are cut into sub-batches of 256 Mbp - 1 Gbp: a staging thread pushes sub-batch i+1 through the pinned
+// windows and the pack kernel (copy stream) while sub-batch i computes and downloads on the context's stream.
+// The PCIe transfer of the ASCII input is the longest stage (48 GB/s); the pipeline hides the rest behind it.
+static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
+                                 const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
+                                 uint64_t **out_off) {
+    // sub-batch size: big enough to keep the pinned-window pipeline efficient (>= 256 Mbp), small enough that the
+    // last sub-batch's compute + download, which nothing overlaps, stays a few percent of the call
+    uint64_t total_bp = 0;
+    for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
+    const uint64_t SUB_BP = std::min<uint64_t>(std::max<uint64_t>(total_bp / 8, 256ull << 20), 1ull << 30);
+    struct Sub {
+        uint32_t c0, c1;
+        pgr_batch *b = nullptr;
+    };
+    std::vector<Sub> subs;
+    for (uint32_t c = 0; c < n;) {
+        uint32_t e = c;
+        uint64_t tot = 0;
+        while (e < n && (e == c || tot + lens[e] <= SUB_BP)) tot += lens[e++];
+        Sub sb;
+        sb.c0 = c;
+        sb.c1 = e;
+        subs.push_back(sb);
+        c = e;
+    }
+    std::vector<uint32_t> rr;  // rid of contig i of the CALL (sub-batches must not restart at 0)
+    if (!rids) {
+        rr.resize(n);
+        for (uint32_t i = 0; i < n; ++i) rr[i] = i;
+        rids = rr.data();
+    }
+    auto destroy_all = [&]() {
+        for (Sub &sb : subs) {
+            pgr_batch_destroy(sb.b);
+            sb.b = nullptr;
+        }
+    };
+    int rc = PGR_OK;
+    for (Sub &sb : subs)
+        if ((rc = batch_alloc(ctx, sb.c1 - sb.c0, lens + sb.c0, &sb.b))) {
+            destroy_all();
+            return rc;
+        }
+    // staging thread
+    std::mutex mu;
+    std::condition_variable cv;
+    size_t n_ready = 0;
+    int stage_rc = PGR_OK;
+    std::string stage_err;
+    std::atomic<bool> cancel{false};
+    std::thread stager([&]() {
+        (void)hipSetDevice(ctx->device);
+        for (size_t i = 0; i < subs.size() && !cancel.load(); ++i) {
+            std::string err;
+            const int r = batch_stage(ctx, subs[i].b, subs[i].c1 - subs[i].c0, seqs + subs[i].c0, lens + subs[i].c0,
+                                      ctx->copy_stream, ctx->cev[0], ctx->cev[1], err);
+            std::lock_guard<std::mutex> lk(mu);
+            if (r) {
+                stage_rc = r;
+                stage_err = err;
+                cv.notify_all();
+                return;
+            }
+            n_ready = i + 1;
+            cv.notify_all();
+        }
+    });
+    pgr_mm128 *mm = nullptr;
+    uint64_t cap = 0, total = 0;
+    uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    if (!off) rc = ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    for (size_t i = 0; i < subs.size() && !rc; ++i) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return n_ready > i || stage_rc != PGR_OK; });
+            if (n_ready <= i) {
+                rc = ctx->fail(stage_rc, stage_err);
+                break;
+            }
+        }
+        Sub &sb = subs[i];
+        pgr_shmmrs *s = nullptr;
+        if ((rc = pgr_shmmrs_compute(ctx, sb.b, spec, rids + sb.c0, padding, &s))) break;
+        pgr_batch_destroy(sb.b);
+        sb.b = nullptr;
+        if (total + s->count > cap) {
+            // the first sub-batch predicts the rest (shimmer density is a property of the spec)
+            const uint64_t guess = i == 0 ? (uint64_t)((double)s->count * subs.size() * 1.1) + 4096 : cap + cap / 2;
+            cap = std::max<uint64_t>(total + s->count, guess);
+            pgr_mm128 *nm = (pgr_mm128 *)realloc(mm, cap * sizeof(pgr_mm128));
+            if (!nm) {
+                pgr_shmmrs_destroy(s);
+                rc = ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+                break;
+            }
+            mm = nm;
+        }
+        if (s->count && (rc = ctx->d2h(mm + total, s->d_mm, s->count * sizeof(pgr_mm128)))) {
+            pgr_shmmrs_destroy(s);
+            break;
+        }
+        for (uint32_t c = sb.c0; c < sb.c1; ++c) off[c] = total + s->h_off[c - sb.c0];
+        total += s->count;
+        pgr_shmmrs_destroy(s);
+    }
+    if (rc) cancel.store(true);
+    stager.join();
+    destroy_all();
+    if (rc) {
+        free(mm);
+        free(off);
+        return rc;
+    }
+    off[n] = total;
+    if (!mm) mm = (pgr_mm128 *)malloc(sizeof(pgr_mm128));
+    *out_mm = mm;
+    *out_off = off;
+    return mm ? PGR_OK : ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+}
+
 extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
                                const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
                                uint64_t **out_off) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null output pointer");
+    if (n && (!seqs || !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
+    *out_mm = nullptr;
+    *out_off = nullptr;
+    uint64_t total_bp = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
+        total_bp += lens[i];
+    }
+    if (n >= 2 && total_bp >= (512ull << 20) && !getenv("PGR_NO_PIPELINE")) {
+        PGR_HIP(ctx, hipSetDevice(ctx->device));
+        return shmmr_batch_pipelined(ctx, spec, n, seqs, lens, rids, padding, out_mm, out_off);
+    }
     pgr_batch *b = nullptr;
     if ((rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b))) return rc;
     pgr_shmmrs *s = nullptr;

@@ -118,6 +118,20 @@ int pgr_ctx::ensure_pinned(size_t bytes) {
     return PGR_OK;
 }
 
+int pgr_ctx::ensure_pinned_out(size_t bytes) {
+    if (bytes <= pinned_out_cap && pinned_out) return PGR_OK;
+    if (pinned_out) (void)hipHostFree(pinned_out);
+    pinned_out = nullptr;
+    pinned_out_cap = 0;
+    hipError_t e = hipHostMalloc(&pinned_out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        pinned_out = nullptr;
+        return fail(PGR_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    pinned_out_cap = bytes;
+    return PGR_OK;
+}
+
 int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
     if (bytes == 0) return PGR_OK;
     if (bytes < (4u << 20)) {  // stream ordered like the pipelined path (the context's stream is non-blocking)
@@ -126,7 +140,7 @@ int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
         return e == hipSuccess ? PGR_OK : fail(PGR_ERR_DEVICE, std::string("D2H copy: ") + hipGetErrorString(e));
     }
     const size_t WIN = 16u << 20;
-    int rc = ensure_pinned(2 * WIN);
+    int rc = ensure_pinned_out(2 * WIN);
     if (rc) return rc;
     const unsigned hw = std::thread::hardware_concurrency();
     const unsigned n_thr = std::max(1u, std::min(4u, hw ? hw / 2 : 1u));
@@ -145,7 +159,7 @@ int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
         for (auto &t : th) t.join();
     };
     const uint8_t *sd = (const uint8_t *)src_dev;
-    uint8_t *dh = (uint8_t *)dst, *pin = (uint8_t *)pinned;
+    uint8_t *dh = (uint8_t *)dst, *pin = (uint8_t *)pinned_out;
     size_t issued = 0, copied = 0;
     int slot = 0;
     hipError_t e = hipSuccess;
@@ -189,4 +203,7 @@ void pgr_ctx::release_all() {
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
     pinned_cap = 0;
+    if (pinned_out) (void)hipHostFree(pinned_out);
+    pinned_out = nullptr;
+    pinned_out_cap = 0;
 }

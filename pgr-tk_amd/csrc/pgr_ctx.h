@@ -24,9 +24,15 @@ struct pgr_ctx {
     std::string err;
     pgr_prof prof = {};
 
-    // pinned staging for H2D
+    // pinned staging for H2D (owned by whoever stages a batch: the calling thread, or the staging thread of the
+    // pipelined pgr_shmmr_batch) and, separately, for result downloads (d2h, calling thread)
     void *pinned = nullptr;
     size_t pinned_cap = 0;
+    void *pinned_out = nullptr;
+    size_t pinned_out_cap = 0;
+    // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t cev[2] = {nullptr, nullptr};
 
     // workspaces
     pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
@@ -45,6 +51,7 @@ struct pgr_ctx {
     int dmalloc(void **out, size_t bytes);
     void dfree(void *p);
     int ensure_pinned(size_t bytes);
+    int ensure_pinned_out(size_t bytes);
     // device -> pageable host memory through the pinned buffer (two windows, D2H of window i+1 overlaps the host
     // copy of window i, which is spread over a few threads); small transfers go straight through hipMemcpy
     int d2h(void *dst, const void *src_dev, size_t bytes);

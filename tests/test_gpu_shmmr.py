@@ -364,3 +364,36 @@ def test_batch_beyond_2_pow_32_bases(gpu_ctx):
         assert np.array_equal(mm["y"][lo:hi] >> np.uint64(32), (mm2["y"] >> np.uint64(32)) + np.uint64(c0))
         b2.close()
         s2.close()
+
+
+def test_pipelined_host_batch(oracle, gpu_ctx):
+    """pgr_shmmr_batch cuts host inputs of >= 512 Mbp into sub-batches that are staged by a second thread / stream
+    while the previous one computes: same result as the single-batch path (PGR_NO_PIPELINE), rids and contig order
+    kept, contigs with N and empty contigs inside, spot checks against the oracle"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(42)
+    lens = [int(x) for x in rng.integers(1_000_000, 30_000_000, 40)]
+    lens[7] = 0
+    lens[20] = 55
+    seqs = [oracle.synth_contig(9, i, L).tobytes() if L else b"" for i, L in enumerate(lens)]
+    s11 = bytearray(seqs[11])
+    s11[100_000:100_400] = b"N" * 400
+    s11[5_000_000] = ord("n")
+    seqs[11] = bytes(s11)
+    assert sum(lens) > 600_000_000
+    spec = P.make_spec(80, 56, 4, 64)
+    rids = [int(x) for x in rng.integers(0, 2 ** 31, len(seqs))]
+    for r in (None, rids):
+        os.environ.pop("PGR_NO_PIPELINE", None)
+        a = P.sequence_to_shmmrs_batch(seqs, spec, rids=r, ctx=gpu_ctx)
+        os.environ["PGR_NO_PIPELINE"] = "1"
+        try:
+            b = P.sequence_to_shmmrs_batch(seqs, spec, rids=r, ctx=gpu_ctx)
+        finally:
+            os.environ.pop("PGR_NO_PIPELINE", None)
+        assert len(a) == len(b) == len(seqs)
+        for i in range(len(seqs)):
+            _assert_same(b[i], a[i], "pipelined vs single batch, contig %d" % i)
+        osp = oracle.spec(80, 56, 4, 64)
+        for i in (0, 7, 11, 20, len(seqs) - 1):
+            _assert_same(oracle.sequence_to_shmmrs(i if r is None else r[i], seqs[i], osp, False), a[i], "contig %d vs oracle" % i)
