@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <chrono>
 #include <atomic>
+#include <functional>
 #include <condition_variable>
 #include <mutex>
 #include <thread>
@@ -908,14 +909,24 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
 
 // ------------------------------------------------------------------------------------------------
 // host-buffer conveniences (the B1 drop-in)
-// Large host inputs are cut into sub-batches of 256 Mbp - 1 Gbp: a staging thread pushes sub-batch i+1 through the pinned
-// windows and the pack kernel (copy stream) while sub-batch i computes and downloads on the context's stream.
-// The PCIe transfer of the ASCII input is the longest stage (48 GB/s); the pipeline hides the rest behind it.
-static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
-                                 const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
-                                 uint64_t **out_off) {
+// Large host inputs are cut into sub-batches of 256 Mbp - 1 Gbp: a staging thread pushes sub-batch i+1 through the
+// pinned windows and the pack kernel (copy stream) while sub-batch i is consumed (shimmers, records, download) on the
+// context's stream.  The PCIe transfer of the ASCII input is the longest stage (48 GB/s); the pipeline hides the rest
+// behind it.  consume(batch, c0, c1) gets contigs [c0, c1) of the call, resident on the GPU.
+bool pgr::worth_pipelining(uint32_t n, const uint64_t *lens) {
+    if (n < 2 || getenv("PGR_NO_PIPELINE")) return false;
+    uint64_t total_bp = 0;
+    for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
+    return total_bp >= (512ull << 20);
+}
+
+int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                         const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume) {
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
     // sub-batch size: big enough to keep the pinned-window pipeline efficient (>= 256 Mbp), small enough that the
-    // last sub-batch's compute + download, which nothing overlaps, stays a few percent of the call
+    // last sub-batch's processing, which nothing overlaps, stays a few percent of the call
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
     const uint64_t SUB_BP = std::min<uint64_t>(std::max<uint64_t>(total_bp / 8, 256ull << 20), 1ull << 30);
@@ -934,12 +945,6 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
         subs.push_back(sb);
         c = e;
     }
-    std::vector<uint32_t> rr;  // rid of contig i of the CALL (sub-batches must not restart at 0)
-    if (!rids) {
-        rr.resize(n);
-        for (uint32_t i = 0; i < n; ++i) rr[i] = i;
-        rids = rr.data();
-    }
     auto destroy_all = [&]() {
         for (Sub &sb : subs) {
             pgr_batch_destroy(sb.b);
@@ -947,12 +952,11 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
         }
     };
     int rc = PGR_OK;
-    for (Sub &sb : subs)
+    for (Sub &sb : subs)  // device allocations stay on the calling thread (the caching allocator is not thread safe)
         if ((rc = batch_alloc(ctx, sb.c1 - sb.c0, lens + sb.c0, &sb.b))) {
             destroy_all();
             return rc;
         }
-    // staging thread
     std::mutex mu;
     std::condition_variable cv;
     size_t n_ready = 0;
@@ -976,10 +980,6 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
             cv.notify_all();
         }
     });
-    pgr_mm128 *mm = nullptr;
-    uint64_t cap = 0, total = 0;
-    uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
-    if (!off) rc = ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     for (size_t i = 0; i < subs.size() && !rc; ++i) {
         {
             std::unique_lock<std::mutex> lk(mu);
@@ -989,34 +989,59 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
                 break;
             }
         }
-        Sub &sb = subs[i];
-        pgr_shmmrs *s = nullptr;
-        if ((rc = pgr_shmmrs_compute(ctx, sb.b, spec, rids + sb.c0, padding, &s))) break;
-        pgr_batch_destroy(sb.b);
-        sb.b = nullptr;
-        if (total + s->count > cap) {
-            // the first sub-batch predicts the rest (shimmer density is a property of the spec)
-            const uint64_t guess = i == 0 ? (uint64_t)((double)s->count * subs.size() * 1.1) + 4096 : cap + cap / 2;
-            cap = std::max<uint64_t>(total + s->count, guess);
-            pgr_mm128 *nm = (pgr_mm128 *)realloc(mm, cap * sizeof(pgr_mm128));
-            if (!nm) {
-                pgr_shmmrs_destroy(s);
-                rc = ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
-                break;
-            }
-            mm = nm;
-        }
-        if (s->count && (rc = ctx->d2h(mm + total, s->d_mm, s->count * sizeof(pgr_mm128)))) {
-            pgr_shmmrs_destroy(s);
-            break;
-        }
-        for (uint32_t c = sb.c0; c < sb.c1; ++c) off[c] = total + s->h_off[c - sb.c0];
-        total += s->count;
-        pgr_shmmrs_destroy(s);
+        rc = consume(subs[i].b, subs[i].c0, subs[i].c1);
+        pgr_batch_destroy(subs[i].b);
+        subs[i].b = nullptr;
     }
     if (rc) cancel.store(true);
     stager.join();
     destroy_all();
+    return rc;
+}
+
+static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
+                                 const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
+                                 uint64_t **out_off) {
+    std::vector<uint32_t> rr;  // rid of contig i of the CALL (sub-batches must not restart at 0)
+    if (!rids) {
+        rr.resize(n);
+        for (uint32_t i = 0; i < n; ++i) rr[i] = i;
+        rids = rr.data();
+    }
+    pgr_mm128 *mm = nullptr;
+    uint64_t cap = 0, total = 0;
+    uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    if (!off) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    bool first = true;
+    uint64_t total_bp = 0;
+    for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
+    int rc = for_each_staged(ctx, n, seqs, lens, [&](pgr_batch *b, uint32_t c0, uint32_t c1) -> int {
+        pgr_shmmrs *s = nullptr;
+        int r = pgr_shmmrs_compute(ctx, b, spec, rids + c0, padding, &s);
+        if (r) return r;
+        if (total + s->count > cap) {
+            // the first sub-batch predicts the rest (shimmer density is a property of the spec)
+            uint64_t guess = cap + cap / 2;
+            if (first && b->total_bases)
+                guess = (uint64_t)((double)s->count * ((double)total_bp / (double)b->total_bases) * 1.1) + 4096;
+            cap = std::max<uint64_t>(total + s->count, guess);
+            pgr_mm128 *nm = (pgr_mm128 *)realloc(mm, cap * sizeof(pgr_mm128));
+            if (!nm) {
+                pgr_shmmrs_destroy(s);
+                return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+            }
+            mm = nm;
+        }
+        first = false;
+        if (s->count && (r = ctx->d2h(mm + total, s->d_mm, s->count * sizeof(pgr_mm128)))) {
+            pgr_shmmrs_destroy(s);
+            return r;
+        }
+        for (uint32_t c = c0; c < c1; ++c) off[c] = total + s->h_off[c - c0];
+        total += s->count;
+        pgr_shmmrs_destroy(s);
+        return PGR_OK;
+    });
     if (rc) {
         free(mm);
         free(off);
@@ -1039,15 +1064,7 @@ extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, c
     if (rc) return rc;
     *out_mm = nullptr;
     *out_off = nullptr;
-    uint64_t total_bp = 0;
-    for (uint32_t i = 0; i < n; ++i) {
-        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
-        total_bp += lens[i];
-    }
-    if (n >= 2 && total_bp >= (512ull << 20) && !getenv("PGR_NO_PIPELINE")) {
-        PGR_HIP(ctx, hipSetDevice(ctx->device));
-        return shmmr_batch_pipelined(ctx, spec, n, seqs, lens, rids, padding, out_mm, out_off);
-    }
+    if (worth_pipelining(n, lens)) return shmmr_batch_pipelined(ctx, spec, n, seqs, lens, rids, padding, out_mm, out_off);
     pgr_batch *b = nullptr;
     if ((rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b))) return rc;
     pgr_shmmrs *s = nullptr;

@@ -265,6 +265,11 @@ extern "C" int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *ix, uint32_t n, cons
                                    const uint32_t *sids) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
+    if (n && (!seqs || !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (worth_pipelining(n, lens))  // stage the next ~Gbp while this one is turned into records (running sids keep order)
+        return for_each_staged(ctx, n, seqs, lens, [&](pgr_batch *sb, uint32_t c0, uint32_t) {
+            return pgr_index_add_resident(ctx, ix, sb, sids ? sids + c0 : nullptr);
+        });
     pgr_batch *b = nullptr;
     int rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b);
     if (rc) return rc;

@@ -1,6 +1,7 @@
 // pgr_ctx.h -- the context object behind the C ABI: one GPU, one stream, grow-only workspaces and a
 // small caching device allocator (so the steady state of repeated calls does no hipMalloc/hipFree).
 #pragma once
+#include <functional>
 #include <map>
 #include <string>
 
@@ -57,6 +58,13 @@ struct pgr_ctx {
     int d2h(void *dst, const void *src_dev, size_t bytes);
     void release_all();
 };
+
+namespace pgr {
+// host inputs of >= 512 Mbp: contigs [c0, c1) are staged on the copy stream while the previous range is consumed
+bool worth_pipelining(uint32_t n, const uint64_t *lens);
+int for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                    const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume);
+}  // namespace pgr
 
 #define PGR_HIP(ctx, expr)                                                                                   \
     do {                                                                                                     \

@@ -480,3 +480,34 @@ def test_pangenome_config4_index_and_query(oracle, gpu_ctx):
             assert got_h == ref_h
             n_chains += sum(len(c) for _, c in ref_h)
     assert n_chains > 96
+
+
+def test_index_from_large_host_batch_pipelined(oracle, gpu_ctx):
+    """pgr_index_add_batch stages large host inputs (>= 512 Mbp) sub-batch by sub-batch on a second stream: same
+    records as the single-batch path, for explicit and for running sequence ids"""
+    import ctypes as C
+    import pgrtk_amd as P
+    from pgrtk_amd import _ffi
+    rng = np.random.default_rng(43)
+    lens = [int(x) for x in rng.integers(5_000_000, 40_000_000, 28)]
+    seqs = [oracle.synth_contig(10, i, L).tobytes() for i, L in enumerate(lens)]
+    assert sum(lens) > 560_000_000
+
+    def build(sids):
+        ix = P.Index(P.make_spec(80, 56, 4, 64), ctx=gpu_ctx)
+        ix.add_seqs(seqs, sids=sids)
+        ix.finalize()
+        r = ix.download()
+        ix.close()
+        return r
+    for sids in (None, [int(x) for x in rng.permutation(len(seqs)) + 5]):
+        os.environ.pop("PGR_NO_PIPELINE", None)
+        a = build(sids)
+        os.environ["PGR_NO_PIPELINE"] = "1"
+        try:
+            b = build(sids)
+        finally:
+            os.environ.pop("PGR_NO_PIPELINE", None)
+        assert len(a) == len(b) > 1_000_000
+        for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+            assert np.array_equal(a[f], b[f]), f
