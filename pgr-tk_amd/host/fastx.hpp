@@ -55,15 +55,14 @@ inline std::vector<SeqRec> read_fastx(const std::string &path) {
             SeqRec r;
             r.name = first_token(h, nl ? nl : end);
             const char *q = nl ? nl + 1 : end;
-            // body until "\n>" (a '>' at the start of a line)
-            while (q < end) {
+            // body: every line up to the next one that starts with '>'
+            while (q < end && *q != '>') {
                 const char *ln = (const char *)memchr(q, '\n', (size_t)(end - q));
                 const char *le = ln ? ln : end;
                 const char *ce = le;
                 while (ce > q && ce[-1] == '\r') --ce;
                 r.seq.append(q, ce);
                 q = ln ? ln + 1 : end;
-                if (q < end && *q == '>') break;
             }
             out.push_back(std::move(r));
             p = q;

@@ -381,8 +381,12 @@ def test_cpp_host_programs_match_python_cli(oracle, gpu_ctx, golden_dir, tmp_pat
     fq = tmp_path / "extra.fq"   # a FASTQ input next to the FASTA one
     recs = oracle.read_fasta(fa)
     fq.write_text("".join("@r%d x\n%s\n+\n%s\n" % (i, recs[i][1][:2500].decode(), "I" * len(recs[i][1][:2500])) for i in (3, 9)))
+    import gzip
+    fgz = tmp_path / "some.fa.gz"   # gzip input, CRLF line ends, a record without sequence
+    with gzip.open(fgz, "wb") as f:
+        f.write(b">g0 first\r\n" + recs[12][1][:1500] + b"\r\n" + recs[12][1][1500:4000] + b"\r\n>empty\r\n>g1\r\n" + recs[13][1][:3000] + b"\n")
     lst = tmp_path / "list.txt"
-    lst.write_text(fa + "\n" + str(fq) + "\n")
+    lst.write_text(fa + "\n" + str(fq) + "\n" + str(fgz) + "\n")
     py, cc = str(tmp_path / "py"), str(tmp_path / "cc")
     for args in ([], ["-w", "48", "-k", "56", "-r", "4", "-m", "12"], ["--reference-sid-quirk"]):
         cli.main(["mdb", str(lst), py] + args)
