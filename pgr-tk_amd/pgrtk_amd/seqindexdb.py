@@ -54,17 +54,20 @@ def _unpack_hps(res, n_queries):
     hps = np.zeros(nh, dtype=HITPAIR)
     if nh:
         C.memmove(hps.ctypes.data, res.hps, nh * HITPAIR.itemsize)
+    # all hit pairs as Python tuples in one go (column lists zipped at C speed), then sliced per chain
+    if nh:
+        pairs = list(zip(zip(hps["qb"].tolist(), hps["qe"].tolist(), hps["qo"].tolist()),
+                         zip(hps["tb"].tolist(), hps["te"].tolist(), hps["to"].tolist())))
+    else:
+        pairs = []
+    q_off, t_off, c_off = q_off.tolist(), t_off.tolist(), c_off.tolist()
+    t_sid, c_score = t_sid.tolist(), c_score.tolist()
     out = []
     for q in range(n_queries):
         targets = []
-        for t in range(int(q_off[q]), int(q_off[q + 1])):
-            chains = []
-            for c in range(int(t_off[t]), int(t_off[t + 1])):
-                hp = hps[int(c_off[c]):int(c_off[c + 1])]
-                chains.append((float(c_score[c]),
-                               [((int(h["qb"]), int(h["qe"]), int(h["qo"])), (int(h["tb"]), int(h["te"]), int(h["to"])))
-                                for h in hp]))
-            targets.append((int(t_sid[t]), chains))
+        for t in range(q_off[q], q_off[q + 1]):
+            chains = [(c_score[c], pairs[c_off[c]:c_off[c + 1]]) for c in range(t_off[t], t_off[t + 1])]
+            targets.append((t_sid[t], chains))
         out.append(targets)
     return out
 
