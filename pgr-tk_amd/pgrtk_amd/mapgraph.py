@@ -77,7 +77,8 @@ def _unpack_bundles(b, with_id):
         C.memmove(verts.ctypes.data, b.vertices, verts.nbytes)
     out = []
     for i in range(nb):
-        path = [(int(v["h0"]), int(v["h1"]), int(v["orient"])) for v in verts[int(off[i]):int(off[i + 1])]]
+        seg = verts[int(off[i]):int(off[i + 1])]
+        path = list(zip(seg["h0"].tolist(), seg["h1"].tolist(), seg["orient"].tolist()))
         out.append((int(b.bundle_id[i]), int(b.mean_ord[i]), path) if with_id else path)
     return out
 
@@ -102,9 +103,14 @@ def principal_bundles_from_adj(ctx, adj, path_len_cutoff):
 
 
 def _smps_to_tuples(smps):
-    return [((int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])),
-             None if r["bundle_id"] < 0 else (int(r["bundle_id"]), int(r["bundle_dir"]), int(r["bundle_pos"])))
-            for r in smps]
+    """annotated shimmer pairs -> [((h0,h1,p0,p1,orientation), (bundle id, direction, position) | None)], columns
+    converted and zipped at C speed"""
+    if len(smps) == 0:
+        return []
+    pairs = zip(smps["h0"].tolist(), smps["h1"].tolist(), smps["bgn"].tolist(), smps["end"].tolist(), smps["orient"].tolist())
+    infos = [None if b < 0 else (b, d, p) for b, d, p in
+             zip(smps["bundle_id"].tolist(), smps["bundle_dir"].tolist(), smps["bundle_pos"].tolist())]
+    return list(zip(pairs, infos))
 
 
 def bundle_decomposition(ctx, ix, min_count, path_len_cutoff, keeps=None):

@@ -327,7 +327,9 @@ class SeqIndexDB:
     def get_smp_adj_list(self, min_count, keeps=None):
         """lib.rs:893-919 -> seq_db::frag_map_to_adj_list: [(sid, (h0,h1,o), (h0,h1,o))]"""
         a = mapgraph.adj_list_records(self.ctx, self._ix, min_count, keeps)
-        return [(int(r["sid"]), mapgraph._vtuple(r["v"]), mapgraph._vtuple(r["w"])) for r in a]
+        v, w = a["v"], a["w"]
+        return list(zip(a["sid"].tolist(), zip(v["h0"].tolist(), v["h1"].tolist(), v["orient"].tolist()),
+                        zip(w["h0"].tolist(), w["h1"].tolist(), w["orient"].tolist())))
 
     def sort_adj_list_by_weighted_dfs(self, adj_list, start):
         """lib.rs:938-985: [(node, parent, weight, is_leaf, global_rank, branch, branch_rank)]"""
