@@ -124,6 +124,26 @@ SYMBOLS = [s[0] for s in _SIGS]
 _lib = None
 
 
+def _share_torch_hip_runtime():
+    """PyTorch wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, no soname); libpgrhip.so links the
+    system one.  Two runtimes in one process only work when torch's initialises first -- otherwise torch.cuda finds no
+    device later.  When torch is installed, load ITS runtime globally before libpgrhip.so: the library then binds to
+    it, the process has one runtime, and the import order of torch and this package stops mattering.
+    (PGR_NO_TORCH_PRELOAD=1 keeps the system runtime.)"""
+    if os.environ.get("PGR_NO_TORCH_PRELOAD"):
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.origin:
+            return
+        rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(rt):
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+    except Exception:
+        pass  # no torch, or an unusual install: the system runtime is used
+
+
 def lib():
     """load libpgrhip.so; raises if it has not been built (no silent fallback)."""
     global _lib
@@ -131,6 +151,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise ImportError("libpgrhip.so not built: run `python __graft_entry__.py build` "
                               "(make -C pgr-tk_amd); expected at " + LIB_PATH)
+        _share_torch_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, res, args in _SIGS:
             f = getattr(L, name)  # AttributeError if a declared symbol is missing

@@ -9,16 +9,8 @@ Rows are int64 tensors [n, words] (MM_WORDS or REC_WORDS).
 
 torch is plumbing here (device memory + the collective); no compute.
 """
-import sys
-
-from . import _ffi
-
-if "torch" not in sys.modules and _ffi._lib is not None:
-    raise ImportError("pgrtk_amd.exchange: import torch BEFORE the first pgrtk_amd call that loads libpgrhip.so -- torch "
-                      "bundles its own HIP runtime, which must initialise before the system runtime libpgrhip.so links "
-                      "against (the other order leaves torch.cuda without devices)")
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
+import torch
+import torch.distributed as dist
 
 REC_WORDS = 5  # one pgr_frag_rec = 40 bytes = 5 x int64
 MM_WORDS = 2   # one MM128 = 16 bytes = 2 x int64 (what the ranks exchange: pairs are adjacent shimmers)

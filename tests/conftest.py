@@ -4,9 +4,8 @@ import sys
 import pytest
 
 try:
-    # torch bundles its own copy of the HIP runtime; it has to initialise BEFORE libpgrhip.so pulls in the system
-    # runtime (/opt/rocm), or torch.cuda finds no device later in the same process (the other order is fine).
-    # Tests that use torch (multi-GPU exchange) therefore need it imported first.
+    # torch bundles its own copy of the HIP runtime.  pgrtk_amd._ffi.lib() binds libpgrhip.so to it,
+    # so the order no longer matters; importing torch first keeps the tests independent of that mechanism.
     import torch  # noqa: F401
 except ImportError:
     pass
