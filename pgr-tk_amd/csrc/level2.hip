@@ -166,7 +166,7 @@ struct FusedLdsT {
 
 // Ordered compaction for lane-strided items k = j*256 + t (consecutive lanes <-> consecutive elements, so
 // the neighbour reads of the predicates are LDS-conflict free).  keep[j] per lane -> rank of every kept item
-// in k order.  Two barriers per call; `ballots` come back for the caller's popcount.
+// in k order.  One barrier per call.
 template <int CM, class FusedLds>
 __device__ __forceinline__ void strided_ranks(FusedLds &L, const bool (&keep)[CM], int C, uint32_t (&rank)[CM],
                                               uint32_t *total) {
@@ -179,19 +179,20 @@ __device__ __forceinline__ void strided_ranks(FusedLds &L, const bool (&keep)[CM
         if (j < C && lane == 0) L.cnt[j][wv] = (uint32_t)__popcll(bal[j]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t acc = 0;
-        for (int j = 0; j < C; ++j)
-            for (int v = 0; v < FUSED_T / 64; ++v) {
-                L.base[j][v] = acc;
-                acc += L.cnt[j][v];
-            }
-        L.total = acc;
-    }
-    __syncthreads();
+    // every lane adds up the (j, wave) counts that precede its own in (j, wave) order: 4 C broadcast LDS reads
+    // instead of a serial prefix by one thread between two more barriers
+    uint32_t acc = 0;
 #pragma unroll
-    for (int j = 0; j < CM; ++j) rank[j] = (j < C) ? L.base[j][wv] + (uint32_t)__popcll(bal[j] & lt) : 0u;
-    *total = L.total;
+    for (int j = 0; j < CM; ++j) {
+        rank[j] = 0u;
+        if (j >= C) continue;
+#pragma unroll
+        for (int v = 0; v < FUSED_T / 64; ++v) {
+            if (v == (int)wv) rank[j] = acc + (uint32_t)__popcll(bal[j] & lt);
+            acc += L.cnt[j][v];
+        }
+    }
+    *total = acc;  // (L.cnt is only rewritten after the barrier every caller places behind its list writes)
 }
 
 // reduce predicate on an indexed LDS list: list[k] -> element index e; neighbours must share the contig id.
