@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
+#include <unistd.h>
 
 #include "pgr_index.h"
 #include "pgr_device.h"
@@ -1303,27 +1305,32 @@ extern "C" int pgr_index_write_mdb(pgr_ctx *ctx, const pgr_index *ix, const char
     uint64_t n = 0;
     int rc = pgr_index_download(ctx, ix, &recs, &n);
     if (rc) return rc;
-    FILE *f = fopen(path, "wb");
+    // written to "<path>.tmp.<pid>" and renamed on success: a failed or short write (disk full, quota) never leaves
+    // a truncated .mdb under the final name
+    const std::string tmp_path = std::string(path) + ".tmp." + std::to_string((long)getpid());
+    FILE *f = fopen(tmp_path.c_str(), "wb");
     if (!f) {
         free(recs);
-        return ctx->fail(PGR_ERR_INVALID_ARG, std::string("cannot open for writing: ") + path);
+        return ctx->fail(PGR_ERR_INVALID_ARG, std::string("cannot open for writing: ") + tmp_path);
     }
     std::vector<uint8_t> buf;
     buf.reserve(1 << 20);
+    bool ok = true;
+    auto flush = [&]() {
+        if (!buf.empty() && ok) ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+        buf.clear();
+    };
     auto put = [&](const void *p, size_t len) {
         const uint8_t *b = (const uint8_t *)p;
         buf.insert(buf.end(), b, b + len);
-        if (buf.size() >= (1 << 20)) {
-            fwrite(buf.data(), 1, buf.size(), f);
-            buf.clear();
-        }
+        if (buf.size() >= (1 << 20)) flush();
     };
     put("mdb", 3);
     const uint32_t hdr[5] = {ix->spec.w, ix->spec.k, ix->spec.r, ix->spec.min_span, ix->spec.sketch ? 1u : 0u};
     put(hdr, sizeof(hdr));
     const uint64_t nk = ix->n_keys;
     put(&nk, 8);
-    for (uint64_t i = 0; i < n;) {
+    for (uint64_t i = 0; i < n && ok;) {
         uint64_t j = i;
         while (j < n && recs[j].h0 == recs[i].h0 && recs[j].h1 == recs[i].h1) ++j;
         const uint64_t head[3] = {recs[i].h0, recs[i].h1, j - i};
@@ -1336,10 +1343,16 @@ extern "C" int pgr_index_write_mdb(pgr_ctx *ctx, const pgr_index *ix, const char
         }
         i = j;
     }
-    if (!buf.empty()) fwrite(buf.data(), 1, buf.size(), f);
-    const bool ok = fclose(f) == 0;
+    flush();
+    ok = ok && !ferror(f);
+    ok = (fclose(f) == 0) && ok;
     free(recs);
-    return ok ? PGR_OK : ctx->fail(PGR_ERR_INVALID_ARG, std::string("write failed: ") + path);
+    if (ok && rename(tmp_path.c_str(), path) != 0) ok = false;
+    if (!ok) {
+        (void)remove(tmp_path.c_str());
+        return ctx->fail(PGR_ERR_INVALID_ARG, std::string("write failed: ") + path);
+    }
+    return PGR_OK;
 }
 
 extern "C" int pgr_index_load_mdb(pgr_ctx *ctx, const char *path, pgr_index **out) {
@@ -1364,20 +1377,24 @@ extern "C" int pgr_index_load_mdb(pgr_ctx *ctx, const char *path, pgr_index **ou
     pgr_index *ix = nullptr;
     int rc = pgr_index_create(ctx, &spec, &ix);
     if (rc) return rc;
+    // the lengths stored in the file are not trusted: every count is checked against the bytes that are really
+    // there, without multiplying (a huge count must not wrap the bound)
+    auto bad = [&](const char *what) {
+        pgr_index_destroy(ix);
+        return ctx->fail(PGR_ERR_INVALID_ARG, std::string(what) + ": " + path);
+    };
+    if (nk > (d.size() - 31) / 24) return bad("truncated .mdb (key count exceeds the file size)");
     std::vector<pgr_frag_rec> recs;
+    recs.reserve((d.size() - 31) / 17);
     size_t off = 31;
+    uint32_t max_sid = 0;
     for (uint64_t kx = 0; kx < nk; ++kx) {
-        if (off + 24 > d.size()) {
-            pgr_index_destroy(ix);
-            return ctx->fail(PGR_ERR_INVALID_ARG, "truncated .mdb");
-        }
+        if (d.size() - off < 24) return bad("truncated .mdb");
         uint64_t head[3];
         memcpy(head, d.data() + off, 24);
         off += 24;
-        if (off + head[2] * 17 > d.size()) {
-            pgr_index_destroy(ix);
-            return ctx->fail(PGR_ERR_INVALID_ARG, "truncated .mdb");
-        }
+        if (head[2] > (d.size() - off) / 17) return bad("truncated .mdb");
+        if (recs.size() + head[2] >= (1ull << 32)) return bad(".mdb holds 2^32 or more fragment signatures");
         for (uint64_t t = 0; t < head[2]; ++t) {
             uint32_t q[4];
             memcpy(q, d.data() + off, 16);
@@ -1391,6 +1408,7 @@ extern "C" int pgr_index_load_mdb(pgr_ctx *ctx, const char *path, pgr_index **ou
             r.orient = d[off + 16];
             r._pad = 0;
             recs.push_back(r);
+            max_sid = std::max(max_sid, r.sid);
             off += 17;
         }
     }
@@ -1400,9 +1418,7 @@ extern "C" int pgr_index_load_mdb(pgr_ctx *ctx, const char *path, pgr_index **ou
         pgr_index_destroy(ix);
         return rc;
     }
-    uint32_t mx = 0;
-    for (const auto &r : recs) mx = std::max(mx, r.sid + 1);
-    ix->next_sid = mx;
+    ix->next_sid = recs.empty() ? 0u : (max_sid == 0xFFFFFFFFu ? max_sid : max_sid + 1);  // no wrap at u32::MAX
     *out = ix;
     return PGR_OK;
 }

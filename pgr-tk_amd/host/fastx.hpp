@@ -1,12 +1,21 @@
 // fastx.hpp -- FASTA / FASTQ (.gz ok, through zlib) with the record semantics of the reference reader
-// (pgr-db/src/fasta_io.rs: id = header up to the first space :94-101, sequence bytes kept as they are,
-// line ends dropped :102-106).  Host-side sequence iteration stays with the caller of the C ABI.
+// (pgr-db/src/fasta_io.rs:46-165), INCLUDING its quirks, because sids, .midx lines and query indices follow from them:
+//   * the first byte of the file decides the format ('@' = FASTQ, anything else = FASTA) and is consumed (:54-68);
+//   * FASTA (:86-119): header = the rest of the line, id = header up to the first ' ' minus '\n' ' ' '\r'; the sequence is
+//     every byte up to the next '>' ANYWHERE (not only at a line start), minus '\n' '>' '\r' (so '\r' is dropped
+//     everywhere, and a '>' inside a sequence line starts a new record whose header is the rest of that line);
+//   * FASTQ (:121-164): id line, sequence line, skip through the next '+', the rest of that line, the quality line,
+//     then everything through the next '@'; when that last step reads nothing (end of file right after the quality
+//     line) the record is DROPPED -- the reference loses the final record of a FASTQ file that ends after its last
+//     quality line; a trailing blank line keeps it.
+// Host-side sequence iteration stays with the caller of the C ABI.
 #pragma once
 #include <zlib.h>
 
 #include <cstring>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace pgrhost {
@@ -35,57 +44,57 @@ inline std::string slurp(const std::string &path) {
     return data;
 }
 
-inline std::string first_token(const char *b, const char *e) {
-    while (e > b && (e[-1] == '\r')) --e;
-    const char *p = b;
-    while (p < e && *p != ' ') ++p;
-    return std::string(b, p);
+// BufRead::read_until on an in-memory file: bytes [pos, first delim] (delimiter included), pos moves past them
+inline std::pair<const char *, const char *> read_until(const std::string &d, size_t &pos, char delim) {
+    const char *b = d.data() + pos, *end = d.data() + d.size();
+    const char *q = (pos < d.size()) ? (const char *)memchr(b, delim, (size_t)(end - b)) : nullptr;
+    const char *e = q ? q + 1 : end;
+    pos = (size_t)(e - d.data());
+    return {b, e};
+}
+
+inline std::string record_id(const char *b, const char *e) {  // fasta_io.rs:94-101
+    std::string id;
+    for (const char *p = b; p < e; ++p) {
+        if (*p == ' ') break;
+        if (*p != '\n' && *p != '\r') id.push_back(*p);
+    }
+    return id;
 }
 
 inline std::vector<SeqRec> read_fastx(const std::string &path) {
     const std::string data = slurp(path);
     std::vector<SeqRec> out;
-    if (data.empty()) return out;
-    const char *p = data.data(), *end = p + data.size();
-    if (*p == '>') {
-        while (p < end) {
-            // p at '>' of a record
-            const char *h = p + 1;
-            const char *nl = (const char *)memchr(h, '\n', (size_t)(end - h));
+    if (data.empty()) throw std::runtime_error("empty file: " + path);  // fasta_io.rs:58-63
+    const bool fastq = data[0] == '@';
+    size_t pos = 1;  // the format byte is consumed
+    if (!fastq) {
+        for (;;) {
+            const auto h = read_until(data, pos, '\n');
+            if (h.first == h.second) break;  // read_until returned 0: end of file
             SeqRec r;
-            r.name = first_token(h, nl ? nl : end);
-            const char *q = nl ? nl + 1 : end;
-            // body: every line up to the next one that starts with '>'
-            while (q < end && *q != '>') {
-                const char *ln = (const char *)memchr(q, '\n', (size_t)(end - q));
-                const char *le = ln ? ln : end;
-                const char *ce = le;
-                while (ce > q && ce[-1] == '\r') --ce;
-                r.seq.append(q, ce);
-                q = ln ? ln + 1 : end;
-            }
-            out.push_back(std::move(r));
-            p = q;
-        }
-    } else if (*p == '@') {
-        std::vector<std::pair<const char *, const char *>> lines;
-        while (p < end) {
-            const char *ln = (const char *)memchr(p, '\n', (size_t)(end - p));
-            lines.emplace_back(p, ln ? ln : end);
-            p = ln ? ln + 1 : end;
-        }
-        // four lines per record; a trailing partial record is dropped
-        const size_t n_lines = lines.size() + (data.back() == '\n' ? 1 : 0);  // as if split on '\n'
-        for (size_t i = 0; i + 3 < n_lines; i += 4) {
-            SeqRec r;
-            r.name = first_token(lines[i].first + 1, lines[i].second);
-            const char *b = lines[i + 1].first, *e = lines[i + 1].second;
-            while (e > b && e[-1] == '\r') --e;
-            r.seq.assign(b, e);
+            r.name = record_id(h.first, h.second);
+            const auto b = read_until(data, pos, '>');
+            r.seq.reserve((size_t)(b.second - b.first));
+            for (const char *p = b.first; p < b.second; ++p)
+                if (*p != '\n' && *p != '>' && *p != '\r') r.seq.push_back(*p);
             out.push_back(std::move(r));
         }
     } else {
-        throw std::runtime_error("not a FASTA/FASTQ file: " + path);
+        for (;;) {
+            const auto h = read_until(data, pos, '\n');
+            SeqRec r;
+            r.name = record_id(h.first, h.second);
+            const auto b = read_until(data, pos, '\n');
+            for (const char *p = b.first; p < b.second; ++p)
+                if (*p != '\n' && *p != '\r') r.seq.push_back(*p);
+            (void)read_until(data, pos, '+');
+            (void)read_until(data, pos, '\n');
+            (void)read_until(data, pos, '\n');
+            const auto t = read_until(data, pos, '@');
+            if (t.first == t.second) break;  // fasta_io.rs:159-162: the record read last is dropped
+            out.push_back(std::move(r));
+        }
     }
     return out;
 }

@@ -90,13 +90,22 @@ int main(int argc, char **argv) {
     }
     if ((rc = pgr_index_finalize(ctx, ix))) die(ctx, "pgr_index_finalize", rc);
     if ((rc = pgr_index_write_mdb(ctx, ix, (pos[1] + ".mdb").c_str()))) die(ctx, "pgr_index_write_mdb", rc);
-    FILE *f = fopen((pos[1] + ".midx").c_str(), "w");  // seq_db.rs:798-805
-    if (!f) {
-        fprintf(stderr, "pgr-mdb: can't write %s.midx\n", pos[1].c_str());
-        return 1;
+    {  // seq_db.rs:798-805; written to a temporary name and renamed, every write checked
+        const std::string final_path = pos[1] + ".midx", tmp_path = final_path + ".tmp";
+        FILE *f = fopen(tmp_path.c_str(), "w");
+        bool ok = f != nullptr;
+        for (size_t i = 0; ok && i < midx.size(); ++i) {
+            const Midx &m = midx[i];
+            ok = fprintf(f, "%u\t%zu\t%s\t%s\n", m.sid, m.len, m.name.c_str(), m.src.c_str()) >= 0;
+        }
+        if (f) ok = (fclose(f) == 0) && ok;
+        if (ok) ok = rename(tmp_path.c_str(), final_path.c_str()) == 0;
+        if (!ok) {
+            (void)remove(tmp_path.c_str());
+            fprintf(stderr, "pgr-mdb: can't write %s\n", final_path.c_str());
+            return 1;
+        }
     }
-    for (const Midx &m : midx) fprintf(f, "%u\t%zu\t%s\t%s\n", m.sid, m.len, m.name.c_str(), m.src.c_str());
-    fclose(f);
     fprintf(stderr, "%zu sequences, %llu shimmer pairs, %llu keys -> %s.mdb / .midx\n", midx.size(),
             (unsigned long long)pgr_index_n_records(ix), (unsigned long long)pgr_index_n_keys(ix), pos[1].c_str());
     pgr_index_destroy(ix);

@@ -16,30 +16,47 @@ from .engine import frag_recs_batch, make_spec
 
 
 def read_fastx(filepath):
-    """FASTA / FASTQ (.gz ok) with the reference reader's record semantics (pgr-db/src/fasta_io.rs:
-    id = header up to the first space :94-101, sequence bytes kept as they are, newlines dropped
-    :102-106).  Returns [(name: str, seq: bytes)]."""
+    """FASTA / FASTQ (.gz ok) with the reference reader's record semantics, quirks included (pgr-db/src/fasta_io.rs:46-165;
+    the same emulation as host/fastx.hpp): the first byte picks the format ('@' FASTQ, anything else FASTA) and is consumed;
+    FASTA id = header up to the first space, the sequence runs to the next '>' ANYWHERE and drops '\\n' '>' '\\r'; FASTQ
+    drops the record read last when the file ends right after its quality line (:159-162).  Returns [(name, seq bytes)]."""
     opener = gzip.open if filepath.endswith(".gz") else open
-    recs = []
     with opener(filepath, "rb") as f:
         data = f.read()
     if not data:
-        return recs
-    if data[:1] == b">":
-        for chunk in data.split(b"\n>"):
-            chunk = chunk[1:] if chunk[:1] == b">" else chunk
-            nl = chunk.find(b"\n")
-            head = chunk if nl < 0 else chunk[:nl]
-            body = b"" if nl < 0 else chunk[nl + 1:]
-            name = head.rstrip(b"\r").split(b" ")[0]
-            recs.append((name.decode("utf-8", "replace"), body.replace(b"\n", b"").replace(b"\r", b"")))
-    elif data[:1] == b"@":
-        lines = data.split(b"\n")
-        for i in range(0, len(lines) - 3, 4):
-            recs.append((lines[i][1:].rstrip(b"\r").split(b" ")[0].decode("utf-8", "replace"),
-                         lines[i + 1].rstrip(b"\r")))
+        raise ValueError("empty file: " + filepath)
+    n = len(data)
+    pos = 1
+
+    def read_until(delim):  # BufRead::read_until: bytes through the delimiter (included)
+        nonlocal pos
+        q = data.find(delim, pos) if pos < n else -1
+        e = n if q < 0 else q + 1
+        out = data[pos:e]
+        pos = e
+        return out
+
+    def rec_id(head):
+        return head.split(b" ", 1)[0].replace(b"\n", b"").replace(b"\r", b"").decode("utf-8", "replace")
+
+    recs = []
+    if data[:1] != b"@":
+        while True:
+            head = read_until(b"\n")
+            if not head:
+                break
+            body = read_until(b">")
+            recs.append((rec_id(head), body.replace(b"\n", b"").replace(b">", b"").replace(b"\r", b"")))
     else:
-        raise ValueError("not a FASTA/FASTQ file: " + filepath)
+        while True:
+            head = read_until(b"\n")
+            seq = read_until(b"\n").replace(b"\n", b"").replace(b"\r", b"")
+            read_until(b"+")
+            read_until(b"\n")
+            read_until(b"\n")
+            if not read_until(b"@"):
+                break
+            recs.append((rec_id(head), seq))
     return recs
 
 
@@ -448,6 +465,6 @@ class SeqIndexDB:
                 blk["orient"] = recs["orient"][s:e]
                 f.write(blk.tobytes())
         with open(prefix + ".midx", "w") as f:
-            for sid in range(self._n_seqs):
+            for sid in sorted(self.seq_info):  # an .midx may hold sparse sids (multi-file indexes, the sid quirk)
                 name, source, ln = self.seq_info[sid]
                 f.write("%d\t%d\t%s\t%s\n" % (sid, ln, name, source if source is not None else "-"))

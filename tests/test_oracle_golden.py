@@ -91,3 +91,102 @@ def test_sparse_aln_runs_g5(oracle, golden_dir):
             assert hp not in seen
             seen.add(hp)
     assert len(seen) == len({tuple(int(v) for v in r) for r in h})
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Chaining has no expected output in the reference (aln.rs:484): the strongest pin available without rustc is two
+# restatements written separately that agree.  oracle/pgr_oracle.c (C, arrays) vs oracle/aln_second_reading.py (pure
+# Python from the Rust text, dicts / sets keyed by value, numpy float32).
+def _chains_equal(c_chains, py_chains):
+    """same chains in the same extraction order, scores bit-identical as f32"""
+    assert len(c_chains) == len(py_chains)
+    for (sc, hc), (sp, hp) in zip(c_chains, py_chains):
+        assert np.float32(sc).tobytes() == np.float32(sp).tobytes(), (sc, sp)
+        assert [tuple(h) for h in hc] == [h[0] + h[1] for h in hp]
+
+
+def _load_test_hits(golden_dir):
+    h = np.loadtxt(os.path.join(golden_dir, "test_hits"), dtype=np.uint32)
+    return [((int(r[0]), int(r[1]), int(r[2])), (int(r[3]), int(r[4]), int(r[5]))) for r in h]
+
+
+def test_sparse_aln_two_independent_readings_on_test_hits(oracle, golden_dir):
+    import aln_second_reading as A2
+    hits = _load_test_hits(golden_dir)
+    flat = [a + b for a, b in hits]
+    # the reference's own call (aln.rs:481), pgr-query's defaults, and two runs that exercise max_gap / orientation
+    for max_span, penalty, max_gap, oriented in [(8, 0.5, None, False), (8, 0.025, None, False), (3, 0.1, 50000, True),
+                                                 (16, 0.025, 2000, False)]:
+        c = oracle.sparse_aln(flat, max_span, penalty, max_gap, oriented)
+        p = A2.sparse_aln(hits, max_span, penalty, max_gap, oriented)
+        _chains_equal(c, p)
+        # and as canonically sorted sets (what survives any tie-break order)
+        assert sorted((tuple(map(tuple, hc))) for _, hc in c) == sorted(tuple(h[0] + h[1] for h in hp) for _, hp in p)
+
+
+def test_sparse_aln_two_independent_readings_on_random_groups(oracle):
+    import aln_second_reading as A2
+    rng = np.random.default_rng(20260928)
+    for case in range(200):
+        n = int(rng.integers(2, 60))
+        colinear = case % 3 != 0
+        hits = []
+        q = int(rng.integers(1, 500))
+        for _ in range(n):
+            ql = int(rng.integers(20, 400))
+            if colinear:
+                t = q + int(rng.integers(-300, 300)) + 100000
+            else:
+                t = int(rng.integers(1, 200000))
+            o = int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            hits.append(((q, q + ql, o[0]), (max(1, t), max(1, t) + ql + int(rng.integers(-5, 6)) + 5, o[1])))
+            if rng.random() < 0.15:  # the same query interval on another target interval
+                hits.append(((q, q + ql, o[0]), (max(1, t) + 5000, max(1, t) + 5000 + ql, o[1])))
+            if rng.random() < 0.7:
+                q += int(rng.integers(0, 600))
+        rng.shuffle(hits)
+        hits = [tuple(map(tuple, h)) for h in hits]
+        if len(set(hits)) < len(hits):  # duplicated hit pairs can make the predecessor map cyclic: defined separately
+            hits = list(dict.fromkeys(hits))
+        if len(hits) < 2:
+            continue
+        max_span = int(rng.integers(1, 12))
+        penalty = float(rng.choice([0.0, 0.025, 0.5, 1.5]))
+        max_gap = None if rng.random() < 0.5 else int(rng.integers(100, 5000))
+        oriented = bool(rng.integers(0, 2))
+        c = oracle.sparse_aln([a + b for a, b in hits], max_span, penalty, max_gap, oriented)
+        p = A2.sparse_aln(hits, max_span, penalty, max_gap, oriented)
+        _chains_equal(c, p)
+
+
+def test_query_fragment_to_hps_two_independent_readings(oracle, test_seqs):
+    """raw_query_fragment + count filters + chaining (seq_db.rs:1200-1228, aln.rs:147-242): the C oracle's index and
+    query against the dict-of-lists reading, on the reference's own test sequences (repeat rich: the count filters fire)"""
+    import aln_second_reading as A2
+    sp = oracle.spec(80, 56, 4, 64)
+    seqs = [s for _, s in test_seqs]
+    ix = oracle.Index(sp)
+    frag_map = {}
+    for sid, s in enumerate(seqs):
+        ix.add_seq(sid, s)
+        for r in oracle.frag_recs(oracle.sequence_to_shmmrs(sid, s, sp), sid):
+            frag_map.setdefault((int(r["h0"]), int(r["h1"])), []).append(
+                (int(r["frg_id"]), int(r["sid"]), int(r["bgn"]), int(r["end"]), int(r["orient"])))
+    ix.finalize()
+    rng = np.random.default_rng(7)
+    n_checked = 0
+    for case in range(24):
+        src = seqs[int(rng.integers(0, len(seqs)))]
+        a = int(rng.integers(0, max(1, len(src) - 1500)))
+        q = src[a:a + int(rng.integers(800, 3000))]
+        kw = [dict(), dict(max_count=2, query_max_count=2, target_max_count=2), dict(max_aln_span=2, oriented=True),
+              dict(max_gap=500, target_max_count=1)][case % 4]
+        ref = ix.query_fragment_to_hps(q, 0.025, **kw)
+        mm = oracle.sequence_to_shmmrs(0, q, sp)
+        shm = [(int(x) >> 8, (int(y) & 0xFFFFFFFF) >> 1) for x, y in zip(mm["x"], mm["y"])]
+        got = A2.query_fragment_to_hps(A2.raw_query_fragment(frag_map, shm), 0.025, **kw)
+        assert sorted(got) == [sid for sid, _ in ref]
+        for sid, chains in ref:
+            _chains_equal([(sc, hps) for sc, hps in chains], got[sid])
+            n_checked += len(chains)
+    assert n_checked > 100

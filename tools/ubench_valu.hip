@@ -7,16 +7,29 @@
 #include <vector>
 #include <string>
 
-#define ITERS 4096
+__device__ unsigned long long g_cyc[256 * 8 * 4];
+__device__ unsigned long long g_wall[256 * 8 * 4];  // the same interval in ticks of the constant 100 MHz clock  // shader cycles (s_memtime) every wave spent in its loop
+
+#ifndef ITERS
+#define ITERS 32768  // ~2-4 ms per launch: launch overhead and the clock ramp are negligible
+#endif
 #define UNROLL 8
 
 #define KERNEL(name, decl, body)                                            \
     __global__ __launch_bounds__(256) void name(uint32_t *out, uint32_t seed) { \
         decl;                                                               \
+        const unsigned long long c0 = __builtin_readcyclecounter();         \
+        const unsigned long long w0 = wall_clock64();                       \
         for (int it = 0; it < ITERS; ++it) {                                \
             body                                                            \
         }                                                                   \
+        const unsigned long long c1 = __builtin_readcyclecounter();         \
         out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(acc);              \
+        const unsigned long long w1 = wall_clock64();                       \
+        if ((threadIdx.x & 63) == 0) {                                      \
+            g_cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = c1 - c0;           \
+            g_wall[blockIdx.x * 4 + (threadIdx.x >> 6)] = w1 - w0;          \
+        }                                                                   \
     }
 
 // 8 independent chains a0..a7 (32-bit) / q0..q7 (64-bit)
@@ -167,19 +180,35 @@ int main() {
         hipMemcpy(hc, dc, 24, hipMemcpyDeviceToHost);
         printf("clock calibration: %llu shader cycles, %llu wall ticks in %.3f ms -> shader %.0f MHz, wall %.0f MHz\n", hc[0], hc[1], ms, hc[0] / ms / 1e3, hc[1] / ms / 1e3);
     }
-    printf("%-34s %10s %14s\n", "sequence", "ms", "cyc/seq/SIMD");
+    printf("8 waves per SIMD, 8 independent chains per wave, %d iterations.  cyc(nominal) = HIP-event time x nominal clock /\n"
+           "sequences per SIMD.  cyc(memtime) = mean s_memtime ticks a wave spent in its loop / (sequences per wave x 8 waves).\n"
+           "memtime MHz = s_memtime ticks per second of the constant 100 MHz wall clock, read by the same waves around the\n"
+           "same loop: the rate s_memtime really ran at.  The authoritative cycle count is the PMC one: run this binary under\n"
+           "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_VALU and divide (GRBM_GUI_ACTIVE / 8 XCDs) by (SQ_INSTS_VALU / 1024 SIMDs)\n"
+           "(tools/ubench_table.py does that).\n", ITERS);
+    printf("%-36s %9s %12s %12s %12s\n", "sequence", "ms", "cyc(nominal)", "cyc(memtime)", "memtime MHz");
     for (auto &c : cases) {
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
         c.fn<<<blocks, 256>>>(d, 12345);  // warm
         hipDeviceSynchronize();
         hipEventRecord(e0);
-        for (int r = 0; r < 3; ++r) c.fn<<<blocks, 256>>>(d, 12345 + r);
+        c.fn<<<blocks, 256>>>(d, 12346);
         hipEventRecord(e1); hipEventSynchronize(e1);
-        float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 3;
+        float ms; hipEventElapsedTime(&ms, e0, e1);
         // sequences issued per SIMD: waves per SIMD * ITERS * per_iter
         const double waves_per_simd = (double)blocks * 4 / (prop.multiProcessorCount * 4);
         const double seqs = waves_per_simd * ITERS * c.per_iter;
-        printf("%-34s %10.3f %14.2f\n", c.name, ms, ms * 1e-3 * clk / seqs);
+        static unsigned long long hc[256 * 8 * 4];
+        hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_cyc), sizeof(hc));
+        double cs = 0;
+        for (int i = 0; i < blocks * 4; ++i) cs += (double)hc[i];
+        static unsigned long long hw[256 * 8 * 4];
+        hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_wall), sizeof(hw));
+        double ws = 0;
+        for (int i = 0; i < blocks * 4; ++i) ws += (double)hw[i];
+        const double cyc_wave = cs / (blocks * 4);
+        const double cyc_mem = cyc_wave / ((double)ITERS * c.per_iter * waves_per_simd);
+        printf("%-36s %9.3f %12.2f %12.2f %12.0f\n", c.name, ms, ms * 1e-3 * clk / seqs, cyc_mem, cs / ws * 100.0);
     }
     return 0;
 }
