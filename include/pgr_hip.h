@@ -106,9 +106,12 @@ int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n_seqs, const uint8_t *const *se
                          const uint64_t *lens, pgr_batch **out);
 /* counter-based synthetic contigs generated on the device:
  * base(c,i) = (splitmix64(seed ^ c*0x9E3779B97F4A7C15 ^ (i>>5)) >> (2*(i&31))) & 3,
- * c = contig0 + index.  Identical to oracle orc_synth_contig.                              */
+ * c = contig0 + index (the CPU checker generates the same bytes).         */
 int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n_seqs, const uint64_t *lens, uint64_t seed,
                         uint64_t contig0, pgr_batch **out);
+/* the same for an arbitrary list of global contig ids (one rank's shard of a partitioned contig set) */
+int pgr_batch_synthetic_ids(pgr_ctx *ctx, uint32_t n_seqs, const uint64_t *lens, uint64_t seed,
+                            const uint64_t *contig_ids, pgr_batch **out);
 void pgr_batch_destroy(pgr_batch *b);
 uint64_t pgr_batch_total_bases(const pgr_batch *b);
 
@@ -122,11 +125,24 @@ const uint64_t *pgr_shmmrs_device_offsets(const pgr_shmmrs *s);
 int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 **out_mm, uint64_t **out_off);
 void pgr_shmmrs_destroy(pgr_shmmrs *s);
 
+/* 128-bit content checksum of every contig's shimmer list, computed on the GPU: out[2c], out[2c+1] (host, 2 * n_seqs
+ * words).  Order sensitive (the ordinal of an element enters) and independent of the rid field; the formula is stated
+ * at shmmr_checksum_kernel (csrc/level2.hip).  Lets a caller -- bench.py, the tests -- compare a full-size result with a
+ * CPU run of the reference algorithm without moving the lists. */
+int pgr_shmmrs_checksum(pgr_ctx *ctx, const pgr_shmmrs *s, uint64_t *out);
+
 /* copy the MM128 list of a resident result into caller-owned DEVICE memory (e.g. a torch tensor that is then
  * all-gathered over RCCL: 16 B per shimmer instead of 40 B per pair record). capacity in elements; rid_add is
  * added to every rid (MM128.y >> 32), turning rank-local contig indices into global sequence ids. */
 int pgr_shmmrs_copy_to_device(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 *d_out, uint64_t capacity,
                               uint32_t rid_add);
+
+/* the same with an explicit rid per contig (rids[i] replaces the contig index i): one rank's shard of a partitioned
+ * contig set carries arbitrary global sequence ids */
+int pgr_shmmrs_copy_to_device_rids(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 *d_out, uint64_t capacity,
+                                   const uint32_t *rids);
+/* host copy of the n_seqs + 1 list offsets of a resident result (no device traffic) */
+int pgr_shmmrs_offsets(const pgr_shmmrs *s, uint64_t *out);
 
 /* device pair records from a resident result; d_out must hold count - n_nonempty records;
  * returns the number written in *n_out.  sids may be NULL.  d_out is a DEVICE pointer
@@ -201,6 +217,11 @@ typedef struct {
     uint64_t *c_off;
     uint64_t n_hps;
     pgr_hitpair *hps;
+    /* (query, target) groups on which the reference's chain extraction never terminates (aln.rs:105-131: every
+     * unvisited hit pair has a non-positive score, e.g. bgn == end).  Such a group keeps the chains extracted up to
+     * that point; the other groups of the batch are unaffected. */
+    uint64_t n_nonterminating;
+    void *_owner; /* the one host block all arrays above live in (released by pgr_hps_result_free) */
 } pgr_hps_result;
 
 int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries,
@@ -208,7 +229,31 @@ int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries,
                         uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
                         uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
                         pgr_hps_result *out);
+/* the same on queries that are already resident on the GPU (pgr_batch_from_ascii): the stages of B2 without the
+ * host -> device copy of the ASCII queries */
+int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const pgr_batch *queries, float penalty,
+                           uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
+                           uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
+                           pgr_hps_result *out);
 void pgr_hps_result_free(pgr_hps_result *r);
+
+/* counts and host-side stage times of the LAST pgr_query_hps_batch / _resident on the context (what bench.py prices the
+ * query leg with: 24 B per hit pair emitted + 0.25 B per query base + 17 B per looked-up signature) */
+typedef struct {
+    uint64_t n_queries, query_bases;
+    uint64_t n_query_pairs; /* shimmer pairs of the queries = index lookups                      */
+    uint64_t n_signatures;  /* fragment signatures under the looked-up keys (before the filters) */
+    uint64_t n_hits;        /* hit pairs after the count filters (input of the chaining)          */
+    uint64_t n_groups;      /* (query, target) groups with >= 2 hits                              */
+    uint64_t n_chains, n_hps;
+    float stage_ms;  /* host time to stage the ASCII queries (pinned copy + enqueue of H2D and pack)   */
+    float shmmr_ms;  /* query shimmers (pgr_shmmrs_compute)                                             */
+    float lookup_ms; /* pair records, index lookup, multiplicities, count filters (1 round trip)       */
+    float chain_ms;  /* hit expansion, sort by (group, qb), sparse_aln, packing, download (2 round trips) */
+    float result_ms; /* host assembly of the flat result                                                */
+    float total_ms;
+} pgr_query_prof;
+int pgr_ctx_last_query_prof(const pgr_ctx *ctx, pgr_query_prof *out);
 
 /* aln::sparse_aln on caller-provided hit pairs (pgr-tk/src/lib.rs:1539 `sparse_aln`):
  * n_groups groups, group g = hits[g_off[g], g_off[g+1]).  Output as above with one
@@ -216,6 +261,34 @@ void pgr_hps_result_free(pgr_hps_result *r);
 int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_hitpair *hits,
                          const uint64_t *g_off, uint32_t max_span, float penalty, int has_max_gap,
                          uint32_t max_gap, int oriented, pgr_hps_result *out);
+
+/* ------------------------------------------------------------------ multi-GPU exchange
+ * One process per GPU.  Contigs are sharded across ranks (the reference's unit of parallelism is the contig,
+ * pgr-db/src/seq_db.rs:460-467); after every rank has computed the shimmers of its shard the per-rank MM128 lists
+ * (rid = global sequence id) are all-gathered over RCCL / xGMI, and the rank that owns the frag_map -- or every rank,
+ * for a replicated query index -- derives the pair records from them (pgr_index_add_shmmrs) in the order the serial
+ * insert of seq_db.rs:605-612 produces.  The reference has no counterpart (single process); the only FFI precedent
+ * is the opaque-handle style of the AGC binding (pgr-db/src/agc_io.rs:76-116), followed here.
+ *   rank 0: pgr_exchange_unique_id() -> 128 bytes, handed to the other ranks by the HOST program (pipe, file, MPI ...)
+ *   all   : pgr_exchange_create(ctx, id, rank, world)             (collective: ncclCommInitRank)
+ *   step  : pgr_exchange_allgather_shmmrs_start(...)  enqueues the collective on the exchange's own stream behind the
+ *           work already queued on the context's stream and returns at once;  pgr_exchange_wait() blocks until the
+ *           lists have arrived and returns every rank's element count.  Rank r's list is d_out[r * cap_per_rank ...].
+ *   cap_per_rank is a capacity agreed at start-up (all ranks pass the same value, >= every rank's count): the
+ *   collective is one padded ncclAllGather, no rank needs another rank's size to post it.
+ * RCCL is loaded at the first call (dlopen "librccl.so.1"); without it these functions fail with PGR_ERR_DEVICE. */
+#define PGR_UNIQUE_ID_BYTES 128
+typedef struct pgr_exchange pgr_exchange;
+int pgr_exchange_unique_id(pgr_ctx *ctx, uint8_t *id /* PGR_UNIQUE_ID_BYTES */);
+int pgr_exchange_create(pgr_ctx *ctx, const uint8_t *id, int rank, int world, pgr_exchange **out);
+void pgr_exchange_destroy(pgr_exchange *x);
+int pgr_exchange_rank(const pgr_exchange *x);
+int pgr_exchange_world(const pgr_exchange *x);
+int pgr_exchange_allgather_shmmrs_start(pgr_exchange *x, const pgr_mm128 *d_local, uint64_t n_local, pgr_mm128 *d_out,
+                                        uint64_t cap_per_rank);
+int pgr_exchange_wait(pgr_exchange *x, uint64_t *counts /* world entries, may be NULL */);
+/* device pointer to the `world` element counts of the last all-gather */
+const uint64_t *pgr_exchange_device_counts(const pgr_exchange *x);
 
 /* ------------------------------------------------------------------ next: MAP-graph + principal bundles
  * Consumers of the frag_map (BASELINE.json configs[3], pgr-pbundle-decomp).  The data-parallel parts run on

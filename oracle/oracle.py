@@ -94,6 +94,16 @@ def lib():
         L.orc_shmmr_batch_threads.argtypes = [C.POINTER(Spec), C.c_uint32, C.POINTER(C.c_void_p),
                                               C.POINTER(C.c_uint64), C.c_int, C.POINTER(C.c_uint64)]
         L.orc_free.argtypes = [C.c_void_p]
+        L.orc_shmmr_checksum.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_synth_checksums_threads.restype = C.c_int
+        L.orc_synth_checksums_threads.argtypes = [C.POINTER(Spec), C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int,
+                                                  C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_index_add_synth_threads.restype = C.c_int
+        L.orc_index_add_synth_threads.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]
+        L.orc_query_batch_threads.restype = C.c_int
+        L.orc_query_batch_threads.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_float,
+                                              C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
+                                              C.c_int, C.POINTER(_HpsResult), C.POINTER(C.c_int)]
         _lib = L
     return _lib
 
@@ -173,6 +183,24 @@ def shmmr_batch_threads(sp, seqs, n_threads):
     return int(tot), np.array(counts[:], dtype=np.uint64)
 
 
+def synth_checksums_threads(sp, n, seed, contig0, length, n_threads):
+    """all n synthetic contigs (generated inside the workers, one task per contig like rayon par_iter) ->
+    (counts[n], checksums[n, 2], busy seconds per thread spent inside sequence_to_shmmrs)"""
+    counts = np.zeros(max(n, 1), dtype=np.uint64)
+    sums = np.zeros((max(n, 1), 2), dtype=np.uint64)
+    busy = np.zeros(max(n_threads, 1), dtype=np.float64)
+    lib().orc_synth_checksums_threads(C.byref(sp), n, seed, contig0, length, n_threads, counts.ctypes.data, sums.ctypes.data,
+                                      busy.ctypes.data)
+    return counts[:n], sums[:n], busy
+
+
+def shmmr_checksum(mm):
+    a = np.ascontiguousarray(mm, dtype=MM128)
+    out = np.zeros(2, dtype=np.uint64)
+    lib().orc_shmmr_checksum(a.ctypes.data, a.size, out.ctypes.data)
+    return out
+
+
 def _unpack_hps(res):
     out = []
     hps = None
@@ -220,6 +248,9 @@ class Index:
         if f(self._h, sid, a.ctypes.data, a.size) != 0:
             raise ValueError("spec rejected")
 
+    def add_synth_threads(self, n, sid0, seed, contig0, length, n_threads):
+        lib().orc_index_add_synth_threads(self._h, n, sid0, seed, contig0, length, n_threads)
+
     def finalize(self):
         lib().orc_index_finalize(self._h)
 
@@ -250,6 +281,32 @@ class Index:
         if rc:
             raise RuntimeError("query_fragment_to_hps failed rc=%d" % rc)
         return out
+
+
+def query_batch_threads(ix, seqs, penalty, n_threads, max_count=128, query_max_count=128, target_max_count=128,
+                        max_aln_span=8, max_gap=None, oriented=False):
+    """one task per query on n_threads (= the rayon loop of pgr-query.rs:135-138) -> (list of per-query results,
+    wall seconds of the threaded section)"""
+    import time
+    ix.finalize()
+    arrs = [_as_bytes_array(s) for s in seqs]
+    n = len(arrs)
+    ptrs = (C.c_void_p * max(n, 1))(*[a.ctypes.data for a in arrs])
+    lens = (C.c_uint64 * max(n, 1))(*[a.size for a in arrs])
+    results = (_HpsResult * max(n, 1))()
+    rcs = (C.c_int * max(n, 1))()
+    t0 = time.perf_counter()
+    lib().orc_query_batch_threads(ix._h, n, ptrs, lens, penalty, max_count, query_max_count, target_max_count, max_aln_span,
+                                  int(max_gap is not None), int(max_gap or 0), int(oriented), n_threads, results, rcs)
+    dt = time.perf_counter() - t0
+    out = []
+    for i in range(n):
+        if rcs[i]:
+            out.append(None)
+        else:
+            out.append(_unpack_hps(results[i])[0])
+        lib().orc_hps_result_free(C.byref(results[i]))
+    return out, dt
 
 
 def read_fasta(path):

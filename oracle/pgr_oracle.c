@@ -899,3 +899,223 @@ uint64_t orc_shmmr_batch_threads(const orc_spec *spec, uint32_t n_seqs, const ui
     pthread_mutex_destroy(&job.mu);
     return job.total;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/* Content checksum of a shimmer list: 128 bits per contig, order sensitive (the ordinal of every element is mixed in),
+ * additive (so that the GPU can accumulate it in any order).  The same formula is in libpgrhip's
+ * shmmr_checksum_kernel (pgr-tk_amd/csrc/level2.hip); bench.py compares the two for ALL contigs of BASELINE.json
+ * configs[1].  Only x and the low 32 bits of y (pos << 1 | strand) enter: the rid field is the caller's choice. */
+void orc_shmmr_checksum(const orc_mm128 *mm, size_t n, uint64_t out[2]) {
+    uint64_t a = 0, b = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint64_t x = mm[i].x, ylo = mm[i].y & 0xFFFFFFFFULL;
+        a += splitmix64(x ^ (0x9E3779B97F4A7C15ULL * (uint64_t)(i + 1)));
+        b += splitmix64((ylo | ((uint64_t)i << 32)) + 0xD1B54A32D192ED03ULL * x);
+    }
+    out[0] = a;
+    out[1] = b;
+}
+
+/* one task per contig (= rayon par_iter, seq_db.rs:460-467); every worker GENERATES its contig (counter-based
+ * generator), runs sequence_to_shmmrs and keeps only count + checksum, so host memory stays at
+ * n_threads contigs.  busy_s[t] = seconds thread t spent inside orc_sequence_to_shmmrs (generation not included). */
+typedef struct {
+    const orc_spec *spec;
+    uint32_t n;
+    uint64_t seed, contig0;
+    size_t len;
+    uint64_t *counts, *sums;
+    double *busy;
+    uint32_t next;
+    pthread_mutex_t mu;
+} synth_job;
+
+typedef struct {
+    synth_job *job;
+    int tid;
+} synth_arg;
+
+#include <time.h>
+static double now_s(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
+static void *synth_worker(void *argp) {
+    synth_arg *sa = (synth_arg *)argp;
+    synth_job *job = sa->job;
+    uint8_t *buf = (uint8_t *)malloc(job->len ? job->len : 1);
+    double busy = 0.0;
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        uint32_t i = job->next++;
+        pthread_mutex_unlock(&job->mu);
+        if (i >= job->n) break;
+        orc_synth_contig(job->seed, job->contig0 + i, job->len, buf);
+        orc_mm128 *o = NULL;
+        const double t0 = now_s();
+        size_t n = orc_sequence_to_shmmrs(i, buf, job->len, job->spec, 0, &o);
+        busy += now_s() - t0;
+        if (n == (size_t)-1) n = 0;
+        job->counts[i] = n;
+        orc_shmmr_checksum(o, n, job->sums + 2 * (size_t)i);
+        free(o);
+    }
+    free(buf);
+    job->busy[sa->tid] = busy;
+    return NULL;
+}
+
+int orc_synth_checksums_threads(const orc_spec *spec, uint32_t n, uint64_t seed, uint64_t contig0, size_t len,
+                                int n_threads, uint64_t *counts, uint64_t *sums, double *busy_s) {
+    synth_job job;
+    job.spec = spec;
+    job.n = n;
+    job.seed = seed;
+    job.contig0 = contig0;
+    job.len = len;
+    job.counts = counts;
+    job.sums = sums;
+    job.busy = busy_s;
+    job.next = 0;
+    pthread_mutex_init(&job.mu, NULL);
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    synth_arg *args = (synth_arg *)malloc(sizeof(synth_arg) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; t++) {
+        args[t].job = &job;
+        args[t].tid = t;
+        pthread_create(&th[t], NULL, synth_worker, &args[t]);
+    }
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    free(args);
+    pthread_mutex_destroy(&job.mu);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* query baseline: one task per query (= the rayon loop of pgr-query.rs:135-138) against one finalized index; the
+ * results are kept (results[i]) so that the caller can compare chain CONTENT with the GPU's. */
+typedef struct {
+    const orc_index *ix;
+    uint32_t n;
+    const uint8_t *const *seqs;
+    const uint64_t *lens;
+    float penalty;
+    uint32_t max_count, query_max_count, target_max_count, max_aln_span;
+    int has_max_gap;
+    uint32_t max_gap;
+    int oriented;
+    orc_hps_result *results;
+    int *rcs;
+    uint32_t next;
+    pthread_mutex_t mu;
+} query_job;
+
+static void *query_worker(void *argp) {
+    query_job *job = (query_job *)argp;
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        uint32_t i = job->next++;
+        pthread_mutex_unlock(&job->mu);
+        if (i >= job->n) break;
+        job->rcs[i] = orc_query_fragment_to_hps(job->ix, job->seqs[i], (size_t)job->lens[i], job->penalty, job->max_count,
+                                                job->query_max_count, job->target_max_count, job->max_aln_span,
+                                                job->has_max_gap, job->max_gap, job->oriented, &job->results[i]);
+    }
+    return NULL;
+}
+
+int orc_query_batch_threads(const orc_index *ix, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens, float penalty,
+                            uint32_t max_count, uint32_t query_max_count, uint32_t target_max_count,
+                            uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented, int n_threads,
+                            orc_hps_result *results, int *rcs) {
+    query_job job;
+    job.ix = ix;
+    job.n = n;
+    job.seqs = seqs;
+    job.lens = lens;
+    job.penalty = penalty;
+    job.max_count = max_count;
+    job.query_max_count = query_max_count;
+    job.target_max_count = target_max_count;
+    job.max_aln_span = max_aln_span;
+    job.has_max_gap = has_max_gap;
+    job.max_gap = max_gap;
+    job.oriented = oriented;
+    job.results = results;
+    job.rcs = rcs;
+    job.next = 0;
+    pthread_mutex_init(&job.mu, NULL);
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, query_worker, &job);
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    free(th);
+    pthread_mutex_destroy(&job.mu);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* index over n synthetic contigs (sid = sid0 + i, contig id = contig0 + i): the pair records of every contig are
+ * computed by a pool of threads (one task per contig, seq_db.rs:460-467), then inserted serially in sid order exactly as
+ * load_index_from_seq_vec does (seq_db.rs:605-612).  For bench.py's query baseline: an index of a bounded sample. */
+typedef struct {
+    const orc_spec *spec;
+    uint32_t n, sid0;
+    uint64_t seed, contig0;
+    size_t len;
+    orc_frag_rec **recs;
+    size_t *n_recs;
+    uint32_t next;
+    pthread_mutex_t mu;
+} synth_index_job;
+
+static void *synth_index_worker(void *argp) {
+    synth_index_job *job = (synth_index_job *)argp;
+    uint8_t *buf = (uint8_t *)malloc(job->len ? job->len : 1);
+    for (;;) {
+        pthread_mutex_lock(&job->mu);
+        uint32_t i = job->next++;
+        pthread_mutex_unlock(&job->mu);
+        if (i >= job->n) break;
+        orc_synth_contig(job->seed, job->contig0 + i, job->len, buf);
+        orc_mm128 *sh = NULL;
+        size_t ns = orc_sequence_to_shmmrs(job->sid0 + i, buf, job->len, job->spec, 0, &sh);
+        if (ns == (size_t)-1) ns = 0;
+        job->n_recs[i] = orc_shmmrs_to_frag_recs(sh, ns, job->sid0 + i, 0, &job->recs[i]);
+        free(sh);
+    }
+    free(buf);
+    return NULL;
+}
+
+int orc_index_add_synth_threads(orc_index *ix, uint32_t n, uint32_t sid0, uint64_t seed, uint64_t contig0, size_t len,
+                                int n_threads) {
+    synth_index_job job;
+    job.spec = &ix->spec;
+    job.n = n;
+    job.sid0 = sid0;
+    job.seed = seed;
+    job.contig0 = contig0;
+    job.len = len;
+    job.recs = (orc_frag_rec **)calloc(n ? n : 1, sizeof(orc_frag_rec *));
+    job.n_recs = (size_t *)calloc(n ? n : 1, sizeof(size_t));
+    job.next = 0;
+    pthread_mutex_init(&job.mu, NULL);
+    if (n_threads < 1) n_threads = 1;
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)n_threads);
+    for (int t = 0; t < n_threads; t++) pthread_create(&th[t], NULL, synth_index_worker, &job);
+    for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+    for (uint32_t i = 0; i < n; i++) {
+        for (size_t j = 0; j < job.n_recs[i]; j++) index_push(ix, &job.recs[i][j]);
+        free(job.recs[i]);
+    }
+    free(th);
+    free(job.recs);
+    free(job.n_recs);
+    pthread_mutex_destroy(&job.mu);
+    return 0;
+}

@@ -127,6 +127,22 @@ uint64_t orc_shmmr_batch_threads(const orc_spec *spec, uint32_t n_seqs, const ui
 
 void orc_free(void *);
 
+/* ---- full-size content checks and threaded baselines (bench.py cpu_baseline legs) ---- */
+/* 128-bit order-sensitive checksum of a shimmer list (x and the low 32 bits of y); same formula on the GPU */
+void orc_shmmr_checksum(const orc_mm128 *mm, size_t n, uint64_t out[2]);
+/* n synthetic contigs of `len` bases (orc_synth_contig(seed, contig0 + i)), generated inside the workers, one task per
+ * contig: counts[n], sums[2n], busy_s[n_threads] = seconds each thread spent inside orc_sequence_to_shmmrs */
+int orc_synth_checksums_threads(const orc_spec *spec, uint32_t n, uint64_t seed, uint64_t contig0, size_t len,
+                                int n_threads, uint64_t *counts, uint64_t *sums, double *busy_s);
+/* index over n synthetic contigs (sid0 + i <- contig0 + i): records computed by a thread pool, inserted in sid order */
+int orc_index_add_synth_threads(orc_index *ix, uint32_t n, uint32_t sid0, uint64_t seed, uint64_t contig0, size_t len,
+                                int n_threads);
+/* one task per query on n_threads (the rayon loop of pgr-query.rs:135-138); results[n], rcs[n] */
+int orc_query_batch_threads(const orc_index *ix, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens, float penalty,
+                            uint32_t max_count, uint32_t query_max_count, uint32_t target_max_count,
+                            uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented, int n_threads,
+                            orc_hps_result *results, int *rcs);
+
 #ifdef __cplusplus
 }
 #endif

@@ -74,6 +74,7 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->cev[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_alloc);
     if (e != hipSuccess) {
         g_create_error = std::string("context setup: ") + hipGetErrorString(e);
         delete ctx;
@@ -91,6 +92,7 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->ev_end) (void)hipEventDestroy(ctx->ev_end);
+    if (ctx->ev_alloc) (void)hipEventDestroy(ctx->ev_alloc);
     for (auto &ev : ctx->cev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -118,7 +120,6 @@ static int batch_alloc(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, pgr_batch
     b->n = n;
     b->h_word_off.resize((size_t)n + 1);
     b->h_len.resize(n);
-    b->h_n_invalid.assign(n, 0);
     uint64_t words = 0, bases = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (lens[i] >= (1ull << 31)) {
@@ -148,7 +149,12 @@ static int batch_alloc(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, pgr_batch
         PGR_HIP(ctx, hipMemcpyAsync(b->d.len, b->h_len.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice,
                                     ctx->stream));
     PGR_HIP(ctx, hipMemsetAsync(b->d.n_invalid, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), ctx->stream));
-    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // no synchronization: the source vectors live as long as the batch and everything that reads the device arrays is
+    // ordered behind these copies on the context's stream (the staging thread of the pipelined path waits for `ready`)
+    if (hipEventRecord(ctx->ev_alloc, ctx->stream) != hipSuccess) {
+        pgr_batch_destroy(b);
+        return ctx->fail(PGR_ERR_DEVICE, "event record failed");
+    }
     *out = b;
     return PGR_OK;
 }
@@ -175,6 +181,12 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const uint8_t *co
         err = m;
         return code;
     };
+    // the pinned windows are reused from call to call: a previous staging whose copies nobody has waited for yet
+    // (two batches staged back to back) must be over before the host overwrites them
+    if (ctx->staged_unsynced && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+    if (st != ctx->stream && hipStreamWaitEvent(st, ctx->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
+        return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
     // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Two pinned windows of 32 MiB: while window
     // i is on its way to the GPU (H2D + pack kernel) the host threads fill window i+1.
     const uint64_t WIN_WORDS = 1ull << 20;  // 32 MiB of ASCII per window
@@ -228,11 +240,15 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const uint8_t *co
         if (hipEventRecord(done[slot], st) != hipSuccess) return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         used[slot] = true;
     }
-    if (n && hipMemcpyAsync(b->h_n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st) !=
-                 hipSuccess)
-        return fail(PGR_ERR_DEVICE, "D2H of the invalid-base counts failed");
-    if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
-        return fail(PGR_ERR_DEVICE, "pack kernel failed");
+    // (the per-contig counts of non-ACGT bytes stay on the device: pgr_shmmrs_compute fetches them only when a tile was
+    // flagged).  On the context's own stream nothing waits here: the consumer is ordered behind the pack kernels and
+    // synchronizes once at its end; the staging thread of the pipelined path (own stream) hands over finished batches.
+    if (st != ctx->stream) {
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+            return fail(PGR_ERR_DEVICE, "pack kernel failed");
+    } else {
+        ctx->staged_unsynced = true;
+    }
     return PGR_OK;
 }
 
@@ -261,8 +277,8 @@ extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *con
     return PGR_OK;
 }
 
-extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint64_t seed, uint64_t contig0,
-                                   pgr_batch **out) {
+static int batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint64_t seed, uint64_t contig0,
+                           const uint64_t *ids, pgr_batch **out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!out || (n && !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
@@ -270,13 +286,35 @@ extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *len
     pgr_batch *b = nullptr;
     int rc = batch_alloc(ctx, n, lens, &b);
     if (rc) return rc;
-    launch_synth(ctx->stream, b->d, n, b->total_words, seed, contig0);
+    Tmp_list d_ids(ctx);
+    if (ids && n) {
+        if ((rc = d_ids.alloc((size_t)n * sizeof(uint64_t)))) {
+            pgr_batch_destroy(b);
+            return rc;
+        }
+        if (hipMemcpyAsync(d_ids.p, ids, (size_t)n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            pgr_batch_destroy(b);
+            return ctx->fail(PGR_ERR_DEVICE, "H2D of the contig ids failed");
+        }
+    }
+    launch_synth(ctx->stream, b->d, n, b->total_words, seed, contig0, ids && n ? (const uint64_t *)d_ids.p : nullptr);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess) {
         pgr_batch_destroy(b);
         return ctx->fail(PGR_ERR_DEVICE, "synthetic generator kernel failed");
     }
     *out = b;
     return PGR_OK;
+}
+
+extern "C" int pgr_batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint64_t seed, uint64_t contig0,
+                                   pgr_batch **out) {
+    return batch_synthetic(ctx, n, lens, seed, contig0, nullptr, out);
+}
+
+extern "C" int pgr_batch_synthetic_ids(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint64_t seed,
+                                       const uint64_t *contig_ids, pgr_batch **out) {
+    if (ctx && n && !contig_ids) return ctx->fail(PGR_ERR_INVALID_ARG, "null contig id list");
+    return batch_synthetic(ctx, n, lens, seed, 0, contig_ids, out);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -485,6 +523,16 @@ static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
     return PGR_OK;
 }
 
+// One pass of the hot path over a resident batch.  Everything is enqueued on the context's stream with sizes that are
+// upper bounds or estimates; the host reads the true counts ONCE at the end (one hipStreamSynchronize per call in the
+// common case) and repeats a stage only when an estimate turned out too small:
+//   stage 1  level-1 tiles + tails (+ exact islands when a tile flagged a palindromic k-mer / non-ACGT byte)
+//   stage 2  scan of the segment counts (the level-1 total stays on the device)
+//   stage 3  fused reduce x2 + min_span (grid = upper bound, surplus workgroups exit on the device-side total)
+//   stage 4  scan of the block counts, ordered gather into the result, per-contig offsets, rid patch
+// Batches of >= 64 Mbp synchronize once more after stage 1 (a 30 us round trip is nothing there and a flagged batch
+// does not run stages 2-4 twice); smaller ones (the reference's real callers: <= 129 contigs per call, seq_db.rs:561, and
+// single queries, ext.rs:252) run optimistically and redo stages 2-4 after the islands in the rare flagged case.
 extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *rids,
                                   int padding, pgr_shmmrs **out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
@@ -527,17 +575,23 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint64_t slots_total = (uint64_t)n_tiles * slot;
     uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 300ull * n;
 
+    constexpr size_t N_CURSOR = 8;  // [0..2] level 1 (L1Args::cursor), [4..5] fused list stage
+    constexpr size_t N_STATUS = 10;
     if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_tile_desc.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(TileDesc))) ||
         (rc = ctx->ws_tile_flags.ensure(ctx, (size_t)n_tiles + 16)) ||
         (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_cursor.ensure(ctx, 2 * sizeof(unsigned long long))) ||
+        (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long))) ||
         (rc = ctx->ws_flags.ensure(ctx, std::max<uint32_t>(n, 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_off_b.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))))
+        (rc = ctx->ws_off_b.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t))))
         return rc;
+    unsigned long long *d_cursor = (unsigned long long *)ctx->ws_cursor.p;
+    uint64_t *d_status = (uint64_t *)(d_cursor + N_CURSOR);
+    uint64_t *mbox = (uint64_t *)ctx->mailbox;  // pinned: [0, N_STATUS) status, then the n+1 result offsets
     PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t),
                                 hipMemcpyHostToDevice, st));
     uint32_t *d_rids = nullptr;
@@ -559,7 +613,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.r = spec->r;
     a.tc = tc;
     a.sketch = sketch ? 1u : 0u;
-    a.cursor = (unsigned long long *)ctx->ws_cursor.p;
+    a.cursor = d_cursor;
     a.seg_off = (uint64_t *)ctx->ws_seg_off.p;
     a.seg_cnt = (uint32_t *)ctx->ws_seg_cnt.p;
     a.contig_flags = (uint32_t *)ctx->ws_flags.p;
@@ -568,23 +622,26 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     memset(&prof, 0, sizeof(prof));
     prof.n_tiles = n_tiles;
     prof.bases_tiled = bases_tiled;
-    std::vector<uint32_t> flags(n);
-    bool any_invalid = false;
-    for (uint32_t c = 0; c < n; ++c) any_invalid |= b->h_n_invalid[c] != 0;
-
-    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    const bool early_sync = b->total_bases >= (64ull << 20) || !serial.empty();
+    const bool pad_fix = padding && !sketch && spec->r > 1;
+    const bool do_reduce = !sketch && spec->r > 1;
+    const uint32_t halo = do_reduce ? 2 * spec->r * spec->r : 1;
+    const uint32_t slot2 = do_reduce ? 256u : FUSED_BLOCK_ELEMS;
     uint64_t serial_base = 0;  // first element of the serial regions inside the level-1 buffer
-    for (int attempt = 0;; ++attempt) {
-        if (attempt > 4) return ctx->fail(PGR_ERR_INTERNAL, "level-1 buffer kept overflowing");
+    bool islands_done = false;
+
+    // ---- stage 1
+    auto stage1 = [&]() -> int {
         uint64_t serial_total = 0;
         for (uint32_t c : serial) serial_total += (uint64_t)b->h_len[c] / 4 + 4096;
-        if ((rc = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return rc;
+        int r;
+        if ((r = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return r;
         a.out = (pgr_mm128 *)ctx->ws_l1.p;
         a.slot = slot;
         a.ovf_base = slots_total;
         a.cap = cap_par;
         serial_base = slots_total + cap_par;
-        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+        PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, N_CURSOR * sizeof(unsigned long long), st));
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), st));
         PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
         PGR_HIP(ctx, hipMemsetAsync(ctx->ws_tile_flags.p, 0, (size_t)n_tiles + 16, st));
@@ -592,39 +649,32 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (tiled && bases_tiled) launch_level1_tiles(st, a);
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         launch_level1_tails(st, a);
-        if (tiled && bases_tiled && any_invalid) launch_mark_invalid_tiles(st, a);
-        unsigned long long cur[2] = {0, 0};
-        PGR_HIP(ctx, hipMemcpyAsync(cur, ctx->ws_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
-        if (n) PGR_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->ws_flags.p, (size_t)n * sizeof(uint32_t),
-                                           hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipStreamSynchronize(st));
-        PGR_HIP(ctx, hipGetLastError());
-        if (cur[1] || cur[0] > cap_par) {  // cursor region too small: grow and redo
-            cap_par = (uint64_t)((double)cur[0] * 1.1) + 65536;
-            continue;
-        }
-        prof.n_level1 = cur[0];
-        break;
-    }
+        if (tiled && bases_tiled) launch_mark_invalid_tiles(st, a);  // exits per tile for contigs without non-ACGT bytes
+        islands_done = false;
+        return PGR_OK;
+    };
     // ---- islands of exact tiles: around palindromic k-mers (skipped pushes, flagged by the tile kernel) and
-    // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path
-    std::vector<Island> islands;
-    for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false});
-    if (tiled && bases_tiled) {
-        bool need = false;
-        for (uint32_t c = 0; c < n; ++c) need |= (b->h_n_invalid[c] != 0) || (!sketch && (flags[c] & 1u));
-        if (need) {
+    // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path.  Synchronizes.
+    auto run_islands = [&](uint64_t need_word) -> int {
+        std::vector<Island> islands;
+        for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false});
+        if (tiled && bases_tiled && need_word) {
+            std::vector<uint32_t> flags(n), n_invalid(n);
             std::vector<uint8_t> tf(n_tiles);
+            if (n) {
+                PGR_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->ws_flags.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                PGR_HIP(ctx, hipMemcpyAsync(n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            }
             PGR_HIP(ctx, hipMemcpyAsync(tf.data(), ctx->ws_tile_flags.p, n_tiles, hipMemcpyDeviceToHost, st));
             PGR_HIP(ctx, hipStreamSynchronize(st));
             for (uint32_t c = 0; c < n; ++c) {
-                if (b->h_n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
+                if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
                 const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
                 const uint64_t L = b->h_len[c];
                 uint32_t n_flag = 0;
                 for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
                 if (n_flag == 0) continue;
-                if (sketch && b->h_n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
+                if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
                 if (3ull * n_flag > nt) {  // mostly irregular: one island
                     islands.push_back(Island{c, 0, L, false});
                     continue;
@@ -647,61 +697,71 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 }
             }
         }
-    }
-    {
-        std::vector<uint32_t> cs;
-        for (const auto &is : islands) cs.push_back(is.contig);
-        std::sort(cs.begin(), cs.end());
-        prof.n_serial_contigs = std::unique(cs.begin(), cs.end()) - cs.begin();
-    }
-    if (!islands.empty()) {
-        L1Args as = a;
-        as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
-        if ((rc = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base))) return rc;
-        a.out = as.out;
-        for (const auto &is : islands) prof.exact_bases += is.E - is.B;  // final extents (islands may have grown)
-    }
-    PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        {
+            std::vector<uint32_t> cs;
+            for (const auto &is : islands) cs.push_back(is.contig);
+            std::sort(cs.begin(), cs.end());
+            prof.n_serial_contigs = std::unique(cs.begin(), cs.end()) - cs.begin();
+        }
+        if (!islands.empty()) {
+            L1Args as = a;
+            as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
+            int r = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base);
+            if (r) return r;
+            a.out = as.out;
+            prof.exact_bases = 0;
+            for (const auto &is : islands) prof.exact_bases += is.E - is.B;  // final extents (islands may have grown)
+        }
+        islands_done = true;
+        return PGR_OK;
+    };
 
-    // ---- level-1 segment scan: logical (ordered) position of every segment
-    const size_t tb = scan_counts_temp_bytes(n_segs + 1);
-    if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
-    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, (const uint32_t *)ctx->ws_seg_cnt.p,
-                             (uint64_t *)ctx->ws_seg_dst.p, n_segs + 1));
-    uint64_t total1 = 0;
-    PGR_HIP(ctx, hipMemcpyAsync(&total1, (uint64_t *)ctx->ws_seg_dst.p + n_segs, sizeof(uint64_t),
-                                hipMemcpyDeviceToHost, st));
-    const bool pad_fix = padding && !sketch && spec->r > 1;
+    // ---- stages 2-4.  n_blocks: grid of the fused kernel; cap2: its overflow region; cap_res: result capacity
+    pgr_shmmrs *res = new pgr_shmmrs();
+    res->ctx = ctx;
+    res->n = n;
+    res->h_off.assign((size_t)n + 1, 0);
+    auto bail = [&](int code) {
+        pgr_shmmrs_destroy(res);
+        return code;
+    };
+    if ((rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
+    // estimates: level-1 count from the density (low-complexity sequence exceeds it: retried with the true count),
+    // final count from this context's last result with the same spec (first call: a third of the level-1 estimate)
+    const uint64_t l1_bound = slots_total + cap_par + b->total_bases / 4 + 4096ull * n + 4096;  // what stage 1 can emit at all
+    const uint64_t l1_est = std::min<uint64_t>(l1_bound, (uint64_t)((double)b->total_bases * dens * 1.06) + 2048ull * n + 8192);
+    uint32_t n_blocks = (uint32_t)((l1_est + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
+    uint64_t cap2 = (uint64_t)((double)l1_est * 0.01) + 65536;
+    const double spec_key = (double)spec->w * 1e9 + spec->k * 1e6 + spec->r * 1e4 + spec->min_span + (sketch ? 0.5 : 0.0) + (padding ? 0.25 : 0.0);
+    const double ratio = (ctx->est_spec_key == spec_key && ctx->est_final_ratio > 0) ? ctx->est_final_ratio * 1.15 : dens / 3.0 + 1e-4;
+    uint64_t cap_res = std::max<uint64_t>((uint64_t)((double)b->total_bases * ratio) + 64ull * n + 1024, 16);
+    pgr_mm128 *d_list = nullptr;  // ordered final list (before the padding artefact)
+    uint64_t *d_loff = nullptr;
+    uint64_t *d_total1 = (uint64_t *)ctx->ws_seg_dst.p + n_segs;
     std::vector<uint64_t> l1_off;  // only needed for the padding artefact
-    if (pad_fix) {
-        l1_off.resize((size_t)n + 1);
-        launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
-                              (uint64_t *)ctx->ws_off_a.p);
-        PGR_HIP(ctx, hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
-                                    hipMemcpyDeviceToHost, st));
-    }
-    PGR_HIP(ctx, hipStreamSynchronize(st));
-    prof.n_level1 = total1;
-
-    // ---- fused reduce x2 (shmmrutils.rs:533-535) + min_span filter (:536-555) straight from the segments
-    const bool do_reduce = !sketch && spec->r > 1;
-    const uint32_t halo = do_reduce ? 2 * spec->r * spec->r : 1;
-    const uint32_t n_blocks = (uint32_t)((total1 + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
-    if ((rc = ctx->ws_blk_cnt.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))) ||
-        (rc = ctx->ws_blk_base.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_blk_off.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_start_rank.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))))
-        return rc;
-    // fixed output slot per fused workgroup (expected survivors: ~12 % after two reductions + min_span), plus
-    // a cursor-allocated overflow region
-    const uint32_t slot2 = do_reduce ? 256u : FUSED_BLOCK_ELEMS;
-    const uint64_t slots2 = (uint64_t)n_blocks * slot2;
-    uint64_t cap2 = (uint64_t)((double)total1 * 0.01) + 65536;
-    uint64_t n_final = 0;
-    for (int attempt = 0;; ++attempt) {
-        if (attempt > 3) return ctx->fail(PGR_ERR_INTERNAL, "fused select buffer kept overflowing");
-        if ((rc = ctx->ws_list_a.ensure(ctx, (slots2 + cap2 + 1) * sizeof(pgr_mm128)))) return rc;
-        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_cursor.p, 0, 2 * sizeof(unsigned long long), st));
+    auto stage2 = [&]() -> int {
+        const size_t tb = scan_counts_temp_bytes(n_segs + 1);
+        int r;
+        if ((r = ctx->ws_scan_tmp.ensure(ctx, tb))) return r;
+        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, (const uint32_t *)ctx->ws_seg_cnt.p,
+                                 (uint64_t *)ctx->ws_seg_dst.p, n_segs + 1));
+        if (pad_fix)
+            launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
+                                  (uint64_t *)ctx->ws_off_a.p);
+        return PGR_OK;
+    };
+    auto stage3 = [&]() -> int {
+        int r;
+        if ((r = ctx->ws_blk_cnt.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))) ||
+            (r = ctx->ws_blk_base.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
+            (r = ctx->ws_blk_off.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
+            (r = ctx->ws_start_rank.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))))
+            return r;
+        // fixed output slot per fused workgroup (expected survivors: ~12 % after two reductions + min_span), plus
+        // a cursor-allocated overflow region
+        const uint64_t slots2 = (uint64_t)n_blocks * slot2;
+        if ((r = ctx->ws_list_a.ensure(ctx, (slots2 + cap2 + 1) * sizeof(pgr_mm128)))) return r;
+        PGR_HIP(ctx, hipMemsetAsync(d_cursor + 4, 0, 2 * sizeof(unsigned long long), st));
         PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p + n_blocks, 0, sizeof(uint32_t), st));
         FusedArgsPub fa;
         fa.l1 = (const pgr_mm128 *)ctx->ws_l1.p;
@@ -709,7 +769,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         fa.seg_cnt = (const uint32_t *)ctx->ws_seg_cnt.p;
         fa.seg_dst = (const uint64_t *)ctx->ws_seg_dst.p;
         fa.n_segs = n_segs;
-        fa.total = total1;
+        fa.total = d_total1;
         fa.r = spec->r;
         fa.padding = padding ? 1u : 0u;
         fa.min_span = spec->min_span;
@@ -719,64 +779,121 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         fa.slot = slot2;
         fa.ovf_base = slots2;
         fa.cap = cap2;
-        fa.cursor = (unsigned long long *)ctx->ws_cursor.p;
+        fa.cursor = d_cursor + 4;
         fa.blk_off = (uint64_t *)ctx->ws_blk_off.p;
         fa.blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
         fa.blk_first_seg = (uint32_t *)ctx->ws_start_rank.p;
         launch_fused_select_pub(st, fa, n_blocks);
-        unsigned long long cur[2] = {0, 0};
-        PGR_HIP(ctx, hipMemcpyAsync(cur, ctx->ws_cursor.p, sizeof(cur), hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipStreamSynchronize(st));
-        PGR_HIP(ctx, hipGetLastError());
-        if (cur[1] || cur[0] > cap2) {
-            cap2 = (uint64_t)((double)cur[0] * 1.05) + 65536;
+        return PGR_OK;
+    };
+    bool scanned4 = false;
+    auto stage4 = [&]() -> int {
+        int r;
+        if (!scanned4) {  // (a repeat of stage 4 alone only re-gathers into a bigger result buffer)
+            const size_t tb2 = scan_counts_temp_bytes(n_blocks + 1);
+            if ((r = ctx->ws_scan_tmp.ensure(ctx, tb2))) return r;
+            PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb2, (const uint32_t *)ctx->ws_blk_cnt.p,
+                                     (uint64_t *)ctx->ws_blk_base.p, n_blocks + 1));
+            scanned4 = true;
+        }
+        const uint64_t *d_nfinal = (const uint64_t *)ctx->ws_blk_base.p + n_blocks;
+        if (!pad_fix) {  // common case: gather straight into the result buffer
+            ctx->dfree(res->d_mm);
+            res->d_mm = nullptr;
+            if ((r = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return r;
+            d_list = res->d_mm;
+            d_loff = res->d_off;
+        } else {
+            if ((r = ctx->ws_list_b.ensure(ctx, cap_res * sizeof(pgr_mm128)))) return r;
+            d_list = (pgr_mm128 *)ctx->ws_list_b.p;
+            d_loff = (uint64_t *)ctx->ws_off_b.p;
+        }
+        launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_list_a.p, (const uint64_t *)ctx->ws_blk_off.p,
+                               (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list,
+                               cap_res);
+        launch_offsets_by_rid(st, d_list, d_nfinal, cap_res, n, d_loff);
+        if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids);
+        launch_collect_status(st, d_cursor, d_total1, d_nfinal, d_status);
+        PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
+        PGR_HIP(ctx, hipMemcpyAsync(mbox, d_status, N_STATUS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipMemcpyAsync(mbox + N_STATUS, d_loff, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        return PGR_OK;
+    };
+
+    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    int from = 1;  // first stage to (re)run
+    uint64_t n_final = 0;
+    for (int attempt = 0;; ++attempt) {
+        if (attempt > 8) return bail(ctx->fail(PGR_ERR_INTERNAL, "shimmer pipeline: buffers kept overflowing"));
+        if (from <= 1) {
+            if ((rc = stage1())) return bail(rc);
+            if (early_sync) {
+                PGR_HIP(ctx, hipMemcpyAsync(mbox, d_cursor, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+                if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+                    return bail(ctx->fail(PGR_ERR_DEVICE, "level-1 kernels failed on the device"));
+                if (mbox[1] || mbox[0] > cap_par) {  // cursor region too small: grow and redo
+                    cap_par = (uint64_t)((double)mbox[0] * 1.1) + 65536;
+                    continue;
+                }
+                if ((mbox[2] || !serial.empty()) && (rc = run_islands(mbox[2]))) return bail(rc);
+                islands_done = true;
+            }
+            PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+        }
+        if (from <= 2 && (rc = stage2())) return bail(rc);
+        if (from <= 3) {
+            scanned4 = false;
+            if ((rc = stage3())) return bail(rc);
+        }
+        if ((rc = stage4())) return bail(rc);
+        if (pad_fix) {
+            l1_off.resize((size_t)n + 1);
+            PGR_HIP(ctx, hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
+                                        hipMemcpyDeviceToHost, st));
+        }
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+            return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
+        // ---- the one look at the device-side counts
+        const uint64_t l1_alloc = mbox[0], l1_ovf = mbox[1], need_islands = mbox[2], l2_alloc = mbox[4], l2_ovf = mbox[5];
+        const uint64_t total1 = mbox[8];
+        n_final = mbox[9];
+        if (l1_ovf || l1_alloc > cap_par) {  // (only possible without the early synchronization)
+            cap_par = (uint64_t)((double)l1_alloc * 1.1) + 65536;
+            from = 1;
+            continue;
+        }
+        if (!islands_done && (need_islands || !serial.empty())) {
+            if ((rc = run_islands(need_islands))) return bail(rc);
+            PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+            from = 2;
+            continue;
+        }
+        prof.n_level1 = total1;
+        if (total1 > (uint64_t)n_blocks * FUSED_BLOCK_ELEMS) {  // denser than the estimate: the grid missed the tail
+            n_blocks = (uint32_t)((total1 + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
+            cap2 = std::max<uint64_t>(cap2, (uint64_t)((double)total1 * 0.01) + 65536);
+            from = 3;
+            continue;
+        }
+        if (l2_ovf || l2_alloc > cap2) {
+            cap2 = (uint64_t)((double)l2_alloc * 1.05) + 65536;
+            from = 3;
+            continue;
+        }
+        if (n_final > cap_res) {  // more survivors than estimated: bigger result buffer, gather again
+            cap_res = n_final + 16;
+            from = 4;
             continue;
         }
         break;
     }
-    pgr_shmmrs *res = new pgr_shmmrs();
-    res->ctx = ctx;
-    res->n = n;
-    res->h_off.assign((size_t)n + 1, 0);
-    auto bail = [&](int code) {
-        pgr_shmmrs_destroy(res);
-        return code;
-    };
-    // ---- order the block segments: scan + gather, then per-contig offsets from the (internal) rid
-    {
-        const size_t tb2 = scan_counts_temp_bytes(n_blocks + 1);
-        if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb2))) return bail(rc);
-        hipError_t e = scan_counts(st, ctx->ws_scan_tmp.p, tb2, (const uint32_t *)ctx->ws_blk_cnt.p,
-                                   (uint64_t *)ctx->ws_blk_base.p, n_blocks + 1);
-        if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e)));
-        if (hipMemcpyAsync(&n_final, (uint64_t *)ctx->ws_blk_base.p + n_blocks, sizeof(uint64_t), hipMemcpyDeviceToHost,
-                           st) != hipSuccess ||
-            hipStreamSynchronize(st) != hipSuccess)
-            return bail(ctx->fail(PGR_ERR_DEVICE, "D2H of the survivor count failed"));
-    }
-    pgr_mm128 *d_list = nullptr;  // ordered final list (before the padding artefact)
-    uint64_t *d_loff = nullptr;
-    if (!pad_fix) {  // common case: gather straight into the result buffers
-        if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(n_final, 1) * sizeof(pgr_mm128))) ||
-            (rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t))))
-            return bail(rc);
-        d_list = res->d_mm;
-        d_loff = res->d_off;
-    } else {
-        if ((rc = ctx->ws_list_b.ensure(ctx, std::max<uint64_t>(n_final, 1) * sizeof(pgr_mm128)))) return bail(rc);
-        d_list = (pgr_mm128 *)ctx->ws_list_b.p;
-        d_loff = (uint64_t *)ctx->ws_off_b.p;
-    }
-    launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_list_a.p, (const uint64_t *)ctx->ws_blk_off.p,
-                           (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list);
-    launch_offsets_by_rid(st, d_list, n_final, n, d_loff);
-    if (d_rids) launch_patch_rid(st, d_list, n_final, d_rids);
-    if (hipMemcpyAsync(res->h_off.data(), d_loff, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st) !=
-            hipSuccess ||
-        hipStreamSynchronize(st) != hipSuccess)
-        return bail(ctx->fail(PGR_ERR_DEVICE, "D2H of the result offsets failed"));
+    memcpy(res->h_off.data(), mbox + N_STATUS, ((size_t)n + 1) * sizeof(uint64_t));
     res->count = n_final;
     res->rid_is_index = (d_rids == nullptr) && !pad_fix;
+    if (b->total_bases) {
+        ctx->est_spec_key = spec_key;
+        ctx->est_final_ratio = (double)n_final / (double)b->total_bases;
+    }
     if (pad_fix) {
         // reference artefact: reduce_shmmr on an EMPTY list with padding emits its sentinels
         // (shmmrutils.rs:367-380), which survive as exactly two {MAX,MAX} after the second pass + filter
@@ -788,19 +905,17 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         }
         final_off[n] = res->h_off[n] + add;
         res->count = final_off[n];
-        if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(res->count, 1) * sizeof(pgr_mm128))) ||
-            (rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t))))
-            return bail(rc);
+        if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(res->count, 1) * sizeof(pgr_mm128)))) return bail(rc);
         if (hipMemcpyAsync(res->d_off, final_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
                            st) != hipSuccess)
             return bail(ctx->fail(PGR_ERR_DEVICE, "H2D of the result offsets failed"));
         launch_copy_or_sentinel(st, d_list, d_loff, res->d_off, n, res->d_mm);
         res->h_off = final_off;
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+            return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
     }
-    hipEvent_t ev_end = ctx->ev_end;
-    if (hipEventRecord(ev_end, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess ||
-        hipGetLastError() != hipSuccess)
-        return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
+    hipEvent_t ev_end = ctx->ev_end;  // recorded at the end of stage 4, complete since the synchronization above
+    ctx->staged_unsynced = false;
     (void)hipEventElapsedTime(&prof.level1_ms, ctx->ev[1], ctx->ev[2]);
     (void)hipEventElapsedTime(&prof.level1_aux_ms, ctx->ev[2], ctx->ev[3]);
     (void)hipEventElapsedTime(&prof.level2_ms, ctx->ev[3], ev_end);
@@ -848,6 +963,25 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
     return PGR_OK;
 }
 
+extern "C" int pgr_shmmrs_checksum(pgr_ctx *ctx, const pgr_shmmrs *s, uint64_t *out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!s || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t n = s->n;
+    if (n == 0) return PGR_OK;
+    uint64_t max_cnt = 0;
+    for (uint32_t c = 0; c < n; ++c) max_cnt = std::max(max_cnt, s->h_off[c + 1] - s->h_off[c]);
+    Tmp_list sums(ctx);
+    int rc = sums.alloc((size_t)n * 2 * sizeof(uint64_t));
+    if (rc) return rc;
+    PGR_HIP(ctx, hipMemsetAsync(sums.p, 0, (size_t)n * 2 * sizeof(uint64_t), ctx->stream));
+    launch_shmmr_checksum(ctx->stream, s->d_mm, s->d_off, n, max_cnt, (uint64_t *)sums.p);
+    PGR_HIP(ctx, hipMemcpyAsync(out, sums.p, (size_t)n * 2 * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    PGR_HIP(ctx, hipGetLastError());
+    return PGR_OK;
+}
+
 extern "C" int pgr_shmmrs_copy_to_device(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 *d_out, uint64_t capacity,
                                          uint32_t rid_add) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
@@ -862,6 +996,30 @@ extern "C" int pgr_shmmrs_copy_to_device(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_
     return PGR_OK;
 }
 
+extern "C" int pgr_shmmrs_copy_to_device_rids(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 *d_out, uint64_t capacity,
+                                              const uint32_t *rids) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!s || (s->count && !d_out) || (s->n && !rids)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (capacity < s->count) return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the shimmer list");
+    if (!s->rid_is_index) return ctx->fail(PGR_ERR_STATE, "the result already carries caller rids (computed with rids / padding)");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    if (s->count) {
+        int rc;
+        if ((rc = ctx->ws_rids.ensure(ctx, (size_t)s->n * sizeof(uint32_t)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rids.p, rids, (size_t)s->n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+        launch_copy_map_rid(ctx->stream, s->d_mm, s->count, (const uint32_t *)ctx->ws_rids.p, d_out);
+        PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        PGR_HIP(ctx, hipGetLastError());
+    }
+    return PGR_OK;
+}
+
+extern "C" int pgr_shmmrs_offsets(const pgr_shmmrs *s, uint64_t *out) {
+    if (!s || !out) return PGR_ERR_INVALID_ARG;
+    memcpy(out, s->h_off.data(), ((size_t)s->n + 1) * sizeof(uint64_t));
+    return PGR_OK;
+}
+
 extern "C" uint64_t pgr_shmmrs_n_pairs(const pgr_shmmrs *s) {
     if (!s) return 0;
     uint64_t np = 0;
@@ -872,11 +1030,8 @@ extern "C" uint64_t pgr_shmmrs_n_pairs(const pgr_shmmrs *s) {
     return np;
 }
 
-extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
-                                              pgr_frag_rec *d_out, uint64_t capacity, uint64_t *n_out) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!s || !n_out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+int pgr::shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
+                                     pgr_frag_rec *d_out, uint64_t capacity) {
     const uint32_t n = s->n;
     std::vector<uint64_t> rec_off((size_t)n + 1);
     uint64_t np = 0;
@@ -886,12 +1041,12 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
         if (cnt > 1) np += cnt - 1;
     }
     rec_off[n] = np;
-    *n_out = np;
     if (np == 0) return PGR_OK;
     if (!d_out || capacity < np) return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the pair records");
     hipStream_t st = ctx->stream;
     int rc;
     if ((rc = ctx->ws_rec_off.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t)))) return rc;
+    // (pageable source: the runtime stages it before returning, the vector may go out of scope)
     PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rec_off.p, rec_off.data(), ((size_t)n + 1) * sizeof(uint64_t),
                                 hipMemcpyHostToDevice, st));
     uint32_t *d_sids = nullptr;
@@ -902,7 +1057,19 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
     }
     launch_frag_recs(st, s->d_mm, s->d_off, (const uint64_t *)ctx->ws_rec_off.p, n, s->count, d_sids, query_side,
                      s->rid_is_index ? 1 : 0, d_out);
-    PGR_HIP(ctx, hipStreamSynchronize(st));
+    return PGR_OK;
+}
+
+extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
+                                              pgr_frag_rec *d_out, uint64_t capacity, uint64_t *n_out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!s || !n_out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    *n_out = pgr_shmmrs_n_pairs(s);
+    if (*n_out == 0) return PGR_OK;
+    const int rc = shmmrs_to_frag_recs_enqueue(ctx, s, sids, query_side, d_out, capacity);
+    if (rc) return rc;
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     PGR_HIP(ctx, hipGetLastError());
     return PGR_OK;
 }

@@ -132,6 +132,21 @@ int pgr_ctx::ensure_pinned_out(size_t bytes) {
     return PGR_OK;
 }
 
+int pgr_ctx::ensure_mailbox(size_t bytes) {
+    if (bytes <= mailbox_cap && mailbox) return PGR_OK;
+    if (mailbox) (void)hipHostFree(mailbox);
+    mailbox = nullptr;
+    mailbox_cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 4, 4096);
+    hipError_t e = hipHostMalloc(&mailbox, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        mailbox = nullptr;
+        return fail(PGR_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    mailbox_cap = want;
+    return PGR_OK;
+}
+
 int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
     if (bytes == 0) return PGR_OK;
     if (bytes < (4u << 20)) {  // stream ordered like the pipelined path (the context's stream is non-blocking)
@@ -206,4 +221,7 @@ void pgr_ctx::release_all() {
     if (pinned_out) (void)hipHostFree(pinned_out);
     pinned_out = nullptr;
     pinned_out_cap = 0;
+    if (mailbox) (void)hipHostFree(mailbox);
+    mailbox = nullptr;
+    mailbox_cap = 0;
 }

@@ -505,14 +505,14 @@ constexpr int ALN_LDS_MAX = 3584;   // in a 129 KB image up to this many (36 B p
 // the same value.  Tie-break of the chain extraction (FxHashSet order in the reference, unspecified):
 // lowest sorted index.  Outputs are written into the group's own range [gs, gs+n).
 __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start,
-                                  uint64_t n_groups, AlnParams prm, float *__restrict__ v_s, int *__restrict__ pre,
+                                  const uint64_t *__restrict__ n_groups_ptr, AlnParams prm, float *__restrict__ v_s, int *__restrict__ pre,
                                   int *__restrict__ slot, pgr_hitpair *__restrict__ out_hp,
                                   uint32_t *__restrict__ chain_len, float *__restrict__ chain_score,
                                   uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
                                   uint32_t *__restrict__ err, uint32_t *__restrict__ big_list,
                                   uint32_t *__restrict__ n_big, uint32_t cls_stride) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n_groups) return;
+    if (g >= *n_groups_ptr) return;  // the grid is sized by the number of hits (an upper bound known without a round trip)
     const uint64_t gs = g_start[g];
     const int n = (int)(g_start[g + 1] - gs);
     g_nchains[g] = 0;
@@ -600,8 +600,8 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
                 best_s = vs[i];
                 best_v = i;
             }
-        if (best_v < 0) {  // aln.rs:129-131 would spin forever (non-positive scores)
-            atomicExch(err, 1u);
+        if (best_v < 0) {  // aln.rs:129-131 would spin forever (only non-positive scores left): this group ends here
+            atomicAdd(err, 1u);
             break;
         }
         uint32_t len = 0;
@@ -855,8 +855,8 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
                 bv = ov;
             }
         }
-        if (bv < 0) {  // aln.rs:129-131 would spin forever (non-positive scores)
-            if (lane == 0) atomicExch(err, 1u);
+        if (bv < 0) {  // aln.rs:129-131 would spin forever (only non-positive scores left): this group ends here
+            if (lane == 0) atomicAdd(err, 1u);
             break;
         }
         int len = 0, first_v = bv;
@@ -926,13 +926,13 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
 // dense outputs: the chaining kernels leave chains / hit pairs at their group's offset in hit-sized arrays;
 // pack them by group (chain_off / hp_off = exclusive scans of the per-group counts) so that the host receives
 // exactly what it returns
-__global__ void group_counts_kernel(const uint64_t *__restrict__ g_start, uint64_t n_groups,
-                                    const uint32_t *__restrict__ g_nch, const uint32_t *__restrict__ g_nhp,
+__global__ void group_counts_kernel(const uint64_t *__restrict__ g_start, const uint64_t *__restrict__ n_groups_ptr,
+                                    uint64_t n, const uint32_t *__restrict__ g_nch, const uint32_t *__restrict__ g_nhp,
                                     const uint64_t *__restrict__ skey, uint32_t *__restrict__ nch_out,
                                     uint32_t *__restrict__ nhp_out, uint64_t *__restrict__ gkey_out) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > n_groups) return;
-    if (g == n_groups) {  // scan sentinels
+    if (g > n) return;
+    if (g >= *n_groups_ptr) {  // beyond the last group (arrays are sized by the number of hits) + the scan sentinel
         nch_out[g] = 0;
         nhp_out[g] = 0;
         return;
@@ -944,7 +944,7 @@ __global__ void group_counts_kernel(const uint64_t *__restrict__ g_start, uint64
     gkey_out[g] = skey[gs];
 }
 
-__global__ void pack_chains_kernel(const uint64_t *__restrict__ g_start, uint64_t n_groups, uint64_t n,
+__global__ void pack_chains_kernel(const uint64_t *__restrict__ g_start, uint64_t n,
                                    const uint32_t *__restrict__ flags, const uint64_t *__restrict__ rank,
                                    const uint32_t *__restrict__ nch, const uint32_t *__restrict__ nhp,
                                    const uint64_t *__restrict__ chain_off, const uint64_t *__restrict__ hp_off,
@@ -965,29 +965,34 @@ __global__ void pack_chains_kernel(const uint64_t *__restrict__ g_start, uint64_
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// host orchestration of the chaining stage: hits (key = group id, hp) -> per-group chains
+// host orchestration of the chaining stage: hits (key = group id, hp) -> per-group chains.
+// Two host round trips: one for the totals (chains, hit pairs, groups) that size the packed output, one for the
+// download.  Every per-group array is sized by the number of hits (an upper bound on the number of groups) and the
+// kernels read the true group count from device memory, so nothing waits for it.
 namespace {
 
+inline size_t up8(size_t v) { return (v + 7) & ~(size_t)7; }
+
+// one host block = the packed device image (downloaded in one piece) + the small offset arrays built on the host;
+// pgr_hps_result's pointers point into it and pgr_hps_result_free releases it as a whole (`_owner`)
 struct ChainOut {
-    std::vector<uint64_t> g_key;      // key of every group with >= 2 hits
-    std::vector<uint32_t> g_nchains;  // chains per such group
-    // dense per-chain / per-hit-pair outputs, malloc'd: fill_result hands c_score and hps to the caller as they are
-    float *c_score = nullptr;
-    uint32_t *c_len = nullptr;
+    uint8_t *block = nullptr;
+    uint64_t n_groups = 0, n_chains = 0, n_hps = 0, n_nonterm = 0;
+    // views into block (device image)
+    const uint64_t *g_start = nullptr, *g_key = nullptr;
     pgr_hitpair *hps = nullptr;
-    uint64_t n_chains = 0, n_hps = 0;
+    float *c_score = nullptr;
+    const uint32_t *c_len = nullptr, *g_nch = nullptr;
+    size_t image_bytes = 0;
     ChainOut() = default;
     ChainOut(const ChainOut &) = delete;
     ChainOut &operator=(const ChainOut &) = delete;
-    ~ChainOut() {
-        free(c_score);
-        free(c_len);
-        free(hps);
-    }
+    ~ChainOut() { free(block); }
 };
 
+// extra = bytes the caller wants behind the image in the same host block (the offset arrays of fill_result)
 int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uint64_t n, const AlnParams &prm,
-               ChainOut &out) {
+               uint32_t n_queries, ChainOut &out) {
     if (n == 0) return PGR_OK;
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 hits in one batch");
     hipStream_t st = ctx->stream;
@@ -1003,7 +1008,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     Tmp idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), skey(ctx), shp(ctx), flags(ctx), rank(ctx), gstart(ctx);
     if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)) ||
         (rc = skey.alloc(n * 8)) || (rc = shp.alloc(n * sizeof(pgr_hitpair))) || (rc = flags.alloc((n + 1) * 4)) ||
-        (rc = rank.alloc((n + 1) * 8)))
+        (rc = rank.alloc((n + 1) * 8)) || (rc = gstart.alloc((n + 2) * 8)))
         return rc;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
     const size_t tb = sort_pairs_temp_bytes(n);
@@ -1020,10 +1025,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, scan_counts_temp_bytes((uint32_t)(n + 1)), flags.as<uint32_t>(),
                              rank.as<uint64_t>(), (uint32_t)(n + 1)));
     lap("sorted + grouped");
-    uint64_t n_groups = 0;
-    PGR_HIP(ctx, hipMemcpyAsync(&n_groups, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipStreamSynchronize(st));
-    if ((rc = gstart.alloc((n_groups + 1) * 8))) return rc;
+    const uint64_t *d_ngroups = rank.as<uint64_t>() + n;  // number of groups, on the device
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(), rank.as<uint64_t>(),
                        n, gstart.as<uint64_t>());
     Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx), big(ctx),
@@ -1031,12 +1033,12 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     const uint64_t max_big = n / ALN_WAVE_MIN + 1;  // a wave-chained group has at least ALN_WAVE_MIN hits
     if ((rc = v_s.alloc(n * 4)) || (rc = pre.alloc(n * 4)) || (rc = slot.alloc(n * 4)) ||
         (rc = o_hp.alloc(n * sizeof(pgr_hitpair))) || (rc = c_len.alloc(n * 4)) || (rc = c_score.alloc(n * 4)) ||
-        (rc = g_nch.alloc(n_groups * 4)) || (rc = g_nhp.alloc(n_groups * 4)) || (rc = err.alloc(16)) ||
+        (rc = g_nch.alloc(n * 4)) || (rc = g_nhp.alloc(n * 4)) || (rc = err.alloc(16)) ||
         (rc = big.alloc(2 * max_big * 4)) || (rc = trk.alloc(n * 4)))
         return rc;
-    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 16, st));  // [0] error flag, [1], [2] number of groups per wave class
-    hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n_groups, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
-                       gstart.as<uint64_t>(), n_groups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
+    PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 16, st));  // [0] groups the reference never finishes, [1], [2] groups per wave class
+    hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
+                       gstart.as<uint64_t>(), d_ngroups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
                        o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(), g_nch.as<uint32_t>(),
                        g_nhp.as<uint32_t>(), err.as<uint32_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1,
                        (uint32_t)max_big);
@@ -1051,115 +1053,113 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
                        prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(), trk.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
                        c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
     lap("chained");
-    // pack on the device, then download straight into the buffers that are handed to the caller
+    // per-group counts -> offsets of the packed output
     Tmp d_nch(ctx), d_nhp(ctx), d_gkey(ctx), d_choff(ctx), d_hpoff(ctx);
-    if ((rc = d_nch.alloc((n_groups + 1) * 4)) || (rc = d_nhp.alloc((n_groups + 1) * 4)) || (rc = d_gkey.alloc(n_groups * 8)) ||
-        (rc = d_choff.alloc((n_groups + 1) * 8)) || (rc = d_hpoff.alloc((n_groups + 1) * 8)))
+    if ((rc = d_nch.alloc((n + 1) * 4)) || (rc = d_nhp.alloc((n + 1) * 4)) || (rc = d_gkey.alloc(n * 8)) ||
+        (rc = d_choff.alloc((n + 1) * 8)) || (rc = d_hpoff.alloc((n + 1) * 8)))
         return rc;
-    hipLaunchKernelGGL(group_counts_kernel, grid_for(n_groups + 1), dim3(256), 0, st, gstart.as<uint64_t>(), n_groups,
+    hipLaunchKernelGGL(group_counts_kernel, grid_for(n + 1), dim3(256), 0, st, gstart.as<uint64_t>(), d_ngroups, n,
                        g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), skey.as<uint64_t>(), d_nch.as<uint32_t>(),
                        d_nhp.as<uint32_t>(), d_gkey.as<uint64_t>());
-    const size_t tbg = scan_counts_temp_bytes((uint32_t)(n_groups + 1));
-    if ((rc = ctx->ws_scan_tmp.ensure_keep(ctx, tbg, st))) return rc;
-    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nch.as<uint32_t>(), d_choff.as<uint64_t>(), (uint32_t)(n_groups + 1)));
-    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nhp.as<uint32_t>(), d_hpoff.as<uint64_t>(), (uint32_t)(n_groups + 1)));
-    uint64_t totals[2] = {0, 0};
-    uint32_t h_err = 0;
-    PGR_HIP(ctx, hipMemcpyAsync(&totals[0], d_choff.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(&totals[1], d_hpoff.as<uint64_t>() + n_groups, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(&h_err, err.p, 4, hipMemcpyDeviceToHost, st));
+    const size_t tbg = scan_counts_temp_bytes((uint32_t)(n + 1));
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nch.as<uint32_t>(), d_choff.as<uint64_t>(), (uint32_t)(n + 1)));
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nhp.as<uint32_t>(), d_hpoff.as<uint64_t>(), (uint32_t)(n + 1)));
+    // ---- round trip 1: the totals
+    if ((rc = ctx->ensure_mailbox(64))) return rc;
+    uint64_t *mb = (uint64_t *)ctx->mailbox;
+    PGR_HIP(ctx, hipMemcpyAsync(mb + 0, d_choff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(mb + 1, d_hpoff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(mb + 2, d_ngroups, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(mb + 3, err.p, 4, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
     PGR_HIP(ctx, hipGetLastError());
-    if (h_err)
-        return ctx->fail(PGR_ERR_INVALID_ARG,
-                         "sparse_aln: a hit pair with end <= bgn (non-positive score); the reference never terminates "
-                         "on such input (aln.rs:129-131)");
-    const uint64_t n_chains = totals[0], n_hps = totals[1];
-    Tmp p_clen(ctx), p_cscore(ctx), p_hp(ctx);
-    if ((rc = p_clen.alloc(std::max<uint64_t>(n_chains, 1) * 4)) || (rc = p_cscore.alloc(std::max<uint64_t>(n_chains, 1) * 4)) ||
-        (rc = p_hp.alloc(std::max<uint64_t>(n_hps, 1) * sizeof(pgr_hitpair))))
-        return rc;
-    hipLaunchKernelGGL(pack_chains_kernel, grid_for(n), dim3(256), 0, st, gstart.as<uint64_t>(), n_groups, n,
+    const uint64_t n_chains = mb[0], n_hps = mb[1], n_groups = mb[2];
+    out.n_nonterm = (uint32_t)mb[3];
+    // ---- packed device image: g_start | g_key | hps | c_score | c_len | g_nch, one download
+    const size_t o_gstart = 0, o_gkey = o_gstart + (n_groups + 1) * 8, o_hps = o_gkey + n_groups * 8,
+                 o_cscore = o_hps + n_hps * sizeof(pgr_hitpair), o_clen = up8(o_cscore + n_chains * 4),
+                 o_nch = up8(o_clen + n_chains * 4), image = up8(o_nch + (n_groups + 1) * 4);
+    Tmp img(ctx);
+    if ((rc = img.alloc(image))) return rc;
+    uint8_t *dI = img.as<uint8_t>();
+    hipLaunchKernelGGL(pack_chains_kernel, grid_for(n), dim3(256), 0, st, gstart.as<uint64_t>(), n,
                        flags.as<uint32_t>(), rank.as<uint64_t>(), d_nch.as<uint32_t>(), d_nhp.as<uint32_t>(),
                        d_choff.as<uint64_t>(), d_hpoff.as<uint64_t>(), c_len.as<uint32_t>(), c_score.as<float>(),
-                       o_hp.as<pgr_hitpair>(), p_clen.as<uint32_t>(), p_cscore.as<float>(), p_hp.as<pgr_hitpair>());
-    out.c_score = (float *)malloc(std::max<uint64_t>(n_chains, 1) * sizeof(float));
-    out.c_len = (uint32_t *)malloc(std::max<uint64_t>(n_chains, 1) * sizeof(uint32_t));
-    out.hps = (pgr_hitpair *)malloc(std::max<uint64_t>(n_hps, 1) * sizeof(pgr_hitpair));
-    std::vector<uint64_t> h_gstart(n_groups + 1), h_gkey(n_groups);
-    std::vector<uint32_t> h_nch(n_groups + 1);
-    if (!out.c_score || !out.c_len || !out.hps) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
-    if ((rc = ctx->d2h(out.c_score, p_cscore.p, n_chains * 4)) || (rc = ctx->d2h(out.c_len, p_clen.p, n_chains * 4)) ||
-        (rc = ctx->d2h(out.hps, p_hp.p, n_hps * sizeof(pgr_hitpair))) ||
-        (rc = ctx->d2h(h_gstart.data(), gstart.p, (n_groups + 1) * 8)) || (rc = ctx->d2h(h_gkey.data(), d_gkey.p, n_groups * 8)) ||
-        (rc = ctx->d2h(h_nch.data(), d_nch.p, (n_groups + 1) * 4)))
-        return rc;
+                       o_hp.as<pgr_hitpair>(), (uint32_t *)(dI + o_clen), (float *)(dI + o_cscore), (pgr_hitpair *)(dI + o_hps));
+    PGR_HIP(ctx, hipMemcpyAsync(dI + o_gstart, gstart.p, (n_groups + 1) * 8, hipMemcpyDeviceToDevice, st));
+    if (n_groups) PGR_HIP(ctx, hipMemcpyAsync(dI + o_gkey, d_gkey.p, n_groups * 8, hipMemcpyDeviceToDevice, st));
+    PGR_HIP(ctx, hipMemcpyAsync(dI + o_nch, d_nch.p, (n_groups + 1) * 4, hipMemcpyDeviceToDevice, st));
+    // host block: image + room for q_off, t_off, c_off (u64) and t_sid (u32) that fill_result builds
+    const size_t extra = ((size_t)n_queries + 1) * 8 + (n_groups + 1) * 8 + (n_chains + 1) * 8 + up8(n_groups * 4);
+    out.block = (uint8_t *)malloc(image + extra + 8);
+    if (!out.block) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    if ((rc = ctx->d2h(out.block, dI, image))) return rc;  // ---- round trip 2
     PGR_HIP(ctx, hipGetLastError());
+    out.image_bytes = image;
+    out.n_groups = n_groups;
     out.n_chains = n_chains;
     out.n_hps = n_hps;
+    out.g_start = (const uint64_t *)(out.block + o_gstart);
+    out.g_key = (const uint64_t *)(out.block + o_gkey);
+    out.hps = (pgr_hitpair *)(out.block + o_hps);
+    out.c_score = (float *)(out.block + o_cscore);
+    out.c_len = (const uint32_t *)(out.block + o_clen);
+    out.g_nch = (const uint32_t *)(out.block + o_nch);
     lap("downloaded");
-    out.g_key.reserve(n_groups);
-    out.g_nchains.reserve(n_groups);
-    for (uint64_t g = 0; g < n_groups; ++g) {
-        if (h_gstart[g + 1] - h_gstart[g] < 2) continue;  // aln.rs:234
-        out.g_key.push_back(h_gkey[g]);
-        out.g_nchains.push_back(h_nch[g]);
-    }
-    lap("assembled");
     return PGR_OK;
 }
 
-template <class T>
-T *dup_vec(const std::vector<T> &v) {
-    T *p = (T *)malloc(std::max<size_t>(v.size(), 1) * sizeof(T));
-    if (p && !v.empty()) memcpy(p, v.data(), v.size() * sizeof(T));
-    return p;
-}
-
-// groups are sorted by key = (query << 32 | sid): flat result
+// groups are sorted by key = (query << 32 | sid): flat result.  The offset arrays go behind the image in co.block.
 int fill_result(pgr_ctx *ctx, uint32_t n_queries, ChainOut &co, pgr_hps_result *out) {
-    std::vector<uint64_t> q_off((size_t)n_queries + 1, 0), t_off;
-    std::vector<uint32_t> t_sid;
-    t_off.reserve(co.g_key.size() + 1);
-    t_sid.reserve(co.g_key.size());
-    uint64_t n_chains = 0;
-    size_t gi = 0;
+    if (!co.block) {  // no hits at all
+        const size_t bytes = ((size_t)n_queries + 1) * 8 + 3 * 8 + 64;
+        co.block = (uint8_t *)calloc(1, bytes);
+        if (!co.block) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+        co.image_bytes = 0;
+    }
+    uint8_t *p = co.block + co.image_bytes;
+    uint64_t *q_off = (uint64_t *)p;
+    p += ((size_t)n_queries + 1) * 8;
+    uint64_t *t_off = (uint64_t *)p;
+    p += (co.n_groups + 1) * 8;
+    uint64_t *c_off = (uint64_t *)p;
+    p += (co.n_chains + 1) * 8;
+    uint32_t *t_sid = (uint32_t *)p;
+    uint64_t n_targets = 0, n_chains = 0;
+    uint64_t g = 0;
     for (uint32_t q = 0; q < n_queries; ++q) {
-        q_off[q] = t_sid.size();
-        while (gi < co.g_key.size() && (uint32_t)(co.g_key[gi] >> 32) == q) {
-            t_sid.push_back((uint32_t)(co.g_key[gi] & 0xFFFFFFFFull));
-            t_off.push_back(n_chains);
-            n_chains += co.g_nchains[gi];
-            ++gi;
+        q_off[q] = n_targets;
+        for (; g < co.n_groups && (uint32_t)(co.g_key[g] >> 32) <= q; ++g) {
+            if ((uint32_t)(co.g_key[g] >> 32) != q) continue;
+            if (co.g_start[g + 1] - co.g_start[g] < 2) continue;  // aln.rs:234: targets with a single hit are dropped
+            t_sid[n_targets] = (uint32_t)(co.g_key[g] & 0xFFFFFFFFull);
+            t_off[n_targets] = n_chains;
+            n_chains += co.g_nch[g];
+            ++n_targets;
         }
     }
-    q_off[n_queries] = t_sid.size();
-    t_off.push_back(n_chains);
-    uint64_t *c_off = (uint64_t *)malloc((n_chains + 1) * sizeof(uint64_t));
-    out->n_queries = n_queries;
-    out->q_off = dup_vec(q_off);
-    out->n_targets = t_sid.size();
-    out->t_sid = dup_vec(t_sid);
-    out->t_off = dup_vec(t_off);
-    out->n_chains = n_chains;
-    out->c_off = c_off;
-    out->n_hps = co.n_hps;
-    // the dense chain scores / hit pairs go to the caller as they came from the device
-    out->c_score = co.c_score ? co.c_score : (float *)malloc(sizeof(float));
-    out->hps = co.hps ? co.hps : (pgr_hitpair *)malloc(sizeof(pgr_hitpair));
-    co.c_score = nullptr;
-    co.hps = nullptr;
-    if (!out->q_off || !out->t_sid || !out->t_off || !out->c_score || !out->c_off || !out->hps || n_chains != co.n_chains) {
-        pgr_hps_result_free(out);
-        return ctx->fail(n_chains != co.n_chains ? PGR_ERR_INTERNAL : PGR_ERR_NOMEM,
-                         n_chains != co.n_chains ? "chain bookkeeping mismatch" : "host allocation failed");
-    }
+    q_off[n_queries] = n_targets;
+    t_off[n_targets] = n_chains;
+    if (n_chains != co.n_chains) return ctx->fail(PGR_ERR_INTERNAL, "chain bookkeeping mismatch");
     uint64_t n_hp = 0;
     for (uint64_t c = 0; c < n_chains; ++c) {
         c_off[c] = n_hp;
         n_hp += co.c_len[c];
     }
     c_off[n_chains] = n_hp;
+    out->n_queries = n_queries;
+    out->q_off = q_off;
+    out->n_targets = n_targets;
+    out->t_sid = t_sid;
+    out->t_off = t_off;
+    out->n_chains = n_chains;
+    out->c_score = co.c_score ? co.c_score : (float *)t_off;  // (never dereferenced when n_chains == 0)
+    out->c_off = c_off;
+    out->n_hps = co.n_hps;
+    out->hps = co.hps ? co.hps : (pgr_hitpair *)t_off;
+    out->n_nonterminating = co.n_nonterm;
+    out->_owner = co.block;
+    co.block = nullptr;
     return PGR_OK;
 }
 
@@ -1167,13 +1167,133 @@ int fill_result(pgr_ctx *ctx, uint32_t n_queries, ChainOut &co, pgr_hps_result *
 
 extern "C" void pgr_hps_result_free(pgr_hps_result *r) {
     if (!r) return;
-    free(r->q_off);
-    free(r->t_sid);
-    free(r->t_off);
-    free(r->c_score);
-    free(r->c_off);
-    free(r->hps);
+    free(r->_owner);  // every array of the result lives in this one block
     memset(r, 0, sizeof(*r));
+}
+
+extern "C" int pgr_ctx_last_query_prof(const pgr_ctx *ctx, pgr_query_prof *out) {
+    if (!ctx || !out) return PGR_ERR_INVALID_ARG;
+    *out = ctx->qprof;
+    return PGR_OK;
+}
+
+namespace {
+// sum over the query pairs of the number of fragment signatures their key holds in the index (before the count
+// filters): what the lookup stage reads, 17 B each in the reference's layout
+__global__ void sum_ranges_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, uint64_t nq,
+                                  unsigned long long *__restrict__ total) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t v = p < nq ? (uint32_t)(hi[p] - lo[p]) : 0u;
+    v = wave_incl_sum(v);
+    if ((threadIdx.x & 63) == 63 && v) atomicAdd(total, (unsigned long long)v);
+}
+}  // namespace
+
+// B2 on a resident batch of queries (the H2D of the ASCII queries already happened: pgr_batch_from_ascii)
+extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const pgr_batch *b, float penalty,
+                                      uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
+                                      uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
+                                      pgr_hps_result *out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix || !out || !b) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
+    if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
+    if (max_aln_span == 0 || max_aln_span > MAX_SPAN_CAP)
+        return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be in 1..64");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
+        return (float)std::chrono::duration<double, std::milli>(b2 - a).count();
+    };
+    const uint32_t n_queries = b->n;
+    pgr_query_prof qp = {};
+    qp.n_queries = n_queries;
+    qp.query_bases = b->total_bases;
+    const auto t1 = now();
+    // queries -> shimmer-pair records, query side (strict <, seq_db.rs:1213); sid field = query index
+    pgr_shmmrs *s = nullptr;
+    int rc = pgr_shmmrs_compute(ctx, b, &ix->spec, nullptr, 0, &s);
+    if (rc) return rc;
+    const auto t2 = now();
+    auto t3 = t2, t4 = t2;
+    const uint64_t nq = pgr_shmmrs_n_pairs(s);
+    qp.n_query_pairs = nq;
+    ChainOut co;
+    if (nq && ix->n) {
+        Tmp qrec(ctx), lo(ctx), hi(ctx), cnt(ctx), idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), nh(ctx), hoff(ctx), nsig(ctx);
+        if ((rc = qrec.alloc(nq * sizeof(pgr_frag_rec)))) {
+            pgr_shmmrs_destroy(s);
+            return rc;
+        }
+        rc = shmmrs_to_frag_recs_enqueue(ctx, s, nullptr, 1, qrec.as<pgr_frag_rec>(), nq);  // stream ordered, no wait
+        pgr_shmmrs_destroy(s);
+        s = nullptr;
+        if (rc) return rc;
+        if ((rc = lo.alloc(nq * 8)) || (rc = hi.alloc(nq * 8)) || (rc = cnt.alloc(nq * 4)) || (rc = idx_a.alloc(nq * 4)) ||
+            (rc = idx_b.alloc(nq * 4)) || (rc = keys_a.alloc(nq * 8)) || (rc = keys_b.alloc(nq * 8)) ||
+            (rc = nh.alloc((nq + 1) * 4)) || (rc = hoff.alloc((nq + 1) * 8)) || (rc = nsig.alloc(16)))
+            return rc;
+        hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
+                           ix->key_off, ix->n_keys, lo.as<uint64_t>(), hi.as<uint64_t>());
+        PGR_HIP(ctx, hipMemsetAsync(nsig.p, 0, 16, st));
+        hipLaunchKernelGGL(sum_ranges_kernel, grid_for(nq), dim3(256), 0, st, lo.as<uint64_t>(), hi.as<uint64_t>(), nq,
+                           nsig.as<unsigned long long>());
+        // per-query key multiplicities: sort the pairs by (query, h0, h1), count runs
+        hipLaunchKernelGGL(iota_kernel, grid_for(nq), dim3(256), 0, st, idx_a.as<uint32_t>(), nq);
+        const int fields[3] = {2, 3, 1};  // h1, h0, sid(=query)
+        const unsigned bits[3] = {56, 56, 32};
+        if ((rc = sort_perm(ctx, qrec.as<pgr_frag_rec>(), nq, fields, bits, 3, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+                            keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
+            return rc;
+        hipLaunchKernelGGL(run_count_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(),
+                           idx_a.as<uint32_t>(), nq, cnt.as<uint32_t>());
+        QParams qprm{max_count, max_count_query, max_count_target};
+        hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
+                           cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qprm, 0, nh.as<uint32_t>(),
+                           (const uint64_t *)nullptr, (uint64_t *)nullptr, (pgr_hitpair *)nullptr);
+        const size_t tb = scan_counts_temp_bytes((uint32_t)(nq + 1));
+        if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
+        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, nh.as<uint32_t>(), hoff.as<uint64_t>(), (uint32_t)(nq + 1)));
+        if ((rc = ctx->ensure_mailbox(64))) return rc;
+        uint64_t *mb = (uint64_t *)ctx->mailbox;
+        PGR_HIP(ctx, hipMemcpyAsync(mb + 0, hoff.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipMemcpyAsync(mb + 1, nsig.p, 8, hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));  // the number of hits sizes everything behind this point
+        const uint64_t n_hits = mb[0];
+        qp.n_signatures = mb[1];
+        qp.n_hits = n_hits;
+        t3 = now();
+        if (n_hits) {
+            Tmp hkey(ctx), hhp(ctx);
+            if ((rc = hkey.alloc(n_hits * 8)) || (rc = hhp.alloc(n_hits * sizeof(pgr_hitpair)))) return rc;
+            hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
+                               cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qprm, 1,
+                               (uint32_t *)nullptr, hoff.as<uint64_t>(), hkey.as<uint64_t>(), hhp.as<pgr_hitpair>());
+            AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
+            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, n_queries, co))) return rc;
+        }
+        t4 = now();
+    } else {
+        pgr_shmmrs_destroy(s);
+    }
+    rc = fill_result(ctx, n_queries, co, out);
+    const auto t5 = now();
+    qp.n_groups = out->n_targets;
+    qp.n_chains = out->n_chains;
+    qp.n_hps = out->n_hps;
+    qp.shmmr_ms = ms(t1, t2);
+    qp.lookup_ms = ms(t2, t3);
+    qp.chain_ms = ms(t3, t4);
+    qp.result_ms = ms(t4, t5);
+    qp.total_ms = ms(t1, t5);
+    ctx->qprof = qp;
+    if (dbg)
+        fprintf(stderr, "[pgr] query batch %u: shimmers %.2f ms, lookup+counts %.2f, hits+chain %.2f, result %.2f\n", n_queries,
+                qp.shmmr_ms, qp.lookup_ms, qp.chain_ms, qp.result_ms);
+    return rc;
 }
 
 extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries, const uint8_t *const *seqs,
@@ -1186,81 +1306,16 @@ extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
     if (max_aln_span == 0 || max_aln_span > MAX_SPAN_CAP)
         return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be in 1..64");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
-    auto now = [] { return std::chrono::steady_clock::now(); };
-    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) {
-        return std::chrono::duration<double, std::milli>(b - a).count();
-    };
-    const auto t0 = now();
-    // queries -> shimmer-pair records, query side (strict <, seq_db.rs:1213); sid field = query index
+    const auto t0 = std::chrono::steady_clock::now();
     pgr_batch *b = nullptr;
-    int rc = pgr_batch_from_ascii(ctx, n_queries, seqs, lens, &b);
+    int rc = pgr_batch_from_ascii(ctx, n_queries, seqs, lens, &b);  // enqueues H2D + pack; nothing waits here
     if (rc) return rc;
-    const auto t1 = now();
-    pgr_shmmrs *s = nullptr;
-    rc = pgr_shmmrs_compute(ctx, b, &ix->spec, nullptr, 0, &s);
+    const float stage = (float)std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    rc = pgr_query_hps_resident(ctx, ix, b, penalty, max_count, max_count_query, max_count_target, max_aln_span, has_max_gap,
+                                max_gap, oriented, out);
     pgr_batch_destroy(b);
-    if (rc) return rc;
-    const auto t2 = now();
-    auto t3 = t2, t4 = t2;
-    const uint64_t nq = pgr_shmmrs_n_pairs(s);
-    ChainOut co;
-    if (nq && ix->n) {
-        Tmp qrec(ctx), lo(ctx), hi(ctx), cnt(ctx), idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), nh(ctx), hoff(ctx);
-        if ((rc = qrec.alloc(nq * sizeof(pgr_frag_rec)))) {
-            pgr_shmmrs_destroy(s);
-            return rc;
-        }
-        uint64_t n_out = 0;
-        rc = pgr_shmmrs_to_frag_recs_device(ctx, s, nullptr, 1, qrec.as<pgr_frag_rec>(), nq, &n_out);
-        pgr_shmmrs_destroy(s);
-        s = nullptr;
-        if (rc) return rc;
-        if ((rc = lo.alloc(nq * 8)) || (rc = hi.alloc(nq * 8)) || (rc = cnt.alloc(nq * 4)) || (rc = idx_a.alloc(nq * 4)) ||
-            (rc = idx_b.alloc(nq * 4)) || (rc = keys_a.alloc(nq * 8)) || (rc = keys_b.alloc(nq * 8)) ||
-            (rc = nh.alloc((nq + 1) * 4)) || (rc = hoff.alloc((nq + 1) * 8)))
-            return rc;
-        hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
-                           ix->key_off, ix->n_keys, lo.as<uint64_t>(), hi.as<uint64_t>());
-        // per-query key multiplicities: sort the pairs by (query, h0, h1), count runs
-        hipLaunchKernelGGL(iota_kernel, grid_for(nq), dim3(256), 0, st, idx_a.as<uint32_t>(), nq);
-        const int fields[3] = {2, 3, 1};  // h1, h0, sid(=query)
-        const unsigned bits[3] = {56, 56, 32};
-        if ((rc = sort_perm(ctx, qrec.as<pgr_frag_rec>(), nq, fields, bits, 3, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
-                            keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
-            return rc;
-        hipLaunchKernelGGL(run_count_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(),
-                           idx_a.as<uint32_t>(), nq, cnt.as<uint32_t>());
-        QParams qp{max_count, max_count_query, max_count_target};
-        hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
-                           cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qp, 0, nh.as<uint32_t>(),
-                           (const uint64_t *)nullptr, (uint64_t *)nullptr, (pgr_hitpair *)nullptr);
-        const size_t tb = scan_counts_temp_bytes((uint32_t)(nq + 1));
-        if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
-        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, nh.as<uint32_t>(), hoff.as<uint64_t>(), (uint32_t)(nq + 1)));
-        uint64_t n_hits = 0;
-        PGR_HIP(ctx, hipMemcpyAsync(&n_hits, hoff.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipStreamSynchronize(st));
-        t3 = now();
-        if (n_hits) {
-            Tmp hkey(ctx), hhp(ctx);
-            if ((rc = hkey.alloc(n_hits * 8)) || (rc = hhp.alloc(n_hits * sizeof(pgr_hitpair)))) return rc;
-            hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
-                               cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qp, 1,
-                               (uint32_t *)nullptr, hoff.as<uint64_t>(), hkey.as<uint64_t>(), hhp.as<pgr_hitpair>());
-            AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
-            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, co))) return rc;
-        }
-        t4 = now();
-    } else {
-        pgr_shmmrs_destroy(s);
-    }
-    rc = fill_result(ctx, n_queries, co, out);
-    if (dbg)
-        fprintf(stderr, "[pgr] query batch %u: stage+pack %.2f ms, shimmers %.2f, lookup+counts %.2f, hits+chain %.2f, result %.2f\n",
-                n_queries, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, t4), ms(t4, now()));
+    ctx->qprof.stage_ms = stage;  // host time of the staging (pinned memcpy + enqueue); the copy itself overlaps the rest
+    ctx->qprof.total_ms += stage;
     return rc;
 }
 
@@ -1288,7 +1343,7 @@ extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_h
         PGR_HIP(ctx, hipMemcpyAsync(dh.p, hits, n * sizeof(pgr_hitpair), hipMemcpyHostToDevice, ctx->stream));
         PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         AlnParams ap{max_span, penalty, has_max_gap, max_gap, oriented};
-        if ((rc = chain_hits(ctx, dk.as<uint64_t>(), dh.as<pgr_hitpair>(), n, ap, co))) return rc;
+        if ((rc = chain_hits(ctx, dk.as<uint64_t>(), dh.as<pgr_hitpair>(), n, ap, 1, co))) return rc;
     }
     return fill_result(ctx, 1, co, out);
 }

@@ -422,6 +422,7 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         if (s_skip) {
             atomicOr(a.contig_flags + c, 1u);
             a.tile_flags[tile] = 1;
+            atomicOr(a.cursor + 2, 1ull);  // batch-wide "some tile needs the exact path" word (read once by the host)
         }
     }
     // selected keys go through LDS (s_suf is free now; each lane re-reads only its own column, so no barrier
@@ -965,7 +966,10 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
         if (w0 + 32 > hi) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - hi);
         bad = (v[wj] & m) != m;
     }
-    if (bad) a.tile_flags[tile] = 1;
+    if (bad) {
+        a.tile_flags[tile] = 1;
+        atomicOr(a.cursor + 2, 2ull);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -20,21 +20,22 @@ __global__ __launch_bounds__(256) void gather_segments_kernel(const pgr_mm128 *_
                                                               const uint64_t *__restrict__ seg_off,
                                                               const uint32_t *__restrict__ seg_cnt,
                                                               const uint64_t *__restrict__ seg_dst, uint32_t n_segs,
-                                                              pgr_mm128 *__restrict__ dst) {
+                                                              pgr_mm128 *__restrict__ dst, uint64_t dst_cap) {
     const uint32_t seg = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (seg >= n_segs) return;
     const uint32_t lane = threadIdx.x & 63;
     const uint32_t cnt = seg_cnt[seg];
+    if (seg_dst[seg] + cnt > dst_cap) return;  // result buffer sized by estimate: the host retries with the true size
     const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(src) + seg_off[seg];
     ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst) + seg_dst[seg];
     for (uint32_t i = lane; i < cnt; i += 64) d[i] = s[i];
 }
 
 void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,
-                            const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst) {
+                            const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst, uint64_t dst_cap) {
     if (n_segs == 0) return;
     hipLaunchKernelGGL(gather_segments_kernel, dim3((n_segs + 3) / 4), dim3(256), 0, st, src, seg_off, seg_cnt, seg_dst,
-                       n_segs, dst);
+                       n_segs, dst, dst_cap);
 }
 
 namespace {
@@ -250,14 +251,22 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     constexpr int FUSED_CMAX = FusedLds::CMAX;
     __shared__ FusedLds L;
     const uint32_t t = threadIdx.x;
+    const uint64_t total = *a.total;
     const uint64_t core_lo = (uint64_t)blockIdx.x * FUSED_B;
+    if (core_lo >= total) {  // the grid is an upper bound (sized before the level-1 count is known): nothing to do here
+        if (t == 0) {
+            a.blk_off[blockIdx.x] = 0;
+            a.blk_cnt[blockIdx.x] = 0;
+        }
+        return;
+    }
     uint64_t core_hi = core_lo + FUSED_B;
-    if (core_hi > a.total) core_hi = a.total;
+    if (core_hi > total) core_hi = total;
     const uint64_t lo = core_lo >= a.halo ? core_lo - a.halo : 0;
     uint64_t hi = core_hi + a.halo;
-    if (hi > a.total) hi = a.total;
+    if (hi > total) hi = total;
     const int ne = (int)(hi - lo);
-    const bool lo_is_start = (lo == 0), hi_is_end = (hi == a.total);
+    const bool lo_is_start = (lo == 0), hi_is_end = (hi == total);
 
     // ---- stream [lo, hi) of the logical level-1 list into LDS.  Segment descriptors are staged 64 at a time
     // (the segment holding `lo` was located by block_first_seg_kernel); then every lane fetches its own
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     while (done < hi) {
         if (t < FUSED_SEGS + 1) {
             const uint32_t sg = seg0 + t;
-            const uint64_t d = (sg <= a.n_segs) ? a.seg_dst[sg] : a.total;  // seg_dst[n_segs] = total
+            const uint64_t d = (sg <= a.n_segs) ? a.seg_dst[sg] : total;  // seg_dst[n_segs] = total
             L.sdst[t] = d;
             if (t < FUSED_SEGS) L.soff[t] = (sg < a.n_segs) ? a.seg_off[sg] : 0;
         }
@@ -407,10 +416,11 @@ __global__ void block_first_seg_kernel(const uint64_t *__restrict__ seg_dst, uin
 }
 
 // offsets of the final ordered list: off[c] = first element whose (internal) rid >= c
-__global__ void offsets_by_rid_kernel(const pgr_mm128 *__restrict__ mm, uint64_t n, uint32_t n_contigs,
-                                      uint64_t *__restrict__ off) {
+__global__ void offsets_by_rid_kernel(const pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ n_ptr, uint64_t cap,
+                                      uint32_t n_contigs, uint64_t *__restrict__ off) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c > n_contigs) return;
+    const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
     uint64_t lo = 0, hi = n;  // first j with rid(j) >= c
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
@@ -420,9 +430,10 @@ __global__ void offsets_by_rid_kernel(const pgr_mm128 *__restrict__ mm, uint64_t
     off[c] = lo;
 }
 
-__global__ void patch_rid_kernel(pgr_mm128 *__restrict__ mm, uint64_t n, const uint32_t *__restrict__ rids) {
+__global__ void patch_rid_kernel(pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ n_ptr, uint64_t cap,
+                                 const uint32_t *__restrict__ rids) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= cap || i >= *n_ptr) return;
     const uint64_t y = mm[i].y;
     mm[i].y = ((uint64_t)rids[(uint32_t)(y >> 32)] << 32) | (y & 0xFFFFFFFFull);
 }
@@ -436,8 +447,66 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
     else
         hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
 }
-void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off) {
-    hipLaunchKernelGGL(offsets_by_rid_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, mm, n, n_contigs, off);
+void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
+                           uint64_t *off) {
+    hipLaunchKernelGGL(offsets_by_rid_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, mm, n_ptr, cap, n_contigs,
+                       off);
+}
+__global__ void collect_status_kernel(const unsigned long long *__restrict__ cursor, const uint64_t *__restrict__ total1,
+                                      const uint64_t *__restrict__ n_final, uint64_t *__restrict__ status) {
+    const uint32_t t = threadIdx.x;
+    if (t < 8) status[t] = cursor[t];
+    if (t == 8) status[8] = *total1;
+    if (t == 9) status[9] = *n_final;
+}
+void launch_collect_status(hipStream_t st, const unsigned long long *cursor, const uint64_t *total1, const uint64_t *n_final,
+                           uint64_t *status) {
+    hipLaunchKernelGGL(collect_status_kernel, dim3(1), dim3(64), 0, st, cursor, total1, n_final, status);
+}
+
+// ------------------------------------------------------------------ content checksum (bench.py / tests: full-size parity)
+// sums[2c] += splitmix64(x ^ K1 (i+1)), sums[2c+1] += splitmix64((ylo | i << 32) + K2 x), i = ordinal of the element in
+// contig c (splitmix64 = the usual 3-step finaliser, additive constant 0x9E3779B97F4A7C15; K1 = that constant,
+// K2 = 0xD1B54A32D192ED03; sums wrap mod 2^64).  blockIdx.x = contig, blockIdx.y = slice of 4096.
+__device__ __forceinline__ uint64_t splitmix64_dev(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ __launch_bounds__(256) void shmmr_checksum_kernel(const pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ off,
+                                                             unsigned long long *__restrict__ sums) {
+    __shared__ unsigned long long s_a[4], s_b[4];
+    const uint32_t c = blockIdx.x;
+    const uint64_t o = off[c], cnt = off[c + 1] - o;
+    const uint64_t i0 = (uint64_t)blockIdx.y * 4096;
+    if (i0 >= cnt) return;
+    uint64_t a = 0, b = 0;
+    for (uint64_t i = i0 + threadIdx.x; i < cnt && i < i0 + 4096; i += 256) {
+        const pgr_mm128 m = mm[o + i];
+        a += splitmix64_dev(m.x ^ (0x9E3779B97F4A7C15ull * (i + 1)));
+        b += splitmix64_dev(((m.y & 0xFFFFFFFFull) | (i << 32)) + 0xD1B54A32D192ED03ull * m.x);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += shfl_xor64(a, m);
+        b += shfl_xor64(b, m);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        s_a[threadIdx.x >> 6] = a;
+        s_b[threadIdx.x >> 6] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(sums + 2 * (size_t)c, s_a[0] + s_a[1] + s_a[2] + s_a[3]);
+        atomicAdd(sums + 2 * (size_t)c + 1, s_b[0] + s_b[1] + s_b[2] + s_b[3]);
+    }
+}
+void launch_shmmr_checksum(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t max_cnt,
+                           uint64_t *sums) {
+    if (n_contigs == 0 || max_cnt == 0) return;
+    hipLaunchKernelGGL(shmmr_checksum_kernel, dim3(n_contigs, (uint32_t)((max_cnt + 4095) / 4096)), dim3(256), 0, st, mm, off,
+                       (unsigned long long *)sums);
 }
 __global__ void copy_add_rid_kernel(const pgr_mm128 *__restrict__ in, uint64_t n, uint32_t rid_add,
                                     pgr_mm128 *__restrict__ out) {
@@ -447,13 +516,25 @@ __global__ void copy_add_rid_kernel(const pgr_mm128 *__restrict__ in, uint64_t n
     m.y += (uint64_t)rid_add << 32;
     out[i] = m;
 }
+__global__ void copy_map_rid_kernel(const pgr_mm128 *__restrict__ in, uint64_t n, const uint32_t *__restrict__ rids,
+                                    pgr_mm128 *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    pgr_mm128 m = in[i];
+    m.y = ((uint64_t)rids[(uint32_t)(m.y >> 32)] << 32) | (m.y & 0xFFFFFFFFull);
+    out[i] = m;
+}
+void launch_copy_map_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, const uint32_t *rids, pgr_mm128 *out) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(copy_map_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, n, rids, out);
+}
 void launch_copy_add_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, uint32_t rid_add, pgr_mm128 *out) {
     if (n == 0) return;
     hipLaunchKernelGGL(copy_add_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, n, rid_add, out);
 }
-void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, uint64_t n, const uint32_t *rids) {
-    if (n == 0) return;
-    hipLaunchKernelGGL(patch_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, mm, n, rids);
+void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, const uint32_t *rids) {
+    if (cap == 0) return;
+    hipLaunchKernelGGL(patch_rid_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, mm, n_ptr, cap, rids);
 }
 
 }  // namespace pgr

@@ -78,7 +78,7 @@ __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
 
 // base(c,i) = (splitmix64(seed ^ c*GOLD ^ (i>>5)) >> (2*(i&31))) & 3
 __global__ __launch_bounds__(256) void synth_kernel(BatchDev b, uint32_t n, uint64_t total_words, uint64_t seed,
-                                                    uint64_t contig0) {
+                                                    uint64_t contig0, const uint64_t *__restrict__ ids) {
     const uint64_t wi = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (wi >= total_words) return;
     const uint32_t c = find_by_word(b.word_off, n, wi);
@@ -87,7 +87,8 @@ __global__ __launch_bounds__(256) void synth_kernel(BatchDev b, uint32_t n, uint
     const uint64_t first = wl * 32;
     uint32_t p0 = 0, p1 = 0, v = 0;
     if (first < len) {
-        const uint64_t z = splitmix64(seed ^ ((contig0 + c) * 0x9E3779B97F4A7C15ull) ^ wl);
+        const uint64_t cid = ids ? ids[c] : contig0 + c;  // global contig id (a shard of a partitioned set passes its list)
+        const uint64_t z = splitmix64(seed ^ (cid * 0x9E3779B97F4A7C15ull) ^ wl);
         const uint32_t nb = (len - first) >= 32 ? 32u : (uint32_t)(len - first);
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
@@ -112,10 +113,10 @@ void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, cons
 }
 
 void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_words, uint64_t seed,
-                  uint64_t contig0) {
+                  uint64_t contig0, const uint64_t *d_ids) {
     if (total_words == 0) return;
     const uint32_t blocks = (uint32_t)((total_words + 255) / 256);
-    hipLaunchKernelGGL(synth_kernel, dim3(blocks), dim3(256), 0, st, b, n, total_words, seed, contig0);
+    hipLaunchKernelGGL(synth_kernel, dim3(blocks), dim3(256), 0, st, b, n, total_words, seed, contig0, d_ids);
 }
 
 }  // namespace pgr

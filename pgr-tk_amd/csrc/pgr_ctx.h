@@ -22,8 +22,10 @@ struct pgr_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_end = nullptr;
+    hipEvent_t ev_alloc = nullptr;  // after the H2D copies of the last batch_alloc (the staging stream waits for it)
     std::string err;
     pgr_prof prof = {};
+    pgr_query_prof qprof = {};
 
     // pinned staging for H2D (owned by whoever stages a batch: the calling thread, or the staging thread of the
     // pipelined pgr_shmmr_batch) and, separately, for result downloads (d2h, calling thread)
@@ -31,6 +33,12 @@ struct pgr_ctx {
     size_t pinned_cap = 0;
     void *pinned_out = nullptr;
     size_t pinned_out_cap = 0;
+    // pinned mailbox: the handful of device-side counts (+ result offsets) a call reads after its one synchronization
+    void *mailbox = nullptr;
+    size_t mailbox_cap = 0;
+    bool staged_unsynced = false;  // a batch was staged on `stream` and nobody has synchronized since
+    // result-size estimate: final shimmers per base of the last pgr_shmmrs_compute with the spec `est_spec_key`
+    double est_spec_key = -1.0, est_final_ratio = 0.0;
     // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`
     hipStream_t copy_stream = nullptr;
     hipEvent_t cev[2] = {nullptr, nullptr};
@@ -53,6 +61,7 @@ struct pgr_ctx {
     void dfree(void *p);
     int ensure_pinned(size_t bytes);
     int ensure_pinned_out(size_t bytes);
+    int ensure_mailbox(size_t bytes);
     // device -> pageable host memory through the pinned buffer (two windows, D2H of window i+1 overlaps the host
     // copy of window i, which is spread over a few threads); small transfers go straight through hipMemcpy
     int d2h(void *dst, const void *src_dev, size_t bytes);
@@ -60,6 +69,9 @@ struct pgr_ctx {
 };
 
 namespace pgr {
+// pair records of a resident result into d_out (capacity >= pgr_shmmrs_n_pairs), stream ordered: returns without waiting
+int shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
+                                pgr_frag_rec *d_out, uint64_t capacity);
 // host inputs of >= 512 Mbp: contigs [c0, c1) are staged on the copy stream while the previous range is consumed
 bool worth_pipelining(uint32_t n, const uint64_t *lens);
 int for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,

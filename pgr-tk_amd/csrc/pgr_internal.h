@@ -44,7 +44,6 @@ struct pgr_batch {
     pgr::BatchDev d;
     std::vector<uint64_t> h_word_off;  // [n+1]
     std::vector<uint32_t> h_len;       // [n]
-    std::vector<uint32_t> h_n_invalid; // [n]
 };
 
 struct pgr_shmmrs {
@@ -64,7 +63,7 @@ namespace pgr {
 void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, const BatchDev &b, uint32_t n,
                        uint64_t w1);
 void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_words, uint64_t seed,
-                  uint64_t contig0);
+                  uint64_t contig0, const uint64_t *d_ids /* NULL: contig0 + index */);
 
 // level1.hip
 struct TileDesc {  // one per tile, written by tile_desc_kernel (saves every workgroup a 10-step dependent search)
@@ -103,7 +102,8 @@ struct L1Args {
     uint32_t slot;               // elements per tile slot
     uint64_t ovf_base;           // first element of the overflow region (= n_tiles * slot)
     uint64_t cap;                // capacity of the overflow region (elements)
-    unsigned long long *cursor;  // [0] overflow elements allocated, [1] overflow-of-the-overflow flag
+    unsigned long long *cursor;  // [0] overflow elements allocated, [1] overflow-of-the-overflow flag, [2] bit0: a tile saw a
+                                 // palindromic k-mer, bit1: a tile holds a non-ACGT byte (islands of exact tiles needed)
     uint64_t *seg_off;           // [n_tiles + n_contigs]
     uint32_t *seg_cnt;           // [n_tiles + n_contigs]
     uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the exact kernel)
@@ -121,8 +121,9 @@ void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_r
 void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // needs a.desc (after launch_level1_tiles)
 
 // level2.hip
+// dst holds dst_cap elements: segments that would end beyond it are skipped (the host sees the true total and retries)
 void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t *seg_off, const uint32_t *seg_cnt,
-                            const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst);
+                            const uint64_t *seg_dst, uint32_t n_segs, pgr_mm128 *dst, uint64_t dst_cap);
 void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, const uint64_t *rec_off,
                       uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, int rid_is_index,
                       pgr_frag_rec *out);
@@ -141,7 +142,7 @@ struct FusedArgsPub {
     const uint32_t *seg_cnt;
     const uint64_t *seg_dst;
     uint32_t n_segs;
-    uint64_t total;
+    const uint64_t *total;     // device: number of level-1 elements (= seg_dst[n_segs]); workgroups beyond it exit
     uint32_t r, padding, min_span, do_reduce, halo;
     pgr_mm128 *out;            // [0, n_blocks*slot) fixed block slots, then the overflow region
     uint32_t slot;
@@ -153,9 +154,18 @@ struct FusedArgsPub {
     uint32_t *blk_first_seg;  // [n_blocks] scratch
 };
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);
-void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, uint64_t n, uint32_t n_contigs, uint64_t *off);
-void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, uint64_t n, const uint32_t *rids);
+// n_ptr: device, number of elements (clamped to cap)
+void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
+                           uint64_t *off);
+void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, const uint32_t *rids);
+// status[0..7] = cursor[0..7], status[8] = *total1, status[9] = *n_final: everything the host reads after the one sync
+void launch_collect_status(hipStream_t st, const unsigned long long *cursor, const uint64_t *total1, const uint64_t *n_final,
+                           uint64_t *status);
+// 128-bit content checksum per contig (formula at shmmr_checksum_kernel): sums[2c], sums[2c+1]
+void launch_shmmr_checksum(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t max_cnt,
+                           uint64_t *sums);
 void launch_copy_add_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, uint32_t rid_add, pgr_mm128 *out);
+void launch_copy_map_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, const uint32_t *rids, pgr_mm128 *out);
 
 // scan.hip (rocPRIM device scans / sorts: plain library primitives, not the hot path)
 // exclusive scan of n+1 u32 counts (in[n] must be 0) into n+1 u64 offsets: out[n] = total

@@ -7,7 +7,8 @@ calls raise.
 from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PackedSeqs, PgrError, Spec, default_context  # noqa: F401
 from .engine import (Batch, Index, Shmmrs, frag_recs_batch, make_spec, sequence_to_shmmrs,  # noqa: F401
                      sequence_to_shmmrs_batch)
-from .seqindexdb import SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, read_fastx, sparse_aln  # noqa: F401
+from .seqindexdb import (SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, read_fastx, sparse_aln,  # noqa: F401
+                         sparse_aln_groups)
 from . import cli, mapgraph  # noqa: F401
 from .helpers import (get_principle_bundle_bed_file_for_query, group_smps_by_principle_bundle_id, merge_regions, query_sdb, rc, rc_byte_seq, rc_u8_seq,  # noqa: F401
                       string_to_u8, u8_to_string)

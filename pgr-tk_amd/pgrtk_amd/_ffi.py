@@ -48,7 +48,14 @@ class HpsResult(C.Structure):
     _fields_ = [("n_queries", C.c_uint32), ("q_off", C.POINTER(C.c_uint64)), ("n_targets", C.c_uint64),
                 ("t_sid", C.POINTER(C.c_uint32)), ("t_off", C.POINTER(C.c_uint64)), ("n_chains", C.c_uint64),
                 ("c_score", C.POINTER(C.c_float)), ("c_off", C.POINTER(C.c_uint64)), ("n_hps", C.c_uint64),
-                ("hps", C.c_void_p)]
+                ("hps", C.c_void_p), ("n_nonterminating", C.c_uint64), ("_owner", C.c_void_p)]
+
+
+class QueryProf(C.Structure):
+    _fields_ = [("n_queries", C.c_uint64), ("query_bases", C.c_uint64), ("n_query_pairs", C.c_uint64),
+                ("n_signatures", C.c_uint64), ("n_hits", C.c_uint64), ("n_groups", C.c_uint64), ("n_chains", C.c_uint64),
+                ("n_hps", C.c_uint64), ("stage_ms", C.c_float), ("shmmr_ms", C.c_float), ("lookup_ms", C.c_float),
+                ("chain_ms", C.c_float), ("result_ms", C.c_float), ("total_ms", C.c_float)]
 
 
 class Bundles(C.Structure):
@@ -71,6 +78,7 @@ _SIGS = [
                                       C.POINTER(C.c_uint32), C.c_int, _PVP, _PVP]),
     ("pgr_batch_from_ascii", C.c_int, [_VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), _PVP]),
     ("pgr_batch_synthetic", C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, _PVP]),
+    ("pgr_batch_synthetic_ids", C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64), _PVP]),
     ("pgr_batch_destroy", None, [_VP]),
     ("pgr_batch_total_bases", C.c_uint64, [_VP]),
     ("pgr_shmmrs_compute", C.c_int, [_VP, _VP, C.POINTER(Spec), C.POINTER(C.c_uint32), C.c_int, _PVP]),
@@ -81,6 +89,16 @@ _SIGS = [
     ("pgr_shmmrs_destroy", None, [_VP]),
     ("pgr_shmmrs_n_pairs", C.c_uint64, [_VP]),
     ("pgr_shmmrs_copy_to_device", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_uint32]),
+    ("pgr_shmmrs_copy_to_device_rids", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.POINTER(C.c_uint32)]),
+    ("pgr_shmmrs_offsets", C.c_int, [_VP, _VP]),
+    ("pgr_exchange_unique_id", C.c_int, [_VP, _VP]),
+    ("pgr_exchange_create", C.c_int, [_VP, _VP, C.c_int, C.c_int, _PVP]),
+    ("pgr_exchange_destroy", None, [_VP]),
+    ("pgr_exchange_rank", C.c_int, [_VP]),
+    ("pgr_exchange_world", C.c_int, [_VP]),
+    ("pgr_exchange_allgather_shmmrs_start", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
+    ("pgr_exchange_wait", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
+    ("pgr_exchange_device_counts", _VP, [_VP]),
     ("pgr_index_add_shmmrs", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
     ("pgr_shmmrs_to_frag_recs_device", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.c_int, _VP, C.c_uint64,
                                                  C.POINTER(C.c_uint64)]),
@@ -101,7 +119,11 @@ _SIGS = [
     ("pgr_query_hps_batch", C.c_int, [_VP, _VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.c_float, C.c_uint32,
                                       C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_int,
                                       C.POINTER(HpsResult)]),
+    ("pgr_query_hps_resident", C.c_int, [_VP, _VP, _VP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                         C.c_uint32, C.c_int, C.POINTER(HpsResult)]),
     ("pgr_hps_result_free", None, [C.POINTER(HpsResult)]),
+    ("pgr_ctx_last_query_prof", C.c_int, [_VP, C.POINTER(QueryProf)]),
+    ("pgr_shmmrs_checksum", C.c_int, [_VP, _VP, _VP]),
     ("pgr_sparse_aln_batch", C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64), C.c_uint32, C.c_float, C.c_int,
                                        C.c_uint32, C.c_int, C.POINTER(HpsResult)]),
     ("pgr_index_adj_list", C.c_int, [_VP, _VP, C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, _PVP,
@@ -258,6 +280,15 @@ class Context:
         p = Prof()
         self.check(lib().pgr_ctx_last_prof(self._h, C.byref(p)))
         return p
+
+    def synchronize(self):
+        self.check(lib().pgr_ctx_synchronize(self._h))
+
+    def last_query_prof(self):
+        """counts and stage times of the last query batch on this context (pgr_query_prof) as a dict"""
+        p = QueryProf()
+        self.check(lib().pgr_ctx_last_query_prof(self._h, C.byref(p)))
+        return {k: getattr(p, k) for k, _ in QueryProf._fields_}
 
 
 _default_ctx = {}

@@ -41,12 +41,18 @@ class Batch:
         return cls(ctx, h, n)
 
     @classmethod
-    def synthetic(cls, lens, seed, contig0=0, ctx=None):
+    def synthetic(cls, lens, seed, contig0=0, ctx=None, contig_ids=None):
+        """counter-based synthetic contigs generated on the device; contig_ids: explicit global ids (a shard)"""
         ctx = ctx or default_context()
         n = len(lens)
         la = (C.c_uint64 * max(n, 1))(*[int(v) for v in lens])
         h = C.c_void_p()
-        ctx.check(lib().pgr_batch_synthetic(ctx.handle, n, la, int(seed), int(contig0), C.byref(h)))
+        if contig_ids is None:
+            ctx.check(lib().pgr_batch_synthetic(ctx.handle, n, la, int(seed), int(contig0), C.byref(h)))
+        else:
+            assert len(contig_ids) == n
+            ia = (C.c_uint64 * max(n, 1))(*[int(v) for v in contig_ids])
+            ctx.check(lib().pgr_batch_synthetic_ids(ctx.handle, n, la, int(seed), ia, C.byref(h)))
         return cls(ctx, h, n)
 
     @property
@@ -98,11 +104,27 @@ class Shmmrs:
         self.ctx.check(lib().pgr_shmmrs_download(self.ctx.handle, self._h, C.byref(pm), C.byref(po)))
         return _ffi.take(pm, cnt, MM128), _ffi.take(po, self.n + 1, np.dtype("<u8"))
 
-    def copy_into(self, device_ptr, capacity, rid_add=0):
+    def checksum(self):
+        """128-bit content checksum of every contig's list, computed on the GPU -> uint64 array [n, 2]"""
+        out = np.zeros((max(self.n, 1), 2), dtype=np.uint64)
+        self.ctx.check(lib().pgr_shmmrs_checksum(self.ctx.handle, self._h, out.ctypes.data))
+        return out[:self.n]
+
+    def offsets(self):
+        """host copy of the n + 1 list offsets"""
+        out = np.zeros(self.n + 1, dtype=np.uint64)
+        lib().pgr_shmmrs_offsets(self._h, out.ctypes.data)
+        return out
+
+    def copy_into(self, device_ptr, capacity, rid_add=0, rids=None):
         """copy the MM128 list into caller-owned DEVICE memory (e.g. a torch tensor for the RCCL all-gather);
-        rid_add turns rank-local contig indices into global sequence ids"""
-        self.ctx.check(lib().pgr_shmmrs_copy_to_device(self.ctx.handle, self._h, C.c_void_p(device_ptr), capacity,
-                                                       int(rid_add)))
+        rid_add / rids turn rank-local contig indices into global sequence ids"""
+        if rids is not None:
+            keep, rp = _u32_array(rids, self.n)
+            self.ctx.check(lib().pgr_shmmrs_copy_to_device_rids(self.ctx.handle, self._h, C.c_void_p(device_ptr), capacity, rp))
+        else:
+            self.ctx.check(lib().pgr_shmmrs_copy_to_device(self.ctx.handle, self._h, C.c_void_p(device_ptr), capacity,
+                                                           int(rid_add)))
         return self.count
 
     def frag_recs_into(self, device_ptr, capacity, sids=None, query_side=False):
@@ -216,6 +238,20 @@ class Index:
                                                  max_count_query, max_count_target, max_aln_span,
                                                  int(max_gap is not None), int(max_gap or 0), int(bool(oriented)),
                                                  C.byref(res)))
+        return self._unpack_raw(res, n)
+
+    def query_hps_resident_raw(self, batch, penalty, max_count=128, max_count_query=128, max_count_target=128,
+                               max_aln_span=8, max_gap=None, oriented=False):
+        """pgr_query_hps_resident: the queries are a Batch already on the GPU"""
+        res = _ffi.HpsResult()
+        self.ctx.check(lib().pgr_query_hps_resident(self.ctx.handle, self._h, batch._h, float(penalty), max_count,
+                                                    max_count_query, max_count_target, max_aln_span,
+                                                    int(max_gap is not None), int(max_gap or 0), int(bool(oriented)),
+                                                    C.byref(res)))
+        return self._unpack_raw(res, batch.n)
+
+    @staticmethod
+    def _unpack_raw(res, n):
         nt, nc, nh = int(res.n_targets), int(res.n_chains), int(res.n_hps)
         out = {
             "q_off": np.ctypeslib.as_array(res.q_off, shape=(n + 1,)).copy(),
@@ -227,6 +263,7 @@ class Index:
         }
         if nh:
             C.memmove(out["hps"].ctypes.data, res.hps, nh * _ffi.HITPAIR.itemsize)
+        out["n_nonterminating"] = int(res.n_nonterminating)
         lib().pgr_hps_result_free(C.byref(res))
         return out
 

@@ -7,8 +7,17 @@ global sequence id); the shimmer-pair records (40 B per pair) are adjacent shimm
 derived on the receiving GPU (pgr_index_add_shmmrs), 2.5x less traffic than shipping records.
 Rows are int64 tensors [n, words] (MM_WORDS or REC_WORDS).
 
-torch is plumbing here (device memory + the collective); no compute.
+Two transports:
+  * AbiExchange   -- libpgrhip's own pgr_exchange_* entry points (RCCL loaded and driven by the C library, collective
+                     on its own HIP stream): what a Rust / C++ host calls; Python only hands the 128-byte unique id from
+                     rank 0 to the other ranks (any host-side channel does: here the torch process group, in
+                     host/pgr_mdb.cpp a pipe);
+  * PendingAllgather / allgather_records -- torch.distributed (backend "nccl" = RCCL, "gloo" for the CPU tests).
+torch is plumbing here (device memory, process group); no compute.
 """
+import ctypes as C
+
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -29,6 +38,65 @@ def shard_contigs(lens, world_size):
     for s in shards:
         s.sort()
     return shards
+
+
+class _AbiPending:
+    def __init__(self, xch, out, cap):
+        self.xch, self.out, self.cap = xch, out, cap
+
+    def wait(self):
+        """-> (gathered [sum n, 2] in rank order, counts).  Equal counts == cap: a view; otherwise the per-rank slices"""
+        from ._ffi import lib
+        counts = np.zeros(self.xch.world, dtype=np.uint64)
+        self.xch.ctx.check(lib().pgr_exchange_wait(self.xch._h, counts.ctypes.data_as(C.POINTER(C.c_uint64))))
+        counts = [int(c) for c in counts]
+        parts = [self.out[r * self.cap: r * self.cap + c] for r, c in enumerate(counts)]
+        return (parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)), counts
+
+
+class AbiExchange:
+    """pgr_exchange_* through ctypes.  group: a torch.distributed module / process group used ONLY to broadcast the
+    ncclUniqueId bytes (host side); the collective itself never touches torch."""
+
+    def __init__(self, ctx, rank, world, dist_mod=None, unique_id=None):
+        from ._ffi import lib
+        self.ctx, self.rank, self.world = ctx, rank, world
+        if unique_id is None:
+            idb = np.zeros(128, dtype=np.uint8)
+            if rank == 0:
+                ctx.check(lib().pgr_exchange_unique_id(ctx.handle, idb.ctypes.data))
+            if world > 1:
+                d = dist_mod or dist
+                t = torch.from_numpy(idb)
+                if d.get_backend() == "nccl":
+                    t = t.cuda()
+                d.broadcast(t, src=0)
+                idb = t.cpu().numpy()
+            unique_id = idb.tobytes()
+        self.unique_id = unique_id
+        self._h = C.c_void_p()
+        idarr = np.frombuffer(unique_id, dtype=np.uint8).copy()
+        ctx.check(lib().pgr_exchange_create(ctx.handle, idarr.ctypes.data, rank, world, C.byref(self._h)))
+
+    def allgather_async(self, local, n_local, out, cap_per_rank):
+        """local: int64 tensor [>= cap_per_rank, 2] on the GPU holding n_local valid rows; out: [world * cap_per_rank, 2]"""
+        from ._ffi import lib
+        assert local.is_cuda and out.is_cuda and local.shape[0] >= cap_per_rank and out.shape[0] >= self.world * cap_per_rank
+        self.ctx.check(lib().pgr_exchange_allgather_shmmrs_start(self._h, C.c_void_p(local.data_ptr()), int(n_local),
+                                                                 C.c_void_p(out.data_ptr()), int(cap_per_rank)))
+        return _AbiPending(self, out, cap_per_rank)
+
+    def close(self):
+        from ._ffi import lib
+        if self._h:
+            lib().pgr_exchange_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class PendingAllgather:

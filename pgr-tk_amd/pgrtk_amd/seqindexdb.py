@@ -106,6 +106,25 @@ def sparse_aln(sp_hits, max_span, penalty, max_gap=None, orientated=False, ctx=N
     return out[0][0][1] if out[0] else []
 
 
+def sparse_aln_groups(groups, max_span, penalty, max_gap=None, orientated=False, ctx=None):
+    """aln::sparse_aln on many independent groups of hit pairs in ONE call (pgr_sparse_aln_batch).
+    -> {"chains": [[(score, [hit pairs])] per group], "n_nonterminating": groups the reference never finishes}"""
+    ctx = ctx or default_context()
+    flat = [h for g in groups for h in g]
+    a = np.array([(h[0][0], h[0][1], h[0][2], h[1][0], h[1][1], h[1][2]) for h in flat], dtype=HITPAIR)
+    off = np.zeros(len(groups) + 1, dtype=np.uint64)
+    off[1:] = np.cumsum([len(g) for g in groups])
+    res = HpsResult()
+    ctx.check(lib().pgr_sparse_aln_batch(ctx.handle, len(groups), a.ctypes.data, off.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                         max_span, penalty, int(max_gap is not None), int(max_gap or 0),
+                                         int(bool(orientated)), C.byref(res)))
+    n_bad = int(res.n_nonterminating)
+    out = _unpack_hps(res, 1)
+    lib().pgr_hps_result_free(C.byref(res))
+    by_group = {sid: chains for sid, chains in out[0]}
+    return {"chains": [by_group.get(g, []) for g in range(len(groups))], "n_nonterminating": n_bad}
+
+
 def get_shmmr_pairs_from_seq(seq, w=80, k=56, r=4, min_span=16, padding=False, ctx=None):
     """pgrtk.get_shmmr_pairs_from_seq (pgr-tk/src/lib.rs:1581-1613): [(h0, h1, p0, p1, orientation)]"""
     from .engine import sequence_to_shmmrs

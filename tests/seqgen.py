@@ -6,6 +6,13 @@ def rnd(rng, n, alpha=b"ACGT"):
     return bytes(rng.choice(np.frombuffer(alpha, dtype=np.uint8), int(n)))
 
 
+_COMP = bytes.maketrans(b"ACGTacgt", b"TGCAtgca")
+
+
+def rc(seq):
+    return bytes(seq).translate(_COMP)[::-1]
+
+
 def adversarial(rng, mode, L):
     """the edge cases the reference's semantics care about (SURVEY.md section 7 'hard parts')"""
     if mode == 0:

@@ -1,0 +1,262 @@
+"""GPU parity tests added in round 2: the single-synchronisation pipeline on flagged / overflowing inputs, the content
+checksum, the resident query entry point, the C-ABI exchange (1 rank and 2 processes on one device), the strong-scaling
+partitioner end to end, and BASELINE.json configs[4] as one GPU's slice."""
+import os
+import socket
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+import seqgen
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _same(ref, got):
+    return len(ref) == len(got) and np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"])
+
+
+def test_small_calls_take_the_optimistic_path_and_stay_exact(oracle, gpu_ctx):
+    """batches below 64 Mbp run the whole pipeline before the host looks at any count; the rare cases that need a
+    second pass (palindromic k-mers, non-ACGT bytes, denser lists than estimated) must come out exact all the same"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(5)
+    sp_t = (80, 56, 4, 64)
+    cases = {
+        "clean": [seqgen.rnd(rng, 30_000), seqgen.rnd(rng, 777)],
+        "palindrome": [seqgen.rnd(rng, 20_000) + b"AT" * 60 + seqgen.rnd(rng, 20_000)],
+        "n_runs": [seqgen.rnd(rng, 9_000) + b"N" * 300 + seqgen.rnd(rng, 12_000), seqgen.rnd(rng, 5_000)],
+        "low_complexity": [b"A" * 50_000, (b"ACGTTGCA" * 8000)],  # every position ties: far denser than the estimate
+        "mixed": [seqgen.rnd(rng, 40_000), b"", b"ACGT" * 30, seqgen.rnd(rng, 100) + b"n" + seqgen.rnd(rng, 3000)],
+    }
+    for spec_t in (sp_t, (48, 56, 4, 12), (24, 24, 12, 24)):
+        sp = oracle.spec(*spec_t)
+        for name, seqs in cases.items():
+            got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(*spec_t), ctx=gpu_ctx)
+            for i, s in enumerate(seqs):
+                assert _same(oracle.sequence_to_shmmrs(i, s, sp), got[i]), (spec_t, name, i)
+    # the result-size estimate adapts to the previous call: a dense call after sparse ones, and back
+    for seqs in ([seqgen.rnd(rng, 100_000)], [b"C" * 200_000], [seqgen.rnd(rng, 100_000)]):
+        got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(*sp_t), ctx=gpu_ctx)
+        assert _same(oracle.sequence_to_shmmrs(0, seqs[0], oracle.spec(*sp_t)), got[0])
+
+
+def test_shmmrs_checksum_matches_the_checker(oracle, gpu_ctx):
+    import pgrtk_amd as P
+    lens = [300_000, 0, 5_000, 1_000_000, 80]
+    b = P.Batch.synthetic(lens, seed=9, contig0=40, ctx=gpu_ctx)
+    sh = b.shmmrs(P.make_spec())
+    sums = sh.checksum()
+    off = sh.offsets()
+    sp = oracle.spec()
+    for i, L in enumerate(lens):
+        ref = oracle.sequence_to_shmmrs(i, oracle.synth_contig(9, 40 + i, L), sp)
+        assert int(off[i + 1] - off[i]) == len(ref)
+        assert np.array_equal(sums[i], oracle.shmmr_checksum(ref)), i
+    # the threaded checker (what bench.py runs over all 1000 contigs) agrees with the one-contig form
+    counts, csums, busy = oracle.synth_checksums_threads(sp, len(lens) - 1, 9, 40, 300_000, 3)
+    assert np.array_equal(csums[0], sums[0]) and int(counts[0]) == int(off[1] - off[0])
+    # explicit contig ids (a shard of a partitioned set) generate the same contigs
+    b2 = P.Batch.synthetic([1_000_000, 300_000], seed=9, ctx=gpu_ctx, contig_ids=[43, 40])
+    s2 = b2.shmmrs(P.make_spec()).checksum()
+    assert np.array_equal(s2[0], sums[3]) and np.array_equal(s2[1], sums[0])
+
+
+def test_query_resident_equals_host_entry_and_reports_counts(oracle, gpu_ctx):
+    import pgrtk_amd as P
+    rng = np.random.default_rng(12)
+    seqs = [seqgen.rnd(rng, 400_000) for _ in range(4)]
+    seqs.append(seqs[1][1000:90_000] + seqgen.rnd(rng, 50_000))  # shared segment: two targets per query
+    sp = P.make_spec()
+    ix = P.Index(sp, ctx=gpu_ctx)
+    ix.add_seqs(seqs)
+    ix.finalize()
+    qs = [seqs[1][5_000:25_000], seqs[3][100_000:101_000], seqgen.rc(seqs[0][200_000:260_000]), b"ACGT" * 10, b""]
+    r_host = ix.query_hps_raw(qs, 0.025)
+    qb = P.Batch.from_seqs(qs, ctx=gpu_ctx)
+    r_res = ix.query_hps_resident_raw(qb, 0.025)
+    for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps"):
+        assert np.array_equal(r_host[k], r_res[k]), k
+    prof = gpu_ctx.last_query_prof()
+    assert prof["n_queries"] == len(qs) and prof["query_bases"] == sum(len(q) for q in qs)
+    assert prof["n_hps"] == len(r_res["hps"]) and prof["n_chains"] == len(r_res["c_score"])
+    assert prof["n_signatures"] >= prof["n_hits"] >= prof["n_hps"] > 0
+    # content against the checker
+    oix = oracle.Index(oracle.spec())
+    for i, s in enumerate(seqs):
+        oix.add_seq(i, s)
+    for qi, q in enumerate(qs):
+        if len(q) == 0:
+            continue
+        ref = oix.query_fragment_to_hps(q, 0.025)
+        got = []
+        for t in range(int(r_res["q_off"][qi]), int(r_res["q_off"][qi + 1])):
+            ch = []
+            for c in range(int(r_res["t_off"][t]), int(r_res["t_off"][t + 1])):
+                hp = r_res["hps"][int(r_res["c_off"][c]):int(r_res["c_off"][c + 1])]
+                ch.append((float(r_res["c_score"][c]), [tuple(int(v) for v in h) for h in hp]))
+            got.append((int(r_res["t_sid"][t]), ch))
+        assert got == ref, qi
+
+
+def test_degenerate_group_does_not_fail_the_batch(gpu_ctx):
+    """a group whose hits all have end <= bgn never terminates in the reference (aln.rs:105-131); it is reported and
+    cut short, the other groups of the same call are chained normally"""
+    import pgrtk_amd as P
+    good = [((10, 200, 0), (1000, 1190, 0)), ((300, 500, 0), (1300, 1500, 0)), ((600, 900, 0), (1600, 1900, 0))]
+    bad = [((50, 50, 0), (7, 7, 0)), ((80, 80, 0), (9, 9, 0))]
+    res = P.sparse_aln_groups([good, bad, good], 8, 0.025, ctx=gpu_ctx)
+    assert res["n_nonterminating"] == 1
+    assert res["chains"][0] == res["chains"][2] and len(res["chains"][0]) == 1 and len(res["chains"][0][0][1]) == 3
+    assert res["chains"][1] == []
+
+
+def test_exchange_abi_one_rank(gpu_ctx):
+    """pgr_exchange_* with world = 1 on the real device: RCCL is loaded by the library, the collective runs on the
+    exchange's stream, the gathered list equals the local one"""
+    import torch
+    import pgrtk_amd as P
+    from pgrtk_amd import exchange
+    b = P.Batch.synthetic([500_000, 70_000], seed=3, ctx=gpu_ctx)
+    sh = b.shmmrs(P.make_spec())
+    cap = sh.count + 100
+    local = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
+    n = sh.copy_into(local.data_ptr(), cap, rids=[17, 5])
+    out = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
+    xch = exchange.AbiExchange(gpu_ctx, 0, 1)
+    for _ in range(2):  # the handle is reusable step after step
+        out.zero_()
+        g, counts = xch.allgather_async(local, n, out, cap).wait()
+        assert counts == [n] and bool((g == local[:n]).all())
+    xch.close()
+    mm, off = sh.download()
+    got = np.frombuffer(g.cpu().numpy().tobytes(), dtype=P.MM128)
+    assert np.array_equal(got["x"], mm["x"])
+    assert set(int(v) for v in got["y"] >> np.uint64(32)) == {17, 5}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
+    """SURVEY 8e end to end on one GPU box: 2 processes share cuda:0, each takes its shard of ONE ragged contig set from
+    shard_contigs, the lists are all-gathered (RCCL through the C ABI; gloo if RCCL refuses two ranks on one device) and
+    every rank's merged index equals the single-process index bit for bit"""
+    import pgrtk_amd as P
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import exchange_worker as W
+    ref_b = P.Batch.synthetic(W.LENS, seed=W.SEED, ctx=gpu_ctx)
+    ref = P.Index(P.make_spec(), ctx=gpu_ctx)
+    ref.add_resident(ref_b)
+    ref.finalize()
+    want = ref.download()
+    assert len(want) > 40_000
+    used = None
+    for transport in ("abi", "gloo"):
+        with tempfile.TemporaryDirectory() as d:
+            port = _free_port()
+            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+            procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), transport, str(r), "2",
+                                       str(port), d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
+            outs, ok = [], True
+            for p in procs:
+                try:
+                    o, _ = p.communicate(timeout=240)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    o, _ = p.communicate()
+                    ok = False
+                outs.append(o.decode(errors="replace"))
+                ok = ok and p.returncode == 0
+            if not ok:
+                if transport == "abi":
+                    print("RCCL path with two ranks on one device failed, falling back to gloo:\n" + "\n".join(outs)[-1500:])
+                    continue
+                raise AssertionError("\n".join(outs)[-3000:])
+            for r in range(2):
+                got = np.load(os.path.join(d, "records_%d.npy" % r))
+                assert len(got) == len(want)
+                for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+                    assert np.array_equal(got[f], want[f]), (transport, r, f)
+            used = transport
+            break
+    assert used is not None
+    print("two-rank sharded build verified over:", used)
+
+
+def test_bench_strong_mode_plumbing():
+    """bench.py --strong on one rank through the process-group code path (RCCL world 1, pgr_exchange_*)"""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                        "--contigs", "24", "--contig-len", "1000000", "--strong", "--force-dist", "--queries", "0",
+                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, MASTER_PORT=str(_free_port())))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().split("\n")[-1])
+    assert line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 24_000_000 and line["value"] > 0
+
+
+def test_config5_slice_one_gpus_share(oracle, gpu_ctx):
+    """BASELINE.json configs[4] (94 x 3 Gbp over 8 GPUs) as ONE GPU's share: 3525 x 10 Mbp (seed 5) streamed in 4 resident
+    batches into one index.  Density, sortedness, record count == sum(shimmers - 1), and content == the CPU checker on
+    48 sampled contigs (128-bit checksums of their shimmer lists)."""
+    import json
+    import time
+    import pgrtk_amd as P
+    n_total, L, seed = 3525, 10_000_000, 5
+    sp = P.make_spec()
+    ix = P.Index(sp, ctx=gpu_ctx)
+    rng = np.random.default_rng(55)
+    sample = sorted(int(v) for v in rng.choice(n_total, 48, replace=False))
+    sums, counts, n_shmmr, n_pairs = {}, {}, 0, 0
+    t_shmmr = 0.0
+    t0 = time.perf_counter()
+    for b0 in range(0, n_total, 900):
+        ids = list(range(b0, min(n_total, b0 + 900)))
+        batch = P.Batch.synthetic([L] * len(ids), seed=seed, contig0=b0, ctx=gpu_ctx)
+        t1 = time.perf_counter()
+        sh = batch.shmmrs(sp)
+        t_shmmr += time.perf_counter() - t1
+        cs, off = sh.checksum(), sh.offsets()
+        for c in sample:
+            if b0 <= c < b0 + len(ids):
+                sums[c] = cs[c - b0].copy()
+                counts[c] = int(off[c - b0 + 1] - off[c - b0])
+        n_shmmr += sh.count
+        n_pairs += sh.n_pairs
+        del sh
+        ix.add_resident(batch, sids=ids)
+        batch.close()
+    ix.finalize()
+    t_all = time.perf_counter() - t0
+    bp = n_total * L
+    assert ix.n_records == n_pairs == n_shmmr - n_total
+    assert 0.0029 < n_shmmr / bp < 0.0032  # 0.003035 final shimmers per base
+    recs = ix.download()
+    key = recs["h0"].astype(np.uint64)
+    assert bool(np.all(key[1:] >= key[:-1]))
+    same = (recs["h0"][1:] == recs["h0"][:-1]) & (recs["h1"][1:] == recs["h1"][:-1])
+    assert bool(np.all(recs["h1"][1:][recs["h0"][1:] == recs["h0"][:-1]] >= recs["h1"][:-1][recs["h0"][1:] == recs["h0"][:-1]]))
+    assert bool(np.all(recs["sid"][1:][same] >= recs["sid"][:-1][same]))
+    # content: the checker generates the sampled contigs itself
+    osp = oracle.spec()
+    for c in sample:
+        ref = oracle.sequence_to_shmmrs(0, oracle.synth_contig(seed, c, L), osp)
+        assert len(ref) == counts[c] and np.array_equal(oracle.shmmr_checksum(ref), sums[c]), c
+    line = {"workload": "configs[4] slice of one GPU: %d x %d bp, seed %d, 4 resident batches into one index" % (n_total, L, seed),
+            "bp": bp, "shimmers": n_shmmr, "records": int(ix.n_records), "keys": int(ix.n_keys),
+            "shmmr_s": t_shmmr, "total_s_incl_generation_and_sort": t_all, "Gbp_per_s_shimmers": bp / t_shmmr / 1e9,
+            "contigs_content_checked": len(sample)}
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config5_slice.json"), "w") as f:
+        json.dump(line, f)
+    print(json.dumps(line))

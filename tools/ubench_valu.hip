@@ -11,7 +11,7 @@ __device__ unsigned long long g_cyc[256 * 8 * 4];
 __device__ unsigned long long g_wall[256 * 8 * 4];  // the same interval in ticks of the constant 100 MHz clock  // shader cycles (s_memtime) every wave spent in its loop
 
 #ifndef ITERS
-#define ITERS 32768  // ~2-4 ms per launch: launch overhead and the clock ramp are negligible
+#define ITERS 8192   // x 4 copies of the body per iteration: ~2-4 ms per launch (launch overhead, clock ramp and the loop's scalar instructions are negligible)
 #endif
 #define UNROLL 8
 
@@ -21,7 +21,7 @@ __device__ unsigned long long g_wall[256 * 8 * 4];  // the same interval in tick
         const unsigned long long c0 = __builtin_readcyclecounter();         \
         const unsigned long long w0 = wall_clock64();                       \
         for (int it = 0; it < ITERS; ++it) {                                \
-            body                                                            \
+            body body body body                                             \
         }                                                                   \
         const unsigned long long c1 = __builtin_readcyclecounter();         \
         out[blockIdx.x * 256 + threadIdx.x] = (uint32_t)(acc);              \
@@ -68,6 +68,13 @@ KERNEL(k_cmp_cnd4, DECL32, REP8_32("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0,
 KERNEL(k_cmp_sgpr_cnd2, DECL32, REP8_32("v_cmp_lt_u32 s[20:21], %0, %1\n v_cndmask_b32 %0, %0, %1, s[20:21]\n v_cndmask_b32 %0, %1, %0, s[20:21]") FIN32)
 KERNEL(k_cmp_addc, DECL32, REP8_32("v_cmp_lt_u32 vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %0, vcc") FIN32)
 KERNEL(k_cmpf64_addc, DECL64; uint32_t acc2 = 0, REP8_64("v_cmp_lt_f64 vcc, %0, %1\n v_lshl_add_u64 %0, %0, 1, %1") asm volatile("v_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(acc2) :: "vcc"); FIN64 acc ^= acc2;)
+KERNEL(k_mov_b32, DECL32, REP8_32("v_mov_b32 %0, %1") FIN32)
+KERNEL(k_ashrrev_i32, DECL32, REP8_32("v_ashrrev_i32 %0, 3, %0") FIN32)
+KERNEL(k_or3_b32, DECL32, REP8_32("v_or3_b32 %0, %0, %1, %1") FIN32)
+KERNEL(k_bcnt, DECL32, REP8_32("v_bcnt_u32_b32 %0, %0, %1") FIN32)
+KERNEL(k_sub_co_subb, DECL32, REP8_32("v_sub_co_u32 %0, vcc, %0, %1\n v_subb_co_u32 %0, vcc, %0, %1, vcc") FIN32)
+KERNEL(k_add_co_addc, DECL32, REP8_32("v_add_co_u32 %0, vcc, %0, %1\n v_addc_co_u32 %0, vcc, %0, %1, vcc") FIN32)
+KERNEL(k_mov_b64, DECL64, REP8_64("v_mov_b64 %0, %1") FIN64)
 KERNEL(k_min_u32, DECL32, REP8_32("v_min_u32 %0, %0, %1") FIN32)
 KERNEL(k_min3_u32, DECL32, REP8_32("v_min3_u32 %0, %0, %1, %1") FIN32)
 KERNEL(k_alignbit, DECL32, REP8_32("v_alignbit_b32 %0, %0, %1, 7") FIN32)
@@ -155,6 +162,8 @@ int main() {
         {"v_cmp_lt_f64 + lshl_add_u64 (pair)", k_cmp_lt_f64_only, 8}, {"v_cmp_eq_f64 + lshl_add_u64 (pair)", k_cmp_eq_f64_only, 8},
         {"cmp_u32 + 2 cndmask (vcc)", k_cmp_cnd2, 8}, {"cmp_u32 + 4 cndmask (vcc)", k_cmp_cnd4, 8},
         {"cmp_u32->sgpr + 2 cndmask_e64", k_cmp_sgpr_cnd2, 8}, {"cmp_u32 + v_addc (bit accumulate)", k_cmp_addc, 8},
+        {"v_mov_b32", k_mov_b32, 8}, {"v_ashrrev_i32", k_ashrrev_i32, 8}, {"v_or3_b32", k_or3_b32, 8}, {"v_bcnt_u32_b32", k_bcnt, 8},
+        {"v_sub_co_u32 + v_subb_co_u32 (pair)", k_sub_co_subb, 8}, {"v_add_co_u32 + v_addc_co_u32 (pair)", k_add_co_addc, 8}, {"v_mov_b64", k_mov_b64, 8},
         {"v_min_u32", k_min_u32, 8}, {"v_min3_u32", k_min3_u32, 8},
         {"v_alignbit_b32", k_alignbit, 8}, {"v_bfrev_b32", k_bfrev, 8}, {"v_mul_lo_u32", k_mul_lo_u32, 8},
         {"v_mul_u32_u24", k_mul_u32_u24, 8}, {"v_mad_u32_u24", k_mad_u32_u24, 8}, {"v_add3_u32", k_add3_u32, 8},
@@ -180,7 +189,7 @@ int main() {
         hipMemcpy(hc, dc, 24, hipMemcpyDeviceToHost);
         printf("clock calibration: %llu shader cycles, %llu wall ticks in %.3f ms -> shader %.0f MHz, wall %.0f MHz\n", hc[0], hc[1], ms, hc[0] / ms / 1e3, hc[1] / ms / 1e3);
     }
-    printf("8 waves per SIMD, 8 independent chains per wave, %d iterations.  cyc(nominal) = HIP-event time x nominal clock /\n"
+    printf("8 waves per SIMD, 8 independent chains per wave, %d iterations of 4 x 8 sequences.  cyc(nominal) = HIP-event time x nominal clock /\n"
            "sequences per SIMD.  cyc(memtime) = mean s_memtime ticks a wave spent in its loop / (sequences per wave x 8 waves).\n"
            "memtime MHz = s_memtime ticks per second of the constant 100 MHz wall clock, read by the same waves around the\n"
            "same loop: the rate s_memtime really ran at.  The authoritative cycle count is the PMC one: run this binary under\n"
@@ -197,7 +206,7 @@ int main() {
         float ms; hipEventElapsedTime(&ms, e0, e1);
         // sequences issued per SIMD: waves per SIMD * ITERS * per_iter
         const double waves_per_simd = (double)blocks * 4 / (prop.multiProcessorCount * 4);
-        const double seqs = waves_per_simd * ITERS * c.per_iter;
+        const double seqs = waves_per_simd * ITERS * c.per_iter * 4;
         static unsigned long long hc[256 * 8 * 4];
         hipMemcpyFromSymbol(hc, HIP_SYMBOL(g_cyc), sizeof(hc));
         double cs = 0;
@@ -207,7 +216,7 @@ int main() {
         double ws = 0;
         for (int i = 0; i < blocks * 4; ++i) ws += (double)hw[i];
         const double cyc_wave = cs / (blocks * 4);
-        const double cyc_mem = cyc_wave / ((double)ITERS * c.per_iter * waves_per_simd);
+        const double cyc_mem = cyc_wave / ((double)ITERS * c.per_iter * 4 * waves_per_simd);
         printf("%-36s %9.3f %12.2f %12.2f %12.0f\n", c.name, ms, ms * 1e-3 * clk / seqs, cyc_mem, cs / ws * 100.0);
     }
     return 0;
