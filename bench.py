@@ -546,6 +546,11 @@ def main():
                 out["pcie_inclusive"] = pcie_bench(P, ctx, spec, args)
             except Exception as e:  # noqa: BLE001
                 out["pcie_inclusive"] = {"error": repr(e)[:300]}
+        try:  # RCCL prints a version banner through C stdio (block buffered on a pipe): push it out BEFORE the JSON line
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -21,6 +21,10 @@
 #ifndef PGR_FORCE_SHR64
 #define PGR_FORCE_SHR64 1
 #endif
+#ifndef PGR_TILE_V2
+#define PGR_TILE_V2 1  // 1: round-2 instruction selection (strand select from SGPR lane masks, multiplications in the hash,
+                       //    window-row minima folded into the prefix chains); 0: the round-1 code, kept for A/B timing
+#endif
 #ifndef PGR_ABLATE
 #define PGR_ABLATE 0  // timing experiments only (1: no window passes, 2: no u64hash); results are wrong when set
 #endif
@@ -142,6 +146,36 @@ __device__ __forceinline__ uint64_t shr_mask(uint64_t v, uint32_t sh, uint64_t m
     return (v >> sh) & mask;
 }
 
+// --- comparisons into SGPR pairs (wave64 lane masks) and selects from them.  Measured (profiles/r02_ubench): a
+// v_cmp that writes an SGPR pair + v_cndmask_b32 reading it cost 4.1 + 3.5 cycles per wave64 instruction; the same
+// through vcc stalls (5.7 per v_cndmask), and the sign-mask + v_bfi_b32 form costs 4.2 per select plus 3 instructions
+// for the mask.
+__device__ __forceinline__ uint64_t cmp_lt_u64(uint64_t a, uint64_t b) {  // lane mask of a < b
+    uint64_t m;
+    asm("v_cmp_lt_u64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint64_t cmp_eq_u64(uint64_t a, uint64_t b) {
+    uint64_t m;
+    asm("v_cmp_eq_u64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint64_t cmp_eq_u32(uint32_t a, uint32_t b) {
+    uint64_t m;
+    asm("v_cmp_eq_u32 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+}
+__device__ __forceinline__ uint32_t sel(uint64_t mask, uint32_t if_set, uint32_t if_clear) {
+    uint32_t r;
+    asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(mask));
+    return r;
+}
+// acc = 2 * acc + (lane's bit of mask)
+__device__ __forceinline__ void shift_in_mask(uint32_t &acc, uint64_t mask) {
+    uint64_t cy;
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(cy) : "s"(mask));
+}
+
 constexpr uint32_t KEY_EXP = 0x40000000u;   // bit 62: keys are positive normal doubles
 constexpr uint32_t KEY_INF = 0x7FE00000u;   // hi word of the "not a k-mer" sentinel (finite, above every key)
 
@@ -178,7 +212,12 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
     const uint64_t rA1 = shr96_lo64<RS1>(rb2, rb1, rb0), rB1 = shr96_lo64<RS0>(rb2, rb1, rb0);
 
     // x[]: ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
+#if PGR_TILE_V2
+    uint32_t strand_rev = 0;  // strand bits in reversed order (bit 15 - u)
+    uint64_t pal_any = 0;     // lanes (any position) that may hold a palindromic k-mer: SGPR pair
+#else
     uint32_t pal_min = 0xFFFFFFFFu;  // 0 iff some position may hold a palindromic k-mer
+#endif
 #pragma unroll
     for (int u = 0; u < L1_G; ++u) {
         const uint64_t f0 = shr_mask(u >= 8 ? fa0 : fb0, (uint32_t)((L1_G - 1 - u) & 7), kmask);
@@ -191,6 +230,41 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             r0 = rc_plane(f0, k);
             r1 = rc_plane(f1, k);
         }
+#if PGR_TILE_V2
+        // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488): one compare into an SGPR lane
+        // mask, four selects from it, and the strand bit shifted into the per-lane word by an add-with-carry
+        const uint64_t rev = cmp_lt_u64(r0, f0);
+        const uint32_t m0l = sel(rev, (uint32_t)r0, (uint32_t)f0), m0h = sel(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
+        const uint32_t m1l = sel(rev, (uint32_t)r1, (uint32_t)f1), m1h = sel(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
+        uint32_t m1x = m1l ^ 0xAD12CF59u;
+        asm("" : "+v"(m1x));  // keep the constant out of the hash's first step (the optimiser would distribute it)
+        const uint64_t h = u64hash_mad(((uint64_t)m0h << 32) | m0l) ^ u64hash_mad(((uint64_t)m1h << 32) | m1x);
+        shift_in_mask(strand_rev, rev);  // position u ends up at bit 15 - u
+        const uint64_t key = ((uint64_t)and_or((uint32_t)(h >> 32), 0x00FFFFFFu, KEY_EXP) << 32) | (uint32_t)h;
+        uint64_t ok_mask = ~0ull;  // lanes whose position u holds a k-mer
+        if (MASKED) {
+            const uint32_t inval = bit_to_mask(~valid_mask, u);
+            const uint64_t iv = (uint64_t)inval << 32;  // sentinel: only the high word decides
+            x[u] = __longlong_as_double((long long)((key & ~iv) | (((uint64_t)KEY_INF << 32) & iv)));
+            ok_mask = cmp_eq_u32(inval, 0u);
+        } else {
+            x[u] = __longlong_as_double((long long)key);
+        }
+        if (SKETCH) {
+            // exact skip test (shmmrutils.rs:603-606) and the sketch threshold on the full 64-bit hash (:621)
+            const bool skip = (f0 == r0) && (f1 == r1);
+            if (!skip && h < sketch_thr) emit |= 1u << u;
+        } else {
+            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480): low planes equal (probability 2^-(k/2) per
+            // position on random sequence) and the low words of the high planes agree -- a cheap necessary test, a hit
+            // only routes the tile to the exact island path.  Two compares into SGPR masks; the rest is scalar.
+            pal_any |= cmp_eq_u64(f0, r0) & cmp_eq_u32((uint32_t)f1, (uint32_t)r1) & ok_mask;
+        }
+    }
+    strand_bits = __brev(strand_rev) >> 16;
+    const uint32_t pal_min = pal_any ? 0u : 1u;
+
+#else
         // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488); both < 2^56
         const uint64_t dfr = r0 - f0;
         const uint32_t rev = (uint32_t)((int32_t)((uint32_t)(dfr >> 32)) >> 31);  // 0 / ~0
@@ -226,6 +300,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         }
     }
 
+#endif
 #if PGR_ABLATE == 1
     if (true) {
 #pragma unroll
@@ -253,6 +328,33 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         const int wm1 = (int)w - 1;
         const double big = mk_double(0u, KEY_INF);
         double M[L1_G];
+        // w a multiple of 16 (the instantiated specs: 80, 48): the window of position u is the suffix of row t - w/16
+        // from offset u + 1, then w/16 - 1 WHOLE rows, then this lane's prefix 0..u -- the same whole rows for every u,
+        // so their minimum seeds the prefix chain and a window minimum is ONE v_min_f64 on top of the chain
+        constexpr bool FOLD = PGR_TILE_V2 && TW != 0 && (TW % 16) == 0;
+        if (FOLD) {
+            constexpr int NB = (TW ? TW : 16) / 16 - 1;  // whole rows inside every window of the lane
+            double pre = big;
+#pragma unroll
+            for (int i = 1; i <= NB; ++i) {
+                const int ti = (int)t - i;
+                pre = dmin(pre, s_row[ti < 0 ? 0 : ti]);
+            }
+            int ts = (int)t - NB - 1;
+            ts = ts < 0 ? 0 : ts;
+#pragma unroll
+            for (int u = 0; u < L1_G; ++u) {
+                pre = dmin(pre, x[u]);
+                const double m = (u < L1_G - 1) ? dmin(pre, s_suf[u + 1][ts]) : pre;
+                if (MASKED) {  // window ends outside [jstart, jend] do not select anything: M = +0 (below every key)
+                    const uint64_t mb = (uint64_t)__double_as_longlong(m);
+                    const uint64_t keep = (uint64_t)(int64_t)(int32_t)bit_to_mask(mwin_mask, u);
+                    M[u] = __longlong_as_double((long long)(mb & keep));
+                } else {
+                    M[u] = m;
+                }
+            }
+        } else
         {
             const int rs_lo = (-wm1) >> 4;  // floor(-(w-1)/16)
             const int nb = -rs_lo - 1;      // whole rows between the window start row and this row (u small)
@@ -296,7 +398,28 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             s_row[t] = pm;
         }
         __syncthreads();
-        {
+        constexpr bool FOLD2 = PGR_TILE_V2 && TW != 0 && (TW % 16) == 0;
+        if (FOLD2) {
+            // E[u] = max(M[u .. u + w - 1]): this lane's suffix from u, w/16 - 1 whole rows (they seed the suffix chain),
+            // and the prefix of row t + w/16 through offset u - 1
+            constexpr int NB = (TW ? TW : 16) / 16 - 1;
+            double sm = 0.0;
+#pragma unroll
+            for (int i = 1; i <= NB; ++i) {
+                const int ti = (int)t + i;
+                sm = dmax(sm, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
+            }
+            int te = (int)t + NB + 1;
+            te = te > L1_BLOCK - 1 ? L1_BLOCK - 1 : te;
+            uint32_t neq = 0;  // bit u set iff E[u] < x[u]  (E <= x always: every window minimum is <= x)
+#pragma unroll
+            for (int u = L1_G - 1; u >= 0; --u) {
+                sm = dmax(sm, M[u]);
+                const double ev = (u > 0) ? dmax(sm, s_suf[u - 1][te]) : sm;
+                shift_in_lt(neq, ev, x[u]);  // u runs 15..0, so bit u ends up at position u
+            }
+            emit = ~neq & valid_mask & core_mask;
+        } else {
             const int re_lo = wm1 >> 4;
             double acc = 0.0, qlo = 0.0;
             for (int i = 1; i <= re_lo; ++i) {

@@ -61,6 +61,38 @@ __device__ __forceinline__ uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t s)
 __device__ __forceinline__ uint64_t umin64(uint64_t a, uint64_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint64_t umax64(uint64_t a, uint64_t b) { return a > b ? a : b; }
 
+// The same hash with the two steps that are multiplications by a 32-bit constant issued as multiplications: measured on
+// gfx950 (profiles/r02_ubench/valu_cycles.txt) v_mad_u64_u32 and v_mul_lo_u32 cost what one 64-bit shift or add costs
+// (4.2 cycles per wave64 instruction), so
+//   ~key + (key << 21) = key * (2^21 - 1) - 1 : high word (v_not_b32 + v_lshl_add_u32) + ONE v_mad_u64_u32 whose addend
+//                                               carries that high word and the -1            (3 instead of 4 instructions)
+//   key * 265                                 : v_mul_lo_u32 (high word) + ONE v_mad_u64_u32 (2 instead of 3)
+// 17 VALU instructions per hash instead of 20.  The asm keeps hipcc from re-associating them into a full 64 x 64 multiply.
+__device__ __forceinline__ uint64_t u64hash_mad(uint64_t key) {
+    {
+        const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        uint32_t h;  // high word of ~key + (key << 21) without the carry from the low word: ~hi + (hi << 21)
+        asm("v_not_b32 %0, %1\n\tv_lshl_add_u32 %0, %1, 21, %0" : "=&v"(h) : "v"(hi));
+        const uint64_t add = ((uint64_t)h << 32) | 0xFFFFFFFFull;  // + (h << 32) - 1
+        uint64_t cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(key), "=s"(cy) : "v"(lo), "s"(0x1FFFFFu), "v"(add));
+    }
+    key = key ^ (key >> 24);
+    {
+        const uint32_t lo = (uint32_t)key, hi = (uint32_t)(key >> 32);
+        uint32_t h;
+        asm("v_mul_lo_u32 %0, %1, %2" : "=v"(h) : "v"(hi), "s"(265u));
+        const uint64_t add = (uint64_t)h << 32;
+        uint64_t cy;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(key), "=s"(cy) : "v"(lo), "s"(265u), "v"(add));
+    }
+    key = key ^ (key >> 14);
+    key = lshl4_add(key, lshl2_add(key, key));  // key * 21
+    key = key ^ (key >> 28);
+    key = key + shl31(key);
+    return key;
+}
+
 // canonical k-mer -> (x, strand).  f/r: forward / reverse-complement bit planes
 // (shmmrutils.rs:485-500): strand decided on the LOW plane only; x = hash << 8 | k.
 __device__ __forceinline__ uint64_t kmer_x(uint64_t f0, uint64_t f1, uint64_t r0, uint64_t r1, uint32_t k,

@@ -159,7 +159,7 @@ def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
     ref.add_resident(ref_b)
     ref.finalize()
     want = ref.download()
-    assert len(want) > 40_000
+    assert len(want) > 30_000
     used = None
     for transport in ("abi", "gloo"):
         with tempfile.TemporaryDirectory() as d:
@@ -201,7 +201,7 @@ def test_bench_strong_mode_plumbing():
                         "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
                        env=dict(os.environ, MASTER_PORT=str(_free_port())))
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads(r.stdout.strip().split("\n")[-1])
+    line = json.loads([l for l in r.stdout.split("\n") if l.startswith('{"metric"')][-1])
     assert line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 24_000_000 and line["value"] > 0
 
 

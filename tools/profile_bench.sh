@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
-#   tools/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write,pmc_sq,pmc_lds}
+#   tools/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write,pmc_sq,pmc_misc,q_trace}
 # Kernel trace/stats and every PMC group are SEPARATE runs (never --pmc together with tracing domains).
 set -u
 TAG=${1:-run}
@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --queries 0"   # only full-size launches of every kernel
+B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --queries 0 --no-extras"   # only full-size launches of every kernel
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o p -- $B > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $B > $O/pmc_write.log 2>&1
@@ -16,5 +16,6 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_C
           --output-format csv -d $O/pmc_sq -o p -- $B > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
           --output-format csv -d $O/pmc_misc -o p -- $B > $O/pmc_misc.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $O/q_trace -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_trace.log 2>&1
 python $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 ls -R $O | head -40

@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""rocprofv3 kernel trace of tools/query_leg.py -> profiles/<name>/{kernel_stats.csv, summary.json}
+
+    tools/summarize_query_profile.py gpurun_out/<dir>/q_trace profiles/r02_query [reps]
+
+Only the kernels after the 0.5 s gap (the timed query batches) are counted; numbers are per query batch."""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+os.makedirs(dst, exist_ok=True)
+rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "*kernel_trace.csv"))[0])))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+gap_i, gap = 0, 0
+for i in range(1, len(rows)):
+    g = int(rows[i]["Start_Timestamp"]) - int(rows[i - 1]["End_Timestamp"])
+    if g > gap:
+        gap, gap_i = g, i
+q = rows[gap_i:]
+agg = collections.OrderedDict()
+for r in q:
+    n = r["Kernel_Name"]
+    n = n.split("(")[0] if not n.startswith("void rocprim") else "rocprim::" + n.split("detail::")[-1].split("<")[0] + "<" + n.split("<", 2)[-1][:60]
+    d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+    a = agg.setdefault(n, [0, 0.0])
+    a[0] += 1
+    a[1] += d
+span = (int(q[-1]["End_Timestamp"]) - int(q[0]["Start_Timestamp"])) / 1e6
+tot = sum(v[1] for v in agg.values()) / 1e3
+with open(os.path.join(dst, "kernel_stats.csv"), "w") as f:
+    f.write("kernel,launches_per_batch,us_per_batch,percent_of_kernel_time\n")
+    for n, (c, us) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        f.write('"%s",%.1f,%.2f,%.1f\n' % (n, c / reps, us / reps, 100.0 * us / 1e3 / tot))
+dom = max(agg.items(), key=lambda kv: kv[1][1])
+out = {"source": "rocprofv3 --kernel-trace of tools/query_leg.py (%d resident query batches of BASELINE.json configs[2])" % reps,
+       "launches": round(len(q) / reps, 1), "kernel_ms_total": tot / reps, "wall_ms_per_batch_under_the_profiler": span / reps,
+       "dominant_kernel": dom[0], "dominant_kernel_ms": dom[1][1] / 1e3 / reps, "gap_before_timed_batches_ms": gap / 1e6}
+json.dump(out, open(os.path.join(dst, "summary.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
+print(open(os.path.join(dst, "kernel_stats.csv")).read()[:3000])
