@@ -289,6 +289,12 @@ int pgr_exchange_allgather_shmmrs_start(pgr_exchange *x, const pgr_mm128 *d_loca
 int pgr_exchange_wait(pgr_exchange *x, uint64_t *counts /* world entries, may be NULL */);
 /* device pointer to the `world` element counts of the last all-gather */
 const uint64_t *pgr_exchange_device_counts(const pgr_exchange *x);
+/* Blocking convenience for host programs: all-gather the lists of `s` (rids[i] = global sequence id of its contig i;
+ * s == NULL: nothing from this rank in this round) and add EVERY rank's lists to `ix` in rank order (ix == NULL: take
+ * part in the collective only -- ranks that do not own the frag_map).  The counts travel first, their maximum pads the
+ * payload, so no capacity has to be agreed.  All ranks must call it the same number of times. */
+int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs *s, const uint32_t *rids, pgr_index *ix,
+                                   uint64_t *n_gathered /* may be NULL */);
 
 /* ------------------------------------------------------------------ next: MAP-graph + principal bundles
  * Consumers of the frag_map (BASELINE.json configs[3], pgr-pbundle-decomp).  The data-parallel parts run on

@@ -17,11 +17,14 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "pgr_ctx.h"
+#include "pgr_index.h"
 
 namespace {
 
@@ -184,4 +187,47 @@ extern "C" int pgr_exchange_wait(pgr_exchange *x, uint64_t *counts) {
 // device pointer to the world counts of the last all-gather (for consumers that stay on the device)
 extern "C" const uint64_t *pgr_exchange_device_counts(const pgr_exchange *x) {
     return x ? (const uint64_t *)(x->d_cnt + 1) : nullptr;
+}
+
+// Blocking convenience for host programs (host/pgr_mdb.cpp --ranks N): all-gather this rank's lists and add every
+// rank's lists to `ix` in rank order.  Two phases, because a host program has no capacity agreed in advance: the counts
+// first (their maximum becomes the padded size), then the payload.  s == NULL: this rank contributes nothing this round.
+extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs *s, const uint32_t *rids, pgr_index *ix,
+                                              uint64_t *n_gathered) {
+    if (!x) return PGR_ERR_INVALID_ARG;
+    pgr_ctx *ctx = x->ctx;
+    if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is already in flight on this exchange");
+    if (s && s->n && !rids) return ctx->fail(PGR_ERR_INVALID_ARG, "null rid list");
+    Rccl &R = rccl();
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_local = s ? s->count : 0;
+    // phase 1: counts (the compute stream's work is done: pgr_shmmrs_compute synchronizes)
+    x->h_cnt[0] = n_local;
+    PGR_HIP(ctx, hipMemcpyAsync(x->d_cnt, x->h_cnt, sizeof(unsigned long long), hipMemcpyHostToDevice, x->stream));
+    PGR_NCCL(ctx, R.AllGather(x->d_cnt, x->d_cnt + 1, 1, ncclUint64, x->comm, x->stream));
+    PGR_HIP(ctx, hipMemcpyAsync(x->h_cnt + 1, x->d_cnt + 1, (size_t)x->world * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                x->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    uint64_t cap = 0, total = 0;
+    for (int r = 0; r < x->world; ++r) {
+        cap = std::max<uint64_t>(cap, x->h_cnt[1 + r]);
+        total += x->h_cnt[1 + r];
+    }
+    if (n_gathered) *n_gathered = total;
+    if (cap == 0) return PGR_OK;
+    // phase 2: padded payload
+    pgr::Tmp local(ctx), out(ctx);
+    int rc;
+    if ((rc = local.alloc(cap * sizeof(pgr_mm128))) || (rc = out.alloc((size_t)x->world * cap * sizeof(pgr_mm128)))) return rc;
+    if (n_local && (rc = pgr_shmmrs_copy_to_device_rids(ctx, s, local.as<pgr_mm128>(), cap, rids))) return rc;  // synchronizes
+    std::vector<uint64_t> counts((size_t)x->world);
+    if ((rc = pgr_exchange_allgather_shmmrs_start(x, local.as<pgr_mm128>(), n_local, out.as<pgr_mm128>(), cap)) ||
+        (rc = pgr_exchange_wait(x, counts.data())))
+        return rc;
+    if (ix)
+        for (int r = 0; r < x->world; ++r)
+            if (counts[(size_t)r] && (rc = pgr_index_add_shmmrs(ctx, ix, out.as<pgr_mm128>() + (size_t)r * cap, counts[(size_t)r], 1)))
+                return rc;
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the temporaries go back to the allocator
+    return PGR_OK;
 }

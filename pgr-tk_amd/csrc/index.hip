@@ -65,6 +65,17 @@ __global__ void key_flags_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t
     flags[i] = (i == 0 || recs[i].h0 != recs[i - 1].h0 || recs[i].h1 != recs[i - 1].h1) ? 1u : 0u;
 }
 
+// max(sid) + 1 over the records (bounds the target half of the hit-group keys: fewer radix passes per query batch)
+__global__ __launch_bounds__(256) void sid_bound_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n,
+                                                        unsigned long long *__restrict__ out) {
+    unsigned long long m = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        m = umax64(m, (unsigned long long)recs[i].sid + 1ull);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) m = umax64(m, shfl_xor64(m, d));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 __global__ void scatter_starts_kernel(const uint32_t *__restrict__ flags, const uint64_t *__restrict__ rank, uint64_t n,
                                       uint64_t *__restrict__ starts) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -319,9 +330,16 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     const size_t tb = scan_counts_temp_bytes((uint32_t)(n + 1));
     if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
     PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, flags.as<uint32_t>(), rank.as<uint64_t>(), (uint32_t)(n + 1)));
-    uint64_t n_keys = 0;
+    Tmp d_bound(ctx);
+    if ((rc = d_bound.alloc(16))) return rc;
+    PGR_HIP(ctx, hipMemsetAsync(d_bound.p, 0, 16, st));
+    hipLaunchKernelGGL(sid_bound_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, st, ix->recs, n,
+                       d_bound.as<unsigned long long>());
+    uint64_t n_keys = 0, sid_bound = 0;
     PGR_HIP(ctx, hipMemcpyAsync(&n_keys, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(&sid_bound, d_bound.p, 8, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
+    ix->sid_bound = sid_bound;
     if ((rc = ctx->dmalloc((void **)&ix->key_off, (n_keys + 1) * sizeof(uint64_t)))) return rc;
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(),
                        rank.as<uint64_t>(), n, ix->key_off);
@@ -401,6 +419,19 @@ __global__ void run_count_kernel(const pgr_frag_rec *__restrict__ q, const uint3
     for (uint64_t t = i; t < j; ++t) count[sorted[t]] = len;
 }
 
+// the same for queries with few pairs, without sorting: the pairs of one query are contiguous (q_off = record offsets
+// per query), every thread compares its pair with the others of its query
+__global__ void pair_count_kernel(const pgr_frag_rec *__restrict__ q, const uint64_t *__restrict__ q_off, uint64_t nq,
+                                  uint32_t *__restrict__ count) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nq) return;
+    const pgr_frag_rec a = q[p];
+    const uint64_t lo = q_off[a.sid], hi = q_off[a.sid + 1];
+    uint32_t c = 0;
+    for (uint64_t i = lo; i < hi; ++i) c += (q[i].h0 == a.h0 && q[i].h1 == a.h1) ? 1u : 0u;
+    count[p] = c;
+}
+
 struct QParams {
     uint32_t max_count, max_count_query, max_count_target;
 };
@@ -453,13 +484,15 @@ __global__ void hits_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, con
     if (mode == 0) n_hits[p] = n;
 }
 
-// field 0: qb, 1: (query<<32 | sid)
+// field 0: qb, 1: the group key (query << 32 | sid) squeezed to (query << sid_bits | sid): fewer radix passes
 __global__ void hit_key_kernel(const uint64_t *__restrict__ hit_key, const pgr_hitpair *__restrict__ hp,
-                               const uint32_t *__restrict__ idx, int field, uint64_t *__restrict__ keys, uint64_t n) {
+                               const uint32_t *__restrict__ idx, int field, unsigned sid_bits, uint64_t *__restrict__ keys,
+                               uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t j = idx[i];
-    keys[i] = field == 0 ? (uint64_t)hp[j].qb : hit_key[j];
+    const uint64_t k = hit_key[j];
+    keys[i] = field == 0 ? (uint64_t)hp[j].qb : (((k >> 32) << sid_bits) | (k & 0xFFFFFFFFull));
 }
 
 __global__ void gather_hits_kernel(const uint64_t *__restrict__ hit_key, const pgr_hitpair *__restrict__ hp,
@@ -672,8 +705,10 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
     uint32_t *__restrict__ g_nhp, uint32_t *__restrict__ err) {
     static_assert(NMAX % 64 == 0, "the LDS image is also used as a ring of 64-hit blocks");
     __shared__ AlnWaveLds<NMAX> L;
-    if (blockIdx.x >= *n_big) return;
-    const uint32_t g = big_list[blockIdx.x];
+    // the grid is small and fixed (the number of long groups is only known on the device): every workgroup takes the
+    // groups blockIdx.x, blockIdx.x + gridDim.x, ...
+    for (uint32_t gi = blockIdx.x; gi < *n_big; gi += gridDim.x) {
+    const uint32_t g = big_list[gi];
     const uint64_t gs = g_start[g];
     const int n = (int)(g_start[g + 1] - gs);
     const int lane = (int)threadIdx.x;
@@ -919,6 +954,8 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
         g_nchains[g] = n_ch;
         g_nhp[g] = n_out;
     }
+    wave_sync();  // the LDS image is reused by the next group
+    }
 }
 
 
@@ -991,8 +1028,16 @@ struct ChainOut {
 };
 
 // extra = bytes the caller wants behind the image in the same host block (the offset arrays of fill_result)
+inline unsigned bits_for(uint64_t n_values) {  // bits needed for values 0 .. n_values - 1 (at least 1)
+    unsigned b = 1;
+    while (b < 64 && (1ull << b) < n_values) ++b;
+    return b;
+}
+
+// sorted_by_qb: the hits of every group already come in ascending qb (the query path emits them pair by pair in query
+// position order), so only the grouping sort is needed.  sid_bound / n_queries bound the two halves of the group key.
 int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uint64_t n, const AlnParams &prm,
-               uint32_t n_queries, ChainOut &out) {
+               uint32_t n_queries, uint64_t sid_bound, bool sorted_by_qb, ChainOut &out) {
     if (n == 0) return PGR_OK;
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 hits in one batch");
     hipStream_t st = ctx->stream;
@@ -1014,10 +1059,12 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     const size_t tb = sort_pairs_temp_bytes(n);
     if ((rc = ctx->ws_scan_tmp.ensure(ctx, std::max(tb, scan_counts_temp_bytes((uint32_t)(n + 1)))))) return rc;
     uint32_t *cur = idx_a.as<uint32_t>(), *nxt = idx_b.as<uint32_t>();
-    for (int f = 0; f < 2; ++f) {  // stable: by qb (aln.rs:21), then by group
-        hipLaunchKernelGGL(hit_key_kernel, grid_for(n), dim3(256), 0, st, d_key, d_hp, cur, f, keys_a.as<uint64_t>(), n);
+    const unsigned sid_bits = std::min(32u, bits_for(sid_bound ? sid_bound : (1ull << 32)));
+    const unsigned key_bits = std::min(64u, sid_bits + bits_for(n_queries));
+    for (int f = sorted_by_qb ? 1 : 0; f < 2; ++f) {  // stable: by qb (aln.rs:21), then by group
+        hipLaunchKernelGGL(hit_key_kernel, grid_for(n), dim3(256), 0, st, d_key, d_hp, cur, f, sid_bits, keys_a.as<uint64_t>(), n);
         PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), cur, nxt, n,
-                                f == 0 ? 32u : 64u));
+                                f == 0 ? 32u : key_bits));
         std::swap(cur, nxt);
     }
     hipLaunchKernelGGL(gather_hits_kernel, grid_for(n + 1), dim3(256), 0, st, d_key, d_hp, cur, n, skey.as<uint64_t>(),
@@ -1043,12 +1090,12 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
                        g_nhp.as<uint32_t>(), err.as<uint32_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1,
                        (uint32_t)max_big);
     // one wavefront per longer group; the grids are upper bounds, surplus workgroups exit on the device-side counts
-    hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_SMALL>, dim3((uint32_t)max_big), dim3(64), 0, st,
+    hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_SMALL>, dim3((uint32_t)std::min<uint64_t>(max_big, 4096)), dim3(64), 0, st,
                        shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1, prm,
                        v_s.as<float>(), pre.as<int>(), slot.as<int>(), trk.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
                        c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
     const uint64_t max_long = n / (ALN_LDS_SMALL + 1) + 1;
-    hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_MAX>, dim3((uint32_t)max_long), dim3(64), 0, st,
+    hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_MAX>, dim3((uint32_t)std::min<uint64_t>(max_long, 512)), dim3(64), 0, st,
                        shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>() + max_big, err.as<uint32_t>() + 2,
                        prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(), trk.as<int>(), o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(),
                        c_score.as<float>(), g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), err.as<uint32_t>());
@@ -1182,9 +1229,10 @@ namespace {
 // filters): what the lookup stage reads, 17 B each in the reference's layout
 __global__ void sum_ranges_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, uint64_t nq,
                                   unsigned long long *__restrict__ total) {
-    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t v = p < nq ? (uint32_t)(hi[p] - lo[p]) : 0u;
-    v = wave_incl_sum(v);
+    uint32_t v = 0;  // (a key holds < 2^32 signatures in total: the index is limited to 2^32 - 1 records)
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nq; p += (uint64_t)gridDim.x * blockDim.x)
+        v += (uint32_t)(hi[p] - lo[p]);
+    v = wave_incl_sum(v);  // few workgroups: same-address atomics run at ~88 per us on gfx950
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(total, (unsigned long long)v);
 }
 }  // namespace
@@ -1221,6 +1269,8 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     auto t3 = t2, t4 = t2;
     const uint64_t nq = pgr_shmmrs_n_pairs(s);
     qp.n_query_pairs = nq;
+    uint64_t max_pairs = 0;  // most shimmer pairs of one query
+    for (uint32_t c = 0; c < s->n; ++c) max_pairs = std::max(max_pairs, s->h_off[c + 1] - s->h_off[c]);
     ChainOut co;
     if (nq && ix->n) {
         Tmp qrec(ctx), lo(ctx), hi(ctx), cnt(ctx), idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), nh(ctx), hoff(ctx), nsig(ctx);
@@ -1239,17 +1289,23 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
                            ix->key_off, ix->n_keys, lo.as<uint64_t>(), hi.as<uint64_t>());
         PGR_HIP(ctx, hipMemsetAsync(nsig.p, 0, 16, st));
-        hipLaunchKernelGGL(sum_ranges_kernel, grid_for(nq), dim3(256), 0, st, lo.as<uint64_t>(), hi.as<uint64_t>(), nq,
-                           nsig.as<unsigned long long>());
-        // per-query key multiplicities: sort the pairs by (query, h0, h1), count runs
-        hipLaunchKernelGGL(iota_kernel, grid_for(nq), dim3(256), 0, st, idx_a.as<uint32_t>(), nq);
-        const int fields[3] = {2, 3, 1};  // h1, h0, sid(=query)
-        const unsigned bits[3] = {56, 56, 32};
-        if ((rc = sort_perm(ctx, qrec.as<pgr_frag_rec>(), nq, fields, bits, 3, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
-                            keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
-            return rc;
-        hipLaunchKernelGGL(run_count_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(),
-                           idx_a.as<uint32_t>(), nq, cnt.as<uint32_t>());
+        hipLaunchKernelGGL(sum_ranges_kernel, dim3((uint32_t)std::min<uint64_t>(64, (nq + 255) / 256)), dim3(256), 0, st,
+                           lo.as<uint64_t>(), hi.as<uint64_t>(), nq, nsig.as<unsigned long long>());
+        // per-query key multiplicities (aln.rs:180-181).  Queries of up to a few thousand pairs: every pair is compared
+        // with the other pairs of its query (they are contiguous); longer ones: sort by (query, h0, h1), count runs
+        if (max_pairs <= 4096) {
+            hipLaunchKernelGGL(pair_count_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(),
+                               (const uint64_t *)ctx->ws_rec_off.p, nq, cnt.as<uint32_t>());
+        } else {
+            hipLaunchKernelGGL(iota_kernel, grid_for(nq), dim3(256), 0, st, idx_a.as<uint32_t>(), nq);
+            const int fields[3] = {2, 3, 1};  // h1, h0, sid(=query)
+            const unsigned bits[3] = {56, 56, 32};
+            if ((rc = sort_perm(ctx, qrec.as<pgr_frag_rec>(), nq, fields, bits, 3, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+                                keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
+                return rc;
+            hipLaunchKernelGGL(run_count_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(),
+                               idx_a.as<uint32_t>(), nq, cnt.as<uint32_t>());
+        }
         QParams qprm{max_count, max_count_query, max_count_target};
         hipLaunchKernelGGL(hits_kernel, grid_for(nq + 1), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq,
                            cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qprm, 0, nh.as<uint32_t>(),
@@ -1273,7 +1329,8 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
                                cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qprm, 1,
                                (uint32_t *)nullptr, hoff.as<uint64_t>(), hkey.as<uint64_t>(), hhp.as<pgr_hitpair>());
             AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
-            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, n_queries, co))) return rc;
+            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, n_queries, ix->sid_bound, true, co)))
+                return rc;
         }
         t4 = now();
     } else {
@@ -1343,7 +1400,7 @@ extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_h
         PGR_HIP(ctx, hipMemcpyAsync(dh.p, hits, n * sizeof(pgr_hitpair), hipMemcpyHostToDevice, ctx->stream));
         PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         AlnParams ap{max_span, penalty, has_max_gap, max_gap, oriented};
-        if ((rc = chain_hits(ctx, dk.as<uint64_t>(), dh.as<pgr_hitpair>(), n, ap, 1, co))) return rc;
+        if ((rc = chain_hits(ctx, dk.as<uint64_t>(), dh.as<pgr_hitpair>(), n, ap, 1, n_groups, false, co))) return rc;
     }
     return fill_result(ctx, 1, co, out);
 }

@@ -16,6 +16,7 @@ struct pgr_index {
     uint64_t n_keys = 0;
     bool finalized = false;
     uint32_t next_sid = 0;
+    uint64_t sid_bound = 0;  // max(sid) + 1 over the finalized records (0: unknown)
 };
 
 namespace pgr {

@@ -99,6 +99,7 @@ _SIGS = [
     ("pgr_exchange_allgather_shmmrs_start", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_uint64]),
     ("pgr_exchange_wait", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     ("pgr_exchange_device_counts", _VP, [_VP]),
+    ("pgr_exchange_gather_into_index", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), _VP, C.POINTER(C.c_uint64)]),
     ("pgr_index_add_shmmrs", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
     ("pgr_shmmrs_to_frag_recs_device", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.c_int, _VP, C.c_uint64,
                                                  C.POINTER(C.c_uint64)]),

@@ -190,7 +190,9 @@ def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
             used = transport
             break
     assert used is not None
-    print("two-rank sharded build verified over:", used)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "two_rank_transport.txt"), "w") as f:
+        f.write("two-rank sharded build (2 processes, one device) verified over: %s\n" % used)
 
 
 def test_bench_strong_mode_plumbing():

@@ -11,6 +11,20 @@ import json
 import os
 import sys
 
+import re
+
+
+def short_name(n):
+    n = n.replace("(anonymous namespace)::", "")
+    if n.startswith("void "):
+        n = n[5:]
+    if "rocprim" in n:
+        m = re.search(r"(radix_sort_block_sort|radix_sort_onesweep\w*|onesweep\w*|lookback_scan\w*|transform_impl|radix_sort\w*|"
+                      r"histogram\w*|scan\w*|init_\w+)", n)
+        return "rocprim::" + (m.group(1) if m else "kernel(lambda)")
+    return n.split("(")[0].split("<")[0]
+
+
 src, dst = sys.argv[1], sys.argv[2]
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
 os.makedirs(dst, exist_ok=True)
@@ -24,8 +38,7 @@ for i in range(1, len(rows)):
 q = rows[gap_i:]
 agg = collections.OrderedDict()
 for r in q:
-    n = r["Kernel_Name"]
-    n = n.split("(")[0] if not n.startswith("void rocprim") else "rocprim::" + n.split("detail::")[-1].split("<")[0] + "<" + n.split("<", 2)[-1][:60]
+    n = short_name(r["Kernel_Name"])
     d = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     a = agg.setdefault(n, [0, 0.0])
     a[0] += 1
