@@ -26,6 +26,7 @@
 // the files.  The 128-byte RCCL unique id goes from rank 0 to the others through pipes.
 struct RankEnv {
     int rank = 0, world = 1, device = 0;
+    bool force_exchange = false;        // run the exchange code path even with one rank (plumbing test on a 1-GPU box)
     int id_read_fd = -1;                // ranks > 0: read the unique id here
     std::vector<int> id_write_fds;      // rank 0: write it to every other rank
 };
@@ -60,6 +61,7 @@ int main(int argc, char **argv) {
     uint64_t batch_bp = 2000000000ull;
     bool sid_quirk = false;
     int ranks = 1;
+    bool force_exchange = false;
     std::vector<int> devices;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
@@ -79,6 +81,7 @@ int main(int argc, char **argv) {
         else if (a == "--batch-bp") batch_bp = strtoull(val("--batch-bp"), nullptr, 10);
         else if (a == "--reference-sid-quirk") sid_quirk = true;  // load_index_from_reader restarts at 0 per input (seq_db.rs:543)
         else if (a == "--ranks") ranks = atoi(val("--ranks"));
+        else if (a == "--force-exchange") force_exchange = true;
         else if (a == "--devices") {
             std::string v = val("--devices");
             for (size_t p = 0; p <= v.size();) {
@@ -93,7 +96,7 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: pgr-mdb <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch] [--ranks N [--devices 0,1,..]]\n");
         return 2;
     }
-    if (ranks == 1 && devices.empty()) {
+    if (ranks == 1 && devices.empty() && !force_exchange) {
         RankEnv env;
         return run_rank(env, spec, batch_bp, sid_quirk, pos);
     }
@@ -118,6 +121,7 @@ int main(int argc, char **argv) {
             RankEnv env;
             env.rank = r;
             env.world = ranks;
+            env.force_exchange = force_exchange;
             env.device = devices.empty() ? r : devices[(size_t)r % devices.size()];
             for (int q = 1; q < ranks; ++q) {
                 if (r == 0) {
@@ -156,7 +160,7 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
     pgr_index *ix = nullptr;
     if (owner && (rc = pgr_index_create(ctx, &spec, &ix))) die(ctx, "pgr_index_create", rc);
     pgr_exchange *xch = nullptr;
-    if (env.world > 1 || env.id_read_fd >= 0 || !env.id_write_fds.empty()) {
+    if (env.world > 1 || env.force_exchange) {
         uint8_t id[PGR_UNIQUE_ID_BYTES];
         if (env.rank == 0) {
             if ((rc = pgr_exchange_unique_id(ctx, id))) die(ctx, "pgr_exchange_unique_id", rc);

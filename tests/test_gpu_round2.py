@@ -195,6 +195,21 @@ def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
         f.write("two-rank sharded build (2 processes, one device) verified over: %s\n" % used)
 
 
+def test_pgr_mdb_ranks_through_the_c_abi_exchange(tmp_path):
+    """host/pgr_mdb.cpp --ranks: forked rank processes, unique id through pipes, pgr_exchange_gather_into_index -- no Python
+    in the sharded build.  One GPU here, so one rank (RCCL refuses two ranks on one device); the .mdb must be byte-identical
+    to the plain build's"""
+    exe = os.path.join(ROOT, "pgr-tk_amd", "bin", "pgr-mdb")
+    fl = tmp_path / "files.txt"
+    fl.write_text(os.path.join(ROOT, "tests", "golden", "test_seqs.fa") + "\n")
+    for tag, extra in (("plain", []), ("ranks", ["--ranks", "1", "--devices", "0", "--force-exchange", "--batch-bp", "60000"])):
+        r = subprocess.run([exe, str(fl), str(tmp_path / tag)] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+    assert (tmp_path / "plain.mdb").read_bytes() == (tmp_path / "ranks.mdb").read_bytes()
+    assert (tmp_path / "plain.midx").read_bytes() == (tmp_path / "ranks.midx").read_bytes()
+    assert len((tmp_path / "plain.mdb").read_bytes()) > 10_000
+
+
 def test_bench_strong_mode_plumbing():
     """bench.py --strong on one rank through the process-group code path (RCCL world 1, pgr_exchange_*)"""
     import json
