@@ -25,6 +25,15 @@ using namespace pgr;
 
 namespace {
 
+// the few device-side counts the host reads after a stage, gathered into one block: ONE small copy instead of several
+__global__ void gather_words_kernel(const uint64_t *a, const uint64_t *b, const uint64_t *c, const uint32_t *d,
+                                    uint64_t *__restrict__ out) {
+    if (threadIdx.x == 0) out[0] = a ? *a : 0;
+    if (threadIdx.x == 1) out[1] = b ? *b : 0;
+    if (threadIdx.x == 2) out[2] = c ? *c : 0;
+    if (threadIdx.x == 3) out[3] = d ? (uint64_t)*d : 0;
+}
+
 __global__ void iota_kernel(uint32_t *idx, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) idx[i] = (uint32_t)i;
@@ -543,19 +552,35 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
                                   uint32_t *__restrict__ chain_len, float *__restrict__ chain_score,
                                   uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
                                   uint32_t *__restrict__ err, uint32_t *__restrict__ big_list,
-                                  uint32_t *__restrict__ n_big, uint32_t cls_stride) {
+                                  uint32_t *__restrict__ n_big, uint32_t cls_stride,
+                                  uint32_t *__restrict__ span_buf /* max_span > MAX_SPAN_CAP: 3 words per hit */) {
     const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= *n_groups_ptr) return;  // the grid is sized by the number of hits (an upper bound known without a round trip)
-    const uint64_t gs = g_start[g];
-    const int n = (int)(g_start[g + 1] - gs);
-    g_nchains[g] = 0;
-    g_nhp[g] = 0;
-    if (n < 2) return;  // aln.rs:234: targets with a single hit are dropped
-    if (n >= ALN_WAVE_MIN) {  // one wavefront each (sparse_aln_wave_kernel), two size classes
-        const int cls = n > ALN_LDS_SMALL ? 1 : 0;
-        big_list[(size_t)cls * cls_stride + atomicAdd(n_big + cls, 1u)] = (uint32_t)g;
-        return;
+    // (no early return before the ballots below: every lane of the wave takes part in them)
+    const bool live = g < *n_groups_ptr;  // the grid is sized by the number of hits (an upper bound known without a round trip)
+    const uint64_t gs = live ? g_start[g] : 0;
+    const int n = live ? (int)(g_start[g + 1] - gs) : 0;
+    if (live) {
+        g_nchains[g] = 0;
+        g_nhp[g] = 0;
     }
+    // max_span above the LDS span set of the wave kernel (aln.rs:91 accepts any value): every group stays on this
+    // one-thread path with its span set in global memory -- a span set never holds more entries than the group has hits
+    // groups of >= ALN_WAVE_MIN hits: one wavefront each (sparse_aln_wave_kernel), two size classes.  The list slots are
+    // claimed with ONE atomic per wavefront and class (a batch of 10 000 queries has 10 000 such groups; same-address
+    // atomics run at ~88 per us on gfx950)
+    const bool to_wave = n >= ALN_WAVE_MIN && span_buf == nullptr;
+    const int cls = n > ALN_LDS_SMALL ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const uint64_t m = __ballot(to_wave && cls == c);
+        if (m == 0) continue;
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n_big + c, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (to_wave && cls == c) big_list[(size_t)c * cls_stride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)g;
+    }
+    if (to_wave || n < 2) return;  // n < 2: aln.rs:234, targets with a single hit are dropped (and lanes beyond the last group)
     const pgr_hitpair *h = hp + gs;
     float *vs = v_s + gs;
     int *pv = pre + gs;
@@ -571,7 +596,8 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
     }
     vs[sl[0]] = (float)h[0].qe - (float)h[0].qb;  // aln.rs:25-27
     pv[sl[0]] = -1;
-    uint32_t span_q[MAX_SPAN_CAP][3];
+    uint32_t span_loc[MAX_SPAN_CAP][3];
+    uint32_t(*span_q)[3] = span_buf ? reinterpret_cast<uint32_t(*)[3]>(span_buf + 3 * gs) : span_loc;
     for (int i = 1; i < n; ++i) {  // aln.rs:29-103
         const pgr_hitpair cur = h[i];
         int best_v = -1;
@@ -1083,12 +1109,14 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
         (rc = g_nch.alloc(n * 4)) || (rc = g_nhp.alloc(n * 4)) || (rc = err.alloc(16)) ||
         (rc = big.alloc(2 * max_big * 4)) || (rc = trk.alloc(n * 4)))
         return rc;
+    Tmp span_g(ctx);  // only for max_span > MAX_SPAN_CAP
+    if (prm.max_span > MAX_SPAN_CAP && (rc = span_g.alloc(n * 12))) return rc;
     PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 16, st));  // [0] groups the reference never finishes, [1], [2] groups per wave class
     hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
                        gstart.as<uint64_t>(), d_ngroups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
                        o_hp.as<pgr_hitpair>(), c_len.as<uint32_t>(), c_score.as<float>(), g_nch.as<uint32_t>(),
                        g_nhp.as<uint32_t>(), err.as<uint32_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1,
-                       (uint32_t)max_big);
+                       (uint32_t)max_big, span_g.as<uint32_t>());
     // one wavefront per longer group; the grids are upper bounds, surplus workgroups exit on the device-side counts
     hipLaunchKernelGGL(sparse_aln_wave_kernel<ALN_LDS_SMALL>, dim3((uint32_t)std::min<uint64_t>(max_big, 4096)), dim3(64), 0, st,
                        shp.as<pgr_hitpair>(), gstart.as<uint64_t>(), big.as<uint32_t>(), err.as<uint32_t>() + 1, prm,
@@ -1114,10 +1142,11 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     // ---- round trip 1: the totals
     if ((rc = ctx->ensure_mailbox(64))) return rc;
     uint64_t *mb = (uint64_t *)ctx->mailbox;
-    PGR_HIP(ctx, hipMemcpyAsync(mb + 0, d_choff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(mb + 1, d_hpoff.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(mb + 2, d_ngroups, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(mb + 3, err.p, 4, hipMemcpyDeviceToHost, st));
+    Tmp words(ctx);
+    if ((rc = words.alloc(32))) return rc;
+    hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, d_choff.as<uint64_t>() + n, d_hpoff.as<uint64_t>() + n,
+                       d_ngroups, err.as<uint32_t>(), words.as<uint64_t>());
+    PGR_HIP(ctx, hipMemcpyAsync(mb, words.p, 32, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
     PGR_HIP(ctx, hipGetLastError());
     const uint64_t n_chains = mb[0], n_hps = mb[1], n_groups = mb[2];
@@ -1247,8 +1276,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     memset(out, 0, sizeof(*out));
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
     if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
-    if (max_aln_span == 0 || max_aln_span > MAX_SPAN_CAP)
-        return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be in 1..64");
+    if (max_aln_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be at least 1");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const bool dbg = getenv("PGR_DEBUG") != nullptr;
@@ -1315,8 +1343,11 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, nh.as<uint32_t>(), hoff.as<uint64_t>(), (uint32_t)(nq + 1)));
         if ((rc = ctx->ensure_mailbox(64))) return rc;
         uint64_t *mb = (uint64_t *)ctx->mailbox;
-        PGR_HIP(ctx, hipMemcpyAsync(mb + 0, hoff.as<uint64_t>() + nq, 8, hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipMemcpyAsync(mb + 1, nsig.p, 8, hipMemcpyDeviceToHost, st));
+        Tmp words(ctx);
+        if ((rc = words.alloc(32))) return rc;
+        hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, hoff.as<uint64_t>() + nq, nsig.as<uint64_t>(),
+                           (const uint64_t *)nullptr, (const uint32_t *)nullptr, words.as<uint64_t>());
+        PGR_HIP(ctx, hipMemcpyAsync(mb, words.p, 32, hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));  // the number of hits sizes everything behind this point
         const uint64_t n_hits = mb[0];
         qp.n_signatures = mb[1];
@@ -1361,8 +1392,7 @@ extern "C" int pgr_query_hps_batch(pgr_ctx *ctx, const pgr_index *ix, uint32_t n
     if (!ix || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     memset(out, 0, sizeof(*out));
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
-    if (max_aln_span == 0 || max_aln_span > MAX_SPAN_CAP)
-        return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be in 1..64");
+    if (max_aln_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be at least 1");
     const auto t0 = std::chrono::steady_clock::now();
     pgr_batch *b = nullptr;
     int rc = pgr_batch_from_ascii(ctx, n_queries, seqs, lens, &b);  // enqueues H2D + pack; nothing waits here
@@ -1382,7 +1412,7 @@ extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_h
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!out || (n_groups && (!hits || !g_off))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     memset(out, 0, sizeof(*out));
-    if (max_span == 0 || max_span > MAX_SPAN_CAP) return ctx->fail(PGR_ERR_INVALID_ARG, "max_span must be in 1..64");
+    if (max_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_span must be at least 1");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = n_groups ? g_off[n_groups] : 0;
     for (uint32_t g = 0; g < n_groups; ++g)

@@ -344,6 +344,18 @@ class SeqIndexDB:
         return self.query_fragments_to_hps([seq], penalty, max_count, max_count_query, max_count_target, max_aln_span,
                                            max_gap, orientated)[0]
 
+    def query_fragment_to_hps_from_mmap_file(self, seq, penalty, max_count=None, max_count_query=None,
+                                             max_count_target=None, max_aln_span=None, max_gap=None, oriented=False):
+        """ext.rs:285-342 (what pgr-query's default mode and pgr-web call): the reference answers from the mmap'ed `.mdb`
+        through the `.midx` locations (raw_query_fragment_from_mmap_midx, seq_db.rs:1230-1269) and panics unless the backend is
+        file based (AGC / FRG).  Here the `.mdb` of load_from_mdb_index lives on the GPU as the same CSR, so the call is the
+        in-memory query on that backend -- and an error on the others, as in the reference."""
+        if self.backend != "MDB":
+            raise RuntimeError("the call query_fragment_to_hps_from_mmap_file() needs an index-file backend "
+                               "(load_from_mdb_index); this database is " + str(self.backend))
+        return self.query_fragment_to_hps(seq, penalty, max_count, max_count_query, max_count_target, max_aln_span, max_gap,
+                                          oriented)
+
     # ------------------------------------------------------------------ sequences (lib.rs:809-890)
     def get_seq_by_id(self, sid):
         if sid not in self._seqs:

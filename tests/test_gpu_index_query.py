@@ -367,6 +367,14 @@ def test_cli_mdb_and_query(oracle, gpu_ctx, golden_dir, tmp_path):
     sdb = P.SeqIndexDB(ctx=gpu_ctx)
     sdb.load_from_mdb_index(prefix)
     assert sdb.get_shmmr_map() == m and sdb.get_shmmr_spec() == (80, 56, 4, 64, False)
+    # ext.rs:285: the file-backed entry point pgr-query / pgr-web call; an error on in-memory backends as in the reference
+    q = src[200:3000]
+    got = sdb.query_fragment_to_hps_from_mmap_file(q, 0.025)
+    assert got == sdb.query_fragment_to_hps(q, 0.025) and any(sid == 5 for sid, _ in got)
+    mem = P.SeqIndexDB(ctx=gpu_ctx)
+    mem.load_from_seq_list([(n.decode(), s) for n, s in recs[:3]])
+    with pytest.raises(RuntimeError):
+        mem.query_fragment_to_hps_from_mmap_file(q, 0.025)
 
 
 def test_cpp_host_programs_match_python_cli(oracle, gpu_ctx, golden_dir, tmp_path):

@@ -115,6 +115,27 @@ def test_degenerate_group_does_not_fail_the_batch(gpu_ctx):
     assert res["chains"][1] == []
 
 
+def test_max_aln_span_above_64(oracle, gpu_ctx):
+    """aln.rs:91 accepts any max_span; above 64 every group runs on the one-thread kernel with its span set in global memory"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(99)
+    hits, q, t = [], 0, 5000
+    for _ in range(700):
+        q += int(rng.integers(1, 50))
+        t += int(rng.integers(-40, 120))
+        ln = int(rng.integers(30, 200))
+        hits.append(((q, q + ln, int(rng.integers(0, 2))), (max(1, t), max(1, t) + ln, int(rng.integers(0, 2)))))
+        if rng.random() < 0.2:
+            hits.append(((q, q + ln + 3, 0), (max(1, t) + 9000, max(1, t) + 9000 + ln, 0)))
+    hits = list(dict.fromkeys(hits))
+    flat = [a + b for a, b in hits]
+    for span, pen, gap, ori in [(65, 0.01, None, False), (200, 0.002, None, True), (5000, 0.0005, 100000, False)]:
+        got = P.sparse_aln(hits, span, pen, gap, ori, ctx=gpu_ctx)
+        ref = oracle.sparse_aln(flat, span, pen, gap, ori)
+        ref = [(sc, [((x[0], x[1], x[2]), (x[3], x[4], x[5])) for x in hp]) for sc, hp in ref]
+        assert got == ref, span
+
+
 def test_exchange_abi_one_rank(gpu_ctx):
     """pgr_exchange_* with world = 1 on the real device: RCCL is loaded by the library, the collective runs on the
     exchange's stream, the gathered list equals the local one"""
