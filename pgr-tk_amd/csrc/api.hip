@@ -580,17 +580,20 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_tile_desc.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(TileDesc))) ||
-        (rc = ctx->ws_tile_flags.ensure(ctx, (size_t)n_tiles + 16)) ||
         (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long))) ||
-        (rc = ctx->ws_flags.ensure(ctx, std::max<uint32_t>(n, 1) * sizeof(uint32_t))) ||
+        // one block that a single memset clears per call: cursors | contig flags | tile flags  (+ the status words)
+        (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
+                                             std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
         (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_off_b.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t))))
         return rc;
     unsigned long long *d_cursor = (unsigned long long *)ctx->ws_cursor.p;
-    uint64_t *d_status = (uint64_t *)(d_cursor + N_CURSOR);
+    uint32_t *d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
+    uint8_t *d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
+    const size_t zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
+    uint64_t *d_status = (uint64_t *)(((uintptr_t)(d_tflags + (size_t)n_tiles + 16) + 7) & ~(uintptr_t)7);
     uint64_t *mbox = (uint64_t *)ctx->mailbox;  // pinned: [0, N_STATUS) status, then the n+1 result offsets
     PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t),
                                 hipMemcpyHostToDevice, st));
@@ -607,7 +610,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.n_tiles = n_tiles;
     a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
     a.desc = (TileDesc *)ctx->ws_tile_desc.p;
-    a.tile_flags = (uint8_t *)ctx->ws_tile_flags.p;
+    a.tile_flags = d_tflags;
     a.w = w_eff;
     a.k = spec->k;
     a.r = spec->r;
@@ -616,7 +619,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.cursor = d_cursor;
     a.seg_off = (uint64_t *)ctx->ws_seg_off.p;
     a.seg_cnt = (uint32_t *)ctx->ws_seg_cnt.p;
-    a.contig_flags = (uint32_t *)ctx->ws_flags.p;
+    a.contig_flags = d_cflags;
 
     pgr_prof prof;
     memset(&prof, 0, sizeof(prof));
@@ -629,6 +632,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint32_t slot2 = do_reduce ? 256u : FUSED_BLOCK_ELEMS;
     uint64_t serial_base = 0;  // first element of the serial regions inside the level-1 buffer
     bool islands_done = false;
+    bool l2_cursor_clean = false;  // the list stage's cursor words were cleared by stage 1's memset
 
     // ---- stage 1
     auto stage1 = [&]() -> int {
@@ -641,10 +645,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         a.ovf_base = slots_total;
         a.cap = cap_par;
         serial_base = slots_total + cap_par;
-        PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, N_CURSOR * sizeof(unsigned long long), st));
-        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_flags.p, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), st));
-        PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
-        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_tile_flags.p, 0, (size_t)n_tiles + 16, st));
+        PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));  // cursors (both stages), contig flags, tile flags
+        if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
+        l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         if (tiled && bases_tiled) launch_level1_tiles(st, a);
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
@@ -662,10 +665,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
             std::vector<uint32_t> flags(n), n_invalid(n);
             std::vector<uint8_t> tf(n_tiles);
             if (n) {
-                PGR_HIP(ctx, hipMemcpyAsync(flags.data(), ctx->ws_flags.p, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                PGR_HIP(ctx, hipMemcpyAsync(flags.data(), d_cflags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
                 PGR_HIP(ctx, hipMemcpyAsync(n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             }
-            PGR_HIP(ctx, hipMemcpyAsync(tf.data(), ctx->ws_tile_flags.p, n_tiles, hipMemcpyDeviceToHost, st));
+            PGR_HIP(ctx, hipMemcpyAsync(tf.data(), d_tflags, n_tiles, hipMemcpyDeviceToHost, st));
             PGR_HIP(ctx, hipStreamSynchronize(st));
             for (uint32_t c = 0; c < n; ++c) {
                 if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
@@ -761,8 +764,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         // a cursor-allocated overflow region
         const uint64_t slots2 = (uint64_t)n_blocks * slot2;
         if ((r = ctx->ws_list_a.ensure(ctx, (slots2 + cap2 + 1) * sizeof(pgr_mm128)))) return r;
-        PGR_HIP(ctx, hipMemsetAsync(d_cursor + 4, 0, 2 * sizeof(unsigned long long), st));
-        PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p + n_blocks, 0, sizeof(uint32_t), st));
+        if (!l2_cursor_clean) PGR_HIP(ctx, hipMemsetAsync(d_cursor + 4, 0, 2 * sizeof(unsigned long long), st));
+        l2_cursor_clean = false;  // (a repeat of this stage alone clears it again)
+        if (n_blocks == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p, 0, sizeof(uint32_t), st));
         FusedArgsPub fa;
         fa.l1 = (const pgr_mm128 *)ctx->ws_l1.p;
         fa.seg_off = (const uint64_t *)ctx->ws_seg_off.p;
@@ -787,6 +791,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         return PGR_OK;
     };
     bool scanned4 = false;
+    uint64_t host_copy_elems = 0;
     auto stage4 = [&]() -> int {
         int r;
         if (!scanned4) {  // (a repeat of stage 4 alone only re-gathers into a bigger result buffer)
@@ -817,6 +822,13 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
         PGR_HIP(ctx, hipMemcpyAsync(mbox, d_status, N_STATUS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipMemcpyAsync(mbox + N_STATUS, d_loff, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        // a small result that the caller wants on the host anyway (pgr_shmmr_batch) rides along with this round trip
+        host_copy_elems = 0;
+        if (ctx->want_host_copy && !pad_fix && cap_res * sizeof(pgr_mm128) <= (256u << 10) &&
+            ctx->ensure_pinned_out(256u << 10) == PGR_OK) {
+            PGR_HIP(ctx, hipMemcpyAsync(ctx->pinned_out, d_list, cap_res * sizeof(pgr_mm128), hipMemcpyDeviceToHost, st));
+            host_copy_elems = cap_res;
+        }
         return PGR_OK;
     };
 
@@ -889,6 +901,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     }
     memcpy(res->h_off.data(), mbox + N_STATUS, ((size_t)n + 1) * sizeof(uint64_t));
     res->count = n_final;
+    if (host_copy_elems >= n_final && host_copy_elems) res->host_copy = (const pgr_mm128 *)ctx->pinned_out;
+    ctx->want_host_copy = false;
     res->rid_is_index = (d_rids == nullptr) && !pad_fix;
     if (b->total_bases) {
         ctx->est_spec_key = spec_key;
@@ -950,7 +964,9 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
         return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     }
     memcpy(off, s->h_off.data(), ((size_t)s->n + 1) * sizeof(uint64_t));
-    if (s->count) {
+    if (s->count && s->host_copy) {
+        memcpy(mm, s->host_copy, s->count * sizeof(pgr_mm128));
+    } else if (s->count) {
         const int rc = ctx->d2h(mm, s->d_mm, s->count * sizeof(pgr_mm128));
         if (rc) {
             free(mm);
@@ -1235,7 +1251,9 @@ extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, c
     pgr_batch *b = nullptr;
     if ((rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b))) return rc;
     pgr_shmmrs *s = nullptr;
+    ctx->want_host_copy = true;
     rc = pgr_shmmrs_compute(ctx, b, spec, rids, padding, &s);
+    ctx->want_host_copy = false;
     pgr_batch_destroy(b);
     if (rc) return rc;
     rc = pgr_shmmrs_download(ctx, s, out_mm, out_off);

@@ -597,6 +597,7 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
     const uint32_t c = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     const uint32_t sidx = a.tile_first[c + 1] + c;
+    if (c == 0 && lane == 0) a.seg_cnt[a.n_tiles + a.n_contigs] = 0;  // sentinel of the scan over the segment counts
     const uint32_t w = a.w, k = a.k;
     const ContigGeom g = contig_geom(a.b.len[c], w, k);
     const long long n_tail = (a.sketch || g.jend < g.jstart) ? 0 : (g.L - 1 - g.jend);

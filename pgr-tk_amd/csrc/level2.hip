@@ -401,8 +401,9 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
 
 // first segment of every fused workgroup: largest s with seg_dst[s] <= max(0, b*FUSED_B - halo)
 __global__ void block_first_seg_kernel(const uint64_t *__restrict__ seg_dst, uint32_t n_segs, uint32_t n_blocks,
-                                       uint32_t halo, uint32_t *__restrict__ blk_first_seg) {
+                                       uint32_t halo, uint32_t *__restrict__ blk_first_seg, uint32_t *__restrict__ blk_cnt) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b == 0) blk_cnt[n_blocks] = 0;  // sentinel of the scan over the block counts (saves a memset per call)
     if (b >= n_blocks) return;
     const uint64_t core_lo = (uint64_t)b * FUSED_B;
     const uint64_t lo = core_lo >= halo ? core_lo - halo : 0;
@@ -441,7 +442,7 @@ __global__ void patch_rid_kernel(pgr_mm128 *__restrict__ mm, const uint64_t *__r
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks) {
     if (n_blocks == 0) return;
     hipLaunchKernelGGL(block_first_seg_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, a.seg_dst, a.n_segs,
-                       n_blocks, a.halo, a.blk_first_seg);
+                       n_blocks, a.halo, a.blk_first_seg, a.blk_cnt);
     if (a.halo <= 32)
         hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
     else

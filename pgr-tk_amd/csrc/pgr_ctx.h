@@ -36,6 +36,7 @@ struct pgr_ctx {
     // pinned mailbox: the handful of device-side counts (+ result offsets) a call reads after its one synchronization
     void *mailbox = nullptr;
     size_t mailbox_cap = 0;
+    bool want_host_copy = false;   // set by the host-buffer entry points: a small result rides along with the final round trip
     bool staged_unsynced = false;  // a batch was staged on `stream` and nobody has synchronized since
     // result-size estimate: final shimmers per base of the last pgr_shmmrs_compute with the spec `est_spec_key`
     double est_spec_key = -1.0, est_final_ratio = 0.0;

@@ -54,6 +54,7 @@ struct pgr_shmmrs {
     uint64_t *d_off = nullptr;   // [n+1]
     std::vector<uint64_t> h_off; // [n+1]
     bool rid_is_index = false;   // MM128.y >> 32 is the contig index (no rids given, no padding sentinels)
+    const pgr_mm128 *host_copy = nullptr;  // small results: already in the context's pinned buffer (valid until its next use)
 };
 
 namespace pgr {
