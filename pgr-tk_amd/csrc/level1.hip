@@ -214,7 +214,8 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
     // x[]: ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
 #if PGR_TILE_V2
     uint32_t strand_rev = 0;  // strand bits in reversed order (bit 15 - u)
-    uint64_t pal_any = 0;     // lanes (any position) that may hold a palindromic k-mer: SGPR pair
+    uint64_t eq0[L1_G];       // per position: lanes whose low planes are equal (f0 == r0), SGPR pairs
+    uint64_t pal0_any = 0;
 #else
     uint32_t pal_min = 0xFFFFFFFFu;  // 0 iff some position may hold a palindromic k-mer
 #endif
@@ -255,13 +256,25 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             const bool skip = (f0 == r0) && (f1 == r1);
             if (!skip && h < sketch_thr) emit |= 1u << u;
         } else {
-            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480): low planes equal (probability 2^-(k/2) per
-            // position on random sequence) and the low words of the high planes agree -- a cheap necessary test, a hit
-            // only routes the tile to the exact island path.  Two compares into SGPR masks; the rest is scalar.
-            pal_any |= cmp_eq_u64(f0, r0) & cmp_eq_u32((uint32_t)f1, (uint32_t)r1) & ok_mask;
+            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480): the low planes are equal with probability
+            // 2^-(k/2) per position on random sequence, so ONE compare into an SGPR mask per position is kept and the high
+            // planes are only looked at in the (practically never taken) scalar branch behind the loop
+            eq0[u] = cmp_eq_u64(f0, r0) & ok_mask;
+            pal0_any |= eq0[u];
         }
     }
     strand_bits = __brev(strand_rev) >> 16;
+    uint64_t pal_any = 0;
+    if (!SKETCH && pal0_any) {  // wave-uniform: some lane has f0 == r0 somewhere; now the exact test on the high planes
+#pragma unroll
+        for (int u = 0; u < L1_G; ++u) {
+            if (eq0[u] == 0) continue;
+            asm volatile("s_nop 15");  // (marks the cold block for tools/isa_histogram.py: weight 0)
+            const uint64_t f1 = shr_mask(u >= 8 ? fa1 : fb1, (uint32_t)((L1_G - 1 - u) & 7), kmask);
+            const uint64_t r1 = TK ? shr_mask(u >= 8 ? rB1 : rA1, (uint32_t)(u & 7), kmask) : rc_plane(f1, k);
+            pal_any |= eq0[u] & cmp_eq_u64(f1, r1);
+        }
+    }
     const uint32_t pal_min = pal_any ? 0u : 1u;
 
 #else

@@ -12,7 +12,10 @@
 namespace pgr {
 
 // ------------------------------------------------------------------ geometry of the level-1 kernel
-constexpr int L1_BLOCK = 512;            // threads per workgroup (8 wavefronts of 64)
+#ifndef PGR_L1_BLOCK
+#define PGR_L1_BLOCK 512
+#endif
+constexpr int L1_BLOCK = PGR_L1_BLOCK;   // threads per workgroup (8 wavefronts of 64)
 constexpr int L1_G = 16;                 // consecutive positions owned by one lane
 constexpr int L1_EXT = L1_BLOCK * L1_G;  // positions per tile including both halos
 constexpr int L1_WORDS = (L1_EXT + 96) / 32 + 5;  // plane words staged per tile (tile + k-mer look-back)

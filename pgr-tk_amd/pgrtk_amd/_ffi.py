@@ -9,7 +9,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libpgrhip.so")
+# (PGR_HIP_LIB: another build of the same library, for A/B timing of kernel variants)
+LIB_PATH = os.environ.get("PGR_HIP_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libpgrhip.so")
 
 MM128 = np.dtype([("x", "<u8"), ("y", "<u8")])
 FRAG_REC = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("frg_id", "<u4"), ("sid", "<u4"), ("bgn", "<u4"),

@@ -250,15 +250,26 @@ def pbundle_summary_lines(seq_info, partitions, k):
 
 
 def cmd_pbundle_decomp(args):
+    from . import pdb
     sdb = SeqIndexDB()
-    sdb.load_from_fastx(args.fastx_path, args.w, args.k, args.r, args.min_span)
-    bundles, dec = sdb.get_principal_bundle_decomposition(args.min_cov, args.min_branch_size)
-    seq_info = sdb.seq_info
-    if args.decomp_fastx_path or args.include:
-        # decomposition of other sequences with the vertex map voted by <fastx_path>'s own sequences
-        # (rs:247-292 + ext.rs:976-1014): every bundle vertex is a shimmer pair of those sequences, so the map is
-        # exactly the annotation of their pairs
+    if args.precomputed_bundles:
+        # rs:155-218: the bundles and the vertex map come from a .pdb written by an earlier run; its parameters replace
+        # the command line's (rs:239-244); nothing is computed from <fastx_path> but the decomposition of its sequences
+        (args.w, args.k, args.r, args.min_span, args.min_branch_size, args.min_cov, bundles, vmap) = \
+            pdb.read_pdb(args.precomputed_bundles)
+        sdb._reset(args.w, args.k, args.r, args.min_span)
+        dec, seq_info = None, None
+    else:
+        sdb.load_from_fastx(args.fastx_path, args.w, args.k, args.r, args.min_span)
+        bundles, dec = sdb.get_principal_bundle_decomposition(args.min_cov, args.min_branch_size)
+        seq_info = sdb.seq_info
+        # every bundle vertex is a shimmer pair of <fastx_path>'s own sequences, so the vertex map
+        # (get_vertex_map_from_principal_bundles, ext.rs:512-531) is exactly the annotation of their pairs
         vmap = {(smp[0], smp[1]): info for _, smps in dec for smp, info in smps if info is not None}
+        pdb.write_pdb(args.output_prefix + ".pdb", args.w, args.k, args.r, args.min_span, args.min_branch_size, args.min_cov,
+                      bundles, vmap)  # rs:357-383
+    if args.decomp_fastx_path or args.include or dec is None:
+        # decomposition of other sequences with that vertex map (rs:247-292 + ext.rs:976-1014)
         recs = read_fastx(args.decomp_fastx_path or args.fastx_path)
         if args.include:
             want = set(l.strip() for l in open(args.include) if l.strip())
@@ -321,6 +332,8 @@ def main(argv=None):
     b.add_argument("output_prefix")
     b.add_argument("-i", "--include", default=None)
     b.add_argument("-d", "--decomp-fastx-path", dest="decomp_fastx_path", default=None)
+    b.add_argument("--precomputed-bundles", dest="precomputed_bundles", default=None,
+                   help="a .pdb written by an earlier run: skip the bundle computation (its w/k/r/min_span/... win)")
     b.add_argument("-w", type=int, default=48)
     b.add_argument("-k", type=int, default=56)
     b.add_argument("-r", type=int, default=4)

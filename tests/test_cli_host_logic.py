@@ -83,3 +83,22 @@ def test_query_sdb_and_merge_regions_golden():
     assert n_parts > 60
     for c in cases["rc"]:
         assert P.rc(c["seq"]) == c["rc"] and P.rc_byte_seq(list(c["seq"].encode())) == c["rc_bytes"]
+
+
+def test_pdb_bincode_varint_kat():
+    """`.pdb` = "PDB:0.5" + bincode 2 standard (little endian, varint) of the tuple pgr-pbundle-decomp.rs:362-378 encodes.
+    Known answers written by hand from the format description: < 251 one byte; 251 + u16; 252 + u32; 253 + u64; u8 raw."""
+    sys.path.insert(0, os.path.join(ROOT, "pgr-tk_amd"))
+    from pgrtk_amd import pdb
+    bundles = [(250, 251, [(65535, 65536, 1)]), (0, 0, [])]
+    vmap = {((1 << 32) - 1, 1 << 32): (3, 0, 300)}
+    got = pdb.encode(48, 56, 4, 12, 8, 0, bundles, vmap)
+    want = (b"PDB:0.5" + bytes([48, 56, 4, 12, 8, 0]) + bytes([2])            # header, 2 bundles
+            + bytes([250]) + b"\xfb\xfb\x00" + bytes([1])                       # id 250, order 251 -> fb + u16, 1 vertex
+            + b"\xfb\xff\xff" + b"\xfc\x00\x00\x01\x00" + bytes([1])           # 65535 -> fb ffff ; 65536 -> fc + u32 ; dir
+            + bytes([0, 0, 0])                                                   # second bundle: id 0, order 0, no vertices
+            + bytes([1])                                                         # one map entry
+            + b"\xfc\xff\xff\xff\xff" + b"\xfd\x00\x00\x00\x00\x01\x00\x00\x00"  # key: 2^32-1 -> fc + u32 ; 2^32 -> fd + u64
+            + bytes([3, 0]) + b"\xfb\x2c\x01")                                  # (bundle 3, direction 0, position 300)
+    assert got == want
+    assert pdb.decode(got) == (48, 56, 4, 12, 8, 0, bundles, vmap)

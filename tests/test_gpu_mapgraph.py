@@ -219,6 +219,20 @@ def test_cli_pbundle_decomp(oracle, gpu_ctx, tmp_path):
         osm.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
     odec = og.get_principal_bundle_decomposition(vmap, osm)
     assert open(tmp_path / "out2.bed").read().splitlines()[1:] == og.bed_lines({0: "o0", 1: "o1"}, odec, with_id, 24, 300, 3000)
+    # .pdb cache (rs:357-383 / :155-218): the first run wrote it; a run that reads it back (different, ignored, spec on
+    # the command line) reproduces both decompositions without recomputing the bundles
+    from pgrtk_amd import pdb
+    w_, k_, r_, ms_, mbs_, mc_, pb, vm = pdb.read_pdb(str(tmp_path / "out.pdb"))
+    assert (w_, k_, r_, ms_, mbs_, mc_) == (24, 24, 2, 8, 8, 0)
+    assert [(b[0], b[1], [tuple(v) for v in b[2]]) for b in pb] == [(b[0], b[1], [tuple(v) for v in b[2]]) for b in with_id]
+    assert vm == {k2: tuple(v) for k2, v in vmap.items()}
+    cli.main(["pbundle-decomp", str(fa), str(tmp_path / "out3"), "-w", "80", "-r", "4", "--precomputed-bundles",
+              str(tmp_path / "out.pdb"), "--bundle-length-cutoff", "300", "--bundle-merge-distance", "3000"])
+    assert open(tmp_path / "out3.bed").read().splitlines()[1:] == bed[1:]
+    assert open(tmp_path / "out3.ctg.summary.tsv").read() == open(tmp_path / "out.ctg.summary.tsv").read()
+    cli.main(["pbundle-decomp", str(fa), str(tmp_path / "out4"), "--precomputed-bundles", str(tmp_path / "out.pdb"), "-d", str(fb),
+              "--bundle-length-cutoff", "300", "--bundle-merge-distance", "3000"])
+    assert open(tmp_path / "out4.bed").read().splitlines()[1:] == open(tmp_path / "out2.bed").read().splitlines()[1:]
     # the C++ host program above the C ABI writes the same files
     import os
     import subprocess

@@ -11,6 +11,7 @@ What it does (works without a GPU: the code object is in the shared library):
        * blocks of the boundary variant of the tile kernel (they hold the v_bfe_i32 mask expansions that only
          `tile_select<..., MASKED = true>` contains) weigh --masked-weight (default 0: a 10 Mbp contig has 2 boundary
          tiles in 1245);
+       * blocks the source marks cold with `s_nop 15` weigh 0;
        * the body of a backward branch (the output loop `while (em)`) weighs --loop-trips (default 2.45 = expected
          maximum over 64 lanes of the number of level-1 minimizers among a lane's 16 positions at density 2/(w+1));
        * everything else weighs 1;
@@ -136,6 +137,8 @@ def main():
         if any(o.startswith("v_bfe_i32") for o in ops):
             w = a.masked_weight
             n_blocks_masked += 1
+        if any(ins[i][1] == "s_nop" and ins[i][2].strip() == "15" for i in range(s, e)):
+            w = 0.0  # marked cold in the source (the exact palindrome test behind a wave-uniform, practically never taken branch)
         for ls, le in loops:
             if s >= ls and e - 1 <= le:
                 w *= a.loop_trips
