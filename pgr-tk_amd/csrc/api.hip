@@ -817,7 +817,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                                (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list,
                                cap_res);
         launch_offsets_by_rid(st, d_list, d_nfinal, cap_res, n, d_loff);
-        if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids);
+        if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids, n);
         launch_collect_status(st, d_cursor, d_total1, d_nfinal, d_status);
         PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
         PGR_HIP(ctx, hipMemcpyAsync(mbox, d_status, N_STATUS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));

@@ -432,11 +432,15 @@ __global__ void offsets_by_rid_kernel(const pgr_mm128 *__restrict__ mm, const ui
 }
 
 __global__ void patch_rid_kernel(pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ n_ptr, uint64_t cap,
-                                 const uint32_t *__restrict__ rids) {
+                                 const uint32_t *__restrict__ rids, uint32_t n_contigs) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= cap || i >= *n_ptr) return;
     const uint64_t y = mm[i].y;
-    mm[i].y = ((uint64_t)rids[(uint32_t)(y >> 32)] << 32) | (y & 0xFFFFFFFFull);
+    const uint32_t c = (uint32_t)(y >> 32);
+    // when the result buffer turned out too small the gather left holes (uninitialised elements): their "contig" is
+    // garbage and must not index rids[] -- the host sees the true count and repeats the stage with a bigger buffer
+    if (c >= n_contigs) return;
+    mm[i].y = ((uint64_t)rids[c] << 32) | (y & 0xFFFFFFFFull);
 }
 
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks) {
@@ -533,9 +537,10 @@ void launch_copy_add_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, uint32
     if (n == 0) return;
     hipLaunchKernelGGL(copy_add_rid_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, in, n, rid_add, out);
 }
-void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, const uint32_t *rids) {
+void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, const uint32_t *rids,
+                      uint32_t n_contigs) {
     if (cap == 0) return;
-    hipLaunchKernelGGL(patch_rid_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, mm, n_ptr, cap, rids);
+    hipLaunchKernelGGL(patch_rid_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, mm, n_ptr, cap, rids, n_contigs);
 }
 
 }  // namespace pgr

@@ -39,6 +39,12 @@ def test_small_calls_take_the_optimistic_path_and_stay_exact(oracle, gpu_ctx):
             got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(*spec_t), ctx=gpu_ctx)
             for i, s in enumerate(seqs):
                 assert _same(oracle.sequence_to_shmmrs(i, s, sp), got[i]), (spec_t, name, i)
+    # caller rids + a result far bigger than the estimate: the first gather leaves holes, the rid patch must not follow
+    # their garbage (regression: memory access fault found by tools/fuzz_parity.py), the retry must be exact
+    for seqs, rids in (([b"A" * 300_000, seqgen.rnd(rng, 5_000)], [2_000_000_000, 7]), ([b"ACAC" * 60_000], [4_000_000_000])):
+        got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(*sp_t), rids=rids, ctx=gpu_ctx)
+        for i, s in enumerate(seqs):
+            assert _same(oracle.sequence_to_shmmrs(rids[i], s, oracle.spec(*sp_t)), got[i]), ("rids", i)
     # the result-size estimate adapts to the previous call: a dense call after sparse ones, and back
     for seqs in ([seqgen.rnd(rng, 100_000)], [b"C" * 200_000], [seqgen.rnd(rng, 100_000)]):
         got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(*sp_t), ctx=gpu_ctx)

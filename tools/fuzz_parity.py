@@ -58,7 +58,12 @@ def main():
     fails, bases = [], 0
     t0 = time.time()
     with ThreadPoolExecutor(16) as pool:
+        log = open(os.environ["FUZZ_LOG"], "w") if os.environ.get("FUZZ_LOG") else None
         for it in range(iters):
+            if log:  # the last line names the case a crash happened in
+                log.seek(0)
+                log.write("%d\n" % (seed0 + it))
+                log.flush()
             r = one_case(seed0 + it, max_len, ctx, pool)
             if isinstance(r, str):
                 fails.append(r)

@@ -113,8 +113,8 @@ def main():
     ap.add_argument("--masked-weight", type=float, default=0.0)
     ap.add_argument("--loop-trips", type=float, default=2.45)
     ap.add_argument("--positions-per-wave", type=int, default=1024)
-    ap.add_argument("--core-fraction", type=float, default=(8192 - 2 * 79) // 64 * 64 / 8192.0,
-                    help="core positions / extended positions of a tile (w=80: 8000/8192)")
+    ap.add_argument("--core-fraction", type=float, default=(4096 - 2 * 79) // 64 * 64 / 4096.0,
+                    help="core positions / extended positions of a tile (256 lanes x 16, w=80: 3904/4096)")
     ap.add_argument("--measured-valu-per-wave", type=float, default=None)
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
