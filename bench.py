@@ -255,8 +255,11 @@ def query_bench_dist(P, ctx, spec, args, gathered, world, rank, dist, torch, loc
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     ix = P.Index(spec, ctx=ctx)
-    g = gathered.contiguous()
-    ix.add_shmmrs(device_ptr=g.data_ptr(), n=int(g.shape[0]))
+    for part in gathered:  # one rank's list after the other (a sequence never straddles two ranks)
+        if int(part.shape[0]):
+            g = part if part.is_cuda else part.to("cuda:%d" % local_rank)
+            g = g.contiguous()
+            ix.add_shmmrs(device_ptr=g.data_ptr(), n=int(g.shape[0]))
     ix.finalize()
     t_build = time.perf_counter() - t0
     cs, offs, qs_all = make_queries(P, args.seed, all_ids, len(all_ids), args.contig_len, nq, qlen, rng)
@@ -469,7 +472,20 @@ def main():
         gdev = dev if args.backend == "nccl" else "cpu"
         out_bufs = [torch.empty((world * cap_mm, exchange.MM_WORDS), dtype=torch.int64, device=gdev) for _ in range(2)]
         if use_abi:
-            xch = exchange.AbiExchange(ctx, rank, world, dist)  # ncclUniqueId from rank 0 through the process group
+            # ncclUniqueId from rank 0 through the process group.  If the library's own communicator cannot be created on
+            # ANY rank (all ranks agree through an all-reduce), everybody falls back to torch.distributed's all-gather
+            try:
+                xch = exchange.AbiExchange(ctx, rank, world, dist)
+                ok = 1
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: pgr_exchange_create failed (%r): torch.distributed all-gather instead" % (rank, e), file=sys.stderr)
+                xch, ok = None, 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if xch is not None:
+                    xch.close()
+                xch, use_abi = None, False
     del probe
     if use_dist:
         dist.barrier()  # creates the communicator here, not inside the first timed step
@@ -478,8 +494,8 @@ def main():
 
     def finish_pending():
         if state["pending"] is not None:
-            gathered, counts = state["pending"].wait()
-            state["gathered"] = gathered
+            parts, counts = state["pending"].wait(concat=False)  # per-rank views into the gather buffer: no copy
+            state["gathered"] = parts
             state["pending"] = None
 
     def step():
@@ -533,7 +549,6 @@ def main():
     if use_dist and args.queries > 0 and state.get("gathered") is not None:
         try:
             g = state["gathered"]
-            g = g if g.is_cuda else g.to("cuda:%d" % local_rank)
             if args.strong:
                 all_ids = list(range(args.contigs))
             else:

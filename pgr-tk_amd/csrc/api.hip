@@ -408,8 +408,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             next_region += h.d.region_cap;
             descs[q] = h.d;
         }
-        if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(pgr_mm128), st))) return rc;
-        a.out = (pgr_mm128 *)ctx->ws_l1.p;
+        if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
+        a.out = (L1Rec *)ctx->ws_l1.p;
         if ((rc = ctx->ws_serial.ensure(ctx, nq * (sizeof(ChunkDesc) + 2 * sizeof(ChunkState) + sizeof(uint32_t)))))
             return rc;
         ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
@@ -581,6 +581,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_tile_desc.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(TileDesc))) ||
         (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_seg_cid.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
         // one block that a single memset clears per call: cursors | contig flags | tile flags  (+ the status words)
         (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
@@ -619,6 +620,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.cursor = d_cursor;
     a.seg_off = (uint64_t *)ctx->ws_seg_off.p;
     a.seg_cnt = (uint32_t *)ctx->ws_seg_cnt.p;
+    a.seg_cid = (uint32_t *)ctx->ws_seg_cid.p;
     a.contig_flags = d_cflags;
 
     pgr_prof prof;
@@ -639,8 +641,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         uint64_t serial_total = 0;
         for (uint32_t c : serial) serial_total += (uint64_t)b->h_len[c] / 4 + 4096;
         int r;
-        if ((r = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(pgr_mm128)))) return r;
-        a.out = (pgr_mm128 *)ctx->ws_l1.p;
+        if ((r = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(L1Rec)))) return r;
+        a.out = (L1Rec *)ctx->ws_l1.p;
         a.slot = slot;
         a.ovf_base = slots_total;
         a.cap = cap_par;
@@ -768,7 +770,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         l2_cursor_clean = false;  // (a repeat of this stage alone clears it again)
         if (n_blocks == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p, 0, sizeof(uint32_t), st));
         FusedArgsPub fa;
-        fa.l1 = (const pgr_mm128 *)ctx->ws_l1.p;
+        fa.l1 = (const L1Rec *)ctx->ws_l1.p;
+        fa.seg_cid = (const uint32_t *)ctx->ws_seg_cid.p;
+        fa.k = spec->k;
         fa.seg_off = (const uint64_t *)ctx->ws_seg_off.p;
         fa.seg_cnt = (const uint32_t *)ctx->ws_seg_cnt.p;
         fa.seg_dst = (const uint64_t *)ctx->ws_seg_dst.p;

@@ -25,6 +25,9 @@
 #define PGR_TILE_V2 1  // 1: round-2 instruction selection (strand select from SGPR lane masks, multiplications in the hash,
                        //    window-row minima folded into the prefix chains); 0: the round-1 code, kept for A/B timing
 #endif
+#ifndef PGR_TILE_ATTR
+#define PGR_TILE_ATTR  // experiment hook: e.g. -DPGR_TILE_ATTR='__attribute__((amdgpu_waves_per_eu(4,4)))'
+#endif
 #ifndef PGR_ABLATE
 #define PGR_ABLATE 0  // timing experiments only (1: no window passes, 2: no u64hash); results are wrong when set
 #endif
@@ -32,6 +35,14 @@
 namespace pgr {
 
 namespace {
+
+__device__ __forceinline__ L1Rec l1rec_from_xy(uint64_t x, uint64_t y) {  // x = key << 8 | k
+    L1Rec r;
+    r.key_lo = (uint32_t)(x >> 8);
+    r.key_hi = (uint32_t)(x >> 40);
+    r.ypos = (uint32_t)y;
+    return r;
+}
 
 __device__ __forceinline__ uint32_t find_contig(const uint32_t *__restrict__ tile_first, uint32_t n, uint32_t tile) {
     // largest c with tile_first[c] <= tile
@@ -463,7 +474,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
 // TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
 // instantiated with constants so that every row offset, shift and mask is an immediate.
 template <int TW, int TK, bool SKETCH>
-__global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
+__global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a) {
     __shared__ double s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
     __shared__ double s_row[L1_BLOCK];        // row min, later row max
     __shared__ uint2 s_words[L1_WORDS];
@@ -555,6 +566,7 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
         const uint32_t sidx = tile + c;  // one tail segment per preceding contig
         a.seg_off[sidx] = base;
         a.seg_cnt[sidx] = ok ? total : 0u;
+        a.seg_cid[sidx] = c;
         if (s_skip) {
             atomicOr(a.contig_flags + c, 1u);
             a.tile_flags[tile] = 1;
@@ -569,16 +581,17 @@ __global__ __launch_bounds__(L1_BLOCK) void level1_tile_kernel(L1Args a) {
     {
         const unsigned long long base = s_base;
         if (cnt && base != ~0ull) {
-            pgr_mm128 *__restrict__ o = a.out + (base + wave_base + (incl - cnt));
+            L1Rec *__restrict__ o = a.out + (base + wave_base + (incl - cnt));
             const uint32_t q32 = (uint32_t)q;  // core positions are >= 0 and < 2^31
             uint32_t em = emit;
             while (em) {
                 const uint32_t u = (uint32_t)__builtin_ctz(em);
                 em &= em - 1;
                 const uint64_t kb = (uint64_t)__double_as_longlong(s_suf[u][t]);
-                pgr_mm128 m;
-                m.x = (kb << 8) | (uint64_t)k;  // drops bit 62, keeps the low 56 hash bits
-                m.y = ((uint64_t)c << 32) | (((q32 + u) << 1) | ((strand_bits >> u) & 1u));
+                L1Rec m;
+                m.key_lo = (uint32_t)kb;
+                m.key_hi = (uint32_t)(kb >> 32) & 0x00FFFFFFu;  // drops bit 62, keeps the 56 hash bits
+                m.ypos = ((q32 + u) << 1) | ((strand_bits >> u) & 1u);
                 *o++ = m;
             }
         }
@@ -618,6 +631,7 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
         if (lane == 0) {
             a.seg_off[sidx] = 0;
             a.seg_cnt[sidx] = 0;
+            a.seg_cid[sidx] = c;
         }
         return;
     }
@@ -676,6 +690,7 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
         s_base = ok ? a.ovf_base + ob : ~0ull;
         a.seg_off[sidx] = a.ovf_base + ob;
         a.seg_cnt[sidx] = ok ? (uint32_t)n_emit : 0u;
+        a.seg_cid[sidx] = c;
         if (!ok) atomicExch(a.cursor + 1, 1ull);
     }
     __syncthreads();
@@ -683,10 +698,7 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
     if (base != ~0ull) {
         for (int i = lane; i < n_emit; i += 64) {
             const uint32_t idx = s_emit[i];
-            pgr_mm128 m;
-            m.x = s_x[idx];
-            m.y = ((uint64_t)c << 32) | ((uint64_t)(lo + idx) << 1) | (s_st[idx] & 1u);
-            a.out[base + i] = m;
+            a.out[base + i] = l1rec_from_xy(s_x[idx], ((uint64_t)(lo + idx) << 1) | (s_st[idx] & 1u));
         }
     }
 }
@@ -728,7 +740,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
     const uint32_t *__restrict__ vplane = a.b.valid + a.b.word_off[c];
     const long long nwords = (L + 31) >> 5;
-    pgr_mm128 *__restrict__ out = a.out + cd.region_off;
+    L1Rec *__restrict__ out = a.out + cd.region_off;
     const uint64_t cap = cd.region_cap;
     const uint64_t kmask = U64MAX >> (64 - k);
     const uint32_t shift = k - 1;
@@ -881,10 +893,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             if (em) {
                 const uint64_t o = n_out + __popcll(m & lt_mask);
                 if (o < cap) {
-                    pgr_mm128 mm;
-                    mm.x = x;
-                    mm.y = y;
-                    out[o] = mm;
+                    out[o] = l1rec_from_xy(x, y);
                 }
             }
             n_out += __popcll(m);
@@ -923,10 +932,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                     if (emit_on && !draining) {
                         const uint64_t o = n_out + rk;
                         if (o < cap) {
-                            pgr_mm128 mm;
-                            mm.x = x;
-                            mm.y = y;
-                            out[o] = mm;
+                            out[o] = l1rec_from_xy(x, y);
                         }
                     }
                 }
@@ -987,10 +993,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 const uint64_t ex = shfl64(x, iB), ey = shfl64(y, iB);
                 if (emit_on && !draining) {  // the element of a B event sits at the step itself
                     if (lane == 0 && n_out < cap) {
-                        pgr_mm128 mm;
-                        mm.x = ex;
-                        mm.y = ey;
-                        out[n_out] = mm;
+                        out[n_out] = l1rec_from_xy(ex, ey);
                     }
                     n_out += 1;
                 }
@@ -1014,19 +1017,13 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                     if (w0) {
                         const uint64_t o = n_out + __popcll(wm0 & lt_mask);
                         if (o < cap) {
-                            pgr_mm128 mm;
-                            mm.x = x0;
-                            mm.y = y0;
-                            out[o] = mm;
+                            out[o] = l1rec_from_xy(x0, y0);
                         }
                     }
                     if (w1) {
                         const uint64_t o = n_out + n0 + __popcll(wm1 & lt_mask);
                         if (o < cap) {
-                            pgr_mm128 mm;
-                            mm.x = x1;
-                            mm.y = y1;
-                            out[o] = mm;
+                            out[o] = l1rec_from_xy(x1, y1);
                         }
                     }
                     n_out += n0 + n1;
@@ -1058,6 +1055,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         st_out[blockIdx.x] = o_out;
         if (cd.seg != 0xFFFFFFFFu) {
             a.seg_off[cd.seg] = cd.region_off;
+            a.seg_cid[cd.seg] = c;
             if (n_out > cap || n_out > 0xFFFFFFFFull) {
                 stat |= 1u;  // region too small: the host re-runs this chunk with a full-size region
                 a.seg_cnt[cd.seg] = 0;

@@ -2,7 +2,7 @@
 // the two hierarchical reductions (reduce_shmmr, pgr-db/src/shmmrutils.rs:359-415), the min_span
 // stencil (:536-555) and the shimmer-pair records (pgr-db/src/seq_db.rs:381-400, 1205-1217).
 //
-// The level-1 list is ~2.5 % of the positions (16 B each).  It is read ONCE, straight from the unordered
+// The level-1 list is ~2.5 % of the positions (12 B each in HBM: L1Rec).  It is read ONCE, straight from the unordered
 // per-tile segments, by fused_select_kernel (reduce x2 + min_span in LDS); only the survivors (~12 %) are
 // written, ordered by a scan + gather_segments_kernel.  Plain HBM streaming code, no MFMA.
 #include "pgr_device.h"
@@ -10,6 +10,9 @@
 
 #ifndef PGR_ABLATE_L2
 #define PGR_ABLATE_L2 0  // timing experiments only
+#endif
+#ifndef PGR_L2_PACKED
+#define PGR_L2_PACKED 1  // 1: keys in LDS carry a block-local contig ordinal in their top byte (no contig-id reads in the reduce)
 #endif
 
 namespace pgr {
@@ -161,7 +164,9 @@ struct FusedLdsT {
     uint32_t total;
     uint64_t sdst[FUSED_SEGS + 1];  // logical start of the staged segments (+ sentinel)
     uint64_t soff[FUSED_SEGS];      // physical offset
+    uint32_t scid[FUSED_SEGS];      // contig of the segment's records
     uint32_t n_seg;
+    uint32_t wide;  // the block spans more than 254 contigs: the packed keys cannot tell them apart
     unsigned long long base_out;
 };
 
@@ -239,6 +244,41 @@ __device__ __forceinline__ bool reduce_keep_lds(const FusedLds &L, const uint16_
     return a + b + 1 >= r;
 }
 
+// The same predicate on PACKED keys: L.x[e] = ordinal << 56 | hash key, ordinal = contig of the element minus the contig of
+// the block's first element (non-decreasing along the list, at most 254).  A left neighbour of another contig has a
+// smaller ordinal, so its packed key is smaller and "P_n >= P_i" is false by itself; a right neighbour of another
+// contig has a larger ordinal: one compare of the high words against (ordinal_i + 1) << 24 rules it out.  No contig-id
+// reads (6 of the 12 LDS reads per element of the first reduction).  Only without padding.
+template <int TR, class FusedLds>
+__device__ __forceinline__ bool reduce_keep_packed(const FusedLds &L, const uint16_t *list, int n, int k, uint32_t r_rt) {
+    const uint32_t r = TR ? (uint32_t)TR : r_rt;
+    const int e = list ? list[k] : k;
+    const uint64_t pi = L.x[e];
+    const uint32_t lim = (((uint32_t)(pi >> 56)) + 1u) << 24;
+    uint32_t a = 0, b = 0;
+    bool run_a = true, run_b = true;
+#pragma unroll
+    for (uint32_t d = 1; d < (TR ? (uint32_t)TR : 12u); ++d) {
+        if (!TR && d >= r) break;
+        {
+            const int kk = k - (int)d;
+            const bool inside = kk >= 0;
+            const int ee = inside ? (list ? list[kk] : kk) : e;
+            run_a = run_a && inside && L.x[ee] >= pi;
+            a += run_a ? 1u : 0u;
+        }
+        {
+            const int kk = k + (int)d;
+            const bool inside = kk < n;
+            const int ee = inside ? (list ? list[kk] : kk) : e;
+            const uint64_t pn = L.x[ee];
+            run_b = run_b && inside && pn >= pi && (uint32_t)(pn >> 32) < lim;
+            b += run_b ? 1u : 0u;
+        }
+    }
+    return a + b + 1 >= r;
+}
+
 }  // namespace
 
 // FusedArgsPub (pgr_internal.h): l1 = unordered level-1 segments; seg_dst = exclusive scan of seg_cnt
@@ -273,26 +313,53 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     // elements (k = j*256 + t) independently: ~5 outstanding 16-byte loads per lane.
     uint32_t seg0 = a.blk_first_seg[blockIdx.x];
     uint64_t done = lo;  // logical elements below `done` are loaded
+    uint32_t cid0 = 0;   // contig of the block's first element (the first staged segment holds it)
+    bool first_batch = true;
+    if (t == 0) L.wide = 0;
     while (done < hi) {
         if (t < FUSED_SEGS + 1) {
             const uint32_t sg = seg0 + t;
             const uint64_t d = (sg <= a.n_segs) ? a.seg_dst[sg] : total;  // seg_dst[n_segs] = total
             L.sdst[t] = d;
-            if (t < FUSED_SEGS) L.soff[t] = (sg < a.n_segs) ? a.seg_off[sg] : 0;
+            if (t < FUSED_SEGS) {
+                L.soff[t] = (sg < a.n_segs) ? a.seg_off[sg] : 0;
+                L.scid[t] = (sg < a.n_segs) ? a.seg_cid[sg] : 0;
+            }
         }
         __syncthreads();
+        if (first_batch) {
+            cid0 = L.scid[0];
+            first_batch = false;
+        }
         // elements covered by the staged descriptors: [sdst[0], sdst[64]) intersected with [done, hi)
         const uint64_t cover_hi = L.sdst[FUSED_SEGS] < hi ? L.sdst[FUSED_SEGS] : hi;
+        // a lane's elements g, g + 256, ... lie in non-decreasing segments: one binary search for the first, then the
+        // segment index only moves forward (segments hold ~200 elements: 0-2 steps instead of 6 dependent LDS reads)
+        int s_lo = 0;
+        bool first = true;
         for (uint64_t g = done + t; g < cover_hi; g += FUSED_T) {
-            int s_lo = 0, s_hi = FUSED_SEGS;  // largest s with sdst[s] <= g
-            while (s_hi - s_lo > 1) {
-                const int mid = (s_lo + s_hi) >> 1;
-                if (L.sdst[mid] <= g) s_lo = mid;
-                else s_hi = mid;
+            if (first) {
+                int s_hi = FUSED_SEGS;  // largest s with sdst[s] <= g
+                while (s_hi - s_lo > 1) {
+                    const int mid = (s_lo + s_hi) >> 1;
+                    if (L.sdst[mid] <= g) s_lo = mid;
+                    else s_hi = mid;
+                }
+                first = false;
+            } else {
+                while (s_lo + 1 < FUSED_SEGS && L.sdst[s_lo + 1] <= g) ++s_lo;
             }
-            const pgr_mm128 m = a.l1[L.soff[s_lo] + (g - L.sdst[s_lo])];
-            L.x[g - lo] = m.x;
-            L.y[g - lo] = m.y;
+            // 12-byte record -> MM128: x = key << 8 | k, y = contig << 32 | pos << 1 | strand
+            const L1Rec m = a.l1[L.soff[s_lo] + (g - L.sdst[s_lo])];
+            const uint32_t cid = L.scid[s_lo];
+#if PGR_L2_PACKED
+            const uint32_t ord = cid - cid0;
+            if (ord > 254u) L.wide = 1;  // benign race: every writer stores 1
+            L.x[g - lo] = ((uint64_t)(ord & 0xFFu) << 56) | ((uint64_t)m.key_hi << 32) | m.key_lo;
+#else
+            L.x[g - lo] = ((((uint64_t)m.key_hi << 32) | m.key_lo) << 8) | (uint64_t)a.k;
+#endif
+            L.y[g - lo] = ((uint64_t)cid << 32) | m.ypos;
         }
         done = cover_hi > done ? cover_hi : done;
         seg0 += FUSED_SEGS;
@@ -304,6 +371,16 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     if (L.x[t] != 0x1234567ull) {  // load only
         if (t == 0) { a.blk_off[blockIdx.x] = 0; a.blk_cnt[blockIdx.x] = 0; }
         return;
+    }
+#endif
+#if PGR_L2_PACKED
+    // the generic predicate compares contig ids explicitly and the key order is what it needs: it also works on packed
+    // keys EXCEPT that keys of different contigs must not be told apart by the ordinal when the block is wide (ordinals
+    // wrapped) -- there the ordinal byte is cleared again
+    const bool packed = !a.padding && L.wide == 0;
+    if (!packed) {
+        for (int e = (int)t; e < ne; e += FUSED_T) L.x[e] &= 0x00FFFFFFFFFFFFFFull;
+        __syncthreads();
     }
 #endif
     // ---- reduce x2 (shmmrutils.rs:533-535) on index lists, then the min_span stencil (:536-555)
@@ -318,6 +395,12 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
 #pragma unroll
             for (int j = 0; j < FUSED_CMAX; ++j) {
                 const int k = j * FUSED_T + (int)t;
+#if PGR_L2_PACKED
+                if (packed)
+                    keep[j] = (j < C) && k < n_cur &&
+                              (a.r == 4 ? reduce_keep_packed<4, FusedLds>(L, cur, n_cur, k, 4) : reduce_keep_packed<0, FusedLds>(L, cur, n_cur, k, a.r));
+                else
+#endif
                 keep[j] = (j < C) && k < n_cur &&
                           (a.r == 4 ? reduce_keep_lds<4, FusedLds>(L, cur, n_cur, k, 4, a.padding, lo_is_start, hi_is_end)
                                     : reduce_keep_lds<0, FusedLds>(L, cur, n_cur, k, a.r, a.padding, lo_is_start, hi_is_end));
@@ -392,7 +475,11 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
                 const int k = j * FUSED_T + (int)t;
                 const int e = cur ? cur[k] : k;
                 pgr_mm128 m;
+#if PGR_L2_PACKED
+                m.x = (L.x[e] << 8) | (uint64_t)a.k;  // the ordinal byte falls off the top
+#else
                 m.x = L.x[e];
+#endif
                 m.y = L.y[e];
                 a.out[base + rank[j]] = m;
             }

@@ -70,6 +70,14 @@ void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_
                   uint64_t contig0, const uint64_t *d_ids /* NULL: contig0 + index */);
 
 // level1.hip
+// One level-1 minimizer as it crosses HBM between the level-1 kernels and the fused list kernel: 12 bytes instead of a
+// 16-byte MM128.  x = key << 8 | k and the contig id are recomputable by the reader (k from the spec, the contig from
+// the segment the record sits in: seg_cid), so only the 56-bit hash key and pos << 1 | strand travel.
+struct L1Rec {
+    uint32_t key_lo, key_hi;  // hash & (2^56 - 1)
+    uint32_t ypos;            // pos << 1 | strand  (the low word of MM128.y)
+};
+static_assert(sizeof(L1Rec) == 12, "level-1 record");
 struct TileDesc {  // one per tile, written by tile_desc_kernel (saves every workgroup a 10-step dependent search)
     uint64_t word_off;    // first plane word of the contig
     uint32_t len;         // contig length
@@ -102,7 +110,7 @@ struct L1Args {
     const uint32_t *tile_first;  // [n+1] device
     TileDesc *desc;              // [n_tiles] scratch, filled by launch_level1_tiles
     uint32_t w, k, r, tc, sketch;
-    pgr_mm128 *out;              // level-1 segments: [0, n_tiles*slot) fixed tile slots, then the overflow region
+    L1Rec *out;                  // level-1 segments: [0, n_tiles*slot) fixed tile slots, then the overflow region
     uint32_t slot;               // elements per tile slot
     uint64_t ovf_base;           // first element of the overflow region (= n_tiles * slot)
     uint64_t cap;                // capacity of the overflow region (elements)
@@ -110,6 +118,7 @@ struct L1Args {
                                  // palindromic k-mer, bit1: a tile holds a non-ACGT byte (islands of exact tiles needed)
     uint64_t *seg_off;           // [n_tiles + n_contigs]
     uint32_t *seg_cnt;           // [n_tiles + n_contigs]
+    uint32_t *seg_cid;           // [n_tiles + n_contigs] contig of the records of a segment
     uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the exact kernel)
     uint8_t *tile_flags;         // [n_tiles] 1: the tile's extended range holds a palindromic k-mer / non-ACGT byte
 };
@@ -141,9 +150,11 @@ void launch_copy_or_sentinel(hipStream_t st, const pgr_mm128 *in, const uint64_t
 
 constexpr uint32_t FUSED_BLOCK_ELEMS = 1024;
 struct FusedArgsPub {
-    const pgr_mm128 *l1;
+    const L1Rec *l1;
     const uint64_t *seg_off;
     const uint32_t *seg_cnt;
+    const uint32_t *seg_cid;
+    uint32_t k;                // spec.k: x = key << 8 | k
     const uint64_t *seg_dst;
     uint32_t n_segs;
     const uint64_t *total;     // device: number of level-1 elements (= seg_dst[n_segs]); workgroups beyond it exit

@@ -44,13 +44,16 @@ class _AbiPending:
     def __init__(self, xch, out, cap):
         self.xch, self.out, self.cap = xch, out, cap
 
-    def wait(self):
-        """-> (gathered [sum n, 2] in rank order, counts).  Equal counts == cap: a view; otherwise the per-rank slices"""
+    def wait(self, concat=True):
+        """-> (gathered, counts).  concat=True: one [sum n, 2] tensor in rank order (a copy when world > 1);
+        concat=False: the list of per-rank views into the gather buffer -- no copy, what a step loop wants"""
         from ._ffi import lib
         counts = np.zeros(self.xch.world, dtype=np.uint64)
         self.xch.ctx.check(lib().pgr_exchange_wait(self.xch._h, counts.ctypes.data_as(C.POINTER(C.c_uint64))))
         counts = [int(c) for c in counts]
         parts = [self.out[r * self.cap: r * self.cap + c] for r, c in enumerate(counts)]
+        if not concat:
+            return parts, counts
         return (parts[0] if len(parts) == 1 else torch.cat(parts, dim=0)), counts
 
 
@@ -131,7 +134,14 @@ class PendingAllgather:
                 self.out = local.new_empty((world * self.n_max, words))
             self.work = dist.all_gather_into_tensor(self.out, padded, group=group, async_op=True)
 
-    def wait(self):
+    def wait(self, concat=True):
+        if not concat:  # per-rank views (no copy when the counts are equal; the padded buffer is sliced otherwise)
+            if self.work is None:
+                return [], self.counts
+            self.work.wait()
+            if self.out.is_cuda:
+                torch.cuda.current_stream(self.out.device).synchronize()
+            return [self.out[r * self.n_max: r * self.n_max + c] for r, c in enumerate(self.counts)], self.counts
         if self.work is None:
             return self.local.new_zeros((0, self.local.shape[1])), self.counts
         self.work.wait()

@@ -48,6 +48,10 @@ def _worker(rank, world, port, counts, q):
         big = torch.full((world * (max(counts) + 3), exchange.MM_WORDS), -1, dtype=torch.int64)
         g3, c3 = exchange.PendingAllgather(mm, out=big).wait()
         assert c3 == cnts and bool((g3 == out[:, :exchange.MM_WORDS]).all())
+        parts, c5 = exchange.PendingAllgather(mm).wait(concat=False)  # the copy-free form of the step loop
+        assert c5 == cnts and [int(p.shape[0]) for p in parts] == (cnts if max(counts) else [])
+        if max(counts):
+            assert bool((torch.cat(parts, dim=0) == g3).all())
         if max(counts):
             assert g3.data_ptr() == big.data_ptr() or len(set(counts)) > 1  # gathered in place (ragged: re-packed)
             small = torch.empty((1, exchange.MM_WORDS), dtype=torch.int64)
