@@ -36,7 +36,7 @@ struct Tmp_list {  // small RAII device allocation from the context's caching al
 
 static std::string g_create_error;
 
-extern "C" const char *pgr_version(void) { return "pgr-hip 0.1.0 (gfx950)"; }
+extern "C" const char *pgr_version(void) { return "pgr-hip 0.2.0 (gfx950)"; }
 
 extern "C" const char *pgr_last_error(const pgr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
