@@ -25,6 +25,9 @@
 #define PGR_TILE_V2 1  // 1: round-2 instruction selection (strand select from SGPR lane masks, multiplications in the hash,
                        //    window-row minima folded into the prefix chains); 0: the round-1 code, kept for A/B timing
 #endif
+#ifndef PGR_KEY_NOEXP
+#define PGR_KEY_NOEXP PGR_TILE_V2  // 1: window keys are the bare 56-bit hash read as a (possibly denormal) non-negative double
+#endif
 #ifndef PGR_TILE_ATTR
 #define PGR_TILE_ATTR  // experiment hook: e.g. -DPGR_TILE_ATTR='__attribute__((amdgpu_waves_per_eu(4,4)))'
 #endif
@@ -189,6 +192,8 @@ __device__ __forceinline__ void shift_in_mask(uint32_t &acc, uint64_t mask) {
 
 constexpr uint32_t KEY_EXP = 0x40000000u;   // bit 62: keys are positive normal doubles
 constexpr uint32_t KEY_INF = 0x7FE00000u;   // hi word of the "not a k-mer" sentinel (finite, above every key)
+// what a window end outside [jstart, jend] contributes to the max pass: below every key
+constexpr uint64_t NO_WINDOW = PGR_KEY_NOEXP ? 0xFFF0000000000000ull /* -inf */ : 0ull /* +0 */;
 
 }  // namespace
 
@@ -252,7 +257,14 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         asm("" : "+v"(m1x));  // keep the constant out of the hash's first step (the optimiser would distribute it)
         const uint64_t h = u64hash_mad(((uint64_t)m0h << 32) | m0l) ^ u64hash_mad(((uint64_t)m1h << 32) | m1x);
         shift_in_mask(strand_rev, rev);  // position u ends up at bit 15 - u
+#if PGR_KEY_NOEXP
+        // the 56-bit hash itself is a non-negative double (denormal when bits 52-55 are clear: f64 denormals are preserved,
+        // .amdhsa_float_denorm_mode_16_64 3), ordered like the integer: no exponent bit to or in (one 2.4-cycle v_and instead
+        // of a 4.2-cycle v_and_or per position).  "No window" is -inf instead of +0 so that a key of 0 stays exact.
+        const uint64_t key = ((uint64_t)((uint32_t)(h >> 32) & 0x00FFFFFFu) << 32) | (uint32_t)h;
+#else
         const uint64_t key = ((uint64_t)and_or((uint32_t)(h >> 32), 0x00FFFFFFu, KEY_EXP) << 32) | (uint32_t)h;
+#endif
         uint64_t ok_mask = ~0ull;  // lanes whose position u holds a k-mer
         if (MASKED) {
             const uint32_t inval = bit_to_mask(~valid_mask, u);
@@ -373,7 +385,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
                 if (MASKED) {  // window ends outside [jstart, jend] do not select anything: M = +0 (below every key)
                     const uint64_t mb = (uint64_t)__double_as_longlong(m);
                     const uint64_t keep = (uint64_t)(int64_t)(int32_t)bit_to_mask(mwin_mask, u);
-                    M[u] = __longlong_as_double((long long)(mb & keep));
+                    M[u] = __longlong_as_double((long long)((mb & keep) | (~keep & NO_WINDOW)));
                 } else {
                     M[u] = m;
                 }
@@ -403,7 +415,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
                 if (MASKED) {
                     const uint64_t mb = (uint64_t)__double_as_longlong(m);
                     const uint64_t keep = (uint64_t)(int64_t)(int32_t)bit_to_mask(mwin_mask, u);
-                    M[u] = __longlong_as_double((long long)(mb & keep));
+                    M[u] = __longlong_as_double((long long)((mb & keep) | (~keep & NO_WINDOW)));
                 } else {
                     M[u] = m;
                 }
@@ -427,7 +439,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             // E[u] = max(M[u .. u + w - 1]): this lane's suffix from u, w/16 - 1 whole rows (they seed the suffix chain),
             // and the prefix of row t + w/16 through offset u - 1
             constexpr int NB = (TW ? TW : 16) / 16 - 1;
-            double sm = 0.0;
+            double sm = __longlong_as_double((long long)NO_WINDOW);
 #pragma unroll
             for (int i = 1; i <= NB; ++i) {
                 const int ti = (int)t + i;
@@ -445,13 +457,14 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             emit = ~neq & valid_mask & core_mask;
         } else {
             const int re_lo = wm1 >> 4;
-            double acc = 0.0, qlo = 0.0;
+            const double none = __longlong_as_double((long long)NO_WINDOW);
+            double acc = none, qlo = none;
             for (int i = 1; i <= re_lo; ++i) {
                 if (i == re_lo) qlo = acc;
                 const int ti = (int)t + i;
                 acc = dmax(acc, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
             }
-            double sm = 0.0;
+            double sm = none;
             uint32_t neq = 0;  // bit u set iff E[u] < x[u]  (E <= x always: every window minimum is <= x)
 #pragma unroll
             for (int u = L1_G - 1; u >= 0; --u) {
