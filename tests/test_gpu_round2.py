@@ -51,6 +51,38 @@ def test_small_calls_take_the_optimistic_path_and_stay_exact(oracle, gpu_ctx):
         assert _same(oracle.sequence_to_shmmrs(0, seqs[0], oracle.spec(*sp_t)), got[0])
 
 
+def test_large_batch_with_islands_is_exact(oracle, gpu_ctx):
+    """>= 64 Mbp: the pipeline looks at the level-1 flags once before the list stage; non-ACGT bytes (single N, a 300 kbp N
+    run), palindromic (AT)n and a homopolymer stretch turn tiles into islands of the exact state machine, everything else
+    stays on the closed-form tiles.  All contigs compared with the checker (128-bit checksums + counts)."""
+    import pgrtk_amd as P
+    n, L = 8, 10_000_000
+    seqs = []
+    for i in range(n):
+        s = oracle.synth_contig(9, i, L).copy()
+        if i != 3:
+            s[1234567 + i] = ord("N")
+        if i % 4 == 0:
+            s[5_000_000:5_300_000] = ord("N")
+        if i == 2:
+            s[7_000_000:7_000_200] = np.frombuffer(b"AT" * 100, dtype=np.uint8)
+        if i == 5:
+            s[2_000_000:2_050_000] = ord("C")
+        seqs.append(s)
+    b = P.Batch.from_seqs(seqs, ctx=gpu_ctx)
+    sh = b.shmmrs(P.make_spec())
+    prof = gpu_ctx.last_prof()
+    assert prof.n_serial_contigs == 7 and 0 < prof.exact_bases < 0.2 * n * L  # islands, not whole contigs (contig 3 is clean)
+    sums, off = sh.checksum(), sh.offsets()
+    osp = oracle.spec()
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(8) as pool:
+        refs = list(pool.map(lambda i: oracle.sequence_to_shmmrs(i, seqs[i], osp), range(n)))
+    for i in range(n):
+        assert int(off[i + 1] - off[i]) == len(refs[i]), i
+        assert np.array_equal(sums[i], oracle.shmmr_checksum(refs[i])), i
+
+
 def test_shmmrs_checksum_matches_the_checker(oracle, gpu_ctx):
     import pgrtk_amd as P
     lens = [300_000, 0, 5_000, 1_000_000, 80]
