@@ -99,4 +99,16 @@ inline std::vector<SeqRec> read_fastx(const std::string &path) {
     return out;
 }
 
+// Path::with_extension of the output prefix (pgr-query.rs:291-302): an extension the prefix's file name already carries
+// is REPLACED ("out.v1" -> "out.000.hit"); a leading dot alone is not an extension (".out" -> ".out.000.hit")
+inline std::string with_extension(const std::string &prefix, const std::string &ext) {
+    const size_t sl = prefix.find_last_of('/');
+    const size_t name0 = sl == std::string::npos ? 0 : sl + 1;
+    const std::string name = prefix.substr(name0);
+    if (name.empty() || name == "..") return prefix;  // no file name: set_extension leaves the path alone
+    const size_t dot = name.find_last_of('.');
+    const std::string base = (dot == std::string::npos || dot == 0) ? prefix : prefix.substr(0, name0 + dot);
+    return base + "." + ext;
+}
+
 }  // namespace pgrhost

@@ -74,6 +74,8 @@ static std::string f32s(float v) {  // Rust `{}` of an f32: shortest round-trip,
     return std::string(b, r.ptr);
 }
 
+using pgrhost::with_extension;
+
 int main(int argc, char **argv) {
     pgr_spec spec = {48, 56, 4, 12, 0};
     uint32_t min_cov = 0, min_branch = 8;
@@ -201,7 +203,7 @@ int main(int argc, char **argv) {
     for (size_t i = 0; i < order.size(); ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return ctgs[a].name < ctgs[b].name; });
 
-    FILE *bed = fopen((pos[1] + ".bed").c_str(), "w"), *sum = fopen((pos[1] + ".ctg.summary.tsv").c_str(), "w");
+    FILE *bed = fopen(with_extension(pos[1], "bed").c_str(), "w"), *sum = fopen(with_extension(pos[1], "ctg.summary.tsv").c_str(), "w");
     if (!bed || !sum) {
         fprintf(stderr, "pgr-pbundle-decomp: can't write the outputs\n");
         return 1;

@@ -66,6 +66,8 @@ static std::string stem(const std::string &path) {  // basename without its last
     return b;
 }
 
+using pgrhost::with_extension;
+
 int main(int argc, char **argv) {
     pgr_spec spec = {80, 56, 4, 64, 0};
     float gap_penalty = 0.025f;
@@ -207,10 +209,10 @@ int main(int argc, char **argv) {
             regions[sid] = std::move(merged);
         }
         char ext[32];
-        snprintf(ext, sizeof ext, bed_summary ? ".%03zu.hit.bed" : ".%03zu.hit", qi);
-        FILE *hit = fopen((pos[2] + ext).c_str(), "w");
+        snprintf(ext, sizeof ext, bed_summary ? "%03zu.hit.bed" : "%03zu.hit", qi);
+        FILE *hit = fopen(with_extension(pos[2], ext).c_str(), "w");
         if (!hit) {
-            fprintf(stderr, "pgr-query: can't write %s%s\n", pos[2].c_str(), ext);
+            fprintf(stderr, "pgr-query: can't write %s\n", with_extension(pos[2], ext).c_str());
             return 1;
         }
         if (bed_summary)
@@ -244,8 +246,8 @@ int main(int argc, char **argv) {
         fclose(hit);
         if (fastx_file && !only_summary) {
             char fe[32];
-            snprintf(fe, sizeof fe, ".%03zu.fa", qi);
-            FILE *f = fopen((pos[2] + fe).c_str(), "w");
+            snprintf(fe, sizeof fe, "%03zu.fa", qi);
+            FILE *f = fopen(with_extension(pos[2], fe).c_str(), "w");
             if (!f) return 1;
             for (const Fa &x : fa) {
                 const std::string &s = db_seqs[x.sid].seq;

@@ -30,6 +30,19 @@ for _a, _b in zip(b"ACGTacgtNn", b"TGCAtgcaNn"):
     _COMP[_a] = _b
 
 
+def with_extension(prefix, ext):
+    """Rust Path::with_extension, which is how every reference CLI derives its output names from <output_prefix>
+    (pgr-query.rs:291-302, pgr-pbundle-decomp.rs:294-359): an extension the prefix's file name already carries is
+    replaced ("out.v1" -> "out.000.hit"); a leading dot alone is not an extension."""
+    head, name = os.path.split(prefix)
+    if name in ("", ".."):
+        return prefix
+    dot = name.rfind(".")
+    if dot > 0:
+        name = name[:dot]
+    return os.path.join(head, name + "." + ext)
+
+
 def reverse_complement(seq):
     """pgr-db/src/fasta_io.rs:26-44"""
     return _COMP[np.frombuffer(seq, dtype=np.uint8)][::-1].tobytes()
@@ -126,7 +139,7 @@ def cmd_query(args):
         regions = chains_to_regions(qr, args.merge_range_tol)
         ext = "%03d.hit.bed" % idx if args.bed_summary else "%03d.hit" % idx
         fa_recs = []
-        with open(args.output_prefix + "." + ext, "w") as hit:
+        with open(with_extension(args.output_prefix, ext), "w") as hit:
             if args.bed_summary:
                 hit.write("#" + "\t".join(["target", "bgn", "end", "query", "color", "orientation", "q_len",
                                            "aln_anchor_count", "q_idx", "src", "ctg_bgn", "ctg_end"]) + "\n")
@@ -149,7 +162,7 @@ def cmd_query(args):
                                                              ctg, b, e, orientation, tname]) + "\n")
                     fa_recs.append((sid, b, e, orientation, tname))
         if seqs_by_sid is not None:
-            with open(args.output_prefix + ".%03d.fa" % idx, "w") as fa:
+            with open(with_extension(args.output_prefix, "%03d.fa" % idx), "w") as fa:
                 for sid, b, e, orientation, tname in fa_recs:
                     t = seqs_by_sid[sid][b:e]
                     if orientation == 1:
@@ -266,7 +279,7 @@ def cmd_pbundle_decomp(args):
         # every bundle vertex is a shimmer pair of <fastx_path>'s own sequences, so the vertex map
         # (get_vertex_map_from_principal_bundles, ext.rs:512-531) is exactly the annotation of their pairs
         vmap = {(smp[0], smp[1]): info for _, smps in dec for smp, info in smps if info is not None}
-        pdb.write_pdb(args.output_prefix + ".pdb", args.w, args.k, args.r, args.min_span, args.min_branch_size, args.min_cov,
+        pdb.write_pdb(with_extension(args.output_prefix, "pdb"), args.w, args.k, args.r, args.min_span, args.min_branch_size, args.min_cov,
                       bundles, vmap)  # rs:357-383
     if args.decomp_fastx_path or args.include or dec is None:
         # decomposition of other sequences with that vertex map (rs:247-292 + ext.rs:976-1014)
@@ -283,11 +296,11 @@ def cmd_pbundle_decomp(args):
             dec.append((i, [(v, vmap.get((v[0], v[1]))) for v in smps]))
     names = {sid: v[0] for sid, v in seq_info.items()}
     parts = pbundle_partitions(names, dec, args.bundle_length_cutoff, args.bundle_merge_distance)
-    with open(args.output_prefix + ".bed", "w") as f:
+    with open(with_extension(args.output_prefix, "bed"), "w") as f:
         f.write("# cmd: %s\n" % " ".join(sys.argv))
         for line in pbundle_bed_lines(names, dec, bundles, args.k, args.bundle_length_cutoff, args.bundle_merge_distance):
             f.write(line + "\n")
-    with open(args.output_prefix + ".ctg.summary.tsv", "w") as f:
+    with open(with_extension(args.output_prefix, "ctg.summary.tsv"), "w") as f:
         for line in pbundle_summary_lines(seq_info, parts, args.k):
             f.write(line + "\n")
     print("%d sequences, %d principal bundles -> %s.bed / .ctg.summary.tsv" % (len(seq_info), len(bundles),

@@ -102,3 +102,13 @@ def test_pdb_bincode_varint_kat():
             + bytes([3, 0]) + b"\xfb\x2c\x01")                                  # (bundle 3, direction 0, position 300)
     assert got == want
     assert pdb.decode(got) == (48, 56, 4, 12, 8, 0, bundles, vmap)
+
+
+def test_output_names_follow_path_with_extension():
+    """pgr-query.rs:291-302 / pgr-pbundle-decomp.rs:294-359 build every output name with Path::with_extension(prefix)"""
+    from pgrtk_amd.cli import with_extension as w
+    assert w("out", "000.hit") == "out.000.hit"
+    assert w("out.v1", "000.hit") == "out.000.hit"          # an existing extension is replaced
+    assert w("dir.x/out", "bed") == "dir.x/out.bed"          # dots in directories do not count
+    assert w(".out", "pdb") == ".out.pdb"                    # a leading dot is not an extension
+    assert w("a/.out.b", "ctg.summary.tsv") == "a/.out.ctg.summary.tsv"
