@@ -627,7 +627,12 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     memset(&prof, 0, sizeof(prof));
     prof.n_tiles = n_tiles;
     prof.bases_tiled = bases_tiled;
-    const bool early_sync = b->total_bases >= (64ull << 20) || !serial.empty();
+    // big batches look at the level-1 status words once before the list stage is enqueued (one more round trip, ~45 us):
+    // if a tile asked for the exact path the islands are fixed first and the list stage runs once.  Smaller batches run
+    // optimistically and repeat stages 2-4 in the (rare) flagged case: cheaper than the round trip below ~1 Gbp.
+    uint64_t early_bp = 1ull << 30;
+    if (const char *e = getenv("PGR_EARLY_SYNC_BP")) early_bp = strtoull(e, nullptr, 10);
+    const bool early_sync = b->total_bases >= early_bp || !serial.empty();
     const bool pad_fix = padding && !sketch && spec->r > 1;
     const bool do_reduce = !sketch && spec->r > 1;
     const uint32_t halo = do_reduce ? 2 * spec->r * spec->r : 1;

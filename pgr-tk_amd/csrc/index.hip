@@ -85,6 +85,24 @@ __global__ __launch_bounds__(256) void sid_bound_kernel(const pgr_frag_rec *__re
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// lut[b] = first key whose bucket is >= b (b = 2^bits: n_keys); one thread per bucket
+__global__ void build_lut_kernel(const pgr_frag_rec *__restrict__ recs, const uint64_t *__restrict__ key_off, uint64_t n_keys,
+                                 uint32_t bits, uint32_t shift, uint32_t *__restrict__ lut) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nb = 1ull << bits;
+    if (b > nb) return;
+    uint64_t lo = 0, hi = n_keys;
+    if (b == nb) lo = n_keys;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        const uint64_t h0 = recs[key_off[mid]].h0;
+        const uint64_t bk = (h0 >> shift) < nb - 1 ? (h0 >> shift) : nb - 1;
+        if (bk < b) lo = mid + 1;
+        else hi = mid;
+    }
+    lut[b] = (uint32_t)lo;
+}
+
 __global__ void scatter_starts_kernel(const uint32_t *__restrict__ flags, const uint64_t *__restrict__ rank, uint64_t n,
                                       uint64_t *__restrict__ starts) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -165,6 +183,7 @@ extern "C" void pgr_index_destroy(pgr_index *ix) {
     ix->ctx->dfree(ix->raw);
     ix->ctx->dfree(ix->recs);
     ix->ctx->dfree(ix->key_off);
+    ix->ctx->dfree(ix->lut);
     delete ix;
 }
 
@@ -310,8 +329,10 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "index holds more than 2^32-1 records per GPU");
     ctx->dfree(ix->recs);
     ctx->dfree(ix->key_off);
+    ctx->dfree(ix->lut);
     ix->recs = nullptr;
     ix->key_off = nullptr;
+    ix->lut = nullptr;
     ix->n = n;
     ix->n_keys = 0;
     int rc;
@@ -352,9 +373,25 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     if ((rc = ctx->dmalloc((void **)&ix->key_off, (n_keys + 1) * sizeof(uint64_t)))) return rc;
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(),
                        rank.as<uint64_t>(), n, ix->key_off);
+    ix->n_keys = n_keys;
+    // bucket table for the lookups (indexes of >= 4096 keys): ~4 keys per bucket on average, scaled to the key at the
+    // 99th percentile (the rest shares the last bucket)
+    if (n_keys >= 4096) {
+        uint64_t k99 = 0, h99 = 0;
+        PGR_HIP(ctx, hipMemcpyAsync(&k99, ix->key_off + (n_keys - 1 - n_keys / 100), 8, hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        PGR_HIP(ctx, hipMemcpyAsync(&h99, &ix->recs[k99].h0, 8, hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        const unsigned bits = std::min(22u, std::max(4u, bits_for(n_keys) - 2));
+        const unsigned hb = bits_for(h99 + 1);  // bits of the largest bucketed h0
+        ix->lut_bits = bits;
+        ix->lut_shift = hb > bits ? hb - bits : 0;
+        if ((rc = ctx->dmalloc((void **)&ix->lut, ((1ull << bits) + 1) * sizeof(uint32_t)))) return rc;
+        hipLaunchKernelGGL(build_lut_kernel, grid_for((1ull << bits) + 1), dim3(256), 0, st, ix->recs, ix->key_off, n_keys, bits,
+                           ix->lut_shift, ix->lut);
+    }
     PGR_HIP(ctx, hipStreamSynchronize(st));
     PGR_HIP(ctx, hipGetLastError());
-    ix->n_keys = n_keys;
     ix->finalized = true;
     return PGR_OK;
 }
@@ -381,14 +418,23 @@ extern "C" int pgr_index_download(pgr_ctx *ctx, const pgr_index *ix, pgr_frag_re
 // query path
 namespace {
 
-// raw_query_fragment lookup: [lo, hi) = records of the query pair's key (empty when absent)
+// raw_query_fragment lookup: [lo, hi) = records of the query pair's key (empty when absent).  Keys are window minima of a
+// hash: nearly all of them lie in the lowest few percent of the 56-bit range, where the bucket table (pgr_index.h) cuts
+// the binary search over all keys (25 dependent steps of two loads for 3x10^7 keys) down to the few keys of one bucket.
 __global__ void lookup_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, const pgr_frag_rec *__restrict__ recs,
-                              const uint64_t *__restrict__ key_off, uint64_t n_keys, uint64_t *__restrict__ lo_out,
+                              const uint64_t *__restrict__ key_off, uint64_t n_keys, const uint32_t *__restrict__ lut,
+                              uint32_t lut_bits, uint32_t lut_shift, uint64_t *__restrict__ lo_out,
                               uint64_t *__restrict__ hi_out) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nq) return;
     const uint64_t h0 = q[p].h0, h1 = q[p].h1;
     uint64_t lo = 0, hi = n_keys;  // first key >= (h0,h1)
+    if (lut) {
+        const uint64_t top = (1ull << lut_bits) - 1;
+        const uint64_t bk = (h0 >> lut_shift) < top ? (h0 >> lut_shift) : top;
+        lo = lut[bk];
+        hi = lut[bk + 1];
+    }
     while (lo < hi) {
         const uint64_t mid = (lo + hi) >> 1;
         const pgr_frag_rec &r = recs[key_off[mid]];
@@ -520,6 +566,71 @@ __global__ void gather_hits_kernel(const uint64_t *__restrict__ hit_key, const p
     flags[i] = (i == 0 || hit_key[idx[i - 1]] != k) ? 1u : 0u;
 }
 
+// ---- grouping of the hits of the query path without a global sort.  hits_kernel emits the hits pair by pair, so the hits
+// of one query are contiguous ([q_hit_lo(q), q_hit_lo(q+1)) = hit_off[pair_off[q] ..]) and in query-position order; the
+// group key is (query, target sid): a STABLE sort by sid inside every query's segment is the whole job (aln.rs:21 wants the
+// hits of a group in ascending query bgn = the order they already have).  One wavefront per query, ranks by counting in
+// LDS (O(m^2 / 64) per query of m hits: m is a few dozen to a few thousand).  Queries with more hits than SEG_SORT_MAX
+// send the batch to the global radix sort instead (the host knows the maximum from query_hit_max_kernel).
+constexpr uint32_t SEG_SORT_MAX = 4096;
+
+__global__ void query_hit_max_kernel(const uint64_t *__restrict__ pair_off, const uint64_t *__restrict__ hit_off,
+                                     uint32_t n_queries, unsigned long long *__restrict__ out_max) {
+    const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t m = 0;
+    if (q < n_queries) m = hit_off[pair_off[q + 1]] - hit_off[pair_off[q]];
+    for (int off = 32; off; off >>= 1) {
+        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out_max, (unsigned long long)m);
+}
+
+// blockDim.x = 64 (queries of up to a few hundred hits: one wavefront each) or 256 (longer ones)
+__global__ __launch_bounds__(256) void group_sort_kernel(const uint64_t *__restrict__ hit_key, const pgr_hitpair *__restrict__ hp,
+                                                         const uint64_t *__restrict__ pair_off,
+                                                         const uint64_t *__restrict__ hit_off, uint64_t n,
+                                                         uint64_t *__restrict__ key_out, pgr_hitpair *__restrict__ hp_out,
+                                                         uint32_t *__restrict__ flags) {
+    __shared__ __attribute__((aligned(16))) uint32_t sid[SEG_SORT_MAX];
+    __shared__ uint32_t srt[SEG_SORT_MAX];
+    const uint32_t q = blockIdx.x, t = threadIdx.x, T = blockDim.x;
+    if (q == 0 && t == 0) flags[n] = 0;  // sentinel of the scan over the group starts
+    const uint64_t s = hit_off[pair_off[q]];
+    const uint32_t m = (uint32_t)(hit_off[pair_off[q + 1]] - s);
+    if (m == 0 || m > SEG_SORT_MAX) return;  // (m > SEG_SORT_MAX: the host does not take this path)
+    for (uint32_t i = t; i < m; i += T) sid[i] = (uint32_t)hit_key[s + i];
+    __syncthreads();
+    for (uint32_t i0 = 0; i0 < m; i0 += T) {
+        const uint32_t i = i0 + t;
+        const uint32_t mine = i < m ? sid[i] : 0xFFFFFFFFu;
+        uint32_t rank = 0;
+        // elements before the block of i count when <=, elements behind it when <, the block itself with the index
+        // compare (all lanes read the same LDS words: broadcasts, four words per read where the range is aligned)
+        const uint32_t split = i0 + T < m ? i0 + T : m;
+        const uint4 *s4 = reinterpret_cast<const uint4 *>(sid);
+        for (uint32_t j = 0; j < i0 / 4; ++j) {  // i0 is a multiple of 64
+            const uint4 v = s4[j];
+            rank += (v.x <= mine ? 1u : 0u) + (v.y <= mine ? 1u : 0u) + (v.z <= mine ? 1u : 0u) + (v.w <= mine ? 1u : 0u);
+        }
+        for (uint32_t j = i0; j < split; ++j) rank += (sid[j] < mine || (sid[j] == mine && j < i)) ? 1u : 0u;
+        uint32_t j = split;
+        if (split == i0 + T)  // aligned: full groups of four first
+            for (; j + 4 <= m; j += 4) {
+                const uint4 v = s4[j / 4];
+                rank += (v.x < mine ? 1u : 0u) + (v.y < mine ? 1u : 0u) + (v.z < mine ? 1u : 0u) + (v.w < mine ? 1u : 0u);
+            }
+        for (; j < m; ++j) rank += sid[j] < mine ? 1u : 0u;
+        if (i < m) {
+            srt[rank] = mine;
+            key_out[s + rank] = hit_key[s + i];
+            hp_out[s + rank] = hp[s + i];
+        }
+    }
+    __syncthreads();
+    for (uint32_t r = t; r < m; r += T) flags[s + r] = (r == 0 || srt[r - 1] != srt[r]) ? 1u : 0u;
+}
+
 struct AlnParams {
     uint32_t max_span;
     float penalty;
@@ -537,54 +648,19 @@ __device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair 
 __device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
 
 constexpr uint32_t MAX_SPAN_CAP = 64;
-constexpr int ALN_WAVE_MIN = 16;    // groups with at least this many hits are chained by a whole wavefront
+constexpr int ALN_WAVE_MIN = 64;    // groups with at least this many hits are chained by a whole wavefront
 constexpr int ALN_LDS_SMALL = 256;  // ... in a 9 KB LDS image (many workgroups per CU) up to this many hits,
 constexpr int ALN_LDS_MAX = 3584;   // in a 129 KB image up to this many (36 B per hit), in global memory above
+constexpr int ALN_ROW_LDS = 2048;   // hits of the (short) groups of one wavefront of sparse_aln_kernel staged in LDS
 
-// aln::sparse_aln (aln.rs:12-142), one thread per (query, target) group.  The hits of a group are
-// already stably sorted by query bgn (aln.rs:21).  v_s / best_pre_v are FxHashMaps keyed by the
-// HitPair VALUE in the reference, so identical hit pairs share one slot: slot[i] = first index with
-// the same value.  Tie-break of the chain extraction (FxHashSet order in the reference, unspecified):
-// lowest sorted index.  Outputs are written into the group's own range [gs, gs+n).
-__global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start,
-                                  const uint64_t *__restrict__ n_groups_ptr, AlnParams prm, float *__restrict__ v_s, int *__restrict__ pre,
-                                  int *__restrict__ slot, pgr_hitpair *__restrict__ out_hp,
-                                  uint32_t *__restrict__ chain_len, float *__restrict__ chain_score,
-                                  uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
-                                  uint32_t *__restrict__ err, uint32_t *__restrict__ big_list,
-                                  uint32_t *__restrict__ n_big, uint32_t cls_stride,
-                                  uint32_t *__restrict__ span_buf /* max_span > MAX_SPAN_CAP: 3 words per hit */) {
-    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    // (no early return before the ballots below: every lane of the wave takes part in them)
-    const bool live = g < *n_groups_ptr;  // the grid is sized by the number of hits (an upper bound known without a round trip)
-    const uint64_t gs = live ? g_start[g] : 0;
-    const int n = live ? (int)(g_start[g + 1] - gs) : 0;
-    if (live) {
-        g_nchains[g] = 0;
-        g_nhp[g] = 0;
-    }
-    // max_span above the LDS span set of the wave kernel (aln.rs:91 accepts any value): every group stays on this
-    // one-thread path with its span set in global memory -- a span set never holds more entries than the group has hits
-    // groups of >= ALN_WAVE_MIN hits: one wavefront each (sparse_aln_wave_kernel), two size classes.  The list slots are
-    // claimed with ONE atomic per wavefront and class (a batch of 10 000 queries has 10 000 such groups; same-address
-    // atomics run at ~88 per us on gfx950)
-    const bool to_wave = n >= ALN_WAVE_MIN && span_buf == nullptr;
-    const int cls = n > ALN_LDS_SMALL ? 1 : 0;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        const uint64_t m = __ballot(to_wave && cls == c);
-        if (m == 0) continue;
-        const uint32_t lane = threadIdx.x & 63;
-        uint32_t base = 0;
-        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n_big + c, (uint32_t)__popcll(m));
-        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
-        if (to_wave && cls == c) big_list[(size_t)c * cls_stride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)g;
-    }
-    if (to_wave || n < 2) return;  // n < 2: aln.rs:234, targets with a single hit are dropped (and lanes beyond the last group)
-    const pgr_hitpair *h = hp + gs;
-    float *vs = v_s + gs;
-    int *pv = pre + gs;
-    int *sl = slot + gs;
+// The dynamic programme of aln::sparse_aln (aln.rs:25-103) for one group, run by ONE thread.  h / vs / pv / sl are the
+// group's hits and work arrays -- in LDS for the short groups of the query path, in global memory otherwise (generic
+// pointers).  span[] is the span set of the current look-back (aln.rs:70, :91) as a list of candidate INDICES: the
+// candidates come in descending index = non-increasing query bgn order, so an interval that is already in the set can only
+// sit in the trailing entries with the same bgn.
+template <class IdxT>
+__device__ __forceinline__ void aln_dp_thread(const pgr_hitpair *h, int n, float *vs, int *pv, int *sl, IdxT *span,
+                                              const AlnParams &prm) {
     for (int i = 0; i < n; ++i) {
         int s = i;
         for (int j = i - 1; j >= 0 && h[j].qb == h[i].qb; --j)
@@ -596,10 +672,9 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
     }
     vs[sl[0]] = (float)h[0].qe - (float)h[0].qb;  // aln.rs:25-27
     pv[sl[0]] = -1;
-    uint32_t span_loc[MAX_SPAN_CAP][3];
-    uint32_t(*span_q)[3] = span_buf ? reinterpret_cast<uint32_t(*)[3]>(span_buf + 3 * gs) : span_loc;
     for (int i = 1; i < n; ++i) {  // aln.rs:29-103
         const pgr_hitpair cur = h[i];
+        const float cur_len = (float)cur.qe - (float)cur.qb;
         int best_v = -1;
         float best_s = 0.0f;
         uint32_t span_n = 0;
@@ -616,35 +691,114 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
             }
             if (same_q(p, cur)) continue;  // :67
             bool found = false;            // :70
-            for (uint32_t t = 0; t < span_n; ++t)
-                if (span_q[t][0] == p.qb && span_q[t][1] == p.qe && span_q[t][2] == p.qo) {
+            for (int t = (int)span_n - 1; t >= 0; --t) {
+                const pgr_hitpair e = h[span[t]];
+                if (e.qb != p.qb) break;
+                if (e.qe == p.qe && e.qo == p.qo) {
                     found = true;
                     break;
                 }
-            if (!found) {
-                span_q[span_n][0] = p.qb;
-                span_q[span_n][1] = p.qe;
-                span_q[span_n][2] = p.qo;
-                ++span_n;
             }
-            const float p_s = vs[sl[j]];                             // :71
-            float s = p_s + ((float)cur.qe - (float)cur.qb);         // :72
-            const float sum = a + b;                                 // :74-84
+            if (!found) span[span_n++] = (IdxT)j;
+            const int slj = sl[j];
+            const float p_s = vs[slj];      // :71
+            float s = p_s + cur_len;        // :72
+            const float sum = a + b;        // :74-84
             const float pen = prm.penalty * sum;
             s = s - pen;
             if (s > best_s) {  // :86-89
                 best_s = s;
-                best_v = sl[j];
+                best_v = slj;
             }
             if (span_n >= prm.max_span) break;  // :91
         }
+        const int si = sl[i];
         if (best_s > 0.0f) {  // :96-102
-            vs[sl[i]] = best_s;
-            pv[sl[i]] = best_v;
+            vs[si] = best_s;
+            pv[si] = best_v;
         } else {
-            vs[sl[i]] = (float)cur.qe - (float)cur.qb;
-            pv[sl[i]] = -1;
+            vs[si] = cur_len;
+            pv[si] = -1;
         }
+    }
+}
+
+// aln::sparse_aln (aln.rs:12-142), one thread per (query, target) group.  The hits of a group are
+// already stably sorted by query bgn (aln.rs:21).  v_s / best_pre_v are FxHashMaps keyed by the
+// HitPair VALUE in the reference, so identical hit pairs share one slot: slot[i] = first index with
+// the same value.  Tie-break of the chain extraction (FxHashSet order in the reference, unspecified):
+// lowest sorted index.  Outputs are written into the group's own range [gs, gs+n).
+// Groups of fewer than ALN_WAVE_MIN hits (nearly all groups of a query batch) are chained here, their hits and work arrays
+// staged in LDS: 64 independent serial programmes per wavefront cost ~60x fewer instructions than a wavefront per group,
+// and LDS keeps the dependent accesses at ~100 cycles.  Longer groups go to sparse_aln_wave_kernel.
+struct AlnRowLds {
+    pgr_hitpair h[ALN_ROW_LDS];
+    float vs[ALN_ROW_LDS];
+    int sl[ALN_ROW_LDS];
+    int pv[ALN_ROW_LDS];
+    uint8_t span[64][ALN_WAVE_MIN];
+};
+
+__global__ __launch_bounds__(64) void sparse_aln_kernel(
+    const pgr_hitpair *__restrict__ hp, const uint64_t *__restrict__ g_start, const uint64_t *__restrict__ n_groups_ptr,
+    AlnParams prm, float *v_s, int *pre, int *slot, pgr_hitpair *__restrict__ out_hp, uint32_t *__restrict__ chain_len,
+    float *__restrict__ chain_score, uint32_t *__restrict__ g_nchains, uint32_t *__restrict__ g_nhp,
+    uint32_t *__restrict__ err, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big, uint32_t cls_stride,
+    uint32_t *__restrict__ span_buf /* max_span > MAX_SPAN_CAP: one word per hit */) {
+    __shared__ AlnRowLds L;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // (no early return before the ballots below: every lane of the wave takes part in them)
+    const bool live = g < *n_groups_ptr;  // the grid is sized by the number of hits (an upper bound known without a round trip)
+    const uint64_t gs = live ? g_start[g] : 0;
+    const int n = live ? (int)(g_start[g + 1] - gs) : 0;
+    if (live) {
+        g_nchains[g] = 0;
+        g_nhp[g] = 0;
+    }
+    // max_span above the LDS span set of the wave kernel (aln.rs:91 accepts any value): every group stays on this
+    // one-thread path with its span set in global memory -- a span set never holds more entries than the group has hits
+    // groups of >= ALN_WAVE_MIN hits: one wavefront each (sparse_aln_wave_kernel), two size classes.  The list slots are
+    // claimed with ONE atomic per wavefront and class (same-address atomics run at ~88 per us on gfx950)
+    const bool to_wave = n >= ALN_WAVE_MIN && span_buf == nullptr;
+    const int cls = n > ALN_LDS_SMALL ? 1 : 0;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const uint64_t m = __ballot(to_wave && cls == c);
+        if (m == 0) continue;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(n_big + c, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (to_wave && cls == c) big_list[(size_t)c * cls_stride + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)g;
+    }
+    const bool mine = !to_wave && n >= 2;  // n < 2: aln.rs:234, targets with a single hit are dropped (and lanes beyond the last group)
+    if (__ballot(mine) == 0) return;
+    // LDS placement of the short groups of this wavefront (exclusive prefix sum of their sizes over the lanes)
+    const uint32_t want = (mine && n < ALN_WAVE_MIN) ? (uint32_t)n : 0u;
+    const uint32_t lds_base = wave_incl_sum(want) - want;
+    const bool in_lds = want != 0 && lds_base + want <= (uint32_t)ALN_ROW_LDS;
+    const uint64_t stage = __ballot(in_lds);
+    for (uint64_t m = stage; m; m &= m - 1) {  // coalesced copies, one staged group per step
+        const int src = __builtin_ctzll(m);
+        const uint64_t gs_l = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gs >> 32), src) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gs, src);
+        const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane(n, src);
+        const uint32_t b_l = (uint32_t)__builtin_amdgcn_readlane((int)lds_base, src);
+        if (lane < n_l) L.h[b_l + lane] = hp[gs_l + lane];
+    }
+    __syncthreads();
+    if (!mine) return;
+    const pgr_hitpair *h = in_lds ? &L.h[lds_base] : hp + gs;
+    float *vs = in_lds ? &L.vs[lds_base] : v_s + gs;
+    int *pv = in_lds ? &L.pv[lds_base] : pre + gs;
+    int *sl = in_lds ? &L.sl[lds_base] : slot + gs;
+    if (in_lds) {
+        aln_dp_thread<uint8_t>(h, n, vs, pv, sl, L.span[lane], prm);
+    } else if (span_buf) {
+        aln_dp_thread<uint32_t>(h, n, vs, pv, sl, span_buf + gs, prm);
+    } else {
+        uint32_t span_loc[MAX_SPAN_CAP];
+        aln_dp_thread<uint32_t>(h, n, vs, pv, sl, span_loc, prm);
     }
     // extraction (aln.rs:105-140).  A visited value-slot is marked by sl[v] = -1 - v (the DP is done,
     // so sl is free to carry the flag); unvisited representatives have sl[i] == i.
@@ -665,8 +819,7 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
         }
         uint32_t len = 0;
         int v = best_v, first_v = best_v;
-        while (v >= 0 && sl[v] == v) {  // :121-128
-            out_hp[gs + n_out + len] = h[v];
+        while (v >= 0 && sl[v] == v) {  // :121-128 (collected back to front, written in chain order below)
             ++len;
             first_v = v;
             const int nv = pv[v];
@@ -674,10 +827,12 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
             --n_unvisited;
             v = nv;
         }
-        for (uint32_t a = 0, b = len - 1; a < b; ++a, --b) {  // :132 reverse
-            const pgr_hitpair t = out_hp[gs + n_out + a];
-            out_hp[gs + n_out + a] = out_hp[gs + n_out + b];
-            out_hp[gs + n_out + b] = t;
+        // :132 reverse: the walk went from the chain's end to its start; pv links are still intact, walk again and
+        // store from the back
+        v = best_v;
+        for (uint32_t a = 0; a < len; ++a) {
+            out_hp[gs + n_out + (len - 1 - a)] = h[v];
+            v = pv[v];
         }
         chain_len[gs + n_ch] = len;
         chain_score[gs + n_ch] = best_s - vs[first_v];  // :138-139
@@ -687,7 +842,6 @@ __global__ void sparse_aln_kernel(const pgr_hitpair *__restrict__ hp, const uint
     g_nchains[g] = n_ch;
     g_nhp[g] = n_out;
 }
-
 
 // ------------------------------------------------------------------------------------------------
 // sparse_aln for ONE long group per wavefront.  Same recurrence, same f32 operation order and the same tie
@@ -1013,8 +1167,15 @@ __global__ void pack_chains_kernel(const uint64_t *__restrict__ g_start, uint64_
                                    const uint64_t *__restrict__ chain_off, const uint64_t *__restrict__ hp_off,
                                    const uint32_t *__restrict__ c_len, const float *__restrict__ c_score,
                                    const pgr_hitpair *__restrict__ o_hp, uint32_t *__restrict__ d_clen,
-                                   float *__restrict__ d_cscore, pgr_hitpair *__restrict__ d_hp) {
+                                   float *__restrict__ d_cscore, pgr_hitpair *__restrict__ d_hp,
+                                   const uint64_t *__restrict__ gkey, uint64_t n_groups, uint64_t *__restrict__ d_gstart,
+                                   uint64_t *__restrict__ d_gkey, uint32_t *__restrict__ d_nch) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i <= n_groups) {  // the per-group arrays of the image (n_groups <= n: every group has a hit)
+        d_gstart[i] = g_start[i];
+        d_nch[i] = nch[i];
+        if (i < n_groups) d_gkey[i] = gkey[i];
+    }
     if (i >= n) return;
     const uint64_t g = rank[i] - (flags[i] ? 0u : 1u);  // rank = exclusive scan of the group-start flags
     const uint64_t k = i - g_start[g];
@@ -1054,16 +1215,17 @@ struct ChainOut {
 };
 
 // extra = bytes the caller wants behind the image in the same host block (the offset arrays of fill_result)
-inline unsigned bits_for(uint64_t n_values) {  // bits needed for values 0 .. n_values - 1 (at least 1)
-    unsigned b = 1;
-    while (b < 64 && (1ull << b) < n_values) ++b;
-    return b;
-}
 
 // sorted_by_qb: the hits of every group already come in ascending qb (the query path emits them pair by pair in query
 // position order), so only the grouping sort is needed.  sid_bound / n_queries bound the two halves of the group key.
+// seg (query path): per-query hit segments {pair_off, hit_off} on the device when no query has more than SEG_SORT_MAX hits:
+// the grouping runs per query in LDS (group_sort_kernel) instead of through the global sort.
+struct HitSegments {
+    const uint64_t *pair_off = nullptr, *hit_off = nullptr;
+    uint64_t max_hits = 0;  // most hits of one query
+};
 int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uint64_t n, const AlnParams &prm,
-               uint32_t n_queries, uint64_t sid_bound, bool sorted_by_qb, ChainOut &out) {
+               uint32_t n_queries, uint64_t sid_bound, bool sorted_by_qb, ChainOut &out, HitSegments seg = HitSegments()) {
     if (n == 0) return PGR_OK;
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 hits in one batch");
     hipStream_t st = ctx->stream;
@@ -1081,20 +1243,25 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
         (rc = skey.alloc(n * 8)) || (rc = shp.alloc(n * sizeof(pgr_hitpair))) || (rc = flags.alloc((n + 1) * 4)) ||
         (rc = rank.alloc((n + 1) * 8)) || (rc = gstart.alloc((n + 2) * 8)))
         return rc;
-    hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
     const size_t tb = sort_pairs_temp_bytes(n);
     if ((rc = ctx->ws_scan_tmp.ensure(ctx, std::max(tb, scan_counts_temp_bytes((uint32_t)(n + 1)))))) return rc;
-    uint32_t *cur = idx_a.as<uint32_t>(), *nxt = idx_b.as<uint32_t>();
-    const unsigned sid_bits = std::min(32u, bits_for(sid_bound ? sid_bound : (1ull << 32)));
-    const unsigned key_bits = std::min(64u, sid_bits + bits_for(n_queries));
-    for (int f = sorted_by_qb ? 1 : 0; f < 2; ++f) {  // stable: by qb (aln.rs:21), then by group
-        hipLaunchKernelGGL(hit_key_kernel, grid_for(n), dim3(256), 0, st, d_key, d_hp, cur, f, sid_bits, keys_a.as<uint64_t>(), n);
-        PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), cur, nxt, n,
-                                f == 0 ? 32u : key_bits));
-        std::swap(cur, nxt);
+    if (sorted_by_qb && seg.pair_off && n_queries) {
+        hipLaunchKernelGGL(group_sort_kernel, dim3(n_queries), dim3(seg.max_hits <= 256 ? 64 : 256), 0, st, d_key, d_hp, seg.pair_off, seg.hit_off, n,
+                           skey.as<uint64_t>(), shp.as<pgr_hitpair>(), flags.as<uint32_t>());
+    } else {
+        hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
+        uint32_t *cur = idx_a.as<uint32_t>(), *nxt = idx_b.as<uint32_t>();
+        const unsigned sid_bits = std::min(32u, bits_for(sid_bound ? sid_bound : (1ull << 32)));
+        const unsigned key_bits = std::min(64u, sid_bits + bits_for(n_queries));
+        for (int f = sorted_by_qb ? 1 : 0; f < 2; ++f) {  // stable: by qb (aln.rs:21), then by group
+            hipLaunchKernelGGL(hit_key_kernel, grid_for(n), dim3(256), 0, st, d_key, d_hp, cur, f, sid_bits, keys_a.as<uint64_t>(), n);
+            PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), cur, nxt, n,
+                                    f == 0 ? 32u : key_bits));
+            std::swap(cur, nxt);
+        }
+        hipLaunchKernelGGL(gather_hits_kernel, grid_for(n + 1), dim3(256), 0, st, d_key, d_hp, cur, n, skey.as<uint64_t>(),
+                           shp.as<pgr_hitpair>(), flags.as<uint32_t>());
     }
-    hipLaunchKernelGGL(gather_hits_kernel, grid_for(n + 1), dim3(256), 0, st, d_key, d_hp, cur, n, skey.as<uint64_t>(),
-                       shp.as<pgr_hitpair>(), flags.as<uint32_t>());
     PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, scan_counts_temp_bytes((uint32_t)(n + 1)), flags.as<uint32_t>(),
                              rank.as<uint64_t>(), (uint32_t)(n + 1)));
     lap("sorted + grouped");
@@ -1110,7 +1277,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
         (rc = big.alloc(2 * max_big * 4)) || (rc = trk.alloc(n * 4)))
         return rc;
     Tmp span_g(ctx);  // only for max_span > MAX_SPAN_CAP
-    if (prm.max_span > MAX_SPAN_CAP && (rc = span_g.alloc(n * 12))) return rc;
+    if (prm.max_span > MAX_SPAN_CAP && (rc = span_g.alloc(n * 4))) return rc;
     PGR_HIP(ctx, hipMemsetAsync(err.p, 0, 16, st));  // [0] groups the reference never finishes, [1], [2] groups per wave class
     hipLaunchKernelGGL(sparse_aln_kernel, grid_for(n, 64), dim3(64), 0, st, shp.as<pgr_hitpair>(),
                        gstart.as<uint64_t>(), d_ngroups, prm, v_s.as<float>(), pre.as<int>(), slot.as<int>(),
@@ -1158,13 +1325,12 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     Tmp img(ctx);
     if ((rc = img.alloc(image))) return rc;
     uint8_t *dI = img.as<uint8_t>();
-    hipLaunchKernelGGL(pack_chains_kernel, grid_for(n), dim3(256), 0, st, gstart.as<uint64_t>(), n,
+    hipLaunchKernelGGL(pack_chains_kernel, grid_for(n + 1), dim3(256), 0, st, gstart.as<uint64_t>(), n,
                        flags.as<uint32_t>(), rank.as<uint64_t>(), d_nch.as<uint32_t>(), d_nhp.as<uint32_t>(),
                        d_choff.as<uint64_t>(), d_hpoff.as<uint64_t>(), c_len.as<uint32_t>(), c_score.as<float>(),
-                       o_hp.as<pgr_hitpair>(), (uint32_t *)(dI + o_clen), (float *)(dI + o_cscore), (pgr_hitpair *)(dI + o_hps));
-    PGR_HIP(ctx, hipMemcpyAsync(dI + o_gstart, gstart.p, (n_groups + 1) * 8, hipMemcpyDeviceToDevice, st));
-    if (n_groups) PGR_HIP(ctx, hipMemcpyAsync(dI + o_gkey, d_gkey.p, n_groups * 8, hipMemcpyDeviceToDevice, st));
-    PGR_HIP(ctx, hipMemcpyAsync(dI + o_nch, d_nch.p, (n_groups + 1) * 4, hipMemcpyDeviceToDevice, st));
+                       o_hp.as<pgr_hitpair>(), (uint32_t *)(dI + o_clen), (float *)(dI + o_cscore), (pgr_hitpair *)(dI + o_hps),
+                       d_gkey.as<uint64_t>(), n_groups, (uint64_t *)(dI + o_gstart), (uint64_t *)(dI + o_gkey),
+                       (uint32_t *)(dI + o_nch));
     // host block: image + room for q_off, t_off, c_off (u64) and t_sid (u32) that fill_result builds
     const size_t extra = ((size_t)n_queries + 1) * 8 + (n_groups + 1) * 8 + (n_chains + 1) * 8 + up8(n_groups * 4);
     out.block = (uint8_t *)malloc(image + extra + 8);
@@ -1315,7 +1481,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
             (rc = nh.alloc((nq + 1) * 4)) || (rc = hoff.alloc((nq + 1) * 8)) || (rc = nsig.alloc(16)))
             return rc;
         hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
-                           ix->key_off, ix->n_keys, lo.as<uint64_t>(), hi.as<uint64_t>());
+                           ix->key_off, ix->n_keys, ix->lut, ix->lut_bits, ix->lut_shift, lo.as<uint64_t>(), hi.as<uint64_t>());
         PGR_HIP(ctx, hipMemsetAsync(nsig.p, 0, 16, st));
         hipLaunchKernelGGL(sum_ranges_kernel, dim3((uint32_t)std::min<uint64_t>(64, (nq + 255) / 256)), dim3(256), 0, st,
                            lo.as<uint64_t>(), hi.as<uint64_t>(), nq, nsig.as<unsigned long long>());
@@ -1345,8 +1511,11 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         uint64_t *mb = (uint64_t *)ctx->mailbox;
         Tmp words(ctx);
         if ((rc = words.alloc(32))) return rc;
+        // nsig: [0] looked-up signatures, [1] most hits of one query (decides how the hits are grouped, chain_hits)
+        hipLaunchKernelGGL(query_hit_max_kernel, grid_for(n_queries), dim3(256), 0, st, (const uint64_t *)ctx->ws_rec_off.p,
+                           hoff.as<uint64_t>(), n_queries, nsig.as<unsigned long long>() + 1);
         hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, hoff.as<uint64_t>() + nq, nsig.as<uint64_t>(),
-                           (const uint64_t *)nullptr, (const uint32_t *)nullptr, words.as<uint64_t>());
+                           nsig.as<uint64_t>() + 1, (const uint32_t *)nullptr, words.as<uint64_t>());
         PGR_HIP(ctx, hipMemcpyAsync(mb, words.p, 32, hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));  // the number of hits sizes everything behind this point
         const uint64_t n_hits = mb[0];
@@ -1360,7 +1529,13 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
                                cnt.as<uint32_t>(), lo.as<uint64_t>(), hi.as<uint64_t>(), ix->recs, qprm, 1,
                                (uint32_t *)nullptr, hoff.as<uint64_t>(), hkey.as<uint64_t>(), hhp.as<pgr_hitpair>());
             AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
-            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, n_queries, ix->sid_bound, true, co)))
+            HitSegments seg;
+            if (mb[2] <= SEG_SORT_MAX && !getenv("PGR_QUERY_GLOBAL_SORT")) {
+                seg.pair_off = (const uint64_t *)ctx->ws_rec_off.p;
+                seg.hit_off = hoff.as<uint64_t>();
+                seg.max_hits = mb[2];
+            }
+            if ((rc = chain_hits(ctx, hkey.as<uint64_t>(), hhp.as<pgr_hitpair>(), n_hits, ap, n_queries, ix->sid_bound, true, co, seg)))
                 return rc;
         }
         t4 = now();

@@ -14,6 +14,10 @@ struct pgr_index {
     uint64_t n = 0;
     uint64_t *key_off = nullptr;  // [n_keys + 1]
     uint64_t n_keys = 0;
+    // bucket table over the keys: bucket(h0) = min(h0 >> lut_shift, 2^lut_bits - 1); lut[b] = first key whose bucket is >= b,
+    // lut[2^lut_bits] = n_keys.  A lookup searches one bucket (a few keys) instead of all n_keys.  nullptr: no table.
+    uint32_t *lut = nullptr;
+    uint32_t lut_bits = 0, lut_shift = 0;
     bool finalized = false;
     uint32_t next_sid = 0;
     uint64_t sid_bound = 0;  // max(sid) + 1 over the finalized records (0: unknown)
@@ -33,6 +37,12 @@ struct Tmp {
     Tmp(const Tmp &) = delete;
     Tmp &operator=(const Tmp &) = delete;
 };
+
+inline unsigned bits_for(uint64_t n_values) {  // bits needed for values 0 .. n_values - 1 (at least 1)
+    unsigned b = 1;
+    while (b < 64 && (1ull << b) < n_values) ++b;
+    return b;
+}
 
 inline dim3 grid_for(uint64_t n, uint32_t block = 256) { return dim3((uint32_t)((n + block - 1) / block)); }
 

@@ -51,11 +51,14 @@ def test_small_calls_take_the_optimistic_path_and_stay_exact(oracle, gpu_ctx):
         assert _same(oracle.sequence_to_shmmrs(0, seqs[0], oracle.spec(*sp_t)), got[0])
 
 
-def test_large_batch_with_islands_is_exact(oracle, gpu_ctx):
-    """>= 64 Mbp: the pipeline looks at the level-1 flags once before the list stage; non-ACGT bytes (single N, a 300 kbp N
-    run), palindromic (AT)n and a homopolymer stretch turn tiles into islands of the exact state machine, everything else
-    stays on the closed-form tiles.  All contigs compared with the checker (128-bit checksums + counts)."""
+@pytest.mark.parametrize("early_bp", ["1000000", "100000000000"])
+def test_large_batch_with_islands_is_exact(oracle, gpu_ctx, monkeypatch, early_bp):
+    """80 Mbp through both orchestrations: with the early look at the level-1 flags before the list stage (what batches of
+    >= 1 Gbp do) and optimistically (list stage enqueued at once, repeated after the islands).  Non-ACGT bytes (single N, a
+    300 kbp N run), palindromic (AT)n and a homopolymer stretch turn tiles into islands of the exact state machine,
+    everything else stays on the closed-form tiles.  All contigs compared with the checker (128-bit checksums + counts)."""
     import pgrtk_amd as P
+    monkeypatch.setenv("PGR_EARLY_SYNC_BP", early_bp)
     n, L = 8, 10_000_000
     seqs = []
     for i in range(n):
@@ -336,3 +339,80 @@ def test_config5_slice_one_gpus_share(oracle, gpu_ctx):
     with open(os.path.join(ROOT, "gpurun_out", "config5_slice.json"), "w") as f:
         json.dump(line, f)
     print(json.dumps(line))
+
+
+def _random_group(rng, n, dup=0.15):
+    hits, q, t = [], int(rng.integers(0, 100)), int(rng.integers(1000, 9000))
+    while len(hits) < n:
+        q += int(rng.integers(0, 40))  # 0: equal query bgn runs (value slots, span-set tail scan)
+        t += int(rng.integers(-60, 150))
+        ln = int(rng.integers(20, 160))
+        h = ((q, q + ln, int(rng.integers(0, 2))), (max(1, t), max(1, t) + ln, int(rng.integers(0, 2))))
+        hits.append(h)
+        if rng.random() < dup and len(hits) < n:
+            hits.append(h if rng.random() < 0.5 else ((q, q + ln, h[0][2]), (h[1][0] + 5000, h[1][1] + 5000, h[1][2])))
+    return hits
+
+
+def test_sparse_aln_group_size_classes(oracle, gpu_ctx):
+    """groups of 2..63 hits are chained by one thread each with their hits staged in LDS (2048 hits per wavefront: the
+    64 groups of the first wavefronts below overflow it and finish from global memory), 64..256 and longer ones by a
+    wavefront each: all of them against the checker, with duplicates and equal-bgn runs"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(4242)
+    sizes = [int(rng.integers(40, 64)) for _ in range(128)] + [2, 3, 63, 64, 65, 255, 256, 257, 300] + \
+            [int(rng.integers(2, 64)) for _ in range(300)] + [int(rng.integers(64, 200)) for _ in range(20)]
+    groups = [_random_group(rng, n) for n in sizes]
+    for span, pen, gap, ori in [(8, 0.025, None, False), (3, 0.1, 200, True), (64, 0.001, None, False), (100, 0.01, None, False)]:
+        res = P.sparse_aln_groups(groups, span, pen, gap, ori, ctx=gpu_ctx)
+        assert res["n_nonterminating"] == 0
+        for gi, g in enumerate(groups):
+            ref = oracle.sparse_aln([a + b for a, b in g], span, pen, gap, ori)
+            ref = [(sc, [((x[0], x[1], x[2]), (x[3], x[4], x[5])) for x in hp]) for sc, hp in ref]
+            assert res["chains"][gi] == ref, (span, gi, len(g))
+
+
+def _raw_to_lists(r, qi):
+    got = []
+    for t in range(int(r["q_off"][qi]), int(r["q_off"][qi + 1])):
+        ch = []
+        for c in range(int(r["t_off"][t]), int(r["t_off"][t + 1])):
+            hp = r["hps"][int(r["c_off"][c]):int(r["c_off"][c + 1])]
+            ch.append((float(r["c_score"][c]), [tuple(int(v) for v in h) for h in hp]))
+        got.append((int(r["t_sid"][t]), ch))
+    return got
+
+
+def test_query_many_targets_per_query_grouping_paths(oracle, gpu_ctx, monkeypatch):
+    """queries that hit MANY targets (a pangenome-like index: 40 near-identical haplotypes): the per-query LDS grouping of
+    the hits must give what the global sort gives and what the checker gives"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(77)
+    anc = seqgen.rnd(rng, 60_000)
+    haps = []
+    for h in range(40):
+        s = bytearray(anc)
+        for p in rng.integers(0, len(s), 60):
+            s[int(p)] = b"ACGT"[int(rng.integers(0, 4))]
+        haps.append(bytes(s))
+    ix = P.Index(P.make_spec(), ctx=gpu_ctx)
+    ix.add_seqs(haps)
+    ix.finalize()
+    queries = [bytes(anc[o:o + 12_000]) for o in (0, 7_000, 20_000, 33_333, 47_999)]
+    queries.append(seqgen.rc(queries[1]))
+    got = ix.query_hps_raw(queries, 0.025)
+    monkeypatch.setenv("PGR_QUERY_GLOBAL_SORT", "1")
+    alt = ix.query_hps_raw(queries, 0.025)
+    monkeypatch.delenv("PGR_QUERY_GLOBAL_SORT")
+    for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps"):
+        assert np.array_equal(got[k], alt[k]), k
+    oix = oracle.Index(oracle.spec())
+    for sid, s in enumerate(haps):
+        oix.add_seq(sid, s)
+    n_targets = 0
+    for qi, q in enumerate(queries):
+        ref = oix.query_fragment_to_hps(q, 0.025)
+        mine = _raw_to_lists(got, qi)
+        assert sorted(mine) == sorted(ref), qi
+        n_targets += len(ref)
+    assert n_targets >= 5 * 30

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --queries 0 --no-extras"   # only full-size launches of every kernel
+B="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --queries 0 --no-extras"   # only full-size launches of every kernel (the first launches run at ramping clocks: enough steps for the average to mean something)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o p -- $B > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $B > $O/pmc_write.log 2>&1
