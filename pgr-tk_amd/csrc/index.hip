@@ -658,9 +658,8 @@ constexpr int ALN_ROW_LDS = 2048;   // hits of the (short) groups of one wavefro
 // pointers).  span[] is the span set of the current look-back (aln.rs:70, :91) as a list of candidate INDICES: the
 // candidates come in descending index = non-increasing query bgn order, so an interval that is already in the set can only
 // sit in the trailing entries with the same bgn.
-template <class IdxT>
-__device__ __forceinline__ void aln_dp_thread(const pgr_hitpair *h, int n, float *vs, int *pv, int *sl, IdxT *span,
-                                              const AlnParams &prm) {
+template <class IdxT, class H, class F, class I, class S>
+__device__ __forceinline__ void aln_dp_thread(H h, int n, F vs, I pv, I sl, S span, const AlnParams &prm) {
     for (int i = 0; i < n; ++i) {
         int s = i;
         for (int j = i - 1; j >= 0 && h[j].qb == h[i].qb; --j)
@@ -677,7 +676,7 @@ __device__ __forceinline__ void aln_dp_thread(const pgr_hitpair *h, int n, float
         const float cur_len = (float)cur.qe - (float)cur.qb;
         int best_v = -1;
         float best_s = 0.0f;
-        uint32_t span_n = 0;
+        uint32_t span_n = 0, t_qb = 0, t_qe = 0, t_qo = 0;
         for (int j = i - 1; j >= 0; --j) {
             const pgr_hitpair p = h[j];
             if (prm.oriented && ((p.qo ^ p.to) != (cur.qo ^ cur.to))) continue;  // :43-50
@@ -690,16 +689,27 @@ __device__ __forceinline__ void aln_dp_thread(const pgr_hitpair *h, int n, float
                 if (a > mg || b > mg) continue;
             }
             if (same_q(p, cur)) continue;  // :67
-            bool found = false;            // :70
-            for (int t = (int)span_n - 1; t >= 0; --t) {
-                const pgr_hitpair e = h[span[t]];
-                if (e.qb != p.qb) break;
-                if (e.qe == p.qe && e.qo == p.qo) {
+            bool found = false;            // :70 (the newest entry is kept in registers: most checks end there)
+            if (span_n && p.qb == t_qb) {
+                if (p.qe == t_qe && p.qo == t_qo) {
                     found = true;
-                    break;
+                } else {
+                    for (int t = (int)span_n - 2; t >= 0; --t) {
+                        const pgr_hitpair e = h[span[t]];
+                        if (e.qb != p.qb) break;
+                        if (e.qe == p.qe && e.qo == p.qo) {
+                            found = true;
+                            break;
+                        }
+                    }
                 }
             }
-            if (!found) span[span_n++] = (IdxT)j;
+            if (!found) {
+                span[span_n++] = (IdxT)j;
+                t_qb = p.qb;
+                t_qe = p.qe;
+                t_qo = p.qo;
+            }
             const int slj = sl[j];
             const float p_s = vs[slj];      // :71
             float s = p_s + cur_len;        // :72
@@ -721,6 +731,47 @@ __device__ __forceinline__ void aln_dp_thread(const pgr_hitpair *h, int n, float
             pv[si] = -1;
         }
     }
+}
+
+// chain extraction (aln.rs:105-140) by one thread.  A visited value-slot is marked by sl[v] = -1 - v (the DP is done, so sl
+// is free to carry the flag); unvisited representatives have sl[i] == i.  Returns true when only non-positive scores are
+// left (aln.rs:129-131 would spin forever: the group ends there).
+template <class H, class F, class I>
+__device__ __forceinline__ bool aln_extract_thread(H h, int n, F vs, I pv, I sl, pgr_hitpair *__restrict__ o_hp,
+                                                   uint32_t *__restrict__ o_len, float *__restrict__ o_score,
+                                                   uint32_t &n_ch, uint32_t &n_out) {
+    int n_unvisited = 0;
+    for (int i = 0; i < n; ++i) n_unvisited += (sl[i] == i);
+    while (n_unvisited > 0) {
+        float best_s = 0.0f;
+        int best_v = -1;
+        for (int i = 0; i < n; ++i)
+            if (sl[i] == i && vs[i] > best_s) {  // strict >, first (lowest sorted index) wins
+                best_s = vs[i];
+                best_v = i;
+            }
+        if (best_v < 0) return true;
+        uint32_t len = 0;
+        int v = best_v, first_v = best_v;
+        while (v >= 0 && sl[v] == v) {  // :121-128 (counted back to front, written in chain order below)
+            ++len;
+            first_v = v;
+            const int nv = pv[v];
+            sl[v] = -1 - v;  // :133-137
+            --n_unvisited;
+            v = nv;
+        }
+        v = best_v;  // :132 reverse: the pv links are intact, walk again and store from the back
+        for (uint32_t a = 0; a < len; ++a) {
+            o_hp[n_out + (len - 1 - a)] = h[v];
+            v = pv[v];
+        }
+        o_len[n_ch] = len;
+        o_score[n_ch] = best_s - vs[first_v];  // :138-139
+        ++n_ch;
+        n_out += len;
+    }
+    return false;
 }
 
 // aln::sparse_aln (aln.rs:12-142), one thread per (query, target) group.  The hits of a group are
@@ -773,72 +824,58 @@ __global__ __launch_bounds__(64) void sparse_aln_kernel(
     }
     const bool mine = !to_wave && n >= 2;  // n < 2: aln.rs:234, targets with a single hit are dropped (and lanes beyond the last group)
     if (__ballot(mine) == 0) return;
-    // LDS placement of the short groups of this wavefront (exclusive prefix sum of their sizes over the lanes)
+    // LDS placement of the short groups of this wavefront.  The groups of a wavefront are consecutive, so their hits are one
+    // contiguous range of the sorted hit array: when that range fits it is copied as it lies (coalesced, independent loads);
+    // otherwise (a long group in between, or many groups near the limit) the short groups are packed by an exclusive prefix
+    // sum of their sizes and copied one group per step.
     const uint32_t want = (mine && n < ALN_WAVE_MIN) ? (uint32_t)n : 0u;
-    const uint32_t lds_base = wave_incl_sum(want) - want;
-    const bool in_lds = want != 0 && lds_base + want <= (uint32_t)ALN_ROW_LDS;
-    const uint64_t stage = __ballot(in_lds);
-    for (uint64_t m = stage; m; m &= m - 1) {  // coalesced copies, one staged group per step
-        const int src = __builtin_ctzll(m);
-        const uint64_t gs_l = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gs >> 32), src) << 32) |
-                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gs, src);
-        const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane(n, src);
-        const uint32_t b_l = (uint32_t)__builtin_amdgcn_readlane((int)lds_base, src);
-        if (lane < n_l) L.h[b_l + lane] = hp[gs_l + lane];
+    const uint64_t live_m = __ballot(live);
+    const int first_l = __builtin_ctzll(live_m), last_l = 63 - __builtin_clzll(live_m);  // (live_m != 0: some lane is `mine`)
+    const uint64_t ge = gs + (uint64_t)n;
+    const uint64_t r_lo = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gs >> 32), first_l) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gs, first_l);
+    const uint64_t r_hi = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(ge >> 32), last_l) << 32) |
+                          (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)ge, last_l);
+    uint32_t lds_base;
+    bool in_lds;
+    if (r_hi - r_lo <= (uint64_t)ALN_ROW_LDS) {  // wave-uniform
+        const uint32_t R = (uint32_t)(r_hi - r_lo);
+        for (uint32_t e = lane; e < R; e += 64) L.h[e] = hp[r_lo + e];
+        lds_base = (uint32_t)(gs - r_lo);
+        in_lds = want != 0;
+    } else {
+        lds_base = wave_incl_sum(want) - want;
+        in_lds = want != 0 && lds_base + want <= (uint32_t)ALN_ROW_LDS;
+        for (uint64_t m = __ballot(in_lds); m; m &= m - 1) {
+            const int src = __builtin_ctzll(m);
+            const uint64_t gs_l = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(gs >> 32), src) << 32) |
+                                  (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)gs, src);
+            const uint32_t n_l = (uint32_t)__builtin_amdgcn_readlane(n, src);
+            const uint32_t b_l = (uint32_t)__builtin_amdgcn_readlane((int)lds_base, src);
+            if (lane < n_l) L.h[b_l + lane] = hp[gs_l + lane];
+        }
     }
     __syncthreads();
     if (!mine) return;
-    const pgr_hitpair *h = in_lds ? &L.h[lds_base] : hp + gs;
-    float *vs = in_lds ? &L.vs[lds_base] : v_s + gs;
-    int *pv = in_lds ? &L.pv[lds_base] : pre + gs;
-    int *sl = in_lds ? &L.sl[lds_base] : slot + gs;
-    if (in_lds) {
-        aln_dp_thread<uint8_t>(h, n, vs, pv, sl, L.span[lane], prm);
-    } else if (span_buf) {
-        aln_dp_thread<uint32_t>(h, n, vs, pv, sl, span_buf + gs, prm);
-    } else {
-        uint32_t span_loc[MAX_SPAN_CAP];
-        aln_dp_thread<uint32_t>(h, n, vs, pv, sl, span_loc, prm);
-    }
-    // extraction (aln.rs:105-140).  A visited value-slot is marked by sl[v] = -1 - v (the DP is done,
-    // so sl is free to carry the flag); unvisited representatives have sl[i] == i.
+    // two call sites so that each one sees pointers of ONE address space (LDS reads and writes become ds_ instructions; a
+    // pointer that may be either costs a flat access with several times the latency on every dependent step)
     uint32_t n_ch = 0, n_out = 0;
-    int n_unvisited = 0;
-    for (int i = 0; i < n; ++i) n_unvisited += (sl[i] == i);
-    while (n_unvisited > 0) {
-        float best_s = 0.0f;
-        int best_v = -1;
-        for (int i = 0; i < n; ++i)
-            if (sl[i] == i && vs[i] > best_s) {  // strict >, first (lowest sorted index) wins
-                best_s = vs[i];
-                best_v = i;
-            }
-        if (best_v < 0) {  // aln.rs:129-131 would spin forever (only non-positive scores left): this group ends here
-            atomicAdd(err, 1u);
-            break;
+    bool stuck = false;
+    if (in_lds) {
+        aln_dp_thread<uint8_t>(&L.h[lds_base], n, &L.vs[lds_base], &L.pv[lds_base], &L.sl[lds_base], L.span[lane], prm);
+        stuck = aln_extract_thread(&L.h[lds_base], n, &L.vs[lds_base], &L.pv[lds_base], &L.sl[lds_base], out_hp + gs,
+                                   chain_len + gs, chain_score + gs, n_ch, n_out);
+    } else {
+        if (span_buf) {
+            aln_dp_thread<uint32_t>(hp + gs, n, v_s + gs, pre + gs, slot + gs, span_buf + gs, prm);
+        } else {
+            uint32_t span_loc[MAX_SPAN_CAP];
+            aln_dp_thread<uint32_t>(hp + gs, n, v_s + gs, pre + gs, slot + gs, span_loc, prm);
         }
-        uint32_t len = 0;
-        int v = best_v, first_v = best_v;
-        while (v >= 0 && sl[v] == v) {  // :121-128 (collected back to front, written in chain order below)
-            ++len;
-            first_v = v;
-            const int nv = pv[v];
-            sl[v] = -1 - v;  // :133-137
-            --n_unvisited;
-            v = nv;
-        }
-        // :132 reverse: the walk went from the chain's end to its start; pv links are still intact, walk again and
-        // store from the back
-        v = best_v;
-        for (uint32_t a = 0; a < len; ++a) {
-            out_hp[gs + n_out + (len - 1 - a)] = h[v];
-            v = pv[v];
-        }
-        chain_len[gs + n_ch] = len;
-        chain_score[gs + n_ch] = best_s - vs[first_v];  // :138-139
-        ++n_ch;
-        n_out += len;
+        stuck = aln_extract_thread(hp + gs, n, v_s + gs, pre + gs, slot + gs, out_hp + gs, chain_len + gs, chain_score + gs,
+                                   n_ch, n_out);
     }
+    if (stuck) atomicAdd(err, 1u);
     g_nchains[g] = n_ch;
     g_nhp[g] = n_out;
 }

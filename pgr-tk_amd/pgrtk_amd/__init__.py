@@ -6,7 +6,7 @@ calls raise.
 """
 from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PackedSeqs, PgrError, Spec, default_context  # noqa: F401
 from .engine import (Batch, Index, Shmmrs, frag_recs_batch, make_spec, sequence_to_shmmrs,  # noqa: F401
-                     sequence_to_shmmrs_batch)
+                     sequence_to_shmmrs_batch, time_shmmr_batch)
 from .seqindexdb import (SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, read_fastx, sparse_aln,  # noqa: F401
                          sparse_aln_groups)
 from . import cli, mapgraph  # noqa: F401

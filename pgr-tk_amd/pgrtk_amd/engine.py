@@ -160,6 +160,26 @@ def sequence_to_shmmrs_batch(seqs, spec, rids=None, padding=False, ctx=None):
     return [mm[int(off[i]):int(off[i + 1])] for i in range(n)]
 
 
+def time_shmmr_batch(seqs, spec, ctx=None):
+    """seconds spent inside pgr_shmmr_batch + the two pgr_free (what a compiled host pays; pointer arrays built before the
+    clock starts, nothing copied into numpy), and the number of shimmers"""
+    import time
+    ctx = ctx or default_context()
+    arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+    pm, po = C.c_void_p(), C.c_void_p()
+    L, h = lib(), ctx.handle
+    t0 = time.perf_counter()
+    rc = L.pgr_shmmr_batch(h, C.byref(spec), n, ptrs, lens, None, 0, C.byref(pm), C.byref(po))
+    cnt = 0
+    if rc == 0:
+        cnt = int(C.cast(po, C.POINTER(C.c_uint64))[n])
+        L.pgr_free(pm)
+        L.pgr_free(po)
+    dt = time.perf_counter() - t0
+    ctx.check(rc)
+    return dt, cnt
+
+
 def sequence_to_shmmrs(rid, seq, spec, padding=False, ctx=None):
     return sequence_to_shmmrs_batch([seq], spec, rids=[rid], padding=padding, ctx=ctx)[0]
 
@@ -249,6 +269,42 @@ class Index:
                                                     int(max_gap is not None), int(max_gap or 0), int(bool(oriented)),
                                                     C.byref(res)))
         return self._unpack_raw(res, batch.n)
+
+    def time_query_resident(self, batch, penalty, max_count=128, max_count_query=128, max_count_target=128,
+                            max_aln_span=8, max_gap=None, oriented=False):
+        """seconds spent inside pgr_query_hps_resident + pgr_hps_result_free (what a compiled host pays: the result stays in
+        the library's block, nothing is unpacked into numpy arrays), and the number of hit pairs of the result"""
+        import time
+        res = _ffi.HpsResult()
+        L, h, ih, bh = lib(), self.ctx.handle, self._h, batch._h
+        a = (float(penalty), max_count, max_count_query, max_count_target, max_aln_span, int(max_gap is not None),
+             int(max_gap or 0), int(bool(oriented)))
+        t0 = time.perf_counter()
+        rc = L.pgr_query_hps_resident(h, ih, bh, *a, C.byref(res))
+        n = int(res.n_hps) if rc == 0 else 0
+        if rc == 0:
+            L.pgr_hps_result_free(C.byref(res))
+        dt = time.perf_counter() - t0
+        self.ctx.check(rc)
+        return dt, n
+
+    def time_query_host(self, seqs, penalty, max_count=128, max_count_query=128, max_count_target=128, max_aln_span=8,
+                        max_gap=None, oriented=False):
+        """the same for pgr_query_hps_batch (host ASCII in); the pointer arrays are built before the clock starts"""
+        import time
+        arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+        res = _ffi.HpsResult()
+        L, h, ih = lib(), self.ctx.handle, self._h
+        a = (float(penalty), max_count, max_count_query, max_count_target, max_aln_span, int(max_gap is not None),
+             int(max_gap or 0), int(bool(oriented)))
+        t0 = time.perf_counter()
+        rc = L.pgr_query_hps_batch(h, ih, n, ptrs, lens, *a, C.byref(res))
+        nh = int(res.n_hps) if rc == 0 else 0
+        if rc == 0:
+            L.pgr_hps_result_free(C.byref(res))
+        dt = time.perf_counter() - t0
+        self.ctx.check(rc)
+        return dt, nh
 
     @staticmethod
     def _unpack_raw(res, n):

@@ -40,10 +40,14 @@ def main():
     time.sleep(0.5)
     ts = []
     for _ in range(a.reps):
-        t0 = time.perf_counter()
-        r = ix.query_hps_resident_raw(qb, 0.025)
-        ts.append(time.perf_counter() - t0)
-    print("query batches: %s ms; %d hit pairs" % (" ".join("%.3f" % (t * 1e3) for t in ts), len(r["hps"])))
+        dt, n_hps = ix.time_query_resident(qb, 0.025)
+        ts.append(dt)
+    print("query batches (C entry point): %s ms; %d hit pairs" % (" ".join("%.3f" % (t * 1e3) for t in ts), n_hps))
+    p = ctx.last_query_prof()
+    print("stages of the last batch: " + ", ".join("%s %.3f" % (k, p[k]) for k in ("shmmr_ms", "lookup_ms", "chain_ms", "result_ms", "total_ms")))
+    t0 = time.perf_counter()
+    r = ix.query_hps_resident_raw(qb, 0.025)
+    print("through the Python binding (+ numpy copies of the result): %.3f ms" % ((time.perf_counter() - t0) * 1e3))
 
 
 if __name__ == "__main__":
