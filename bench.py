@@ -199,8 +199,9 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
                                          "(SURVEY.md 8d); signatures counted on the device",
             "dominant_kernel": qk.get("dominant_kernel"), "dominant_kernel_ms": qk.get("dominant_kernel_ms"),
             "kernel_ms_total": qk.get("kernel_ms_total"), "launches": qk.get("launches"),
-            "what_holds": "launch / round-trip latency: the batch moves ~37 MB (5 us of HBM time); %d kernel launches and 4 host "
-                          "round trips (one per data-dependent buffer size) take the rest" % (qk.get("launches") or 0),
+            "what_holds": "latency: the batch moves ~37 MB (5 us of HBM time); %d kernel launches, 4 host round trips (one per "
+                          "data-dependent buffer size), the serial critical path of the chaining DP and the PCIe download of "
+                          "the chains take the rest" % (qk.get("launches") or 0),
         },
     }
     return out, ix

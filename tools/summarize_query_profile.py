@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 kernel trace of tools/query_leg.py -> profiles/<name>/{kernel_stats.csv, summary.json}
 
-    tools/summarize_query_profile.py gpurun_out/<dir>/q_trace profiles/r02_query [reps]
+    tools/summarize_query_profile.py gpurun_out/<dir>/q_trace profiles/r02_query [batches]
 
 Only the kernels after the 0.5 s gap (the timed query batches) are counted; numbers are per query batch."""
 import collections
@@ -26,7 +26,7 @@ def short_name(n):
 
 
 src, dst = sys.argv[1], sys.argv[2]
-reps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 0  # 0: one batch per launch of the tile kernel behind the gap
 os.makedirs(dst, exist_ok=True)
 rows = list(csv.DictReader(open(glob.glob(os.path.join(src, "*kernel_trace.csv"))[0])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -36,6 +36,8 @@ for i in range(1, len(rows)):
     if g > gap:
         gap, gap_i = g, i
 q = rows[gap_i:]
+if reps == 0:
+    reps = max(1, sum(1 for r in q if "level1_tile_kernel" in r["Kernel_Name"]))
 agg = collections.OrderedDict()
 for r in q:
     n = short_name(r["Kernel_Name"])
