@@ -1137,6 +1137,21 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
         subs.push_back(sb);
         c = e;
     }
+    // the last sub-batch's processing is the only part of the call nothing overlaps: keep it small (its tail of <= 48 Mbp
+    // becomes a sub-batch of its own)
+    if (!subs.empty() && subs.back().c1 - subs.back().c0 >= 2) {
+        Sub &last = subs.back();
+        uint32_t cut = last.c1;
+        uint64_t tail_bp = 0;
+        while (cut - 1 > last.c0 && tail_bp + lens[cut - 1] <= (48ull << 20)) tail_bp += lens[--cut];
+        if (cut < last.c1 && tail_bp > 0) {
+            Sub tail;
+            tail.c0 = cut;
+            tail.c1 = last.c1;
+            last.c1 = cut;
+            subs.push_back(tail);
+        }
+    }
     auto destroy_all = [&]() {
         for (Sub &sb : subs) {
             pgr_batch_destroy(sb.b);
@@ -1149,6 +1164,10 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
             destroy_all();
             return rc;
         }
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const auto t_start = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
+    if (dbg) fprintf(stderr, "[pgr] pipelined call: %zu sub-batches, allocated at %.2f ms\n", subs.size(), since());
     std::mutex mu;
     std::condition_variable cv;
     size_t n_ready = 0;
@@ -1170,6 +1189,7 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
             }
             n_ready = i + 1;
             cv.notify_all();
+            if (dbg) fprintf(stderr, "[pgr]   sub-batch %zu staged at %.2f ms\n", i, since());
         }
     });
     for (size_t i = 0; i < subs.size() && !rc; ++i) {
@@ -1181,7 +1201,9 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
                 break;
             }
         }
+        const double tc0 = since();
         rc = consume(subs[i].b, subs[i].c0, subs[i].c1);
+        if (dbg) fprintf(stderr, "[pgr]   sub-batch %zu consumed %.2f -> %.2f ms\n", i, tc0, since());
         pgr_batch_destroy(subs[i].b);
         subs[i].b = nullptr;
     }
