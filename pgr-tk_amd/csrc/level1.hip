@@ -541,6 +541,31 @@ __global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1A
     double x[L1_G];
     uint32_t strand_bits = 0, emit = 0;
     const long long q = e0 + (long long)t16;
+    // A wavefront whose 64 x 16 positions all lie outside the contig (the last tile of a contig: a 10 kbp query fills 2.5
+    // tiles, a 1 kbp read a quarter of one) computes nothing: it leaves in the shared rows what the masked variant would --
+    // the "not a k-mer" sentinel for pass 1, "no window" for pass 2 --, meets the barriers of the live path (three in
+    // tile_select unless SKETCH, two in the compaction below) and is done.  Never wavefront 0: thread 0 writes the tile's
+    // segment record even when the contig is shorter than k and no position of the tile is a k-mer.  A separate exit: the live path's registers are
+    // not shared with it.
+    if (!interior && t >= 64 && __all(valid_mask == 0u && mwin_mask == 0u)) {
+        if (!SKETCH) {
+            const double big = mk_double(0u, KEY_INF);
+#pragma unroll
+            for (int u = 0; u < L1_G; ++u) s_suf[u][t] = big;
+            s_row[t] = big;
+            __syncthreads();
+            __syncthreads();
+            const double none = __longlong_as_double((long long)NO_WINDOW);
+#pragma unroll
+            for (int u = 0; u < L1_G; ++u) s_suf[u][t] = none;
+            s_row[t] = none;
+            __syncthreads();
+        }
+        if ((t & 63) == 63) s_wsum[t >> 6] = 0;
+        __syncthreads();
+        __syncthreads();
+        return;
+    }
     const bool wave_full = interior || __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
     if (wave_full)
         tile_select<TW, TK, SKETCH, false>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
