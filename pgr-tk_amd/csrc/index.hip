@@ -58,6 +58,18 @@ __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint
     keys[i] = k;
 }
 
+// does the append order already follow (sid, frg_id)?  (contigs indexed in sid order, their pairs in position order: the
+// usual case) -- then the stable sort by the key alone leaves the records of a key in the order seq_db.rs:605-612 gives
+__global__ void unsorted_flag_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n, uint32_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    bool bad = false;
+    if (i + 1 < n) {
+        const pgr_frag_rec &a = recs[i], &b = recs[i + 1];
+        bad = a.sid > b.sid || (a.sid == b.sid && a.frg_id > b.frg_id);
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 __global__ void gather_recs_kernel(const pgr_frag_rec *__restrict__ in, const uint32_t *__restrict__ idx,
                                    pgr_frag_rec *__restrict__ out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -348,9 +360,18 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)))
         return rc;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
+    // records appended in (sid, frg_id) order need only the two key passes of the stable LSD sort (64 of 176 key bits less)
+    Tmp d_unsorted(ctx);
+    if ((rc = d_unsorted.alloc(16))) return rc;
+    uint32_t unsorted = 1;
+    PGR_HIP(ctx, hipMemsetAsync(d_unsorted.p, 0, 16, st));
+    hipLaunchKernelGGL(unsorted_flag_kernel, grid_for(n), dim3(256), 0, st, ix->raw, n, d_unsorted.as<uint32_t>());
+    PGR_HIP(ctx, hipMemcpyAsync(&unsorted, d_unsorted.p, 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipStreamSynchronize(st));
     const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
     const unsigned bits[4] = {32, 32, 56, 56};
-    if ((rc = sort_perm(ctx, ix->raw, n, fields, bits, 4, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+    const int skip = (unsorted || getenv("PGR_INDEX_FULL_SORT")) ? 0 : 2;
+    if ((rc = sort_perm(ctx, ix->raw, n, fields + skip, bits + skip, 4 - skip, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
                         keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
         return rc;
     hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, ix->raw, idx_a.as<uint32_t>(), ix->recs, n);

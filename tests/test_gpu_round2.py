@@ -416,3 +416,28 @@ def test_query_many_targets_per_query_grouping_paths(oracle, gpu_ctx, monkeypatc
         assert sorted(mine) == sorted(ref), qi
         n_targets += len(ref)
     assert n_targets >= 5 * 30
+
+
+def test_index_sort_shortcut_equals_full_sort(gpu_ctx, monkeypatch):
+    """records appended in (sid, frg_id) order are sorted by the key alone (stable); any other append order, and the forced
+    full sort, must give the same CSR"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(5)
+    base = seqgen.rnd(rng, 120_000)
+    seqs = [base[i * 7_000:i * 7_000 + 60_000] + seqgen.rnd(rng, 20_000) for i in range(6)]  # shared keys across sids
+    sp = P.make_spec()
+
+    def build(order, full):
+        if full:
+            monkeypatch.setenv("PGR_INDEX_FULL_SORT", "1")
+        ix = P.Index(sp, ctx=gpu_ctx)
+        for i in order:  # one call per sequence: the append order is `order`
+            ix.add_seqs([seqs[i]], sids=[i])
+        ix.finalize()
+        monkeypatch.delenv("PGR_INDEX_FULL_SORT", raising=False)
+        return ix.download()
+    ref = build(range(6), True)
+    assert len(ref) > 500 and len(np.unique(ref["sid"])) == 6
+    for order, full in [(range(6), False), ([3, 1, 5, 0, 2, 4], False), ([5, 4, 3, 2, 1, 0], True)]:
+        got = build(order, full)
+        assert np.array_equal(got, ref), (list(order), full)
