@@ -669,7 +669,9 @@ __device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair 
 __device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
 
 constexpr uint32_t MAX_SPAN_CAP = 64;
-constexpr int ALN_WAVE_MIN = 64;    // groups with at least this many hits are chained by a whole wavefront
+constexpr int ALN_WAVE_MIN = 64;    // groups with at least this many hits are chained by a whole wavefront ...
+constexpr int ALN_WAVE_MIN_FEW = 16;  // ... from this size already when the call has few groups (latency, not throughput)
+constexpr uint64_t ALN_FEW_GROUPS = 4096;
 constexpr int ALN_LDS_SMALL = 256;  // ... in a 9 KB LDS image (many workgroups per CU) up to this many hits,
 constexpr int ALN_LDS_MAX = 3584;   // in a 129 KB image up to this many (36 B per hit), in global memory above
 constexpr int ALN_ROW_LDS = 2048;   // hits of the (short) groups of one wavefront of sparse_aln_kernel staged in LDS
@@ -832,7 +834,10 @@ __global__ __launch_bounds__(64) void sparse_aln_kernel(
     // one-thread path with its span set in global memory -- a span set never holds more entries than the group has hits
     // groups of >= ALN_WAVE_MIN hits: one wavefront each (sparse_aln_wave_kernel), two size classes.  The list slots are
     // claimed with ONE atomic per wavefront and class (same-address atomics run at ~88 per us on gfx950)
-    const bool to_wave = n >= ALN_WAVE_MIN && span_buf == nullptr;
+    // a thread chains a 30-hit group in ~80 us, a wavefront in ~25: with few groups in the call (a single query) the machine
+    // is empty either way and the wavefront is quicker; with thousands of groups the threads win by ~60x fewer instructions
+    const int wave_min = *n_groups_ptr < ALN_FEW_GROUPS ? ALN_WAVE_MIN_FEW : ALN_WAVE_MIN;
+    const bool to_wave = n >= wave_min && span_buf == nullptr;
     const int cls = n > ALN_LDS_SMALL ? 1 : 0;
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -1328,7 +1333,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
                        n, gstart.as<uint64_t>());
     Tmp v_s(ctx), pre(ctx), slot(ctx), o_hp(ctx), c_len(ctx), c_score(ctx), g_nch(ctx), g_nhp(ctx), err(ctx), big(ctx),
         trk(ctx);
-    const uint64_t max_big = n / ALN_WAVE_MIN + 1;  // a wave-chained group has at least ALN_WAVE_MIN hits
+    const uint64_t max_big = n / ALN_WAVE_MIN_FEW + 1;  // a wave-chained group has at least ALN_WAVE_MIN_FEW hits
     if ((rc = v_s.alloc(n * 4)) || (rc = pre.alloc(n * 4)) || (rc = slot.alloc(n * 4)) ||
         (rc = o_hp.alloc(n * sizeof(pgr_hitpair))) || (rc = c_len.alloc(n * 4)) || (rc = c_score.alloc(n * 4)) ||
         (rc = g_nch.alloc(n * 4)) || (rc = g_nhp.alloc(n * 4)) || (rc = err.alloc(16)) ||

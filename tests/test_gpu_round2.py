@@ -354,16 +354,22 @@ def _random_group(rng, n, dup=0.15):
     return hits
 
 
-def test_sparse_aln_group_size_classes(oracle, gpu_ctx):
-    """groups of 2..63 hits are chained by one thread each with their hits staged in LDS (2048 hits per wavefront: the
-    64 groups of the first wavefronts below overflow it and finish from global memory), 64..256 and longer ones by a
-    wavefront each: all of them against the checker, with duplicates and equal-bgn runs"""
+@pytest.mark.parametrize("many", [False, True])
+def test_sparse_aln_group_size_classes(oracle, gpu_ctx, many):
+    """short groups are chained by one thread each with their hits staged in LDS (2048 hits per wavefront: the 64 groups of
+    the first wavefronts below overflow it and finish from global memory), longer ones by a wavefront each (up to 256 hits
+    in a small LDS image, above in a big one); "short" is < 64 hits in a call of >= 4096 groups and < 16 otherwise.  All of
+    them against the checker, with duplicates and equal-bgn runs"""
     import pgrtk_amd as P
     rng = np.random.default_rng(4242)
-    sizes = [int(rng.integers(40, 64)) for _ in range(128)] + [2, 3, 63, 64, 65, 255, 256, 257, 300] + \
+    sizes = [int(rng.integers(40, 64)) for _ in range(128)] + [2, 3, 15, 16, 17, 63, 64, 65, 255, 256, 257, 300] + \
             [int(rng.integers(2, 64)) for _ in range(300)] + [int(rng.integers(64, 200)) for _ in range(20)]
+    if many:  # >= 4096 groups in the call: the one-thread path takes everything below 64 hits (else: below 16)
+        sizes += [int(rng.integers(2, 12)) for _ in range(4000)]
     groups = [_random_group(rng, n) for n in sizes]
-    for span, pen, gap, ori in [(8, 0.025, None, False), (3, 0.1, 200, True), (64, 0.001, None, False), (100, 0.01, None, False)]:
+    cases = [(8, 0.025, None, False), (3, 0.1, 200, True)] if many else \
+        [(8, 0.025, None, False), (3, 0.1, 200, True), (64, 0.001, None, False), (100, 0.01, None, False)]
+    for span, pen, gap, ori in cases:
         res = P.sparse_aln_groups(groups, span, pen, gap, ori, ctx=gpu_ctx)
         assert res["n_nonterminating"] == 0
         for gi, g in enumerate(groups):
