@@ -587,14 +587,13 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
                                              std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
         (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_off_b.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_off_b.ensure(ctx, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t))))
         return rc;
     unsigned long long *d_cursor = (unsigned long long *)ctx->ws_cursor.p;
     uint32_t *d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
     uint8_t *d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
     const size_t zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
-    uint64_t *d_status = (uint64_t *)(((uintptr_t)(d_tflags + (size_t)n_tiles + 16) + 7) & ~(uintptr_t)7);
     uint64_t *mbox = (uint64_t *)ctx->mailbox;  // pinned: [0, N_STATUS) status, then the n+1 result offsets
     PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t),
                                 hipMemcpyHostToDevice, st));
@@ -735,7 +734,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         pgr_shmmrs_destroy(res);
         return code;
     };
-    if ((rc = ctx->dmalloc((void **)&res->d_off, ((size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
+    // the pipeline's status words sit right in front of the result offsets: ONE copy brings both to the mailbox
+    if ((rc = ctx->dmalloc((void **)&res->d_block, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
+    res->d_off = res->d_block + N_STATUS;
     // estimates: level-1 count from the density (low-complexity sequence exceeds it: retried with the true count),
     // final count from this context's last result with the same spec (first call: a third of the level-1 estimate)
     const uint64_t l1_bound = slots_total + cap_par + b->total_bases / 4 + 4096ull * n + 4096;  // what stage 1 can emit at all
@@ -820,17 +821,16 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         } else {
             if ((r = ctx->ws_list_b.ensure(ctx, cap_res * sizeof(pgr_mm128)))) return r;
             d_list = (pgr_mm128 *)ctx->ws_list_b.p;
-            d_loff = (uint64_t *)ctx->ws_off_b.p;
+            d_loff = (uint64_t *)ctx->ws_off_b.p + N_STATUS;
         }
         launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_list_a.p, (const uint64_t *)ctx->ws_blk_off.p,
                                (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list,
                                cap_res);
         launch_offsets_by_rid(st, d_list, d_nfinal, cap_res, n, d_loff);
         if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids, n);
-        launch_collect_status(st, d_cursor, d_total1, d_nfinal, d_status);
+        launch_collect_status(st, d_cursor, d_total1, d_nfinal, d_loff - N_STATUS);
         PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
-        PGR_HIP(ctx, hipMemcpyAsync(mbox, d_status, N_STATUS * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipMemcpyAsync(mbox + N_STATUS, d_loff, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipMemcpyAsync(mbox, d_loff - N_STATUS, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         // a small result that the caller wants on the host anyway (pgr_shmmr_batch) rides along with this round trip
         host_copy_elems = 0;
         if (ctx->want_host_copy && !pad_fix && cap_res * sizeof(pgr_mm128) <= (256u << 10) &&
@@ -955,7 +955,7 @@ extern "C" const uint64_t *pgr_shmmrs_device_offsets(const pgr_shmmrs *s) { retu
 extern "C" void pgr_shmmrs_destroy(pgr_shmmrs *s) {
     if (!s) return;
     s->ctx->dfree(s->d_mm);
-    s->ctx->dfree(s->d_off);
+    s->ctx->dfree(s->d_block);
     delete s;
 }
 

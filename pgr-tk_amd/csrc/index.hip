@@ -1225,57 +1225,6 @@ __global__ void group_counts_kernel(const uint64_t *__restrict__ g_start, const 
     gkey_out[g] = skey[gs];
 }
 
-// group_counts + both exclusive scans + the totals for calls of up to a few thousand hits, in ONE single-workgroup launch
-// (four launches less on the path of a single query).  Arrays as in the big path: nch_out / nhp_out / ch_off / hp_off have
-// n + 1 entries (groups beyond the last count 0), words = {chains, hit pairs, groups, non-terminating groups}.
-__global__ __launch_bounds__(256) void group_totals_small_kernel(
-    const uint64_t *__restrict__ g_start, const uint64_t *__restrict__ n_groups_ptr, uint32_t n,
-    const uint32_t *__restrict__ g_nch, const uint32_t *__restrict__ g_nhp, const uint64_t *__restrict__ skey,
-    uint32_t *__restrict__ nch_out, uint32_t *__restrict__ nhp_out, uint64_t *__restrict__ gkey_out,
-    uint64_t *__restrict__ ch_off, uint64_t *__restrict__ hp_off, const uint32_t *__restrict__ err,
-    uint64_t *__restrict__ words) {
-    __shared__ uint32_t s_c[256], s_h[256];
-    const uint32_t t = threadIdx.x;
-    const uint32_t n_groups = (uint32_t)*n_groups_ptr;
-    const uint32_t per = (n + 1 + 255) / 256;  // consecutive groups per thread
-    const uint32_t g0 = t * per, g1 = g0 + per < n + 1 ? g0 + per : n + 1;
-    uint32_t sc = 0, sh = 0;
-    for (uint32_t g = g0; g < g1; ++g) {
-        uint32_t c = 0, h = 0;
-        if (g < n_groups) {
-            const uint64_t gs = g_start[g];
-            const bool real = g_start[g + 1] - gs >= 2;  // aln.rs:234: targets with a single hit are dropped
-            c = real ? g_nch[g] : 0u;
-            h = real ? g_nhp[g] : 0u;
-            gkey_out[g] = skey[gs];
-        }
-        nch_out[g] = c;
-        nhp_out[g] = h;
-        sc += c;
-        sh += h;
-    }
-    s_c[t] = sc;
-    s_h[t] = sh;
-    __syncthreads();
-    uint32_t bc = 0, bh = 0;  // exclusive prefix of the per-thread sums (256 broadcast reads: a tiny kernel, kept simple)
-    for (uint32_t i = 0; i < t; ++i) {
-        bc += s_c[i];
-        bh += s_h[i];
-    }
-    for (uint32_t g = g0; g < g1; ++g) {
-        ch_off[g] = bc;
-        hp_off[g] = bh;
-        bc += nch_out[g];
-        bh += nhp_out[g];
-    }
-    if (t == 255) {  // the last thread's running sums are the totals (its range ends at n + 1 or is empty)
-        words[0] = bc;
-        words[1] = bh;
-        words[2] = n_groups;
-        words[3] = err[0];
-    }
-}
-
 __global__ void pack_chains_kernel(const uint64_t *__restrict__ g_start, uint64_t n,
                                    const uint32_t *__restrict__ flags, const uint64_t *__restrict__ rank,
                                    const uint32_t *__restrict__ nch, const uint32_t *__restrict__ nhp,
@@ -1419,21 +1368,14 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     uint64_t *mb = (uint64_t *)ctx->mailbox;
     Tmp words(ctx);
     if ((rc = words.alloc(32))) return rc;
-    if (n <= 8192) {
-        hipLaunchKernelGGL(group_totals_small_kernel, dim3(1), dim3(256), 0, st, gstart.as<uint64_t>(), d_ngroups, (uint32_t)n,
-                           g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), skey.as<uint64_t>(), d_nch.as<uint32_t>(),
-                           d_nhp.as<uint32_t>(), d_gkey.as<uint64_t>(), d_choff.as<uint64_t>(), d_hpoff.as<uint64_t>(),
-                           err.as<uint32_t>(), words.as<uint64_t>());
-    } else {
-        hipLaunchKernelGGL(group_counts_kernel, grid_for(n + 1), dim3(256), 0, st, gstart.as<uint64_t>(), d_ngroups, n,
-                           g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), skey.as<uint64_t>(), d_nch.as<uint32_t>(),
-                           d_nhp.as<uint32_t>(), d_gkey.as<uint64_t>());
-        const size_t tbg = scan_counts_temp_bytes((uint32_t)(n + 1));
-        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nch.as<uint32_t>(), d_choff.as<uint64_t>(), (uint32_t)(n + 1)));
-        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nhp.as<uint32_t>(), d_hpoff.as<uint64_t>(), (uint32_t)(n + 1)));
-        hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, d_choff.as<uint64_t>() + n, d_hpoff.as<uint64_t>() + n,
-                           d_ngroups, err.as<uint32_t>(), words.as<uint64_t>());
-    }
+    hipLaunchKernelGGL(group_counts_kernel, grid_for(n + 1), dim3(256), 0, st, gstart.as<uint64_t>(), d_ngroups, n,
+                       g_nch.as<uint32_t>(), g_nhp.as<uint32_t>(), skey.as<uint64_t>(), d_nch.as<uint32_t>(),
+                       d_nhp.as<uint32_t>(), d_gkey.as<uint64_t>());
+    const size_t tbg = scan_counts_temp_bytes((uint32_t)(n + 1));
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nch.as<uint32_t>(), d_choff.as<uint64_t>(), (uint32_t)(n + 1)));
+    PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tbg, d_nhp.as<uint32_t>(), d_hpoff.as<uint64_t>(), (uint32_t)(n + 1)));
+    hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, d_choff.as<uint64_t>() + n, d_hpoff.as<uint64_t>() + n,
+                       d_ngroups, err.as<uint32_t>(), words.as<uint64_t>());
     // ---- round trip 1: the totals
     PGR_HIP(ctx, hipMemcpyAsync(mb, words.p, 32, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
@@ -1552,38 +1494,6 @@ __global__ void sum_ranges_kernel(const uint64_t *__restrict__ lo, const uint64_
     v = wave_incl_sum(v);  // few workgroups: same-address atomics run at ~88 per us on gfx950
     if ((threadIdx.x & 63) == 63 && v) atomicAdd(total, (unsigned long long)v);
 }
-// the same figures for small calls in ONE single-workgroup launch (instead of memset + sum_ranges + query_hit_max +
-// gather_words): words = {hits, looked-up signatures, most hits of one query, 0}
-__global__ __launch_bounds__(256) void query_stats_small_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
-                                                                uint64_t nq, const uint64_t *__restrict__ pair_off,
-                                                                const uint64_t *__restrict__ hit_off, uint32_t n_queries,
-                                                                uint64_t *__restrict__ words) {
-    __shared__ uint64_t s_sum[4], s_max[4];
-    uint64_t sum = 0, mx = 0;
-    for (uint64_t p = threadIdx.x; p < nq; p += 256) sum += hi[p] - lo[p];
-    for (uint32_t q = threadIdx.x; q < n_queries; q += 256) {
-        const uint64_t m = hit_off[pair_off[q + 1]] - hit_off[pair_off[q]];
-        mx = m > mx ? m : mx;
-    }
-    for (int off = 32; off; off >>= 1) {
-        sum += (uint64_t)__shfl_xor((unsigned long long)sum, off, 64);
-        const uint64_t o = (uint64_t)__shfl_xor((unsigned long long)mx, off, 64);
-        mx = o > mx ? o : mx;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        s_sum[threadIdx.x >> 6] = sum;
-        s_max[threadIdx.x >> 6] = mx;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t m = s_max[0];
-        for (int i = 1; i < 4; ++i) m = s_max[i] > m ? s_max[i] : m;
-        words[0] = hit_off[nq];
-        words[1] = s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
-        words[2] = m;
-        words[3] = 0;
-    }
-}
 }  // namespace
 
 // B2 on a resident batch of queries (the H2D of the ASCII queries already happened: pgr_batch_from_ascii)
@@ -1636,12 +1546,9 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
             return rc;
         hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
                            ix->key_off, ix->n_keys, ix->lut, ix->lut_bits, ix->lut_shift, lo.as<uint64_t>(), hi.as<uint64_t>());
-        const bool small_call = nq <= 65536 && n_queries <= 65536;  // statistics by one single-workgroup kernel further down
-        if (!small_call) {
-            PGR_HIP(ctx, hipMemsetAsync(nsig.p, 0, 16, st));
-            hipLaunchKernelGGL(sum_ranges_kernel, dim3((uint32_t)std::min<uint64_t>(64, (nq + 255) / 256)), dim3(256), 0, st,
-                               lo.as<uint64_t>(), hi.as<uint64_t>(), nq, nsig.as<unsigned long long>());
-        }
+        PGR_HIP(ctx, hipMemsetAsync(nsig.p, 0, 16, st));
+        hipLaunchKernelGGL(sum_ranges_kernel, dim3((uint32_t)std::min<uint64_t>(64, (nq + 255) / 256)), dim3(256), 0, st,
+                           lo.as<uint64_t>(), hi.as<uint64_t>(), nq, nsig.as<unsigned long long>());
         // per-query key multiplicities (aln.rs:180-181).  Queries of up to a few thousand pairs: every pair is compared
         // with the other pairs of its query (they are contiguous); longer ones: sort by (query, h0, h1), count runs
         if (max_pairs <= 4096) {
@@ -1668,16 +1575,11 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         uint64_t *mb = (uint64_t *)ctx->mailbox;
         Tmp words(ctx);
         if ((rc = words.alloc(32))) return rc;
-        // words: [0] hits, [1] looked-up signatures, [2] most hits of one query (decides how the hits are grouped, chain_hits)
-        if (small_call) {
-            hipLaunchKernelGGL(query_stats_small_kernel, dim3(1), dim3(256), 0, st, lo.as<uint64_t>(), hi.as<uint64_t>(), nq,
-                               (const uint64_t *)ctx->ws_rec_off.p, hoff.as<uint64_t>(), n_queries, words.as<uint64_t>());
-        } else {
-            hipLaunchKernelGGL(query_hit_max_kernel, grid_for(n_queries), dim3(256), 0, st, (const uint64_t *)ctx->ws_rec_off.p,
-                               hoff.as<uint64_t>(), n_queries, nsig.as<unsigned long long>() + 1);
-            hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, hoff.as<uint64_t>() + nq, nsig.as<uint64_t>(),
-                               nsig.as<uint64_t>() + 1, (const uint32_t *)nullptr, words.as<uint64_t>());
-        }
+        // nsig: [0] looked-up signatures, [1] most hits of one query (decides how the hits are grouped, chain_hits)
+        hipLaunchKernelGGL(query_hit_max_kernel, grid_for(n_queries), dim3(256), 0, st, (const uint64_t *)ctx->ws_rec_off.p,
+                           hoff.as<uint64_t>(), n_queries, nsig.as<unsigned long long>() + 1);
+        hipLaunchKernelGGL(gather_words_kernel, dim3(1), dim3(64), 0, st, hoff.as<uint64_t>() + nq, nsig.as<uint64_t>(),
+                           nsig.as<uint64_t>() + 1, (const uint32_t *)nullptr, words.as<uint64_t>());
         PGR_HIP(ctx, hipMemcpyAsync(mb, words.p, 32, hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));  // the number of hits sizes everything behind this point
         const uint64_t n_hits = mb[0];

@@ -54,7 +54,8 @@ struct pgr_shmmrs {
     uint32_t n = 0;
     uint64_t count = 0;
     pgr_mm128 *d_mm = nullptr;   // [count]
-    uint64_t *d_off = nullptr;   // [n+1]
+    uint64_t *d_off = nullptr;   // [n+1]; = d_block + a few status words in front (one D2H copy brings both)
+    uint64_t *d_block = nullptr; // the allocation d_off lives in
     std::vector<uint64_t> h_off; // [n+1]
     bool rid_is_index = false;   // MM128.y >> 32 is the contig index (no rids given, no padding sentinels)
     const pgr_mm128 *host_copy = nullptr;  // small results: already in the context's pinned buffer (valid until its next use)
