@@ -175,6 +175,7 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
     n_hps = int(len(r["hps"]))
     algo = 24.0 * n_hps + 0.25 * prof["query_bases"] + 17.0 * prof["n_signatures"]
     qk = committed("r02_query", "summary.json") or {}
+    qpmc = (committed("r02_query", "pmc_summary.json") or {}).get("per_query_batch", {})
     out = {
         "workload": "BASELINE.json configs[2]: %d x %d bp queries (50%% reverse complement) against the %d x %d bp index, "
                     "penalty 0.025, max counts 128, max_aln_span 8" % (nq, qlen, len(contig_ids), args.contig_len),
@@ -195,6 +196,7 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
         "roofline": {
             "bound": "hbm", "achieved": algo / t_res / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": algo / t_res / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": algo,
+            "traffic": qpmc.get("hbm_bytes"),  # HBM bytes per batch by PMC (profiles/r02_query/pmc_summary.json), all kernels
             "algorithmic_bytes_formula": "24 B x hit pairs emitted + 0.25 B x query bases + 17 B x looked-up signatures "
                                          "(SURVEY.md 8d); signatures counted on the device",
             "dominant_kernel": qk.get("dominant_kernel"), "dominant_kernel_ms": qk.get("dominant_kernel_ms"),

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the rocprofv3 evidence for bench.py on the GPU box (run through gpurun):
-#   tools/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write,pmc_sq,pmc_misc,q_trace}
+#   tools/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/{trace,pmc_fetch,pmc_write,pmc_sq,pmc_misc,q_trace,q_pmc_*}
 # Kernel trace/stats and every PMC group are SEPARATE runs (never --pmc together with tracing domains).
 set -u
 TAG=${1:-run}
@@ -17,5 +17,9 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_C
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
           --output-format csv -d $O/pmc_misc -o p -- $B > $O/pmc_misc.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/q_trace -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_trace.log 2>&1
+# the query leg's counters (separate passes as well): HBM bytes and VALU work per query batch
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/q_pmc_fetch -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/q_pmc_write -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_write.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/q_pmc_sq -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_sq.log 2>&1
 python $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 ls -R $O | head -40

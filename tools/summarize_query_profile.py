@@ -58,3 +58,40 @@ out = {"source": "rocprofv3 --kernel-trace of tools/query_leg.py (%d resident qu
 json.dump(out, open(os.path.join(dst, "summary.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
 print(open(os.path.join(dst, "kernel_stats.csv")).read()[:3000])
+
+# ---- counters of the same batches (optional: <src>/../q_pmc_{fetch,write,sq}): per query batch, summed over the kernels
+#      behind the 0.5 s gap; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB; gfx950 correction as in summarize_profile.py)
+pm = {}
+for d in ("q_pmc_fetch", "q_pmc_write", "q_pmc_sq"):
+    fs = glob.glob(os.path.join(os.path.dirname(src.rstrip("/")), d, "*counter_collection.csv"))
+    if not fs:
+        continue
+    rr = list(csv.DictReader(open(fs[0])))
+    rr.sort(key=lambda r: int(r["Start_Timestamp"]))
+    # the gap: largest distance between consecutive dispatches
+    gi, g = 0, 0
+    for i in range(1, len(rr)):
+        dd = int(rr[i]["Start_Timestamp"]) - int(rr[i - 1]["End_Timestamp"])
+        if dd > g:
+            g, gi = dd, i
+    qq = rr[gi:]
+    nb = max(1, len(set(r["Dispatch_Id"] for r in qq if "level1_tile_kernel" in r["Kernel_Name"])))
+    for r in qq:
+        k = short_name(r["Kernel_Name"])
+        e = pm.setdefault(k, {})
+        e[r["Counter_Name"]] = e.get(r["Counter_Name"], 0.0) + float(r["Counter_Value"]) / nb
+if pm:
+    tot = {}
+    for k, e in pm.items():
+        for c, v in e.items():
+            tot[c] = tot.get(c, 0.0) + v
+    hbm = (2.0 * tot.get("FETCH_SIZE", 0.0) + tot.get("WRITE_SIZE", 0.0)) * 1024.0
+    top = sorted(pm.items(), key=lambda kv: -(2.0 * kv[1].get("FETCH_SIZE", 0.0) + kv[1].get("WRITE_SIZE", 0.0)))[:12]
+    json.dump({"per_query_batch": {"hbm_bytes": hbm, "fetch_size_KiB_raw": tot.get("FETCH_SIZE"), "write_size_KiB": tot.get("WRITE_SIZE"),
+                                   "valu_wave_insts": tot.get("SQ_INSTS_VALU"), "waves": tot.get("SQ_WAVES"),
+                                   "lds_insts": tot.get("SQ_INSTS_LDS")},
+               "correction": "HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes), as for the tile kernel",
+               "kernels_by_hbm_bytes": [{"kernel": k, **{c: v for c, v in e.items()}} for k, e in top]},
+              open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+    print("pmc_summary.json: %.1f MB of HBM traffic per query batch" % (hbm / 1e6))
+
