@@ -97,6 +97,15 @@ __global__ __launch_bounds__(256) void sid_bound_kernel(const pgr_frag_rec *__re
     if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
+// keys[i] = (h0, h1) of key i
+__global__ void gather_keys_kernel(const pgr_frag_rec *__restrict__ recs, const uint64_t *__restrict__ key_off, uint64_t n_keys,
+                                   ulonglong2 *__restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_keys) return;
+    const pgr_frag_rec &r = recs[key_off[i]];
+    keys[i] = make_ulonglong2(r.h0, r.h1);
+}
+
 // lut[b] = first key whose bucket is >= b (b = 2^bits: n_keys); one thread per bucket
 __global__ void build_lut_kernel(const pgr_frag_rec *__restrict__ recs, const uint64_t *__restrict__ key_off, uint64_t n_keys,
                                  uint32_t bits, uint32_t shift, uint32_t *__restrict__ lut) {
@@ -197,6 +206,7 @@ extern "C" void pgr_index_destroy(pgr_index *ix) {
     ix->ctx->dfree(ix->recs);
     ix->ctx->dfree(ix->key_off);
     ix->ctx->dfree(ix->lut);
+    ix->ctx->dfree(ix->keys);
     delete ix;
 }
 
@@ -343,9 +353,11 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     ctx->dfree(ix->recs);
     ctx->dfree(ix->key_off);
     ctx->dfree(ix->lut);
+    ctx->dfree(ix->keys);
     ix->recs = nullptr;
     ix->key_off = nullptr;
     ix->lut = nullptr;
+    ix->keys = nullptr;
     ix->n = n;
     ix->n_keys = 0;
     int rc;
@@ -408,7 +420,10 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
         const unsigned hb = bits_for(h99 + 1);  // bits of the largest bucketed h0
         ix->lut_bits = bits;
         ix->lut_shift = hb > bits ? hb - bits : 0;
-        if ((rc = ctx->dmalloc((void **)&ix->lut, ((1ull << bits) + 1) * sizeof(uint32_t)))) return rc;
+        if ((rc = ctx->dmalloc((void **)&ix->lut, ((1ull << bits) + 1) * sizeof(uint32_t))) ||
+            (rc = ctx->dmalloc((void **)&ix->keys, n_keys * sizeof(ulonglong2))))
+            return rc;
+        hipLaunchKernelGGL(gather_keys_kernel, grid_for(n_keys), dim3(256), 0, st, ix->recs, ix->key_off, n_keys, ix->keys);
         hipLaunchKernelGGL(build_lut_kernel, grid_for((1ull << bits) + 1), dim3(256), 0, st, ix->recs, ix->key_off, n_keys, bits,
                            ix->lut_shift, ix->lut);
     }
@@ -445,8 +460,8 @@ namespace {
 // the binary search over all keys (25 dependent steps of two loads for 3x10^7 keys) down to the few keys of one bucket.
 __global__ void lookup_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, const pgr_frag_rec *__restrict__ recs,
                               const uint64_t *__restrict__ key_off, uint64_t n_keys, const uint32_t *__restrict__ lut,
-                              uint32_t lut_bits, uint32_t lut_shift, uint64_t *__restrict__ lo_out,
-                              uint64_t *__restrict__ hi_out) {
+                              uint32_t lut_bits, uint32_t lut_shift, const ulonglong2 *__restrict__ keys,
+                              uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nq) return;
     const uint64_t h0 = q[p].h0, h1 = q[p].h1;
@@ -457,18 +472,34 @@ __global__ void lookup_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, c
         lo = lut[bk];
         hi = lut[bk + 1];
     }
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        const pgr_frag_rec &r = recs[key_off[mid]];
-        if (r.h0 < h0 || (r.h0 == h0 && r.h1 < h1)) lo = mid + 1;
-        else hi = mid;
-    }
     uint64_t a = 0, b = 0;
-    if (lo < n_keys) {
-        const pgr_frag_rec &r = recs[key_off[lo]];
-        if (r.h0 == h0 && r.h1 == h1) {
-            a = key_off[lo];
-            b = key_off[lo + 1];
+    if (keys) {  // the bucket's keys by themselves: one or two cache lines for the whole search
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            const ulonglong2 kk = keys[mid];
+            if (kk.x < h0 || (kk.x == h0 && kk.y < h1)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < n_keys) {
+            const ulonglong2 kk = keys[lo];
+            if (kk.x == h0 && kk.y == h1) {
+                a = key_off[lo];
+                b = key_off[lo + 1];
+            }
+        }
+    } else {
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            const pgr_frag_rec &r = recs[key_off[mid]];
+            if (r.h0 < h0 || (r.h0 == h0 && r.h1 < h1)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < n_keys) {
+            const pgr_frag_rec &r = recs[key_off[lo]];
+            if (r.h0 == h0 && r.h1 == h1) {
+                a = key_off[lo];
+                b = key_off[lo + 1];
+            }
         }
     }
     lo_out[p] = a;
@@ -1545,7 +1576,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
             (rc = nh.alloc((nq + 1) * 4)) || (rc = hoff.alloc((nq + 1) * 8)) || (rc = nsig.alloc(16)))
             return rc;
         hipLaunchKernelGGL(lookup_kernel, grid_for(nq), dim3(256), 0, st, qrec.as<pgr_frag_rec>(), nq, ix->recs,
-                           ix->key_off, ix->n_keys, ix->lut, ix->lut_bits, ix->lut_shift, lo.as<uint64_t>(), hi.as<uint64_t>());
+                           ix->key_off, ix->n_keys, ix->lut, ix->lut_bits, ix->lut_shift, ix->keys, lo.as<uint64_t>(), hi.as<uint64_t>());
         PGR_HIP(ctx, hipMemsetAsync(nsig.p, 0, 16, st));
         hipLaunchKernelGGL(sum_ranges_kernel, dim3((uint32_t)std::min<uint64_t>(64, (nq + 255) / 256)), dim3(256), 0, st,
                            lo.as<uint64_t>(), hi.as<uint64_t>(), nq, nsig.as<unsigned long long>());

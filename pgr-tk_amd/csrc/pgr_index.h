@@ -18,6 +18,9 @@ struct pgr_index {
     // lut[2^lut_bits] = n_keys.  A lookup searches one bucket (a few keys) instead of all n_keys.  nullptr: no table.
     uint32_t *lut = nullptr;
     uint32_t lut_bits = 0, lut_shift = 0;
+    // the keys by themselves ((h0, h1) per key, 16 B each, same order as key_off): the few keys of a bucket share one or two
+    // cache lines, a search step does not have to go through key_off into the 40-byte records.  nullptr: no table.
+    ulonglong2 *keys = nullptr;
     bool finalized = false;
     uint32_t next_sid = 0;
     uint64_t sid_bound = 0;  // max(sid) + 1 over the finalized records (0: unknown)
