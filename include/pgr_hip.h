@@ -185,7 +185,9 @@ int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs,
  * contiguous and in position order (what pgr_shmmrs_compute produces with rids = global ids); the pair records
  * (seq_db.rs:381-400) are derived on the GPU.  mm is a host or a DEVICE pointer. */
 int pgr_index_add_shmmrs(pgr_ctx *ctx, pgr_index *ix, const pgr_mm128 *mm, uint64_t n, int mm_on_device);
-int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix); /* sort -> CSR (GPU) */
+/* sort -> CSR (GPU).  Also builds the lookup side tables of the query path: a bucket table over the keys and the keys by
+ * themselves (16 B per distinct key + 4 B per bucket, ~0.5 GB for the 3x10^7 keys of a 10 Gbp index). */
+int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix);
 uint64_t pgr_index_n_keys(const pgr_index *ix);
 uint64_t pgr_index_n_records(const pgr_index *ix);
 /* host copy of the sorted records (pgr_free) */
