@@ -398,7 +398,11 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
 
     uint64_t next_region = region_base;
     for (int round = 0; !todo.empty(); ++round) {
-        if (round > 200) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
+        // Every round settles at least one seam or grows / merges an island, so the number of rounds is bounded by the number
+        // of chunks plus the growth steps.  Inside a long run of non-ACGT bytes the machine carries the k-mer from BEFORE the
+        // run (shmmrutils.rs:461-476), which no warm-up inside the run can reproduce: the true state then travels down the
+        // run one chunk per round (an 18 Mbp N run of a reference chromosome: ~550 rounds of ~0.15 ms).
+        if (round > 1024 + 4 * (int)ch.size()) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
         const size_t nq = todo.size();
         std::vector<ChunkDesc> descs(nq);
         for (size_t q = 0; q < nq; ++q) {

@@ -86,6 +86,23 @@ def test_large_batch_with_islands_is_exact(oracle, gpu_ctx, monkeypatch, early_b
         assert np.array_equal(sums[i], oracle.shmmr_checksum(refs[i])), i
 
 
+def test_multi_mbp_run_of_n_inside_a_contig(oracle, gpu_ctx):
+    """a 7 Mbp run of N inside a 24 Mbp contig (reference chromosomes carry such gaps): fewer than a third of the tiles are
+    irregular, so the run becomes an island of ~215 chunks; inside the run the machine carries the k-mer from before it, every
+    seam has to be corrected with the true state of the chunk in front, one per round -- found by the fuzzer when the number
+    of rounds was capped at 200"""
+    import pgrtk_amd as P
+    s = oracle.synth_contig(21, 0, 24_000_000).copy()
+    s[9_000_000:16_000_000] = ord("N")
+    t = oracle.synth_contig(21, 1, 3_000_000).copy()
+    sh = P.Batch.from_seqs([s, t], ctx=gpu_ctx).shmmrs(P.make_spec())
+    sums, off = sh.checksum(), sh.offsets()
+    for i, q in enumerate((s, t)):
+        ref = oracle.sequence_to_shmmrs(i, q, oracle.spec())
+        assert int(off[i + 1] - off[i]) == len(ref), i
+        assert np.array_equal(sums[i], oracle.shmmr_checksum(ref)), i
+
+
 def test_shmmrs_checksum_matches_the_checker(oracle, gpu_ctx):
     import pgrtk_amd as P
     lens = [300_000, 0, 5_000, 1_000_000, 80]

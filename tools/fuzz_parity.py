@@ -64,7 +64,10 @@ def main():
                 log.seek(0)
                 log.write("%d\n" % (seed0 + it))
                 log.flush()
-            r = one_case(seed0 + it, max_len, ctx, pool)
+            try:
+                r = one_case(seed0 + it, max_len, ctx, pool)
+            except Exception as e:  # an error code from the library is a failure of that case, not the end of the campaign
+                r = "seed %d: %r" % (seed0 + it, e)
             if isinstance(r, str):
                 fails.append(r)
                 print("FAIL", r, flush=True)
