@@ -878,7 +878,30 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         if (wj + 1 < nwords) v_lo = vplane[wj + 1];
         const uint64_t V = ((uint64_t)v_hi << 32) | v_lo;
         const bool kmer_only = base < pm;
-        if (kmer_only && V == 0) continue;  // nothing touches the k-mer here (shmmrutils.rs:461-476)
+        if (kmer_only && V == 0) {
+            // nothing touches the k-mer here (shmmrutils.rs:461-476).  Inside a long run of non-ACGT bytes (a chunk deep in
+            // an 18 Mbp gap of a reference chromosome rolls from the last k valid bases in FRONT of the gap): jump to the
+            // next block of 64 positions that holds a valid base, 64 blocks per step, instead of visiting every block
+            long long nb = base + 64;
+            while (nb < pm) {
+                const long long bl = nb + 64ll * lane;
+                uint32_t any = 0;
+                if (bl < pm) {
+                    const long long w2 = bl >> 5;
+                    any = vplane[w2];
+                    if (w2 + 1 < nwords) any |= vplane[w2 + 1];
+                }
+                const uint64_t m = __ballot(any != 0u);
+                if (m) {
+                    nb += 64ll * ((long long)__ffsll((unsigned long long)m) - 1);
+                    break;
+                }
+                nb += 64ll * 64;
+            }
+            if (nb > pm) nb = pm;  // (pm and base are congruent mod 64)
+            base = nb - 64;
+            continue;
+        }
         uint2 p_hi = planes[wj], p_lo = make_uint2(0, 0);
         if (wj + 1 < nwords) p_lo = planes[wj + 1];
         const uint64_t P0 = ((uint64_t)p_hi.x << 32) | p_lo.x;  // position base+i at bit 63-i
