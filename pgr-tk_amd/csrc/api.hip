@@ -376,6 +376,9 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             if (j + 1 == nch && is.E < L) h.d.drain_end = std::min<uint64_t>(L, is.E + 320);
             h.d.seg = seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, h.d.cs / tc);
             h.d.warm = 256;
+            // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
+            // (ties, shmmrutils.rs:516-527), the sparse region estimate would overflow and the chunk run twice
+            h.full_cap = nch >= 8;
             todo.push_back(ch.size());
             ch.push_back(h);
         }

@@ -918,6 +918,12 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             F1 = shfl64(f1, 63);
             R0 = shfl64(r0, 63);
             R1 = shfl64(r1, 63);
+        } else if (V == 0) {
+            // no valid base in the block (inside a run of N): the k-mer stays what it was for all 64 positions
+            f0 = F0;
+            f1 = F1;
+            r0 = R0;
+            r1 = R1;
         } else {
             // bytes outside ACGT do not touch the k-mer (shmmrutils.rs:461-476): roll uniformly
             f0 = f1 = r0 = r1 = 0;
