@@ -410,6 +410,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         std::vector<ChunkDesc> descs(nq);
         for (size_t q = 0; q < nq; ++q) {
             HChunk &h = ch[todo[q]];
+            h.d.ring_out = h.probe ? 0xFFFFFFFFu : (uint32_t)todo[q];
+            if (!h.d.override_state) h.d.ring_in = 0xFFFFFFFFu;
             h.d.region_off = next_region;
             h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
             next_region += h.d.region_cap;
@@ -425,7 +427,9 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         uint32_t *d_stat = (uint32_t *)(d_out + nq);
         PGR_HIP(ctx, hipMemcpyAsync(d_desc, descs.data(), nq * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
         PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
-        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat);
+        // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
+        if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
+        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p);
         std::vector<ChunkState> r_in(nq), r_out(nq);
         std::vector<uint32_t> r_stat(nq);
         PGR_HIP(ctx, hipMemcpyAsync(r_in.data(), d_in, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
@@ -487,6 +491,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
                 if (memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
                     h.d.override_state = 1;
                     h.d.in_state = s_out[i - 1];
+                    h.d.ring_in = (uint32_t)(i - 1);  // the ring the chunk in front left at its end
                     h.d.warm = 1024;
                     again = true;
                 }

@@ -768,7 +768,7 @@ __device__ __forceinline__ uint64_t ring_signature(const uint64_t *s_rx, uint32_
 __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkDesc *__restrict__ descs,
                                                           ChunkState *__restrict__ st_in,
                                                           ChunkState *__restrict__ st_out,
-                                                          uint32_t *__restrict__ status) {
+                                                          uint32_t *__restrict__ status, uint64_t *__restrict__ rings) {
     __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
     const uint32_t lane = threadIdx.x;
     const ChunkDesc cd = descs[blockIdx.x];
@@ -835,6 +835,20 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     ChunkState o_out;
     auto seam = [&]() {
             // seam: record the warmed-up state, or install the true state handed over by the host
+            if (cd.override_state && cd.ring_in != 0xFFFFFFFFu && !a.sketch) {
+                // the ring the chunk in front left at its end (push order): inside a stretch of skipped pushes the ring
+                // still holds what was pushed in front of the stretch, which no warm-up inside it can rebuild
+                const uint64_t *rg = rings + (size_t)cd.ring_in * CHUNK_RING_WORDS;
+                __syncthreads();
+                s_rx[lane] = rg[lane];
+                s_rx[lane + 64] = rg[lane + 64];
+                s_ry[lane] = rg[128 + lane];
+                s_ry[lane + 64] = rg[128 + lane + 64];
+                rlen = (uint32_t)rg[256];
+                rstart = 0;
+                rend = rlen % w;
+                __syncthreads();
+            }
             const uint64_t sig = ring_signature(s_rx, rstart, rlen, w, lane);
             if (cd.override_state) {
                 const ChunkState t = cd.in_state;
@@ -857,9 +871,20 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 st_in[blockIdx.x] = o;
             }
         };
+    auto leave_ring = [&]() {  // the ring at the end of the by-step range, in push order, for the chunk behind this one
+        if (cd.ring_out == 0xFFFFFFFFu || a.sketch) return;
+        uint64_t *rg = rings + (size_t)cd.ring_out * CHUNK_RING_WORDS;
+        const uint32_t q0 = lane, q1 = lane + 64;
+        rg[q0] = q0 < w ? s_rx[(rstart + q0) % w] : U64MAX;
+        rg[q1] = q1 < w ? s_rx[(rstart + q1) % w] : U64MAX;
+        rg[128 + q0] = q0 < w ? s_ry[(rstart + q0) % w] : U64MAX;
+        rg[128 + q1] = q1 < w ? s_ry[(rstart + q1) % w] : U64MAX;
+        if (lane == 0) rg[256] = rlen;
+    };
     for (long long base = pk; base < drain_end; base += 64) {
         if (base >= ce && !out_captured) {
             // end of the by-step range: this is the state the next chunk / the island-end probe must match
+            leave_ring();
             sig_out = ring_signature(s_rx, rstart, rlen, w, lane);
             o_out.min_x = a.sketch ? 0 : min_x;
             o_out.min_y = a.sketch ? 0 : min_y;
@@ -1108,6 +1133,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     if (cs > 0 && cs >= drain_end) seam();  // probe: nothing to emit, only the warmed-up state at cs
     // ---- state at the end of the by-step range (the next chunk's seam) and the segment entry
     if (!out_captured) {
+        leave_ring();
         sig_out = ring_signature(s_rx, rstart, rlen, w, lane);
         o_out.min_x = a.sketch ? 0 : min_x;
         o_out.min_y = a.sketch ? 0 : min_y;
@@ -1206,9 +1232,9 @@ void launch_level1_tails(hipStream_t st, const L1Args &a) {
     hipLaunchKernelGGL(level1_tail_kernel, dim3(a.n_contigs), dim3(64), 0, st, a);
 }
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
-                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status) {
+                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings) {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status);
+    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings);
 }
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges) {
     if (n_ranges == 0) return;

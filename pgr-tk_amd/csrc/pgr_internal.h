@@ -103,7 +103,12 @@ struct ChunkDesc {
     uint32_t warm;            // machine warm-up positions before cs (multiple of 64)
     uint32_t override_state;  // 1: install in_state at cs instead of trusting the warm-up
     ChunkState in_state;
+    // ring buffer hand-over (slots of CHUNK_RING_WORDS u64 in a device array): the chunk leaves its ring at ce in ring_out;
+    // with override_state it takes the ring of the chunk in front from ring_in (0xFFFFFFFF: keep the warmed-up ring) --
+    // inside a stretch of skipped pushes (palindromic k-mers, shmmrutils.rs:477-480) no warm-up can rebuild it
+    uint32_t ring_in, ring_out;
 };
+constexpr uint32_t CHUNK_RING_WORDS = 2 * 128 + 1;  // x[128], y[128] in push order, fill
 struct L1Args {
     BatchDev b;
     uint32_t n_contigs;
@@ -127,7 +132,7 @@ void launch_level1_tiles(hipStream_t st, const L1Args &a);
 void launch_level1_tails(hipStream_t st, const L1Args &a);
 // exact state machine, one wavefront per chunk; status bit0 = region overflow, bit1 = override impossible
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
-                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status);
+                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings);
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list);
 // seg_cnt[s] = 0 for s in [ranges[2i], ranges[2i+1])
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges);

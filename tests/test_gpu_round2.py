@@ -103,6 +103,28 @@ def test_multi_mbp_run_of_n_inside_a_contig(oracle, gpu_ctx):
         assert np.array_equal(sums[i], oracle.shmmr_checksum(ref)), i
 
 
+def test_long_palindromic_stretch_stays_an_island(oracle, gpu_ctx):
+    """120 kbp of (AT)n and 70 kbp of (ACGT)n inside 6 Mbp contigs: every k-mer there is its own reverse complement and is not
+    pushed (shmmrutils.rs:477-480), so the ring buffer keeps what was pushed in FRONT of the stretch and no warm-up inside it can
+    rebuild that.  The chunks of the island hand their ring over (one per round); before, the whole contig fell back to ONE
+    serial chunk (1.2 s for 30 Mbp, found with tools/repeat_like_bench.py)"""
+    import pgrtk_amd as P
+    seqs = []
+    for i, (unit, n) in enumerate(((b"AT", 120_000), (b"ACGT", 70_000))):
+        s = oracle.synth_contig(23, i, 6_000_000).copy()
+        rep = np.frombuffer(unit * (n // len(unit)), dtype=np.uint8)
+        s[2_500_000:2_500_000 + len(rep)] = rep
+        seqs.append(s)
+    sh = P.Batch.from_seqs(seqs, ctx=gpu_ctx).shmmrs(P.make_spec())
+    prof = gpu_ctx.last_prof()
+    assert prof.n_serial_contigs == 2 and prof.exact_bases < 600_000  # islands around the stretches, not whole contigs
+    sums, off = sh.checksum(), sh.offsets()
+    for i, q in enumerate(seqs):
+        ref = oracle.sequence_to_shmmrs(i, q, oracle.spec())
+        assert int(off[i + 1] - off[i]) == len(ref), i
+        assert np.array_equal(sums[i], oracle.shmmr_checksum(ref)), i
+
+
 def test_shmmrs_checksum_matches_the_checker(oracle, gpu_ctx):
     import pgrtk_amd as P
     lens = [300_000, 0, 5_000, 1_000_000, 80]
