@@ -546,50 +546,91 @@ struct QParams {
 
 // aln.rs:197-228: number of hits a query pair contributes (mode 0) or the hits themselves (mode 1).
 // Records of one key are sorted by sid, so target_shmer_pair_count[(key,sid)] = count * run length.
-__global__ void hits_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, const uint32_t *__restrict__ count,
-                            const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi,
-                            const pgr_frag_rec *__restrict__ recs, QParams prm, int mode, uint32_t *__restrict__ n_hits,
-                            const uint64_t *__restrict__ hit_off, uint64_t *__restrict__ hit_key,
-                            pgr_hitpair *__restrict__ hit_hp) {
+// A pair whose key holds up to HITS_HEAVY records is walked by its own thread.  A key of a repeat can hold 10^5 records in a
+// pangenome index (a serial thread pays ~0.4 us per record): those pairs are taken by the whole wavefront afterwards, 64
+// records per step -- a lane at the start of a sid run finds the run's end by binary search (the run either passes the
+// target filter as a whole, and is then at most max_count_target long, or is skipped as a whole).
+constexpr uint64_t HITS_HEAVY = 64;
+
+__device__ __forceinline__ void emit_hit(const pgr_frag_rec &qp, const pgr_frag_rec &r, uint64_t o, uint64_t *__restrict__ hit_key,
+                                         pgr_hitpair *__restrict__ hit_hp) {
+    pgr_hitpair h;
+    h.qb = qp.bgn;
+    h.qe = qp.end;
+    h.qo = qp.orient;
+    h.tb = r.bgn;
+    h.te = r.end;
+    h.to = r.orient;
+    hit_hp[o] = h;
+    hit_key[o] = ((uint64_t)qp.sid << 32) | r.sid;  // (query, target)
+}
+
+__global__ __launch_bounds__(256) void hits_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq,
+                                                   const uint32_t *__restrict__ count, const uint64_t *__restrict__ lo,
+                                                   const uint64_t *__restrict__ hi, const pgr_frag_rec *__restrict__ recs,
+                                                   QParams prm, int mode, uint32_t *__restrict__ n_hits,
+                                                   const uint64_t *__restrict__ hit_off, uint64_t *__restrict__ hit_key,
+                                                   pgr_hitpair *__restrict__ hit_hp) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p > nq) return;
-    if (p == nq) {
-        if (mode == 0) n_hits[nq] = 0;
-        return;
-    }
-    const uint32_t c = count[p];
+    const uint32_t lane = threadIdx.x & 63;
+    // (no early return: the lanes of a wavefront work together on its heavy pairs below)
+    if (p == nq && mode == 0) n_hits[nq] = 0;
+    const bool live = p < nq;
+    const uint32_t c = live ? count[p] : 0;
+    const bool pass = live && c <= prm.max_count && c <= prm.max_count_query;
+    const uint64_t s0 = pass ? lo[p] : 0, e0 = pass ? hi[p] : 0;
+    const bool heavy = e0 - s0 > HITS_HEAVY;
     uint32_t n = 0;
-    uint64_t o = mode ? hit_off[p] : 0;
-    if (c <= prm.max_count && c <= prm.max_count_query) {
+    if (pass && !heavy) {
         const pgr_frag_rec qp = q[p];
-        uint64_t s = lo[p];
-        const uint64_t e = hi[p];
-        while (s < e) {
+        uint64_t o = mode ? hit_off[p] : 0;
+        uint64_t s = s0;
+        while (s < e0) {
             const uint32_t sid = recs[s].sid;
             uint64_t t = s + 1;
-            while (t < e && recs[t].sid == sid) ++t;
-            const uint64_t tcount = (uint64_t)(t - s) * c;
-            if (tcount <= prm.max_count_target) {
-                if (mode) {
-                    for (uint64_t u = s; u < t; ++u) {
-                        pgr_hitpair h;
-                        h.qb = qp.bgn;
-                        h.qe = qp.end;
-                        h.qo = qp.orient;
-                        h.tb = recs[u].bgn;
-                        h.te = recs[u].end;
-                        h.to = recs[u].orient;
-                        hit_hp[o] = h;
-                        hit_key[o] = ((uint64_t)qp.sid << 32) | sid;  // (query, target)
-                        ++o;
-                    }
-                }
+            while (t < e0 && recs[t].sid == sid) ++t;
+            if ((uint64_t)(t - s) * c <= prm.max_count_target) {
+                if (mode)
+                    for (uint64_t u = s; u < t; ++u) emit_hit(qp, recs[u], o++, hit_key, hit_hp);
                 n += (uint32_t)(t - s);
             }
             s = t;
         }
     }
-    if (mode == 0) n_hits[p] = n;
+    for (uint64_t hm = __ballot(heavy); hm; hm &= hm - 1) {  // wave-uniform loop over the heavy pairs of these 64
+        const int src = __builtin_ctzll(hm);
+        const uint64_t ps = shfl64(s0, src), pe = shfl64(e0, src);
+        const uint32_t pc = (uint32_t)__shfl((int)c, src, 64);
+        const uint64_t pp = p - lane + (uint64_t)src;  // index of that pair
+        const pgr_frag_rec qp = q[pp];
+        uint64_t kept = 0;  // kept records of the pair so far (all lanes hold the same value)
+        const uint64_t obase = mode ? hit_off[pp] : 0;
+        for (uint64_t b0 = ps; b0 < pe; b0 += 64) {
+            const uint64_t u = b0 + lane;
+            uint32_t run = 0;  // > 0: a sid run that passes the filter starts at u and is `run` records long
+            if (u < pe) {
+                const uint32_t sid = recs[u].sid;
+                if (u == ps || recs[u - 1].sid != sid) {
+                    uint64_t a = u + 1, bnd = pe;  // first index in (u, pe] whose sid differs (sids ascend inside a key)
+                    while (a < bnd) {
+                        const uint64_t mid = (a + bnd) >> 1;
+                        if (recs[mid].sid == sid) a = mid + 1;
+                        else bnd = mid;
+                    }
+                    const uint64_t len = a - u;
+                    if (len * pc <= prm.max_count_target) run = (uint32_t)len;
+                }
+            }
+            const uint32_t incl = wave_incl_sum(run);
+            if (mode && run) {
+                uint64_t o = obase + kept + (incl - run);
+                for (uint32_t k = 0; k < run; ++k) emit_hit(qp, recs[u + k], o++, hit_key, hit_hp);
+            }
+            kept += (uint32_t)__shfl((int)incl, 63, 64);
+        }
+        if ((int)lane == src) n = (uint32_t)kept;
+    }
+    if (mode == 0 && live) n_hits[p] = n;
 }
 
 // field 0: qb, 1: the group key (query << 32 | sid) squeezed to (query << sid_bits | sid): fewer radix passes

@@ -486,3 +486,29 @@ def test_index_sort_shortcut_equals_full_sort(gpu_ctx, monkeypatch):
     for order, full in [(range(6), False), ([3, 1, 5, 0, 2, 4], False), ([5, 4, 3, 2, 1, 0], True)]:
         got = build(order, full)
         assert np.array_equal(got, ref), (list(order), full)
+
+
+@pytest.mark.parametrize("max_target", [128, 20, 4000])
+def test_query_through_a_repeat_heavy_keys(oracle, gpu_ctx, max_target):
+    """the shimmer pairs of a repeat unit that 300 sequences share are keys with hundreds of records (more than HITS_HEAVY = 64):
+    the wavefront takes such keys 64 records per step (runs of one sid pass or fail the target filter as a whole); against
+    the checker, with three settings of the target filter"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(3)
+    unit = seqgen.rnd(rng, 600)
+    seqs = [seqgen.rnd(rng, 2500) + unit * 25 + seqgen.rnd(rng, 2500) for _ in range(300)]
+    queries = [seqs[17][500:2500] + unit * 5 + seqs[17][-2500:-300], unit * 3 + seqs[5][-2500:], seqs[9][:3000]]
+    ix = P.Index(P.make_spec(), ctx=gpu_ctx)
+    ix.add_seqs(seqs)
+    ix.finalize()
+    got = ix.query_hps_raw(queries, 0.025, 128, 128, max_target)
+    oix = oracle.Index(oracle.spec())
+    for sid, s in enumerate(seqs):
+        oix.add_seq(sid, s)
+    n_targets = 0
+    for qi, q in enumerate(queries):
+        ref = oix.query_fragment_to_hps(q, 0.025, 128, 128, max_target)
+        assert sorted(_raw_to_lists(got, qi)) == sorted(ref), qi
+        n_targets += len(ref)
+    assert gpu_ctx.last_query_prof()["n_signatures"] > 300
+    assert n_targets >= 100
