@@ -405,8 +405,8 @@ def pcie_bench(P, ctx, spec, args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)  # the first launches run at ramping clocks
     ap.add_argument("--contigs", type=int, default=1000, help="contigs per GPU (weak scaling) / in total (--strong)")
     ap.add_argument("--contig-len", type=int, default=10_000_000)
     ap.add_argument("--seed", type=int, default=2)
