@@ -149,8 +149,8 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
     # (a) the metric's convention: inputs resident in HBM when the timed region starts
     qb = P.Batch.from_seqs(qs, ctx=ctx)
     ctx.synchronize()
-    # timed: the C entry point + pgr_hps_result_free, i.e. what a compiled host pays; the Python binding's copy of the result
-    # into numpy arrays is reported next to it (python_binding_s) and never part of the metric
+    # timed: the C entry point + pgr_hps_result_free, i.e. what a compiled host pays; the same call through the Python binding
+    # (numpy views of the result block, released with the last view) is reported next to it (python_binding_s)
     t_py, _, r = med3(lambda: ix.query_hps_resident_raw(qb, 0.025))
     t_res, reps_res, _ = med3(lambda: ix.time_query_resident(qb, 0.025)[0])
     prof = ctx.last_query_prof()

@@ -197,6 +197,19 @@ def frag_recs_batch(seqs, spec, sids=None, query_side=False, ctx=None):
     return [recs[int(off[i]):int(off[i + 1])] for i in range(n)]
 
 
+class _HpsOwner:
+    """owns one pgr_hps_result: releases the library's block when the last view of it is gone"""
+
+    def __init__(self, res):
+        self._res = res
+
+    def __del__(self):
+        try:
+            lib().pgr_hps_result_free(C.byref(self._res))
+        except Exception:
+            pass
+
+
 class Index:
     """ShmmrToFrags on the GPU (pgr_index): sorted CSR of fragment signatures + the query entry point."""
 
@@ -308,20 +321,25 @@ class Index:
 
     @staticmethod
     def _unpack_raw(res, n):
+        """numpy VIEWS of the library's result block (no copies: the hit pairs of a 10 000-query batch are 7 MB); the block is
+        released (pgr_hps_result_free) when the last of the arrays is garbage collected"""
         nt, nc, nh = int(res.n_targets), int(res.n_chains), int(res.n_hps)
-        out = {
-            "q_off": np.ctypeslib.as_array(res.q_off, shape=(n + 1,)).copy(),
-            "t_sid": np.ctypeslib.as_array(res.t_sid, shape=(max(nt, 1),))[:nt].copy(),
-            "t_off": np.ctypeslib.as_array(res.t_off, shape=(nt + 1,)).copy(),
-            "c_score": np.ctypeslib.as_array(res.c_score, shape=(max(nc, 1),))[:nc].copy(),
-            "c_off": np.ctypeslib.as_array(res.c_off, shape=(nc + 1,)).copy(),
-            "hps": np.zeros(nh, dtype=_ffi.HITPAIR),
+        owner = _HpsOwner(res)
+
+        def view(ptr, count, dtype):
+            dtype = np.dtype(dtype)
+            if count == 0 or not ptr:
+                return np.zeros(0, dtype=dtype)
+            buf = (C.c_char * (count * dtype.itemsize)).from_address(C.cast(ptr, C.c_void_p).value)
+            buf._owner = owner  # the array's base keeps the ctypes buffer alive, the buffer keeps the C block alive
+            a = np.frombuffer(buf, dtype=dtype)
+            a.flags.writeable = False
+            return a
+        return {
+            "q_off": view(res.q_off, n + 1, "<u8"), "t_sid": view(res.t_sid, nt, "<u4"), "t_off": view(res.t_off, nt + 1, "<u8"),
+            "c_score": view(res.c_score, nc, "<f4"), "c_off": view(res.c_off, nc + 1, "<u8"),
+            "hps": view(res.hps, nh, _ffi.HITPAIR), "n_nonterminating": int(res.n_nonterminating),
         }
-        if nh:
-            C.memmove(out["hps"].ctypes.data, res.hps, nh * _ffi.HITPAIR.itemsize)
-        out["n_nonterminating"] = int(res.n_nonterminating)
-        lib().pgr_hps_result_free(C.byref(res))
-        return out
 
     def close(self):
         if self._h:

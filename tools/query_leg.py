@@ -47,7 +47,7 @@ def main():
     print("stages of the last batch: " + ", ".join("%s %.3f" % (k, p[k]) for k in ("shmmr_ms", "lookup_ms", "chain_ms", "result_ms", "total_ms")))
     t0 = time.perf_counter()
     r = ix.query_hps_resident_raw(qb, 0.025)
-    print("through the Python binding (+ numpy copies of the result): %.3f ms" % ((time.perf_counter() - t0) * 1e3))
+    print("through the Python binding (numpy views of the result block): %.3f ms" % ((time.perf_counter() - t0) * 1e3))
 
 
 if __name__ == "__main__":
