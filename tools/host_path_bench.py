@@ -1,5 +1,5 @@
 """PCIe-inclusive rate of the B1 drop-in (pgr_shmmr_batch: host ASCII in, host MM128 out), timed at the C ABI (what a
-Rust caller sees) and through the Python convenience (which copies the result once more into numpy).
+Rust caller sees) and through the Python convenience (the result becomes a numpy view of the library's buffer).
 Not the bench metric (bench.py times resident inputs); quoted in DESIGN.md section 5."""
 import ctypes as C
 import os
@@ -39,7 +39,7 @@ print("pgr_shmmr_batch at the C ABI (host ASCII -> host MM128), %d x %d bp: %.1f
 t0 = time.perf_counter()
 out = P.sequence_to_shmmrs_batch(seqs, sp, ctx=ctx)
 dt = time.perf_counter() - t0
-print("through the Python convenience (+ one numpy copy of the result): %.1f ms = %.1f Gbp/s" % (dt * 1e3, n * L / dt / 1e9))
+print("through the Python convenience (a numpy view of the result buffer): %.1f ms = %.1f Gbp/s" % (dt * 1e3, n * L / dt / 1e9))
 t0 = time.perf_counter()
 b = P.Batch.from_seqs(seqs, ctx=ctx)
 t1 = time.perf_counter()
