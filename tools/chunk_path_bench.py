@@ -1,5 +1,7 @@
+import os
 import sys, time
-sys.path.insert(0, "/root/repo/pgr-tk_amd"); sys.path.insert(0, "/root/repo/oracle")
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "pgr-tk_amd")); sys.path.insert(0, os.path.join(_R, "oracle"))
 import numpy as np, pgrtk_amd as P, oracle as O
 ctx = P.default_context(0)
 import os

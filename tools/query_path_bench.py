@@ -1,7 +1,9 @@
+import os
 """breakdown of the query leg (configs[2] shape at reduced index size): where the time of
 pgr_query_hps_batch goes.  Run under rocprofv3 --kernel-trace --stats for the kernel view."""
 import sys, time
-sys.path.insert(0, "/root/repo/pgr-tk_amd"); sys.path.insert(0, "/root/repo")
+_R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_R, "pgr-tk_amd")); sys.path.insert(0, _R)
 import numpy as np, pgrtk_amd as P
 from bench import synth_substrings
 ctx = P.default_context(0)
