@@ -98,12 +98,38 @@ int pgr_frag_recs_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n_seqs,
                         const uint8_t *const *seqs, const uint64_t *lens, const uint32_t *sids,
                         int query_side, pgr_frag_rec **out_recs, uint64_t **out_off);
 
+/* ------------------------------------------------------------------ packed host input
+ * "pack ASCII -> 2-bit + N-mask (or accept pre-packed)".  A host that keeps -- or
+ * produces -- its sequences 2-bit packed hands them over in the layout pgr_batch keeps in HBM, and 0.25 B per base
+ * (0.375 with a validity plane) cross PCIe instead of 1 B:
+ *   contig c owns words [woff[c], woff[c+1]),  woff[c] = sum_{i<c} ceil(lens[i] / 32)   (pgr_packed_words = woff[n])
+ *   word j of a contig holds bases 32j .. 32j+31, base i at bit 31 - (i % 32)  (MSB first: a k-mer's fmmer.0 / fmmer.1,
+ *   shmmrutils.rs:462-467, is a plain bit field of consecutive words)
+ *   planes[w] = low bits of the 2-bit codes | high bits << 32    (A/a/0 -> 0, C/c/1 -> 1, G/g/2 -> 2, T/t/3 -> 3,
+ *                                                                  shmmrutils.rs:426-436)
+ *   valid[w]  = bit set: the byte was a base; NULL: every base of every contig is valid
+ * Bits past a contig's end and plane bits of invalid positions are ignored (cleaned on the device).
+ * pgr_pack_ascii is the library's own threaded CPU packer (AVX2 when the CPU has it; no GPU involved): ASCII contigs ->
+ * planes / valid arrays of pgr_packed_words(n, lens) words each; n_threads <= 0: all CPUs the process may use;
+ * *n_invalid (may be NULL) = number of non-ACGT bytes.  pgr_shmmr_batch / pgr_batch_from_ascii use the same packer
+ * internally, writing straight into their pinned staging windows. */
+uint64_t pgr_packed_words(uint32_t n_seqs, const uint64_t *lens);
+int pgr_pack_ascii(uint32_t n_seqs, const uint8_t *const *seqs, const uint64_t *lens, int n_threads, uint64_t *planes,
+                   uint32_t *valid, uint64_t *n_invalid);
+/* B1 with packed input: everything else as pgr_shmmr_batch */
+int pgr_shmmr_batch_packed(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n_seqs, const uint64_t *lens,
+                           const uint64_t *planes, const uint32_t *valid, const uint32_t *rids, int padding,
+                           pgr_mm128 **out_mm, uint64_t **out_off);
+
 /* ------------------------------------------------------------------ device-resident path
  * (what bench.py times: inputs already in HBM, results left in HBM)                        */
 
-/* H2D + ASCII -> 2-bit planes (+ validity plane) */
+/* ASCII -> 2-bit planes + validity plane (host threads, into pinned windows) + H2D */
 int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n_seqs, const uint8_t *const *seqs,
                          const uint64_t *lens, pgr_batch **out);
+/* H2D of packed planes (layout above) */
+int pgr_batch_from_packed(pgr_ctx *ctx, uint32_t n_seqs, const uint64_t *lens, const uint64_t *planes,
+                          const uint32_t *valid, pgr_batch **out);
 /* counter-based synthetic contigs generated on the device:
  * base(c,i) = (splitmix64(seed ^ c*0x9E3779B97F4A7C15 ^ (i>>5)) >> (2*(i&31))) & 3,
  * c = contig0 + index (the CPU checker generates the same bytes).         */
@@ -177,6 +203,8 @@ void pgr_index_destroy(pgr_index *ix);
 /* load_index_from_seq_vec (seq_db.rs:573-615): append contigs; sids[i] NULL -> running id */
 int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *ix, uint32_t n_seqs, const uint8_t *const *seqs,
                         const uint64_t *lens, const uint32_t *sids);
+int pgr_index_add_packed(pgr_ctx *ctx, pgr_index *ix, uint32_t n_seqs, const uint64_t *lens, const uint64_t *planes,
+                         const uint32_t *valid, const uint32_t *sids);
 int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_batch *b, const uint32_t *sids);
 /* merge pair records computed elsewhere (other GPUs, after the RCCL all-gather) */
 int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs, uint64_t n,

@@ -36,7 +36,7 @@ struct Tmp_list {  // small RAII device allocation from the context's caching al
 
 static std::string g_create_error;
 
-extern "C" const char *pgr_version(void) { return "pgr-hip 0.2.0 (gfx950)"; }
+extern "C" const char *pgr_version(void) { return "pgr-hip 0.3.0 (gfx950)"; }
 
 extern "C" const char *pgr_last_error(const pgr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -172,11 +172,12 @@ extern "C" void pgr_batch_destroy(pgr_batch *b) {
 
 extern "C" uint64_t pgr_batch_total_bases(const pgr_batch *b) { return b ? b->total_bases : 0; }
 
-// Stage the ASCII bytes of an allocated batch: host threads fill two pinned windows, H2D + pack kernel on `st`.
+// Round-2 staging, kept behind PGR_GPU_PACK for A/B timing: the ASCII bytes themselves cross PCIe (1 B per base) and a
+// kernel packs them.  Host threads fill two pinned windows, H2D + pack kernel on `st`.
 // Thread-compatible with a compute call running on ctx->stream: touches only the batch, ctx->pinned, ctx->ws_ascii and
 // the two events it is given.  Errors come back as a code + message (the caller owns ctx->err).
-static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
-                       hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, std::string &err) {
+static int batch_stage_ascii_gpu(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+                                hipStream_t st, hipEvent_t ev0, hipEvent_t ev1, std::string &err) {
     auto fail = [&](int code, const std::string &m) {
         err = m;
         return code;
@@ -252,29 +253,138 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const uint8_t *co
     return PGR_OK;
 }
 
+// Stage the bases of an allocated batch.  Two kinds of host input (pgr::StageSrc):
+//   ASCII   host threads pack 32 bytes -> one plane word + one validity word (csrc/hostpack.cpp) straight into a pinned
+//           window; 0.375 B per base cross PCIe instead of 1 B, and no pack kernel runs on the GPU;
+//   packed  the caller's planes (+ validity plane) are copied into the pinned window as they are and a small kernel
+//           cleans what the library relies on (bits past a contig's end, plane bits of invalid positions, the per-contig
+//           counts of non-ACGT bytes).
+// Two pinned windows: while window i is on its way to the GPU the host threads fill window i+1.
+// Thread-compatible with a compute call running on ctx->stream: touches only the batch, ctx->pinned and the two events
+// it is given.  Errors come back as a code + message (the caller owns ctx->err).
+static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &src, hipStream_t st, hipEvent_t ev0,
+                       hipEvent_t ev1, std::string &err) {
+    auto fail = [&](int code, const std::string &m) {
+        err = m;
+        return code;
+    };
+    // the pinned windows are reused from call to call: a previous staging whose copies nobody has waited for yet
+    // (two batches staged back to back) must be over before the host overwrites them
+    if (ctx->staged_unsynced && hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+    if (st != ctx->stream && hipStreamWaitEvent(st, ctx->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
+        return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+    const bool packed = src.planes != nullptr;
+    const bool gpu_pack = !packed && getenv("PGR_GPU_PACK") != nullptr;  // A/B switch: round-2 path (ASCII over PCIe + pack kernel)
+    if (gpu_pack) return batch_stage_ascii_gpu(ctx, b, n, src.seqs, src.lens, st, ev0, ev1, err);
+    constexpr uint64_t PIECE = 1ull << 16;        // words per host job (2 MiB of ASCII / 0.75 MiB packed)
+    constexpr uint64_t WIN_WORDS = 40 * PIECE;    // 84 Mbp = 30 MiB of planes + validity per window
+    const uint64_t win_words = std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
+    if (ctx->ensure_pinned(2 * win_words * 12)) return fail(PGR_ERR_NOMEM, "staging buffers: " + ctx->err);
+    hipEvent_t done[2] = {ev0, ev1};
+    bool used[2] = {false, false};
+    b->h_n_invalid.assign(std::max<uint32_t>(n, 1), 0);
+    uint32_t c = 0;
+    int slot = 0;
+    struct Job {
+        uint32_t c;
+        uint64_t wl0, wl1;  // words of contig c
+        uint64_t out;       // first word inside the window
+    };
+    std::vector<Job> jobs;
+    for (uint64_t w0 = 0; w0 < b->total_words; w0 += win_words, slot ^= 1) {
+        const uint64_t w1 = std::min(b->total_words, w0 + win_words);
+        uint64_t *pin_planes = (uint64_t *)((uint8_t *)ctx->pinned + (size_t)slot * win_words * 12);
+        uint32_t *pin_valid = (uint32_t *)(pin_planes + win_words);
+        if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess)  // this window's previous trip is over
+            return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+        while (c < n && b->h_word_off[c + 1] <= w0) ++c;
+        jobs.clear();
+        for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1; ++cc) {
+            const uint64_t cw0 = b->h_word_off[cc], cw1 = b->h_word_off[cc + 1];
+            const uint64_t lo = std::max(cw0, w0), hi = std::min(cw1, w1);
+            for (uint64_t o = lo; o < hi; o += PIECE) jobs.push_back(Job{cc, o - cw0, std::min(hi, o + PIECE) - cw0, o - w0});
+        }
+        const bool has_valid = !packed || src.valid != nullptr;
+        HostPool::instance().parallel_for(jobs.size(), [&](size_t i) {
+            const Job &j = jobs[i];
+            if (!packed) {
+                const uint64_t bad = pack_words(src.seqs[j.c], src.lens[j.c], j.wl0, j.wl1, pin_planes + j.out, pin_valid + j.out);
+                if (bad) __atomic_fetch_add(&b->h_n_invalid[j.c], (uint32_t)bad, __ATOMIC_RELAXED);
+            } else {
+                const uint64_t g = src.word0 + b->h_word_off[j.c] + j.wl0;  // word of the caller's arrays
+                memcpy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
+                if (src.valid) memcpy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
+            }
+        });
+        if (hipMemcpyAsync(b->d.planes + w0, pin_planes, (w1 - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
+            (has_valid &&
+             hipMemcpyAsync(b->d.valid + w0, pin_valid, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess))
+            return fail(PGR_ERR_DEVICE, "H2D copy of the packed window failed");
+        if (packed) launch_sanitize_packed(st, b->d, n, w0, w1, has_valid ? 1 : 0);
+        if (hipEventRecord(done[slot], st) != hipSuccess) return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+        used[slot] = true;
+    }
+    // per-contig counts of non-ACGT bytes (host-packed input: counted by the packer; packed input: by the kernel above)
+    if (!packed && n &&
+        hipMemcpyAsync(b->d.n_invalid, b->h_n_invalid.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess)
+        return fail(PGR_ERR_DEVICE, "H2D copy of the invalid-byte counts failed");
+    // On the context's own stream nothing waits here: the consumer is ordered behind the copies and synchronizes once at
+    // its end; the staging thread of the pipelined path (own stream) hands over finished batches.
+    if (st != ctx->stream) {
+        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
+            return fail(PGR_ERR_DEVICE, "staging failed on the device");
+    } else {
+        ctx->staged_unsynced = true;
+    }
+    return PGR_OK;
+}
+
+static int batch_from_host(pgr_ctx *ctx, uint32_t n, const StageSrc &src, pgr_batch **out) {
+    *out = nullptr;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    pgr_batch *b = nullptr;
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = batch_alloc(ctx, n, src.lens, &b);
+    if (rc) return rc;
+    std::string err;
+    if ((rc = batch_stage(ctx, b, n, src, ctx->stream, ctx->ev[0], ctx->ev[1], err))) {
+        pgr_batch_destroy(b);
+        return ctx->fail(rc, err);
+    }
+    if (dbg)
+        fprintf(stderr, "[pgr] batch from host (%s) %u seqs, %.1f Mbp: %.2f ms\n", src.planes ? "packed" : "ASCII", n,
+                b->total_bases / 1e6, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    *out = b;
+    return PGR_OK;
+}
+
 extern "C" int pgr_batch_from_ascii(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
                                     pgr_batch **out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!out || (n && (!seqs || !lens))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
     for (uint32_t i = 0; i < n; ++i)
         if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
-    pgr_batch *b = nullptr;
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = batch_alloc(ctx, n, lens, &b);
-    if (rc) return rc;
-    std::string err;
-    if ((rc = batch_stage(ctx, b, n, seqs, lens, ctx->stream, ctx->ev[0], ctx->ev[1], err))) {
-        pgr_batch_destroy(b);
-        return ctx->fail(rc, err);
-    }
-    if (dbg)
-        fprintf(stderr, "[pgr] batch_from_ascii %u seqs, %.1f MB: %.2f ms\n", n, b->total_bases / 1e6,
-                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-    *out = b;
-    return PGR_OK;
+    StageSrc src;
+    src.seqs = seqs;
+    src.lens = lens;
+    return batch_from_host(ctx, n, src, out);
+}
+
+extern "C" int pgr_batch_from_packed(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, const uint64_t *planes,
+                                     const uint32_t *valid, pgr_batch **out) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out || (n && !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    if (pgr_packed_words(n, lens) && !planes) return ctx->fail(PGR_ERR_INVALID_ARG, "null plane array");
+    static const uint64_t no_words = 0;
+    StageSrc src;
+    src.lens = lens;
+    src.planes = planes ? planes : &no_words;
+    src.valid = valid;
+    return batch_from_host(ctx, n, src, out);
 }
 
 static int batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint64_t seed, uint64_t contig0,
@@ -746,6 +856,12 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         pgr_shmmrs_destroy(res);
         return code;
     };
+// a failing HIP call behind this point must release `res` (and its device blocks) on its way out
+#define PGR_HIP_BAIL(expr)                                                                                        \
+    do {                                                                                                          \
+        hipError_t _e = (expr);                                                                                   \
+        if (_e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e))); \
+    } while (0)
     // the pipeline's status words sit right in front of the result offsets: ONE copy brings both to the mailbox
     if ((rc = ctx->dmalloc((void **)&res->d_block, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
     res->d_off = res->d_block + N_STATUS;
@@ -853,7 +969,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         return PGR_OK;
     };
 
-    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], st));
+    PGR_HIP_BAIL(hipEventRecord(ctx->ev[0], st));
     int from = 1;  // first stage to (re)run
     uint64_t n_final = 0;
     for (int attempt = 0;; ++attempt) {
@@ -861,7 +977,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (from <= 1) {
             if ((rc = stage1())) return bail(rc);
             if (early_sync) {
-                PGR_HIP(ctx, hipMemcpyAsync(mbox, d_cursor, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+                PGR_HIP_BAIL(hipMemcpyAsync(mbox, d_cursor, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
                 if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
                     return bail(ctx->fail(PGR_ERR_DEVICE, "level-1 kernels failed on the device"));
                 if (mbox[1] || mbox[0] > cap_par) {  // cursor region too small: grow and redo
@@ -871,7 +987,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 if ((mbox[2] || !serial.empty()) && (rc = run_islands(mbox[2]))) return bail(rc);
                 islands_done = true;
             }
-            PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+            PGR_HIP_BAIL(hipEventRecord(ctx->ev[3], st));
         }
         if (from <= 2 && (rc = stage2())) return bail(rc);
         if (from <= 3) {
@@ -881,7 +997,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if ((rc = stage4())) return bail(rc);
         if (pad_fix) {
             l1_off.resize((size_t)n + 1);
-            PGR_HIP(ctx, hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
+            PGR_HIP_BAIL(hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
                                         hipMemcpyDeviceToHost, st));
         }
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
@@ -897,7 +1013,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         }
         if (!islands_done && (need_islands || !serial.empty())) {
             if ((rc = run_islands(need_islands))) return bail(rc);
-            PGR_HIP(ctx, hipEventRecord(ctx->ev[3], st));
+            PGR_HIP_BAIL(hipEventRecord(ctx->ev[3], st));
             from = 2;
             continue;
         }
@@ -949,6 +1065,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
             return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
     }
+#undef PGR_HIP_BAIL
     hipEvent_t ev_end = ctx->ev_end;  // recorded at the end of stage 4, complete since the synchronization above
     ctx->staged_unsynced = false;
     (void)hipEventElapsedTime(&prof.level1_ms, ctx->ev[1], ctx->ev[2]);
@@ -1070,7 +1187,12 @@ extern "C" uint64_t pgr_shmmrs_n_pairs(const pgr_shmmrs *s) {
 int pgr::shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
                                      pgr_frag_rec *d_out, uint64_t capacity) {
     const uint32_t n = s->n;
-    std::vector<uint64_t> rec_off((size_t)n + 1);
+    // the source of an asynchronous H2D copy lives in the context, not on this stack frame (large pageable sources are
+    // pinned and read by the DMA engine after hipMemcpyAsync has returned).  It is rewritten by the next call only: `s` is
+    // the product of a pgr_shmmrs_compute, which synchronized the stream behind any earlier copy from this vector, and the
+    // callers that enqueue twice on one result synchronize in between
+    std::vector<uint64_t> &rec_off = ctx->keep_rec_off;
+    rec_off.resize((size_t)n + 1);
     uint64_t np = 0;
     for (uint32_t c = 0; c < n; ++c) {
         rec_off[c] = np;
@@ -1083,7 +1205,6 @@ int pgr::shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const ui
     hipStream_t st = ctx->stream;
     int rc;
     if ((rc = ctx->ws_rec_off.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t)))) return rc;
-    // (pageable source: the runtime stages it before returning, the vector may go out of scope)
     PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rec_off.p, rec_off.data(), ((size_t)n + 1) * sizeof(uint64_t),
                                 hipMemcpyHostToDevice, st));
     uint32_t *d_sids = nullptr;
@@ -1124,11 +1245,12 @@ bool pgr::worth_pipelining(uint32_t n, const uint64_t *lens) {
     return total_bp >= (512ull << 20);
 }
 
-int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
                          const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume) {
     PGR_HIP(ctx, hipSetDevice(ctx->device));
-    for (uint32_t i = 0; i < n; ++i)
-        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
+    const uint64_t *lens = src.lens;
+    for (uint32_t i = 0; i < n && !src.planes; ++i)
+        if (lens[i] && !src.seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
     // sub-batch size: big enough to keep the pinned-window pipeline efficient (>= 256 Mbp), small enough that the
     // last sub-batch's processing, which nothing overlaps, stays a few percent of the call
     uint64_t total_bp = 0;
@@ -1137,6 +1259,7 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
     struct Sub {
         uint32_t c0, c1;
         pgr_batch *b = nullptr;
+        uint64_t word0 = 0;  // first word of contig c0 in the caller's packed arrays
     };
     std::vector<Sub> subs;
     for (uint32_t c = 0; c < n;) {
@@ -1162,6 +1285,14 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
             tail.c1 = last.c1;
             last.c1 = cut;
             subs.push_back(tail);
+        }
+    }
+    {
+        uint64_t w = 0;
+        uint32_t c = 0;
+        for (Sub &sb : subs) {
+            for (; c < sb.c0; ++c) w += (lens[c] + 31) / 32;
+            sb.word0 = w;
         }
     }
     auto destroy_all = [&]() {
@@ -1190,8 +1321,11 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
         (void)hipSetDevice(ctx->device);
         for (size_t i = 0; i < subs.size() && !cancel.load(); ++i) {
             std::string err;
-            const int r = batch_stage(ctx, subs[i].b, subs[i].c1 - subs[i].c0, seqs + subs[i].c0, lens + subs[i].c0,
-                                      ctx->copy_stream, ctx->cev[0], ctx->cev[1], err);
+            StageSrc ss = src;
+            if (ss.seqs) ss.seqs += subs[i].c0;
+            ss.lens += subs[i].c0;
+            ss.word0 = src.word0 + subs[i].word0;
+            const int r = batch_stage(ctx, subs[i].b, subs[i].c1 - subs[i].c0, ss, ctx->copy_stream, ctx->cev[0], ctx->cev[1], err);
             std::lock_guard<std::mutex> lk(mu);
             if (r) {
                 stage_rc = r;
@@ -1225,9 +1359,9 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, c
     return rc;
 }
 
-static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
-                                 const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
-                                 uint64_t **out_off) {
+static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const StageSrc &src,
+                                 const uint32_t *rids, int padding, pgr_mm128 **out_mm, uint64_t **out_off) {
+    const uint64_t *lens = src.lens;
     std::vector<uint32_t> rr;  // rid of contig i of the CALL (sub-batches must not restart at 0)
     if (!rids) {
         rr.resize(n);
@@ -1241,7 +1375,7 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     bool first = true;
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
-    int rc = for_each_staged(ctx, n, seqs, lens, [&](pgr_batch *b, uint32_t c0, uint32_t c1) -> int {
+    int rc = for_each_staged(ctx, n, src, [&](pgr_batch *b, uint32_t c0, uint32_t c1) -> int {
         pgr_shmmrs *s = nullptr;
         int r = pgr_shmmrs_compute(ctx, b, spec, rids + c0, padding, &s);
         if (r) return r;
@@ -1280,19 +1414,15 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     return mm ? PGR_OK : ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
 }
 
-extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
-                               const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
-                               uint64_t **out_off) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null output pointer");
-    if (n && (!seqs || !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+static int shmmr_batch_host(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const StageSrc &src, const uint32_t *rids,
+                            int padding, pgr_mm128 **out_mm, uint64_t **out_off) {
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
     *out_mm = nullptr;
     *out_off = nullptr;
-    if (worth_pipelining(n, lens)) return shmmr_batch_pipelined(ctx, spec, n, seqs, lens, rids, padding, out_mm, out_off);
+    if (worth_pipelining(n, src.lens)) return shmmr_batch_pipelined(ctx, spec, n, src, rids, padding, out_mm, out_off);
     pgr_batch *b = nullptr;
-    if ((rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b))) return rc;
+    if ((rc = batch_from_host(ctx, n, src, &b))) return rc;
     pgr_shmmrs *s = nullptr;
     ctx->want_host_copy = true;
     rc = pgr_shmmrs_compute(ctx, b, spec, rids, padding, &s);
@@ -1302,6 +1432,35 @@ extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, c
     rc = pgr_shmmrs_download(ctx, s, out_mm, out_off);
     pgr_shmmrs_destroy(s);
     return rc;
+}
+
+extern "C" int pgr_shmmr_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,
+                               const uint64_t *lens, const uint32_t *rids, int padding, pgr_mm128 **out_mm,
+                               uint64_t **out_off) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null output pointer");
+    if (n && (!seqs || !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (lens[i] && !seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
+    StageSrc src;
+    src.seqs = seqs;
+    src.lens = lens;
+    return shmmr_batch_host(ctx, spec, n, src, rids, padding, out_mm, out_off);
+}
+
+extern "C" int pgr_shmmr_batch_packed(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint64_t *lens,
+                                      const uint64_t *planes, const uint32_t *valid, const uint32_t *rids, int padding,
+                                      pgr_mm128 **out_mm, uint64_t **out_off) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null output pointer");
+    if (n && !lens) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (pgr_packed_words(n, lens) && !planes) return ctx->fail(PGR_ERR_INVALID_ARG, "null plane array");
+    static const uint64_t no_words = 0;
+    StageSrc src;
+    src.lens = lens;
+    src.planes = planes ? planes : &no_words;
+    src.valid = valid;
+    return shmmr_batch_host(ctx, spec, n, src, rids, padding, out_mm, out_off);
 }
 
 extern "C" int pgr_frag_recs_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const uint8_t *const *seqs,

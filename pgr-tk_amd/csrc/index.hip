@@ -325,21 +325,43 @@ extern "C" int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_bat
     return PGR_OK;
 }
 
+static int index_add_host(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const StageSrc &src, const uint32_t *sids) {
+    if (worth_pipelining(n, src.lens))  // stage the next ~Gbp while this one is turned into records (running sids keep order)
+        return for_each_staged(ctx, n, src, [&](pgr_batch *sb, uint32_t c0, uint32_t) {
+            return pgr_index_add_resident(ctx, ix, sb, sids ? sids + c0 : nullptr);
+        });
+    pgr_batch *b = nullptr;
+    int rc = src.planes ? pgr_batch_from_packed(ctx, n, src.lens, src.planes, src.valid, &b)
+                        : pgr_batch_from_ascii(ctx, n, src.seqs, src.lens, &b);
+    if (rc) return rc;
+    rc = pgr_index_add_resident(ctx, ix, b, sids);
+    pgr_batch_destroy(b);
+    return rc;
+}
+
 extern "C" int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
                                    const uint32_t *sids) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
     if (n && (!seqs || !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    if (worth_pipelining(n, lens))  // stage the next ~Gbp while this one is turned into records (running sids keep order)
-        return for_each_staged(ctx, n, seqs, lens, [&](pgr_batch *sb, uint32_t c0, uint32_t) {
-            return pgr_index_add_resident(ctx, ix, sb, sids ? sids + c0 : nullptr);
-        });
-    pgr_batch *b = nullptr;
-    int rc = pgr_batch_from_ascii(ctx, n, seqs, lens, &b);
-    if (rc) return rc;
-    rc = pgr_index_add_resident(ctx, ix, b, sids);
-    pgr_batch_destroy(b);
-    return rc;
+    StageSrc src;
+    src.seqs = seqs;
+    src.lens = lens;
+    return index_add_host(ctx, ix, n, src, sids);
+}
+
+extern "C" int pgr_index_add_packed(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const uint64_t *lens, const uint64_t *planes,
+                                    const uint32_t *valid, const uint32_t *sids) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
+    if (n && !lens) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (pgr_packed_words(n, lens) && !planes) return ctx->fail(PGR_ERR_INVALID_ARG, "null plane array");
+    static const uint64_t no_words = 0;
+    StageSrc src;
+    src.lens = lens;
+    src.planes = planes ? planes : &no_words;
+    src.valid = valid;
+    return index_add_host(ctx, ix, n, src, sids);
 }
 
 extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
@@ -1560,11 +1582,14 @@ namespace {
 // filters): what the lookup stage reads, 17 B each in the reference's layout
 __global__ void sum_ranges_kernel(const uint64_t *__restrict__ lo, const uint64_t *__restrict__ hi, uint64_t nq,
                                   unsigned long long *__restrict__ total) {
-    uint32_t v = 0;  // (a key holds < 2^32 signatures in total: the index is limited to 2^32 - 1 records)
+    // 64-bit sums: ONE key holds < 2^32 signatures, the pairs of a repeat-heavy query batch together can hold more
+    uint64_t v = 0;
     for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < nq; p += (uint64_t)gridDim.x * blockDim.x)
-        v += (uint32_t)(hi[p] - lo[p]);
-    v = wave_incl_sum(v);  // few workgroups: same-address atomics run at ~88 per us on gfx950
-    if ((threadIdx.x & 63) == 63 && v) atomicAdd(total, (unsigned long long)v);
+        v += hi[p] - lo[p];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += shfl_xor64(v, d);
+    // few workgroups: same-address atomics run at ~88 per us on gfx950
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(total, (unsigned long long)v);
 }
 }  // namespace
 

@@ -69,6 +69,25 @@ __global__ __launch_bounds__(256) void pack_ascii_kernel(const uint8_t *__restri
     b.valid[wi] = v;
 }
 
+// packed host input (pgr_batch_from_packed): one lane per word
+__global__ __launch_bounds__(256) void sanitize_packed_kernel(BatchDev b, uint32_t n, uint64_t w0, uint64_t w1, int has_valid) {
+    const uint64_t wi = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (wi >= w1) return;
+    const uint32_t c = find_by_word(b.word_off, n, wi);
+    const uint64_t first = (wi - b.word_off[c]) * 32;
+    const uint64_t len = b.len[c];
+    const uint32_t nb = first >= len ? 0u : ((len - first) >= 32 ? 32u : (uint32_t)(len - first));
+    const uint32_t tail = nb == 32 ? 0xFFFFFFFFu : (nb == 0 ? 0u : ~(0xFFFFFFFFu >> nb));  // base i at bit 31 - i
+    const uint32_t v = has_valid ? (b.valid[wi] & tail) : tail;
+    uint2 p = b.planes[wi];
+    p.x &= v;
+    p.y &= v;
+    b.planes[wi] = p;
+    b.valid[wi] = v;
+    const uint32_t n_bad = nb - __popc(v);
+    if (n_bad) atomicAdd(b.n_invalid + c, n_bad);
+}
+
 __device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -110,6 +129,12 @@ void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, cons
     if (w1 <= w0) return;
     const uint32_t blocks = (uint32_t)((w1 - w0 + 255) / 256);
     hipLaunchKernelGGL(pack_ascii_kernel, dim3(blocks), dim3(256), 0, st, d_ascii, w0, b, n, w1);
+}
+
+void launch_sanitize_packed(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t w0, uint64_t w1, int has_valid) {
+    if (w1 <= w0) return;
+    const uint32_t blocks = (uint32_t)((w1 - w0 + 255) / 256);
+    hipLaunchKernelGGL(sanitize_packed_kernel, dim3(blocks), dim3(256), 0, st, b, n, w0, w1, has_valid);
 }
 
 void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_words, uint64_t seed,

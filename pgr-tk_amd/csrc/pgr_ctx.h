@@ -6,6 +6,7 @@
 #include <string>
 
 #include "pgr_internal.h"
+#include "pgr_host.h"
 
 namespace pgr {
 struct DevBuf {
@@ -40,6 +41,7 @@ struct pgr_ctx {
     bool staged_unsynced = false;  // a batch was staged on `stream` and nobody has synchronized since
     // result-size estimate: final shimmers per base of the last pgr_shmmrs_compute with the spec `est_spec_key`
     double est_spec_key = -1.0, est_final_ratio = 0.0;
+    std::vector<uint64_t> keep_rec_off;  // source of the async H2D copy of shmmrs_to_frag_recs_enqueue
     // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`
     hipStream_t copy_stream = nullptr;
     hipEvent_t cev[2] = {nullptr, nullptr};
@@ -70,12 +72,21 @@ struct pgr_ctx {
 };
 
 namespace pgr {
+// host input of a staged batch: ASCII contigs (seqs), or the packed planes of pgr_batch_from_packed (planes != NULL; the
+// arrays cover the contigs of the WHOLE call, word0 = first word of the sub-batch's first contig)
+struct StageSrc {
+    const uint8_t *const *seqs = nullptr;
+    const uint64_t *lens = nullptr;
+    const uint64_t *planes = nullptr;
+    const uint32_t *valid = nullptr;
+    uint64_t word0 = 0;
+};
 // pair records of a resident result into d_out (capacity >= pgr_shmmrs_n_pairs), stream ordered: returns without waiting
 int shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
                                 pgr_frag_rec *d_out, uint64_t capacity);
 // host inputs of >= 512 Mbp: contigs [c0, c1) are staged on the copy stream while the previous range is consumed
 bool worth_pipelining(uint32_t n, const uint64_t *lens);
-int for_each_staged(pgr_ctx *ctx, uint32_t n, const uint8_t *const *seqs, const uint64_t *lens,
+int for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
                     const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume);
 }  // namespace pgr
 

@@ -47,6 +47,7 @@ struct pgr_batch {
     pgr::BatchDev d;
     std::vector<uint64_t> h_word_off;  // [n+1]
     std::vector<uint32_t> h_len;       // [n]
+    std::vector<uint32_t> h_n_invalid; // [n] non-ACGT bytes counted by the host packer (source of an async H2D copy)
 };
 
 struct pgr_shmmrs {
@@ -67,6 +68,9 @@ namespace pgr {
 // pack.hip
 void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, const BatchDev &b, uint32_t n,
                        uint64_t w1);
+// packed host input: clean words [w0, w1) (bits past the contig end, plane bits of invalid positions) and count the
+// non-ACGT positions per contig; has_valid == 0: every base is valid, the validity plane is written from the lengths
+void launch_sanitize_packed(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t w0, uint64_t w1, int has_valid);
 void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_words, uint64_t seed,
                   uint64_t contig0, const uint64_t *d_ids /* NULL: contig0 + index */);
 

@@ -11,6 +11,8 @@
 #include <string>
 #include <vector>
 
+#include <cerrno>
+#include <csignal>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -96,6 +98,12 @@ int main(int argc, char **argv) {
         fprintf(stderr, "usage: pgr-mdb <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch] [--ranks N [--devices 0,1,..]]\n");
         return 2;
     }
+    if (sid_quirk && (ranks > 1 || force_exchange)) {
+        // per-input sid restarts make sids ambiguous across files: the sharded build tells contigs apart by their sid, two
+        // contigs of different files with the same sid next to each other in a rank's list would be fused into one
+        fprintf(stderr, "pgr-mdb: --reference-sid-quirk cannot be combined with --ranks / --force-exchange\n");
+        return 2;
+    }
     if (ranks == 1 && devices.empty() && !force_exchange) {
         RankEnv env;
         return run_rank(env, spec, batch_bp, sid_quirk, pos);
@@ -143,10 +151,30 @@ int main(int argc, char **argv) {
         close(pipes[(size_t)r].first);
         close(pipes[(size_t)r].second);
     }
+    // a rank that dies between two collectives leaves the others blocked in RCCL for ever: at the first abnormal exit the
+    // remaining ranks are terminated and the build fails
     int bad = 0;
-    for (pid_t k : kids) {
+    size_t left = kids.size();
+    while (left) {
         int st = 0;
-        if (waitpid(k, &st, 0) < 0 || !WIFEXITED(st) || WEXITSTATUS(st) != 0) bad = 1;
+        const pid_t k = waitpid(-1, &st, 0);
+        if (k < 0) {
+            if (errno == EINTR) continue;
+            bad = 1;
+            break;
+        }
+        auto it = std::find(kids.begin(), kids.end(), k);
+        if (it == kids.end()) continue;
+        *it = -1;
+        --left;
+        if (!WIFEXITED(st) || WEXITSTATUS(st) != 0) {
+            if (!bad) {
+                fprintf(stderr, "pgr-mdb: a rank process failed; terminating the other ranks\n");
+                for (pid_t o : kids)
+                    if (o > 0) kill(o, SIGTERM);
+            }
+            bad = 1;
+        }
     }
     return bad;
 }

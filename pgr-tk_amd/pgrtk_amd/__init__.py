@@ -5,12 +5,13 @@ include/pgr_hip.h).  There is no CPU path: without the built library and a gfx95
 calls raise.
 """
 from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PackedSeqs, PgrError, Spec, default_context  # noqa: F401
-from .engine import (Batch, Index, Shmmrs, frag_recs_batch, make_spec, sequence_to_shmmrs,  # noqa: F401
-                     sequence_to_shmmrs_batch, time_shmmr_batch)
+from .engine import (Batch, Index, PackedBases, Shmmrs, frag_recs_batch, make_spec, pack_ascii,  # noqa: F401
+                     sequence_to_shmmrs, sequence_to_shmmrs_batch, sequence_to_shmmrs_batch_packed, time_shmmr_batch,
+                     time_shmmr_batch_packed)
 from .seqindexdb import (SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, read_fastx, sparse_aln,  # noqa: F401
                          sparse_aln_groups)
 from . import cli, mapgraph  # noqa: F401
 from .helpers import (get_principle_bundle_bed_file_for_query, group_smps_by_principle_bundle_id, merge_regions, query_sdb, rc, rc_byte_seq, rc_u8_seq,  # noqa: F401
                       string_to_u8, u8_to_string)
 
-__version__ = "0.2.0"
+__version__ = "0.3.0"

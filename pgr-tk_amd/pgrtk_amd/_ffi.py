@@ -78,6 +78,12 @@ _SIGS = [
     ("pgr_frag_recs_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
                                       C.POINTER(C.c_uint32), C.c_int, _PVP, _PVP]),
     ("pgr_batch_from_ascii", C.c_int, [_VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), _PVP]),
+    ("pgr_packed_words", C.c_uint64, [C.c_uint32, C.POINTER(C.c_uint64)]),
+    ("pgr_pack_ascii", C.c_int, [C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.c_int, _VP, _VP, C.POINTER(C.c_uint64)]),
+    ("pgr_shmmr_batch_packed", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, C.POINTER(C.c_uint64), _VP, _VP,
+                                         C.POINTER(C.c_uint32), C.c_int, _PVP, _PVP]),
+    ("pgr_batch_from_packed", C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), _VP, _VP, _PVP]),
+    ("pgr_index_add_packed", C.c_int, [_VP, _VP, C.c_uint32, C.POINTER(C.c_uint64), _VP, _VP, C.POINTER(C.c_uint32)]),
     ("pgr_batch_synthetic", C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.c_uint64, _PVP]),
     ("pgr_batch_synthetic_ids", C.c_int, [_VP, C.c_uint32, C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64), _PVP]),
     ("pgr_batch_destroy", None, [_VP]),

@@ -24,6 +24,46 @@ def _u32_array(vals, n):
     return a, a.ctypes.data_as(C.POINTER(C.c_uint32))
 
 
+class PackedBases:
+    """contigs as 2-bit planes + validity plane in HOST memory, the layout of pgr_batch_from_packed (include/pgr_hip.h):
+    lens[n], planes[words] (low plane | high plane << 32), valid[words] or None (every base valid)"""
+
+    def __init__(self, lens, planes, valid=None):
+        self.lens = np.ascontiguousarray(lens, dtype=np.uint64)
+        self.planes = np.ascontiguousarray(planes, dtype=np.uint64)
+        self.valid = None if valid is None else np.ascontiguousarray(valid, dtype=np.uint32)
+        self.n = int(self.lens.size)
+        words = int(((self.lens + np.uint64(31)) // np.uint64(32)).sum()) if self.n else 0
+        assert self.planes.size >= words and (self.valid is None or self.valid.size >= words)
+
+    def __len__(self):
+        return self.n
+
+    @property
+    def total_bases(self):
+        return int(self.lens.sum()) if self.n else 0
+
+    def _args(self):
+        la = self.lens if self.n else np.zeros(1, dtype=np.uint64)
+        return (la.ctypes.data_as(C.POINTER(C.c_uint64)), C.c_void_p(self.planes.ctypes.data if self.planes.size else 0),
+                C.c_void_p(self.valid.ctypes.data) if self.valid is not None and self.valid.size else None)
+
+
+def pack_ascii(seqs, n_threads=0):
+    """pgr_pack_ascii: the library's threaded CPU packer (no GPU involved) -> (PackedBases, number of non-ACGT bytes)"""
+    arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
+    words = int(lib().pgr_packed_words(n, lens))
+    planes = np.empty(max(words, 1), dtype=np.uint64)
+    valid = np.empty(max(words, 1), dtype=np.uint32)
+    bad = C.c_uint64()
+    rc = lib().pgr_pack_ascii(n, ptrs, lens, int(n_threads), C.c_void_p(planes.ctypes.data), C.c_void_p(valid.ctypes.data),
+                              C.byref(bad))
+    if rc != 0:
+        raise _ffi.PgrError(rc, "pgr_pack_ascii: bad arguments")
+    lens_np = np.ctypeslib.as_array(lens, shape=(max(n, 1),))[:n].copy()
+    return PackedBases(lens_np, planes[:words], valid[:words]), int(bad.value)
+
+
 class Batch:
     """contigs resident on the GPU as 2-bit planes (pgr_batch)."""
 
@@ -39,6 +79,15 @@ class Batch:
         h = C.c_void_p()
         ctx.check(lib().pgr_batch_from_ascii(ctx.handle, n, ptrs, lens, C.byref(h)))
         return cls(ctx, h, n)
+
+    @classmethod
+    def from_packed(cls, packed, ctx=None):
+        """H2D of host-packed planes (PackedBases)"""
+        ctx = ctx or default_context()
+        la, pp, vp = packed._args()
+        h = C.c_void_p()
+        ctx.check(lib().pgr_batch_from_packed(ctx.handle, packed.n, la, pp, vp, C.byref(h)))
+        return cls(ctx, h, packed.n)
 
     @classmethod
     def synthetic(cls, lens, seed, contig0=0, ctx=None, contig_ids=None):
@@ -160,6 +209,39 @@ def sequence_to_shmmrs_batch(seqs, spec, rids=None, padding=False, ctx=None):
     return [mm[int(off[i]):int(off[i + 1])] for i in range(n)]
 
 
+def sequence_to_shmmrs_batch_packed(packed, spec, rids=None, padding=False, ctx=None):
+    """the same on host-packed input (PackedBases): pgr_shmmr_batch_packed"""
+    ctx = ctx or default_context()
+    n = packed.n
+    la, pp, vp = packed._args()
+    keep, rp = _u32_array(rids, n)
+    pm, po = C.c_void_p(), C.c_void_p()
+    ctx.check(lib().pgr_shmmr_batch_packed(ctx.handle, C.byref(spec), n, la, pp, vp, rp, int(padding), C.byref(pm), C.byref(po)))
+    off = _ffi.take(po, n + 1, np.dtype("<u8"))
+    mm = _ffi.take(pm, int(off[n]) if n else 0, MM128)
+    return [mm[int(off[i]):int(off[i + 1])] for i in range(n)]
+
+
+def time_shmmr_batch_packed(packed, spec, ctx=None):
+    """seconds inside pgr_shmmr_batch_packed + the two pgr_free, and the number of shimmers"""
+    import time
+    ctx = ctx or default_context()
+    n = packed.n
+    la, pp, vp = packed._args()
+    pm, po = C.c_void_p(), C.c_void_p()
+    L, h = lib(), ctx.handle
+    t0 = time.perf_counter()
+    rc = L.pgr_shmmr_batch_packed(h, C.byref(spec), n, la, pp, vp, None, 0, C.byref(pm), C.byref(po))
+    cnt = 0
+    if rc == 0:
+        cnt = int(C.cast(po, C.POINTER(C.c_uint64))[n])
+        L.pgr_free(pm)
+        L.pgr_free(po)
+    dt = time.perf_counter() - t0
+    ctx.check(rc)
+    return dt, cnt
+
+
 def time_shmmr_batch(seqs, spec, ctx=None):
     """seconds spent inside pgr_shmmr_batch + the two pgr_free (what a compiled host pays; pointer arrays built before the
     clock starts, nothing copied into numpy), and the number of shimmers"""
@@ -227,6 +309,11 @@ class Index:
         arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
         keep, sp = _u32_array(sids, n)
         self.ctx.check(lib().pgr_index_add_batch(self.ctx.handle, self._h, n, ptrs, lens, sp))
+
+    def add_packed(self, packed, sids=None):
+        la, pp, vp = packed._args()
+        keep, sp = _u32_array(sids, packed.n)
+        self.ctx.check(lib().pgr_index_add_packed(self.ctx.handle, self._h, packed.n, la, pp, vp, sp))
 
     def add_records(self, recs=None, device_ptr=None, n=None):
         """merge pair records computed elsewhere: a host FRAG_REC array, or n records at a DEVICE pointer

@@ -1,0 +1,75 @@
+"""The library's CPU packer (pgr_pack_ascii, csrc/hostpack.cpp) against a numpy restatement of the reference's base table
+(pgr-db/src/shmmrutils.rs:426-436).  Host code only: runs without a GPU."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def ref_pack(seq):
+    """numpy restatement: base i of a contig -> bit 31 - (i % 32) of word i // 32"""
+    a = np.frombuffer(bytes(seq), dtype=np.uint8)
+    code = np.full(256, 4, dtype=np.uint8)
+    for ch, c in ((0, 0), (1, 1), (2, 2), (3, 3)):
+        code[ch] = c
+    for ch, c in zip(b"ACGT", range(4)):
+        code[ch] = c
+        code[ch | 0x20] = c
+    c = code[a]
+    nw = (len(a) + 31) // 32
+    lo = np.zeros(nw * 32, dtype=np.uint64)
+    hi = np.zeros(nw * 32, dtype=np.uint64)
+    v = np.zeros(nw * 32, dtype=np.uint64)
+    ok = c < 4
+    lo[:len(a)] = np.where(ok, c & 1, 0)
+    hi[:len(a)] = np.where(ok, c >> 1, 0)
+    v[:len(a)] = ok
+    sh = (np.uint64(31) - np.arange(32, dtype=np.uint64))[None, :]
+    pl = (lo.reshape(nw, 32) << sh).sum(axis=1, dtype=np.uint64)
+    ph = (hi.reshape(nw, 32) << sh).sum(axis=1, dtype=np.uint64)
+    pv = (v.reshape(nw, 32) << sh).sum(axis=1, dtype=np.uint64)
+    return pl | (ph << np.uint64(32)), pv.astype(np.uint32), int((~ok).sum())
+
+
+def cases():
+    rng = np.random.default_rng(5)
+    out = [b"", b"A", b"ACGT" * 8, b"ACGT" * 8 + b"N", bytes(range(256)), bytes(range(256)) * 3 + b"acgtn"]
+    for n in (31, 32, 33, 63, 64, 65, 1000, 65536 * 32 + 17):  # the last one crosses a job boundary of the packer
+        out.append(rng.choice(np.frombuffer(b"ACGTacgtNn\x00\x01\x02\x03*-", dtype=np.uint8), n).tobytes())
+    out.append(rng.integers(0, 256, 5000, dtype=np.uint8).tobytes())
+    return out
+
+
+def check(P):
+    seqs = cases()
+    packed, bad = P.pack_ascii(seqs, n_threads=3)
+    off = 0
+    tot_bad = 0
+    for s in seqs:
+        pl, pv, nb = ref_pack(s)
+        nw = len(pl)
+        assert np.array_equal(packed.planes[off:off + nw], pl), len(s)
+        assert np.array_equal(packed.valid[off:off + nw], pv), len(s)
+        off += nw
+        tot_bad += nb
+    assert off == packed.planes.size and bad == tot_bad
+    assert [int(v) for v in packed.lens] == [len(s) for s in seqs]
+
+
+def test_pack_ascii_matches_the_base_table():
+    sys.path.insert(0, os.path.join(ROOT, "pgr-tk_amd"))
+    import pgrtk_amd as P
+    check(P)
+
+
+def test_pack_ascii_scalar_path_matches_too():
+    """the same with the AVX2 path switched off (PGR_NO_AVX2 is read once per process)"""
+    env = dict(os.environ, PGR_NO_AVX2="1", PGR_HOST_THREADS="2")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_hostpack_cpu as t; import pgrtk_amd as P; "
+            "t.check(P); print('ok')") % (os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
