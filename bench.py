@@ -10,14 +10,19 @@ N=1 workload = BASELINE.json configs[1]: 1000 x 10 Mbp.
 
 N > 1, default (weak scaling): every rank runs the same per-GPU workload on its own contigs.
 N > 1, --strong: ONE set of --contigs contigs is partitioned over the ranks by exchange.shard_contigs (greedy,
-length balanced: the partitioner of SURVEY.md section 8e).  In both modes the per-rank shimmer lists are all-gathered
-over RCCL inside the timed region (libpgrhip's own exchange entry points, pgr_exchange_*; --exchange torch uses
-torch.distributed instead).
+length balanced: the partitioner of SURVEY.md section 8e).
+N > 1, what a step is: shimmers + pair records of the rank's contigs, then the MERGE inside the timed region -- the key
+space is cut into N ranges (splitters from a pooled sample), every pair record travels to the rank that owns its range
+(one variable all-to-all over RCCL: libpgrhip's pgr_exchange_shard_records; --exchange torch uses torch.distributed) and
+each rank sorts its range into its shard of the frag_map (pgr_index_finalize): `value` is defined on that sum,
+`exchange_ms` / `merge_ms` say how it splits.  At N = 1 there is nothing to merge: the step is BASELINE configs[1]
+(shimmers + pair records) and the index build is timed beside it (`index_build_ms`, `value_incl_index_build`).
 
-After the timed region rank 0 (N=1 only) adds: the content check of ALL contigs against the CPU restatement of the
-reference (128-bit checksum per contig), the CPU baseline taken from that same run, the query leg (BASELINE.json
-configs[2]) with its own roofline and CPU baseline, small-call latencies, and the PCIe-inclusive throughput of the
-host-buffer entry point.  Prints ONE JSON line on rank 0.
+After the timed region: EVERY rank checks the shimmer lists of its own contigs against the CPU restatement of the
+reference (128-bit checksum per contig) and the exchanged record set against what was sent (order-independent checksum
+summed over the ranks, key ranges disjoint and ordered); rank 0 reports the CPU baseline from its own run.  N = 1 adds
+the query leg (BASELINE.json configs[2]) with its own roofline and CPU baseline, real-genome shapes, small-call
+latencies, the PCIe-inclusive throughput of the host entry points and the time to index 100 Gbp.  ONE JSON line, rank 0.
 """
 import argparse
 import json
@@ -254,22 +259,16 @@ def query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores):
     }
 
 
-def query_bench_dist(P, ctx, spec, args, gathered, world, rank, dist, torch, local_rank, all_ids):
-    """BASELINE.json configs[2] on N GPUs: every rank builds the (replicated) index of ALL ranks' contigs from the
-    all-gathered MM128 lists (pgr_index_add_shmmrs derives the pair records), the queries are sharded round robin, every
-    rank chains its own share; value = all queries / slowest rank."""
+def query_bench_dist(P, ctx, spec, args, shard, xch, exchange, world, rank, dist, torch, local_rank, all_ids):
+    """BASELINE.json configs[2] on N GPUs: the replicated query index is the concatenation of the finalized key-range
+    shards (all-gathered in rank order: already sorted, no sort), the queries are sharded round robin, every rank chains
+    its own share; value = all queries / slowest rank."""
     import numpy as np
     rng = np.random.default_rng(3)
     nq, qlen = args.queries, 10_000
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    ix = P.Index(spec, ctx=ctx)
-    for part in gathered:  # one rank's list after the other (a sequence never straddles two ranks)
-        if int(part.shape[0]):
-            g = part if part.is_cuda else part.to("cuda:%d" % local_rank)
-            g = g.contiguous()
-            ix.add_shmmrs(device_ptr=g.data_ptr(), n=int(g.shape[0]))
-    ix.finalize()
+    ix = xch.allgather_index(shard) if xch is not None else exchange.allgather_index_torch(shard)
     t_build = time.perf_counter() - t0
     cs, offs, qs_all = make_queries(P, args.seed, all_ids, len(all_ids), args.contig_len, nq, qlen, rng)
     mine = np.arange(rank, nq, world)
@@ -297,9 +296,10 @@ def query_bench_dist(P, ctx, spec, args, gathered, world, rank, dist, torch, loc
     t_q = float(t[0].item())
     return {
         "workload": "BASELINE.json configs[2] on %d GPUs: %d x %d bp queries sharded round robin, every rank holds the index of "
-                    "all %d contigs built from the all-gathered shimmer lists; queries resident in HBM" % (world, nq, qlen, len(all_ids)),
-        "index_build_s": float(t[1].item()), "index_records": ix.n_records, "query_s": t_q, "queries_per_s": nq / t_q,
-        "hit_pairs": int(agg[0].item()), "hit_pairs_per_s": float(agg[0].item()) / t_q,
+                    "all %d contigs = the key-range shards all-gathered in rank order; queries resident in HBM" %
+                    (world, nq, qlen, len(all_ids)),
+        "replicate_index_s": float(t[1].item()), "index_records": ix.n_records, "index_keys": ix.n_keys, "query_s": t_q,
+        "queries_per_s": nq / t_q, "hit_pairs": int(agg[0].item()), "hit_pairs_per_s": float(agg[0].item()) / t_q,
         "queries_with_best_chain_on_source": int(agg[1].item()),
     }
 
@@ -323,30 +323,37 @@ def effective_cpus():
     return max(1, n)
 
 
-def cpu_baseline(spec_t, n_contigs, contig_len, seed, contig0, gpu_counts, gpu_sums, cores):
-    """the oracle (CPU restatement of the reference, one task per contig like rayon par_iter) over ALL contigs of the
-    workload, generated inside the workers; every contig's 128-bit content checksum must equal the GPU's.
+def cpu_baseline(spec_t, contig_ids, contig_len, seed, gpu_counts, gpu_sums, cores, budget_s=None):
+    """the oracle (CPU restatement of the reference, one task per contig like rayon par_iter) over the contigs `contig_ids`
+    of the workload, generated inside the workers; every contig's 128-bit content checksum must equal the GPU's.
+    budget_s: bound the CPU work to about that many seconds on `cores` threads (a prefix of the contigs is checked then).
     Checker + baseline only."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
     sp = O.spec(*spec_t)
+    n_all = len(contig_ids)
+    n = n_all
+    if budget_s is not None:  # ~66 Mbp/s per thread (measured, reported below as per_core_Mbp_per_s)
+        n = max(1, min(n_all, int(budget_s * cores * 60e6 / max(1, contig_len))))
+    ids = np.asarray(contig_ids[:n], dtype=np.uint64)
     t0 = time.perf_counter()
-    counts, sums, busy = O.synth_checksums_threads(sp, n_contigs, seed, contig0, contig_len, cores)
+    counts, sums, busy = O.synth_checksums_ids_threads(sp, ids, seed, contig_len, cores)
     wall = time.perf_counter() - t0
     busy_wall = float(busy.sum()) / cores  # the threaded section's duration without the time spent generating contigs
-    ok_counts = bool(np.array_equal(counts, np.asarray(gpu_counts, dtype=np.uint64)))
-    n_match = int(np.sum(np.all(sums == np.asarray(gpu_sums, dtype=np.uint64), axis=1)))
-    bp = n_contigs * contig_len
+    ok_counts = bool(np.array_equal(counts, np.asarray(gpu_counts[:n], dtype=np.uint64)))
+    n_match = int(np.sum(np.all(sums == np.asarray(gpu_sums[:n], dtype=np.uint64), axis=1)))
+    bp = n * contig_len
     return {
         "value": bp / busy_wall / 1e9, "unit": "Gbp/s", "cores": cores, "kind": "port",
-        "sample": "all %d x %d bp synthetic contigs of the workload, one task per contig on %d threads (= the CPUs this "
-                  "container may use: affinity capped by the cgroup quota; the host shows %d): %.1f s wall of which %.1f s per "
+        "sample": "%d of this rank's %d x %d bp synthetic contigs, one task per contig on %d threads (= the CPUs this "
+                  "process may use: affinity capped by the cgroup quota%s; the host shows %d): %.1f s wall of which %.1f s per "
                   "thread inside sequence_to_shmmrs (the rest generates the contigs)" %
-                  (n_contigs, contig_len, cores, os.cpu_count() or 0, wall, busy_wall),
+                  (n, n_all, contig_len, cores, "" if budget_s is None else ", shared between the ranks of this node",
+                   os.cpu_count() or 0, wall, busy_wall),
         "per_core_Mbp_per_s": bp / float(busy.sum()) / 1e6,
-        "contigs_checked": int(n_contigs), "contigs_with_identical_checksum": n_match,
-        "content_match": bool(n_match == n_contigs and ok_counts), "counts_match_gpu": ok_counts,
+        "contigs_checked": int(n), "contigs_with_identical_checksum": n_match,
+        "content_match": bool(n_match == n and ok_counts), "counts_match_gpu": ok_counts,
         "check": "128-bit order-sensitive checksum of (x, pos, strand) per contig, GPU (pgr_shmmrs_checksum) vs CPU",
     }
 
@@ -385,21 +392,191 @@ def latency_bench(P, ctx, spec, args):
 
 
 def pcie_bench(P, ctx, spec, args):
-    """B1 as the reference would call it: host ASCII in, host MM128 out (pgr_shmmr_batch).  Never the bench `value`."""
+    """B1 as a host calls it: host bases in, host MM128 out.  Three forms of input: ASCII (pgr_shmmr_batch: the library's
+    CPU packer fills the pinned windows, 0.375 B per base cross PCIe), packed planes + validity plane
+    (pgr_shmmr_batch_packed, 0.375 B per base, no packing inside the call) and packed planes alone (0.25 B per base).
+    Never the bench `value`."""
     import numpy as np
-    n = 52  # 520 Mbp: above the 512 Mbp threshold of the pipelined (sub-batched, double-buffered) path
+    n = 104  # 1.04 Gbp: the pipelined (sub-batched, double-buffered) path
     seqs = [synth_contig_ascii(args.seed, c, 10_000_000) for c in range(n)]
-    P.time_shmmr_batch(seqs, spec, ctx=ctx)  # warm-up: pinned windows, workspaces
-    reps, n_sh = [], 0
-    for _ in range(3):  # the C entry point + release of the result (no numpy copies: those belong to the Python binding)
-        dt, n_sh = P.time_shmmr_batch(seqs, spec, ctx=ctx)
-        reps.append(dt)
-    t = sorted(reps)[1]
     bp = n * 10_000_000
-    return {"value": bp / t / 1e9, "unit": "Gbp/s", "bp": bp, "s": t, "s_reps": reps, "shimmers": int(n_sh),
-            "ascii_GB_per_s": bp / t / 1e9, "pcie_peak_GB_per_s": PCIE_PEAK_GBPS,
-            "note": "pgr_shmmr_batch: 1 byte per base crosses PCIe; sub-batches staged on a copy stream while the previous "
-                    "one computes"}
+
+    def med3(f):
+        f()  # warm-up: pinned windows, workspaces
+        reps = [f() for _ in range(3)]
+        return sorted(r[0] for r in reps)[1], [r[0] for r in reps], reps[0][1]
+    # the C entry points + release of the result (no numpy copies: those belong to the Python binding)
+    t_a, reps_a, n_sh = med3(lambda: P.time_shmmr_batch(seqs, spec, ctx=ctx))
+    tp = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        packed, n_bad = P.pack_ascii(seqs)
+        tp.append(time.perf_counter() - t0)
+    t_pack = sorted(tp)[1]
+    t_p, reps_p, n_sh_p = med3(lambda: P.time_shmmr_batch_packed(packed, spec, ctx=ctx))
+    bare = P.PackedBases(packed.lens, packed.planes, None)
+    t_b, reps_b, n_sh_b = med3(lambda: P.time_shmmr_batch_packed(bare, spec, ctx=ctx))
+    return {"value": bp / t_p / 1e9, "unit": "Gbp/s", "bp": bp, "s": t_p, "s_reps": reps_p, "shimmers": int(n_sh_p),
+            "input": "host-packed 2-bit planes + validity plane (pgr_shmmr_batch_packed): 0.375 B per base on the link",
+            "link_GB_per_s": 0.375 * bp / t_p / 1e9, "pcie_peak_GB_per_s": PCIE_PEAK_GBPS,
+            "packed_planes_only": {"value": bp / t_b / 1e9, "s": t_b, "s_reps": reps_b, "link_GB_per_s": 0.25 * bp / t_b / 1e9,
+                                   "note": "validity plane omitted (every base is ACGT): 0.25 B per base"},
+            "ascii_input": {"value": bp / t_a / 1e9, "s": t_a, "s_reps": reps_a,
+                            "note": "pgr_shmmr_batch: ASCII in; the library's CPU packer writes the pinned windows, 0.375 B per "
+                                    "base cross PCIe (round 2: the ASCII bytes crossed, 40 Gbp/s)"},
+            "host_packer": {"s": t_pack, "GB_per_s": bp / t_pack / 1e9, "threads": effective_cpus(), "non_acgt_bytes": int(n_bad),
+                            "note": "pgr_pack_ascii over the same contigs on the CPUs this process may use; NOT inside the packed "
+                                    "entry points' time (a host that stores or decodes its sequences 2-bit packed never runs it)"},
+            "same_shimmer_count_all_inputs": bool(n_sh == n_sh_p == n_sh_b),
+            "note": "sub-batches staged on a copy stream while the previous one computes; results (16 B per shimmer) come back "
+                    "through pinned windows"}
+
+
+def chromosome_like(seed=31, L=248_000_000):
+    """one reference-chromosome-like contig: an 18 Mbp run of N (centromere gap), forty gaps of 50 kbp - 1 Mbp, 300 isolated
+    N, 200 lower-case (soft-masked) stretches"""
+    import numpy as np
+    rng = np.random.default_rng(1)
+    s = np.concatenate([synth_substrings(seed, [0], [o], min(16_000_000, L - o))[0] for o in range(0, L, 16_000_000)])
+    s[int(L * 0.488):int(L * 0.488) + 18_000_000] = ord("N")
+    for _ in range(40):
+        a = int(rng.integers(0, L - 2_000_000))
+        s[a:a + int(rng.integers(50_000, 1_000_000))] = ord("N")
+    for _ in range(300):
+        s[int(rng.integers(0, L))] = ord("N")
+    for _ in range(200):
+        a = int(rng.integers(0, L - 100_000))
+        s[a:a + int(rng.integers(100, 50_000))] |= 0x20  # the same bases for the reference's table
+    return s
+
+
+def repeat_like(seed=7, lens=(30_000_000, 20_000_000, 10_000_000)):
+    """repeat-rich contigs the way assemblies have them: 171-bp satellite arrays with 1.5 % divergence, microsatellites,
+    reverse-complement symmetric units ((AT)n, (ACGT)n: every k-mer is its own reverse complement), homopolymers, tandem
+    duplications of a 10 kbp unit"""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+
+    def rnd(n):
+        return rng.choice(acgt, int(n))
+
+    def contig(L):
+        parts, n = [], 0
+        while n < L:
+            r = rng.random()
+            if r < 0.35:
+                p = rnd(rng.integers(50_000, 2_000_000))
+            elif r < 0.6:
+                total = int(rng.integers(200_000, 3_000_000))
+                p = np.tile(rnd(171), total // 171 + 1)[:total].copy()
+                m = rng.random(total) < 0.015
+                p[m] = rng.choice(acgt, int(m.sum()))
+            elif r < 0.8:
+                u = rnd(rng.integers(2, 7))
+                p = np.tile(u, int(rng.integers(1_000, 50_000)) // len(u) + 1)
+            elif r < 0.85:
+                u = np.frombuffer([b"AT", b"CG", b"ACGT", b"AATT", b"GAATTC"][int(rng.integers(0, 5))], dtype=np.uint8)
+                p = np.tile(u, int(rng.integers(1_000, 200_000)) // len(u) + 1)
+            elif r < 0.9:
+                p = np.full(int(rng.integers(100, 20_000)), acgt[int(rng.integers(0, 4))], dtype=np.uint8)
+            else:
+                p = np.tile(rnd(10_000), int(rng.integers(3, 40)))
+            parts.append(p)
+            n += len(p)
+        return np.concatenate(parts)[:L]
+    return [contig(L) for L in lens]
+
+
+def shapes_bench(P, ctx, spec, spec_t, cores, check):
+    """what real genomes look like next to the i.i.d. ACGT of the headline: gaps, satellites, a million short reads.  Inputs
+    resident in HBM; every result compared with the CPU restatement (whole-contig 128-bit checksums)."""
+    import numpy as np
+    O = None
+    if check:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O  # checker only
+
+    def run(batch):
+        batch.shmmrs(spec)
+        ts = []
+        sh = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            sh = batch.shmmrs(spec)
+            ts.append(time.perf_counter() - t0)
+        return min(ts), sh, ctx.last_prof()
+    out = {}
+    # 1. chromosome-like
+    s = chromosome_like()
+    b = P.Batch.from_seqs([s], ctx=ctx)
+    t, sh, prof = run(b)
+    e = {"bp": int(len(s)), "ms": t * 1e3, "Gbp_per_s": len(s) / t / 1e9, "shimmers": sh.count,
+         "Mbp_through_exact_islands": prof.exact_bases / 1e6, "non_acgt_bytes": int((s == ord("N")).sum()),
+         "what": "one 248 Mbp contig: an 18 Mbp run of N, forty gaps of 50 kbp - 1 Mbp, 300 isolated N, lower-case stretches"}
+    if O is not None:
+        t0 = time.perf_counter()
+        ref = O.sequence_to_shmmrs(0, s, O.spec(*spec_t))
+        e["cpu_one_thread_s"] = time.perf_counter() - t0
+        e["content_match"] = bool(len(ref) == sh.count and np.array_equal(sh.checksum()[0], O.shmmr_checksum(ref)))
+    out["chromosome_like"] = e
+    del b, sh, s
+    # 2. repeat-rich
+    seqs = repeat_like()
+    b = P.Batch.from_seqs(seqs, ctx=ctx)
+    t, sh, prof = run(b)
+    bp = sum(len(q) for q in seqs)
+    e = {"bp": int(bp), "ms": t * 1e3, "Gbp_per_s": bp / t / 1e9, "shimmers": sh.count, "level1_minimizers": int(prof.n_level1),
+         "Mbp_through_exact_islands": prof.exact_bases / 1e6,
+         "what": "60 Mbp in 3 contigs: satellite arrays, microsatellites, (AT)n / (ACGT)n, homopolymers, tandem duplications"}
+    if O is not None:
+        sums, off = sh.checksum(), sh.offsets()
+        ok = True
+        for i, q in enumerate(seqs):
+            ref = O.sequence_to_shmmrs(i, q, O.spec(*spec_t))
+            ok = ok and int(off[i + 1] - off[i]) == len(ref) and bool(np.array_equal(sums[i], O.shmmr_checksum(ref)))
+        e["content_match"] = bool(ok)
+    out["repeat_like"] = e
+    del b, sh, seqs
+    # 3. a million short reads
+    n, L = 1_000_000, 1_000
+    b = P.Batch.synthetic([L] * n, seed=41, ctx=ctx)
+    t, sh, prof = run(b)
+    e = {"bp": n * L, "ms": t * 1e3, "Gbp_per_s": n * L / t / 1e9, "shimmers": sh.count, "what": "10^6 x 1 kbp reads"}
+    if O is not None:
+        n_chk = 125_000
+        cnt, ref, _ = O.synth_checksums_threads(O.spec(*spec_t), n_chk, 41, 0, L, cores)
+        sums, off = sh.checksum(), sh.offsets()
+        same = int(np.sum((off[1:n_chk + 1] - off[:n_chk] == cnt) & np.all(sums[:n_chk] == ref, axis=1)))
+        e["reads_checked"] = n_chk
+        e["content_match"] = bool(same == n_chk)
+    out["short_reads"] = e
+    return out
+
+
+def target_100gbp(P, ctx, spec, args):
+    """BASELINE.json's target as a number: wall time to SHIMMER-index 100 Gbp of DISTINCT synthetic contigs (10 batches of
+    1000 x 10 Mbp, contig ids 0 .. 9999) into ONE index on this GPU -- generation of the synthetic input on the device,
+    shimmers, pair records, and the sort into the frag_map included (target: under 60 s on 8 GPUs)."""
+    n_b, n_c, L = 10, 1000, 10_000_000
+    ctx.synchronize()
+    t0 = time.perf_counter()
+    ix = P.Index(spec, ctx=ctx)
+    for bi in range(n_b):
+        ids = list(range(bi * n_c, (bi + 1) * n_c))
+        b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=ctx, contig_ids=ids)
+        ix.add_resident(b, sids=ids)
+        del b
+    t1 = time.perf_counter()
+    ix.finalize()
+    ctx.synchronize()
+    t2 = time.perf_counter()
+    bp = n_b * n_c * L
+    return {"bp": bp, "s": t2 - t0, "Gbp_per_s": bp / (t2 - t0) / 1e9, "batches_s": t1 - t0, "sort_into_frag_map_s": t2 - t1,
+            "index_records": ix.n_records, "index_keys": ix.n_keys, "n_gpus": 1,
+            "target": "BASELINE.json: >= 100 Gbp SHIMMER-indexed in under 60 s on 8 x MI355X",
+            "what": "%d batches of %d x %d bp distinct synthetic contigs generated on the device, one index (sorted CSR) at the end" %
+                    (n_b, n_c, L)}
 
 
 def main():
@@ -413,7 +590,7 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="partition ONE set of --contigs contigs over the ranks with exchange.shard_contigs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the all-gather of the shimmer lists")
+    ap.add_argument("--no-exchange", action="store_true", help="N>1: skip the merge (no record exchange, no index shards)")
     ap.add_argument("--exchange", default="abi", choices=["abi", "torch"],
                     help="N>1: abi = libpgrhip's pgr_exchange_* (RCCL linked by the library), torch = torch.distributed")
     ap.add_argument("--queries", type=int, default=10_000, help="query leg (after the timed region); 0 = off")
@@ -464,74 +641,60 @@ def main():
     batch = P.Batch.synthetic(lens, seed=args.seed, ctx=ctx, contig_ids=contig_ids)  # inputs resident in HBM
     bp_per_step = batch.total_bases
 
-    # ---- set-up (untimed): one probe pass sizes the output buffers, so that no step allocates
+    # ---- set-up (untimed): one probe pass sizes the record buffer, so that no step allocates it
     probe = batch.shmmrs(spec)
     dev = "cuda:%d" % local_rank
-    n_max = max(len(exchange.shard_contigs([args.contig_len] * args.contigs, world)[r]) for r in range(world)) if args.strong \
-        else args.contigs
-    cap_mm = int(probe.count * 1.05 * n_max / max(1, len(contig_ids))) + 1024
     rec_buf = torch.empty((int(probe.n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64, device=dev)
+    del probe
     xch = None
-    mm_bufs = out_bufs = None
     do_exchange = use_dist and not args.no_exchange
     use_abi = do_exchange and args.exchange == "abi" and args.backend == "nccl"
-    if do_exchange:
-        # double buffered: the all-gather of step i overlaps the kernels of step i+1
-        mm_bufs = [torch.empty((cap_mm, exchange.MM_WORDS), dtype=torch.int64, device=dev) for _ in range(2)]
-        gdev = dev if args.backend == "nccl" else "cpu"
-        out_bufs = [torch.empty((world * cap_mm, exchange.MM_WORDS), dtype=torch.int64, device=gdev) for _ in range(2)]
-        if use_abi:
-            # ncclUniqueId from rank 0 through the process group.  If the library's own communicator cannot be created on
-            # ANY rank (all ranks agree through an all-reduce), everybody falls back to torch.distributed's all-gather
-            try:
-                xch = exchange.AbiExchange(ctx, rank, world, dist)
-                ok = 1
-            except Exception as e:  # noqa: BLE001
-                print("rank %d: pgr_exchange_create failed (%r): torch.distributed all-gather instead" % (rank, e), file=sys.stderr)
-                xch, ok = None, 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                if xch is not None:
-                    xch.close()
-                xch, use_abi = None, False
-    del probe
+    if use_abi:
+        # ncclUniqueId from rank 0 through the process group.  If the library's own communicator cannot be created on
+        # ANY rank (all ranks agree through an all-reduce), everybody uses torch.distributed as the transport instead
+        try:
+            xch = exchange.AbiExchange(ctx, rank, world, dist)
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            print("rank %d: pgr_exchange_create failed (%r): torch.distributed transport instead" % (rank, e), file=sys.stderr)
+            xch, ok = None, 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if xch is not None:
+                xch.close()
+            xch, use_abi = None, False
     if use_dist:
         dist.barrier()  # creates the communicator here, not inside the first timed step
         torch.cuda.synchronize()
-    state = {"i": 0, "pending": None}
-
-    def finish_pending():
-        if state["pending"] is not None:
-            parts, counts = state["pending"].wait(concat=False)  # per-rank views into the gather buffer: no copy
-            state["gathered"] = parts
-            state["pending"] = None
+    state = {}
 
     def step():
         sh = batch.shmmrs(spec)
-        slot = state["i"] & 1
-        state["i"] += 1
-        n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=contig_ids)  # the per-GPU index shard
-        if mm_bufs is not None:
-            # what travels: the final MM128 lists with global sequence ids (16 B per shimmer; the pair records
-            # are adjacent shimmers and are re-derived by the receiver, pgr_index_add_shmmrs)
-            cnt = sh.count
-            finish_pending()  # step i-1's lists have arrived everywhere (and its buffer slot is free again)
-            sh.copy_into(mm_bufs[slot].data_ptr(), mm_bufs[slot].shape[0], rids=contig_ids)
-            if use_abi:
-                state["pending"] = xch.allgather_async(mm_bufs[slot], cnt, out_bufs[slot], cap_mm)
-            else:
-                local = mm_bufs[slot][:cnt]
-                state["pending"] = exchange.PendingAllgather(local if args.backend == "nccl" else local.cpu(),
-                                                             out=out_bufs[slot])
+        n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=contig_ids)  # this rank's pair records
         p = ctx.last_prof()
-        state["sh"] = sh
-        state["n_pairs"] = n
-        return p.level1_ms, p.level1_aux_ms, p.level2_ms, p.total_ms, p.bases_tiled, p.n_level1
+        x_ms = m_ms = 0.0
+        if do_exchange:
+            # the merge (seq_db.rs:605-612 is ONE map): key-range shards.  Every record travels to the rank that owns its
+            # range of first hashes (sample -> splitters -> stable partition -> one variable all-to-all), then each rank
+            # sorts its range: the shards in rank order are the single-process CSR
+            t0 = time.perf_counter()
+            ix = P.Index(spec, ctx=ctx)
+            if use_abi:
+                got, spl = xch.shard_records(rec_buf.data_ptr(), n, ix)
+            else:
+                got, spl = exchange.shard_records_torch(ctx, rec_buf.data_ptr(), n, ix)
+            t1 = time.perf_counter()
+            ix.finalize()
+            t2 = time.perf_counter()
+            x_ms, m_ms = (t1 - t0) * 1e3, (t2 - t1) * 1e3
+            state.update(shard=ix, splitters=spl, received=got)
+        state.update(sh=sh, n_pairs=n)
+        return p.level1_ms, p.level1_aux_ms, p.level2_ms, p.total_ms, p.bases_tiled, p.n_level1, x_ms, m_ms
 
     def sync():
-        finish_pending()
         torch.cuda.synchronize()
+        ctx.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
@@ -544,36 +707,87 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     total_bp = bp_per_step
+    tdev = dev if args.backend == "nccl" else "cpu"
+    k = max(1, args.steps)
+    x_ms = sum(p[6] for p in profs) / k
+    m_ms = sum(p[7] for p in profs) / k
     if use_dist:
-        tdev = ("cuda:%d" % local_rank) if args.backend == "nccl" else "cpu"
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+        t = torch.tensor([dt, x_ms, m_ms], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, x_ms, m_ms = float(t[0].item()), float(t[1].item()), float(t[2].item())
         t = torch.tensor([float(bp_per_step)], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         total_bp = int(t.item())
 
-    # query leg on N GPUs (after the timed region; a failure here must not cost the headline line)
-    dist_query = None
-    if use_dist and args.queries > 0 and state.get("gathered") is not None:
+    # ---- after the timed region: every rank proves what it computed and what it received
+    cores = effective_cpus()
+    sh = state["sh"]
+    my_cpu = None
+    if not args.no_cpu_baseline:
         try:
-            g = state["gathered"]
-            if args.strong:
-                all_ids = list(range(args.contigs))
-            else:
-                all_ids = list(range(world * args.contigs))
-            dist_query = query_bench_dist(P, ctx, spec, args, g, world, rank, dist, torch, local_rank, all_ids)
+            _mm_off = [int(v) for v in sh.offsets()]
+            gpu_counts = [_mm_off[i + 1] - _mm_off[i] for i in range(len(contig_ids))]
+            # N ranks share the node's CPUs: each checks its own contigs on cores / N threads, ~25 s of CPU work at most
+            my_cores = cores if world == 1 else max(1, cores // world)
+            my_cpu = cpu_baseline(spec_t, contig_ids, args.contig_len, args.seed, gpu_counts, sh.checksum(), my_cores,
+                                  budget_s=None if world == 1 else 25.0)
+        except Exception as e:  # noqa: BLE001
+            my_cpu = {"error": repr(e)[:300]}
+    exch_check = None
+    if do_exchange:
+        try:
+            sent = P.records_checksum(rec_buf.data_ptr(), state["n_pairs"], ctx=ctx)
+            shard = state["shard"]
+            mine = {"rank": rank, "sent": sent, "n_sent": int(state["n_pairs"]), "shard": shard.records_checksum(),
+                    "n_shard": int(shard.n_records), "n_keys": int(shard.n_keys), "key_range": shard.key_range(),
+                    "splitters": state["splitters"],
+                    "cpu": None if my_cpu is None else {k2: my_cpu.get(k2) for k2 in
+                                                        ("contigs_checked", "contigs_with_identical_checksum", "content_match",
+                                                         "counts_match_gpu", "error")}}
+            allv = [None] * world
+            dist.all_gather_object(allv, mine)
+            M = (1 << 64) - 1
+            s_sent = [sum(v["sent"][i] for v in allv) & M for i in (0, 1)]
+            s_shard = [sum(v["shard"][i] for v in allv) & M for i in (0, 1)]
+            spl = allv[0]["splitters"]
+            ranges_ok = all(v["splitters"] == spl for v in allv)
+            for r, v in enumerate(allv):
+                if v["n_shard"]:
+                    lo, hi = v["key_range"]
+                    ranges_ok = ranges_ok and (r == 0 or lo >= spl[r - 1]) and (r == world - 1 or hi < spl[r])
+            n_tot = sum(v["n_shard"] for v in allv)
+            exch_check = {
+                "what": "key-range sharded merge: every pair record went to the rank owning its range of first hashes",
+                "transport": "pgr_exchange_shard_records (RCCL behind the C ABI)" if use_abi else "torch.distributed (%s)" % args.backend,
+                "records_sent_all_ranks": sum(v["n_sent"] for v in allv), "records_in_shards": n_tot,
+                "checksum_of_sent_records": ["%016x" % x for x in s_sent], "checksum_of_shard_records": ["%016x" % x for x in s_shard],
+                "content_match": bool(s_sent == s_shard and n_tot == sum(v["n_sent"] for v in allv)),
+                "key_ranges_disjoint_and_ordered": bool(ranges_ok),
+                "records_per_shard": [v["n_shard"] for v in allv], "keys_per_shard": [v["n_keys"] for v in allv],
+                "largest_shard_over_mean": (max(v["n_shard"] for v in allv) * world / n_tot) if n_tot else None,
+                "check": "order-independent 128-bit checksum (pgr_records_checksum) of the records every rank produced, summed "
+                         "over the ranks, == the same over the records of the finalized shards; shard key ranges against the splitters",
+                "ranks_cpu_check": [v["cpu"] for v in allv],
+            }
+        except Exception as e:  # noqa: BLE001
+            exch_check = {"error": repr(e)[:300]}
+
+    # query leg on N GPUs (a failure here must not cost the headline line)
+    dist_query = None
+    if do_exchange and args.queries > 0 and state.get("shard") is not None:
+        try:
+            all_ids = list(range(args.contigs)) if args.strong else list(range(world * args.contigs))
+            dist_query = query_bench_dist(P, ctx, spec, args, state["shard"], xch if use_abi else None, exchange, world, rank, dist,
+                                          torch, local_rank, all_ids)
         except Exception as e:  # noqa: BLE001
             dist_query = {"error": repr(e)[:300]}
     if rank == 0:
-        k = max(1, args.steps)
         l1_ms = sum(p[0] for p in profs) / k
         aux_ms = sum(p[1] for p in profs) / k
         l2_ms = sum(p[2] for p in profs) / k
         tot_ms = sum(p[3] for p in profs) / k
         bases_tiled = profs[-1][4] if profs else 0
         achieved = ALGO_BYTES_PER_BP * bases_tiled / (l1_ms * 1e-3) / 1e9 if l1_ms > 0 else 0.0
-        sh = state["sh"]
         tr = committed("traffic.json") or {}
         out = {
             "metric": "Gbp/s SHIMMER-indexed (k=56,w=80,r=4)",
@@ -589,11 +803,12 @@ def main():
                             "lists + shimmer-pair records%s" %
                             (("%d x %d bp in total, partitioned over the ranks by shard_contigs" % (args.contigs, args.contig_len))
                              if args.strong else ("%d x %d bp per GPU" % (args.contigs, args.contig_len)), args.seed,
-                             "" if world == 1 else (", per-GPU shimmer lists (pair endpoints, 16 B each) all-gathered over RCCL "
-                                                    "(%s)" % ("pgr_exchange_*" if use_abi else "torch.distributed")
-                                                    if do_exchange else ", no exchange")),
+                             "" if not do_exchange else
+                             "; then the merge inside the timed step: pair records all-to-all by key range (%s), every rank "
+                             "sorts its range into its shard of the frag_map" %
+                             ("pgr_exchange_shard_records over RCCL" if use_abi else "torch.distributed " + args.backend)),
                 "bp_per_gpu_per_step": bp_per_step, "bp_per_step_all_gpus": total_bp,
-                "parallelism": "contig-sharded x%d" % world,
+                "parallelism": "contig-sharded x%d%s" % (world, ", key-range sharded index" if do_exchange else ""),
                 "final_shimmers_per_gpu": sh.count, "pair_records_per_gpu": state["n_pairs"],
             },
             "roofline": {
@@ -605,13 +820,39 @@ def main():
                 "valu_issue": valu_issue(bases_tiled, l1_ms),
                 "note": "achieved / peak / frac are the HBM-roofline figures of the metric (algorithmic bytes / launch time "
                         "against 8 TB/s).  What binds the kernel is VALU issue (two 64-bit mix hashes per position): see "
-                        "valu_issue.frac_of_cycle_weighted_bound and DESIGN.md section 5",
+                        "valu_issue and DESIGN.md section 5",
             },
             "stage_ms": {"level1_tile": l1_ms, "level1_tail_serial": aux_ms, "level2": l2_ms, "compute_total": tot_ms},
         }
-        cores = effective_cpus()
+        if do_exchange:
+            out["exchange_ms"] = x_ms   # sample + splitters + partition + counts + all-to-all (max over ranks, mean over steps)
+            out["merge_ms"] = m_ms      # sort of the rank's key range -> CSR + lookup tables (pgr_index_finalize)
+            out["value_definition"] = "all ranks' bases / (shimmers + pair records + exchange_ms + merge_ms), slowest rank"
+            out["exchange"] = exch_check
+        if my_cpu is not None:
+            out["cpu_baseline"] = my_cpu
+            if exch_check and "ranks_cpu_check" in exch_check:
+                rc_ = [c for c in exch_check["ranks_cpu_check"] if c]
+                out["cpu_baseline"]["contigs_checked_all_ranks"] = sum(int(c.get("contigs_checked") or 0) for c in rc_)
+                out["cpu_baseline"]["content_match_all_ranks"] = bool(rc_ and all(c.get("content_match") for c in rc_))
         if dist_query is not None:
             out["query"] = dist_query
+        if world == 1 and not do_exchange:
+            try:  # what the N > 1 merge costs when there is nothing to exchange: the same records into an index
+                reps = []
+                for _ in range(3):
+                    ctx.synchronize()
+                    t0 = time.perf_counter()
+                    ixb = P.Index(spec, ctx=ctx)
+                    ixb.add_records(device_ptr=rec_buf.data_ptr(), n=state["n_pairs"])
+                    ixb.finalize()
+                    reps.append(time.perf_counter() - t0)
+                    del ixb
+                ib = sorted(reps)[1] * 1e3
+                out["index_build_ms"] = ib
+                out["value_incl_index_build"] = total_bp / ((dt / max(1, args.steps)) + ib * 1e-3) / 1e9
+            except Exception as e:  # noqa: BLE001
+                out["index_build_ms"] = {"error": repr(e)[:300]}
         if world == 1 and args.queries > 0 and dist_query is None:
             try:
                 out["query"], _ix = query_bench(P, ctx, batch, spec, args, contig_ids)
@@ -620,23 +861,15 @@ def main():
                     out["query"]["cpu_baseline"] = query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores)
             except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
                 out.setdefault("query", {})["error"] = repr(e)[:300]
-        if world == 1 and not args.no_cpu_baseline:
-            try:
-                _mm_off = [int(v) for v in sh.offsets()]
-                gpu_counts = [_mm_off[i + 1] - _mm_off[i] for i in range(len(contig_ids))]
-                out["cpu_baseline"] = cpu_baseline(spec_t, len(contig_ids), args.contig_len, args.seed, contig_ids[0],
-                                                   gpu_counts, sh.checksum(), cores)
-            except Exception as e:  # noqa: BLE001
-                out["cpu_baseline"] = {"error": repr(e)[:300]}
         if world == 1 and not args.no_extras:
-            try:
-                out["latency"] = latency_bench(P, ctx, spec, args)
-            except Exception as e:  # noqa: BLE001
-                out["latency"] = {"error": repr(e)[:300]}
-            try:
-                out["pcie_inclusive"] = pcie_bench(P, ctx, spec, args)
-            except Exception as e:  # noqa: BLE001
-                out["pcie_inclusive"] = {"error": repr(e)[:300]}
+            for name, fn in (("latency", lambda: latency_bench(P, ctx, spec, args)),
+                             ("pcie_inclusive", lambda: pcie_bench(P, ctx, spec, args)),
+                             ("shapes", lambda: shapes_bench(P, ctx, spec, spec_t, cores, not args.no_cpu_baseline)),
+                             ("target_100Gbp", lambda: target_100gbp(P, ctx, spec, args))):
+                try:
+                    out[name] = fn()
+                except Exception as e:  # noqa: BLE001
+                    out[name] = {"error": repr(e)[:300]}
         try:  # RCCL prints a version banner through C stdio (block buffered on a pipe): push it out BEFORE the JSON line
             import ctypes
             ctypes.CDLL(None).fflush(None)
@@ -645,6 +878,7 @@ def main():
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
+        state.clear()
         if xch is not None:
             xch.close()
         dist.destroy_process_group()

@@ -326,6 +326,38 @@ const uint64_t *pgr_exchange_device_counts(const pgr_exchange *x);
 int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs *s, const uint32_t *rids, pgr_index *ix,
                                    uint64_t *n_gathered /* may be NULL */);
 
+/* ------------------------------------------------------------------ key-range sharded index
+ * The frag_map of the reference is one hash map filled serially (pgr-db/src/seq_db.rs:605-612).  With one process per GPU
+ * the key space is cut into `world` ranges of the first hash h0 and every pair record travels to the rank that owns its
+ * range: each rank sorts total / world records however many ranks there are, and the shards' CSRs in rank order ARE the
+ * single-process CSR (same keys, same per-key (sid, frg_id) order).
+ *   pgr_exchange_shard_records   collective: pooled sample of h0 -> world - 1 splitters (returned in splitters_out when
+ *                                not NULL), stable partition of this rank's records (device pointer), counts, one variable
+ *                                all-to-all (grouped ncclSend / ncclRecv) straight into `ix`.  *n_received = records that
+ *                                arrived in this call.  Finish the shard with pgr_index_finalize.
+ *   pgr_exchange_allgather_index collective: the replicated query index from the finalized shards (the concatenation of
+ *                                the sorted ranges needs no sort).
+ * The collective-free pieces, for hosts that bring their own transport (the tests run two ranks on one GPU over gloo):
+ *   pgr_shard_sample_keys  up to n_samples first hashes of the records, evenly spaced (host output)
+ *   pgr_shard_splitters    host only: quantiles of the pooled samples; record -> rank = number of splitters <= h0
+ *   pgr_shard_partition    d_out = the records grouped by destination rank (stable), counts[world] on the host
+ *   pgr_records_checksum / pgr_index_records_checksum   order-independent 128-bit content checksum of a record set: the
+ *                          sums over all ranks before and after the exchange must agree                              */
+int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d_recs, uint64_t n, pgr_index *ix,
+                               uint64_t *splitters_out /* world - 1, may be NULL */, uint64_t *n_received /* may be NULL */);
+int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *shard, pgr_index **out);
+int pgr_shard_sample_keys(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uint64_t n, uint32_t n_samples, uint64_t *out,
+                          uint32_t *n_out);
+int pgr_shard_splitters(const uint64_t *samples, uint64_t n, int world, uint64_t *splitters /* world - 1 */);
+int pgr_shard_partition(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uint64_t n, const uint64_t *splitters, int world,
+                        pgr_frag_rec *d_out, uint64_t *counts /* host, world */);
+int pgr_records_checksum(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uint64_t n, uint64_t out[2]);
+int pgr_index_records_checksum(pgr_ctx *ctx, const pgr_index *ix, uint64_t out[2]);
+/* device pointer to the index's records: sorted after pgr_index_finalize, in append order before */
+const pgr_frag_rec *pgr_index_device_records(const pgr_index *ix);
+/* first hash of the first and of the last record of a finalized index (a shard's key range) */
+int pgr_index_key_range(pgr_ctx *ctx, const pgr_index *ix, uint64_t *h0_min, uint64_t *h0_max);
+
 /* ------------------------------------------------------------------ next: MAP-graph + principal bundles
  * Consumers of the frag_map (BASELINE.json configs[3], pgr-pbundle-decomp).  The data-parallel parts run on
  * the GPU (adjacency list = one sort + a 2-point stencil over all records; bundle lookup of every shimmer pair);

@@ -98,6 +98,9 @@ def lib():
         L.orc_synth_checksums_threads.restype = C.c_int
         L.orc_synth_checksums_threads.argtypes = [C.POINTER(Spec), C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int,
                                                   C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_synth_checksums_ids_threads.restype = C.c_int
+        L.orc_synth_checksums_ids_threads.argtypes = [C.POINTER(Spec), C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p,
+                                                      C.c_size_t, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_index_add_synth_threads.restype = C.c_int
         L.orc_index_add_synth_threads.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint64, C.c_size_t, C.c_int]
         L.orc_query_batch_threads.restype = C.c_int
@@ -191,6 +194,18 @@ def synth_checksums_threads(sp, n, seed, contig0, length, n_threads):
     busy = np.zeros(max(n_threads, 1), dtype=np.float64)
     lib().orc_synth_checksums_threads(C.byref(sp), n, seed, contig0, length, n_threads, counts.ctypes.data, sums.ctypes.data,
                                       busy.ctypes.data)
+    return counts[:n], sums[:n], busy
+
+
+def synth_checksums_ids_threads(sp, ids, seed, length, n_threads):
+    """the same for an explicit list of contig ids (one rank's shard of a partitioned contig set)"""
+    ids = np.ascontiguousarray(ids, dtype=np.uint64)
+    n = int(ids.size)
+    counts = np.zeros(max(n, 1), dtype=np.uint64)
+    sums = np.zeros((max(n, 1), 2), dtype=np.uint64)
+    busy = np.zeros(max(n_threads, 1), dtype=np.float64)
+    lib().orc_synth_checksums_ids_threads(C.byref(sp), n, seed, 0, ids.ctypes.data if n else None, length, n_threads,
+                                          counts.ctypes.data, sums.ctypes.data, busy.ctypes.data)
     return counts[:n], sums[:n], busy
 
 

@@ -923,6 +923,7 @@ typedef struct {
     const orc_spec *spec;
     uint32_t n;
     uint64_t seed, contig0;
+    const uint64_t *ids; /* NULL: contig0 + i */
     size_t len;
     uint64_t *counts, *sums;
     double *busy;
@@ -952,7 +953,7 @@ static void *synth_worker(void *argp) {
         uint32_t i = job->next++;
         pthread_mutex_unlock(&job->mu);
         if (i >= job->n) break;
-        orc_synth_contig(job->seed, job->contig0 + i, job->len, buf);
+        orc_synth_contig(job->seed, job->ids ? job->ids[i] : job->contig0 + i, job->len, buf);
         orc_mm128 *o = NULL;
         const double t0 = now_s();
         size_t n = orc_sequence_to_shmmrs(i, buf, job->len, job->spec, 0, &o);
@@ -969,10 +970,17 @@ static void *synth_worker(void *argp) {
 
 int orc_synth_checksums_threads(const orc_spec *spec, uint32_t n, uint64_t seed, uint64_t contig0, size_t len,
                                 int n_threads, uint64_t *counts, uint64_t *sums, double *busy_s) {
+    return orc_synth_checksums_ids_threads(spec, n, seed, contig0, NULL, len, n_threads, counts, sums, busy_s);
+}
+
+/* the same for an arbitrary list of contig ids (one rank's shard of a partitioned contig set); ids == NULL: contig0 + i */
+int orc_synth_checksums_ids_threads(const orc_spec *spec, uint32_t n, uint64_t seed, uint64_t contig0, const uint64_t *ids,
+                                    size_t len, int n_threads, uint64_t *counts, uint64_t *sums, double *busy_s) {
     synth_job job;
     job.spec = spec;
     job.n = n;
     job.seed = seed;
+    job.ids = ids;
     job.contig0 = contig0;
     job.len = len;
     job.counts = counts;

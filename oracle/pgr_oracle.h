@@ -134,6 +134,8 @@ void orc_shmmr_checksum(const orc_mm128 *mm, size_t n, uint64_t out[2]);
  * contig: counts[n], sums[2n], busy_s[n_threads] = seconds each thread spent inside orc_sequence_to_shmmrs */
 int orc_synth_checksums_threads(const orc_spec *spec, uint32_t n, uint64_t seed, uint64_t contig0, size_t len,
                                 int n_threads, uint64_t *counts, uint64_t *sums, double *busy_s);
+int orc_synth_checksums_ids_threads(const orc_spec *spec, uint32_t n, uint64_t seed, uint64_t contig0, const uint64_t *ids,
+                                    size_t len, int n_threads, uint64_t *counts, uint64_t *sums, double *busy_s);
 /* index over n synthetic contigs (sid0 + i <- contig0 + i): records computed by a thread pool, inserted in sid order */
 int orc_index_add_synth_threads(orc_index *ix, uint32_t n, uint32_t sid0, uint64_t seed, uint64_t contig0, size_t len,
                                 int n_threads);

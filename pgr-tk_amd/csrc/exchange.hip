@@ -34,6 +34,11 @@ struct Rccl {
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
     std::string err;
 };
@@ -59,6 +64,11 @@ Rccl &rccl() {
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.Broadcast = (decltype(r.Broadcast))sym("ncclBroadcast");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     return r;
@@ -229,5 +239,151 @@ extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs 
             if (counts[(size_t)r] && (rc = pgr_index_add_shmmrs(ctx, ix, out.as<pgr_mm128>() + (size_t)r * cap, counts[(size_t)r], 1)))
                 return rc;
     PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the temporaries go back to the allocator
+    return PGR_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Key-range sharded index ("key-range partitioned"; the pieces without a collective are in
+// csrc/shard.hip).  One variable all-to-all: every rank cuts ITS pair records into `world` key ranges (splitters = quantiles
+// of a pooled sample of first hashes, identical on every rank) and sends range r to rank r with grouped ncclSend/ncclRecv,
+// straight into the receiver's index.  Each rank then sorts total/world records, whatever the number of ranks.
+namespace {
+constexpr uint32_t SHARD_SAMPLES = 4096;  // per rank; the imbalance of the ranges is ~1/sqrt(world * samples)
+constexpr size_t REC_WORDS = sizeof(pgr_frag_rec) / 8;
+static_assert(sizeof(pgr_frag_rec) % 8 == 0, "records travel as u64 words");
+}  // namespace
+
+extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d_recs, uint64_t n, pgr_index *ix,
+                                          uint64_t *splitters_out, uint64_t *n_received) {
+    if (!x) return PGR_ERR_INVALID_ARG;
+    pgr_ctx *ctx = x->ctx;
+    if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange (call pgr_exchange_wait)");
+    if (!ix || (n && !d_recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (ix->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "index belongs to another context");
+    Rccl &R = rccl();
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    const int world = x->world, me = x->rank;
+    int rc;
+    // ---- 1. pooled sample of first hashes -> splitters (the same on every rank)
+    std::vector<uint64_t> mine(1 + SHARD_SAMPLES, 0);
+    uint32_t n_s = 0;
+    if ((rc = pgr_shard_sample_keys(ctx, d_recs, n, SHARD_SAMPLES, mine.data() + 1, &n_s))) return rc;  // synchronizes
+    mine[0] = n_s;
+    pgr::Tmp d_smp(ctx), d_all(ctx);
+    if ((rc = d_smp.alloc(mine.size() * 8)) || (rc = d_all.alloc((size_t)world * mine.size() * 8))) return rc;
+    std::vector<uint64_t> all((size_t)world * mine.size());
+    PGR_HIP(ctx, hipMemcpyAsync(d_smp.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, x->stream));
+    PGR_NCCL(ctx, R.AllGather(d_smp.p, d_all.p, mine.size(), ncclUint64, x->comm, x->stream));
+    PGR_HIP(ctx, hipMemcpyAsync(all.data(), d_all.p, all.size() * 8, hipMemcpyDeviceToHost, x->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    std::vector<uint64_t> pool;
+    for (int r = 0; r < world; ++r) {
+        const uint64_t *blk = all.data() + (size_t)r * mine.size();
+        pool.insert(pool.end(), blk + 1, blk + 1 + std::min<uint64_t>(blk[0], SHARD_SAMPLES));
+    }
+    std::vector<uint64_t> splitters((size_t)std::max(world - 1, 1));
+    if (pgr_shard_splitters(pool.data(), pool.size(), world, splitters.data())) return ctx->fail(PGR_ERR_INTERNAL, "splitters");
+    if (splitters_out)
+        for (int j = 0; j + 1 < world; ++j) splitters_out[j] = splitters[(size_t)j];
+    // ---- 2. stable partition of this rank's records by destination
+    pgr::Tmp d_part(ctx);
+    std::vector<uint64_t> send_cnt((size_t)world, 0);
+    if ((rc = d_part.alloc(std::max<uint64_t>(n, 1) * sizeof(pgr_frag_rec)))) return rc;
+    if ((rc = pgr_shard_partition(ctx, d_recs, n, splitters.data(), world, d_part.as<pgr_frag_rec>(), send_cnt.data()))) return rc;
+    // ---- 3. everybody's counts: M[src][dst]
+    pgr::Tmp d_cnt(ctx), d_mat(ctx);
+    if ((rc = d_cnt.alloc((size_t)world * 8)) || (rc = d_mat.alloc((size_t)world * world * 8))) return rc;
+    std::vector<uint64_t> mat((size_t)world * world);
+    PGR_HIP(ctx, hipMemcpyAsync(d_cnt.p, send_cnt.data(), (size_t)world * 8, hipMemcpyHostToDevice, x->stream));
+    PGR_NCCL(ctx, R.AllGather(d_cnt.p, d_mat.p, (size_t)world, ncclUint64, x->comm, x->stream));
+    PGR_HIP(ctx, hipMemcpyAsync(mat.data(), d_mat.p, mat.size() * 8, hipMemcpyDeviceToHost, x->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    uint64_t recv_total = 0;
+    for (int s = 0; s < world; ++s) recv_total += mat[(size_t)s * world + me];
+    if (ix->n_raw + recv_total >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "index shard would hold 2^32 or more records");
+    if ((rc = pgr::index_grow_raw(ctx, ix, ix->n_raw + recv_total))) return rc;
+    // ---- 4. the payload: blocks arrive in source-rank order, each in its sender's (sid, frg_id) order
+    PGR_NCCL(ctx, R.GroupStart());
+    uint64_t s_off = 0, r_off = 0;
+    ncclResult_t nr = ncclSuccess;
+    hipError_t he = hipSuccess;
+    for (int p = 0; p < world; ++p) {
+        const uint64_t sc = send_cnt[(size_t)p], rcv = mat[(size_t)p * world + me];
+        if (p == me) {
+            if (sc && he == hipSuccess)
+                he = hipMemcpyAsync(ix->raw + ix->n_raw + r_off, d_part.as<pgr_frag_rec>() + s_off, sc * sizeof(pgr_frag_rec),
+                                    hipMemcpyDeviceToDevice, x->stream);
+        } else {
+            if (sc && nr == ncclSuccess)
+                nr = R.Send(d_part.as<pgr_frag_rec>() + s_off, sc * REC_WORDS, ncclUint64, p, x->comm, x->stream);
+            if (rcv && nr == ncclSuccess)
+                nr = R.Recv(ix->raw + ix->n_raw + r_off, rcv * REC_WORDS, ncclUint64, p, x->comm, x->stream);
+        }
+        s_off += sc;
+        r_off += rcv;
+    }
+    const ncclResult_t ge = R.GroupEnd();
+    if (nr != ncclSuccess || ge != ncclSuccess)
+        return ctx->fail(PGR_ERR_DEVICE, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(nr != ncclSuccess ? nr : ge));
+    if (he != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("local block copy: ") + hipGetErrorString(he));
+    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    PGR_HIP(ctx, hipGetLastError());
+    ix->n_raw += recv_total;
+    ix->finalized = false;
+    if (n_received) *n_received = recv_total;
+    return PGR_OK;
+}
+
+// The replicated query index from the finalized shards: every rank receives every shard in rank order (ncclBroadcast per
+// rank, grouped).  The ranges are disjoint and ascending, so the concatenation is already the sorted record array of the
+// whole index; pgr_index_finalize notices and skips the sort.
+extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *shard, pgr_index **out) {
+    if (!x) return PGR_ERR_INVALID_ARG;
+    pgr_ctx *ctx = x->ctx;
+    if (!shard || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (!shard->finalized) return ctx->fail(PGR_ERR_STATE, "shard index not finalized");
+    if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange");
+    *out = nullptr;
+    Rccl &R = rccl();
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    const int world = x->world, me = x->rank;
+    int rc;
+    x->h_cnt[0] = shard->n;
+    PGR_HIP(ctx, hipMemcpyAsync(x->d_cnt, x->h_cnt, sizeof(unsigned long long), hipMemcpyHostToDevice, x->stream));
+    PGR_NCCL(ctx, R.AllGather(x->d_cnt, x->d_cnt + 1, 1, ncclUint64, x->comm, x->stream));
+    PGR_HIP(ctx, hipMemcpyAsync(x->h_cnt + 1, x->d_cnt + 1, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                x->stream));
+    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    uint64_t total = 0;
+    for (int r = 0; r < world; ++r) total += x->h_cnt[1 + r];
+    if (total >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "replicated index would hold 2^32 or more records");
+    pgr_index *full = nullptr;
+    if ((rc = pgr_index_create(ctx, &shard->spec, &full))) return rc;
+    if ((rc = pgr::index_grow_raw(ctx, full, total))) {
+        pgr_index_destroy(full);
+        return rc;
+    }
+    ncclResult_t nr = R.GroupStart();
+    uint64_t off = 0;
+    for (int r = 0; r < world && nr == ncclSuccess; ++r) {
+        const uint64_t c = x->h_cnt[1 + r];
+        if (c) nr = R.Broadcast(r == me ? (const void *)shard->recs : (const void *)(full->raw + off), full->raw + off, c * REC_WORDS,
+                                ncclUint64, r, x->comm, x->stream);
+        off += c;
+    }
+    const ncclResult_t ge = R.GroupEnd();
+    hipError_t he = hipStreamSynchronize(x->stream);
+    if (nr != ncclSuccess || ge != ncclSuccess || he != hipSuccess) {
+        pgr_index_destroy(full);
+        return ctx->fail(PGR_ERR_DEVICE, std::string("index all-gather: ") +
+                                             (he != hipSuccess ? hipGetErrorString(he) : R.GetErrorString(nr != ncclSuccess ? nr : ge)));
+    }
+    full->n_raw = total;
+    full->next_sid = shard->next_sid;
+    if ((rc = pgr_index_finalize(ctx, full))) {
+        pgr_index_destroy(full);
+        return rc;
+    }
+    *out = full;
     return PGR_OK;
 }

@@ -62,12 +62,16 @@ __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint
 // usual case) -- then the stable sort by the key alone leaves the records of a key in the order seq_db.rs:605-612 gives
 __global__ void unsorted_flag_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n, uint32_t *__restrict__ flag) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    bool bad = false;
+    bool bad = false, bad_key = false;
     if (i + 1 < n) {
         const pgr_frag_rec &a = recs[i], &b = recs[i + 1];
-        bad = a.sid > b.sid || (a.sid == b.sid && a.frg_id > b.frg_id);
+        const bool id_gt = a.sid > b.sid || (a.sid == b.sid && a.frg_id > b.frg_id);
+        bad = id_gt;
+        // flag[1]: not already in full (h0, h1, sid, frg_id) order (concatenated sorted key ranges need no sort at all)
+        bad_key = a.h0 > b.h0 || (a.h0 == b.h0 && (a.h1 > b.h1 || (a.h1 == b.h1 && id_gt)));
     }
     if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+    if (__ballot(bad_key) && (threadIdx.x & 63) == 0) atomicOr(flag + 1, 1u);
 }
 
 __global__ void gather_recs_kernel(const pgr_frag_rec *__restrict__ in, const uint32_t *__restrict__ idx,
@@ -162,9 +166,7 @@ void pgr::launch_gather_recs(hipStream_t st, const pgr_frag_rec *in, const uint3
     if (n) hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, in, idx, out, n);
 }
 
-namespace {
-
-int grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) {
+int pgr::index_grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) {
     if (need <= ix->cap_raw) return PGR_OK;
     const uint64_t cap = std::max<uint64_t>(need + need / 2, 1024);
     pgr_frag_rec *np = nullptr;
@@ -183,8 +185,7 @@ int grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) {
     ix->cap_raw = cap;
     return PGR_OK;
 }
-
-}  // namespace
+static int grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) { return pgr::index_grow_raw(ctx, ix, need); }
 
 // ------------------------------------------------------------------------------------------------
 extern "C" int pgr_index_create(pgr_ctx *ctx, const pgr_spec *spec, pgr_index **out) {
@@ -398,18 +399,24 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     // records appended in (sid, frg_id) order need only the two key passes of the stable LSD sort (64 of 176 key bits less)
     Tmp d_unsorted(ctx);
     if ((rc = d_unsorted.alloc(16))) return rc;
-    uint32_t unsorted = 1;
+    uint32_t unsorted[2] = {1, 1};
     PGR_HIP(ctx, hipMemsetAsync(d_unsorted.p, 0, 16, st));
     hipLaunchKernelGGL(unsorted_flag_kernel, grid_for(n), dim3(256), 0, st, ix->raw, n, d_unsorted.as<uint32_t>());
-    PGR_HIP(ctx, hipMemcpyAsync(&unsorted, d_unsorted.p, 4, hipMemcpyDeviceToHost, st));
+    PGR_HIP(ctx, hipMemcpyAsync(unsorted, d_unsorted.p, 8, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
-    const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
-    const unsigned bits[4] = {32, 32, 56, 56};
-    const int skip = (unsorted || getenv("PGR_INDEX_FULL_SORT")) ? 0 : 2;
-    if ((rc = sort_perm(ctx, ix->raw, n, fields + skip, bits + skip, 4 - skip, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
-                        keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
-        return rc;
-    hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, ix->raw, idx_a.as<uint32_t>(), ix->recs, n);
+    const bool full_sort = getenv("PGR_INDEX_FULL_SORT") != nullptr;
+    if (!unsorted[1] && !full_sort) {
+        // already in (h0, h1, sid, frg_id) order: the concatenation of finalized key-range shards (csrc/exchange.hip)
+        PGR_HIP(ctx, hipMemcpyAsync(ix->recs, ix->raw, n * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, st));
+    } else {
+        const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
+        const unsigned bits[4] = {32, 32, 56, 56};
+        const int skip = (unsorted[0] || full_sort) ? 0 : 2;
+        if ((rc = sort_perm(ctx, ix->raw, n, fields + skip, bits + skip, 4 - skip, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+                            keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
+            return rc;
+        hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, ix->raw, idx_a.as<uint32_t>(), ix->recs, n);
+    }
     // distinct keys -> key_off
     if ((rc = flags.alloc((n + 1) * 4)) || (rc = rank.alloc((n + 1) * 8))) return rc;
     hipLaunchKernelGGL(key_flags_kernel, grid_for(n + 1), dim3(256), 0, st, ix->recs, n, flags.as<uint32_t>());

@@ -56,6 +56,8 @@ enum RecField { F_FRG_ID = 0, F_SID = 1, F_H1 = 2, F_H0 = 3, F_BGN = 4, F_END = 
 // idx_a: in = initial permutation, out = sorted permutation
 int sort_perm(pgr_ctx *ctx, const pgr_frag_rec *recs, uint64_t n, const int *fields, const unsigned *bits, int n_fields,
               uint32_t *idx_a, uint32_t *idx_b, uint64_t *keys_a, uint64_t *keys_b);
+// room for `need` appended records (contents kept)
+int index_grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need);
 void launch_iota(hipStream_t st, uint32_t *idx, uint64_t n);
 void launch_gather_recs(hipStream_t st, const pgr_frag_rec *in, const uint32_t *idx, pgr_frag_rec *out, uint64_t n);
 

@@ -196,6 +196,14 @@ class Shmmrs:
             pass
 
 
+def records_checksum(device_ptr, n, ctx=None):
+    """order-independent 128-bit content checksum of n pair records at a DEVICE pointer -> (a, b)"""
+    ctx = ctx or default_context()
+    out = np.zeros(2, dtype=np.uint64)
+    ctx.check(lib().pgr_records_checksum(ctx.handle, C.c_void_p(device_ptr), int(n), out.ctypes.data))
+    return int(out[0]), int(out[1])
+
+
 def sequence_to_shmmrs_batch(seqs, spec, rids=None, padding=False, ctx=None):
     """batched shmmrutils::sequence_to_shmmrs (shmmrutils.rs:657-669) -> list of MM128 arrays"""
     ctx = ctx or default_context()
@@ -295,11 +303,30 @@ class _HpsOwner:
 class Index:
     """ShmmrToFrags on the GPU (pgr_index): sorted CSR of fragment signatures + the query entry point."""
 
-    def __init__(self, spec, ctx=None):
+    def __init__(self, spec, ctx=None, _handle=None):
         self.ctx = ctx or default_context()
         self.spec = spec
         self._h = C.c_void_p()
-        self.ctx.check(lib().pgr_index_create(self.ctx.handle, C.byref(spec), C.byref(self._h)))
+        if _handle is not None:  # an index the library built (pgr_exchange_allgather_index, pgr_index_load_mdb)
+            self._h = _handle
+        else:
+            self.ctx.check(lib().pgr_index_create(self.ctx.handle, C.byref(spec), C.byref(self._h)))
+
+    def records_checksum(self):
+        """order-independent 128-bit content checksum of the index's records -> (a, b)"""
+        out = np.zeros(2, dtype=np.uint64)
+        self.ctx.check(lib().pgr_index_records_checksum(self.ctx.handle, self._h, out.ctypes.data))
+        return int(out[0]), int(out[1])
+
+    def key_range(self):
+        """(first hash of the first record, first hash of the last record) of a finalized index"""
+        lo, hi = C.c_uint64(), C.c_uint64()
+        self.ctx.check(lib().pgr_index_key_range(self.ctx.handle, self._h, C.byref(lo), C.byref(hi)))
+        return int(lo.value), int(hi.value)
+
+    @property
+    def device_records(self):
+        return lib().pgr_index_device_records(self._h)
 
     def add_resident(self, batch, sids=None):
         keep, sp = _u32_array(sids, batch.n)

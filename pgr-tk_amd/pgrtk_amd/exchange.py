@@ -89,6 +89,24 @@ class AbiExchange:
                                                                  C.c_void_p(out.data_ptr()), int(cap_per_rank)))
         return _AbiPending(self, out, cap_per_rank)
 
+    def shard_records(self, recs_ptr, n, index):
+        """pgr_exchange_shard_records: this rank's pair records (DEVICE pointer) travel to the ranks that own their key
+        ranges, straight into `index` (finish it with index.finalize()).  -> (records received, splitters)"""
+        from ._ffi import lib
+        spl = np.zeros(max(self.world - 1, 1), dtype=np.uint64)
+        got = C.c_uint64()
+        self.ctx.check(lib().pgr_exchange_shard_records(self._h, C.c_void_p(recs_ptr), int(n), index._h,
+                                                        spl.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(got)))
+        return int(got.value), [int(v) for v in spl[:self.world - 1]]
+
+    def allgather_index(self, shard):
+        """pgr_exchange_allgather_index: the replicated (finalized) index from every rank's finalized shard"""
+        from ._ffi import lib
+        from .engine import Index
+        h = C.c_void_p()
+        self.ctx.check(lib().pgr_exchange_allgather_index(self._h, shard._h, C.byref(h)))
+        return Index(shard.spec, ctx=self.ctx, _handle=h)
+
     def close(self):
         from ._ffi import lib
         if self._h:
@@ -180,3 +198,89 @@ def allgather_records(local, group=None):
         return out, counts_h
     parts = [out[r * n_max: r * n_max + counts_h[r]] for r in range(world)]
     return torch.cat(parts, dim=0), counts_h
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# key-range sharded index over torch.distributed (the transport of the CPU / one-GPU tests; on a multi-GPU node
+# AbiExchange.shard_records does the same through RCCL inside the library).  The device work -- sampling, stable
+# partition, checksums -- is libpgrhip's (pgr_shard_*); torch only moves bytes.
+SHARD_SAMPLES = 4096
+
+
+def shard_splitters(samples_per_rank, world):
+    """pgr_shard_splitters on the pooled samples (a list of uint64 arrays, one per rank) -> world - 1 splitters"""
+    from ._ffi import lib
+    pool = np.ascontiguousarray(np.concatenate([np.asarray(a, dtype=np.uint64) for a in samples_per_rank])
+                                if samples_per_rank else np.zeros(0, dtype=np.uint64))
+    spl = np.zeros(max(world - 1, 1), dtype=np.uint64)
+    rc = lib().pgr_shard_splitters(C.c_void_p(pool.ctypes.data if pool.size else 0), int(pool.size), int(world),
+                                   C.c_void_p(spl.ctypes.data))
+    if rc != 0:
+        raise ValueError("pgr_shard_splitters: bad arguments")
+    return spl[:world - 1]
+
+
+def shard_records_torch(ctx, recs_ptr, n, index, group=None):
+    """the steps of pgr_exchange_shard_records with torch.distributed as the transport.  recs_ptr: DEVICE pointer to this
+    rank's n pair records.  -> (records received, splitters)"""
+    from ._ffi import lib
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    # 1. pooled sample -> splitters
+    smp = np.zeros(1 + SHARD_SAMPLES, dtype=np.uint64)
+    n_s = C.c_uint32()
+    ctx.check(lib().pgr_shard_sample_keys(ctx.handle, C.c_void_p(recs_ptr), int(n), SHARD_SAMPLES,
+                                          C.c_void_p(smp.ctypes.data + 8), C.byref(n_s)))
+    smp[0] = n_s.value
+    t = torch.from_numpy(smp.view(np.int64))
+    allt = torch.empty(world * smp.size, dtype=torch.int64)
+    if on_gpu:
+        t, allt = t.to(dev), allt.to(dev)
+    dist.all_gather_into_tensor(allt, t, group=group)
+    alls = allt.cpu().numpy().view(np.uint64).reshape(world, smp.size)
+    spl = shard_splitters([alls[r, 1:1 + int(alls[r, 0])] for r in range(world)], world)
+    # 2. stable partition by destination rank (device)
+    part = torch.empty((max(int(n), 1), REC_WORDS), dtype=torch.int64, device=dev)
+    counts = np.zeros(world, dtype=np.uint64)
+    spl_arg = np.ascontiguousarray(spl) if world > 1 else np.zeros(1, dtype=np.uint64)
+    ctx.check(lib().pgr_shard_partition(ctx.handle, C.c_void_p(recs_ptr), int(n), C.c_void_p(spl_arg.ctypes.data), world,
+                                        C.c_void_p(part.data_ptr()), C.c_void_p(counts.ctypes.data)))
+    # 3. counts, 4. payload
+    send_cnt = torch.from_numpy(counts.astype(np.int64))
+    recv_cnt = torch.empty(world, dtype=torch.int64)
+    if on_gpu:
+        send_cnt, recv_cnt = send_cnt.to(dev), recv_cnt.to(dev)
+    dist.all_to_all_single(recv_cnt, send_cnt, group=group)
+    rc_l = [int(v) for v in recv_cnt.cpu()]
+    sc_l = [int(v) for v in counts]
+    src = part[:int(n)] if on_gpu else part[:int(n)].cpu()
+    out = torch.empty((sum(rc_l), REC_WORDS), dtype=torch.int64, device=src.device)
+    dist.all_to_all_single(out, src, output_split_sizes=rc_l, input_split_sizes=sc_l, group=group)
+    if on_gpu:
+        torch.cuda.current_stream().synchronize()
+    got = out if on_gpu else out.to(dev)
+    if got.shape[0]:
+        index.add_records(device_ptr=got.data_ptr(), n=int(got.shape[0]))
+    return int(got.shape[0]), [int(v) for v in spl]
+
+
+def allgather_index_torch(shard, group=None):
+    """the replicated index from the finalized shards over torch.distributed (counterpart of pgr_exchange_allgather_index)"""
+    from .engine import Index
+    world = dist.get_world_size(group)
+    on_gpu = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    n = shard.n_records
+    # (the shard's sorted records go through host memory here: this is the test transport; a multi-GPU node uses
+    # AbiExchange.allgather_index, device to device)
+    mine = torch.from_numpy(np.ascontiguousarray(shard.download()).view(np.int64).reshape(n, REC_WORDS).copy()).to(dev) if n \
+        else torch.empty((0, REC_WORDS), dtype=torch.int64, device=dev)
+    gathered, counts = PendingAllgather(mine[:n] if on_gpu else mine[:n].cpu(), group=group).wait()
+    g = gathered if gathered.is_cuda else gathered.to(dev)
+    full = Index(shard.spec, ctx=shard.ctx)
+    if int(g.shape[0]):
+        g = g.contiguous()
+        full.add_records(device_ptr=g.data_ptr(), n=int(g.shape[0]))
+    full.finalize()
+    return full
