@@ -334,7 +334,9 @@ int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs *s, const u
  *   pgr_exchange_shard_records   collective: pooled sample of h0 -> world - 1 splitters (returned in splitters_out when
  *                                not NULL), stable partition of this rank's records (device pointer), counts, one variable
  *                                all-to-all (grouped ncclSend / ncclRecv) straight into `ix`.  *n_received = records that
- *                                arrived in this call.  Finish the shard with pgr_index_finalize.
+ *                                arrived in this call.  A host that feeds ONE index over several calls passes
+ *                                reuse_splitters != 0 from the second call on (the ranges must not move between calls).
+ *                                Finish the shard with pgr_index_finalize.
  *   pgr_exchange_allgather_index collective: the replicated query index from the finalized shards (the concatenation of
  *                                the sorted ranges needs no sort).
  * The collective-free pieces, for hosts that bring their own transport (the tests run two ranks on one GPU over gloo):
@@ -344,7 +346,8 @@ int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs *s, const u
  *   pgr_records_checksum / pgr_index_records_checksum   order-independent 128-bit content checksum of a record set: the
  *                          sums over all ranks before and after the exchange must agree                              */
 int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d_recs, uint64_t n, pgr_index *ix,
-                               uint64_t *splitters_out /* world - 1, may be NULL */, uint64_t *n_received /* may be NULL */);
+                               int reuse_splitters, uint64_t *splitters_out /* world - 1, may be NULL */,
+                               uint64_t *n_received /* may be NULL */);
 int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *shard, pgr_index **out);
 int pgr_shard_sample_keys(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uint64_t n, uint32_t n_samples, uint64_t *out,
                           uint32_t *n_out);

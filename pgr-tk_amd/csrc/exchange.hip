@@ -85,6 +85,8 @@ struct pgr_exchange {
     unsigned long long *d_cnt = nullptr;   // [1 + world]: this rank's count, then everybody's
     unsigned long long *h_cnt = nullptr;   // pinned [1 + world]
     bool in_flight = false;
+    std::vector<uint64_t> splitters;  // world - 1 key-range boundaries of the last pgr_exchange_shard_records that sampled
+    bool have_splitters = false;
 };
 
 static_assert(PGR_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "pgr_hip.h and rccl.h disagree on the unique id size");
@@ -254,7 +256,7 @@ static_assert(sizeof(pgr_frag_rec) % 8 == 0, "records travel as u64 words");
 }  // namespace
 
 extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d_recs, uint64_t n, pgr_index *ix,
-                                          uint64_t *splitters_out, uint64_t *n_received) {
+                                          int reuse_splitters, uint64_t *splitters_out, uint64_t *n_received) {
     if (!x) return PGR_ERR_INVALID_ARG;
     pgr_ctx *ctx = x->ctx;
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange (call pgr_exchange_wait)");
@@ -264,6 +266,11 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     const int world = x->world, me = x->rank;
     int rc;
+    if (reuse_splitters && !x->have_splitters) return ctx->fail(PGR_ERR_STATE, "no splitters yet: the first call must sample");
+    std::vector<uint64_t> splitters((size_t)std::max(world - 1, 1));
+    if (reuse_splitters) {
+        splitters = x->splitters;
+    } else {
     // ---- 1. pooled sample of first hashes -> splitters (the same on every rank)
     std::vector<uint64_t> mine(1 + SHARD_SAMPLES, 0);
     uint32_t n_s = 0;
@@ -281,8 +288,10 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
         const uint64_t *blk = all.data() + (size_t)r * mine.size();
         pool.insert(pool.end(), blk + 1, blk + 1 + std::min<uint64_t>(blk[0], SHARD_SAMPLES));
     }
-    std::vector<uint64_t> splitters((size_t)std::max(world - 1, 1));
     if (pgr_shard_splitters(pool.data(), pool.size(), world, splitters.data())) return ctx->fail(PGR_ERR_INTERNAL, "splitters");
+    x->splitters = splitters;
+    x->have_splitters = true;
+    }
     if (splitters_out)
         for (int j = 0; j + 1 < world; ++j) splitters_out[j] = splitters[(size_t)j];
     // ---- 2. stable partition of this rank's records by destination

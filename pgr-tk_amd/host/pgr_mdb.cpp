@@ -23,9 +23,11 @@
 
 // --ranks N: the sharded build of SURVEY.md section 8e without Python.  One process per GPU (forked BEFORE the first HIP
 // call); every rank reads the inputs, takes its contigs from the greedy length-balanced partition (the unit of
-// parallelism is the contig, pgr-db/src/seq_db.rs:460-467), computes their shimmers with global sequence ids and takes
-// part in pgr_exchange_gather_into_index round after round; rank 0 owns the frag_map (seq_db.rs:605-612) and writes
-// the files.  The 128-byte RCCL unique id goes from rank 0 to the others through pipes.
+// parallelism is the contig, pgr-db/src/seq_db.rs:460-467), computes their pair records with global sequence ids and
+// takes part in pgr_exchange_shard_records round after round: the frag_map (seq_db.rs:605-612) is key-range sharded,
+// rank r owns the r-th range of first hashes and sorts only that.  Every rank writes its shard as <prefix>.mdb.rank<r>,
+// the parent concatenates the shards in rank order into <prefix>.mdb (ascending ranges: the file is byte-identical to
+// the single-process one), rank 0 writes the .midx.  The 128-byte RCCL unique id goes from rank 0 to the others through pipes.
 struct RankEnv {
     int rank = 0, world = 1, device = 0;
     bool force_exchange = false;        // run the exchange code path even with one rank (plumbing test on a 1-GPU box)
@@ -50,6 +52,21 @@ static std::vector<std::vector<size_t>> shard_by_length(const std::vector<uint64
     return shards;
 }
 
+// contigs -> pair records of `ix`.  Default: pgr_index_add_batch (the library packs the ASCII bytes on the host while it
+// stages them).  --prepack: this program packs first (pgr_pack_ascii, all its CPUs) and hands over 2-bit planes
+// (pgr_index_add_packed): what a host does that keeps its sequences packed.
+static bool prepack = false;
+static int add_contigs(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const std::vector<const uint8_t *> &ptrs,
+                       const std::vector<uint64_t> &lens, const std::vector<uint32_t> &sids, bool packed_first) {
+    if (!packed_first) return pgr_index_add_batch(ctx, ix, n, ptrs.data(), lens.data(), sids.data());
+    const uint64_t words = pgr_packed_words(n, lens.data());
+    std::vector<uint64_t> planes((size_t)words);
+    std::vector<uint32_t> valid((size_t)words);
+    const int rc = pgr_pack_ascii(n, ptrs.data(), lens.data(), 0, planes.data(), valid.data(), nullptr);
+    if (rc) return rc;
+    return pgr_index_add_packed(ctx, ix, n, lens.data(), planes.data(), valid.data(), sids.data());
+}
+
 static void die(pgr_ctx *ctx, const char *what, int rc) {
     fprintf(stderr, "pgr-mdb: %s failed (%d): %s\n", what, rc, ctx ? pgr_last_error(ctx) : pgr_last_error(nullptr));
     exit(1);
@@ -57,6 +74,7 @@ static void die(pgr_ctx *ctx, const char *what, int rc) {
 
 static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp, bool sid_quirk,
                     const std::vector<std::string> &pos);
+static int merge_mdb_shards(const std::string &prefix, int ranks);
 
 int main(int argc, char **argv) {
     pgr_spec spec = {80, 56, 4, 64, 0};
@@ -84,6 +102,7 @@ int main(int argc, char **argv) {
         else if (a == "--reference-sid-quirk") sid_quirk = true;  // load_index_from_reader restarts at 0 per input (seq_db.rs:543)
         else if (a == "--ranks") ranks = atoi(val("--ranks"));
         else if (a == "--force-exchange") force_exchange = true;
+        else if (a == "--prepack") prepack = true;
         else if (a == "--devices") {
             std::string v = val("--devices");
             for (size_t p = 0; p <= v.size();) {
@@ -95,7 +114,7 @@ int main(int argc, char **argv) {
         } else pos.push_back(a);
     }
     if (pos.size() != 2 || ranks < 1) {
-        fprintf(stderr, "usage: pgr-mdb <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch] [--ranks N [--devices 0,1,..]]\n");
+        fprintf(stderr, "usage: pgr-mdb <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch] [--prepack] [--ranks N [--devices 0,1,..]]\n");
         return 2;
     }
     if (sid_quirk && (ranks > 1 || force_exchange)) {
@@ -176,7 +195,62 @@ int main(int argc, char **argv) {
             bad = 1;
         }
     }
-    return bad;
+    if (bad) return bad;
+    return merge_mdb_shards(pos[1], ranks);
+}
+
+// <prefix>.mdb.rank0 .. rank<N-1> (each a complete .mdb of one key range, keys ascending) -> <prefix>.mdb
+static int merge_mdb_shards(const std::string &prefix, int ranks) {
+    const std::string final_path = prefix + ".mdb", tmp_path = final_path + ".tmp";
+    std::vector<std::string> parts;
+    uint64_t n_keys = 0;
+    unsigned char hdr0[31];
+    for (int r = 0; r < ranks; ++r) {
+        parts.push_back(prefix + ".mdb.rank" + std::to_string(r));
+        FILE *f = fopen(parts.back().c_str(), "rb");
+        unsigned char hdr[31];
+        if (!f || fread(hdr, 1, 31, f) != 31 || memcmp(hdr, "mdb", 3) != 0) {
+            if (f) fclose(f);
+            fprintf(stderr, "pgr-mdb: shard file %s missing or damaged\n", parts.back().c_str());
+            return 1;
+        }
+        fclose(f);
+        if (r == 0) memcpy(hdr0, hdr, 31);
+        else if (memcmp(hdr0, hdr, 23) != 0) {
+            fprintf(stderr, "pgr-mdb: shard files disagree on the ShmmrSpec\n");
+            return 1;
+        }
+        uint64_t nk;
+        memcpy(&nk, hdr + 23, 8);
+        n_keys += nk;
+    }
+    FILE *o = fopen(tmp_path.c_str(), "wb");
+    bool ok = o != nullptr;
+    if (ok) {
+        memcpy(hdr0 + 23, &n_keys, 8);
+        ok = fwrite(hdr0, 1, 31, o) == 31;
+    }
+    std::vector<char> buf(4u << 20);
+    for (size_t r = 0; ok && r < parts.size(); ++r) {
+        FILE *f = fopen(parts[r].c_str(), "rb");
+        ok = f && fseek(f, 31, SEEK_SET) == 0;
+        size_t got;
+        while (ok && (got = fread(buf.data(), 1, buf.size(), f)) > 0) ok = fwrite(buf.data(), 1, got, o) == got;
+        if (f) {
+            ok = ok && !ferror(f);
+            fclose(f);
+        }
+    }
+    if (o) ok = (fclose(o) == 0) && ok;
+    if (ok) ok = rename(tmp_path.c_str(), final_path.c_str()) == 0;
+    for (const auto &pth : parts) (void)remove(pth.c_str());
+    if (!ok) {
+        (void)remove(tmp_path.c_str());
+        fprintf(stderr, "pgr-mdb: can't write %s\n", final_path.c_str());
+        return 1;
+    }
+    fprintf(stderr, "%d key-range shards, %llu keys -> %s\n", ranks, (unsigned long long)n_keys, final_path.c_str());
+    return 0;
 }
 
 static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp, bool sid_quirk,
@@ -184,9 +258,9 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
     pgr_ctx *ctx = nullptr;
     int rc = pgr_ctx_create(env.device, &ctx);
     if (rc) die(nullptr, "pgr_ctx_create", rc);
-    const bool owner = env.rank == 0;  // owns the frag_map and writes the files
-    pgr_index *ix = nullptr;
-    if (owner && (rc = pgr_index_create(ctx, &spec, &ix))) die(ctx, "pgr_index_create", rc);
+    const bool owner = env.rank == 0;  // writes the .midx (and, without an exchange, the .mdb)
+    pgr_index *ix = nullptr;  // plain build: the frag_map; sharded build: this rank's key range of it
+    if ((rc = pgr_index_create(ctx, &spec, &ix))) die(ctx, "pgr_index_create", rc);
     pgr_exchange *xch = nullptr;
     if (env.world > 1 || env.force_exchange) {
         uint8_t id[PGR_UNIQUE_ID_BYTES];
@@ -243,8 +317,7 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
                     lens.push_back(recs[q].seq.size());
                     sids.push_back(sid + (uint32_t)(q - i));
                 }
-                if ((rc = pgr_index_add_batch(ctx, ix, (uint32_t)(j - i), ptrs.data(), lens.data(), sids.data())))
-                    die(ctx, "pgr_index_add_batch", rc);
+                if ((rc = add_contigs(ctx, ix, (uint32_t)(j - i), ptrs, lens, sids, prepack))) die(ctx, "pgr_index_add_batch", rc);
                 for (size_t q = i; q < j; ++q) midx.push_back(Midx{sid++, recs[q].seq.size(), recs[q].name, path});
                 i = j;
             }
@@ -283,42 +356,49 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
         for (const auto &sh : shards) n_rounds = std::max(n_rounds, rounds_of(sh));
         const std::vector<size_t> &mine = shards[(size_t)env.rank];
         size_t i = 0;
-        uint64_t gathered_total = 0;
+        uint64_t sent_total = 0, received_total = 0;
         for (size_t round = 0; round < n_rounds; ++round) {
-            pgr_batch *b = nullptr;
-            pgr_shmmrs *sh = nullptr;
-            std::vector<uint32_t> rids;
+            // this round's pair records of this rank (an index object is the library's container for device records)
+            pgr_index *part = nullptr;
+            if ((rc = pgr_index_create(ctx, &spec, &part))) die(ctx, "pgr_index_create", rc);
             if (i < mine.size()) {
                 size_t j = i;
                 uint64_t tot = 0;
                 while (j < mine.size() && (j == i || tot + lens_all[mine[j]] <= batch_bp)) tot += lens_all[mine[j++]];
                 std::vector<const uint8_t *> ptrs;
                 std::vector<uint64_t> lens;
+                std::vector<uint32_t> sids;
                 for (size_t q = i; q < j; ++q) {
                     ptrs.push_back((const uint8_t *)all[mine[q]].seq.data());
                     lens.push_back(lens_all[mine[q]]);
-                    rids.push_back(sids_all[mine[q]]);
+                    sids.push_back(sids_all[mine[q]]);
                 }
-                if ((rc = pgr_batch_from_ascii(ctx, (uint32_t)(j - i), ptrs.data(), lens.data(), &b))) die(ctx, "pgr_batch_from_ascii", rc);
-                if ((rc = pgr_shmmrs_compute(ctx, b, &spec, nullptr, 0, &sh))) die(ctx, "pgr_shmmrs_compute", rc);
+                if ((rc = add_contigs(ctx, part, (uint32_t)(j - i), ptrs, lens, sids, prepack))) die(ctx, "pgr_index_add_batch", rc);
                 i = j;
             }
-            uint64_t n_g = 0;
-            if ((rc = pgr_exchange_gather_into_index(xch, sh, rids.data(), ix, &n_g))) die(ctx, "pgr_exchange_gather_into_index", rc);
-            gathered_total += n_g;
-            pgr_shmmrs_destroy(sh);
-            pgr_batch_destroy(b);
+            const uint64_t n_part = pgr_index_n_records(part);
+            uint64_t got = 0;
+            // the key ranges are fixed by the first round's pooled sample and kept for the later rounds
+            if ((rc = pgr_exchange_shard_records(xch, pgr_index_device_records(part), n_part, ix, round > 0, nullptr, &got)))
+                die(ctx, "pgr_exchange_shard_records", rc);
+            sent_total += n_part;
+            received_total += got;
+            pgr_index_destroy(part);
         }
-        fprintf(stderr, "rank %d/%d (device %d): %zu of %zu contigs, %zu exchange rounds, %llu shimmers gathered\n", env.rank,
-                env.world, env.device, mine.size(), all.size(), n_rounds, (unsigned long long)gathered_total);
+        fprintf(stderr, "rank %d/%d (device %d): %zu of %zu contigs, %zu exchange rounds, %llu pair records sent, %llu in its key range\n",
+                env.rank, env.world, env.device, mine.size(), all.size(), n_rounds, (unsigned long long)sent_total,
+                (unsigned long long)received_total);
     }
+    const bool sharded = xch != nullptr;
     if (xch) pgr_exchange_destroy(xch);
+    if ((rc = pgr_index_finalize(ctx, ix))) die(ctx, "pgr_index_finalize", rc);
+    const std::string mdb_path = sharded ? pos[1] + ".mdb.rank" + std::to_string(env.rank) : pos[1] + ".mdb";
+    if ((rc = pgr_index_write_mdb(ctx, ix, mdb_path.c_str()))) die(ctx, "pgr_index_write_mdb", rc);
     if (!owner) {
+        pgr_index_destroy(ix);
         pgr_ctx_destroy(ctx);
         return 0;
     }
-    if ((rc = pgr_index_finalize(ctx, ix))) die(ctx, "pgr_index_finalize", rc);
-    if ((rc = pgr_index_write_mdb(ctx, ix, (pos[1] + ".mdb").c_str()))) die(ctx, "pgr_index_write_mdb", rc);
     {  // seq_db.rs:798-805; written to a temporary name and renamed, every write checked
         const std::string final_path = pos[1] + ".midx", tmp_path = final_path + ".tmp";
         FILE *f = fopen(tmp_path.c_str(), "w");

@@ -107,7 +107,7 @@ _SIGS = [
     ("pgr_exchange_wait", C.c_int, [_VP, C.POINTER(C.c_uint64)]),
     ("pgr_exchange_device_counts", _VP, [_VP]),
     ("pgr_exchange_gather_into_index", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), _VP, C.POINTER(C.c_uint64)]),
-    ("pgr_exchange_shard_records", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    ("pgr_exchange_shard_records", C.c_int, [_VP, _VP, C.c_uint64, _VP, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     ("pgr_exchange_allgather_index", C.c_int, [_VP, _VP, _PVP]),
     ("pgr_shard_sample_keys", C.c_int, [_VP, _VP, C.c_uint64, C.c_uint32, _VP, C.POINTER(C.c_uint32)]),
     ("pgr_shard_splitters", C.c_int, [_VP, C.c_uint64, C.c_int, _VP]),

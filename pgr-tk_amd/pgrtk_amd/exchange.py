@@ -89,13 +89,13 @@ class AbiExchange:
                                                                  C.c_void_p(out.data_ptr()), int(cap_per_rank)))
         return _AbiPending(self, out, cap_per_rank)
 
-    def shard_records(self, recs_ptr, n, index):
+    def shard_records(self, recs_ptr, n, index, reuse_splitters=False):
         """pgr_exchange_shard_records: this rank's pair records (DEVICE pointer) travel to the ranks that own their key
         ranges, straight into `index` (finish it with index.finalize()).  -> (records received, splitters)"""
         from ._ffi import lib
         spl = np.zeros(max(self.world - 1, 1), dtype=np.uint64)
         got = C.c_uint64()
-        self.ctx.check(lib().pgr_exchange_shard_records(self._h, C.c_void_p(recs_ptr), int(n), index._h,
+        self.ctx.check(lib().pgr_exchange_shard_records(self._h, C.c_void_p(recs_ptr), int(n), index._h, int(reuse_splitters),
                                                         spl.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(got)))
         return int(got.value), [int(v) for v in spl[:self.world - 1]]
 

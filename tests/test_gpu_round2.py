@@ -297,17 +297,25 @@ def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
 
 
 def test_pgr_mdb_ranks_through_the_c_abi_exchange(tmp_path):
-    """host/pgr_mdb.cpp --ranks: forked rank processes, unique id through pipes, pgr_exchange_gather_into_index -- no Python
-    in the sharded build.  One GPU here, so one rank (RCCL refuses two ranks on one device); the .mdb must be byte-identical
-    to the plain build's"""
+    """host/pgr_mdb.cpp --ranks: forked rank processes, unique id through pipes, pgr_exchange_shard_records round after round
+    (the key ranges fixed by the first round), every rank writes its shard, the parent concatenates them -- no Python in the
+    sharded build.  One GPU here, so one rank (RCCL refuses two ranks on one device); the .mdb must be byte-identical to the
+    plain build's.  --prepack: the host program packs the bases itself and hands over 2-bit planes (pgr_index_add_packed)."""
     exe = os.path.join(ROOT, "pgr-tk_amd", "bin", "pgr-mdb")
     fl = tmp_path / "files.txt"
     fl.write_text(os.path.join(ROOT, "tests", "golden", "test_seqs.fa") + "\n")
-    for tag, extra in (("plain", []), ("ranks", ["--ranks", "1", "--devices", "0", "--force-exchange", "--batch-bp", "60000"])):
+    for tag, extra in (("plain", []), ("ranks", ["--ranks", "1", "--devices", "0", "--force-exchange", "--batch-bp", "60000"]),
+                       ("prepack", ["--prepack"]),
+                       ("ranks_prepack", ["--ranks", "1", "--force-exchange", "--prepack", "--batch-bp", "100000"])):
         r = subprocess.run([exe, str(fl), str(tmp_path / tag)] + extra, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr[-2000:]
-    assert (tmp_path / "plain.mdb").read_bytes() == (tmp_path / "ranks.mdb").read_bytes()
-    assert (tmp_path / "plain.midx").read_bytes() == (tmp_path / "ranks.midx").read_bytes()
+    for tag in ("ranks", "prepack", "ranks_prepack"):
+        assert (tmp_path / "plain.mdb").read_bytes() == (tmp_path / (tag + ".mdb")).read_bytes(), tag
+        assert (tmp_path / "plain.midx").read_bytes() == (tmp_path / (tag + ".midx")).read_bytes(), tag
+    assert not list(tmp_path.glob("*.rank*"))  # the shard files are gone after the merge
+    r = subprocess.run([exe, str(fl), str(tmp_path / "x"), "--ranks", "1", "--force-exchange", "--reference-sid-quirk"],
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "cannot be combined" in r.stderr
     assert len((tmp_path / "plain.mdb").read_bytes()) > 10_000
 
 
