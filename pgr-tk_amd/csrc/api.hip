@@ -445,7 +445,12 @@ struct Island {
 static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
                              const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base) {
     hipStream_t st = ctx->stream;
-    constexpr uint64_t CS = 32768;
+    // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
+    // (one per chunk) -- never below 4096: a chunk owns the segment-table entry of the tile it starts in (tc <= 4096)
+    uint64_t island_bases = 0;
+    for (const Island &is : islands) island_bases += is.E - is.B;
+    const uint64_t CS = std::min<uint64_t>(32768, std::max<uint64_t>(4096, ((island_bases / 4096 + 4095) / 4096) * 4096));
+    std::vector<uint32_t> zero_ranges;  // segment ranges of (re)built islands, cleared by ONE kernel before the next chunk launch
     struct HChunk {
         ChunkDesc d;
         size_t island;
@@ -468,11 +473,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         const uint32_t seg0 = tile_first[c] + c;
         uint32_t rng[2] = {seg0 + (uint32_t)(is.B / tc), seg0 + (uint32_t)((is.E + tc - 1) / tc)};
         if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
-        Tmp_list d_r(ctx);
-        if ((rc = d_r.alloc(sizeof(rng)))) return rc;
-        PGR_HIP(ctx, hipMemcpyAsync(d_r.p, rng, sizeof(rng), hipMemcpyHostToDevice, st));
-        launch_zero_seg_ranges(st, a, (const uint32_t *)d_r.p, 1);
-        PGR_HIP(ctx, hipStreamSynchronize(st));
+        zero_ranges.push_back(rng[0]);
+        zero_ranges.push_back(rng[1]);
         const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
         for (uint64_t j = 0; j < nch; ++j) {
             HChunk h;
@@ -535,6 +537,12 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         ChunkState *d_in = (ChunkState *)(d_desc + nq);
         ChunkState *d_out = d_in + nq;
         uint32_t *d_stat = (uint32_t *)(d_out + nq);
+        Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
+        if (!zero_ranges.empty()) {
+            if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
+            PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
+        }
         PGR_HIP(ctx, hipMemcpyAsync(d_desc, descs.data(), nq * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
         PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
         // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
@@ -547,6 +555,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         PGR_HIP(ctx, hipMemcpyAsync(r_stat.data(), d_stat, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));
         PGR_HIP(ctx, hipGetLastError());
+        zero_ranges.clear();
         s_in.resize(ch.size());
         s_out.resize(ch.size());
         status.resize(ch.size());
@@ -705,6 +714,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_cid.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
         (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
+        (rc = ctx->ws_tile_lv.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(uint64_t))) ||
         // one block that a single memset clears per call: cursors | contig flags | tile flags  (+ the status words)
         (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
                                              std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
@@ -733,6 +743,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
     a.desc = (TileDesc *)ctx->ws_tile_desc.p;
     a.tile_flags = d_tflags;
+    a.tile_lv = nullptr;  // set once mark_invalid_tiles has filled it and run_islands has made it cumulative
     a.w = w_eff;
     a.k = spec->k;
     a.r = spec->r;
@@ -780,7 +791,11 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (tiled && bases_tiled) launch_level1_tiles(st, a);
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         launch_level1_tails(st, a);
-        if (tiled && bases_tiled) launch_mark_invalid_tiles(st, a);  // exits per tile for contigs without non-ACGT bytes
+        if (tiled && bases_tiled) {  // flags tiles with a non-ACGT byte in reach, records every tile's last valid position
+            L1Args am = a;
+            am.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
+            launch_mark_invalid_tiles(st, am);
+        }
         islands_done = false;
         return PGR_OK;
     };
@@ -837,6 +852,15 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (!islands.empty()) {
             L1Args as = a;
             as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
+            if (tiled && bases_tiled && n_tiles) {
+                // per-tile "last valid position" (written by mark_invalid_tiles) -> cumulative: the chunks' k-mer look-back
+                // and forward roll cross a run of N of any length in one step
+                const size_t tb = scan_max_temp_bytes(n_tiles);
+                int r2;
+                if ((r2 = ctx->ws_scan_tmp.ensure(ctx, tb))) return r2;
+                PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
+                as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
+            }
             int r = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base);
             if (r) return r;
             a.out = as.out;

@@ -798,10 +798,23 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     long long pm = cs - (long long)cd.warm;
     if (pm < 0) pm = 0;
     long long pk = pm;
+    // last valid position below x (x > 0) when the tile table can tell: the scanned entry of the tile that holds x - 1 is the
+    // last valid position up to the END of that tile; if it lies below x it is the answer (-1: none), otherwise unknown (-2)
+    const uint64_t *__restrict__ tile_lv = a.tile_lv ? a.tile_lv + a.tile_first[c] : nullptr;
+    auto last_valid_below = [&](long long x) -> long long {
+        if (!tile_lv) return -2;
+        const uint64_t e = tile_lv[(x - 1) / (long long)a.tc];
+        const long long lv = ((uint32_t)(e >> 32) == c + 1) ? (long long)(uint32_t)e - 1 : -1;
+        return lv < x ? lv : -2;
+    };
     if (pm > 0) {
         // look back (64 blocks of 64 positions per step) until k valid bases precede pm
         uint32_t have = 0;
         long long hi = pm;  // blocks [hi - 64(lane+1), hi - 64 lane)
+        {   // a chunk deep inside a run of N starts right behind the last valid base in front of the run
+            const long long lv = last_valid_below(hi);
+            if (lv >= -1) hi = ((lv + 64) / 64) * 64;  // smallest multiple of 64 above lv (0 when there is none)
+        }
         while (have < k && hi > 0) {
             const long long b0 = hi - 64ll * (lane + 1);
             uint32_t cnt = 0;
@@ -813,8 +826,13 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 pk = hi - 64ll * (l0 + 1);
                 have = k;
             } else {
-                have += __shfl(incl, 63, 64);
+                const uint32_t got = __shfl(incl, 63, 64);
+                have += got;
                 hi -= 64ll * 64;
+                if (got == 0 && hi > 0) {  // nothing valid in these 4096 positions: skip the rest of the run in one step
+                    const long long lv = last_valid_below(hi);
+                    if (lv >= -1) hi = ((lv + 64) / 64) * 64;
+                }
                 pk = hi > 0 ? hi : 0;
             }
         }
@@ -908,6 +926,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             // an 18 Mbp gap of a reference chromosome rolls from the last k valid bases in FRONT of the gap): jump to the
             // next block of 64 positions that holds a valid base, 64 blocks per step, instead of visiting every block
             long long nb = base + 64;
+            {   // the rest of the way to pm holds no valid base at all (the usual case inside a long run of N)
+                const long long lv = pm > 0 ? last_valid_below(pm) : -2;
+                if (lv >= -1 && lv < nb) nb = pm;
+            }
             while (nb < pm) {
                 const long long bl = nb + 64ll * lane;
                 uint32_t any = 0;
@@ -1179,9 +1201,31 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
     if (tile >= a.n_tiles) return;
     const TileDesc td = a.desc[tile];
     const uint32_t c = td.contig;
-    if (a.b.n_invalid[c] == 0) return;
     const long long L = td.len;
+    {
+        long long c1 = (long long)(td.tile_local + 1) * a.tc;
+        if (c1 > L) c1 = L;
+        if (a.b.n_invalid[c] == 0) {  // every base valid
+            a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)c1;
+            return;
+        }
+    }
     const uint32_t *__restrict__ v = a.b.valid + td.word_off;
+    {   // last valid position of the tile's core [c0, c1)
+        const long long c0 = (long long)td.tile_local * a.tc;
+        long long c1 = c0 + a.tc;
+        if (c1 > L) c1 = L;
+        long long last = -1;
+        for (long long wj = (c1 - 1) >> 5; wj >= (c0 >> 5) && last < 0; --wj) {
+            uint32_t m = 0xFFFFFFFFu;
+            const long long w0 = wj << 5;
+            if (w0 < c0) m &= 0xFFFFFFFFu >> (uint32_t)(c0 - w0);
+            if (w0 + 32 > c1) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - c1);
+            const uint32_t bits = v[wj] & m;  // position w0 + i at bit 31 - i
+            if (bits) last = w0 + 31 - (long long)__builtin_ctz(bits);
+        }
+        a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)(last + 1);
+    }
     long long lo = (long long)td.tile_local * a.tc - (long long)(a.w - 1) - (long long)(a.k - 1) - 64;
     long long hi = (long long)(td.tile_local + 1) * a.tc + (long long)(a.w - 1) + 64;
     if (lo < 0) lo = 0;

@@ -49,7 +49,7 @@ struct pgr_ctx {
     // workspaces
     pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
         ws_scan_tmp, ws_list_a, ws_list_b, ws_off_a, ws_off_b, ws_blk_cnt, ws_blk_base, ws_start_rank, ws_rids,
-        ws_rec_off, ws_blk_off, ws_tile_desc, ws_tile_flags, ws_seg_cid;
+        ws_rec_off, ws_blk_off, ws_tile_desc, ws_tile_flags, ws_seg_cid, ws_tile_lv;
 
     // caching allocator for result buffers: size -> free blocks
     std::multimap<size_t, void *> free_blocks;

@@ -131,6 +131,10 @@ struct L1Args {
     uint32_t *seg_cid;           // [n_tiles + n_contigs] contig of the records of a segment
     uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the exact kernel)
     uint8_t *tile_flags;         // [n_tiles] 1: the tile's extended range holds a palindromic k-mer / non-ACGT byte
+    // [n_tiles] (contig + 1) << 32 | (last valid position <= the end of the tile's core) + 1, low word 0 when the contig has
+    // no valid base up to there.  Written per tile by mark_invalid_tiles_kernel, made cumulative by an inclusive max-scan
+    // before the exact-machine chunks run: their k-mer look-back crosses a multi-Mbp run of N in one step with it.
+    uint64_t *tile_lv;
 };
 void launch_level1_tiles(hipStream_t st, const L1Args &a);
 void launch_level1_tails(hipStream_t st, const L1Args &a);
@@ -142,6 +146,9 @@ void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges);
 // tile_flags |= 1 for tiles (of the listed contigs) whose extended range contains a non-ACGT byte
 void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // needs a.desc (after launch_level1_tiles)
+// inclusive max-scan of a.tile_lv in place (rocPRIM); temp from scan_max_temp_bytes
+size_t scan_max_temp_bytes(uint32_t n);
+hipError_t scan_max_inplace(hipStream_t st, void *temp, size_t temp_bytes, uint64_t *v, uint32_t n);
 
 // level2.hip
 // dst holds dst_cap elements: segments that would end beyond it are skipped (the host sees the true total and retries)

@@ -33,6 +33,16 @@ hipError_t scan_counts(hipStream_t st, void *temp, size_t temp_bytes, const uint
                                    rocprim::plus<uint64_t>(), st);
 }
 
+// inclusive max-scan of u64 values in place
+size_t scan_max_temp_bytes(uint32_t n) {
+    size_t bytes = 0;
+    (void)rocprim::inclusive_scan(nullptr, bytes, (const uint64_t *)nullptr, (uint64_t *)nullptr, (size_t)n, rocprim::maximum<uint64_t>());
+    return bytes;
+}
+hipError_t scan_max_inplace(hipStream_t st, void *temp, size_t temp_bytes, uint64_t *v, uint32_t n) {
+    return rocprim::inclusive_scan(temp, temp_bytes, (const uint64_t *)v, v, (size_t)n, rocprim::maximum<uint64_t>(), st);
+}
+
 // stable LSD radix sort of 64-bit keys (bits [0, end_bit)) with a 32-bit payload
 size_t sort_pairs_temp_bytes(uint64_t n) {
     size_t bytes = 0;
