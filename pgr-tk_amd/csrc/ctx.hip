@@ -157,21 +157,17 @@ int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
     const size_t WIN = 16u << 20;
     int rc = ensure_pinned_out(2 * WIN);
     if (rc) return rc;
-    const unsigned hw = std::thread::hardware_concurrency();
-    const unsigned n_thr = std::max(1u, std::min(4u, hw ? hw / 2 : 1u));
+    // the destination is usually fresh malloc'd memory: its first touch (page faults) is spread over the pool's threads
     auto host_copy = [&](uint8_t *d, const uint8_t *s, size_t len) {
-        if (n_thr == 1 || len < (2u << 20)) {
+        constexpr size_t PIECE = 1u << 20;
+        if (len < 2 * PIECE) {
             memcpy(d, s, len);
             return;
         }
-        const size_t part = (len + n_thr - 1) / n_thr;
-        std::vector<std::thread> th;
-        for (unsigned i = 1; i < n_thr; ++i) {
-            const size_t o = std::min(len, (size_t)i * part), l = std::min(part, len - o);
-            if (l) th.emplace_back([=] { memcpy(d + o, s + o, l); });
-        }
-        memcpy(d, s, std::min(part, len));
-        for (auto &t : th) t.join();
+        pgr::HostPool::instance().parallel_for((len + PIECE - 1) / PIECE, [&](size_t i) {
+            const size_t o = i * PIECE;
+            memcpy(d + o, s + o, std::min(PIECE, len - o));
+        });
     };
     const uint8_t *sd = (const uint8_t *)src_dev;
     uint8_t *dh = (uint8_t *)dst, *pin = (uint8_t *)pinned_out;
