@@ -326,6 +326,8 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         used[slot] = true;
     }
     // per-contig counts of non-ACGT bytes (host-packed input: counted by the packer; packed input: by the kernel above)
+    if (!packed)
+        for (uint32_t i = 0; i < n; ++i) b->host_saw_invalid = b->host_saw_invalid || b->h_n_invalid[i] != 0;
     if (!packed && n &&
         hipMemcpyAsync(b->d.n_invalid, b->h_n_invalid.data(), (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess)
         return fail(PGR_ERR_DEVICE, "H2D copy of the invalid-byte counts failed");
@@ -440,6 +442,10 @@ struct Island {
     uint32_t contig;
     uint64_t B, E;
     bool whole;  // one chunk for the whole contig (last resort)
+    // a tile of the island saw a palindromic k-mer: inside a stretch of skipped pushes a chunk needs the true state of the
+    // chunk in front (one seam per round), so such islands keep long chunks; islands around non-ACGT bytes verify at the
+    // first try and are cut short for parallelism
+    bool pal = true;
 };
 
 static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
@@ -449,7 +455,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
     // (one per chunk) -- never below 4096: a chunk owns the segment-table entry of the tile it starts in (tc <= 4096)
     uint64_t island_bases = 0;
     for (const Island &is : islands) island_bases += is.E - is.B;
-    const uint64_t CS = std::min<uint64_t>(32768, std::max<uint64_t>(4096, ((island_bases / 4096 + 4095) / 4096) * 4096));
+    const uint64_t CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(4096, ((island_bases / 4096 + 4095) / 4096) * 4096));
     std::vector<uint32_t> zero_ranges;  // segment ranges of (re)built islands, cleared by ONE kernel before the next chunk launch
     struct HChunk {
         ChunkDesc d;
@@ -475,6 +481,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
         zero_ranges.push_back(rng[0]);
         zero_ranges.push_back(rng[1]);
+        const uint64_t CS = is.pal ? 32768 : CS_SHORT;
         const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
         for (uint64_t j = 0; j < nch; ++j) {
             HChunk h;
@@ -631,6 +638,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
                         islands[jj].B >= islands[ii].B && islands[jj].E > islands[ii].B && !islands[jj].whole &&
                         islands[jj].E != 0) {
                         islands[ii].E = std::max(islands[ii].E, islands[jj].E);
+                        islands[ii].pal = islands[ii].pal || islands[jj].pal;
                         for (auto &h : ch)
                             if (h.island == jj) h.retired = true;
                         islands[jj].E = islands[jj].B = 0;  // absorbed
@@ -705,6 +713,11 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint32_t slot = std::min<uint32_t>(tc, (((uint32_t)((double)tc * dens * 2.0) + 64 + 63) / 64) * 64);
     const uint64_t slots_total = (uint64_t)n_tiles * slot;
     uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 300ull * n;
+    // low-complexity / N-rich input overflows the fixed tile slots by far more than that: remember what the last call with
+    // this spec needed per base (a genome comes as many similar batches) instead of running stage 1 twice every time
+    const double l1_key = (double)spec->w * 1e3 + spec->k + (sketch ? 0.5 : 0.0);
+    if (ctx->est_l1_key == l1_key && ctx->est_ovf_ratio > 0)
+        cap_par = std::max<uint64_t>(cap_par, (uint64_t)((double)bases_tiled * ctx->est_ovf_ratio * 1.1) + 65536 + 300ull * n);
 
     constexpr size_t N_CURSOR = 8;  // [0..2] level 1 (L1Args::cursor), [4..5] fused list stage
     constexpr size_t N_STATUS = 10;
@@ -764,7 +777,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     // optimistically and repeat stages 2-4 in the (rare) flagged case: cheaper than the round trip below ~1 Gbp.
     uint64_t early_bp = 1ull << 30;
     if (const char *e = getenv("PGR_EARLY_SYNC_BP")) early_bp = strtoull(e, nullptr, 10);
-    const bool early_sync = b->total_bases >= early_bp || !serial.empty();
+    // (a batch the host packer has counted non-ACGT bytes in is known to need islands: look at the flags before the list stage)
+    const bool early_sync = b->total_bases >= early_bp || !serial.empty() || b->host_saw_invalid;
     const bool pad_fix = padding && !sketch && spec->r > 1;
     const bool do_reduce = !sketch && spec->r > 1;
     const uint32_t halo = do_reduce ? 2 * spec->r * spec->r : 1;
@@ -803,7 +817,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path.  Synchronizes.
     auto run_islands = [&](uint64_t need_word) -> int {
         std::vector<Island> islands;
-        for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false});
+        for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false, true});
         if (tiled && bases_tiled && need_word) {
             std::vector<uint32_t> flags(n), n_invalid(n);
             std::vector<uint8_t> tf(n_tiles);
@@ -822,7 +836,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 if (n_flag == 0) continue;
                 if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
                 if (3ull * n_flag > nt) {  // mostly irregular: one island
-                    islands.push_back(Island{c, 0, L, false});
+                    bool pal = false;
+                    for (uint32_t t = 0; t < nt; ++t) pal = pal || (tf[t0 + t] & 1);
+                    islands.push_back(Island{c, 0, L, false, pal});
                     continue;
                 }
                 for (uint32_t t = 0; t < nt;) {
@@ -833,12 +849,15 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                     uint32_t ta = t > 0 ? t - 1 : 0, tb = t;
                     while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
                     if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
-                    Island is{c, (uint64_t)ta * tc, std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false};
+                    Island is{c, (uint64_t)ta * tc, std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
+                    for (uint32_t q = ta; q <= tb; ++q) is.pal = is.pal || (tf[t0 + q] & 1);
                     if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
-                    if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B)
+                    if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
                         islands.back().E = std::max(islands.back().E, is.E);
-                    else
+                        islands.back().pal = islands.back().pal || is.pal;
+                    } else {
                         islands.push_back(is);
+                    }
                     t = tb + 1;
                 }
             }
@@ -996,6 +1015,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     PGR_HIP_BAIL(hipEventRecord(ctx->ev[0], st));
     int from = 1;  // first stage to (re)run
     uint64_t n_final = 0;
+    uint64_t l1_alloc_seen = 0;  // elements the level-1 kernels took from the overflow region
     for (int attempt = 0;; ++attempt) {
         if (attempt > 8) return bail(ctx->fail(PGR_ERR_INTERNAL, "shimmer pipeline: buffers kept overflowing"));
         if (from <= 1) {
@@ -1004,6 +1024,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 PGR_HIP_BAIL(hipMemcpyAsync(mbox, d_cursor, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
                 if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
                     return bail(ctx->fail(PGR_ERR_DEVICE, "level-1 kernels failed on the device"));
+                l1_alloc_seen = mbox[0];
                 if (mbox[1] || mbox[0] > cap_par) {  // cursor region too small: grow and redo
                     cap_par = (uint64_t)((double)mbox[0] * 1.1) + 65536;
                     continue;
@@ -1030,6 +1051,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         const uint64_t l1_alloc = mbox[0], l1_ovf = mbox[1], need_islands = mbox[2], l2_alloc = mbox[4], l2_ovf = mbox[5];
         const uint64_t total1 = mbox[8];
         n_final = mbox[9];
+        l1_alloc_seen = l1_alloc;
         if (l1_ovf || l1_alloc > cap_par) {  // (only possible without the early synchronization)
             cap_par = (uint64_t)((double)l1_alloc * 1.1) + 65536;
             from = 1;
@@ -1068,6 +1090,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     if (b->total_bases) {
         ctx->est_spec_key = spec_key;
         ctx->est_final_ratio = (double)n_final / (double)b->total_bases;
+    }
+    if (bases_tiled) {
+        ctx->est_l1_key = l1_key;
+        ctx->est_ovf_ratio = (double)l1_alloc_seen / (double)bases_tiled;
     }
     if (pad_fix) {
         // reference artefact: reduce_shmmr on an EMPTY list with padding emits its sentinels

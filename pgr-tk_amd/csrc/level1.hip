@@ -1239,7 +1239,7 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
         bad = (v[wj] & m) != m;
     }
     if (bad) {
-        a.tile_flags[tile] = 1;
+        a.tile_flags[tile] |= 2;  // (bit 0: the tile kernel, which has finished, saw a palindromic k-mer)
         atomicOr(a.cursor + 2, 2ull);
     }
 }

@@ -41,6 +41,8 @@ struct pgr_ctx {
     bool staged_unsynced = false;  // a batch was staged on `stream` and nobody has synchronized since
     // result-size estimate: final shimmers per base of the last pgr_shmmrs_compute with the spec `est_spec_key`
     double est_spec_key = -1.0, est_final_ratio = 0.0;
+    // overflow-region need of the level-1 kernels per tiled base, last call with the spec `est_l1_key`
+    double est_l1_key = -1.0, est_ovf_ratio = 0.0;
     std::vector<uint64_t> keep_rec_off;  // source of the async H2D copy of shmmrs_to_frag_recs_enqueue
     // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`
     hipStream_t copy_stream = nullptr;

@@ -48,6 +48,7 @@ struct pgr_batch {
     std::vector<uint64_t> h_word_off;  // [n+1]
     std::vector<uint32_t> h_len;       // [n]
     std::vector<uint32_t> h_n_invalid; // [n] non-ACGT bytes counted by the host packer (source of an async H2D copy)
+    bool host_saw_invalid = false;     // the host packer counted at least one
 };
 
 struct pgr_shmmrs {
