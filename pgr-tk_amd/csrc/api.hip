@@ -262,8 +262,15 @@ static int batch_stage_ascii_gpu(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const u
 // Two pinned windows: while window i is on its way to the GPU the host threads fill window i+1.
 // Thread-compatible with a compute call running on ctx->stream: touches only the batch, ctx->pinned and the two events
 // it is given.  Errors come back as a code + message (the caller owns ctx->err).
+// pipe != NULL: this batch is one of a sequence staged back to back by the pipelined entry points; the two windows keep
+// rolling from one batch into the next (no restart, no synchronization at the end: the caller orders its consumer behind
+// an event it records on `st`).
+struct StagePipe {
+    bool used[2] = {false, false};
+    int slot = 0;
+};
 static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &src, hipStream_t st, hipEvent_t ev0,
-                       hipEvent_t ev1, std::string &err) {
+                       hipEvent_t ev1, std::string &err, StagePipe *pipe = nullptr) {
     auto fail = [&](int code, const std::string &m) {
         err = m;
         return code;
@@ -279,13 +286,15 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     if (gpu_pack) return batch_stage_ascii_gpu(ctx, b, n, src.seqs, src.lens, st, ev0, ev1, err);
     constexpr uint64_t PIECE = 1ull << 16;        // words per host job (2 MiB of ASCII / 0.75 MiB packed)
     constexpr uint64_t WIN_WORDS = 40 * PIECE;    // 84 Mbp = 30 MiB of planes + validity per window
-    const uint64_t win_words = std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
+    // (a pipe keeps ONE window layout for all its batches: a window of the previous batch may still be on its way)
+    const uint64_t win_words = pipe ? WIN_WORDS : std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
     if (ctx->ensure_pinned(2 * win_words * 12)) return fail(PGR_ERR_NOMEM, "staging buffers: " + ctx->err);
     hipEvent_t done[2] = {ev0, ev1};
-    bool used[2] = {false, false};
+    StagePipe local;
+    bool *used = pipe ? pipe->used : local.used;
+    int &slot = pipe ? pipe->slot : local.slot;
     b->h_n_invalid.assign(std::max<uint32_t>(n, 1), 0);
     uint32_t c = 0;
-    int slot = 0;
     struct Job {
         uint32_t c;
         uint64_t wl0, wl1;  // words of contig c
@@ -333,6 +342,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         return fail(PGR_ERR_DEVICE, "H2D copy of the invalid-byte counts failed");
     // On the context's own stream nothing waits here: the consumer is ordered behind the copies and synchronizes once at
     // its end; the staging thread of the pipelined path (own stream) hands over finished batches.
+    if (pipe) return PGR_OK;
     if (st != ctx->stream) {
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
             return fail(PGR_ERR_DEVICE, "staging failed on the device");
@@ -1367,6 +1377,18 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
     int stage_rc = PGR_OK;
     std::string stage_err;
     std::atomic<bool> cancel{false};
+    // one event per sub-batch, recorded behind its last copy on the copy stream: the consumer's stream waits for it on the
+    // device, the staging thread never blocks on a finished sub-batch and keeps its two windows rolling into the next one
+    const bool legacy = getenv("PGR_GPU_PACK") != nullptr && !src.planes;
+    std::vector<hipEvent_t> ready(subs.size(), nullptr);
+    for (auto &e : ready)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            for (auto &q : ready)
+                if (q) (void)hipEventDestroy(q);
+            destroy_all();
+            return ctx->fail(PGR_ERR_DEVICE, "event creation failed");
+        }
+    StagePipe pipe;
     std::thread stager([&]() {
         (void)hipSetDevice(ctx->device);
         for (size_t i = 0; i < subs.size() && !cancel.load(); ++i) {
@@ -1375,7 +1397,12 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
             if (ss.seqs) ss.seqs += subs[i].c0;
             ss.lens += subs[i].c0;
             ss.word0 = src.word0 + subs[i].word0;
-            const int r = batch_stage(ctx, subs[i].b, subs[i].c1 - subs[i].c0, ss, ctx->copy_stream, ctx->cev[0], ctx->cev[1], err);
+            int r = batch_stage(ctx, subs[i].b, subs[i].c1 - subs[i].c0, ss, ctx->copy_stream, ctx->cev[0], ctx->cev[1], err,
+                                legacy ? nullptr : &pipe);
+            if (!r && hipEventRecord(ready[i], ctx->copy_stream) != hipSuccess) {
+                r = PGR_ERR_DEVICE;
+                err = "event record failed";
+            }
             std::lock_guard<std::mutex> lk(mu);
             if (r) {
                 stage_rc = r;
@@ -1398,6 +1425,10 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
             }
         }
         const double tc0 = since();
+        if (hipStreamWaitEvent(ctx->stream, ready[i], 0) != hipSuccess) {
+            rc = ctx->fail(PGR_ERR_DEVICE, "stream wait failed");
+            break;
+        }
         rc = consume(subs[i].b, subs[i].c0, subs[i].c1);
         if (dbg) fprintf(stderr, "[pgr]   sub-batch %zu consumed %.2f -> %.2f ms\n", i, tc0, since());
         pgr_batch_destroy(subs[i].b);
@@ -1405,6 +1436,8 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
     }
     if (rc) cancel.store(true);
     stager.join();
+    if (rc) (void)hipStreamSynchronize(ctx->copy_stream);  // nothing of a cancelled call may still read the pinned windows
+    for (auto &e : ready) (void)hipEventDestroy(e);
     destroy_all();
     return rc;
 }
@@ -1425,10 +1458,16 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     bool first = true;
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
+    const bool dbg = getenv("PGR_DEBUG") != nullptr;
     int rc = for_each_staged(ctx, n, src, [&](pgr_batch *b, uint32_t c0, uint32_t c1) -> int {
         pgr_shmmrs *s = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         int r = pgr_shmmrs_compute(ctx, b, spec, rids + c0, padding, &s);
         if (r) return r;
+        if (dbg)
+            fprintf(stderr, "[pgr]     compute %.2f ms (%.1f Mbp, %llu shimmers)\n",
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), b->total_bases / 1e6,
+                    (unsigned long long)s->count);
         if (total + s->count > cap) {
             // the first sub-batch predicts the rest (shimmer density is a property of the spec)
             uint64_t guess = cap + cap / 2;
