@@ -314,23 +314,30 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
             const uint64_t lo = std::max(cw0, w0), hi = std::min(cw1, w1);
             for (uint64_t o = lo; o < hi; o += PIECE) jobs.push_back(Job{cc, o - cw0, std::min(hi, o + PIECE) - cw0, o - w0});
         }
-        const bool has_valid = !packed || src.valid != nullptr;
+        std::atomic<uint64_t> win_bad{0};
         HostPool::instance().parallel_for(jobs.size(), [&](size_t i) {
             const Job &j = jobs[i];
             if (!packed) {
                 const uint64_t bad = pack_words(src.seqs[j.c], src.lens[j.c], j.wl0, j.wl1, pin_planes + j.out, pin_valid + j.out);
-                if (bad) __atomic_fetch_add(&b->h_n_invalid[j.c], (uint32_t)bad, __ATOMIC_RELAXED);
+                if (bad) {
+                    __atomic_fetch_add(&b->h_n_invalid[j.c], (uint32_t)bad, __ATOMIC_RELAXED);
+                    win_bad.fetch_add(bad, std::memory_order_relaxed);
+                }
             } else {
                 const uint64_t g = src.word0 + b->h_word_off[j.c] + j.wl0;  // word of the caller's arrays
                 memcpy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
                 if (src.valid) memcpy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
             }
         });
+        // the validity plane only travels when it says something: a window of ASCII in which the packer met no non-ACGT byte
+        // (the usual case) and packed input without a validity plane put 0.25 B per base on the link, the plane is written on
+        // the device from the contig lengths
+        const bool has_valid = packed ? src.valid != nullptr : win_bad.load() != 0;
         if (hipMemcpyAsync(b->d.planes + w0, pin_planes, (w1 - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
             (has_valid &&
              hipMemcpyAsync(b->d.valid + w0, pin_valid, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess))
             return fail(PGR_ERR_DEVICE, "H2D copy of the packed window failed");
-        if (packed) launch_sanitize_packed(st, b->d, n, w0, w1, has_valid ? 1 : 0);
+        if (packed || !has_valid) launch_sanitize_packed(st, b->d, n, w0, w1, has_valid ? 1 : 0);
         if (hipEventRecord(done[slot], st) != hipSuccess) return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         used[slot] = true;
     }

@@ -16,6 +16,11 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_THREAD_C
           --output-format csv -d $O/pmc_sq -o p -- $B > $O/pmc_sq.log 2>&1
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR \
           --output-format csv -d $O/pmc_misc -o p -- $B > $O/pmc_misc.log 2>&1
+# VALU busy by counter (round 3): cycles with a VALU instruction active per SIMD against the cycles the shader engines were busy
+rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VALU2 SQ_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_CYCLES \
+          --output-format csv -d $O/pmc_valu -o p -- $B > $O/pmc_valu.log 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE \
+          --output-format csv -d $O/pmc_valu2 -o p -- $B > $O/pmc_valu2.log 2>&1
 rocprofv3 --kernel-trace --output-format csv -d $O/q_trace -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_trace.log 2>&1
 # the query leg's counters (separate passes as well): HBM bytes and VALU work per query batch
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/q_pmc_fetch -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_fetch.log 2>&1

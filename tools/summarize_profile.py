@@ -22,7 +22,7 @@ shutil.copyfile(glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))[0], o
 if os.path.exists(os.path.join(src, "bench.json")):
     shutil.copyfile(os.path.join(src, "bench.json"), os.path.join(dst, "bench.json"))
 out = {}
-for d in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc"]:
+for d in ["pmc_fetch", "pmc_write", "pmc_sq", "pmc_misc", "pmc_valu", "pmc_valu2"]:
     fs = glob.glob(os.path.join(src, d, "*counter_collection.csv"))
     if not fs:
         continue

@@ -43,8 +43,11 @@ for line in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubenc
         kn = line[len("KERNEL("):].split(",")[0].strip()
         asm = line.split('REP8_', 1)[1].split('("', 1)[1].split('")', 1)[0]
         names[kn] = [p.strip().split()[0] for p in asm.split("\\n")]
+    elif line.startswith("KERNEL(k_mad_u64_u32_asm"):
+        names["k_mad_u64_u32_asm"] = ["v_mad_u64_u32"]
 rows = []
 table = {}
+variants = {}
 for kn, c in last.items():
     if not kn.startswith("k_") or kn == "k_clock" or c.get("SQ_INSTS_VALU", 0) <= 0:
         continue
@@ -56,8 +59,17 @@ for kn, c in last.items():
     rows.append((kn, ops, ms, g, n, cyc, g / ms / 1e3))
     if kn == "k_cndmask":  # reads a vcc nobody writes: measures a dependency stall, not the issue rate -> not a cost
         continue
+    variant = {"k_lshlrev_b32_vgpr": "v_lshlrev_b32 (shift in a VGPR)", "k_lshrrev_b32_vgpr": "v_lshrrev_b32 (shift in a VGPR)",
+               "k_lshlrev_b32_e64": "v_lshlrev_b32 (VOP3 encoding)", "k_lshrrev_b32_e64": "v_lshrrev_b32 (VOP3 encoding)",
+               "k_lshlrev_b32_by1": "v_lshlrev_b32 (by 1)", "k_ashrrev_i32_vgpr": "v_ashrrev_i32 (shift in a VGPR)",
+               "k_mad_u64_u32": None}.get(kn, "")
+    if variant is None:
+        continue  # (the C++ expression form of round 2; k_mad_u64_u32_asm is the instruction itself)
+    if variant:
+        variants[variant] = round(cyc, 3)
+        continue
     if ops and len(set(ops)) == 1:
-        table[ops[0]] = round(cyc, 3)
+        table[ops[0].replace("_e64", "")] = round(cyc, 3)
     elif ops:
         table["+".join(ops)] = round(cyc, 3)
 with open(os.path.join(dst, "valu_cycles.txt"), "w") as f:
@@ -79,7 +91,7 @@ out = {"source": os.path.basename(os.path.normpath(src)), "unit": "cycles per wa
                       "note": "MI355X_MICROARCH.md: SIMD-32, a wave64 VALU instruction issues over 2 cycles; 1024 SIMDs x 2.4 GHz / 2"},
        "class_simple": round(sum(simple) / len(simple), 3) if simple else None,
        "class_full": round(sum(full) / len(full), 3) if full else None,
-       "opcodes": table}
+       "opcodes": table, "encoding_variants": variants}
 json.dump(out, open(os.path.join(dst, "valu_cycles.json"), "w"), indent=1)
 if os.path.exists(os.path.join(src, "ubench_valu.txt")):
     shutil.copyfile(os.path.join(src, "ubench_valu.txt"), os.path.join(dst, "ubench_valu.txt"))

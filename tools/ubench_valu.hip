@@ -139,6 +139,49 @@ KERNEL(k_cmp_lt_u32, DECL32, REP8_32("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %
 KERNEL(k_mov_dpp, DECL32, REP8_32("v_mov_b32_dpp %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf") FIN32)
 KERNEL(k_min_dpp, DECL32, REP8_32("v_min_u32_dpp %0, %0, %1 row_shr:1 row_mask:0xf bank_mask:0xf") FIN32)
 
+// ---- round 3: every opcode of level1_tile_kernel measured by itself (no "class" costs left in tools/isa_histogram.py).
+// Compares write a scalar pair that nothing reads; selects / carries read a scalar pair that nothing rewrites (s[90:93] are
+// far above what these tiny kernels allocate), so no dependency stall enters -- the issue rate is what is measured.
+KERNEL(k_cndmask_sgpr, DECL32, REP8_32("v_cndmask_b32 %0, %0, %1, s[90:91]") FIN32)
+KERNEL(k_addc_sgpr, DECL32, REP8_32("v_addc_co_u32 %0, s[92:93], %0, %1, s[90:91]") FIN32)
+KERNEL(k_cmp_lt_u64_sgpr, DECL64, REP8_64("v_cmp_lt_u64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_eq_u64_sgpr, DECL64, REP8_64("v_cmp_eq_u64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_gt_u64_sgpr, DECL64, REP8_64("v_cmp_gt_u64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_le_u64_sgpr, DECL64, REP8_64("v_cmp_le_u64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_lt_i64_sgpr, DECL64, REP8_64("v_cmp_lt_i64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_gt_i64_sgpr, DECL64, REP8_64("v_cmp_gt_i64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_le_i64_sgpr, DECL64, REP8_64("v_cmp_le_i64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_lt_f64_sgpr, DECL64, REP8_64("v_cmp_lt_f64 s[92:93], %0, %1") FIN64)
+KERNEL(k_cmp_eq_u32_sgpr, DECL32, REP8_32("v_cmp_eq_u32 s[92:93], %0, %1") FIN32)
+KERNEL(k_cmp_ne_u32_sgpr, DECL32, REP8_32("v_cmp_ne_u32 s[92:93], %0, %1") FIN32)
+KERNEL(k_cmp_lt_u32_sgpr, DECL32, REP8_32("v_cmp_lt_u32 s[92:93], %0, %1") FIN32)
+KERNEL(k_cmp_gt_u32_sgpr, DECL32, REP8_32("v_cmp_gt_u32 s[92:93], %0, %1") FIN32)
+KERNEL(k_cmp_ge_u32_sgpr, DECL32, REP8_32("v_cmp_ge_u32 s[92:93], %0, %1") FIN32)
+KERNEL(k_max_u32, DECL32, REP8_32("v_max_u32 %0, %0, %1") FIN32)
+KERNEL(k_max_i32, DECL32, REP8_32("v_max_i32 %0, %0, %1") FIN32)
+KERNEL(k_med3_i32, DECL32, REP8_32("v_med3_i32 %0, %0, %1, %1") FIN32)
+KERNEL(k_mul_hi_u32, DECL32, REP8_32("v_mul_hi_u32 %0, %0, %1") FIN32)
+KERNEL(k_ffbl_b32, DECL32, REP8_32("v_ffbl_b32 %0, %0") FIN32)
+KERNEL(k_mbcnt_lo, DECL32, REP8_32("v_mbcnt_lo_u32_b32 %0, %1, %0") FIN32)
+KERNEL(k_mbcnt_hi, DECL32, REP8_32("v_mbcnt_hi_u32_b32 %0, %1, %0") FIN32)
+KERNEL(k_subrev_u32, DECL32, REP8_32("v_subrev_u32 %0, %0, %1") FIN32)
+KERNEL(k_bitop3_b32, DECL32, REP8_32("v_bitop3_b32 %0, %0, %1, %1 bitop3:0x96") FIN32)
+KERNEL(k_readfirstlane, DECL32, REP8_32("v_readfirstlane_b32 s92, %0") FIN32)
+// v_mad_u64_u32 as the tile kernel issues it (one 32 x 32 -> 64 product added to a 64-bit register pair)
+KERNEL(k_mad_u64_u32_asm, DECL64; uint32_t m0 = seed | 3,
+       asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q0) : "v"(m0)); asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q1) : "v"(m0));
+       asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q2) : "v"(m0)); asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q3) : "v"(m0));
+       asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q4) : "v"(m0)); asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q5) : "v"(m0));
+       asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q6) : "v"(m0)); asm volatile("v_mad_u64_u32 %0, s[92:93], %1, %1, %0" : "+v"(q7) : "v"(m0)); FIN64)
+// the left / right shift split of round 2 (4.15 vs 2.45 cycles): the same opcodes with the shift amount in a VGPR and in the
+// 64-bit (VOP3) encoding
+KERNEL(k_lshlrev_b32_vgpr, DECL32, REP8_32("v_lshlrev_b32 %0, %1, %0") FIN32)
+KERNEL(k_lshrrev_b32_vgpr, DECL32, REP8_32("v_lshrrev_b32 %0, %1, %0") FIN32)
+KERNEL(k_lshlrev_b32_e64, DECL32, REP8_32("v_lshlrev_b32_e64 %0, 3, %0") FIN32)
+KERNEL(k_lshrrev_b32_e64, DECL32, REP8_32("v_lshrrev_b32_e64 %0, 3, %0") FIN32)
+KERNEL(k_lshlrev_b32_by1, DECL32, REP8_32("v_lshlrev_b32 %0, 1, %0") FIN32)
+KERNEL(k_ashrrev_i32_vgpr, DECL32, REP8_32("v_ashrrev_i32 %0, %1, %0") FIN32)
+
 __global__ void k_clock(unsigned long long *out) {
     unsigned long long t0 = __builtin_readcyclecounter();
     unsigned long long w0 = wall_clock64();
@@ -176,6 +219,7 @@ int main() {
         {"c++ umin64", k_cpp_umin64, 8}, {"c++ fmin64 (f64 min)", k_cpp_fmin64, 8}, {"c++ q^(q>>24)", k_cpp_xorshr, 8},
         {"u64hash reference form", k_hash_ref, 8}, {"u64hash 32-bit halves", k_hash_32, 8}, {"u64hash with 64-bit muls", k_hash_mul, 8},
         {"v_cmp_lt_u32+cnd (pair)", k_cmp_lt_u32, 8}, {"v_mov_b32_dpp", k_mov_dpp, 8}, {"v_min_u32_dpp", k_min_dpp, 8},
+        {"cndmask_sgpr", k_cndmask_sgpr, 8}, {"addc_sgpr", k_addc_sgpr, 8}, {"cmp_lt_u64_sgpr", k_cmp_lt_u64_sgpr, 8}, {"cmp_eq_u64_sgpr", k_cmp_eq_u64_sgpr, 8}, {"cmp_gt_u64_sgpr", k_cmp_gt_u64_sgpr, 8}, {"cmp_le_u64_sgpr", k_cmp_le_u64_sgpr, 8}, {"cmp_lt_i64_sgpr", k_cmp_lt_i64_sgpr, 8}, {"cmp_gt_i64_sgpr", k_cmp_gt_i64_sgpr, 8}, {"cmp_le_i64_sgpr", k_cmp_le_i64_sgpr, 8}, {"cmp_lt_f64_sgpr", k_cmp_lt_f64_sgpr, 8}, {"cmp_eq_u32_sgpr", k_cmp_eq_u32_sgpr, 8}, {"cmp_ne_u32_sgpr", k_cmp_ne_u32_sgpr, 8}, {"cmp_lt_u32_sgpr", k_cmp_lt_u32_sgpr, 8}, {"cmp_gt_u32_sgpr", k_cmp_gt_u32_sgpr, 8}, {"cmp_ge_u32_sgpr", k_cmp_ge_u32_sgpr, 8}, {"max_u32", k_max_u32, 8}, {"max_i32", k_max_i32, 8}, {"med3_i32", k_med3_i32, 8}, {"mul_hi_u32", k_mul_hi_u32, 8}, {"ffbl_b32", k_ffbl_b32, 8}, {"mbcnt_lo", k_mbcnt_lo, 8}, {"mbcnt_hi", k_mbcnt_hi, 8}, {"subrev_u32", k_subrev_u32, 8}, {"bitop3_b32", k_bitop3_b32, 8}, {"readfirstlane", k_readfirstlane, 8}, {"mad_u64_u32_asm", k_mad_u64_u32_asm, 8}, {"lshlrev_b32_vgpr", k_lshlrev_b32_vgpr, 8}, {"lshrrev_b32_vgpr", k_lshrrev_b32_vgpr, 8}, {"lshlrev_b32_e64", k_lshlrev_b32_e64, 8}, {"lshrrev_b32_e64", k_lshrrev_b32_e64, 8}, {"lshlrev_b32_by1", k_lshlrev_b32_by1, 8}, {"ashrrev_i32_vgpr", k_ashrrev_i32_vgpr, 8},
     };
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const double clk = prop.clockRate * 1e3;  // Hz
