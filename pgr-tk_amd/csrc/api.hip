@@ -1161,7 +1161,7 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     *out_mm = nullptr;
     *out_off = nullptr;
-    pgr_mm128 *mm = (pgr_mm128 *)malloc(std::max<uint64_t>(s->count, 1) * sizeof(pgr_mm128));
+    pgr_mm128 *mm = (pgr_mm128 *)host_result_alloc(std::max<uint64_t>(s->count, 1) * sizeof(pgr_mm128));
     uint64_t *off = (uint64_t *)malloc(((size_t)s->n + 1) * sizeof(uint64_t));
     if (!mm || !off) {
         free(mm);
@@ -1481,11 +1481,14 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
             if (first && b->total_bases)
                 guess = (uint64_t)((double)s->count * ((double)total_bp / (double)b->total_bases) * 1.1) + 4096;
             cap = std::max<uint64_t>(total + s->count, guess);
-            pgr_mm128 *nm = (pgr_mm128 *)realloc(mm, cap * sizeof(pgr_mm128));
+            // (grown by allocate + copy: the block is huge-page advised, realloc would hand back plain pages)
+            pgr_mm128 *nm = (pgr_mm128 *)host_result_alloc(cap * sizeof(pgr_mm128));
             if (!nm) {
                 pgr_shmmrs_destroy(s);
                 return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
             }
+            if (total) memcpy(nm, mm, total * sizeof(pgr_mm128));
+            free(mm);
             mm = nm;
         }
         first = false;

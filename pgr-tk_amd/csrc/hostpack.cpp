@@ -8,6 +8,7 @@
 // link instead of 1 B (SURVEY.md section 7 step 3, K1 "or accept pre-packed").
 #include <immintrin.h>
 #include <sched.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
@@ -56,6 +57,17 @@ unsigned host_cpus() {
         return std::max(1u, c);
     }();
     return n;
+}
+
+// Host memory for a big result the caller releases with pgr_free (= free): 2 MiB aligned and advised to use transparent
+// huge pages, so that the first touch of a 50 MB shimmer list costs a few dozen page faults instead of twelve thousand.
+void *host_result_alloc(size_t bytes) {
+    if (bytes < (8u << 20)) return malloc(bytes ? bytes : 1);
+    void *p = nullptr;
+    const size_t rounded = (bytes + (2u << 20) - 1) & ~(size_t)((2u << 20) - 1);
+    if (posix_memalign(&p, 2u << 20, rounded) != 0) return malloc(bytes);
+    (void)madvise(p, rounded, MADV_HUGEPAGE);
+    return p;
 }
 
 // ------------------------------------------------------------------ thread pool

@@ -466,7 +466,7 @@ extern "C" int pgr_index_download(pgr_ctx *ctx, const pgr_index *ix, pgr_frag_re
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix || !out || !n) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized");
-    *out = (pgr_frag_rec *)malloc(std::max<uint64_t>(ix->n, 1) * sizeof(pgr_frag_rec));
+    *out = (pgr_frag_rec *)host_result_alloc(std::max<uint64_t>(ix->n, 1) * sizeof(pgr_frag_rec));
     if (!*out) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     *n = ix->n;
     if (ix->n) {
@@ -1498,7 +1498,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
                        (uint32_t *)(dI + o_nch));
     // host block: image + room for q_off, t_off, c_off (u64) and t_sid (u32) that fill_result builds
     const size_t extra = ((size_t)n_queries + 1) * 8 + (n_groups + 1) * 8 + (n_chains + 1) * 8 + up8(n_groups * 4);
-    out.block = (uint8_t *)malloc(image + extra + 8);
+    out.block = (uint8_t *)host_result_alloc(image + extra + 8);
     if (!out.block) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     if ((rc = ctx->d2h(out.block, dI, image))) return rc;  // ---- round trip 2
     PGR_HIP(ctx, hipGetLastError());

@@ -10,6 +10,9 @@ namespace pgr {
 // CPUs this process may use (affinity capped by the cgroup quota; PGR_HOST_THREADS overrides)
 unsigned host_cpus();
 
+// malloc-compatible (released with free / pgr_free) memory for big results: huge-page advised
+void *host_result_alloc(size_t bytes);
+
 // Persistent worker threads for the host side of the staging pipelines (packing, pinned-window copies).  Loops may be
 // submitted from several threads at once (the staging thread of a pipelined call and the caller's download); the
 // submitting thread always works on its own loop.
