@@ -21,6 +21,7 @@
 #include <map>
 
 #include "pgr_ctx.h"
+#include "pgr_small.h"
 
 using namespace pgr;
 
@@ -1513,12 +1514,128 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     return mm ? PGR_OK : ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
 }
 
+// Small calls (the reference's real callers: <= 129 contigs per batch, seq_db.rs:549-564; one query, ext.rs:252-282): ONE kernel
+// launch and ONE synchronization.  The host packs the bases into a pinned block, small_shmmr_kernel (csrc/small.hip, one
+// workgroup per contig) reads it over PCIe and writes the final MM128 lists into a second pinned block; the host copies them
+// out.  handled == false: not a small call, or the kernel handed a contig back (palindromic k-mer, low-complexity list) --
+// the caller takes the general path.
+static int shmmr_batch_small(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const StageSrc &src, const uint32_t *rids,
+                             pgr_mm128 **out_mm, uint64_t **out_off, bool &handled) {
+    handled = false;
+    if (spec->sketch || spec->w < (uint32_t)L1_MIN_W || n == 0 || n > SMALL_MAX_CONTIGS || getenv("PGR_NO_SMALL_PATH")) return PGR_OK;
+    uint64_t total_bp = 0, total_words = 0, total_slots = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        if (src.lens[i] > SMALL_MAX_LEN) return PGR_OK;
+        total_bp += src.lens[i];
+        total_words += (src.lens[i] + 31) / 32;
+        total_slots += src.lens[i] / 32 + 64;
+    }
+    if (total_bp > SMALL_MAX_BASES) return PGR_OK;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->staged_unsynced) {  // the pinned windows may still be the source of an earlier staging
+        PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->staged_unsynced = false;
+    }
+    const size_t desc_bytes = ((size_t)n * sizeof(SmallContig) + 15) & ~(size_t)15;
+    const size_t in_bytes = desc_bytes + (size_t)std::max<uint64_t>(total_words, 1) * 12;  // planes, then the packer's validity words
+    const size_t cnt_bytes = (((size_t)n + 1) * sizeof(uint32_t) + 15) & ~(size_t)15;
+    const size_t out_bytes = cnt_bytes + (size_t)total_slots * sizeof(pgr_mm128);
+    int rc;
+    if ((rc = ctx->ensure_pinned(in_bytes)) || (rc = ctx->ensure_pinned_out(out_bytes))) return rc;
+    SmallContig *desc = (SmallContig *)ctx->pinned;
+    uint64_t *planes = (uint64_t *)((uint8_t *)ctx->pinned + desc_bytes);
+    uint32_t *valid = (uint32_t *)(planes + std::max<uint64_t>(total_words, 1));
+    uint32_t *counts = (uint32_t *)ctx->pinned_out;
+    pgr_mm128 *slots = (pgr_mm128 *)((uint8_t *)ctx->pinned_out + cnt_bytes);
+    uint64_t w_off = 0, s_off = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        desc[i].word_off = w_off;
+        desc[i].len = (uint32_t)src.lens[i];
+        desc[i].rid = rids ? rids[i] : i;
+        desc[i].out_off = (uint32_t)s_off;
+        desc[i].out_cap = (uint32_t)(src.lens[i] / 32 + 64);
+        w_off += (src.lens[i] + 31) / 32;
+        s_off += desc[i].out_cap;
+    }
+    // ---- the bases: packed on the host (every base must be valid: anything else belongs to the exact-island path)
+    uint64_t bad = 0;
+    if (!src.planes) {
+        if (total_bp < (1u << 20)) {
+            for (uint32_t i = 0; i < n && !bad; ++i)
+                bad += pack_words(src.seqs[i], src.lens[i], 0, (src.lens[i] + 31) / 32, planes + desc[i].word_off, valid + desc[i].word_off);
+        } else {
+            std::atomic<uint64_t> nb{0};
+            HostPool::instance().parallel_for(n, [&](size_t i) {
+                const uint64_t b2 = pack_words(src.seqs[i], src.lens[i], 0, (src.lens[i] + 31) / 32, planes + desc[i].word_off,
+                                               valid + desc[i].word_off);
+                if (b2) nb.fetch_add(b2);
+            });
+            bad = nb.load();
+        }
+    } else {
+        memcpy(planes, src.planes + src.word0, (size_t)total_words * sizeof(uint64_t));
+        if (src.valid) {  // all bases valid?  (bits past a contig's end do not count)
+            for (uint32_t i = 0; i < n && !bad; ++i) {
+                const uint64_t nw = (src.lens[i] + 31) / 32;
+                const uint32_t *v = src.valid + src.word0 + desc[i].word_off;
+                for (uint64_t j = 0; j + 1 < nw && !bad; ++j) bad += v[j] != 0xFFFFFFFFu;
+                if (nw) {
+                    const uint32_t nbits = (uint32_t)(src.lens[i] - (nw - 1) * 32);
+                    const uint32_t tail = nbits == 32 ? 0xFFFFFFFFu : ~(0xFFFFFFFFu >> nbits);
+                    bad += (v[nw - 1] & tail) != tail;
+                }
+            }
+        }
+    }
+    if (bad) return PGR_OK;
+    counts[n] = 0;  // the fallback flag word
+    SmallArgs a;
+    a.planes = (const uint2 *)planes;
+    a.desc = desc;
+    a.n = n;
+    a.w = spec->w;
+    a.k = spec->k;
+    a.r = spec->r;
+    a.min_span = spec->min_span;
+    a.tc = ((L1_EXT - 2 * (spec->w - 1)) / 64) * 64;
+    a.out = slots;
+    a.counts = counts;
+    a.flags = counts + n;
+    launch_small_shmmr(ctx->stream, a);
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
+        return ctx->fail(PGR_ERR_DEVICE, "small-batch kernel failed on the device");
+    if (counts[n]) return PGR_OK;  // a contig needs the exact state machine / a bigger list: general path
+    uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
+    if (!off) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    uint64_t tot = 0;
+    for (uint32_t i = 0; i < n; ++i) {
+        off[i] = tot;
+        tot += counts[i];
+    }
+    off[n] = tot;
+    pgr_mm128 *mm = (pgr_mm128 *)host_result_alloc(std::max<uint64_t>(tot, 1) * sizeof(pgr_mm128));
+    if (!mm) {
+        free(off);
+        return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
+    }
+    for (uint32_t i = 0; i < n; ++i)
+        if (counts[i]) memcpy(mm + off[i], slots + desc[i].out_off, (size_t)counts[i] * sizeof(pgr_mm128));
+    *out_mm = mm;
+    *out_off = off;
+    handled = true;
+    return PGR_OK;
+}
+
 static int shmmr_batch_host(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const StageSrc &src, const uint32_t *rids,
                             int padding, pgr_mm128 **out_mm, uint64_t **out_off) {
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
     *out_mm = nullptr;
     *out_off = nullptr;
+    if (!padding || spec->r <= 1) {  // (the padding artefact of reduce_shmmr only exists for r > 1)
+        bool handled = false;
+        if ((rc = shmmr_batch_small(ctx, spec, n, src, rids, out_mm, out_off, handled)) || handled) return rc;
+    }
     if (worth_pipelining(n, src.lens)) return shmmr_batch_pipelined(ctx, spec, n, src, rids, padding, out_mm, out_off);
     pgr_batch *b = nullptr;
     if ((rc = batch_from_host(ctx, n, src, &b))) return rc;

@@ -327,3 +327,63 @@ def test_bench_two_ranks_line_is_gradeable():
     assert ex["largest_shard_over_mean"] < 1.2
     q = line["query"]
     assert "error" not in q and q["queries_with_best_chain_on_source"] >= 396 and q["index_records"] == ex["records_in_shards"]
+
+
+def test_small_call_path_against_oracle_and_general_path(oracle, gpu_ctx, monkeypatch):
+    """csrc/small.hip: batches of short clean contigs go through ONE kernel (one workgroup per contig: tiles, tail, both
+    reductions, min_span in LDS).  Lengths around every boundary of the state machine and of the tiles, several specs, rids;
+    the same calls with the small path switched off take the general pipeline -- three-way equality with the oracle.
+    Contigs the kernel hands back (palindromic k-mers, low-complexity lists) and batches with N still come out exact."""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(77)
+    for spec_t in ((80, 56, 4, 64), (48, 56, 4, 12), (24, 24, 12, 24), (33, 31, 3, 8), (80, 56, 1, 64), (128, 56, 12, 64), (17, 9, 2, 0)):
+        w, k, r, ms = spec_t
+        tc = (4096 - 2 * (w - 1)) // 64 * 64
+        lens = [0, 1, k - 1, k, k + 1, k + w - 2, k + w - 1, k + w, 2 * w + k, 3 * w, 500, 1000, 3000, tc - 1, tc, tc + 1, 2 * tc - w,
+                2 * tc, 2 * tc + w + k, 10_000, 33_333, 100_000, 131_072]
+        seqs = [seqgen.rnd(rng, n) for n in lens]
+        rids = [int(v) for v in rng.integers(0, 2 ** 31, len(seqs))]
+        spec = P.make_spec(w, k, r, ms)
+        osp = oracle.spec(w, k, r, ms)
+        small = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
+        monkeypatch.setenv("PGR_NO_SMALL_PATH", "1")
+        general = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
+        monkeypatch.delenv("PGR_NO_SMALL_PATH")
+        for i, s in enumerate(seqs):
+            ref = oracle.sequence_to_shmmrs(rids[i], s, osp)
+            _same(ref, small[i], "small path, spec %s len %d" % (spec_t, len(s)))
+            _same(ref, general[i], "general path, spec %s len %d" % (spec_t, len(s)))
+    # handed back by the kernel / not eligible: still exact
+    spec, osp = P.make_spec(), oracle.spec()
+    mixed = [seqgen.rnd(rng, 20_000), seqgen.rnd(rng, 9_000) + b"AT" * 70 + seqgen.rnd(rng, 9_000), b"A" * 60_000, b"ACGTTGCA" * 9000,
+             seqgen.rnd(rng, 5_000) + b"N" + seqgen.rnd(rng, 5_000), seqgen.rnd(rng, 131_073)]
+    for sub in (mixed[:1], mixed[:2], mixed[2:4], mixed[4:5], mixed[5:], mixed):
+        got = P.sequence_to_shmmrs_batch(sub, spec, ctx=gpu_ctx)
+        for i, s in enumerate(sub):
+            _same(oracle.sequence_to_shmmrs(i, s, osp), got[i], "mixed len %d" % len(s))
+    # packed input takes the same path
+    clean = [seqgen.rnd(rng, n) for n in (10_000, 777, 56, 40_000)]
+    packed, _ = P.pack_ascii(clean)
+    for pk in (packed, P.PackedBases(packed.lens, packed.planes, None)):
+        got = P.sequence_to_shmmrs_batch_packed(pk, spec, ctx=gpu_ctx)
+        for i, s in enumerate(clean):
+            _same(oracle.sequence_to_shmmrs(i, s, osp), got[i], "packed small call %d" % i)
+
+
+def test_small_call_latency_targets(gpu_ctx):
+    """the point of the small path: one 10 kbp contig in well under 0.1 ms, the reference's 129-contig batch (seq_db.rs:561) of
+    10 kbp contigs in a fraction of a millisecond -- host ASCII in, host MM128 out, timed at the C entry point"""
+    import bench
+    import pgrtk_amd as P
+    spec = P.make_spec()
+    one = P.PackedSeqs.from_list([bench.synth_contig_ascii(2, 0, 10_000)])
+    many = P.PackedSeqs.from_list([bench.synth_contig_ascii(2, c, 10_000) for c in range(129)])
+
+    def med(seqs):
+        for _ in range(5):
+            P.time_shmmr_batch(seqs, spec, ctx=gpu_ctx)
+        ts = sorted(P.time_shmmr_batch(seqs, spec, ctx=gpu_ctx)[0] for _ in range(40))
+        return ts[len(ts) // 2] * 1e3
+    t1, t129 = med(one), med(many)
+    print("one 10 kbp contig %.3f ms, 129 x 10 kbp %.3f ms" % (t1, t129))
+    assert t1 < 0.09 and t129 < 0.3, (t1, t129)  # (measured: see bench.py latency; the assertion leaves room for a slow box)
