@@ -680,6 +680,119 @@ static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
     return PGR_OK;
 }
 
+// One pass of the hot path over a resident batch of SHORT contigs (query batches, reads, fragmented assemblies): the
+// one-workgroup-per-contig kernel of csrc/small.hip replaces tiles + tails + segment scans + the fused list kernel -- 4 launches
+// and one synchronization instead of ~15 dependent operations.  handled == false: not eligible, or a contig was handed back
+// (non-ACGT byte, palindromic k-mer, low-complexity list): the caller runs the general pipeline.
+static int shmmrs_compute_small(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *rids, pgr_shmmrs **out,
+                                bool &handled) {
+    handled = false;
+    const uint32_t n = b->n;
+    if (n == 0 || spec->sketch || spec->w < (uint32_t)L1_MIN_W || b->host_saw_invalid || getenv("PGR_NO_SMALL_PATH")) return PGR_OK;
+    uint32_t max_len = 0;
+    uint64_t total_slots = 0;
+    for (uint32_t c = 0; c < n; ++c) {
+        if (b->h_len[c] > SMALL_MAX_LEN) return PGR_OK;
+        max_len = std::max(max_len, b->h_len[c]);
+        total_slots += b->h_len[c] / 32 + 64;
+    }
+    if (total_slots >= (1ull << 32)) return PGR_OK;
+    hipStream_t st = ctx->stream;
+    std::vector<SmallContig> &desc = ctx->keep_small_desc;  // source of an async H2D copy: lives in the context
+    desc.resize(n);
+    uint64_t s_off = 0;
+    for (uint32_t c = 0; c < n; ++c) {
+        desc[c].word_off = b->h_word_off[c];
+        desc[c].len = b->h_len[c];
+        desc[c].rid = rids ? rids[c] : c;
+        desc[c].out_off = (uint32_t)s_off;
+        desc[c].out_cap = b->h_len[c] / 32 + 64;
+        s_off += desc[c].out_cap;
+    }
+    constexpr size_t N_STATUS = 10;  // (same result layout as the general path: status words in front of the offsets)
+    int rc;
+    if ((rc = ctx->ws_small_desc.ensure(ctx, (size_t)n * sizeof(SmallContig))) ||
+        (rc = ctx->ws_small_cnt.ensure(ctx, 2 * ((size_t)n + 1) * sizeof(uint32_t))) ||
+        (rc = ctx->ws_list_a.ensure(ctx, (size_t)total_slots * sizeof(pgr_mm128))) ||
+        (rc = ctx->ws_scan_tmp.ensure(ctx, scan_counts_temp_bytes(n + 1))) ||
+        (rc = ctx->ensure_mailbox(((size_t)n + 2) * sizeof(uint64_t))))
+        return rc;
+    uint32_t *d_counts = (uint32_t *)ctx->ws_small_cnt.p, *d_clean = d_counts + (n + 1);
+    pgr_shmmrs *res = new pgr_shmmrs();
+    res->ctx = ctx;
+    res->n = n;
+    auto bail = [&](int code) {
+        pgr_shmmrs_destroy(res);
+        return code;
+    };
+    if ((rc = ctx->dmalloc((void **)&res->d_block, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
+    res->d_off = res->d_block + N_STATUS;
+    const double dens = 2.0 / (double)(spec->w + 1);
+    const double spec_key = (double)spec->w * 1e9 + spec->k * 1e6 + spec->r * 1e4 + spec->min_span;
+    const double ratio = (ctx->est_spec_key == spec_key && ctx->est_final_ratio > 0) ? ctx->est_final_ratio * 1.15 : dens / 3.0 + 1e-4;
+    uint64_t cap_res = std::max<uint64_t>((uint64_t)((double)b->total_bases * ratio) + 64ull * n + 1024, 16);
+    uint64_t *mbox = (uint64_t *)ctx->mailbox;
+    hipError_t e = hipEventRecord(ctx->ev[0], st);
+    if (e == hipSuccess) e = hipMemcpyAsync(ctx->ws_small_desc.p, desc.data(), (size_t)n * sizeof(SmallContig), hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemsetAsync(d_counts + n, 0, sizeof(uint32_t), st);  // the fallback flag word
+    if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string("small path set-up: ") + hipGetErrorString(e)));
+    SmallArgs a;
+    a.planes = b->d.planes;
+    a.valid = b->d.valid;
+    a.l1_cap = small_l1_cap(max_len, spec->w);
+    a.desc = (const SmallContig *)ctx->ws_small_desc.p;
+    a.n = n;
+    a.w = spec->w;
+    a.k = spec->k;
+    a.r = spec->r;
+    a.min_span = spec->min_span;
+    a.tc = ((L1_EXT - 2 * (spec->w - 1)) / 64) * 64;
+    a.out = (pgr_mm128 *)ctx->ws_list_a.p;
+    a.counts = d_counts;
+    a.flags = d_counts + n;
+    launch_small_shmmr(st, a);
+    launch_small_counts(st, d_counts, n, d_clean);
+    if (scan_counts(st, ctx->ws_scan_tmp.p, scan_counts_temp_bytes(n + 1), d_clean, res->d_off, n + 1) != hipSuccess)
+        return bail(ctx->fail(PGR_ERR_DEVICE, "scan failed"));
+    for (int attempt = 0;; ++attempt) {
+        ctx->dfree(res->d_mm);
+        res->d_mm = nullptr;
+        if ((rc = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return bail(rc);
+        launch_small_gather(st, (const pgr_mm128 *)ctx->ws_list_a.p, a.desc, d_counts, res->d_off, n, res->d_mm, cap_res);
+        e = hipEventRecord(ctx->ev_end, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(mbox, res->d_off, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(mbox + n + 1, d_counts + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string("small path: ") + hipGetErrorString(e)));
+        if ((uint32_t)mbox[n + 1]) {  // a contig needs the general pipeline
+            pgr_shmmrs_destroy(res);
+            return PGR_OK;
+        }
+        if (mbox[n] <= cap_res || attempt > 0) break;
+        cap_res = mbox[n] + 16;  // more survivors than estimated: gather again into a bigger buffer
+    }
+    res->h_off.assign(mbox, mbox + n + 1);
+    res->count = mbox[n];
+    res->rid_is_index = rids == nullptr;
+    ctx->staged_unsynced = false;
+    ctx->want_host_copy = false;
+    if (b->total_bases) {
+        ctx->est_spec_key = spec_key;
+        ctx->est_final_ratio = (double)res->count / (double)b->total_bases;
+    }
+    pgr_prof prof;
+    memset(&prof, 0, sizeof(prof));
+    (void)hipEventElapsedTime(&prof.total_ms, ctx->ev[0], ctx->ev_end);
+    prof.level1_ms = prof.total_ms;  // (one kernel does levels 1 and 2)
+    prof.bases_tiled = b->total_bases;
+    prof.n_tiles = n;
+    ctx->prof = prof;
+    *out = res;
+    handled = true;
+    return PGR_OK;
+}
+
 // One pass of the hot path over a resident batch.  Everything is enqueued on the context's stream with sizes that are
 // upper bounds or estimates; the host reads the true counts ONCE at the end (one hipStreamSynchronize per call in the
 // common case) and repeats a stage only when an estimate turned out too small:
@@ -699,6 +812,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     if (rc) return rc;
     if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
+    if (!(padding && !spec->sketch && spec->r > 1)) {  // batches of short contigs: one workgroup per contig, 4 launches
+        bool handled = false;
+        if ((rc = shmmrs_compute_small(ctx, b, spec, rids, out, handled)) || handled) return rc;
+    }
     hipStream_t st = ctx->stream;
     const uint32_t n = b->n;
     const bool sketch = spec->sketch != 0;
@@ -1589,8 +1706,12 @@ static int shmmr_batch_small(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, con
     }
     if (bad) return PGR_OK;
     counts[n] = 0;  // the fallback flag word
+    uint32_t max_len = 0;
+    for (uint32_t i = 0; i < n; ++i) max_len = std::max<uint32_t>(max_len, (uint32_t)src.lens[i]);
     SmallArgs a;
     a.planes = (const uint2 *)planes;
+    a.valid = nullptr;  // checked above
+    a.l1_cap = small_l1_cap(max_len, spec->w);
     a.desc = desc;
     a.n = n;
     a.w = spec->w;

@@ -204,7 +204,7 @@ void pgr_ctx::release_all() {
     pgr::DevBuf *bufs[] = {&ws_ascii,    &ws_tile_first, &ws_seg_off,    &ws_seg_cnt, &ws_seg_dst,
                            &ws_cursor,   &ws_flags,      &ws_l1,         &ws_serial,  &ws_scan_tmp,
                            &ws_list_a,   &ws_list_b,     &ws_off_a,      &ws_off_b,   &ws_blk_cnt,
-                           &ws_blk_base, &ws_start_rank, &ws_rids,       &ws_rec_off,    &ws_blk_off,    &ws_tile_desc,  &ws_tile_flags, &ws_seg_cid, &ws_tile_lv};
+                           &ws_blk_base, &ws_start_rank, &ws_rids,       &ws_rec_off,    &ws_blk_off,    &ws_tile_desc,  &ws_tile_flags, &ws_seg_cid, &ws_tile_lv, &ws_small_desc, &ws_small_cnt};
     for (auto *b : bufs) b->release(this);
     for (auto &kv : free_blocks) (void)hipFree(kv.second);
     free_blocks.clear();

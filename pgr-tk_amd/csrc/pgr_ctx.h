@@ -7,6 +7,7 @@
 
 #include "pgr_internal.h"
 #include "pgr_host.h"
+#include "pgr_small.h"
 
 namespace pgr {
 struct DevBuf {
@@ -43,6 +44,7 @@ struct pgr_ctx {
     double est_spec_key = -1.0, est_final_ratio = 0.0;
     // overflow-region need of the level-1 kernels per tiled base, last call with the spec `est_l1_key`
     double est_l1_key = -1.0, est_ovf_ratio = 0.0;
+    std::vector<pgr::SmallContig> keep_small_desc;  // source of the async H2D copy of shmmrs_compute_small
     std::vector<uint64_t> keep_rec_off;  // source of the async H2D copy of shmmrs_to_frag_recs_enqueue
     // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`
     hipStream_t copy_stream = nullptr;
@@ -51,7 +53,7 @@ struct pgr_ctx {
     // workspaces
     pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
         ws_scan_tmp, ws_list_a, ws_list_b, ws_off_a, ws_off_b, ws_blk_cnt, ws_blk_base, ws_start_rank, ws_rids,
-        ws_rec_off, ws_blk_off, ws_tile_desc, ws_tile_flags, ws_seg_cid, ws_tile_lv;
+        ws_rec_off, ws_blk_off, ws_tile_desc, ws_tile_flags, ws_seg_cid, ws_tile_lv, ws_small_desc, ws_small_cnt;
 
     // caching allocator for result buffers: size -> free blocks
     std::multimap<size_t, void *> free_blocks;

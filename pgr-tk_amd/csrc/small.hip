@@ -23,8 +23,9 @@ namespace pgr {
 
 namespace {
 
-constexpr int SMALL_L1_CAP = 4096;  // level-1 minimizers per contig held in LDS (expected: 0.0247 per base at w = 80)
-
+// The level-1 list (hash key 8 B + pos/strand 4 B per minimizer) lives in DYNAMIC LDS sized by the longest contig of the batch
+// (SmallArgs::l1_cap, at most SMALL_L1_CAP_MAX): a batch of 10 kbp queries needs 320 entries = 3.75 KB next to the 35 KB of the
+// tile stage, so that four workgroups share a CU exactly as with level1_tile_kernel.
 struct SmallLds {
     double suf[L1_G][L1_BLOCK];  // tile stage: window rows; later: scratch of the tail and the level-2 index lists
     double row[L1_BLOCK];
@@ -34,8 +35,7 @@ struct SmallLds {
     int skip;
     uint32_t n1;        // level-1 minimizers so far
     uint32_t overflow;  // the list would not hold them
-    uint64_t key[SMALL_L1_CAP];   // 56-bit hash keys of the level-1 list, position order
-    uint32_t ypos[SMALL_L1_CAP];  // pos << 1 | strand
+    uint32_t invalid;   // the contig holds a non-ACGT byte
 };
 
 // ordered compaction of the k in [0, n) with pred(k): out[j] = src ? src[k] : k.  Returns the number kept (uniform).
@@ -67,9 +67,9 @@ __device__ __forceinline__ uint32_t compact_indices(SmallLds &L, uint32_t n, con
 
 // reduce_shmmr without padding on an index list: list[k] (or k itself) -> element of the level-1 arrays
 template <int TR>
-__device__ __forceinline__ bool reduce_keep(const SmallLds &L, const uint16_t *list, int n, int k, uint32_t r_rt) {
+__device__ __forceinline__ bool reduce_keep(const uint64_t *key, const uint16_t *list, int n, int k, uint32_t r_rt) {
     const uint32_t r = TR ? (uint32_t)TR : r_rt;
-    const uint64_t xi = L.key[list ? list[k] : k];
+    const uint64_t xi = key[list ? list[k] : k];
     uint32_t a = 0, b = 0;
     bool run_a = true, run_b = true;
 #pragma unroll
@@ -78,14 +78,14 @@ __device__ __forceinline__ bool reduce_keep(const SmallLds &L, const uint16_t *l
         {
             const int kk = k - (int)d;
             const bool inside = kk >= 0;
-            const uint64_t xn = L.key[inside ? (list ? list[kk] : kk) : 0];
+            const uint64_t xn = key[inside ? (list ? list[kk] : kk) : 0];
             run_a = run_a && inside && xn >= xi;
             a += run_a ? 1u : 0u;
         }
         {
             const int kk = k + (int)d;
             const bool inside = kk < n;
-            const uint64_t xn = L.key[inside ? (list ? list[kk] : kk) : 0];
+            const uint64_t xn = key[inside ? (list ? list[kk] : kk) : 0];
             run_b = run_b && inside && xn >= xi;
             b += run_b ? 1u : 0u;
         }
@@ -98,9 +98,13 @@ __device__ __forceinline__ bool reduce_keep(const SmallLds &L, const uint16_t *l
 template <int TW, int TK>
 __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
     __shared__ SmallLds L;
+    extern __shared__ uint64_t small_dyn[];
     const uint32_t t = threadIdx.x;
     const uint32_t c = blockIdx.x;
     const SmallContig cd = a.desc[c];
+    const uint32_t l1_cap = a.l1_cap;
+    uint64_t *key = small_dyn;                                            // [l1_cap] 56-bit hash keys, position order
+    uint32_t *ypos = reinterpret_cast<uint32_t *>(small_dyn + l1_cap);    // [l1_cap] pos << 1 | strand
     const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
     if (cd.len == 0) {
         if (t == 0) a.counts[c] = 0;
@@ -116,6 +120,26 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
         L.n1 = 0;
         L.overflow = 0;
         L.skip = 0;
+        L.invalid = 0;
+    }
+    if (a.valid) {  // resident batches: nobody has looked at the validity plane yet (the host entry points pack and check)
+        __syncthreads();
+        const uint32_t *__restrict__ v = a.valid + cd.word_off;
+        bool bad = false;
+        for (long long j = t; j < nwords; j += L1_BLOCK) {
+            uint32_t want = 0xFFFFFFFFu;
+            if (j == nwords - 1 && (g.L & 31)) want = ~(0xFFFFFFFFu >> (uint32_t)(g.L & 31));
+            bad = bad || (v[j] & want) != want;
+        }
+        if (bad) L.invalid = 1;  // (benign race: all writers store 1)
+        __syncthreads();
+        if (L.invalid) {
+            if (t == 0) {
+                a.counts[c] = SMALL_FALLBACK;
+                atomicOr(a.flags, 1u);
+            }
+            return;
+        }
     }
     // ---------------------------------------------------------------- level 1: the tiles of the contig, in order
     for (uint32_t tile_local = 0; tile_local < nt; ++tile_local) {
@@ -164,7 +188,7 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
             total += L.wsum[i];
         }
         const uint32_t base = L.n1;  // (written behind the barrier at the end of the previous tile)
-        const bool fits = base + total <= (uint32_t)SMALL_L1_CAP;
+        const bool fits = base + total <= l1_cap;
         // the selected keys go through the lane's own column of the (now free) window rows, as in level1_tile_kernel: a loop
         // over the ~0.4 set bits per lane instead of 16 predicated stores; no barrier needed for a lane's own data
 #pragma unroll
@@ -177,8 +201,8 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
                 const uint32_t u = (uint32_t)__builtin_ctz(em);
                 em &= em - 1;
                 const uint64_t kb = (uint64_t)__double_as_longlong(L.suf[u][t]);
-                L.key[o] = kb & 0x00FFFFFFFFFFFFFFull;
-                L.ypos[o] = ((q32 + u) << 1) | ((strand_bits >> u) & 1u);
+                key[o] = kb & 0x00FFFFFFFFFFFFFFull;
+                ypos[o] = ((q32 + u) << 1) | ((strand_bits >> u) & 1u);
                 ++o;
             }
         }
@@ -242,13 +266,13 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
                 }
             }
             const uint32_t base = L.n1;
-            const bool fits = base + (uint32_t)n_emit <= (uint32_t)SMALL_L1_CAP;
+            const bool fits = base + (uint32_t)n_emit <= l1_cap;
             __builtin_amdgcn_wave_barrier();
             if (fits) {
                 for (int i = (int)t; i < n_emit; i += 64) {
                     const uint32_t idx = s_emit[i];
-                    L.key[base + i] = s_x[idx] >> 8;
-                    L.ypos[base + i] = ((uint32_t)(lo + idx) << 1) | (s_st[idx] & 1u);
+                    key[base + i] = s_x[idx] >> 8;
+                    ypos[base + i] = ((uint32_t)(lo + idx) << 1) | (s_st[idx] & 1u);
                 }
             }
             if (t == 0) {
@@ -268,16 +292,16 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
     // ---------------------------------------------------------------- level 2 on index lists (in the free window rows)
     const uint32_t n1 = L.n1;
     uint16_t *idx_a = reinterpret_cast<uint16_t *>(&L.suf[0][0]);
-    uint16_t *idx_b = idx_a + SMALL_L1_CAP;
-    uint16_t *idx_c = idx_b + SMALL_L1_CAP;
+    uint16_t *idx_b = idx_a + l1_cap;
+    uint16_t *idx_c = idx_b + l1_cap;
     __syncthreads();  // (the tail's scratch lives in the same memory)
     const uint16_t *fin = nullptr;  // nullptr: the identity list
     uint32_t n3 = n1;
     if (a.r > 1) {
-        const uint32_t n2 = (a.r == 4) ? compact_indices(L, n1, nullptr, idx_a, [&](uint32_t kk) { return reduce_keep<4>(L, nullptr, (int)n1, (int)kk, 4); })
-                                       : compact_indices(L, n1, nullptr, idx_a, [&](uint32_t kk) { return reduce_keep<0>(L, nullptr, (int)n1, (int)kk, a.r); });
-        n3 = (a.r == 4) ? compact_indices(L, n2, idx_a, idx_b, [&](uint32_t kk) { return reduce_keep<4>(L, idx_a, (int)n2, (int)kk, 4); })
-                        : compact_indices(L, n2, idx_a, idx_b, [&](uint32_t kk) { return reduce_keep<0>(L, idx_a, (int)n2, (int)kk, a.r); });
+        const uint32_t n2 = (a.r == 4) ? compact_indices(L, n1, nullptr, idx_a, [&](uint32_t kk) { return reduce_keep<4>(key, nullptr, (int)n1, (int)kk, 4); })
+                                       : compact_indices(L, n1, nullptr, idx_a, [&](uint32_t kk) { return reduce_keep<0>(key, nullptr, (int)n1, (int)kk, a.r); });
+        n3 = (a.r == 4) ? compact_indices(L, n2, idx_a, idx_b, [&](uint32_t kk) { return reduce_keep<4>(key, idx_a, (int)n2, (int)kk, 4); })
+                        : compact_indices(L, n2, idx_a, idx_b, [&](uint32_t kk) { return reduce_keep<0>(key, idx_a, (int)n2, (int)kk, a.r); });
         fin = idx_b;
     }
     // min_span stencil on the unfiltered neighbours (shmmrutils.rs:536-555): first and last always stay
@@ -285,9 +309,9 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
     const uint32_t n4 = compact_indices(L, n3, fin, idx_c, [&](uint32_t i) {
         if (i == 0 || i + 1 == n3) return true;
         const uint32_t e = fin ? fin[i] : i, ep = fin ? fin[i - 1] : i - 1, en = fin ? fin[i + 1] : i + 1;
-        const uint32_t p = L.ypos[e] >> 1, pp = L.ypos[ep] >> 1, pn = L.ypos[en] >> 1;
-        const uint64_t xk = L.key[e];
-        return (p - pp > ms) && (pn - p > ms) && L.key[ep] != xk && L.key[en] != xk;
+        const uint32_t p = ypos[e] >> 1, pp = ypos[ep] >> 1, pn = ypos[en] >> 1;
+        const uint64_t xk = key[e];
+        return (p - pp > ms) && (pn - p > ms) && key[ep] != xk && key[en] != xk;
     });
     if (n4 > cd.out_cap) {
         if (t == 0) {
@@ -300,21 +324,56 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
     for (uint32_t j = t; j < n4; j += L1_BLOCK) {
         const uint32_t e = idx_c[j];
         pgr_mm128 m;
-        m.x = (L.key[e] << 8) | (uint64_t)k;
-        m.y = ((uint64_t)cd.rid << 32) | L.ypos[e];
+        m.x = (key[e] << 8) | (uint64_t)k;
+        m.y = ((uint64_t)cd.rid << 32) | ypos[e];
         out[j] = m;
     }
     if (t == 0) a.counts[c] = n4;
 }
 
+uint32_t small_l1_cap(uint32_t max_len, uint32_t w) {
+    const double expect = 2.0 * (double)max_len / (double)(w + 1);  // level-1 density 2 / (w + 1)
+    const uint32_t cap = (((uint32_t)(expect * 1.15) + 32 + 63) / 64) * 64;
+    return cap > SMALL_L1_CAP_MAX ? SMALL_L1_CAP_MAX : cap;
+}
+
 void launch_small_shmmr(hipStream_t st, const SmallArgs &a) {
     if (a.n == 0) return;
+    const size_t dyn = (size_t)a.l1_cap * 12;
     if (a.w == 80 && a.k == 56)
-        hipLaunchKernelGGL((small_shmmr_kernel<80, 56>), dim3(a.n), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((small_shmmr_kernel<80, 56>), dim3(a.n), dim3(L1_BLOCK), dyn, st, a);
     else if (a.w == 48 && a.k == 56)
-        hipLaunchKernelGGL((small_shmmr_kernel<48, 56>), dim3(a.n), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((small_shmmr_kernel<48, 56>), dim3(a.n), dim3(L1_BLOCK), dyn, st, a);
     else
-        hipLaunchKernelGGL((small_shmmr_kernel<0, 0>), dim3(a.n), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((small_shmmr_kernel<0, 0>), dim3(a.n), dim3(L1_BLOCK), dyn, st, a);
+}
+
+// ------------------------------------------------------------------ resident results: slots -> one contiguous list
+// one wavefront per contig copies its slot behind the contigs in front of it (off = exclusive scan of the counts)
+__global__ __launch_bounds__(256) void small_gather_kernel(const pgr_mm128 *__restrict__ slots, const SmallContig *__restrict__ desc,
+                                                           const uint32_t *__restrict__ counts, const uint64_t *__restrict__ off, uint32_t n,
+                                                           pgr_mm128 *__restrict__ dst, uint64_t dst_cap) {
+    const uint32_t c = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= n) return;
+    const uint32_t cnt = counts[c];
+    if (cnt == SMALL_FALLBACK || off[c] + cnt > dst_cap) return;  // (the host sees the flag / the true total and repeats)
+    const ulonglong2 *s = reinterpret_cast<const ulonglong2 *>(slots) + desc[c].out_off;
+    ulonglong2 *d = reinterpret_cast<ulonglong2 *>(dst) + off[c];
+    for (uint32_t i = threadIdx.x & 63; i < cnt; i += 64) d[i] = s[i];
+}
+// counts with the fallback marker read as 0 (input of the scan); counts[n] (the flag word's place) = 0 as the scan's sentinel
+__global__ void small_counts_kernel(const uint32_t *__restrict__ counts, uint32_t n, uint32_t *__restrict__ clean) {
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > n) return;
+    clean[c] = (c == n || counts[c] == SMALL_FALLBACK) ? 0u : counts[c];
+}
+void launch_small_counts(hipStream_t st, const uint32_t *counts, uint32_t n, uint32_t *clean) {
+    hipLaunchKernelGGL(small_counts_kernel, dim3((n + 1 + 255) / 256), dim3(256), 0, st, counts, n, clean);
+}
+void launch_small_gather(hipStream_t st, const pgr_mm128 *slots, const SmallContig *desc, const uint32_t *counts, const uint64_t *off,
+                         uint32_t n, pgr_mm128 *dst, uint64_t dst_cap) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(small_gather_kernel, dim3((n + 3) / 4), dim3(256), 0, st, slots, desc, counts, off, n, dst, dst_cap);
 }
 
 }  // namespace pgr

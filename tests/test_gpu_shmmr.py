@@ -23,18 +23,26 @@ def _assert_same(ref, got, what=""):
 def _check_batch(oracle, gpu_ctx, seqs, spec_t, padding=False, rids=None, what=""):
     import pgrtk_amd as P
     w, k, r, ms, sk = spec_t
-    # the host entry point (batches of short clean contigs take the one-launch kernel of csrc/small.hip, everything else the
-    # general pipeline) AND the resident path (always the general pipeline): both must equal the oracle
+    # three routes to the same answer: the host entry point and the resident path (batches of short clean contigs take the
+    # one-workgroup-per-contig kernel of csrc/small.hip there, everything else the general pipeline), and the resident path
+    # with that kernel switched off (always the general pipeline: tiles, tails, islands, fused list stage)
     got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding, ctx=gpu_ctx)
-    res = P.Batch.from_seqs(seqs, ctx=gpu_ctx).shmmrs(P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding)
-    mm, off = res.download()
+    batch = P.Batch.from_seqs(seqs, ctx=gpu_ctx)
+    mm, off = batch.shmmrs(P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding).download()
+    os.environ["PGR_NO_SMALL_PATH"] = "1"
+    try:
+        mm_g, off_g = batch.shmmrs(P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding).download()
+    finally:
+        del os.environ["PGR_NO_SMALL_PATH"]
     osp = oracle.spec(w, k, r, ms, sk)
-    assert len(got) == len(seqs) and len(off) == len(seqs) + 1
+    assert len(got) == len(seqs) and len(off) == len(seqs) + 1 == len(off_g)
     for i, s in enumerate(seqs):
         rid = i if rids is None else rids[i]
         ref = oracle.sequence_to_shmmrs(rid, s, osp, padding)
-        _assert_same(ref, got[i], "%s seq %d (len %d) spec %s pad %s" % (what, i, len(s), spec_t, padding))
-        _assert_same(ref, mm[int(off[i]):int(off[i + 1])], "%s (resident path) seq %d (len %d) spec %s pad %s" % (what, i, len(s), spec_t, padding))
+        tag = "seq %d (len %d) spec %s pad %s" % (i, len(s), spec_t, padding)
+        _assert_same(ref, got[i], "%s %s" % (what, tag))
+        _assert_same(ref, mm[int(off[i]):int(off[i + 1])], "%s (resident) %s" % (what, tag))
+        _assert_same(ref, mm_g[int(off_g[i]):int(off_g[i + 1])], "%s (general pipeline) %s" % (what, tag))
     return got
 
 
