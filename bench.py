@@ -391,6 +391,8 @@ def latency_bench(P, ctx, spec, args):
         return ts[len(ts) // 2] * 1e3, ts[len(ts) // 10] * 1e3
     m1, p1 = med(lambda: P.time_shmmr_batch(one, spec, ctx=ctx))
     m1py, p1py = med(lambda: P.sequence_to_shmmrs_batch(one, spec, ctx=ctx))
+    many = P.PackedSeqs.from_list([synth_contig_ascii(args.seed, c, 10_000) for c in range(129)])  # seq_db.rs:561: 129 contigs per batch
+    m129, p129 = med(lambda: P.time_shmmr_batch(many, spec, ctx=ctx))
     # single 10 kbp query against an index of 8 x 1 Mbp
     b = P.Batch.synthetic([1_000_000] * 8, seed=args.seed, ctx=ctx)
     ix = P.Index(spec, ctx=ctx)
@@ -400,7 +402,10 @@ def latency_bench(P, ctx, spec, args):
     m2, p2 = med(lambda: ix.time_query_host(q, 0.025))
     m2py, p2py = med(lambda: ix.query_hps_raw(q, 0.025))
     return {"shmmr_batch_one_10kbp_contig_ms": {"median": m1, "p10": p1, "with_python_unpacking": {"median": m1py, "p10": p1py}},
+            "shmmr_batch_129_x_10kbp_contigs_ms": {"median": m129, "p10": p129},
             "query_hps_batch_one_10kbp_query_ms": {"median": m2, "p10": p2, "with_python_unpacking": {"median": m2py, "p10": p2py}},
+            "path": "batches of short clean contigs: one kernel launch + one synchronization (csrc/small.hip, one workgroup per contig; "
+                    "round 2: ~15 dependent device operations, 0.13 ms for one 10 kbp contig)",
             "note": "host ASCII in, host result out: the C entry point + release of the result, called through ctypes; "
                     "with_python_unpacking adds the binding's copies into numpy arrays; index of 8 x 1 Mbp for the query"}
 

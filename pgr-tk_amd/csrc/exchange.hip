@@ -47,9 +47,16 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
-        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        // a copy that is already in the process (PyTorch loads its own librccl.so) is taken first: two RCCL instances in one
+        // process would each keep their own communicators, topology state and IPC handles on the same GPUs
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            r.handle = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
             if (r.handle) break;
+        }
+        if (!r.handle && dlsym(RTLD_DEFAULT, "ncclCommInitRank")) r.handle = dlopen(nullptr, RTLD_NOW);  // linked into the host program
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (r.handle) break;
+            r.handle = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!r.handle) {
             r.err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?");
