@@ -70,8 +70,10 @@ __global__ void unsorted_flag_kernel(const pgr_frag_rec *__restrict__ recs, uint
         // flag[1]: not already in full (h0, h1, sid, frg_id) order (concatenated sorted key ranges need no sort at all)
         bad_key = a.h0 > b.h0 || (a.h0 == b.h0 && (a.h1 > b.h1 || (a.h1 == b.h1 && id_gt)));
     }
-    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
-    if (__ballot(bad_key) && (threadIdx.x & 63) == 0) atomicOr(flag + 1, 1u);
+    // (records that are not in key order flag nearly every wavefront: one same-address atomic per wavefront would cost
+    // milliseconds -- ~88 per microsecond on gfx950 -- so a wavefront that already sees the flag set leaves it alone)
+    if (__ballot(bad) && (threadIdx.x & 63) == 0 && flag[0] == 0) atomicOr(flag, 1u);
+    if (__ballot(bad_key) && (threadIdx.x & 63) == 0 && flag[1] == 0) atomicOr(flag + 1, 1u);
 }
 
 __global__ void gather_recs_kernel(const pgr_frag_rec *__restrict__ in, const uint32_t *__restrict__ idx,
