@@ -95,10 +95,19 @@ void pgr_ctx::dfree(void *p) {
     }
     const size_t bytes = it->second;
     live_blocks.erase(it);
-    // keep at most 64 GiB cached (288 GB of HBM3E per GPU)
-    if (cached_bytes + bytes > (64ull << 30)) {
+    // keep at most 160 GiB cached (288 GB of HBM3E per GPU; a failing hipMalloc drops the cache and retries).  Beyond that
+    // the smallest cached blocks make room: hipFree synchronizes the device, so a full cache that frees every incoming
+    // block (round 2) turned a streaming index build into a chain of device-wide stalls
+    const size_t CAP = 160ull << 30;
+    if (bytes > CAP) {
         (void)hipFree(p);
         return;
+    }
+    while (cached_bytes + bytes > CAP && !free_blocks.empty()) {
+        auto it2 = free_blocks.begin();
+        (void)hipFree(it2->second);
+        cached_bytes -= it2->first;
+        free_blocks.erase(it2);
     }
     free_blocks.emplace(bytes, p);
     cached_bytes += bytes;

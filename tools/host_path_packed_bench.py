@@ -52,5 +52,7 @@ for name, f in (("pgr_shmmr_batch (ASCII)", lambda: P.time_shmmr_batch(seqs, sp,
     print("%-40s %7.2f ms = %6.1f Gbp/s" % (name, ts[1] * 1e3, bp / ts[1] / 1e9))
 sys.stdout.flush()
 os.environ["PGR_DEBUG"] = "1"
-print("--- timeline of one pipelined packed call", flush=True)
-P.time_shmmr_batch_packed(packed, sp, ctx=ctx)
+print("--- timeline of one pipelined packed call (planes only)", flush=True)
+P.time_shmmr_batch_packed(bare, sp, ctx=ctx)
+print("--- timeline of one pipelined ASCII call", flush=True)
+P.time_shmmr_batch(seqs, sp, ctx=ctx)
