@@ -72,6 +72,8 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     e = hipSetDevice(device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->d2h_ev[i], hipEventDisableTiming);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->cev[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
@@ -96,6 +98,9 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     if (ctx->ev_alloc) (void)hipEventDestroy(ctx->ev_alloc);
     for (auto &ev : ctx->cev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->d2h_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -1589,6 +1594,33 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
     const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    // The download of sub-batch i runs on its own stream while sub-batch i + 1 computes: its list goes to one of two pinned
+    // blocks asynchronously, the host copies it out (pool threads) when the next compute call has returned.
+    struct Pending {
+        pgr_shmmrs *s = nullptr;
+        uint64_t dst = 0;  // first element in mm
+        int slot = 0;
+    } pend;
+    int slot = 0;
+    auto finish_pending = [&]() -> int {
+        if (!pend.s) return PGR_OK;
+        pgr_shmmrs *ps = pend.s;
+        pend.s = nullptr;
+        int r = PGR_OK;
+        if (hipEventSynchronize(ctx->d2h_ev[pend.slot]) != hipSuccess) r = ctx->fail(PGR_ERR_DEVICE, "result download failed");
+        if (!r && ps->count) {
+            const uint8_t *srcp = (const uint8_t *)ctx->pinned_out + (size_t)pend.slot * ctx->d2h_slot_bytes;
+            uint8_t *dstp = (uint8_t *)(mm + pend.dst);
+            const size_t len = ps->count * sizeof(pgr_mm128);
+            constexpr size_t PIECE = 1u << 20;
+            HostPool::instance().parallel_for((len + PIECE - 1) / PIECE, [&](size_t i) {
+                const size_t o = i * PIECE;
+                memcpy(dstp + o, srcp + o, std::min(PIECE, len - o));
+            });
+        }
+        pgr_shmmrs_destroy(ps);
+        return r;
+    };
     int rc = for_each_staged(ctx, n, src, [&](pgr_batch *b, uint32_t c0, uint32_t c1) -> int {
         pgr_shmmrs *s = nullptr;
         const auto t0 = std::chrono::steady_clock::now();
@@ -1598,6 +1630,10 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
             fprintf(stderr, "[pgr]     compute %.2f ms (%.1f Mbp, %llu shimmers)\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), b->total_bases / 1e6,
                     (unsigned long long)s->count);
+        if ((r = finish_pending())) {  // (before mm may move)
+            pgr_shmmrs_destroy(s);
+            return r;
+        }
         if (total + s->count > cap) {
             // the first sub-batch predicts the rest (shimmer density is a property of the spec)
             uint64_t guess = cap + cap / 2;
@@ -1615,15 +1651,42 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
             mm = nm;
         }
         first = false;
-        if (s->count && (r = ctx->d2h(mm + total, s->d_mm, s->count * sizeof(pgr_mm128)))) {
-            pgr_shmmrs_destroy(s);
-            return r;
-        }
         for (uint32_t c = c0; c < c1; ++c) off[c] = total + s->h_off[c - c0];
+        const size_t bytes = s->count * sizeof(pgr_mm128);
+        // two pinned blocks of the largest sub-batch result seen so far (growing them waits for nothing: none is pending here)
+        if (bytes > ctx->d2h_slot_bytes || !ctx->pinned_out) {
+            const size_t want = std::max<size_t>(bytes + bytes / 4, 1u << 20);
+            if ((r = ctx->ensure_pinned_out(2 * want))) {
+                pgr_shmmrs_destroy(s);
+                return r;
+            }
+            ctx->d2h_slot_bytes = ctx->pinned_out_cap / 2;
+        }
+        if (bytes) {
+            if (hipMemcpyAsync((uint8_t *)ctx->pinned_out + (size_t)slot * ctx->d2h_slot_bytes, s->d_mm, bytes, hipMemcpyDeviceToHost,
+                               ctx->d2h_stream) != hipSuccess) {
+                pgr_shmmrs_destroy(s);
+                return ctx->fail(PGR_ERR_DEVICE, "result download failed");
+            }
+        }
+        if (hipEventRecord(ctx->d2h_ev[slot], ctx->d2h_stream) != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->d2h_stream);
+            pgr_shmmrs_destroy(s);
+            return ctx->fail(PGR_ERR_DEVICE, "event record failed");
+        }
+        pend.s = s;
+        pend.dst = total;
+        pend.slot = slot;
+        slot ^= 1;
         total += s->count;
-        pgr_shmmrs_destroy(s);
         return PGR_OK;
     });
+    if (!rc) rc = finish_pending();
+    if (pend.s) {  // an error left a download in flight
+        (void)hipStreamSynchronize(ctx->d2h_stream);
+        pgr_shmmrs_destroy(pend.s);
+        pend.s = nullptr;
+    }
     if (rc) {
         free(mm);
         free(off);

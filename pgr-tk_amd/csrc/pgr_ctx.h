@@ -49,6 +49,10 @@ struct pgr_ctx {
     // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`
     hipStream_t copy_stream = nullptr;
     hipEvent_t cev[2] = {nullptr, nullptr};
+    // third stream + events: the result of sub-batch i goes to the host while sub-batch i + 1 computes (pipelined host calls)
+    hipStream_t d2h_stream = nullptr;
+    hipEvent_t d2h_ev[2] = {nullptr, nullptr};
+    size_t d2h_slot_bytes = 0;  // half of pinned_out when the pipelined download uses it as two blocks
 
     // workspaces
     pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
