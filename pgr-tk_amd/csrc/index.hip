@@ -58,22 +58,46 @@ __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint
     keys[i] = k;
 }
 
-// does the append order already follow (sid, frg_id)?  (contigs indexed in sid order, their pairs in position order: the
-// usual case) -- then the stable sort by the key alone leaves the records of a key in the order seq_db.rs:605-612 gives
-__global__ void unsorted_flag_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n, uint32_t *__restrict__ flag) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+// one pass over the appended records (grid-stride, a few thousand workgroups: one atomic per workgroup and statistic):
+// stats[0] |= 1 not in (sid, frg_id) append order, stats[1] |= 1 not already in (h0, h1, sid, frg_id) order,
+// stats[2] = max(sid) + 1, stats[3] = max(h1) (h0 <= h1: bounds the radix passes of both key fields)
+__global__ __launch_bounds__(256) void raw_stats_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n,
+                                                        unsigned long long *__restrict__ stats) {
     bool bad = false, bad_key = false;
-    if (i + 1 < n) {
-        const pgr_frag_rec &a = recs[i], &b = recs[i + 1];
-        const bool id_gt = a.sid > b.sid || (a.sid == b.sid && a.frg_id > b.frg_id);
-        bad = id_gt;
-        // flag[1]: not already in full (h0, h1, sid, frg_id) order (concatenated sorted key ranges need no sort at all)
-        bad_key = a.h0 > b.h0 || (a.h0 == b.h0 && (a.h1 > b.h1 || (a.h1 == b.h1 && id_gt)));
+    unsigned long long msid = 0, mh = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const pgr_frag_rec a = recs[i];
+        msid = umax64(msid, (unsigned long long)a.sid + 1ull);
+        mh = umax64(mh, a.h1);
+        if (i + 1 < n) {
+            const pgr_frag_rec &b = recs[i + 1];
+            const bool id_gt = a.sid > b.sid || (a.sid == b.sid && a.frg_id > b.frg_id);
+            bad = bad || id_gt;
+            bad_key = bad_key || a.h0 > b.h0 || (a.h0 == b.h0 && (a.h1 > b.h1 || (a.h1 == b.h1 && id_gt)));
+        }
     }
-    // (records that are not in key order flag nearly every wavefront: one same-address atomic per wavefront would cost
-    // milliseconds -- ~88 per microsecond on gfx950 -- so a wavefront that already sees the flag set leaves it alone)
-    if (__ballot(bad) && (threadIdx.x & 63) == 0 && flag[0] == 0) atomicOr(flag, 1u);
-    if (__ballot(bad_key) && (threadIdx.x & 63) == 0 && flag[1] == 0) atomicOr(flag + 1, 1u);
+    __shared__ unsigned long long s_sid[4], s_h[4];
+    __shared__ uint32_t s_bad[2];
+    if (threadIdx.x < 2) s_bad[threadIdx.x] = 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        msid = umax64(msid, shfl_xor64(msid, d));
+        mh = umax64(mh, shfl_xor64(mh, d));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+        s_sid[threadIdx.x >> 6] = msid;
+        s_h[threadIdx.x >> 6] = mh;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) s_bad[0] = 1;      // (benign race: all writers store 1)
+    if (__ballot(bad_key) && (threadIdx.x & 63) == 0) s_bad[1] = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMax(stats + 2, umax64(umax64(s_sid[0], s_sid[1]), umax64(s_sid[2], s_sid[3])));
+        atomicMax(stats + 3, umax64(umax64(s_h[0], s_h[1]), umax64(s_h[2], s_h[3])));
+        if (s_bad[0]) atomicOr(stats, 1ull);
+        if (s_bad[1]) atomicOr(stats + 1, 1ull);
+    }
 }
 
 __global__ void gather_recs_kernel(const pgr_frag_rec *__restrict__ in, const uint32_t *__restrict__ idx,
@@ -90,17 +114,6 @@ __global__ void key_flags_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t
         return;
     }
     flags[i] = (i == 0 || recs[i].h0 != recs[i - 1].h0 || recs[i].h1 != recs[i - 1].h1) ? 1u : 0u;
-}
-
-// max(sid) + 1 over the records (bounds the target half of the hit-group keys: fewer radix passes per query batch)
-__global__ __launch_bounds__(256) void sid_bound_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n,
-                                                        unsigned long long *__restrict__ out) {
-    unsigned long long m = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
-        m = umax64(m, (unsigned long long)recs[i].sid + 1ull);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) m = umax64(m, shfl_xor64(m, d));
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
 }
 
 // keys[i] = (h0, h1) of key i
@@ -398,22 +411,28 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)))
         return rc;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
-    // records appended in (sid, frg_id) order need only the two key passes of the stable LSD sort (64 of 176 key bits less)
-    Tmp d_unsorted(ctx);
-    if ((rc = d_unsorted.alloc(16))) return rc;
-    uint32_t unsorted[2] = {1, 1};
-    PGR_HIP(ctx, hipMemsetAsync(d_unsorted.p, 0, 16, st));
-    hipLaunchKernelGGL(unsorted_flag_kernel, grid_for(n), dim3(256), 0, st, ix->raw, n, d_unsorted.as<uint32_t>());
-    PGR_HIP(ctx, hipMemcpyAsync(unsorted, d_unsorted.p, 8, hipMemcpyDeviceToHost, st));
+    // one look at the appended records: append order, key order, largest sid, largest hash
+    //   records appended in (sid, frg_id) order need only the two key passes of the stable LSD sort (64 of 176 key bits less);
+    //   records already in full key order (concatenated key-range shards, csrc/exchange.hip) need no sort at all;
+    //   the largest hash bounds the radix passes (shimmer hashes are minima of minima: a few bits below 2^56)
+    Tmp d_stats(ctx);
+    if ((rc = d_stats.alloc(32))) return rc;
+    uint64_t stats[4] = {1, 1, 0, 0};
+    PGR_HIP(ctx, hipMemsetAsync(d_stats.p, 0, 32, st));
+    hipLaunchKernelGGL(raw_stats_kernel, dim3((uint32_t)std::min<uint64_t>(2048, (n + 255) / 256)), dim3(256), 0, st, ix->raw, n,
+                       d_stats.as<unsigned long long>());
+    PGR_HIP(ctx, hipMemcpyAsync(stats, d_stats.p, 32, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
+    ix->sid_bound = stats[2];
     const bool full_sort = getenv("PGR_INDEX_FULL_SORT") != nullptr;
-    if (!unsorted[1] && !full_sort) {
-        // already in (h0, h1, sid, frg_id) order: the concatenation of finalized key-range shards (csrc/exchange.hip)
+    if (!stats[1] && !full_sort) {
+        // already in (h0, h1, sid, frg_id) order
         PGR_HIP(ctx, hipMemcpyAsync(ix->recs, ix->raw, n * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, st));
     } else {
+        const unsigned hb = full_sort ? 56u : std::max(1u, std::min(56u, bits_for(stats[3] + 1)));
         const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
-        const unsigned bits[4] = {32, 32, 56, 56};
-        const int skip = (unsorted[0] || full_sort) ? 0 : 2;
+        const unsigned bits[4] = {32, 32, hb, hb};
+        const int skip = (stats[0] || full_sort) ? 0 : 2;
         if ((rc = sort_perm(ctx, ix->raw, n, fields + skip, bits + skip, 4 - skip, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
                             keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
             return rc;
@@ -425,16 +444,9 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     const size_t tb = scan_counts_temp_bytes((uint32_t)(n + 1));
     if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb))) return rc;
     PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, flags.as<uint32_t>(), rank.as<uint64_t>(), (uint32_t)(n + 1)));
-    Tmp d_bound(ctx);
-    if ((rc = d_bound.alloc(16))) return rc;
-    PGR_HIP(ctx, hipMemsetAsync(d_bound.p, 0, 16, st));
-    hipLaunchKernelGGL(sid_bound_kernel, dim3((uint32_t)std::min<uint64_t>(1024, (n + 255) / 256)), dim3(256), 0, st, ix->recs, n,
-                       d_bound.as<unsigned long long>());
-    uint64_t n_keys = 0, sid_bound = 0;
+    uint64_t n_keys = 0;
     PGR_HIP(ctx, hipMemcpyAsync(&n_keys, rank.as<uint64_t>() + n, 8, hipMemcpyDeviceToHost, st));
-    PGR_HIP(ctx, hipMemcpyAsync(&sid_bound, d_bound.p, 8, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
-    ix->sid_bound = sid_bound;
     if ((rc = ctx->dmalloc((void **)&ix->key_off, (n_keys + 1) * sizeof(uint64_t)))) return rc;
     hipLaunchKernelGGL(scatter_starts_kernel, grid_for(n + 1), dim3(256), 0, st, flags.as<uint32_t>(),
                        rank.as<uint64_t>(), n, ix->key_off);
