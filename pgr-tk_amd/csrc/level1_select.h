@@ -13,6 +13,10 @@
 #define PGR_TILE_V2 1  // 1: round-2 instruction selection (strand select from SGPR lane masks, multiplications in the hash,
                        //    window-row minima folded into the prefix chains); 0: the round-1 code, kept for A/B timing
 #endif
+#ifndef PGR_TILE_V3
+#define PGR_TILE_V3 1  // 1: round-3 instruction selection on top of V2 (canonical low plane by v_min_f64, key mask folded into a
+                       //    v_bitop3_b32); 0: the round-2 code, kept for A/B timing
+#endif
 #ifndef PGR_KEY_NOEXP
 #define PGR_KEY_NOEXP PGR_TILE_V2  // 1: window keys are the bare 56-bit hash read as a (possibly denormal) non-negative double
 #endif
@@ -239,13 +243,33 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488): one compare into an SGPR lane
         // mask, four selects from it, and the strand bit shifted into the per-lane word by an add-with-carry
         const uint64_t rev = cmp_lt_u64(r0, f0);
+#if PGR_TILE_V3
+        // the canonical low plane is min(f0, r0) (reverse iff r0 < f0, and equal planes are the same either way): both are k <= 56
+        // bit patterns, i.e. non-negative finite doubles ordered like the integers (denormals preserved) -- ONE v_min_f64
+        // (4.2 cycles) instead of two selects (8.3)
+        const uint64_t m0 = (uint64_t)__double_as_longlong(dmin(__longlong_as_double((long long)f0), __longlong_as_double((long long)r0)));
+        const uint32_t m0l = (uint32_t)m0, m0h = (uint32_t)(m0 >> 32);
+#else
         const uint32_t m0l = sel(rev, (uint32_t)r0, (uint32_t)f0), m0h = sel(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
+#endif
         const uint32_t m1l = sel(rev, (uint32_t)r1, (uint32_t)f1), m1h = sel(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
         uint32_t m1x = m1l ^ 0xAD12CF59u;
         asm("" : "+v"(m1x));  // keep the constant out of the hash's first step (the optimiser would distribute it)
+#if PGR_TILE_V3 && PGR_KEY_NOEXP
+        // h = A ^ B is only needed as the 56-bit key (the sketch threshold aside): low word one v_xor, high word
+        // (Ahi ^ Bhi) & 0x00FFFFFF as ONE v_bitop3_b32 (3.65 cycles; v_xor + v_and: 4.9)
+        const uint64_t hA = u64hash_mad(((uint64_t)m0h << 32) | m0l), hB = u64hash_mad(((uint64_t)m1h << 32) | m1x);
+        const uint64_t h = SKETCH ? (hA ^ hB) : 0ull;
+        uint32_t key_hi;
+        asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(key_hi) : "v"((uint32_t)(hA >> 32)), "v"((uint32_t)(hB >> 32)), "s"(0x00FFFFFFu));
+        shift_in_mask(strand_rev, rev);  // position u ends up at bit 15 - u
+        const uint64_t key = ((uint64_t)key_hi << 32) | ((uint32_t)hA ^ (uint32_t)hB);
+#else
         const uint64_t h = u64hash_mad(((uint64_t)m0h << 32) | m0l) ^ u64hash_mad(((uint64_t)m1h << 32) | m1x);
         shift_in_mask(strand_rev, rev);  // position u ends up at bit 15 - u
-#if PGR_KEY_NOEXP
+#endif
+#if PGR_TILE_V3 && PGR_KEY_NOEXP
+#elif PGR_KEY_NOEXP
         // the 56-bit hash itself is a non-negative double (denormal when bits 52-55 are clear: f64 denormals are preserved,
         // .amdhsa_float_denorm_mode_16_64 3), ordered like the integer: no exponent bit to or in (one 2.4-cycle v_and instead
         // of a 4.2-cycle v_and_or per position).  "No window" is -inf instead of +0 so that a key of 0 stays exact.
