@@ -212,33 +212,54 @@ __global__ __launch_bounds__(64) void level1_tail_kernel(L1Args a) {
         s_st[i] = st;
     }
     __syncthreads();
-    // every lane runs the same (uniform) tiny machine; lane 0 records the emissions
+    // The tiny machine, wave-parallel: every lane keeps its (at most 4) elements i = lane + 64 q in registers, the state
+    // (mdist, n_emit) is wave-uniform, a rescan is one min-reduction + one ballot per slice instead of two serial walks over the
+    // window in LDS (~20 us of dependent LDS latency per contig -- 10 000 queries or 10^6 reads feel that).
     int n_emit = 0;
     {
-        uint64_t mn = U64MAX;
-        int mi = 0;
-        for (int i = 0; i < (int)w; ++i) {
-            const uint64_t v = s_x[i];
-            if (v <= mn) {  // right-most arg-min of the window ending at jend
-                mn = v;
-                mi = i;
-            }
+        uint64_t xq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (int)lane + 64 * q;
+            xq[q] = i < n ? s_x[i] : U64MAX;
         }
+        const uint64_t lt = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+        auto window_min = [&](int lo2, int hi2) {
+            uint64_t v = U64MAX;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = (int)lane + 64 * q;
+                if (i >= lo2 && i <= hi2) v = umin64(v, xq[q]);
+            }
+            return wave_min64(v);
+        };
+        // elements of [lo2, hi2] equal to m2, in index order: recorded when `record`; returns the index of the last one
+        auto equal_to = [&](int lo2, int hi2, uint64_t m2, bool record) {
+            int last = lo2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = (int)lane + 64 * q;
+                const bool e = i >= lo2 && i <= hi2 && xq[q] == m2;
+                const uint64_t bal = __ballot(e);
+                if (bal == 0) continue;
+                if (record) {
+                    const int pos = n_emit + (int)__popcll(bal & lt);
+                    if (e && pos < 256) s_emit[pos] = (uint32_t)i;
+                    n_emit = n_emit + (int)__popcll(bal) > 256 ? 256 : n_emit + (int)__popcll(bal);
+                }
+                last = 64 * q + 63 - (int)__clzll((long long)bal);
+            }
+            return last;
+        };
+        // right-most arg-min of the window ending at jend
+        const uint64_t mn = window_min(0, (int)w - 1);
+        const int mi = equal_to(0, (int)w - 1, mn, false);
         int mdist = (int)w - 1 - mi;
         for (int j = (int)w; j < n; ++j) {
             if (mdist == (int)w - 1) {
                 const int wl = j - (int)w + 1;
-                uint64_t m2 = U64MAX;
-                for (int i = wl; i <= j; ++i) m2 = umin64(m2, s_x[i]);
-                int last = wl;
-                for (int i = wl; i <= j; ++i) {
-                    if (s_x[i] == m2) {
-                        if (lane == 0 && n_emit < 256) s_emit[n_emit] = (uint32_t)i;
-                        if (n_emit < 256) ++n_emit;
-                        last = i;
-                    }
-                }
-                mdist = j - last;
+                const uint64_t m2 = window_min(wl, j);
+                mdist = j - equal_to(wl, j, m2, true);
             } else {
                 ++mdist;
             }

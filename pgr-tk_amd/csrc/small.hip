@@ -235,34 +235,52 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
             s_st[i] = st;
         }
         __syncthreads();
-        if (t < 64) {  // every lane of the wavefront runs the same tiny machine; lane 0 records
+        if (t < 64) {  // the tiny machine, wave-parallel exactly as in level1_tail_kernel (level1.hip)
             int n_emit = 0;
-            uint64_t mn = U64MAX;
-            int mi = 0;
-            for (int i = 0; i < (int)w; ++i) {
-                const uint64_t v = s_x[i];
-                if (v <= mn) {
-                    mn = v;
-                    mi = i;
+            {
+                uint64_t xq[4];
+#pragma unroll
+                for (int q2 = 0; q2 < 4; ++q2) {
+                    const int i = (int)t + 64 * q2;
+                    xq[q2] = i < n ? s_x[i] : U64MAX;
                 }
-            }
-            int mdist = (int)w - 1 - mi;
-            for (int j = (int)w; j < n; ++j) {
-                if (mdist == (int)w - 1) {
-                    const int wl = j - (int)w + 1;
-                    uint64_t m2 = U64MAX;
-                    for (int i = wl; i <= j; ++i) m2 = umin64(m2, s_x[i]);
-                    int last = wl;
-                    for (int i = wl; i <= j; ++i) {
-                        if (s_x[i] == m2) {
-                            if (t == 0 && n_emit < 256) s_emit[n_emit] = (uint32_t)i;
-                            if (n_emit < 256) ++n_emit;
-                            last = i;
-                        }
+                const uint64_t lt = (t == 0) ? 0ull : (U64MAX >> (64 - t));
+                auto window_min = [&](int lo2, int hi2) {
+                    uint64_t v = U64MAX;
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const int i = (int)t + 64 * q2;
+                        if (i >= lo2 && i <= hi2) v = umin64(v, xq[q2]);
                     }
-                    mdist = j - last;
-                } else {
-                    ++mdist;
+                    return wave_min64(v);
+                };
+                auto equal_to = [&](int lo2, int hi2, uint64_t m2, bool record) {
+                    int last = lo2;
+#pragma unroll
+                    for (int q2 = 0; q2 < 4; ++q2) {
+                        const int i = (int)t + 64 * q2;
+                        const bool e = i >= lo2 && i <= hi2 && xq[q2] == m2;
+                        const uint64_t bal = __ballot(e);
+                        if (bal == 0) continue;
+                        if (record) {
+                            const int pos = n_emit + (int)__popcll(bal & lt);
+                            if (e && pos < 256) s_emit[pos] = (uint32_t)i;
+                            n_emit = n_emit + (int)__popcll(bal) > 256 ? 256 : n_emit + (int)__popcll(bal);
+                        }
+                        last = 64 * q2 + 63 - (int)__clzll((long long)bal);
+                    }
+                    return last;
+                };
+                const uint64_t mn = window_min(0, (int)w - 1);
+                int mdist = (int)w - 1 - equal_to(0, (int)w - 1, mn, false);
+                for (int j = (int)w; j < n; ++j) {
+                    if (mdist == (int)w - 1) {
+                        const int wl = j - (int)w + 1;
+                        const uint64_t m2 = window_min(wl, j);
+                        mdist = j - equal_to(wl, j, m2, true);
+                    } else {
+                        ++mdist;
+                    }
                 }
             }
             const uint32_t base = L.n1;
