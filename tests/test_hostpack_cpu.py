@@ -73,3 +73,23 @@ def test_pack_ascii_scalar_path_matches_too():
             "t.check(P); print('ok')") % (os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_shard_splitters_are_quantiles_of_the_pooled_sample():
+    """pgr_shard_splitters (host only): world - 1 ascending splitters at the quantiles of the pooled samples, the same from any
+    order of the pool; a record's rank = number of splitters <= its first hash"""
+    sys.path.insert(0, os.path.join(ROOT, "pgr-tk_amd"))
+    from pgrtk_amd import exchange
+    rng = np.random.default_rng(9)
+    pool = [rng.integers(0, 2 ** 50, n, dtype=np.uint64) for n in (4096, 100, 0, 4096)]
+    for world in (1, 2, 3, 8):
+        spl = exchange.shard_splitters(pool, world)
+        assert len(spl) == world - 1 and list(spl) == sorted(spl)
+        spl2 = exchange.shard_splitters(pool[::-1], world)
+        assert np.array_equal(spl, spl2)
+        allv = np.sort(np.concatenate(pool))
+        if world > 1:
+            dest = np.searchsorted(spl, allv, side="right")
+            sizes = np.bincount(dest, minlength=world)
+            assert sizes.max() - sizes.min() <= 2  # the pool itself is cut into equal parts
+    assert len(exchange.shard_splitters([np.zeros(0, dtype=np.uint64)], 4)) == 3  # empty pool: still world - 1 splitters
