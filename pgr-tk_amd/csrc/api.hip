@@ -89,8 +89,6 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
 
 extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     if (!ctx) return;
-    for (pgr_ctx *ax : ctx->aux) pgr_ctx_destroy(ax);
-    ctx->aux.clear();
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     ctx->release_all();

@@ -1614,11 +1614,15 @@ __global__ void sum_ranges_kernel(const uint64_t *__restrict__ lo, const uint64_
 }
 }  // namespace
 
-// B2 on a resident batch of queries (the H2D of the ASCII queries already happened: pgr_batch_from_ascii), on ONE context
-static int query_hps_resident_one(pgr_ctx *ctx, const pgr_index *ix, const pgr_batch *b, float penalty,
-                                  uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
-                                  uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
-                                  pgr_hps_result *out) {
+// B2 on a resident batch of queries (the H2D of the ASCII queries already happened: pgr_batch_from_ascii).
+// (Measured and rejected in round 3: cutting a 10 000-query batch into 2-4 parts that run concurrently on contexts of their own
+// -- own host threads, streams, workspaces, one shared index -- so that one part's host round trips hide behind the other's
+// kernels: 1.34 / 1.62 / 1.34 ms against 1.12 ms in one piece.  A part does not get faster by being smaller: its time is the
+// chain of ~45 dependent operations, and two such chains submitted from two threads slow each other down.)
+extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const pgr_batch *b, float penalty,
+                                      uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
+                                      uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
+                                      pgr_hps_result *out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix || !out || !b) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     memset(out, 0, sizeof(*out));
@@ -1738,159 +1742,6 @@ static int query_hps_resident_one(pgr_ctx *ctx, const pgr_index *ix, const pgr_b
     if (dbg)
         fprintf(stderr, "[pgr] query batch %u: shimmers %.2f ms, lookup+counts %.2f, hits+chain %.2f, result %.2f\n", n_queries,
                 qp.shmmr_ms, qp.lookup_ms, qp.chain_ms, qp.result_ms);
-    return rc;
-}
-
-// Big query batches are cut into parts that run CONCURRENTLY, each on a context of its own (own streams, workspaces and
-// allocator; created at first use and kept) driven by its own host thread, all reading the same index: a query batch is ~45
-// dependent device operations and 4 host round trips around < 1 ms of kernels that do not fill the chip, so one part's round
-// trips and launch gaps hide behind the other part's kernels.  Queries are independent (pgr-query.rs:135-138 maps over
-// them), the result is the concatenation of the parts' results.
-namespace {
-struct BatchView : pgr_batch {};  // contigs [c0, c1) of another batch: shares its device arrays, owns nothing
-
-void make_view(const pgr_batch *b, uint32_t c0, uint32_t c1, pgr_ctx *owner, BatchView &v) {
-    v.ctx = owner;
-    v.n = c1 - c0;
-    v.d = b->d;
-    v.d.word_off = b->d.word_off + c0;  // (absolute word offsets: the plane pointers stay the batch's)
-    v.d.len = b->d.len + c0;
-    v.d.n_invalid = b->d.n_invalid + c0;
-    v.h_word_off.assign(b->h_word_off.begin() + c0, b->h_word_off.begin() + c1 + 1);
-    v.h_len.assign(b->h_len.begin() + c0, b->h_len.begin() + c1);
-    v.total_bases = 0;
-    for (uint32_t c = c0; c < c1; ++c) v.total_bases += b->h_len[c];
-    v.total_words = b->h_word_off[c1] - b->h_word_off[c0];
-    v.host_saw_invalid = b->host_saw_invalid;
-}
-}  // namespace
-
-extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const pgr_batch *b, float penalty,
-                                      uint32_t max_count, uint32_t max_count_query, uint32_t max_count_target,
-                                      uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
-                                      pgr_hps_result *out) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!ix || !out || !b) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    unsigned parts = 1;
-    if (b->n >= 2048 && b->total_bases >= (16ull << 20)) parts = 2;
-    if (const char *e = getenv("PGR_QUERY_SPLIT")) parts = (unsigned)std::max(1, std::min(4, atoi(e)));
-    if (parts > b->n) parts = 1;
-    if (parts == 1 || b->ctx != ctx || !ix->finalized || max_aln_span == 0)
-        return query_hps_resident_one(ctx, ix, b, penalty, max_count, max_count_query, max_count_target, max_aln_span, has_max_gap,
-                                      max_gap, oriented, out);
-    memset(out, 0, sizeof(*out));
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
-    while (ctx->aux.size() + 1 < parts) {
-        pgr_ctx *ax = nullptr;
-        const int rc = pgr_ctx_create(ctx->device, &ax);
-        if (rc) return ctx->fail(rc, std::string("auxiliary context: ") + pgr_last_error(nullptr));
-        ctx->aux.push_back(ax);
-    }
-    // the batch may still be on its way to the GPU on this context's stream: the other contexts' streams wait for it
-    PGR_HIP(ctx, hipEventRecord(ctx->ev_alloc, ctx->stream));
-    for (unsigned p = 1; p < parts; ++p) PGR_HIP(ctx, hipStreamWaitEvent(ctx->aux[p - 1]->stream, ctx->ev_alloc, 0));
-    std::vector<BatchView> views(parts);
-    std::vector<pgr_hps_result> res(parts);
-    std::vector<int> rcs(parts, PGR_OK);
-    // parts of equal numbers of bases
-    std::vector<uint32_t> cut(parts + 1, b->n);
-    cut[0] = 0;
-    {
-        uint64_t acc = 0;
-        unsigned p = 1;
-        for (uint32_t c = 0; c < b->n && p < parts; ++c) {
-            acc += b->h_len[c];
-            if (acc * parts >= b->total_bases * p) cut[p++] = c + 1;
-        }
-    }
-    for (unsigned p = 0; p < parts; ++p) make_view(b, cut[p], cut[p + 1], p == 0 ? ctx : ctx->aux[p - 1], views[p]);
-    HostPool::instance().parallel_for(parts, [&](size_t p) {
-        pgr_ctx *c = p == 0 ? ctx : ctx->aux[p - 1];
-        rcs[p] = views[p].n ? query_hps_resident_one(c, ix, &views[p], penalty, max_count, max_count_query, max_count_target,
-                                                     max_aln_span, has_max_gap, max_gap, oriented, &res[p])
-                            : PGR_OK;
-        if (!views[p].n) memset(&res[p], 0, sizeof(res[p]));
-    }, parts);
-    int rc = PGR_OK;
-    for (unsigned p = 0; p < parts && !rc; ++p)
-        if (rcs[p]) rc = p == 0 ? rcs[p] : ctx->fail(rcs[p], ctx->aux[p - 1]->err);
-    // ---- one result: concatenate, offsets shifted
-    uint64_t nt = 0, nc = 0, nh = 0, nn = 0;
-    for (unsigned p = 0; p < parts; ++p) {
-        nt += res[p].n_targets;
-        nc += res[p].n_chains;
-        nh += res[p].n_hps;
-        nn += res[p].n_nonterminating;
-    }
-    auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
-    const size_t o_q = 0, o_tsid = up16(o_q + ((size_t)b->n + 1) * 8), o_toff = up16(o_tsid + nt * 4), o_cs = up16(o_toff + (nt + 1) * 8),
-                 o_coff = up16(o_cs + nc * 4), o_hps = up16(o_coff + (nc + 1) * 8), total = o_hps + nh * sizeof(pgr_hitpair) + 16;
-    uint8_t *blk = rc ? nullptr : (uint8_t *)host_result_alloc(total);
-    if (!rc && !blk) rc = ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
-    if (!rc) {
-        uint64_t *q_off = (uint64_t *)(blk + o_q), *t_off = (uint64_t *)(blk + o_toff), *c_off = (uint64_t *)(blk + o_coff);
-        uint32_t *t_sid = (uint32_t *)(blk + o_tsid);
-        float *c_score = (float *)(blk + o_cs);
-        pgr_hitpair *hps = (pgr_hitpair *)(blk + o_hps);
-        uint64_t bt = 0, bc = 0, bh = 0;
-        for (unsigned p = 0; p < parts; ++p) {
-            const pgr_hps_result &r = res[p];
-            const uint32_t nq = views[p].n;
-            for (uint32_t i = 0; i < nq; ++i) q_off[cut[p] + i] = (r.q_off ? r.q_off[i] : 0) + bt;
-            for (uint64_t i = 0; i < r.n_targets; ++i) t_off[bt + i] = r.t_off[i] + bc;
-            for (uint64_t i = 0; i < r.n_chains; ++i) c_off[bc + i] = r.c_off[i] + bh;
-            if (r.n_targets) memcpy(t_sid + bt, r.t_sid, r.n_targets * 4);
-            if (r.n_chains) memcpy(c_score + bc, r.c_score, r.n_chains * 4);
-            if (r.n_hps) {
-                const uint8_t *src = (const uint8_t *)r.hps;
-                uint8_t *dst = (uint8_t *)(hps + bh);
-                const size_t len = r.n_hps * sizeof(pgr_hitpair);
-                constexpr size_t PIECE = 1u << 20;
-                HostPool::instance().parallel_for((len + PIECE - 1) / PIECE, [&](size_t i) {
-                    memcpy(dst + i * PIECE, src + i * PIECE, std::min(PIECE, len - i * PIECE));
-                });
-            }
-            bt += r.n_targets;
-            bc += r.n_chains;
-            bh += r.n_hps;
-        }
-        q_off[b->n] = bt;
-        t_off[bt] = bc;
-        c_off[bc] = bh;
-        out->n_queries = b->n;
-        out->q_off = q_off;
-        out->n_targets = nt;
-        out->t_sid = t_sid;
-        out->t_off = t_off;
-        out->n_chains = nc;
-        out->c_score = c_score;
-        out->c_off = c_off;
-        out->n_hps = nh;
-        out->hps = hps;
-        out->n_nonterminating = nn;
-        out->_owner = blk;
-    }
-    pgr_query_prof qp = {};
-    for (unsigned p = 0; p < parts; ++p) {
-        const pgr_query_prof &q = (p == 0 ? ctx : ctx->aux[p - 1])->qprof;
-        if (!rcs[p] && views[p].n) {
-            qp.n_queries += q.n_queries;
-            qp.query_bases += q.query_bases;
-            qp.n_query_pairs += q.n_query_pairs;
-            qp.n_signatures += q.n_signatures;
-            qp.n_hits += q.n_hits;
-            qp.n_groups += q.n_groups;
-            qp.n_chains += q.n_chains;
-            qp.n_hps += q.n_hps;
-            qp.shmmr_ms = std::max(qp.shmmr_ms, q.shmmr_ms);
-            qp.lookup_ms = std::max(qp.lookup_ms, q.lookup_ms);
-            qp.chain_ms = std::max(qp.chain_ms, q.chain_ms);
-            qp.result_ms = std::max(qp.result_ms, q.result_ms);
-            qp.total_ms = std::max(qp.total_ms, q.total_ms);
-        }
-        pgr_hps_result_free(&res[p]);
-    }
-    ctx->qprof = qp;
     return rc;
 }
 

@@ -54,9 +54,6 @@ struct pgr_ctx {
     hipEvent_t d2h_ev[2] = {nullptr, nullptr};
     size_t d2h_slot_bytes = 0;  // half of pinned_out when the pipelined download uses it as two blocks
 
-    // contexts of the concurrently running parts of a big query batch (pgr_query_hps_resident); owned, created at first use
-    std::vector<pgr_ctx *> aux;
-
     // workspaces
     pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
         ws_scan_tmp, ws_list_a, ws_list_b, ws_off_a, ws_off_b, ws_blk_cnt, ws_blk_base, ws_start_rank, ws_rids,

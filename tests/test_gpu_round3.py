@@ -388,46 +388,3 @@ def test_small_call_latency_targets(gpu_ctx):
     print("one 10 kbp contig %.3f ms, 129 x 10 kbp %.3f ms" % (t1, t129))
     assert t1 < 0.09 and t129 < 0.3, (t1, t129)  # (measured: see bench.py latency; the assertion leaves room for a slow box)
 
-
-def test_query_batch_in_concurrent_parts_equals_one_part(oracle, gpu_ctx, monkeypatch):
-    """pgr_query_hps_resident cuts big query batches into parts that run concurrently on contexts of their own (their own host
-    threads, streams and workspaces, one shared index) and concatenates the results: 1, 2, 3 and 4 parts must give the same
-    flat result, and that result must be the oracle's (queries of different sizes, some without any hit, reverse complements)"""
-    import pgrtk_amd as P
-    rng = np.random.default_rng(12)
-    spec = P.make_spec()
-    contigs = [seqgen.rnd(rng, 400_000) for _ in range(6)]
-    ix = P.Index(spec, ctx=gpu_ctx)
-    ix.add_seqs(contigs)
-    ix.finalize()
-    oix = oracle.Index(oracle.spec())
-    for i, c in enumerate(contigs):
-        oix.add_seq(i, c)
-    oix.finalize()
-    queries = []
-    for i in range(45):
-        c = contigs[int(rng.integers(0, 6))]
-        a = int(rng.integers(0, 380_000))
-        q = c[a:a + int(rng.integers(2_000, 20_000))]
-        if i % 3 == 0:
-            q = seqgen.rc(q)
-        if i % 11 == 0:
-            q = seqgen.rnd(rng, 3_000)  # no hit at all
-        queries.append(q)
-    qb = P.Batch.from_seqs(queries, ctx=gpu_ctx)
-    results = {}
-    for parts in ("1", "2", "3", "4"):
-        monkeypatch.setenv("PGR_QUERY_SPLIT", parts)
-        results[parts] = ix.query_hps_resident_raw(qb, 0.025)
-        prof = gpu_ctx.last_query_prof()
-        assert prof["n_queries"] == len(queries) and prof["n_hps"] == len(results[parts]["hps"])
-    monkeypatch.delenv("PGR_QUERY_SPLIT")
-    for parts in ("2", "3", "4"):
-        for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps"):
-            assert np.array_equal(results["1"][k], results[parts][k]), (parts, k)
-    import bench
-    r = results["2"]
-    for qi, q in enumerate(queries):
-        want = [(sid, [(np.float32(sc).tobytes(), [tuple(h) for h in hps]) for sc, hps in chains])
-                for sid, chains in oix.query_fragment_to_hps(q, 0.025)]
-        assert bench.chains_of(r, qi) == want, qi
