@@ -50,8 +50,28 @@ if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
         # micro-kernels without any second-path instruction (profiles/r03_ubench: 4.17).
         t["valu2_wave_insts_per_launch"] = out[dom[0]]["SQ_ACTIVE_INST_VALU2"]["mean_per_launch"]
         t["gui_active_cycles_per_launch"] = out[dom[0]]["GRBM_GUI_ACTIVE"]["mean_per_launch"]
+    # the opcode histogram of the same build and the measured opcode costs live next to the counters (tools/isa_histogram.py,
+    # tools/ubench_table.py); bench.py follows these two keys
+    if os.path.exists(os.path.join(dst, "isa_histogram.json")):
+        t["isa_histogram"] = name + "/isa_histogram.json"
+    ub = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench", "valu_cycles.json")))
+    if ub:
+        t["valu_cycles"] = os.path.relpath(ub[-1], os.path.join(ROOT, "profiles"))
     json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(json.dumps(t))
+    # bench.json was written by the same gpurun command BEFORE these counters were summarized: its derived blocks (PMC traffic,
+    # VALU occupancy) were computed from the previous profile's counters.  Recompute them -- with bench.py's own function, from
+    # the launch time that run measured -- so that the line and the counters next to it belong to the same build.
+    if bench.get("roofline"):
+        sys.path.insert(0, ROOT)
+        import bench as bench_mod
+        r = bench["roofline"]
+        r["traffic"] = t["hbm_bytes_per_launch"]
+        vi = bench_mod.valu_issue(r["bp_per_launch"], r["avg_launch_ms"])
+        if vi:
+            r["valu_issue"] = vi
+        bench["derived_blocks"] = "roofline.traffic and roofline.valu_issue recomputed by tools/summarize_profile.py from the counters of this same profile run"
+        json.dump(bench, open(os.path.join(dst, "bench.json"), "w"))
 for row in csv.DictReader(open(os.path.join(dst, "kernel_stats.csv"))):
     if "pgr::" in row["Name"]:
         print("%-60s calls %3s avg %10.3f ms  %5s%%" % (row["Name"][:60], row["Calls"], float(row["AverageNs"]) / 1e6, row["Percentage"]))
