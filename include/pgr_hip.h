@@ -282,6 +282,10 @@ typedef struct {
     float chain_ms;  /* hit expansion, sort by (group, qb), sparse_aln, packing, download (2 round trips) */
     float result_ms; /* host assembly of the flat result                                                */
     float total_ms;
+    /* 0: one kernel per stage over the whole batch (any batch).  1: one wavefront per query does every stage behind the pair
+     * records (batches of short queries, csrc/query_fused.hip): lookup_ms and result_ms are 0, chain_ms holds that stage.   */
+    uint32_t path;
+    uint32_t _pad;
 } pgr_query_prof;
 int pgr_ctx_last_query_prof(const pgr_ctx *ctx, pgr_query_prof *out);
 

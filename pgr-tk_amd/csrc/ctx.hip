@@ -1,6 +1,9 @@
 // ctx.hip -- context memory management (workspaces, pinned staging, caching device allocator).
 #include <algorithm>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <unordered_map>
 #include <thread>
 #include <vector>
 
@@ -229,4 +232,72 @@ void pgr_ctx::release_all() {
     if (mailbox) (void)hipHostFree(mailbox);
     mailbox = nullptr;
     mailbox_cap = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pinned host blocks for results a kernel writes DIRECTLY into host memory (query_fused.hip): the block the library hands to
+// the caller IS the memory the GPU wrote over PCIe -- no staging copy, no second synchronization.  hipHostMalloc costs about a
+// millisecond, so released blocks are kept (process wide: a result may outlive its context) up to a cap.
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_by_cap;
+    std::unordered_map<void *, size_t> live;  // blocks handed out
+    size_t cached = 0;
+    static constexpr size_t CACHE_CAP = 1ull << 30;
+    static PinnedPool &instance() {
+        static PinnedPool *p = new PinnedPool();  // never destroyed: results may be released during process teardown
+        return *p;
+    }
+};
+}  // namespace
+
+void *pgr::pinned_result_acquire(size_t min_bytes, size_t *cap) {
+    PinnedPool &P = PinnedPool::instance();
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.free_by_cap.lower_bound(min_bytes);
+        if (it != P.free_by_cap.end() && it->first <= 4 * std::max<size_t>(min_bytes, 1u << 20)) {
+            void *p = it->second;
+            *cap = it->first;
+            P.cached -= it->first;
+            P.free_by_cap.erase(it);
+            P.live[p] = *cap;
+            return p;
+        }
+    }
+    size_t want = 1u << 20;
+    while (want < min_bytes) want <<= 1;
+    void *p = nullptr;
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> g(P.mu);
+    P.live[p] = want;
+    *cap = want;
+    return p;
+}
+
+void pgr::result_block_release(void *p) {
+    if (!p) return;
+    PinnedPool &P = PinnedPool::instance();
+    size_t cap = 0;
+    {
+        std::lock_guard<std::mutex> g(P.mu);
+        auto it = P.live.find(p);
+        if (it == P.live.end()) {
+            cap = 0;
+        } else {
+            cap = it->second;
+            P.live.erase(it);
+            if (P.cached + cap <= PinnedPool::CACHE_CAP) {
+                P.free_by_cap.emplace(cap, p);
+                P.cached += cap;
+                return;
+            }
+        }
+    }
+    if (cap) (void)hipHostFree(p);
+    else free(p);  // an ordinary host block (host_result_alloc)
 }

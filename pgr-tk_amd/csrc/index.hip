@@ -20,6 +20,7 @@
 
 #include "pgr_index.h"
 #include "pgr_device.h"
+#include "pgr_aln.h"
 
 using namespace pgr;
 
@@ -507,44 +508,8 @@ __global__ void lookup_kernel(const pgr_frag_rec *__restrict__ q, uint64_t nq, c
                               uint64_t *__restrict__ lo_out, uint64_t *__restrict__ hi_out) {
     const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= nq) return;
-    const uint64_t h0 = q[p].h0, h1 = q[p].h1;
-    uint64_t lo = 0, hi = n_keys;  // first key >= (h0,h1)
-    if (lut) {
-        const uint64_t top = (1ull << lut_bits) - 1;
-        const uint64_t bk = (h0 >> lut_shift) < top ? (h0 >> lut_shift) : top;
-        lo = lut[bk];
-        hi = lut[bk + 1];
-    }
-    uint64_t a = 0, b = 0;
-    if (keys) {  // the bucket's keys by themselves: one or two cache lines for the whole search
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            const ulonglong2 kk = keys[mid];
-            if (kk.x < h0 || (kk.x == h0 && kk.y < h1)) lo = mid + 1;
-            else hi = mid;
-        }
-        if (lo < n_keys) {
-            const ulonglong2 kk = keys[lo];
-            if (kk.x == h0 && kk.y == h1) {
-                a = key_off[lo];
-                b = key_off[lo + 1];
-            }
-        }
-    } else {
-        while (lo < hi) {
-            const uint64_t mid = (lo + hi) >> 1;
-            const pgr_frag_rec &r = recs[key_off[mid]];
-            if (r.h0 < h0 || (r.h0 == h0 && r.h1 < h1)) lo = mid + 1;
-            else hi = mid;
-        }
-        if (lo < n_keys) {
-            const pgr_frag_rec &r = recs[key_off[lo]];
-            if (r.h0 == h0 && r.h1 == h1) {
-                a = key_off[lo];
-                b = key_off[lo + 1];
-            }
-        }
-    }
+    uint64_t a, b;
+    lookup_range(q[p].h0, q[p].h1, recs, key_off, n_keys, lut, lut_bits, lut_shift, keys, a, b);
     lo_out[p] = a;
     hi_out[p] = b;
 }
@@ -583,18 +548,12 @@ __global__ void pair_count_kernel(const pgr_frag_rec *__restrict__ q, const uint
     count[p] = c;
 }
 
-struct QParams {
-    uint32_t max_count, max_count_query, max_count_target;
-};
-
 // aln.rs:197-228: number of hits a query pair contributes (mode 0) or the hits themselves (mode 1).
 // Records of one key are sorted by sid, so target_shmer_pair_count[(key,sid)] = count * run length.
 // A pair whose key holds up to HITS_HEAVY records is walked by its own thread.  A key of a repeat can hold 10^5 records in a
 // pangenome index (a serial thread pays ~0.4 us per record): those pairs are taken by the whole wavefront afterwards, 64
 // records per step -- a lane at the start of a sid run finds the run's end by binary search (the run either passes the
 // target filter as a whole, and is then at most max_count_target long, or is skipped as a whole).
-constexpr uint64_t HITS_HEAVY = 64;
-
 __device__ __forceinline__ void emit_hit(const pgr_frag_rec &qp, const pgr_frag_rec &r, uint64_t o, uint64_t *__restrict__ hit_key,
                                          pgr_hitpair *__restrict__ hit_hp) {
     pgr_hitpair h;
@@ -768,23 +727,6 @@ __global__ __launch_bounds__(256) void group_sort_kernel(const uint64_t *__restr
     for (uint32_t r = t; r < m; r += T) flags[s + r] = (r == 0 || srt[r - 1] != srt[r]) ? 1u : 0u;
 }
 
-struct AlnParams {
-    uint32_t max_span;
-    float penalty;
-    int has_max_gap;
-    uint32_t max_gap;
-    int oriented;
-};
-
-__device__ __forceinline__ bool same_q(const pgr_hitpair &a, const pgr_hitpair &b) {
-    return a.qb == b.qb && a.qe == b.qe && a.qo == b.qo;
-}
-__device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair &b) {
-    return same_q(a, b) && a.tb == b.tb && a.te == b.te && a.to == b.to;
-}
-__device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
-
-constexpr uint32_t MAX_SPAN_CAP = 64;
 constexpr int ALN_WAVE_MIN = 64;    // groups with at least this many hits are chained by a whole wavefront ...
 constexpr int ALN_WAVE_MIN_FEW = 16;  // ... from this size already when the call has few groups (latency, not throughput)
 constexpr uint64_t ALN_FEW_GROUPS = 4096;
@@ -1037,24 +979,6 @@ struct AlnWaveLds {
     uint32_t span_q[MAX_SPAN_CAP][3];
     uint32_t cand[4][64];  // qb, qe, qo, considered-flag of the 64 candidates of the current look-back batch
 };
-
-// maximum over the wavefront (DPP row shifts + row broadcasts; lanes without a source see -inf)
-__device__ __forceinline__ float wave_max_f32(float v) {
-    const int ninf = __float_as_int(-INFINITY);
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x111, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x112, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x114, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x118, 0xf, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x142, 0xa, 0xf, false)));
-    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x143, 0xc, 0xf, false)));
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-
-__device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders LDS and global accesses of the wave
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
 
 template <int NMAX>
 __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
@@ -1588,7 +1512,7 @@ int fill_result(pgr_ctx *ctx, uint32_t n_queries, ChainOut &co, pgr_hps_result *
 
 extern "C" void pgr_hps_result_free(pgr_hps_result *r) {
     if (!r) return;
-    free(r->_owner);  // every array of the result lives in this one block
+    result_block_release(r->_owner);  // every array of the result lives in this one block (malloc'd, or pinned: query_fused.hip)
     memset(r, 0, sizeof(*r));
 }
 
@@ -1662,6 +1586,39 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         pgr_shmmrs_destroy(s);
         s = nullptr;
         if (rc) return rc;
+        // batches of short queries: everything behind the pair records in one kernel, one wavefront per query (query_fused.hip)
+        if (ix->fused_skip == 0 && query_fused_eligible(n_queries, max_pairs, max_aln_span)) {
+            QueryFusedCounts fc;
+            bool declined = false;
+            const QParams fqp{max_count, max_count_query, max_count_target};
+            const AlnParams fap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
+            if ((rc = query_fused(ctx, ix, qrec.as<pgr_frag_rec>(), (const uint64_t *)ctx->ws_rec_off.p, n_queries, max_pairs, fqp, fap, out,
+                                  &fc,
+                                  &declined)))
+                return rc;
+            if (!declined) {
+                const auto t5 = now();
+                qp.n_signatures = fc.n_signatures;
+                qp.n_hits = fc.n_hits;
+                qp.n_groups = out->n_targets;
+                qp.n_chains = out->n_chains;
+                qp.n_hps = out->n_hps;
+                qp.shmmr_ms = ms(t1, t2);
+                qp.chain_ms = ms(t2, t5);  // (lookup, hits, chaining, packing, download: one stage here)
+                qp.total_ms = ms(t1, t5);
+                qp.path = 1;
+                ctx->qprof = qp;
+                if (dbg)
+                    fprintf(stderr, "[pgr] query batch %u (one wavefront per query): shimmers %.2f ms, the rest %.2f\n", n_queries,
+                            qp.shmmr_ms, qp.chain_ms);
+                return PGR_OK;
+            }
+            // the batch does not fit (a long query, a repeat key, a long group): the stage-by-stage path below takes it, and
+            // the next calls on this index do not try again for a while
+            ix->fused_skip = 16;
+        } else if (ix->fused_skip) {
+            --ix->fused_skip;
+        }
         if ((rc = lo.alloc(nq * 8)) || (rc = hi.alloc(nq * 8)) || (rc = cnt.alloc(nq * 4)) || (rc = idx_a.alloc(nq * 4)) ||
             (rc = idx_b.alloc(nq * 4)) || (rc = keys_a.alloc(nq * 8)) || (rc = keys_b.alloc(nq * 8)) ||
             (rc = nh.alloc((nq + 1) * 4)) || (rc = hoff.alloc((nq + 1) * 8)) || (rc = nsig.alloc(16)))

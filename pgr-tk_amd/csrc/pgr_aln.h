@@ -1,0 +1,116 @@
+// pgr_aln.h -- device helpers shared by the query kernels of index.hip (one kernel per stage, any batch) and query_fused.hip
+// (one wavefront per short query, every stage behind the query's pair records in one kernel).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "pgr_index.h"
+
+namespace pgr {
+
+// count filters of aln::query_fragment_to_hps (aln.rs:197-228)
+struct QParams {
+    uint32_t max_count, max_count_query, max_count_target;
+};
+
+// a pair whose key holds more records than this is walked by a whole wavefront in hits_kernel
+constexpr uint64_t HITS_HEAVY = 64;
+
+// aln::sparse_aln (aln.rs:12-142)
+struct AlnParams {
+    uint32_t max_span;
+    float penalty;
+    int has_max_gap;
+    uint32_t max_gap;
+    int oriented;
+};
+
+constexpr uint32_t MAX_SPAN_CAP = 64;
+
+__device__ __forceinline__ bool same_q(const pgr_hitpair &a, const pgr_hitpair &b) {
+    return a.qb == b.qb && a.qe == b.qe && a.qo == b.qo;
+}
+__device__ __forceinline__ bool same_hp(const pgr_hitpair &a, const pgr_hitpair &b) {
+    return same_q(a, b) && a.tb == b.tb && a.te == b.te && a.to == b.to;
+}
+__device__ __forceinline__ float absf(float v) { return v < 0.0f ? -v : v; }
+
+// maximum over the wavefront (DPP row shifts + row broadcasts; lanes without a source see -inf)
+__device__ __forceinline__ float wave_max_f32(float v) {
+    const int ninf = __float_as_int(-INFINITY);
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x111, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x112, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x114, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x118, 0xf, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x142, 0xa, 0xf, false)));
+    v = fmaxf(v, __int_as_float(__builtin_amdgcn_update_dpp(ninf, __float_as_int(v), 0x143, 0xc, 0xf, false)));
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders LDS and global accesses of the wave
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// raw_query_fragment lookup (seq_db.rs:1200-1228): [a, b) = records of the key (h0, h1), empty when absent.  Keys are window
+// minima of a hash: nearly all of them lie in the lowest few percent of the 56-bit range, where the bucket table
+// (pgr_index.h) cuts the binary search over all keys (25 dependent steps of two loads for 3x10^7 keys) down to the few keys of
+// one bucket.
+__device__ __forceinline__ void lookup_range(uint64_t h0, uint64_t h1, const pgr_frag_rec *__restrict__ recs,
+                                             const uint64_t *__restrict__ key_off, uint64_t n_keys,
+                                             const uint32_t *__restrict__ lut, uint32_t lut_bits, uint32_t lut_shift,
+                                             const ulonglong2 *__restrict__ keys, uint64_t &a, uint64_t &b) {
+    uint64_t lo = 0, hi = n_keys;  // first key >= (h0,h1)
+    if (lut) {
+        const uint64_t top = (1ull << lut_bits) - 1;
+        const uint64_t bk = (h0 >> lut_shift) < top ? (h0 >> lut_shift) : top;
+        lo = lut[bk];
+        hi = lut[bk + 1];
+    }
+    a = 0;
+    b = 0;
+    if (keys) {  // the bucket's keys by themselves: one or two cache lines for the whole search
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            const ulonglong2 kk = keys[mid];
+            if (kk.x < h0 || (kk.x == h0 && kk.y < h1)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < n_keys) {
+            const ulonglong2 kk = keys[lo];
+            if (kk.x == h0 && kk.y == h1) {
+                a = key_off[lo];
+                b = key_off[lo + 1];
+            }
+        }
+    } else {
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            const pgr_frag_rec &r = recs[key_off[mid]];
+            if (r.h0 < h0 || (r.h0 == h0 && r.h1 < h1)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < n_keys) {
+            const pgr_frag_rec &r = recs[key_off[lo]];
+            if (r.h0 == h0 && r.h1 == h1) {
+                a = key_off[lo];
+                b = key_off[lo + 1];
+            }
+        }
+    }
+}
+
+// ---- query_fused.hip: the stages behind the queries' pair records for batches of SHORT queries, one wavefront per query.
+// declined = the batch does not fit the path (a query with more pairs / hits than the kernel's LDS image, a key with more
+// than HITS_HEAVY records, a (query, target) group too long for the register DP): the caller takes the general path.
+struct QueryFusedCounts {
+    uint64_t n_signatures = 0, n_hits = 0;
+};
+constexpr uint32_t QF_MAX_PAIRS = 128;  // shimmer pairs of one query
+bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span);
+int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, uint32_t n_queries,
+                uint64_t max_pairs, const QParams &qp, const AlnParams &ap, pgr_hps_result *out, QueryFusedCounts *counts,
+                bool *declined);
+
+}  // namespace pgr

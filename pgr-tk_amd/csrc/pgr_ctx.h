@@ -96,6 +96,10 @@ int shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_
 bool worth_pipelining(uint32_t n, const uint64_t *lens);
 int for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
                     const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume);
+// pinned host blocks a kernel writes a result into (ctx.hip): acquire returns nullptr when the host cannot pin more memory;
+// result_block_release takes any result block of the library -- pinned ones go back to the pool, the others to free()
+void *pinned_result_acquire(size_t min_bytes, size_t *cap);
+void result_block_release(void *p);
 }  // namespace pgr
 
 #define PGR_HIP(ctx, expr)                                                                                   \

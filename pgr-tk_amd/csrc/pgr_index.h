@@ -24,6 +24,10 @@ struct pgr_index {
     bool finalized = false;
     uint32_t next_sid = 0;
     uint64_t sid_bound = 0;  // max(sid) + 1 over the finalized records (0: unknown)
+    // query path: calls left that go straight to the stage-by-stage kernels after the one-wavefront-per-query kernel
+    // (query_fused.hip) declined a batch on this index
+    mutable uint32_t fused_skip = 0;
+    mutable uint32_t fused_hits = 0;  // slot size (hits per query) the last batch of short queries needed, 0: the minimum
 };
 
 namespace pgr {

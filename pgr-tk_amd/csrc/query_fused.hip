@@ -1,0 +1,825 @@
+// query_fused.hip -- query_fragment_to_hps for batches of SHORT queries: every stage behind the queries' shimmer-pair records in
+// ONE kernel, one wavefront per query.
+//
+// The general path (index.hip) runs one kernel per stage over the whole batch: lookup, pair multiplicities, hit counts, scan,
+// [host reads the number of hits], hit expansion, grouping sort, scan, group starts, chaining (three kernels), counts, two
+// scans, [host reads the totals], packing, download -- ~25 launches and three host round trips behind the shimmers.  For the
+// reference's own use (pgr-query: a gene-sized query against the index; BASELINE.json configs[2]: 10 000 x 10 kbp) a query
+// has ~30 shimmer pairs and ~30 hits: every one of those kernels is a few microseconds of work and the batch costs the sum
+// of their latencies.  Here a wavefront keeps ITS query's pairs, hits and chains in LDS and registers:
+//
+//   aln.rs:147-242 query_fragment_to_hps   lookup of every pair (seq_db.rs:1200-1228), per-query key multiplicities
+//                                          (aln.rs:180-181), count filters (aln.rs:197-228), hits in query order
+//   aln.rs:230-240                         grouping by target sid (stable: the hits of a group stay in query order)
+//   aln.rs:12-142  sparse_aln              per group: lane j holds hit j; look-back of hit i = one step of all lanes
+//                                          (filters -> ballot, "stop after max_span distinct query intervals" -> popcounts of
+//                                          the ballot, best predecessor -> wave maximum), chain extraction by readlane walks
+//
+// and leaves chains in a fixed-size slot of its query.  Two small kernels turn the slots into the flat result (exclusive scans
+// of the per-query counts; packing), which the host downloads in one piece after ONE look at the totals.
+//
+// f32 arithmetic in the reference's operation order, no contraction (-ffp-contract=off), the same tie rules as
+// sparse_aln_kernel / sparse_aln_wave_kernel (index.hip): tests/test_gpu_query_fused.py compares the two paths with each other
+// and with the CPU restatement of the reference.
+//
+// The path DECLINES a batch it cannot hold (the flag is read with the totals): a query with more than QF_MAX_PAIRS pairs or
+// QF_H hits, a key with more than HITS_HEAVY records, a (query, target) group of more than 64 hits.  The caller then
+// takes the general path and the index remembers the refusal for its next calls.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "pgr_aln.h"
+#include "pgr_device.h"
+#include "pgr_host.h"
+#include "pgr_index.h"
+
+namespace pgr {
+
+namespace {
+
+// P = pairs a query may have (64 .. QF_MAX_PAIRS), H = hits a query may have = entries of its slot (64 .. QF_H_MAX): powers of
+// two chosen per call from the longest query of the batch and the index's records per key; the kernel's LDS image is sized by
+// them (36 B per pair + 36 B per hit, + 12 B per hit and 1.8 KB for the look-back of groups of more than 64 hits, which
+// batches with queries of more than 64 pairs can have)
+constexpr uint32_t QF_P_MIN = 64, QF_H_MIN = 64, QF_H_MAX = 512;
+constexpr uint32_t QF_DECLINE = 1u, QF_MORE_HITS = 2u;  // flags[0]: the batch does not fit at all / fits with a larger H
+
+struct QfArgs {
+    const pgr_frag_rec *qrec;
+    const uint64_t *pair_off;
+    uint32_t n_queries;
+    const pgr_frag_rec *recs;
+    const uint64_t *key_off;
+    uint64_t n_keys;
+    const uint32_t *lut;
+    uint32_t lut_bits, lut_shift;
+    const ulonglong2 *keys;
+    QParams qp;
+    AlnParams ap;
+    uint32_t P, H;  // pairs / hits a query may have (H = entries of a slot)
+    uint32_t long_groups;  // the LDS image has the work arrays of groups of more than 64 hits
+    // per-query slots of H entries: chains in their final order
+    pgr_hitpair *s_hp;   // hit pairs of the chains
+    float *s_cscore;     // score per chain
+    uint32_t *s_choff;   // first hit pair of the chain, relative to the slot
+    uint32_t *s_tsid;    // target sid per kept (>= 2 hits) group
+    uint32_t *s_tcoff;   // first chain of the target, relative to the slot
+    // per-query counts: targets, chains, hit pairs of chains, hits after the filters, looked-up signatures
+    uint32_t *q_nt, *q_nc, *q_nh, *q_nhit;
+    unsigned long long *q_nsig;
+    uint32_t *flags;  // [0] QF_DECLINE | QF_MORE_HITS, [1] groups the reference never finishes, [2] most hits of one query
+};
+
+// dynamic LDS: h0[P] h1[P] lo[P] (u64) | nrec[P] pc[P] hoff[P] (u32) | hit[H] (24 B) | hsid[H] ssid[H] perm[H] (u32)
+//              [ | vs[H] (f32) sl[H] pv[H] (i32) | span_q[64][3] cand[4][64] (u32) ]
+inline size_t qf_lds_bytes(uint32_t P, uint32_t H, bool long_groups) {
+    return (size_t)P * 36 + (size_t)H * (sizeof(pgr_hitpair) + 12) + (long_groups ? (size_t)H * 12 + (64 * 3 + 4 * 64) * 4 : 0);
+}
+
+// sparse_aln for one group of n <= 64 hits (hit[perm[0..n)], ascending query bgn), the whole wavefront, hit j in lane j.
+// Appends the group's chains to the slot: hit pairs at o_hp[nh..], scores / first-hit offsets at [nc..]; returns true when
+// the reference would never finish the group (aln.rs:129-131).
+__device__ __forceinline__ bool chain_group_regs(const pgr_hitpair *hit, const uint32_t *perm, const int n, const AlnParams &prm,
+                                                 const int lane,
+                                                 pgr_hitpair *__restrict__ o_hp, float *__restrict__ o_cscore,
+                                                 uint32_t *__restrict__ o_choff, uint32_t &nc, uint32_t &nh) {
+    const bool in = lane < n;
+    auto hs = [&](int x) -> pgr_hitpair { return hit[perm[x]]; };
+    const pgr_hitpair h = hs(in ? lane : 0);
+    // value slot (v_s / best_pre_v are keyed by the HitPair VALUE, aln.rs:24): the earliest identical hit pair -- identical
+    // pairs share their query bgn, so they sit in the run of equal bgn around the lane.  eqm: the LATER hits with this lane's
+    // query interval (qb, qe, qo), what the span set of a look-back (aln.rs:70) sees before it reaches this lane.
+    int sl = lane;
+    uint64_t eqm = 0;
+    for (int d = 1;; ++d) {
+        const int o = lane - d;
+        const pgr_hitpair x = hs(o >= 0 ? o : 0);
+        const bool v = in && o >= 0 && x.qb == h.qb;
+        if (!__ballot(v)) break;
+        if (v && same_hp(x, h)) sl = o;
+    }
+    for (int d = 1;; ++d) {
+        const int o = lane + d;
+        const pgr_hitpair x = hs(o < n ? o : 0);
+        const bool v = in && o < n && x.qb == h.qb;
+        if (!__ballot(v)) break;
+        if (v && same_q(x, h)) eqm |= 1ull << o;
+    }
+    const bool has_dup = __ballot(in && sl != lane) != 0;
+    const uint64_t above = lane == 63 ? 0ull : (U64MAX << (lane + 1));
+    float vs = 0.0f;
+    int pv = -1;
+    if (lane == 0) vs = (float)h.qe - (float)h.qb;  // aln.rs:25-27 (sl[0] == 0)
+    for (int i = 1; i < n; ++i) {  // aln.rs:29-103
+        const uint32_t cqb = (uint32_t)__builtin_amdgcn_readlane((int)h.qb, i), cqe = (uint32_t)__builtin_amdgcn_readlane((int)h.qe, i),
+                       cqo = (uint32_t)__builtin_amdgcn_readlane((int)h.qo, i), ctb = (uint32_t)__builtin_amdgcn_readlane((int)h.tb, i),
+                       cte = (uint32_t)__builtin_amdgcn_readlane((int)h.te, i), cto = (uint32_t)__builtin_amdgcn_readlane((int)h.to, i);
+        const float cur_len = (float)cqe - (float)cqb;
+        bool cons = lane < i;
+        if (prm.oriented && ((h.qo ^ h.to) != (cqo ^ cto))) cons = false;  // :43-50
+        float a = (float)cqb - (float)h.qe;
+        float b = (cqo == cto) ? ((float)ctb - (float)h.te) : ((float)cte - (float)h.tb);
+        a = absf(a);
+        b = absf(b);
+        if (prm.has_max_gap) {  // :52-65
+            const float mg = (float)prm.max_gap;
+            if (a > mg || b > mg) cons = false;
+        }
+        if (h.qb == cqb && h.qe == cqe && h.qo == cqo) cons = false;  // :67
+        const uint64_t cm = __ballot(cons);
+        float best_s = 0.0f;
+        int best_v = -1;
+        if (cm) {
+            // candidates are taken from lane i-1 downwards.  A candidate opens a new query interval of the span set (:70)
+            // unless a considered candidate above it has the same interval; the look-back stops behind the candidate that
+            // completes max_span intervals (:91), i.e. a candidate is scored iff fewer than max_span intervals were opened
+            // above it.
+            const bool fresh = cons && (eqm & cm) == 0;
+            const uint64_t fm = __ballot(fresh);
+            const bool proc = cons && (uint32_t)__popcll(fm & above) < prm.max_span;
+            const float p_s = has_dup ? __shfl(vs, sl, 64) : vs;  // :71
+            float s = p_s + cur_len;                              // :72
+            const float sum = a + b;                              // :74-84
+            const float pen = prm.penalty * sum;
+            s = s - pen;
+            if (!proc) s = -INFINITY;
+            const float m = wave_max_f32(s);
+            if (m > 0.0f) {  // :86-89: strict > from 0, the nearest candidate among equal maxima
+                const uint64_t mm = __ballot(proc && s == m);
+                best_s = m;
+                best_v = __builtin_amdgcn_readlane(sl, 63 - __builtin_clzll(mm));
+            }
+        }
+        const int si = __builtin_amdgcn_readlane(sl, i);
+        if (lane == si) {  // :96-102
+            vs = best_s > 0.0f ? best_s : cur_len;
+            pv = best_s > 0.0f ? best_v : -1;
+        }
+    }
+    // chain extraction (aln.rs:105-140): best unvisited value slot, walk its predecessors until a visited one
+    uint64_t unv = __ballot(in && sl == lane);
+    bool stuck = false;
+    while (unv) {
+        const bool cand = (unv >> lane) & 1ull;
+        const float m = wave_max_f32(cand ? vs : -INFINITY);
+        if (!(m > 0.0f)) {  // only non-positive scores left: aln.rs:129-131 would spin forever
+            stuck = true;
+            break;
+        }
+        const int bv = __builtin_ctzll(__ballot(cand && vs == m));  // strict >: the lowest sorted index among equal maxima
+        int len = 0, first_v = bv, v = bv, ord = -1;
+        while (v >= 0 && ((unv >> v) & 1ull)) {  // :121-128
+            if (lane == v) ord = len;
+            ++len;
+            first_v = v;
+            unv &= ~(1ull << v);  // :133-137
+            v = __builtin_amdgcn_readlane(pv, v);
+        }
+        if (ord >= 0) o_hp[nh + (uint32_t)(len - 1 - ord)] = h;  // :132 reversed
+        const float first_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs), first_v));
+        if (lane == 0) {
+            o_cscore[nc] = m - first_s;  // :138-139
+            o_choff[nc] = nh;
+        }
+        ++nc;
+        nh += (uint32_t)len;
+    }
+    return stuck;
+}
+
+// sparse_aln for one group of more than 64 hits with its work arrays in LDS: the scheme of sparse_aln_wave_kernel (index.hip)
+// -- the look-back of a hit evaluates 64 candidates per step, the span set (aln.rs:70, :91) is carried between steps in
+// span_q -- on hits reached through the permutation.  Same outputs as chain_group_regs.
+__device__ __forceinline__ bool chain_group_lds(const pgr_hitpair *hit, const uint32_t *perm, const int n, const AlnParams &prm,
+                                                const int lane, float *vs, int *sl, int *pv, uint32_t (*span_q)[3],
+                                                uint32_t (*cand)[64], pgr_hitpair *__restrict__ o_hp,
+                                                float *__restrict__ o_cscore, uint32_t *__restrict__ o_choff, uint32_t &nc,
+                                                uint32_t &nh) {
+    auto hs = [&](int x) -> pgr_hitpair { return hit[perm[x]]; };
+    for (int i = lane; i < n; i += 64) {  // value slots: the earliest identical hit pair of the run of equal query bgn
+        int s = i;
+        const pgr_hitpair hi = hs(i);
+        for (int j = i - 1; j >= 0; --j) {
+            const pgr_hitpair hj = hs(j);
+            if (hj.qb != hi.qb) break;
+            if (same_hp(hj, hi)) s = j;
+        }
+        sl[i] = s;
+    }
+    wave_sync();
+    if (lane == 0) {  // aln.rs:25-27
+        const pgr_hitpair h0 = hs(0);
+        vs[sl[0]] = (float)h0.qe - (float)h0.qb;
+        pv[sl[0]] = -1;
+    }
+    wave_sync();
+    for (int i = 1; i < n; ++i) {  // aln.rs:29-103
+        const pgr_hitpair cur = hs(i);
+        const float cur_len = (float)cur.qe - (float)cur.qb;
+        float best_s = 0.0f;
+        int best_v = -1;
+        uint32_t span_n = 0;
+        bool stop = false;
+        for (int jb = i - 1; jb >= 0 && !stop; jb -= 64) {
+            const int j = jb - lane;
+            bool cons = j >= 0;
+            const pgr_hitpair p = cons ? hs(j) : cur;
+            float a = 0.0f, b = 0.0f;
+            if (cons) {
+                if (prm.oriented && ((p.qo ^ p.to) != (cur.qo ^ cur.to))) cons = false;  // :43-50
+                a = (float)cur.qb - (float)p.qe;
+                b = (cur.qo == cur.to) ? ((float)cur.tb - (float)p.te) : ((float)cur.te - (float)p.tb);
+                a = absf(a);
+                b = absf(b);
+                if (prm.has_max_gap) {  // :52-65
+                    const float mg = (float)prm.max_gap;
+                    if (a > mg || b > mg) cons = false;
+                }
+                if (same_q(p, cur)) cons = false;  // :67
+            }
+            const uint64_t cm = __ballot(cons);
+            if (!cm) continue;
+            // span set in candidate order, lane parallel: a candidate opens a new distinct query interval unless an earlier
+            // step (span_q) or an earlier considered lane of this step has the same interval (equal intervals share their
+            // qb, and the candidates are sorted by qb: the lanes to look at are the run of equal qb right before this lane)
+            cand[0][lane] = p.qb;
+            cand[1][lane] = p.qe;
+            cand[2][lane] = p.qo;
+            cand[3][lane] = cons ? 1u : 0u;
+            wave_sync();
+            bool fresh = cons;
+            for (uint32_t t = 0; t < span_n; ++t)
+                if (p.qb == span_q[t][0] && p.qe == span_q[t][1] && p.qo == span_q[t][2]) fresh = false;
+            if (fresh)
+                for (int l = lane - 1; l >= 0 && cand[0][l] == p.qb; --l)
+                    if (cand[3][l] && cand[1][l] == p.qe && cand[2][l] == p.qo) {
+                        fresh = false;
+                        break;
+                    }
+            const uint64_t lt = lane ? (U64MAX >> (64 - lane)) : 0ull;
+            const uint64_t nm = __ballot(fresh);
+            const uint32_t before = (uint32_t)__popcll(nm & lt);  // distinct intervals opened by earlier lanes
+            const uint32_t need = prm.max_span - span_n;           // >= 1: the look-back has not stopped yet
+            const uint64_t sm = __ballot(fresh && before + 1 == need);
+            const int stop_lane = sm ? __builtin_ctzll(sm) : 64;  // the candidate completing the span set is scored
+            if (fresh && lane <= stop_lane) {
+                span_q[span_n + before][0] = p.qb;
+                span_q[span_n + before][1] = p.qe;
+                span_q[span_n + before][2] = p.qo;
+            }
+            span_n += (uint32_t)__popcll(stop_lane < 63 ? nm & (U64MAX >> (63 - stop_lane)) : nm);
+            wave_sync();  // span_q is read back in the next step
+            const bool proc = cons && lane <= stop_lane;
+            float s = -INFINITY;
+            int slj = 0;
+            if (proc) {
+                slj = sl[j];
+                const float p_s = vs[slj];  // :71
+                s = p_s + cur_len;          // :72
+                const float sum = a + b;    // :74-84
+                const float pen = prm.penalty * sum;
+                s = s - pen;
+            }
+            const float m = wave_max_f32(s);  // :86-89: strict >, the nearest candidate among equal maxima
+            if (m > best_s) {
+                const int l = __builtin_ctzll(__ballot(proc && s == m));
+                best_s = m;
+                best_v = __builtin_amdgcn_readlane(slj, l);
+            }
+            if (stop_lane < 64) stop = true;
+        }
+        if (lane == 0) {  // :96-102
+            const int si = sl[i];
+            vs[si] = best_s > 0.0f ? best_s : cur_len;
+            pv[si] = best_s > 0.0f ? best_v : -1;
+        }
+        wave_sync();
+    }
+    // extraction (aln.rs:105-140); a visited value slot is marked by sl[v] = -1 - v
+    int n_unvisited = 0;
+    for (int base = 0; base < n; base += 64) {
+        const int i = base + lane;
+        n_unvisited += (int)__popcll(__ballot(i < n && sl[i] == i));
+    }
+    while (n_unvisited > 0) {
+        float bs = 0.0f;
+        int bv = -1;
+        for (int i = lane; i < n; i += 64)
+            if (sl[i] == i && vs[i] > bs) {  // strict >: the lowest index of this lane's maxima
+                bs = vs[i];
+                bv = i;
+            }
+        for (int off = 32; off; off >>= 1) {  // wave arg-max: highest score, ties to the lowest sorted index
+            const float os = __shfl_xor(bs, off, 64);
+            const int ov = __shfl_xor(bv, off, 64);
+            if (ov >= 0 && (bv < 0 || os > bs || (os == bs && ov < bv))) {
+                bs = os;
+                bv = ov;
+            }
+        }
+        if (bv < 0) return true;  // aln.rs:129-131 would spin forever (only non-positive scores left)
+        int len = 0, first_v = bv;
+        if (lane == 0) {
+            int v = bv;
+            while (v >= 0 && sl[v] == v) {  // :121-128
+                o_hp[nh + len] = hs(v);
+                ++len;
+                first_v = v;
+                const int nv = pv[v];
+                sl[v] = -1 - v;  // :133-137
+                v = nv;
+            }
+        }
+        len = __builtin_amdgcn_readfirstlane(len);
+        first_v = __builtin_amdgcn_readfirstlane(first_v);
+        wave_sync();
+        for (int x = lane; x < len / 2; x += 64) {  // :132 reverse
+            const pgr_hitpair t = o_hp[nh + x];
+            o_hp[nh + x] = o_hp[nh + len - 1 - x];
+            o_hp[nh + len - 1 - x] = t;
+        }
+        if (lane == 0) {
+            o_cscore[nc] = bs - vs[first_v];  // :138-139
+            o_choff[nc] = nh;
+        }
+        ++nc;
+        nh += (uint32_t)len;
+        n_unvisited -= len;
+        wave_sync();
+    }
+    return false;
+}
+
+// lookup_range with the bucket's keys loaded at once when they are few (independent loads: one memory round trip instead of
+// one per step of the binary search)
+__device__ __forceinline__ void lookup_range_short(uint64_t h0, uint64_t h1, const QfArgs &a, uint64_t &lo_out, uint64_t &hi_out) {
+    if (a.lut && a.keys) {
+        const uint64_t top = (1ull << a.lut_bits) - 1;
+        const uint64_t bk = (h0 >> a.lut_shift) < top ? (h0 >> a.lut_shift) : top;
+        const uint64_t lo = a.lut[bk], hi = a.lut[bk + 1];
+        if (hi - lo <= 8) {
+            uint64_t found = U64MAX;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const uint64_t k = lo + (uint64_t)j;
+                if (k < hi) {
+                    const ulonglong2 kk = a.keys[k];
+                    if (kk.x == h0 && kk.y == h1) found = k;
+                }
+            }
+            lo_out = hi_out = 0;
+            if (found != U64MAX) {
+                lo_out = a.key_off[found];
+                hi_out = a.key_off[found + 1];
+            }
+            return;
+        }
+    }
+    lookup_range(h0, h1, a.recs, a.key_off, a.n_keys, a.lut, a.lut_bits, a.lut_shift, a.keys, lo_out, hi_out);
+}
+
+__global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t qf_dyn[];
+    const uint32_t P = a.P, H = a.H;
+    uint64_t *L_h0 = reinterpret_cast<uint64_t *>(qf_dyn), *L_h1 = L_h0 + P, *L_lo = L_h1 + P;
+    uint32_t *L_nrec = reinterpret_cast<uint32_t *>(L_lo + P), *L_pc = L_nrec + P, *L_hoff = L_pc + P;
+    pgr_hitpair *hit = reinterpret_cast<pgr_hitpair *>(L_hoff + P);
+    uint32_t *hsid = reinterpret_cast<uint32_t *>(hit + H), *ssid = hsid + H, *perm = ssid + H;
+    const uint32_t q = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    const uint64_t p0 = a.pair_off[q];
+    const uint64_t np64 = a.pair_off[q + 1] - p0;
+    uint32_t nt = 0, nc = 0, nh = 0, m = 0;
+    unsigned long long nsig = 0;
+    bool decline = np64 > (uint64_t)P;
+    const int np = decline ? 0 : (int)np64;
+    // ---- lookup of every pair
+    for (int i = lane; i < np; i += 64) {
+        const uint64_t h0 = a.qrec[p0 + i].h0, h1 = a.qrec[p0 + i].h1;
+        uint64_t lo, hi;
+        lookup_range_short(h0, h1, a, lo, hi);
+        L_h0[i] = h0;
+        L_h1[i] = h1;
+        L_lo[i] = lo;
+        L_nrec[i] = (uint32_t)(hi - lo);  // (one key holds fewer than 2^32 records)
+        nsig += hi - lo;
+    }
+    wave_sync();
+    // ---- multiplicity of the pair's key inside the query (aln.rs:180-181), count filters (aln.rs:197-228), hit counts
+    for (int i0 = 0; i0 < np; i0 += 64) {
+        const int i = i0 + lane;
+        const bool live = i < np;
+        uint32_t c = 0, n = 0;
+        if (live) {
+            const uint64_t h0 = L_h0[i], h1 = L_h1[i];
+            for (int j = 0; j < np; ++j) c += (L_h0[j] == h0 && L_h1[j] == h1) ? 1u : 0u;
+        }
+        const bool pass = live && c <= a.qp.max_count && c <= a.qp.max_count_query;
+        const uint32_t nr = pass ? L_nrec[i] : 0u;
+        if (nr > (uint32_t)HITS_HEAVY) decline = true;
+        else if (nr) {
+            const uint64_t s0 = L_lo[i], e0 = s0 + nr;
+            uint64_t s = s0;
+            while (s < e0) {  // records of one key are sorted by sid: target_shmer_pair_count[(key, sid)] = c * run length
+                const uint32_t sid = a.recs[s].sid;
+                uint64_t t = s + 1;
+                while (t < e0 && a.recs[t].sid == sid) ++t;
+                if ((uint64_t)(t - s) * c <= a.qp.max_count_target) n += (uint32_t)(t - s);
+                s = t;
+            }
+        }
+        if (live) L_pc[i] = pass ? c : 0u;
+        const uint32_t incl = wave_incl_sum(n);
+        if (live) L_hoff[i] = m + incl - n;
+        m += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    const uint32_t n_hits = m;
+    const bool any_decline = __ballot(decline) != 0;
+    if (any_decline || m > H) {
+        if (lane == 0) {
+            if (any_decline) atomicOr(a.flags, QF_DECLINE);
+            else {
+                atomicOr(a.flags, QF_MORE_HITS);
+                atomicMax(a.flags + 2, m);
+            }
+            a.q_nt[q] = 0;
+            a.q_nc[q] = 0;
+            a.q_nh[q] = 0;
+            a.q_nhit[q] = 0;
+            a.q_nsig[q] = 0;
+        }
+        return;
+    }
+    wave_sync();
+    // ---- the hits, pair by pair = in query position order (aln.rs:21 wants a group's hits in ascending query bgn)
+    for (int i = lane; i < np; i += 64) {
+        const uint32_t c = L_pc[i];
+        if (c == 0) continue;
+        const pgr_frag_rec qr = a.qrec[p0 + i];
+        const uint64_t s0 = L_lo[i], e0 = s0 + L_nrec[i];
+        uint32_t o = L_hoff[i];
+        uint64_t s = s0;
+        while (s < e0) {
+            const uint32_t sid = a.recs[s].sid;
+            uint64_t t = s + 1;
+            while (t < e0 && a.recs[t].sid == sid) ++t;
+            if ((uint64_t)(t - s) * c <= a.qp.max_count_target)
+                for (uint64_t u = s; u < t; ++u) {
+                    const pgr_frag_rec r = a.recs[u];
+                    pgr_hitpair hp;
+                    hp.qb = qr.bgn;
+                    hp.qe = qr.end;
+                    hp.qo = qr.orient;
+                    hp.tb = r.bgn;
+                    hp.te = r.end;
+                    hp.to = r.orient;
+                    hit[o] = hp;
+                    hsid[o] = sid;
+                    ++o;
+                }
+            s = t;
+        }
+    }
+    wave_sync();
+    // ---- stable sort by target sid: rank by counting; the hits stay where they are, perm[rank] = position
+    for (uint32_t i0 = 0; i0 < m; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        if (i < m) {
+            const uint32_t mine = hsid[i];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < m; ++j) {
+                const uint32_t o = hsid[j];
+                rank += (o < mine || (o == mine && j < i)) ? 1u : 0u;
+            }
+            perm[rank] = i;
+            ssid[rank] = mine;
+        }
+    }
+    wave_sync();
+    // ---- groups = runs of equal sid; targets with a single hit are dropped (aln.rs:234)
+    const size_t sb = (size_t)q * H;
+    pgr_hitpair *o_hp = a.s_hp + sb;
+    float *o_cscore = a.s_cscore + sb;
+    uint32_t *o_choff = a.s_choff + sb;
+    uint32_t n_stuck = 0;
+    uint32_t gs = 0;
+    while (gs < m) {
+        const uint32_t sid = ssid[gs];
+        uint32_t ge = gs + 1;
+        for (;;) {  // first index behind gs with another sid, 64 at a time
+            const uint32_t i = ge + (uint32_t)lane;
+            const uint64_t diff = __ballot(i >= m || ssid[i < m ? i : 0] != sid);
+            if (diff) {
+                ge += (uint32_t)__builtin_ctzll(diff);
+                break;
+            }
+            ge += 64;
+        }
+        const uint32_t n = ge - gs;
+        if (n > 64 && !a.long_groups) {
+            decline = true;
+            break;
+        }
+        if (n >= 2) {
+            if (lane == 0) {
+                a.s_tsid[sb + nt] = sid;
+                a.s_tcoff[sb + nt] = nc;
+            }
+            ++nt;
+            bool stuck;
+            if (n <= 64) {
+                stuck = chain_group_regs(hit, perm + gs, (int)n, a.ap, lane, o_hp, o_cscore, o_choff, nc, nh);
+            } else {
+                float *w_vs = reinterpret_cast<float *>(perm + H);
+                int *w_sl = reinterpret_cast<int *>(w_vs + H), *w_pv = w_sl + H;
+                uint32_t(*w_span)[3] = reinterpret_cast<uint32_t(*)[3]>(w_pv + H);
+                uint32_t(*w_cand)[64] = reinterpret_cast<uint32_t(*)[64]>(w_pv + H + 64 * 3);
+                stuck = chain_group_lds(hit, perm + gs, (int)n, a.ap, lane, w_vs, w_sl, w_pv, w_span, w_cand, o_hp, o_cscore,
+                                        o_choff, nc, nh);
+            }
+            if (stuck) ++n_stuck;
+        }
+        gs = ge;
+    }
+    for (int d = 32; d >= 1; d >>= 1) nsig += shfl_xor64(nsig, d);
+    if (lane == 0) {
+        if (decline) atomicOr(a.flags, QF_DECLINE);
+        if (n_stuck) atomicAdd(a.flags + 1, n_stuck);
+        a.q_nt[q] = decline ? 0 : nt;
+        a.q_nc[q] = decline ? 0 : nc;
+        a.q_nh[q] = decline ? 0 : nh;
+        a.q_nhit[q] = n_hits;
+        a.q_nsig[q] = nsig;
+    }
+}
+
+// exclusive scans of the per-query counts (one workgroup: a batch has 1 .. 10^6 queries) -> where every query's targets, chains
+// and hit pairs start in the flat result; q_off of the result; the totals (straight into the host's pinned mailbox).
+// words: [0] targets [1] chains [2] hit pairs [3] signatures [4] hits [5] QF_DECLINE | QF_MORE_HITS [6] non-terminating groups
+//        [7] set by the packing kernel: the host block is too small [8] most hits of one query that overflowed its slot
+// The counts of one query are < 2^10 and a batch has <= 2^20 queries: 32-bit sums.  Chunks of 1024 queries: coalesced loads,
+// one workgroup scan per chunk, the running totals carried in registers.
+constexpr int QF_SCAN_T = 1024;
+__global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t *__restrict__ q_nt, const uint32_t *__restrict__ q_nc,
+                                                                 const uint32_t *__restrict__ q_nh, const uint32_t *__restrict__ q_nhit,
+                                                                 const unsigned long long *__restrict__ q_nsig,
+                                                                 const uint32_t *__restrict__ flags, uint32_t n,
+                                                                 uint64_t *__restrict__ t0, uint64_t *__restrict__ c0,
+                                                                 uint64_t *__restrict__ h0, uint64_t *__restrict__ img_q_off,
+                                                                 uint64_t *__restrict__ words) {
+    __shared__ uint32_t part[3][QF_SCAN_T / 64];
+    __shared__ unsigned long long red[2][QF_SCAN_T / 64];
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    uint32_t base_t = 0, base_c = 0, base_h = 0;  // totals of the chunks before this one (the same in every thread)
+    unsigned long long sig = 0, hits = 0;
+    for (uint32_t q0 = 0; q0 < n; q0 += QF_SCAN_T) {
+        const uint32_t q = q0 + t;
+        const bool live = q < n;
+        const uint32_t vt = live ? q_nt[q] : 0u, vc = live ? q_nc[q] : 0u, vh = live ? q_nh[q] : 0u;
+        if (live) {
+            sig += q_nsig[q];
+            hits += q_nhit[q];
+        }
+        const uint32_t it = wave_incl_sum(vt), ic = wave_incl_sum(vc), ih = wave_incl_sum(vh);
+        if (lane == 63) {
+            part[0][w] = it;
+            part[1][w] = ic;
+            part[2][w] = ih;
+        }
+        __syncthreads();
+        uint32_t bt = 0, bc = 0, bh = 0, at = 0, ac = 0, ah = 0;
+        for (uint32_t x = 0; x < QF_SCAN_T / 64; ++x) {
+            const uint32_t pt = part[0][x], pc = part[1][x], ph = part[2][x];
+            if (x < w) {
+                bt += pt;
+                bc += pc;
+                bh += ph;
+            }
+            at += pt;
+            ac += pc;
+            ah += ph;
+        }
+        if (live) {
+            const uint64_t T = (uint64_t)base_t + bt + it - vt;
+            t0[q] = T;
+            c0[q] = (uint64_t)base_c + bc + ic - vc;
+            h0[q] = (uint64_t)base_h + bh + ih - vh;
+            img_q_off[q] = T;
+        }
+        base_t += at;
+        base_c += ac;
+        base_h += ah;
+        __syncthreads();
+    }
+    for (int d = 32; d >= 1; d >>= 1) {
+        sig += shfl_xor64(sig, d);
+        hits += shfl_xor64(hits, d);
+    }
+    if (lane == 0) {
+        red[0][w] = sig;
+        red[1][w] = hits;
+    }
+    __syncthreads();
+    if (t == 0) {
+        unsigned long long s = 0, h = 0;
+        for (uint32_t x = 0; x < QF_SCAN_T / 64; ++x) {
+            s += red[0][x];
+            h += red[1][x];
+        }
+        img_q_off[n] = base_t;
+        words[0] = base_t;
+        words[1] = base_c;
+        words[2] = base_h;
+        words[3] = s;
+        words[4] = h;
+        words[5] = flags[0];
+        words[6] = flags[1];
+        words[8] = flags[2];
+    }
+}
+
+inline __host__ __device__ size_t qf_up8(size_t v) { return (v + 7) & ~(size_t)7; }
+
+// flat result = q_off | t_off | c_off | hps | c_score | t_sid (every section 8-byte aligned), the layout pgr_hps_result points into
+struct QfLayout {
+    size_t o_toff, o_coff, o_hps, o_cscore, o_tsid, bytes;
+};
+inline __host__ __device__ QfLayout qf_layout(uint64_t nq, uint64_t nt, uint64_t nc, uint64_t nh) {
+    QfLayout l;
+    l.o_toff = (nq + 1) * 8;
+    l.o_coff = l.o_toff + (nt + 1) * 8;
+    l.o_hps = l.o_coff + (nc + 1) * 8;
+    l.o_cscore = l.o_hps + nh * sizeof(pgr_hitpair);
+    l.o_tsid = qf_up8(l.o_cscore + nc * 4);
+    l.bytes = qf_up8(l.o_tsid + nt * 4);
+    return l;
+}
+
+// words[7] = 1: the result does not fit the host block (cap bytes); nothing is written, the host calls again with a larger one
+__global__ __launch_bounds__(64) void query_pack_kernel(const QfArgs a, const uint64_t *__restrict__ t0, const uint64_t *__restrict__ c0,
+                                                        const uint64_t *__restrict__ h0, uint64_t *__restrict__ words,
+                                                        uint8_t *__restrict__ img, uint64_t cap) {
+    const uint32_t q = blockIdx.x, lane = threadIdx.x;
+    if (words[5]) return;  // declined or asked for larger slots: there is no result
+    const uint64_t NT = words[0], NC = words[1], NH = words[2];
+    const QfLayout l = qf_layout(a.n_queries, NT, NC, NH);
+    if (l.bytes > cap) {
+        if (q == 0 && lane == 0) words[7] = 1;
+        return;
+    }
+    uint64_t *t_off = (uint64_t *)(img + l.o_toff), *c_off = (uint64_t *)(img + l.o_coff);
+    pgr_hitpair *hps = (pgr_hitpair *)(img + l.o_hps);
+    float *c_score = (float *)(img + l.o_cscore);
+    uint32_t *t_sid = (uint32_t *)(img + l.o_tsid);
+    if (q == 0 && lane == 0) {
+        t_off[NT] = NC;
+        c_off[NC] = NH;
+    }
+    const uint32_t nt = a.q_nt[q], nc = a.q_nc[q], nh = a.q_nh[q];
+    const uint64_t T0 = t0[q], C0 = c0[q], H0 = h0[q];
+    const size_t sb = (size_t)q * a.H;
+    for (uint32_t i = lane; i < nt; i += 64) {
+        t_sid[T0 + i] = a.s_tsid[sb + i];
+        t_off[T0 + i] = C0 + a.s_tcoff[sb + i];
+    }
+    for (uint32_t i = lane; i < nc; i += 64) {
+        c_score[C0 + i] = a.s_cscore[sb + i];
+        c_off[C0 + i] = H0 + a.s_choff[sb + i];
+    }
+    // hit pairs: 24 bytes each, copied as 8-byte words (slot and destination are 8-byte aligned)
+    const uint64_t *src = (const uint64_t *)(a.s_hp + sb);
+    uint64_t *dst = (uint64_t *)(hps + H0);
+    for (uint32_t i = lane; i < nh * 3; i += 64) dst[i] = src[i];
+}
+
+}  // namespace
+
+bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span) {
+    if (getenv("PGR_NO_FUSED_QUERY")) return false;
+    // the slots are sized by the number of queries (up to QF_H_MAX x 40 B each)
+    return n_queries >= 1 && n_queries <= (1u << 20) && max_pairs <= QF_MAX_PAIRS && max_aln_span >= 1 && max_aln_span <= 64;
+}
+
+int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, uint32_t n_queries,
+                uint64_t max_pairs, const QParams &qp, const AlnParams &ap, pgr_hps_result *out, QueryFusedCounts *counts,
+                bool *declined) {
+    *declined = false;
+    hipStream_t st = ctx->stream;
+    int rc;
+    // P: the longest query's pairs.  H: its pairs x the index's records per key with room, or what the last batch on this
+    // index needed; a query with more hits makes the kernel ask for a larger H (once per call)
+    uint32_t P = QF_P_MIN;
+    while (P < max_pairs) P <<= 1;
+    const double per_key = ix->n_keys ? (double)ix->n / (double)ix->n_keys : 1.0;
+    const uint64_t want_h = std::max<uint64_t>((uint64_t)((double)max_pairs * per_key * 1.5) + 8, ix->fused_hits);
+    uint32_t H = QF_H_MIN;
+    while (H < QF_H_MAX && H < want_h) H <<= 1;
+    if (const char *e = getenv("PGR_FUSED_QUERY_HITS")) H = (uint32_t)std::min<long>(QF_H_MAX, std::max<long>(QF_H_MIN, atol(e))) & ~63u;
+    const size_t nq = n_queries;
+    if ((rc = ctx->ensure_mailbox(128))) return rc;
+    uint64_t *mb = (uint64_t *)ctx->mailbox;  // pinned: the kernels write the totals here
+    Tmp cnt(ctx), offs(ctx);
+    // cnt: q_nsig | q_nt | q_nc | q_nh | q_nhit | flags ; offs: t0 | c0 | h0
+    if ((rc = cnt.alloc(nq * 24 + 16)) || (rc = offs.alloc(nq * 24))) return rc;
+    QfArgs a;
+    a.qrec = d_qrec;
+    a.pair_off = d_pair_off;
+    a.n_queries = n_queries;
+    a.recs = ix->recs;
+    a.key_off = ix->key_off;
+    a.n_keys = ix->n_keys;
+    a.lut = ix->lut;
+    a.lut_bits = ix->lut_bits;
+    a.lut_shift = ix->lut_shift;
+    a.keys = ix->keys;
+    a.qp = qp;
+    a.ap = ap;
+    a.P = P;
+    a.long_groups = P > 64 ? 1u : 0u;
+    a.q_nsig = cnt.as<unsigned long long>();
+    a.q_nt = cnt.as<uint32_t>() + 2 * nq;
+    a.q_nc = a.q_nt + nq;
+    a.q_nh = a.q_nc + nq;
+    a.q_nhit = a.q_nh + nq;
+    a.flags = a.q_nhit + nq;
+    uint64_t *t0 = offs.as<uint64_t>(), *c0 = t0 + nq, *h0 = c0 + nq;
+    uint8_t *block = nullptr;
+    size_t cap = 0;
+    for (int round = 0;; ++round) {
+        const size_t slots = nq * H;
+        Tmp s_hp(ctx), s_f(ctx);  // s_f: s_cscore | s_choff | s_tsid | s_tcoff
+        if ((rc = s_hp.alloc(slots * sizeof(pgr_hitpair))) || (rc = s_f.alloc(slots * 16))) return rc;
+        a.H = H;
+        a.s_hp = s_hp.as<pgr_hitpair>();
+        a.s_cscore = s_f.as<float>();
+        a.s_choff = s_f.as<uint32_t>() + slots;
+        a.s_tsid = s_f.as<uint32_t>() + 2 * slots;
+        a.s_tcoff = s_f.as<uint32_t>() + 3 * slots;
+        // the host block of the result, written by the packing kernel over PCIe: sized by an estimate (a quarter of the slots
+        // filled), again with the exact size when that was too small
+        const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
+        size_t want = std::min(lmax.bytes, (nq + 1) * 8 + slots * 10 + 4096);
+        if (!block && !(block = (uint8_t *)pinned_result_acquire(want, &cap))) {
+            *declined = true;  // the host cannot pin more memory: the stage-by-stage path needs none
+            return PGR_OK;
+        }
+        PGR_HIP(ctx, hipMemsetAsync(a.flags, 0, 12, st));
+        hipLaunchKernelGGL(query_fused_kernel, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
+        bool again = false;
+        for (int attempt = 0;; ++attempt) {
+            mb[5] = 0;
+            mb[7] = 0;
+            hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig,
+                               a.flags, n_queries, t0, c0, h0, (uint64_t *)block, mb);
+            hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, block, (uint64_t)cap);
+            hipError_t e = hipStreamSynchronize(st);  // ---- the one wait of this stage
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e != hipSuccess) {
+                result_block_release(block);
+                return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
+            }
+            if ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || round))) {
+                result_block_release(block);
+                *declined = true;
+                return PGR_OK;
+            }
+            if (mb[5] & QF_MORE_HITS) {  // every query fits a larger slot: once more with it
+                while (H < mb[8]) H <<= 1;
+                again = true;
+                break;
+            }
+            if (!mb[7]) break;
+            result_block_release(block);
+            block = nullptr;
+            if (attempt) return ctx->fail(PGR_ERR_INTERNAL, "query result does not fit its own size");
+            want = qf_layout(nq, mb[0], mb[1], mb[2]).bytes;
+            if (!(block = (uint8_t *)pinned_result_acquire(want, &cap))) {
+                *declined = true;
+                return PGR_OK;
+            }
+        }
+        if (!again) break;
+    }
+    ix->fused_hits = H > QF_H_MIN ? H : 0;
+    const uint64_t NT = mb[0], NC = mb[1], NH = mb[2];
+    counts->n_signatures = mb[3];
+    counts->n_hits = mb[4];
+    const QfLayout l = qf_layout(nq, NT, NC, NH);
+    out->n_queries = n_queries;
+    out->q_off = (uint64_t *)block;
+    out->n_targets = NT;
+    out->t_off = (uint64_t *)(block + l.o_toff);
+    out->t_sid = (uint32_t *)(block + l.o_tsid);
+    out->n_chains = NC;
+    out->c_off = (uint64_t *)(block + l.o_coff);
+    out->c_score = (float *)(block + l.o_cscore);
+    out->n_hps = NH;
+    out->hps = (pgr_hitpair *)(block + l.o_hps);
+    out->n_nonterminating = mb[6];
+    out->_owner = block;
+    return PGR_OK;
+}
+
+}  // namespace pgr

@@ -56,7 +56,8 @@ class QueryProf(C.Structure):
     _fields_ = [("n_queries", C.c_uint64), ("query_bases", C.c_uint64), ("n_query_pairs", C.c_uint64),
                 ("n_signatures", C.c_uint64), ("n_hits", C.c_uint64), ("n_groups", C.c_uint64), ("n_chains", C.c_uint64),
                 ("n_hps", C.c_uint64), ("stage_ms", C.c_float), ("shmmr_ms", C.c_float), ("lookup_ms", C.c_float),
-                ("chain_ms", C.c_float), ("result_ms", C.c_float), ("total_ms", C.c_float)]
+                ("chain_ms", C.c_float), ("result_ms", C.c_float), ("total_ms", C.c_float),
+                ("path", C.c_uint32), ("_pad", C.c_uint32)]
 
 
 class Bundles(C.Structure):

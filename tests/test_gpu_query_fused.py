@@ -1,0 +1,172 @@
+"""GPU parity of the one-wavefront-per-query path (csrc/query_fused.hip): batches of short queries run every stage behind the
+pair records -- lookup (seq_db.rs:1200-1228), count filters (aln.rs:147-242), grouping, aln::sparse_aln (aln.rs:12-142) -- in one
+kernel.  Checked against the CPU oracle AND against the stage-by-stage kernels (PGR_NO_FUSED_QUERY=1), with the path that ran
+read back from pgr_query_prof.path; batches the kernel cannot hold must decline and still give the oracle's answer."""
+import os
+
+import numpy as np
+import pytest
+
+import seqgen
+from test_gpu_index_query import _build_pair, _make_db_seqs, _oracle_hps_to_tuples, revcomp
+
+pytestmark = pytest.mark.gpu
+
+KW = dict(penalty=0.025, max_count=128, max_count_query=128, max_count_target=128, max_aln_span=8, max_gap=None, orientated=False)
+
+
+def _args(kw):
+    return (kw["penalty"], kw["max_count"], kw["max_count_query"], kw["max_count_target"], kw["max_aln_span"], kw["max_gap"],
+            kw["orientated"])
+
+
+def _check_vs_oracle(oix, queries, got, kw):
+    n_chains = 0
+    for q, g in zip(queries, got):
+        ref = _oracle_hps_to_tuples(oix.query_fragment_to_hps(q, *_args(kw)))
+        assert [t[0] for t in ref] == [t[0] for t in g]
+        for (sid, rc), (_, gc) in zip(ref, g):
+            assert len(rc) == len(gc), sid
+            for (rs, rh), (gs, gh) in zip(rc, gc):
+                assert rs == gs, (sid, rs, gs)  # f32, bit exact
+                assert rh == gh
+            n_chains += len(rc)
+    return n_chains
+
+
+def _general(sdb, queries, kw):
+    os.environ["PGR_NO_FUSED_QUERY"] = "1"
+    try:
+        return sdb.query_fragments_to_hps(queries, *_args(kw))
+    finally:
+        del os.environ["PGR_NO_FUSED_QUERY"]
+
+
+def _short_queries(rng, seqs, n, lo=1500, hi=11000):
+    out = []
+    for i in range(n):
+        src = seqs[int(rng.integers(0, 12))]
+        a = int(rng.integers(0, max(1, len(src) - hi)))
+        q = src[a:a + int(rng.integers(lo, hi))]
+        if i % 2:
+            q = revcomp(q)
+        if i % 5 == 0:  # a few SNPs
+            qa = bytearray(q)
+            for p in rng.integers(0, len(qa), 5):
+                qa[p] = ord("ACGT"[int(rng.integers(0, 4))])
+            q = bytes(qa)
+        out.append(q)
+    return out
+
+
+@pytest.mark.parametrize("variant", ["default", "max_gap", "oriented", "tight_counts", "span1", "span2", "span64"])
+def test_short_query_batches_take_the_fused_path_and_match(oracle, gpu_ctx, variant):
+    rng = np.random.default_rng(41)
+    seqs, core = _make_db_seqs(rng)
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    kw = dict(KW)
+    if variant == "max_gap":
+        kw["max_gap"] = 2000
+    elif variant == "oriented":
+        kw["orientated"] = True
+    elif variant == "tight_counts":
+        kw.update(max_count=1, max_count_query=1, max_count_target=1)
+    elif variant == "span1":
+        kw.update(max_aln_span=1)
+    elif variant == "span2":
+        kw.update(max_aln_span=2, penalty=0.5)
+    elif variant == "span64":
+        kw.update(max_aln_span=64, penalty=0.001)
+    queries = _short_queries(rng, seqs, 150)
+    queries += [b"", seqgen.rnd(rng, 50), seqgen.rnd(rng, 5000), core[0][:9000], revcomp(core[1][100:7000]), b"N" * 3000,
+                core[2][:4000] + b"NNNN" + core[2][4000:8000]]
+    got = sdb.query_fragments_to_hps(queries, *_args(kw))
+    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert _check_vs_oracle(oix, queries, got, kw) > 100
+    assert _general(sdb, queries, kw) == got
+    assert gpu_ctx.last_query_prof()["path"] == 0
+    one = sdb.query_fragment_to_hps(queries[3], *_args(kw))
+    assert gpu_ctx.last_query_prof()["path"] == 1 and one == got[3]
+
+
+def test_repeated_hits_share_value_slots_and_intervals(oracle, gpu_ctx):
+    """tandem copies inside the targets: one query pair hits several places of one target, so groups hold hit pairs with equal
+    query intervals (the span set's distinct-interval rule, aln.rs:70/:91) and identical hit pairs (shared value slots)"""
+    rng = np.random.default_rng(42)
+    unit = seqgen.rnd(rng, 6000)
+    seqs = []
+    for i in range(6):
+        parts = [seqgen.rnd(rng, 3000)]
+        for _ in range(int(rng.integers(2, 5))):
+            parts += [unit, seqgen.rnd(rng, int(rng.integers(200, 1500)))]
+        seqs.append(b"".join(parts))
+    seqs += [seqs[0], seqs[1]] + [seqgen.rnd(rng, 20000) for _ in range(4)]
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    queries = [unit, unit[500:5500], revcomp(unit), unit[:3000] + unit[:3000], seqs[8][2000:9000]]
+    for kw in (dict(KW), dict(KW, max_aln_span=2), dict(KW, max_aln_span=3, orientated=True), dict(KW, max_gap=500),
+               dict(KW, max_count_target=2), dict(KW, max_count_query=1)):
+        got = sdb.query_fragments_to_hps(queries, *_args(kw))
+        path = gpu_ctx.last_query_prof()["path"]
+        _check_vs_oracle(oix, queries, got, kw)
+        assert _general(sdb, queries, kw) == got
+        assert path in (0, 1)
+
+
+def test_batches_that_do_not_fit_decline_and_fall_back(oracle, gpu_ctx):
+    rng = np.random.default_rng(43)
+    seqs, core = _make_db_seqs(rng)
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    short = _short_queries(rng, seqs, 20)
+    # (a) a query with more pairs than the kernel holds: not eligible, no attempt
+    got = sdb.query_fragments_to_hps(short + [core[0] + core[1] + core[2]], *_args(KW))
+    assert gpu_ctx.last_query_prof()["path"] == 0
+    _check_vs_oracle(oix, short + [core[0] + core[1] + core[2]], got, KW)
+    got = sdb.query_fragments_to_hps(short, *_args(KW))
+    assert gpu_ctx.last_query_prof()["path"] == 1
+    # (b) more hits than the first guess of the slot size: the kernel asks for larger slots and runs again
+    copies = [core[0][:20000]] * 12 + [seqgen.rnd(rng, 5000)]
+    sdb2, oix2 = _build_pair(oracle, gpu_ctx, copies)
+    q2 = [core[0][1000:9000], core[0][5000:9000], seqgen.rnd(rng, 3000)]
+    got2 = sdb2.query_fragments_to_hps(q2, *_args(KW))
+    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert _check_vs_oracle(oix2, q2, got2, KW) > 5
+    assert _general(sdb2, q2, KW) == got2
+    # (c) more hits than the largest slot: declined on the device, answered by the stage-by-stage kernels
+    copies = [core[0][:20000]] * 40 + [seqgen.rnd(rng, 5000)]
+    sdb4, oix4 = _build_pair(oracle, gpu_ctx, copies)
+    got4 = sdb4.query_fragments_to_hps(q2, *_args(KW))
+    assert gpu_ctx.last_query_prof()["path"] == 0
+    assert _check_vs_oracle(oix4, q2, got4, KW) > 5
+    # the index remembers: the next calls do not try again, later ones do (and decline again)
+    for _ in range(20):
+        g = sdb4.query_fragments_to_hps(q2[2:], *_args(KW))
+    assert g == got4[2:]
+    # (d) a group of more than 64 hits: the look-back with its work arrays in LDS
+    copies3 = [core[1][:30000], seqgen.rnd(rng, 5000), core[1][2000:28000]]
+    sdb3, oix3 = _build_pair(oracle, gpu_ctx, copies3)
+    q3 = [core[1][:29000], revcomp(core[1][1000:27000]), core[1][:9000]]
+    for kw in (KW, dict(KW, max_aln_span=2), dict(KW, max_gap=3000, orientated=True), dict(KW, max_aln_span=64, penalty=0.0)):
+        got3 = sdb3.query_fragments_to_hps(q3, *_args(kw))
+        assert gpu_ctx.last_query_prof()["path"] == 1
+        assert _check_vs_oracle(oix3, q3, got3, kw) >= 3
+        assert _general(sdb3, q3, kw) == got3
+
+
+def test_many_short_queries_equal_the_stage_by_stage_path(oracle, gpu_ctx):
+    """5000 queries of 2-10 kbp against 40 Mbp: the shape of BASELINE.json configs[2] (scaled); every array of the flat result
+    equal between the two paths, a sample against the oracle"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(44)
+    seqs = [seqgen.rnd(rng, 1_000_000) for _ in range(40)]
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    queries = []
+    for i in range(5000):
+        src = seqs[int(rng.integers(0, 40))]
+        a = int(rng.integers(0, len(src) - 10000))
+        q = src[a:a + int(rng.integers(2000, 10000))]
+        queries.append(revcomp(q) if i % 2 else q)
+    got = sdb.query_fragments_to_hps(queries, *_args(KW))
+    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert _general(sdb, queries, KW) == got
+    idx = [int(i) for i in rng.integers(0, 5000, 60)]
+    assert _check_vs_oracle(oix, [queries[i] for i in idx], [got[i] for i in idx], KW) >= 60
