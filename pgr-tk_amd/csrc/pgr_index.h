@@ -28,6 +28,7 @@ struct pgr_index {
     // (query_fused.hip) declined a batch on this index
     mutable uint32_t fused_skip = 0;
     mutable uint32_t fused_hits = 0;  // slot size (hits per query) the last batch of short queries needed, 0: the minimum
+    mutable float fused_bytes_per_q = 0;  // result bytes per query of that batch (sizes the first download of the next one)
 };
 
 namespace pgr {

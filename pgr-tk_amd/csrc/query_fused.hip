@@ -555,12 +555,13 @@ __global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
     }
 }
 
-// exclusive scans of the per-query counts (one workgroup: a batch has 1 .. 10^6 queries) -> where every query's targets, chains
+// exclusive scans of the per-query counts (one workgroup: a batch has 1 .. 2^17 queries) -> where every query's targets, chains
 // and hit pairs start in the flat result; q_off of the result; the totals (straight into the host's pinned mailbox).
 // words: [0] targets [1] chains [2] hit pairs [3] signatures [4] hits [5] QF_DECLINE | QF_MORE_HITS [6] non-terminating groups
-//        [7] set by the packing kernel: the host block is too small [8] most hits of one query that overflowed its slot
-// The counts of one query are < 2^10 and a batch has <= 2^20 queries: 32-bit sums.  Chunks of 1024 queries: coalesced loads,
-// one workgroup scan per chunk, the running totals carried in registers.
+//        [8] most hits of one query that overflowed its slot
+// Every wavefront takes one contiguous sixteenth of the queries: it adds its range up, the sixteen sums are exchanged once, then
+// it scans its range 64 queries per step with the running total in a register -- no barrier inside the loops.  The counts of
+// one query are < 2^10: 32-bit sums.
 constexpr int QF_SCAN_T = 1024;
 __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t *__restrict__ q_nt, const uint32_t *__restrict__ q_nc,
                                                                  const uint32_t *__restrict__ q_nh, const uint32_t *__restrict__ q_nhit,
@@ -569,69 +570,72 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
                                                                  uint64_t *__restrict__ t0, uint64_t *__restrict__ c0,
                                                                  uint64_t *__restrict__ h0, uint64_t *__restrict__ img_q_off,
                                                                  uint64_t *__restrict__ words) {
-    __shared__ uint32_t part[3][QF_SCAN_T / 64];
-    __shared__ unsigned long long red[2][QF_SCAN_T / 64];
+    constexpr uint32_t NW = QF_SCAN_T / 64;
+    __shared__ uint32_t tot[3][NW];
+    __shared__ unsigned long long red[2][NW];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
-    uint32_t base_t = 0, base_c = 0, base_h = 0;  // totals of the chunks before this one (the same in every thread)
+    const uint32_t R = (((n + NW - 1) / NW) + 63) & ~63u;  // queries per wavefront, a multiple of 64
+    const uint32_t lo = w * R < n ? w * R : n, hi = lo + R < n ? lo + R : n;
+    uint32_t st = 0, sc = 0, sh = 0;
     unsigned long long sig = 0, hits = 0;
-    for (uint32_t q0 = 0; q0 < n; q0 += QF_SCAN_T) {
-        const uint32_t q = q0 + t;
-        const bool live = q < n;
-        const uint32_t vt = live ? q_nt[q] : 0u, vc = live ? q_nc[q] : 0u, vh = live ? q_nh[q] : 0u;
-        if (live) {
-            sig += q_nsig[q];
-            hits += q_nhit[q];
-        }
-        const uint32_t it = wave_incl_sum(vt), ic = wave_incl_sum(vc), ih = wave_incl_sum(vh);
-        if (lane == 63) {
-            part[0][w] = it;
-            part[1][w] = ic;
-            part[2][w] = ih;
-        }
-        __syncthreads();
-        uint32_t bt = 0, bc = 0, bh = 0, at = 0, ac = 0, ah = 0;
-        for (uint32_t x = 0; x < QF_SCAN_T / 64; ++x) {
-            const uint32_t pt = part[0][x], pc = part[1][x], ph = part[2][x];
-            if (x < w) {
-                bt += pt;
-                bc += pc;
-                bh += ph;
-            }
-            at += pt;
-            ac += pc;
-            ah += ph;
-        }
-        if (live) {
-            const uint64_t T = (uint64_t)base_t + bt + it - vt;
-            t0[q] = T;
-            c0[q] = (uint64_t)base_c + bc + ic - vc;
-            h0[q] = (uint64_t)base_h + bh + ih - vh;
-            img_q_off[q] = T;
-        }
-        base_t += at;
-        base_c += ac;
-        base_h += ah;
-        __syncthreads();
+    for (uint32_t q = lo + lane; q < hi; q += 64) {
+        st += q_nt[q];
+        sc += q_nc[q];
+        sh += q_nh[q];
+        sig += q_nsig[q];
+        hits += q_nhit[q];
     }
     for (int d = 32; d >= 1; d >>= 1) {
+        st += (uint32_t)__shfl_xor((int)st, d, 64);
+        sc += (uint32_t)__shfl_xor((int)sc, d, 64);
+        sh += (uint32_t)__shfl_xor((int)sh, d, 64);
         sig += shfl_xor64(sig, d);
         hits += shfl_xor64(hits, d);
     }
     if (lane == 0) {
+        tot[0][w] = st;
+        tot[1][w] = sc;
+        tot[2][w] = sh;
         red[0][w] = sig;
         red[1][w] = hits;
     }
     __syncthreads();
+    uint32_t bt = 0, bc = 0, bh = 0;
+    for (uint32_t x = 0; x < w; ++x) {
+        bt += tot[0][x];
+        bc += tot[1][x];
+        bh += tot[2][x];
+    }
+    for (uint32_t q0 = lo; q0 < hi; q0 += 64) {
+        const uint32_t q = q0 + lane;
+        const bool live = q < hi;
+        const uint32_t vt = live ? q_nt[q] : 0u, vc = live ? q_nc[q] : 0u, vh = live ? q_nh[q] : 0u;
+        const uint32_t it = wave_incl_sum(vt), ic = wave_incl_sum(vc), ih = wave_incl_sum(vh);
+        if (live) {
+            const uint64_t T = (uint64_t)bt + it - vt;
+            t0[q] = T;
+            c0[q] = (uint64_t)bc + ic - vc;
+            h0[q] = (uint64_t)bh + ih - vh;
+            img_q_off[q] = T;
+        }
+        bt += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+        bc += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+        bh += (uint32_t)__builtin_amdgcn_readlane((int)ih, 63);
+    }
     if (t == 0) {
+        uint32_t T = 0, Cn = 0, Hn = 0;
         unsigned long long s = 0, h = 0;
-        for (uint32_t x = 0; x < QF_SCAN_T / 64; ++x) {
+        for (uint32_t x = 0; x < NW; ++x) {
+            T += tot[0][x];
+            Cn += tot[1][x];
+            Hn += tot[2][x];
             s += red[0][x];
             h += red[1][x];
         }
-        img_q_off[n] = base_t;
-        words[0] = base_t;
-        words[1] = base_c;
-        words[2] = base_h;
+        img_q_off[n] = T;
+        words[0] = T;
+        words[1] = Cn;
+        words[2] = Hn;
         words[3] = s;
         words[4] = h;
         words[5] = flags[0];
@@ -657,18 +661,14 @@ inline __host__ __device__ QfLayout qf_layout(uint64_t nq, uint64_t nt, uint64_t
     return l;
 }
 
-// words[7] = 1: the result does not fit the host block (cap bytes); nothing is written, the host calls again with a larger one
+// slots -> the flat result (a device image sized for full slots; the host downloads the part that is used)
 __global__ __launch_bounds__(64) void query_pack_kernel(const QfArgs a, const uint64_t *__restrict__ t0, const uint64_t *__restrict__ c0,
-                                                        const uint64_t *__restrict__ h0, uint64_t *__restrict__ words,
-                                                        uint8_t *__restrict__ img, uint64_t cap) {
+                                                        const uint64_t *__restrict__ h0, const uint64_t *__restrict__ words,
+                                                        uint8_t *__restrict__ img) {
     const uint32_t q = blockIdx.x, lane = threadIdx.x;
     if (words[5]) return;  // declined or asked for larger slots: there is no result
     const uint64_t NT = words[0], NC = words[1], NH = words[2];
     const QfLayout l = qf_layout(a.n_queries, NT, NC, NH);
-    if (l.bytes > cap) {
-        if (q == 0 && lane == 0) words[7] = 1;
-        return;
-    }
     uint64_t *t_off = (uint64_t *)(img + l.o_toff), *c_off = (uint64_t *)(img + l.o_coff);
     pgr_hitpair *hps = (pgr_hitpair *)(img + l.o_hps);
     float *c_score = (float *)(img + l.o_cscore);
@@ -699,7 +699,7 @@ __global__ __launch_bounds__(64) void query_pack_kernel(const QfArgs a, const ui
 bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span) {
     if (getenv("PGR_NO_FUSED_QUERY")) return false;
     // the slots are sized by the number of queries (up to QF_H_MAX x 40 B each)
-    return n_queries >= 1 && n_queries <= (1u << 20) && max_pairs <= QF_MAX_PAIRS && max_aln_span >= 1 && max_aln_span <= 64;
+    return n_queries >= 1 && n_queries <= (1u << 17) && max_pairs <= QF_MAX_PAIRS && max_aln_span >= 1 && max_aln_span <= 64;
 }
 
 int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, uint32_t n_queries,
@@ -749,58 +749,66 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
     size_t cap = 0;
     for (int round = 0;; ++round) {
         const size_t slots = nq * H;
-        Tmp s_hp(ctx), s_f(ctx);  // s_f: s_cscore | s_choff | s_tsid | s_tcoff
-        if ((rc = s_hp.alloc(slots * sizeof(pgr_hitpair))) || (rc = s_f.alloc(slots * 16))) return rc;
+        Tmp s_hp(ctx), s_f(ctx), img(ctx);  // s_f: s_cscore | s_choff | s_tsid | s_tcoff ; img: the flat result, full slots
+        const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
+        if ((rc = s_hp.alloc(slots * sizeof(pgr_hitpair))) || (rc = s_f.alloc(slots * 16)) || (rc = img.alloc(lmax.bytes))) return rc;
         a.H = H;
         a.s_hp = s_hp.as<pgr_hitpair>();
         a.s_cscore = s_f.as<float>();
         a.s_choff = s_f.as<uint32_t>() + slots;
         a.s_tsid = s_f.as<uint32_t>() + 2 * slots;
         a.s_tcoff = s_f.as<uint32_t>() + 3 * slots;
-        // the host block of the result, written by the packing kernel over PCIe: sized by an estimate (a quarter of the slots
-        // filled), again with the exact size when that was too small
-        const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
-        size_t want = std::min(lmax.bytes, (nq + 1) * 8 + slots * 10 + 4096);
-        if (!block && !(block = (uint8_t *)pinned_result_acquire(want, &cap))) {
+        // The host block of the result is pinned: the DMA engine writes it, the caller reads it, no staging copy.  How much to
+        // download is known on the device only: the copy is enqueued for an estimate (what the last batch on this index needed
+        // per query, with room; first time: a quarter of the slots) and the rest follows when the totals say there is more.
+        const size_t est = std::min(lmax.bytes, ix->fused_bytes_per_q > 0 ? (size_t)(nq * (double)ix->fused_bytes_per_q * 1.125) + 65536
+                                                                          : (nq + 1) * 8 + slots * 10 + 4096);
+        if (!block && !(block = (uint8_t *)pinned_result_acquire(est, &cap))) {
             *declined = true;  // the host cannot pin more memory: the stage-by-stage path needs none
             return PGR_OK;
         }
+        const size_t first = std::min(est, cap);
         PGR_HIP(ctx, hipMemsetAsync(a.flags, 0, 12, st));
         hipLaunchKernelGGL(query_fused_kernel, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
-        bool again = false;
-        for (int attempt = 0;; ++attempt) {
-            mb[5] = 0;
-            mb[7] = 0;
-            hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig,
-                               a.flags, n_queries, t0, c0, h0, (uint64_t *)block, mb);
-            hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, block, (uint64_t)cap);
-            hipError_t e = hipStreamSynchronize(st);  // ---- the one wait of this stage
-            if (e == hipSuccess) e = hipGetLastError();
+        hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
+                           n_queries, t0, c0, h0, img.as<uint64_t>(), mb);
+        hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, img.as<uint8_t>());
+        hipError_t e = hipMemcpyAsync(block, img.p, first, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);  // ---- the one wait of this stage
+        if (e == hipSuccess) e = hipGetLastError();
+        if (e != hipSuccess) {
+            result_block_release(block);
+            return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
+        }
+        if ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || round))) {
+            result_block_release(block);
+            *declined = true;
+            return PGR_OK;
+        }
+        if (mb[5] & QF_MORE_HITS) {  // every query fits a larger slot: once more with it
+            while (H < mb[8]) H <<= 1;
+            continue;
+        }
+        const size_t need = qf_layout(nq, mb[0], mb[1], mb[2]).bytes;
+        if (need > first) {  // more than the estimate
+            if (need > cap) {
+                result_block_release(block);
+                if (!(block = (uint8_t *)pinned_result_acquire(need, &cap))) {
+                    *declined = true;
+                    return PGR_OK;
+                }
+                e = hipMemcpyAsync(block, img.p, need, hipMemcpyDeviceToHost, st);
+            } else {
+                e = hipMemcpyAsync(block + first, img.as<uint8_t>() + first, need - first, hipMemcpyDeviceToHost, st);
+            }
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e != hipSuccess) {
                 result_block_release(block);
-                return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
-            }
-            if ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || round))) {
-                result_block_release(block);
-                *declined = true;
-                return PGR_OK;
-            }
-            if (mb[5] & QF_MORE_HITS) {  // every query fits a larger slot: once more with it
-                while (H < mb[8]) H <<= 1;
-                again = true;
-                break;
-            }
-            if (!mb[7]) break;
-            result_block_release(block);
-            block = nullptr;
-            if (attempt) return ctx->fail(PGR_ERR_INTERNAL, "query result does not fit its own size");
-            want = qf_layout(nq, mb[0], mb[1], mb[2]).bytes;
-            if (!(block = (uint8_t *)pinned_result_acquire(want, &cap))) {
-                *declined = true;
-                return PGR_OK;
+                return ctx->fail(PGR_ERR_DEVICE, std::string("query result download: ") + hipGetErrorString(e));
             }
         }
-        if (!again) break;
+        ix->fused_bytes_per_q = (float)((double)need / (double)nq);
+        break;
     }
     ix->fused_hits = H > QF_H_MIN ? H : 0;
     const uint64_t NT = mb[0], NC = mb[1], NH = mb[2];
