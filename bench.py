@@ -193,8 +193,9 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
                 ok += 1
     n_hps = int(len(r["hps"]))
     algo = 24.0 * n_hps + 0.25 * prof["query_bases"] + 17.0 * prof["n_signatures"]
-    qk = committed("r02_query", "summary.json") or {}
-    qpmc = (committed("r02_query", "pmc_summary.json") or {}).get("per_query_batch", {})
+    qk = committed("r03_query", "summary.json") or {}
+    qpmc = (committed("r03_query", "pmc_summary.json") or {}).get("per_query_batch", {})
+    fused = int(prof.get("path", 0)) == 1
     out = {
         "workload": "BASELINE.json configs[2]: %d x %d bp queries (50%% reverse complement) against the %d x %d bp index, "
                     "penalty 0.025, max counts 128, max_aln_span 8" % (nq, qlen, len(contig_ids), args.contig_len),
@@ -212,17 +213,24 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
                            "note": "pgr_query_hps_batch: host ASCII in, host chains out"},
         "counts": {k: int(prof[k]) for k in ("n_query_pairs", "n_signatures", "n_hits", "n_groups", "n_chains", "n_hps")},
         "stage_ms": {k: float(prof[k]) for k in ("shmmr_ms", "lookup_ms", "chain_ms", "result_ms", "total_ms")},
+        "path": ("one wavefront per query behind the shimmers (csrc/query_fused.hip): lookup, count filters, grouping, chaining "
+                 "DP in one kernel; stage_ms.chain_ms holds all of it, download included" if fused else
+                 "one kernel per stage over the whole batch (csrc/index.hip)"),
         "roofline": {
             "bound": "hbm", "achieved": algo / t_res / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": algo / t_res / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": algo,
-            "traffic": qpmc.get("hbm_bytes"),  # HBM bytes per batch by PMC (profiles/r02_query/pmc_summary.json), all kernels
+            "traffic": qpmc.get("hbm_bytes"),  # HBM bytes per batch by PMC (profiles/r03_query/pmc_summary.json), all kernels
             "algorithmic_bytes_formula": "24 B x hit pairs emitted + 0.25 B x query bases + 17 B x looked-up signatures "
                                          "(SURVEY.md 8d); signatures counted on the device",
             "dominant_kernel": qk.get("dominant_kernel"), "dominant_kernel_ms": qk.get("dominant_kernel_ms"),
             "kernel_ms_total": qk.get("kernel_ms_total"), "launches": qk.get("launches"),
-            "what_holds": "latency: the batch moves ~37 MB (5 us of HBM time); %d kernel launches, 4 host round trips (one per "
-                          "data-dependent buffer size), the serial critical path of the chaining DP and the PCIe download of "
-                          "the chains take the rest" % (qk.get("launches") or 0),
+            "what_holds": ("latency and PCIe: the batch moves ~37 MB of HBM traffic (5 us at the roofline); %d kernel launches and two "
+                           "host waits.  The shimmers of 10 000 x 10 kbp take 0.45 ms (the tile kernel 0.26: a 10 kbp query fills 2.6 "
+                           "tiles), the per-query kernel 0.09 ms (a wavefront's chain of ~10 dependent memory accesses, ~6 000 "
+                           "wavefronts in flight), the 7 MB of chains cross PCIe in 0.14 ms (52 GB/s)" if fused else
+                           "latency: the batch moves ~37 MB (5 us of HBM time); %d kernel launches, 4 host round trips (one per "
+                           "data-dependent buffer size), the serial critical path of the chaining DP and the PCIe download of "
+                           "the chains take the rest") % (qk.get("launches") or 0),
         },
     }
     return out, ix

@@ -2,7 +2,9 @@
 """Randomised parity campaign for the index / query path (GPU box): random repeat-rich databases, random queries
 (substrings, reverse complements, chimeras, mutated, unrelated), random count filters / span / gap / orientation
 parameters; SeqIndexDB.query_fragments_to_hps compared with the oracle's query_fragment_to_hps, chains and f32 scores
-bit exact.   usage: fuzz_query.py [iterations] [seed0]"""
+bit exact.   usage: fuzz_query.py [iterations] [seed0] [short]
+"short": every query is short enough for the one-wavefront-per-query path (csrc/query_fused.hip) -- the summary says how many
+batches took it -- and the same batch is run through the stage-by-stage kernels as well (both must equal the oracle)."""
 import os
 import sys
 import time
@@ -21,9 +23,15 @@ def rc(s):
     return s.translate(COMP)[::-1]
 
 
+SHORT = len(sys.argv) > 3 and sys.argv[3] == "short"
+PATHS = [0, 0]
+
+
 def one_case(seed, ctx):
     rng = np.random.default_rng(seed)
-    spec_t = [(80, 56, 4, 64), (48, 56, 4, 12), (24, 24, 2, 8), (31, 21, 3, 16)][int(rng.integers(0, 4))]
+    si = int(rng.integers(0, 4))
+    spec_t = [(80, 56, 4, 64), (48, 56, 4, 12), (24, 24, 2, 8), (31, 21, 3, 16)][si]
+    qmax = [30000, 9000, 1200, 2500][si] if SHORT else 60000
     cores = [seqgen.rnd(rng, int(rng.integers(2000, 40000))) for _ in range(int(rng.integers(2, 6)))]
     seqs = []
     for _ in range(int(rng.integers(2, 14))):
@@ -43,16 +51,19 @@ def one_case(seed, ctx):
         oix.add_seq(i, s)
     oix.finalize()
     queries = []
-    for _ in range(int(rng.integers(3, 12))):
+    for _ in range(int(rng.integers(3, 12)) if not SHORT else int(rng.integers(1, 200))):
         kind = rng.random()
         src = seqs[int(rng.integers(0, len(seqs)))]
         if kind < 0.5 and len(src) > 100:
             a = int(rng.integers(0, len(src) - 50))
-            q = src[a:a + int(rng.integers(50, 60000))]
-        elif kind < 0.7:
+            q = src[a:a + int(rng.integers(50, qmax))]
+        elif kind < 0.7 and not SHORT:
             q = cores[int(rng.integers(0, len(cores)))] + cores[int(rng.integers(0, len(cores)))]
         elif kind < 0.8:
             q = seqgen.rnd(rng, int(rng.integers(0, 5000)))
+        elif SHORT:
+            a = int(rng.integers(0, max(1, len(src) - 50)))
+            q = (src[a:a + int(rng.integers(50, qmax // 2))]) * 2  # a query that repeats itself: multiplicities > 1
         else:
             q = src
         if rng.random() < 0.5:
@@ -69,6 +80,14 @@ def one_case(seed, ctx):
     gap = None if rng.random() < 0.6 else int(rng.choice([0, 500, 5000, 100000]))
     ori = bool(rng.random() < 0.3)
     got = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
+    PATHS[int(ctx.last_query_prof()["path"])] += 1
+    if SHORT:
+        os.environ["PGR_NO_FUSED_QUERY"] = "1"
+        got2 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
+        del os.environ["PGR_NO_FUSED_QUERY"]
+        if got2 != got:
+            return "seed %d: the two query paths differ (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
+                seed, spec_t, pen, mc, mq, mt, span, gap, ori)
     n_chains = 0
     for qi, q in enumerate(queries):
         try:
@@ -97,8 +116,9 @@ def main():
             print("FAIL", r, flush=True)
         else:
             chains += r[1]
-    print("fuzz_query: %d cases (seeds %d..%d), %d chains compared, %d failures, %.0f s" % (iters, seed0, seed0 + iters - 1, chains,
-                                                                                         len(fails), time.time() - t0))
+    print("fuzz_query%s: %d cases (seeds %d..%d), %d chains compared, %d failures, %.0f s; batches by path: %d stage by stage, %d one "
+          "wavefront per query" % (" short" if SHORT else "", iters, seed0, seed0 + iters - 1, chains, len(fails), time.time() - t0,
+                                   PATHS[0], PATHS[1]))
     sys.exit(1 if fails else 0)
 
 

@@ -2,7 +2,7 @@
 """Opcode histogram of a kernel in libpgrhip.so, weighted by measured issue cost -> the VALU-issue lower bound.
 
     tools/isa_histogram.py [--so pgr-tk_amd/lib/libpgrhip.so] [--kernel level1_tile_kernelILi80ELi56ELb0]
-                           [--costs profiles/r02_ubench/valu_cycles.json] [--out profiles/<name>/isa_histogram.json]
+                           [--costs profiles/r03_ubench/valu_cycles.json] [--out profiles/<name>/isa_histogram.json]
 
 What it does (works without a GPU: the code object is in the shared library):
   1. llvm-objdump --offloading extracts the gfx950 code objects of the library, llvm-objdump -d disassembles them;
@@ -109,7 +109,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--so", default=os.path.join(ROOT, "pgr-tk_amd", "lib", "libpgrhip.so"))
     ap.add_argument("--kernel", default="level1_tile_kernelILi80ELi56ELb0")
-    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r02_ubench", "valu_cycles.json"))
+    ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r03_ubench", "valu_cycles.json"))
     ap.add_argument("--masked-weight", type=float, default=0.0)
     ap.add_argument("--loop-trips", type=float, default=2.45)
     ap.add_argument("--positions-per-wave", type=int, default=1024)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """rocprofv3 kernel trace of tools/query_leg.py -> profiles/<name>/{kernel_stats.csv, summary.json}
 
-    tools/summarize_query_profile.py gpurun_out/<dir>/q_trace profiles/r02_query [batches]
+    tools/summarize_query_profile.py gpurun_out/<dir>/q_trace profiles/r03_query [batches]
 
 Only the kernels after the 0.5 s gap (the timed query batches) are counted; numbers are per query batch."""
 import collections
