@@ -1587,7 +1587,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         s = nullptr;
         if (rc) return rc;
         // batches of short queries: everything behind the pair records in one kernel, one wavefront per query (query_fused.hip)
-        if (ix->fused_skip == 0 && query_fused_eligible(n_queries, max_pairs, max_aln_span)) {
+        if (ix->fused_skip.load(std::memory_order_relaxed) == 0 && query_fused_eligible(n_queries, max_pairs, max_aln_span)) {
             QueryFusedCounts fc;
             bool declined = false;
             const QParams fqp{max_count, max_count_query, max_count_target};
@@ -1615,9 +1615,10 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
             }
             // the batch does not fit (a long query, a repeat key, a long group): the stage-by-stage path below takes it, and
             // the next calls on this index do not try again for a while
-            ix->fused_skip = 16;
-        } else if (ix->fused_skip) {
-            --ix->fused_skip;
+            ix->fused_skip.store(16, std::memory_order_relaxed);
+        } else {
+            const uint32_t left = ix->fused_skip.load(std::memory_order_relaxed);
+            if (left) ix->fused_skip.store(left - 1, std::memory_order_relaxed);
         }
         if ((rc = lo.alloc(nq * 8)) || (rc = hi.alloc(nq * 8)) || (rc = cnt.alloc(nq * 4)) || (rc = idx_a.alloc(nq * 4)) ||
             (rc = idx_b.alloc(nq * 4)) || (rc = keys_a.alloc(nq * 8)) || (rc = keys_b.alloc(nq * 8)) ||

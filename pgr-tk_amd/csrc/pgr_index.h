@@ -2,6 +2,7 @@
 // mapgraph.hip (MAP-graph adjacency list, principal bundles).
 #pragma once
 #include <algorithm>
+#include <atomic>
 
 #include "pgr_ctx.h"
 
@@ -26,9 +27,10 @@ struct pgr_index {
     uint64_t sid_bound = 0;  // max(sid) + 1 over the finalized records (0: unknown)
     // query path: calls left that go straight to the stage-by-stage kernels after the one-wavefront-per-query kernel
     // (query_fused.hip) declined a batch on this index
-    mutable uint32_t fused_skip = 0;
-    mutable uint32_t fused_hits = 0;  // slot size (hits per query) the last batch of short queries needed, 0: the minimum
-    mutable float fused_bytes_per_q = 0;  // result bytes per query of that batch (sizes the first download of the next one)
+    // (hints only, relaxed atomics: contexts on several threads may query one index)
+    mutable std::atomic<uint32_t> fused_skip{0};
+    mutable std::atomic<uint32_t> fused_hits{0};  // slot size (hits per query) the last batch of short queries needed, 0: the minimum
+    mutable std::atomic<float> fused_bytes_per_q{0.0f};  // result bytes per query of that batch (sizes the next first download)
 };
 
 namespace pgr {

@@ -713,7 +713,7 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
     uint32_t P = QF_P_MIN;
     while (P < max_pairs) P <<= 1;
     const double per_key = ix->n_keys ? (double)ix->n / (double)ix->n_keys : 1.0;
-    const uint64_t want_h = std::max<uint64_t>((uint64_t)((double)max_pairs * per_key * 1.5) + 8, ix->fused_hits);
+    const uint64_t want_h = std::max<uint64_t>((uint64_t)((double)max_pairs * per_key * 1.5) + 8, ix->fused_hits.load(std::memory_order_relaxed));
     uint32_t H = QF_H_MIN;
     while (H < QF_H_MAX && H < want_h) H <<= 1;
     if (const char *e = getenv("PGR_FUSED_QUERY_HITS")) H = (uint32_t)std::min<long>(QF_H_MAX, std::max<long>(QF_H_MIN, atol(e))) & ~63u;
@@ -747,6 +747,7 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
     uint64_t *t0 = offs.as<uint64_t>(), *c0 = t0 + nq, *h0 = c0 + nq;
     uint8_t *block = nullptr;
     size_t cap = 0;
+    const float bytes_hint = ix->fused_bytes_per_q.load(std::memory_order_relaxed);
     for (int round = 0;; ++round) {
         const size_t slots = nq * H;
         Tmp s_hp(ctx), s_f(ctx), img(ctx);  // s_f: s_cscore | s_choff | s_tsid | s_tcoff ; img: the flat result, full slots
@@ -761,7 +762,7 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
         // The host block of the result is pinned: the DMA engine writes it, the caller reads it, no staging copy.  How much to
         // download is known on the device only: the copy is enqueued for an estimate (what the last batch on this index needed
         // per query, with room; first time: a quarter of the slots) and the rest follows when the totals say there is more.
-        const size_t est = std::min(lmax.bytes, ix->fused_bytes_per_q > 0 ? (size_t)(nq * (double)ix->fused_bytes_per_q * 1.125) + 65536
+        const size_t est = std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.125) + 65536
                                                                           : (nq + 1) * 8 + slots * 10 + 4096);
         if (!block && !(block = (uint8_t *)pinned_result_acquire(est, &cap))) {
             *declined = true;  // the host cannot pin more memory: the stage-by-stage path needs none
@@ -807,10 +808,10 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
                 return ctx->fail(PGR_ERR_DEVICE, std::string("query result download: ") + hipGetErrorString(e));
             }
         }
-        ix->fused_bytes_per_q = (float)((double)need / (double)nq);
+        ix->fused_bytes_per_q.store((float)((double)need / (double)nq), std::memory_order_relaxed);
         break;
     }
-    ix->fused_hits = H > QF_H_MIN ? H : 0;
+    ix->fused_hits.store(H > QF_H_MIN ? H : 0, std::memory_order_relaxed);
     const uint64_t NT = mb[0], NC = mb[1], NH = mb[2];
     counts->n_signatures = mb[3];
     counts->n_hits = mb[4];
