@@ -937,12 +937,13 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         uint64_t serial_total = 0;
         for (uint32_t c : serial) serial_total += (uint64_t)b->h_len[c] / 4 + 4096;
         int r;
-        if ((r = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + 1) * sizeof(L1Rec)))) return r;
+        if ((r = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + (uint64_t)n * L1_TAIL_SLOT + 1) * sizeof(L1Rec)))) return r;
         a.out = (L1Rec *)ctx->ws_l1.p;
         a.slot = slot;
         a.ovf_base = slots_total;
         a.cap = cap_par;
-        serial_base = slots_total + cap_par;
+        a.tail_base = slots_total + cap_par;  // the contigs' tail slots sit between the overflow region and the exact regions
+        serial_base = a.tail_base + (uint64_t)n * L1_TAIL_SLOT;  // (run_exact_islands grows the buffer behind this point)
         PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));  // cursors (both stages), contig flags, tile flags
         if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
         l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)

@@ -114,6 +114,7 @@ struct ChunkDesc {
     uint32_t ring_in, ring_out;
 };
 constexpr uint32_t CHUNK_RING_WORDS = 2 * 128 + 1;  // x[128], y[128] in push order, fill
+constexpr uint32_t L1_TAIL_SLOT = 4;
 struct L1Args {
     BatchDev b;
     uint32_t n_contigs;
@@ -125,6 +126,8 @@ struct L1Args {
     uint32_t slot;               // elements per tile slot
     uint64_t ovf_base;           // first element of the overflow region (= n_tiles * slot)
     uint64_t cap;                // capacity of the overflow region (elements)
+    uint64_t tail_base;          // first element of the contigs' tail slots (L1_TAIL_SLOT elements per contig; the tail kernel
+                                 // allocates from the overflow region only when a tail emits more)
     unsigned long long *cursor;  // [0] overflow elements allocated, [1] overflow-of-the-overflow flag, [2] bit0: a tile saw a
                                  // palindromic k-mer, bit1: a tile holds a non-ACGT byte (islands of exact tiles needed)
     uint64_t *seg_off;           // [n_tiles + n_contigs]
