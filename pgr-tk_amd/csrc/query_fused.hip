@@ -769,7 +769,10 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
             return PGR_OK;
         }
         const size_t first = std::min(est, cap);
-        PGR_HIP(ctx, hipMemsetAsync(a.flags, 0, 12, st));
+        if (hipMemsetAsync(a.flags, 0, 12, st) != hipSuccess) {
+            result_block_release(block);
+            return ctx->fail(PGR_ERR_DEVICE, "query kernels: clearing the flags failed");
+        }
         hipLaunchKernelGGL(query_fused_kernel, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
         hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
                            n_queries, t0, c0, h0, img.as<uint64_t>(), mb);
