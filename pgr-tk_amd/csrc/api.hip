@@ -818,6 +818,13 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!b || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
+    const bool dbg_t = getenv("PGR_DEBUG_TIMES") != nullptr;  // host-side timeline of the call on stderr
+    const auto dbg_t0 = std::chrono::steady_clock::now();
+    auto dbg_lap = [&](const char *what) {
+        if (dbg_t)
+            fprintf(stderr, "[pgr] shmmrs_compute %-28s at %7.1f us\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
+    };
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
     if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
@@ -885,8 +892,11 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     uint8_t *d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
     const size_t zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
     uint64_t *mbox = (uint64_t *)ctx->mailbox;  // pinned: [0, N_STATUS) status, then the n+1 result offsets
-    PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t),
-                                hipMemcpyHostToDevice, st));
+    // (through the pinned mailbox -- free until this call's results come back into it, and the stream orders the two: a copy
+    // from pageable memory is staged by the runtime, ~15 us during which nothing else is enqueued)
+    memcpy(mbox, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t));
+    PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, mbox, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    dbg_lap("plan + tile table uploaded");
     uint32_t *d_rids = nullptr;
     if (rids && n) {
         if ((rc = ctx->ws_rids.ensure(ctx, (size_t)n * sizeof(uint32_t)))) return rc;
@@ -1147,6 +1157,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids, n);
         launch_collect_status(st, d_cursor, d_total1, d_nfinal, d_loff - N_STATUS);
         PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
+        // a consumer of the result that does not want to wait for the host (the query path: pair records, lookup, chaining)
+        // enqueues its kernels here, behind stage 4 and in front of the one synchronization; a repeated pass calls it again.
+        // (In front of the copies to the host as well: a DMA between two kernels costs ~20 us of bubbles.)
+        if (ctx->post_enqueue && !pad_fix && (r = ctx->post_enqueue(d_list, d_loff, cap_res, d_nfinal))) return r;
         PGR_HIP(ctx, hipMemcpyAsync(mbox, d_loff - N_STATUS, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         // a small result that the caller wants on the host anyway (pgr_shmmr_batch) rides along with this round trip
         host_copy_elems = 0;
@@ -1191,8 +1205,10 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
             PGR_HIP_BAIL(hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
                                         hipMemcpyDeviceToHost, st));
         }
+        dbg_lap("all stages enqueued");
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
             return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
+        dbg_lap("synchronized");
         // ---- the one look at the device-side counts
         const uint64_t l1_alloc = mbox[0], l1_ovf = mbox[1], need_islands = mbox[2], l2_alloc = mbox[4], l2_ovf = mbox[5];
         const uint64_t total1 = mbox[8];
@@ -1270,6 +1286,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     (void)hipEventElapsedTime(&prof.total_ms, ctx->ev[0], ev_end);
     ctx->prof = prof;
     *out = res;
+    dbg_lap("done");
     return PGR_OK;
 }
 

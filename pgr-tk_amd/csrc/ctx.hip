@@ -144,6 +144,16 @@ int pgr_ctx::ensure_pinned_out(size_t bytes) {
     return PGR_OK;
 }
 
+int pgr_ctx::ensure_qmail() {
+    if (qmail) return PGR_OK;
+    if (hipHostMalloc(&qmail, 256, hipHostMallocDefault) != hipSuccess) {
+        qmail = nullptr;
+        return fail(PGR_ERR_NOMEM, "hipHostMalloc of the query mailbox failed");
+    }
+    memset(qmail, 0, 256);
+    return PGR_OK;
+}
+
 int pgr_ctx::ensure_mailbox(size_t bytes) {
     if (bytes <= mailbox_cap && mailbox) return PGR_OK;
     if (mailbox) (void)hipHostFree(mailbox);
@@ -232,6 +242,8 @@ void pgr_ctx::release_all() {
     if (mailbox) (void)hipHostFree(mailbox);
     mailbox = nullptr;
     mailbox_cap = 0;
+    if (qmail) (void)hipHostFree(qmail);
+    qmail = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <unistd.h>
 
@@ -1565,16 +1566,68 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     qp.n_queries = n_queries;
     qp.query_bases = b->total_bases;
     const auto t1 = now();
+    const QParams fqp{max_count, max_count_query, max_count_target};
+    const AlnParams fap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
+    auto fused_done = [&](const QueryFusedCounts &fc, std::chrono::steady_clock::time_point t2, int path) {
+        const auto t5 = now();
+        qp.n_signatures = fc.n_signatures;
+        qp.n_hits = fc.n_hits;
+        qp.n_groups = out->n_targets;
+        qp.n_chains = out->n_chains;
+        qp.n_hps = out->n_hps;
+        qp.shmmr_ms = ms(t1, t2);
+        qp.chain_ms = ms(t2, t5);  // (lookup, hits, chaining, packing, download: one stage here)
+        qp.total_ms = ms(t1, t5);
+        qp.path = (uint32_t)path;
+        ctx->qprof = qp;
+        if (getenv("PGR_DEBUG_TIMES")) fprintf(stderr, "[pgr] query: result ready at %.1f us\n", qp.total_ms * 1e3);
+        if (dbg)
+            fprintf(stderr, "[pgr] query batch %u (one wavefront per query%s): shimmers %.2f ms, the rest %.2f\n", n_queries,
+                    path == 2 ? ", enqueued behind the shimmer pipeline" : "", qp.shmmr_ms, qp.chain_ms);
+    };
+    // Batches of short queries (query_fused.hip).  When an earlier batch on this index has shown what its queries look like
+    // (pairs per query), the per-query kernel is enqueued BEHIND the shimmer pipeline, in front of that pipeline's one
+    // synchronization: pair records and offsets are derived on the device, the whole query is one host wait.  A batch that does
+    // not fit the guess declines on the device and is done again below with what the host knows by then.
+    const bool fused_on = ix->n && ix->fused_skip.load(std::memory_order_relaxed) == 0;
+    const uint32_t pairs_hint = ix->fused_pairs.load(std::memory_order_relaxed);
+    std::unique_ptr<QueryFusedRun> chained;
+    if (fused_on && pairs_hint && query_fused_eligible(n_queries, pairs_hint, max_aln_span) && !getenv("PGR_NO_QUERY_CHAINING")) {
+        chained.reset(new QueryFusedRun(ctx, ix, n_queries, pairs_hint, fqp, fap));
+        QueryFusedRun *run = chained.get();
+        ctx->post_enqueue = [run](const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count) {
+            return run->enqueue_from_shimmers(d_mm, d_off, cap, d_count);
+        };
+    }
     // queries -> shimmer-pair records, query side (strict <, seq_db.rs:1213); sid field = query index
     pgr_shmmrs *s = nullptr;
     int rc = pgr_shmmrs_compute(ctx, b, &ix->spec, nullptr, 0, &s);
+    ctx->post_enqueue = nullptr;
     if (rc) return rc;
     const auto t2 = now();
+    if (getenv("PGR_DEBUG_TIMES")) fprintf(stderr, "[pgr] query: shimmers returned at %.1f us\n", ms(t1, t2) * 1e3);
     auto t3 = t2, t4 = t2;
     const uint64_t nq = pgr_shmmrs_n_pairs(s);
     qp.n_query_pairs = nq;
     uint64_t max_pairs = 0;  // most shimmer pairs of one query
     for (uint32_t c = 0; c < s->n; ++c) max_pairs = std::max(max_pairs, s->h_off[c + 1] - s->h_off[c]);
+    ix->fused_pairs.store((uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_pairs, 1), 1u << 30), std::memory_order_relaxed);
+    bool structural_decline = false;  // the per-query kernel cannot hold this batch whatever its sizes
+    if (chained && chained->enqueued) {
+        QueryFusedCounts fc;
+        bool declined = false;
+        if ((rc = chained->finish(out, &fc, &declined))) {
+            pgr_shmmrs_destroy(s);
+            return rc;
+        }
+        if (!declined) {
+            pgr_shmmrs_destroy(s);
+            fused_done(fc, t2, 2);
+            return PGR_OK;
+        }
+        structural_decline = max_pairs <= chained->P;  // (otherwise the guess was too small: once more below)
+    }
+    chained.reset();
     ChainOut co;
     if (nq && ix->n) {
         Tmp qrec(ctx), lo(ctx), hi(ctx), cnt(ctx), idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), nh(ctx), hoff(ctx), nsig(ctx);
@@ -1586,35 +1639,22 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         pgr_shmmrs_destroy(s);
         s = nullptr;
         if (rc) return rc;
-        // batches of short queries: everything behind the pair records in one kernel, one wavefront per query (query_fused.hip)
-        if (ix->fused_skip.load(std::memory_order_relaxed) == 0 && query_fused_eligible(n_queries, max_pairs, max_aln_span)) {
+        if (fused_on && !structural_decline && query_fused_eligible(n_queries, max_pairs, max_aln_span)) {
+            QueryFusedRun run(ctx, ix, n_queries, max_pairs, fqp, fap);
             QueryFusedCounts fc;
             bool declined = false;
-            const QParams fqp{max_count, max_count_query, max_count_target};
-            const AlnParams fap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
-            if ((rc = query_fused(ctx, ix, qrec.as<pgr_frag_rec>(), (const uint64_t *)ctx->ws_rec_off.p, n_queries, max_pairs, fqp, fap, out,
-                                  &fc,
-                                  &declined)))
-                return rc;
+            if ((rc = run.enqueue(qrec.as<pgr_frag_rec>(), (const uint64_t *)ctx->ws_rec_off.p))) return rc;
+            PGR_HIP(ctx, hipStreamSynchronize(st));
+            if ((rc = run.finish(out, &fc, &declined))) return rc;
             if (!declined) {
-                const auto t5 = now();
-                qp.n_signatures = fc.n_signatures;
-                qp.n_hits = fc.n_hits;
-                qp.n_groups = out->n_targets;
-                qp.n_chains = out->n_chains;
-                qp.n_hps = out->n_hps;
-                qp.shmmr_ms = ms(t1, t2);
-                qp.chain_ms = ms(t2, t5);  // (lookup, hits, chaining, packing, download: one stage here)
-                qp.total_ms = ms(t1, t5);
-                qp.path = 1;
-                ctx->qprof = qp;
-                if (dbg)
-                    fprintf(stderr, "[pgr] query batch %u (one wavefront per query): shimmers %.2f ms, the rest %.2f\n", n_queries,
-                            qp.shmmr_ms, qp.chain_ms);
+                fused_done(fc, t2, 1);
                 return PGR_OK;
             }
-            // the batch does not fit (a long query, a repeat key, a long group): the stage-by-stage path below takes it, and
-            // the next calls on this index do not try again for a while
+            structural_decline = true;
+        }
+        if (structural_decline) {
+            // a long query, a repeat key, a long group: the stage-by-stage kernels below take the batch, and the next calls
+            // on this index do not try again for a while
             ix->fused_skip.store(16, std::memory_order_relaxed);
         } else {
             const uint32_t left = ix->fused_skip.load(std::memory_order_relaxed);

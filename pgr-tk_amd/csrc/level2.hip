@@ -88,6 +88,75 @@ void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, 
                        n_contigs, n, sids, query_side, rid_is_index, out);
 }
 
+// ---- the same on the device only, for a consumer that is enqueued BEHIND the shimmer pipeline before the host has seen its
+// counts (query path, index.hip): rec_off from the list offsets by one workgroup (sixteen wavefronts each add up and then scan a
+// contiguous sixteenth of the contigs), the records with the element count read from device memory.  The list may hold garbage
+// when the pipeline is about to repeat a stage (result buffer smaller than the result): every index is checked.
+__global__ __launch_bounds__(1024) void pair_offsets_kernel(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ rec_off) {
+    constexpr uint32_t NW = 16;
+    __shared__ unsigned long long tot[NW];
+    const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const uint32_t R = (((n + NW - 1) / NW) + 63) & ~63u;
+    const uint32_t lo = w * R < n ? w * R : n, hi = lo + R < n ? lo + R : n;
+    auto pairs_of = [&](uint32_t c) -> uint32_t {
+        const uint64_t a = off[c], b = off[c + 1];
+        return b > a + 1 ? (uint32_t)(b - a - 1) : 0u;  // (b < a: garbage offsets of a pass that will be repeated)
+    };
+    unsigned long long s = 0;
+    for (uint32_t c = lo + lane; c < hi; c += 64) s += pairs_of(c);
+    for (int d = 32; d >= 1; d >>= 1) s += shfl_xor64(s, d);
+    if (lane == 0) tot[w] = s;
+    __syncthreads();
+    unsigned long long base = 0;
+    for (uint32_t x = 0; x < w; ++x) base += tot[x];
+    for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
+        const uint32_t c = c0 + lane;
+        const uint32_t v = c < hi ? pairs_of(c) : 0u;
+        const uint32_t incl = wave_incl_sum(v);
+        if (c < hi) rec_off[c] = base + incl - v;
+        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    }
+    if (t == 0) {
+        unsigned long long all = 0;
+        for (uint32_t x = 0; x < NW; ++x) all += tot[x];
+        rec_off[n] = all;
+    }
+}
+
+__global__ __launch_bounds__(256) void frag_recs_dev_kernel(const pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ off,
+                                                            const uint64_t *__restrict__ rec_off, uint32_t n, uint64_t cap,
+                                                            const uint64_t *__restrict__ total_ptr, int query_side,
+                                                            pgr_frag_rec *__restrict__ out, uint64_t out_cap) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = *total_ptr < cap ? *total_ptr : cap;
+    if (i + 1 >= total) return;
+    const uint32_t c = (uint32_t)(mm[i].y >> 32);  // (the rid field is the contig index: the caller did not override rids)
+    if (c >= n || i < off[c] || i + 1 >= off[c + 1]) return;  // last shimmer of the contig starts no pair
+    const uint64_t o = rec_off[c] + (i - off[c]);
+    if (o >= out_cap) return;
+    const pgr_mm128 s0 = mm[i], s1 = mm[i + 1];
+    const uint64_t h0 = s0.x >> 8, h1 = s1.x >> 8;
+    const bool keep = query_side ? (h0 < h1) : (h0 <= h1);  // seq_db.rs:1213 vs :391
+    pgr_frag_rec r;
+    r.h0 = keep ? h0 : h1;
+    r.h1 = keep ? h1 : h0;
+    r.frg_id = (uint32_t)(i - off[c]);
+    r.sid = c;
+    r.bgn = (uint32_t)((s0.y & 0xFFFFFFFFull) >> 1) + 1;
+    r.end = (uint32_t)((s1.y & 0xFFFFFFFFull) >> 1) + 1;
+    r.orient = keep ? 0u : 1u;
+    r._pad = 0;
+    out[o] = r;
+}
+
+void launch_frag_recs_dev(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t cap,
+                          const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap) {
+    hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), 0, st, off, n_contigs, rec_off);
+    if (cap < 2) return;
+    hipLaunchKernelGGL(frag_recs_dev_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, mm, off, rec_off, n_contigs, cap,
+                       total_ptr, query_side, out, out_cap);
+}
+
 }  // namespace pgr
 
 namespace pgr {

@@ -109,8 +109,35 @@ struct QueryFusedCounts {
 };
 constexpr uint32_t QF_MAX_PAIRS = 128;  // shimmer pairs of one query
 bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span);
-int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, uint32_t n_queries,
-                uint64_t max_pairs, const QParams &qp, const AlnParams &ap, pgr_hps_result *out, QueryFusedCounts *counts,
-                bool *declined);
+
+// One batch through the per-query kernel.  enqueue*() puts the kernels and the first download on the context's stream (nothing
+// waits); finish() runs behind a synchronization of that stream and hands out the result -- or says `declined`.
+//   enqueue(qrec, pair_off)          the queries' pair records are already on the device
+//   enqueue_from_shimmers(...)       builds them from the shimmer pipeline's device result first: this is what
+//                                    pgr_ctx::post_enqueue calls so that the whole query needs ONE host wait
+struct QueryFusedRun {
+    pgr_ctx *ctx;
+    const pgr_index *ix;
+    uint32_t n_queries;
+    QParams qp;
+    AlnParams ap;
+    uint32_t P = 0, H = 0;
+    bool enqueued = false, no_pinned = false;
+    QueryFusedRun(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries, uint64_t max_pairs, const QParams &qp, const AlnParams &ap);
+    ~QueryFusedRun();
+    QueryFusedRun(const QueryFusedRun &) = delete;
+    QueryFusedRun &operator=(const QueryFusedRun &) = delete;
+    int enqueue(const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off);
+    int enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count);
+    int finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *declined);
+
+private:
+    void *d_cnt = nullptr, *d_offs = nullptr, *d_shp = nullptr, *d_sf = nullptr, *d_img = nullptr, *d_qrec = nullptr, *d_rec_off = nullptr;
+    size_t cnt_bytes = 0, offs_bytes = 0, shp_bytes = 0, sf_bytes = 0, img_bytes = 0, qrec_bytes = 0, rec_off_bytes = 0;
+    uint8_t *block = nullptr;  // pinned host block of the result
+    size_t cap = 0, first = 0;
+    const pgr_frag_rec *qrec_used = nullptr;
+    const uint64_t *pair_off_used = nullptr;
+};
 
 }  // namespace pgr

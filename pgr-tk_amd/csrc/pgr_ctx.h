@@ -73,6 +73,12 @@ struct pgr_ctx {
     int ensure_pinned(size_t bytes);
     int ensure_pinned_out(size_t bytes);
     int ensure_mailbox(size_t bytes);
+    // a second, small pinned mailbox for a consumer whose kernels run behind the shimmer pipeline's (which owns `mailbox`)
+    void *qmail = nullptr;
+    int ensure_qmail();
+    // set by a caller of pgr_shmmrs_compute around the call: invoked (general pipeline only) with the device list, its offsets
+    // [n+1], the list's capacity and the device address of the true count, right before the pipeline's one synchronization
+    std::function<int(const pgr_mm128 *, const uint64_t *, uint64_t, const uint64_t *)> post_enqueue;
     // device -> pageable host memory through the pinned buffer (two windows, D2H of window i+1 overlaps the host
     // copy of window i, which is spread over a few threads); small transfers go straight through hipMemcpy
     int d2h(void *dst, const void *src_dev, size_t bytes);

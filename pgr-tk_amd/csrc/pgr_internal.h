@@ -161,6 +161,10 @@ void launch_gather_segments(hipStream_t st, const pgr_mm128 *src, const uint64_t
 void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, const uint64_t *rec_off,
                       uint32_t n_contigs, uint64_t n, const uint32_t *sids, int query_side, int rid_is_index,
                       pgr_frag_rec *out);
+// device-only variant (no host counts): rec_off[n+1] computed from `off`, the element count read from *total_ptr (capped by cap);
+// garbage-tolerant (every index checked).  rid field = contig index.
+void launch_frag_recs_dev(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t cap,
+                          const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap);
 
 void launch_contig_offsets(hipStream_t st, const uint64_t *seg_dst, const uint32_t *tile_first, uint32_t n,
                            uint32_t n_segs, uint64_t *off);

@@ -698,34 +698,67 @@ __global__ __launch_bounds__(64) void query_pack_kernel(const QfArgs a, const ui
 
 bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span) {
     if (getenv("PGR_NO_FUSED_QUERY")) return false;
-    // the slots are sized by the number of queries (up to QF_H_MAX x 40 B each)
+    // slots and the result image are sized by the number of queries (up to QF_H_MAX x ~90 B each)
     return n_queries >= 1 && n_queries <= (1u << 17) && max_pairs <= QF_MAX_PAIRS && max_aln_span >= 1 && max_aln_span <= 64;
 }
 
-int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, uint32_t n_queries,
-                uint64_t max_pairs, const QParams &qp, const AlnParams &ap, pgr_hps_result *out, QueryFusedCounts *counts,
-                bool *declined) {
-    *declined = false;
-    hipStream_t st = ctx->stream;
-    int rc;
+QueryFusedRun::QueryFusedRun(pgr_ctx *c, const pgr_index *i, uint32_t nq, uint64_t max_pairs, const QParams &q, const AlnParams &p)
+    : ctx(c), ix(i), n_queries(nq), qp(q), ap(p) {
     // P: the longest query's pairs.  H: its pairs x the index's records per key with room, or what the last batch on this
     // index needed; a query with more hits makes the kernel ask for a larger H (once per call)
-    uint32_t P = QF_P_MIN;
+    P = QF_P_MIN;
     while (P < max_pairs) P <<= 1;
     const double per_key = ix->n_keys ? (double)ix->n / (double)ix->n_keys : 1.0;
-    const uint64_t want_h = std::max<uint64_t>((uint64_t)((double)max_pairs * per_key * 1.5) + 8, ix->fused_hits.load(std::memory_order_relaxed));
-    uint32_t H = QF_H_MIN;
+    const uint64_t want_h =
+        std::max<uint64_t>((uint64_t)((double)max_pairs * per_key * 1.5) + 8, ix->fused_hits.load(std::memory_order_relaxed));
+    H = QF_H_MIN;
     while (H < QF_H_MAX && H < want_h) H <<= 1;
     if (const char *e = getenv("PGR_FUSED_QUERY_HITS")) H = (uint32_t)std::min<long>(QF_H_MAX, std::max<long>(QF_H_MIN, atol(e))) & ~63u;
-    const size_t nq = n_queries;
-    if ((rc = ctx->ensure_mailbox(128))) return rc;
-    uint64_t *mb = (uint64_t *)ctx->mailbox;  // pinned: the kernels write the totals here
-    Tmp cnt(ctx), offs(ctx);
-    // cnt: q_nsig | q_nt | q_nc | q_nh | q_nhit | flags ; offs: t0 | c0 | h0
-    if ((rc = cnt.alloc(nq * 24 + 16)) || (rc = offs.alloc(nq * 24))) return rc;
+}
+
+QueryFusedRun::~QueryFusedRun() {
+    for (void *p : {d_cnt, d_offs, d_shp, d_sf, d_img, d_qrec, d_rec_off}) ctx->dfree(p);
+    if (block) result_block_release(block);
+}
+
+namespace {
+int grow(pgr_ctx *ctx, void *&p, size_t &have, size_t want) {
+    if (want <= have && p) return PGR_OK;
+    ctx->dfree(p);
+    p = nullptr;
+    have = 0;
+    const int rc = ctx->dmalloc(&p, std::max<size_t>(want, 16));
+    if (rc == PGR_OK) have = want;
+    return rc;
+}
+}  // namespace
+
+// pair records of the queries from the shimmer pipeline's device result, without the host: then enqueue()
+int QueryFusedRun::enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count) {
+    int rc;
+    if ((rc = grow(ctx, d_qrec, qrec_bytes, (size_t)cap * sizeof(pgr_frag_rec))) ||
+        (rc = grow(ctx, d_rec_off, rec_off_bytes, ((size_t)n_queries + 1) * 8)))
+        return rc;
+    launch_frag_recs_dev(ctx->stream, d_mm, d_off, n_queries, cap, d_count, 1, (uint64_t *)d_rec_off, (pgr_frag_rec *)d_qrec, cap);
+    return enqueue((const pgr_frag_rec *)d_qrec, (const uint64_t *)d_rec_off);
+}
+
+// the per-query kernel, the offsets, the packing and the first download, all stream ordered; finish() after a synchronization
+int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off) {
+    hipStream_t st = ctx->stream;
+    int rc;
+    const size_t nq = n_queries, slots = nq * H;
+    if ((rc = ctx->ensure_qmail())) return rc;
+    uint64_t *mb = (uint64_t *)ctx->qmail;  // pinned: the kernels write the totals here
+    const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
+    // d_cnt: q_nsig | q_nt | q_nc | q_nh | q_nhit | flags ; d_offs: t0 | c0 | h0 ; d_sf: s_cscore | s_choff | s_tsid | s_tcoff
+    if ((rc = grow(ctx, d_cnt, cnt_bytes, nq * 24 + 16)) || (rc = grow(ctx, d_offs, offs_bytes, nq * 24)) ||
+        (rc = grow(ctx, d_shp, shp_bytes, slots * sizeof(pgr_hitpair))) || (rc = grow(ctx, d_sf, sf_bytes, slots * 16)) ||
+        (rc = grow(ctx, d_img, img_bytes, lmax.bytes)))
+        return rc;
     QfArgs a;
-    a.qrec = d_qrec;
-    a.pair_off = d_pair_off;
+    a.qrec = qrec;
+    a.pair_off = pair_off;
     a.n_queries = n_queries;
     a.recs = ix->recs;
     a.key_off = ix->key_off;
@@ -737,88 +770,98 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
     a.qp = qp;
     a.ap = ap;
     a.P = P;
+    a.H = H;
     a.long_groups = P > 64 ? 1u : 0u;
-    a.q_nsig = cnt.as<unsigned long long>();
-    a.q_nt = cnt.as<uint32_t>() + 2 * nq;
+    a.q_nsig = (unsigned long long *)d_cnt;
+    a.q_nt = (uint32_t *)d_cnt + 2 * nq;
     a.q_nc = a.q_nt + nq;
     a.q_nh = a.q_nc + nq;
     a.q_nhit = a.q_nh + nq;
     a.flags = a.q_nhit + nq;
-    uint64_t *t0 = offs.as<uint64_t>(), *c0 = t0 + nq, *h0 = c0 + nq;
-    uint8_t *block = nullptr;
-    size_t cap = 0;
+    a.s_hp = (pgr_hitpair *)d_shp;
+    a.s_cscore = (float *)d_sf;
+    a.s_choff = (uint32_t *)d_sf + slots;
+    a.s_tsid = (uint32_t *)d_sf + 2 * slots;
+    a.s_tcoff = (uint32_t *)d_sf + 3 * slots;
+    uint64_t *t0 = (uint64_t *)d_offs, *c0 = t0 + nq, *h0 = c0 + nq;
+    // The host block of the result is pinned: the DMA engine writes it, the caller reads it, no staging copy.  How much to
+    // download is known on the device only: the copy is enqueued for an estimate (what the last batch on this index needed
+    // per query, with room; first time: a quarter of the slots) and the rest follows when the totals say there is more.
     const float bytes_hint = ix->fused_bytes_per_q.load(std::memory_order_relaxed);
-    for (int round = 0;; ++round) {
-        const size_t slots = nq * H;
-        Tmp s_hp(ctx), s_f(ctx), img(ctx);  // s_f: s_cscore | s_choff | s_tsid | s_tcoff ; img: the flat result, full slots
-        const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
-        if ((rc = s_hp.alloc(slots * sizeof(pgr_hitpair))) || (rc = s_f.alloc(slots * 16)) || (rc = img.alloc(lmax.bytes))) return rc;
-        a.H = H;
-        a.s_hp = s_hp.as<pgr_hitpair>();
-        a.s_cscore = s_f.as<float>();
-        a.s_choff = s_f.as<uint32_t>() + slots;
-        a.s_tsid = s_f.as<uint32_t>() + 2 * slots;
-        a.s_tcoff = s_f.as<uint32_t>() + 3 * slots;
-        // The host block of the result is pinned: the DMA engine writes it, the caller reads it, no staging copy.  How much to
-        // download is known on the device only: the copy is enqueued for an estimate (what the last batch on this index needed
-        // per query, with room; first time: a quarter of the slots) and the rest follows when the totals say there is more.
-        const size_t est = std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.125) + 65536
-                                                                          : (nq + 1) * 8 + slots * 10 + 4096);
-        if (!block && !(block = (uint8_t *)pinned_result_acquire(est, &cap))) {
-            *declined = true;  // the host cannot pin more memory: the stage-by-stage path needs none
-            return PGR_OK;
-        }
-        const size_t first = std::min(est, cap);
-        if (hipMemsetAsync(a.flags, 0, 12, st) != hipSuccess) {
-            result_block_release(block);
-            return ctx->fail(PGR_ERR_DEVICE, "query kernels: clearing the flags failed");
-        }
+    const size_t est = std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.125) + 65536
+                                                            : (nq + 1) * 8 + slots * 10 + 4096);
+    if (!block && !(block = (uint8_t *)pinned_result_acquire(est, &cap))) {
+        no_pinned = true;  // the host cannot pin more memory: the stage-by-stage path needs none
+        return PGR_OK;
+    }
+    first = std::min(est, cap);
+    hipError_t e = hipMemsetAsync(a.flags, 0, 12, st);
+    if (e == hipSuccess) {
         hipLaunchKernelGGL(query_fused_kernel, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
         hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
-                           n_queries, t0, c0, h0, img.as<uint64_t>(), mb);
-        hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, img.as<uint8_t>());
-        hipError_t e = hipMemcpyAsync(block, img.p, first, hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);  // ---- the one wait of this stage
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) {
-            result_block_release(block);
-            return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
-        }
+                           n_queries, t0, c0, h0, (uint64_t *)d_img, mb);
+        hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, (uint8_t *)d_img);
+        e = hipMemcpyAsync(block, d_img, first, hipMemcpyDeviceToHost, st);
+    }
+    if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
+    qrec_used = qrec;
+    pair_off_used = pair_off;
+    enqueued = true;
+    return PGR_OK;
+}
+
+// behind a synchronization of the stream: the totals are in the mailbox.  declined: the batch is for the stage-by-stage path.
+int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *declined) {
+    *declined = false;
+    if (no_pinned || !enqueued) {
+        *declined = true;
+        return PGR_OK;
+    }
+    hipStream_t st = ctx->stream;
+    const size_t nq = n_queries;
+    uint64_t *mb = (uint64_t *)ctx->qmail;
+    for (int round = 0;; ++round) {
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
         if ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || round))) {
-            result_block_release(block);
             *declined = true;
             return PGR_OK;
         }
         if (mb[5] & QF_MORE_HITS) {  // every query fits a larger slot: once more with it
             while (H < mb[8]) H <<= 1;
+            int rc = enqueue(qrec_used, pair_off_used);
+            if (rc) return rc;
+            if (no_pinned) {
+                *declined = true;
+                return PGR_OK;
+            }
+            if (hipStreamSynchronize(st) != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, "query kernels failed on the device");
             continue;
         }
-        const size_t need = qf_layout(nq, mb[0], mb[1], mb[2]).bytes;
-        if (need > first) {  // more than the estimate
-            if (need > cap) {
-                result_block_release(block);
-                if (!(block = (uint8_t *)pinned_result_acquire(need, &cap))) {
-                    *declined = true;
-                    return PGR_OK;
-                }
-                e = hipMemcpyAsync(block, img.p, need, hipMemcpyDeviceToHost, st);
-            } else {
-                e = hipMemcpyAsync(block + first, img.as<uint8_t>() + first, need - first, hipMemcpyDeviceToHost, st);
-            }
-            if (e == hipSuccess) e = hipStreamSynchronize(st);
-            if (e != hipSuccess) {
-                result_block_release(block);
-                return ctx->fail(PGR_ERR_DEVICE, std::string("query result download: ") + hipGetErrorString(e));
-            }
-        }
-        ix->fused_bytes_per_q.store((float)((double)need / (double)nq), std::memory_order_relaxed);
         break;
     }
-    ix->fused_hits.store(H > QF_H_MIN ? H : 0, std::memory_order_relaxed);
     const uint64_t NT = mb[0], NC = mb[1], NH = mb[2];
+    const QfLayout l = qf_layout(nq, NT, NC, NH);
+    const size_t need = l.bytes;
+    if (need > first) {  // more than the estimate
+        hipError_t e;
+        if (need > cap) {
+            result_block_release(block);
+            if (!(block = (uint8_t *)pinned_result_acquire(need, &cap))) {
+                *declined = true;
+                return PGR_OK;
+            }
+            e = hipMemcpyAsync(block, d_img, need, hipMemcpyDeviceToHost, st);
+        } else {
+            e = hipMemcpyAsync(block + first, (const uint8_t *)d_img + first, need - first, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query result download: ") + hipGetErrorString(e));
+    }
+    ix->fused_bytes_per_q.store((float)((double)need / (double)nq), std::memory_order_relaxed);
+    ix->fused_hits.store(H > QF_H_MIN ? H : 0, std::memory_order_relaxed);
     counts->n_signatures = mb[3];
     counts->n_hits = mb[4];
-    const QfLayout l = qf_layout(nq, NT, NC, NH);
     out->n_queries = n_queries;
     out->q_off = (uint64_t *)block;
     out->n_targets = NT;
@@ -831,6 +874,7 @@ int query_fused(pgr_ctx *ctx, const pgr_index *ix, const pgr_frag_rec *d_qrec, c
     out->hps = (pgr_hitpair *)(block + l.o_hps);
     out->n_nonterminating = mb[6];
     out->_owner = block;
+    block = nullptr;  // the caller's now
     return PGR_OK;
 }
 

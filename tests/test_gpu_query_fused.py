@@ -86,7 +86,7 @@ def test_short_query_batches_take_the_fused_path_and_match(oracle, gpu_ctx, vari
     assert _general(sdb, queries, kw) == got
     assert gpu_ctx.last_query_prof()["path"] == 0
     one = sdb.query_fragment_to_hps(queries[3], *_args(kw))
-    assert gpu_ctx.last_query_prof()["path"] == 1 and one == got[3]
+    assert gpu_ctx.last_query_prof()["path"] in (1, 2) and one == got[3]
 
 
 def test_repeated_hits_share_value_slots_and_intervals(oracle, gpu_ctx):
@@ -122,7 +122,7 @@ def test_batches_that_do_not_fit_decline_and_fall_back(oracle, gpu_ctx):
     assert gpu_ctx.last_query_prof()["path"] == 0
     _check_vs_oracle(oix, short + [core[0] + core[1] + core[2]], got, KW)
     got = sdb.query_fragments_to_hps(short, *_args(KW))
-    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert gpu_ctx.last_query_prof()["path"] in (1, 2)
     # (b) more hits than the first guess of the slot size: the kernel asks for larger slots and runs again
     copies = [core[0][:20000]] * 12 + [seqgen.rnd(rng, 5000)]
     sdb2, oix2 = _build_pair(oracle, gpu_ctx, copies)
@@ -147,7 +147,7 @@ def test_batches_that_do_not_fit_decline_and_fall_back(oracle, gpu_ctx):
     q3 = [core[1][:29000], revcomp(core[1][1000:27000]), core[1][:9000]]
     for kw in (KW, dict(KW, max_aln_span=2), dict(KW, max_gap=3000, orientated=True), dict(KW, max_aln_span=64, penalty=0.0)):
         got3 = sdb3.query_fragments_to_hps(q3, *_args(kw))
-        assert gpu_ctx.last_query_prof()["path"] == 1
+        assert gpu_ctx.last_query_prof()["path"] in (1, 2)
         assert _check_vs_oracle(oix3, q3, got3, kw) >= 3
         assert _general(sdb3, q3, kw) == got3
 
@@ -170,3 +170,53 @@ def test_many_short_queries_equal_the_stage_by_stage_path(oracle, gpu_ctx):
     assert _general(sdb, queries, KW) == got
     idx = [int(i) for i in rng.integers(0, 5000, 60)]
     assert _check_vs_oracle(oix, [queries[i] for i in idx], [got[i] for i in idx], KW) >= 60
+
+
+def test_second_batch_on_an_index_is_enqueued_behind_the_shimmer_pipeline(oracle, gpu_ctx):
+    """From the second batch on an index on, the per-query kernel runs behind the shimmer pipeline without a host wait in between
+    (pgr_query_prof.path == 2): pair records and their offsets are derived on the device from a guess of the queries' sizes.  Same
+    results; a batch that outgrows the guess is answered all the same."""
+    rng = np.random.default_rng(45)
+    seqs = [seqgen.rnd(rng, 1_000_000) for _ in range(24)]
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+
+    def batch(n, lo, hi):
+        out = []
+        for i in range(n):
+            src = seqs[int(rng.integers(0, 24))]
+            a = int(rng.integers(0, len(src) - hi))
+            q = src[a:a + int(rng.integers(lo, hi))]
+            out.append(revcomp(q) if i % 2 else q)
+        return out
+    os.environ["PGR_NO_SMALL_PATH"] = "1"  # (small batches of short contigs have a shimmer kernel of their own: not this test)
+    try:
+        q1 = batch(300, 2000, 9000)
+        g1 = sdb.query_fragments_to_hps(q1, *_args(KW))
+        assert gpu_ctx.last_query_prof()["path"] == 1
+        g1b = sdb.query_fragments_to_hps(q1, *_args(KW))
+        assert gpu_ctx.last_query_prof()["path"] == 2 and g1b == g1
+        assert _check_vs_oracle(oix, q1[:40], g1b[:40], KW) >= 40
+        # other parameters, other queries of the same kind
+        kw = dict(KW, max_aln_span=2, max_gap=4000, orientated=True)
+        q2 = batch(500, 1500, 9500) + [b"", seqgen.rnd(rng, 300), b"N" * 2000]
+        g2 = sdb.query_fragments_to_hps(q2, *_args(kw))
+        assert gpu_ctx.last_query_prof()["path"] == 2
+        assert _general(sdb, q2, kw) == g2
+        assert _check_vs_oracle(oix, q2[:30], g2[:30], kw) >= 30
+        # longer queries than the guess (pairs per query): declined on the device, done again with the host's numbers
+        q3 = batch(200, 24000, 33000)
+        g3 = sdb.query_fragments_to_hps(q3, *_args(KW))
+        assert gpu_ctx.last_query_prof()["path"] == 1
+        assert _check_vs_oracle(oix, q3[:10], g3[:10], KW) >= 10
+        g3b = sdb.query_fragments_to_hps(q3, *_args(KW))
+        assert gpu_ctx.last_query_prof()["path"] == 2 and g3b == g3
+        # a batch the kernel cannot hold at all (a query of 400 kbp): stage by stage, and still right
+        q4 = q1[:50] + [seqs[3][:400000]]
+        g4 = sdb.query_fragments_to_hps(q4, *_args(KW))
+        assert gpu_ctx.last_query_prof()["path"] == 0
+        assert g4[:50] == g1[:50] and _check_vs_oracle(oix, q4[50:], g4[50:], KW) >= 1
+        # empty batch of pairs
+        g5 = sdb.query_fragments_to_hps([b"ACGT" * 10, b""], *_args(KW))
+        assert g5 == [[], []]
+    finally:
+        del os.environ["PGR_NO_SMALL_PATH"]

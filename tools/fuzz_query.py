@@ -24,7 +24,7 @@ def rc(s):
 
 
 SHORT = len(sys.argv) > 3 and sys.argv[3] == "short"
-PATHS = [0, 0]
+PATHS = [0, 0, 0]
 
 
 def one_case(seed, ctx):
@@ -85,6 +85,15 @@ def one_case(seed, ctx):
         os.environ["PGR_NO_FUSED_QUERY"] = "1"
         got2 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
         del os.environ["PGR_NO_FUSED_QUERY"]
+        # once more on the same index through the general shimmer pipeline: from the second batch on the per-query kernel is
+        # enqueued behind it without a host wait (path 2)
+        os.environ["PGR_NO_SMALL_PATH"] = "1"
+        got3 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
+        del os.environ["PGR_NO_SMALL_PATH"]
+        PATHS[int(ctx.last_query_prof()["path"])] += 1
+        if got3 != got:
+            return "seed %d: the chained query path differs (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
+                seed, spec_t, pen, mc, mq, mt, span, gap, ori)
         if got2 != got:
             return "seed %d: the two query paths differ (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
                 seed, spec_t, pen, mc, mq, mt, span, gap, ori)
@@ -117,8 +126,9 @@ def main():
         else:
             chains += r[1]
     print("fuzz_query%s: %d cases (seeds %d..%d), %d chains compared, %d failures, %.0f s; batches by path: %d stage by stage, %d one "
-          "wavefront per query" % (" short" if SHORT else "", iters, seed0, seed0 + iters - 1, chains, len(fails), time.time() - t0,
-                                   PATHS[0], PATHS[1]))
+          "wavefront per query, %d of those enqueued behind the shimmer pipeline" % (
+              " short" if SHORT else "", iters, seed0, seed0 + iters - 1, chains, len(fails), time.time() - t0, PATHS[0],
+              PATHS[1] + PATHS[2], PATHS[2]))
     sys.exit(1 if fails else 0)
 
 
