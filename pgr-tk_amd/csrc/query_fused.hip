@@ -786,9 +786,9 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off) {
     uint64_t *t0 = (uint64_t *)d_offs, *c0 = t0 + nq, *h0 = c0 + nq;
     // The host block of the result is pinned: the DMA engine writes it, the caller reads it, no staging copy.  How much to
     // download is known on the device only: the copy is enqueued for an estimate (what the last batch on this index needed
-    // per query, with room; first time: a quarter of the slots) and the rest follows when the totals say there is more.
+    // per query + 5 %; first time: a quarter of the slots) and the rest follows when the totals say there is more.
     const float bytes_hint = ix->fused_bytes_per_q.load(std::memory_order_relaxed);
-    const size_t est = std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.125) + 65536
+    const size_t est = std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.05) + 32768
                                                             : (nq + 1) * 8 + slots * 10 + 4096);
     if (!block && !(block = (uint8_t *)pinned_result_acquire(est, &cap))) {
         no_pinned = true;  // the host cannot pin more memory: the stage-by-stage path needs none

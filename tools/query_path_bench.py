@@ -18,3 +18,9 @@ ix.query_hps_raw(qs[:100], 0.025)
 for rep in range(3):
     t0 = time.perf_counter(); r = ix.query_hps_raw(qs, 0.025); dt = time.perf_counter() - t0
     print("query batch: %d x %d bp in %.1f ms (%.0f q/s, %d hit pairs)" % (nq, ql, dt * 1e3, nq / dt, len(r["hps"])))
+# the C entry point alone (no numpy copies of the result) and the library's own account of the last call
+for rep in range(4):
+    dt, n_hps = ix.time_query_host(qs, 0.025)
+    p = ctx.last_query_prof()
+    print("pgr_query_hps_batch: %.3f ms; staging (host pack + enqueue) %.3f, shimmers %.3f, rest %.3f, path %d" % (
+        dt * 1e3, p["stage_ms"], p["shmmr_ms"], p["chain_ms"] + p["lookup_ms"] + p["result_ms"], p["path"]))
