@@ -95,3 +95,20 @@ if pm:
               open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
     print("pmc_summary.json: %.1f MB of HBM traffic per query batch" % (hbm / 1e6))
 
+# The bench line of the same gpurun command (copied to profiles/<tile profile>/bench.json by summarize_profile.py) was printed BEFORE
+# this summary existed: the derived fields of its query block (launches, kernel time, PMC traffic) came from the previous profile.
+# Refresh them from this run's trace so that the line and the trace next to it belong to the same build.
+bj = os.path.join(os.path.dirname(os.path.abspath(dst)), "r03_tile", "bench.json")
+if os.path.exists(bj) and os.path.exists(os.path.join(os.path.dirname(src.rstrip("/")), "bench.json")):
+    bench = json.load(open(bj))
+    r = bench.get("query", {}).get("roofline")
+    if r is not None:
+        r.update({"dominant_kernel": out["dominant_kernel"], "dominant_kernel_ms": out["dominant_kernel_ms"],
+                  "kernel_ms_total": out["kernel_ms_total"], "launches": out["launches"]})
+        if pm:
+            r["traffic"] = hbm
+        if isinstance(r.get("what_holds"), str):
+            import re
+            r["what_holds"] = re.sub(r"\d+ kernel launches", "%d kernel launches" % round(out["launches"]), r["what_holds"])
+        bench["derived_blocks_query"] = "query.roofline.{launches, kernel_ms_total, dominant_kernel*, traffic} refreshed by tools/summarize_query_profile.py from the trace of this same profile run"
+        json.dump(bench, open(bj, "w"))
