@@ -1153,9 +1153,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_list_a.p, (const uint64_t *)ctx->ws_blk_off.p,
                                (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list,
                                cap_res);
-        launch_offsets_by_rid(st, d_list, d_nfinal, cap_res, n, d_loff);
+        launch_offsets_by_rid(st, d_list, d_nfinal, cap_res, n, d_loff, d_cursor, d_total1, d_loff - N_STATUS);  // + status words
         if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids, n);
-        launch_collect_status(st, d_cursor, d_total1, d_nfinal, d_loff - N_STATUS);
         PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
         // a consumer of the result that does not want to wait for the host (the query path: pair records, lookup, chaining)
         // enqueues its kernels here, behind stage 4 and in front of the one synchronization; a repeated pass calls it again.

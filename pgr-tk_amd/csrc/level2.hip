@@ -92,29 +92,44 @@ void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, 
 // counts (query path, index.hip): rec_off from the list offsets by one workgroup (sixteen wavefronts each add up and then scan a
 // contiguous sixteenth of the contigs), the records with the element count read from device memory.  The list may hold garbage
 // when the pipeline is about to repeat a stage (result buffer smaller than the result): every index is checked.
-__global__ __launch_bounds__(1024) void pair_offsets_kernel(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ rec_off) {
+__global__ __launch_bounds__(1024) void pair_offsets_kernel(const uint64_t *__restrict__ off, uint32_t n, uint64_t *__restrict__ rec_off,
+                                                            uint32_t *__restrict__ clear3) {
     constexpr uint32_t NW = 16;
+    constexpr int U = 8;  // chunks of 64 contigs whose loads are in flight together
     __shared__ unsigned long long tot[NW];
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (clear3 && t < 3) clear3[t] = 0;  // (the consumer's flag words: saves it a memset between two kernels)
     const uint32_t R = (((n + NW - 1) / NW) + 63) & ~63u;
     const uint32_t lo = w * R < n ? w * R : n, hi = lo + R < n ? lo + R : n;
     auto pairs_of = [&](uint32_t c) -> uint32_t {
+        if (c >= hi) return 0u;
         const uint64_t a = off[c], b = off[c + 1];
         return b > a + 1 ? (uint32_t)(b - a - 1) : 0u;  // (b < a: garbage offsets of a pass that will be repeated)
     };
     unsigned long long s = 0;
-    for (uint32_t c = lo + lane; c < hi; c += 64) s += pairs_of(c);
+    for (uint32_t c0 = lo; c0 < hi; c0 += 64 * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = pairs_of(c0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) s += v[u];
+    }
     for (int d = 32; d >= 1; d >>= 1) s += shfl_xor64(s, d);
     if (lane == 0) tot[w] = s;
     __syncthreads();
     unsigned long long base = 0;
     for (uint32_t x = 0; x < w; ++x) base += tot[x];
-    for (uint32_t c0 = lo; c0 < hi; c0 += 64) {
-        const uint32_t c = c0 + lane;
-        const uint32_t v = c < hi ? pairs_of(c) : 0u;
-        const uint32_t incl = wave_incl_sum(v);
-        if (c < hi) rec_off[c] = base + incl - v;
-        base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    for (uint32_t c0 = lo; c0 < hi; c0 += 64 * U) {
+        uint32_t v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = pairs_of(c0 + 64 * u + lane);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t c = c0 + 64 * u + lane;
+            const uint32_t incl = wave_incl_sum(v[u]);
+            if (c < hi) rec_off[c] = base + incl - v[u];
+            base += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        }
     }
     if (t == 0) {
         unsigned long long all = 0;
@@ -150,8 +165,9 @@ __global__ __launch_bounds__(256) void frag_recs_dev_kernel(const pgr_mm128 *__r
 }
 
 void launch_frag_recs_dev(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t cap,
-                          const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap) {
-    hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), 0, st, off, n_contigs, rec_off);
+                          const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap,
+                          uint32_t *clear3) {
+    hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), 0, st, off, n_contigs, rec_off, clear3);
     if (cap < 2) return;
     hipLaunchKernelGGL(frag_recs_dev_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, mm, off, rec_off, n_contigs, cap,
                        total_ptr, query_side, out, out_cap);
@@ -572,10 +588,18 @@ __global__ void block_first_seg_kernel(const uint64_t *__restrict__ seg_dst, uin
     blk_first_seg[b] = s_lo;
 }
 
-// offsets of the final ordered list: off[c] = first element whose (internal) rid >= c
+// offsets of the final ordered list: off[c] = first element whose (internal) rid >= c.  The first ten threads also collect the
+// pipeline's status words (cursors, level-1 total, final count) in front of the offsets: one copy brings both to the host.
 __global__ void offsets_by_rid_kernel(const pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ n_ptr, uint64_t cap,
-                                      uint32_t n_contigs, uint64_t *__restrict__ off) {
+                                      uint32_t n_contigs, uint64_t *__restrict__ off,
+                                      const unsigned long long *__restrict__ cursor, const uint64_t *__restrict__ total1,
+                                      uint64_t *__restrict__ status) {
     const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (status) {
+        if (c < 8) status[c] = cursor[c];
+        if (c == 8) status[8] = *total1;
+        if (c == 9) status[9] = *n_ptr;
+    }
     if (c > n_contigs) return;
     const uint64_t n = *n_ptr < cap ? *n_ptr : cap;
     uint64_t lo = 0, hi = n;  // first j with rid(j) >= c
@@ -609,9 +633,9 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
         hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
 }
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
-                           uint64_t *off) {
+                           uint64_t *off, const unsigned long long *cursor, const uint64_t *total1, uint64_t *status) {
     hipLaunchKernelGGL(offsets_by_rid_kernel, dim3((n_contigs + 1 + 255) / 256), dim3(256), 0, st, mm, n_ptr, cap, n_contigs,
-                       off);
+                       off, cursor, total1, status);
 }
 __global__ void collect_status_kernel(const unsigned long long *__restrict__ cursor, const uint64_t *__restrict__ total1,
                                       const uint64_t *__restrict__ n_final, uint64_t *__restrict__ status) {

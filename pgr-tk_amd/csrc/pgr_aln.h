@@ -127,7 +127,7 @@ struct QueryFusedRun {
     ~QueryFusedRun();
     QueryFusedRun(const QueryFusedRun &) = delete;
     QueryFusedRun &operator=(const QueryFusedRun &) = delete;
-    int enqueue(const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off);
+    int enqueue(const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, bool flags_cleared = false);
     int enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count);
     int finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *declined);
 

@@ -164,7 +164,8 @@ void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, 
 // device-only variant (no host counts): rec_off[n+1] computed from `off`, the element count read from *total_ptr (capped by cap);
 // garbage-tolerant (every index checked).  rid field = contig index.
 void launch_frag_recs_dev(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t cap,
-                          const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap);
+                          const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap,
+                          uint32_t *clear3 = nullptr);  // clear3: three 32-bit words zeroed on the way (the consumer's flags)
 
 void launch_contig_offsets(hipStream_t st, const uint64_t *seg_dst, const uint32_t *tile_first, uint32_t n,
                            uint32_t n_segs, uint64_t *off);
@@ -196,7 +197,8 @@ struct FusedArgsPub {
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);
 // n_ptr: device, number of elements (clamped to cap)
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
-                           uint64_t *off);
+                           uint64_t *off, const unsigned long long *cursor = nullptr, const uint64_t *total1 = nullptr,
+                           uint64_t *status = nullptr);
 void launch_patch_rid(hipStream_t st, pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, const uint32_t *rids,
                       uint32_t n_contigs);
 // status[0..7] = cursor[0..7], status[8] = *total1, status[9] = *n_final: everything the host reads after the one sync

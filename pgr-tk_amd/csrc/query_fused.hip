@@ -576,14 +576,30 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
     const uint32_t t = threadIdx.x, lane = t & 63, w = t >> 6;
     const uint32_t R = (((n + NW - 1) / NW) + 63) & ~63u;  // queries per wavefront, a multiple of 64
     const uint32_t lo = w * R < n ? w * R : n, hi = lo + R < n ? lo + R : n;
+    constexpr int U = 8;  // chunks of 64 queries whose loads are in flight together
     uint32_t st = 0, sc = 0, sh = 0;
     unsigned long long sig = 0, hits = 0;
-    for (uint32_t q = lo + lane; q < hi; q += 64) {
-        st += q_nt[q];
-        sc += q_nc[q];
-        sh += q_nh[q];
-        sig += q_nsig[q];
-        hits += q_nhit[q];
+    for (uint32_t q0 = lo; q0 < hi; q0 += 64 * U) {
+        uint32_t a[U], b[U], c[U], d[U];
+        unsigned long long e[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 64 * u + lane;
+            const bool live = q < hi;
+            a[u] = live ? q_nt[q] : 0u;
+            b[u] = live ? q_nc[q] : 0u;
+            c[u] = live ? q_nh[q] : 0u;
+            d[u] = live ? q_nhit[q] : 0u;
+            e[u] = live ? q_nsig[q] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            st += a[u];
+            sc += b[u];
+            sh += c[u];
+            hits += d[u];
+            sig += e[u];
+        }
     }
     for (int d = 32; d >= 1; d >>= 1) {
         st += (uint32_t)__shfl_xor((int)st, d, 64);
@@ -606,21 +622,31 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
         bc += tot[1][x];
         bh += tot[2][x];
     }
-    for (uint32_t q0 = lo; q0 < hi; q0 += 64) {
-        const uint32_t q = q0 + lane;
-        const bool live = q < hi;
-        const uint32_t vt = live ? q_nt[q] : 0u, vc = live ? q_nc[q] : 0u, vh = live ? q_nh[q] : 0u;
-        const uint32_t it = wave_incl_sum(vt), ic = wave_incl_sum(vc), ih = wave_incl_sum(vh);
-        if (live) {
-            const uint64_t T = (uint64_t)bt + it - vt;
-            t0[q] = T;
-            c0[q] = (uint64_t)bc + ic - vc;
-            h0[q] = (uint64_t)bh + ih - vh;
-            img_q_off[q] = T;
+    for (uint32_t q0 = lo; q0 < hi; q0 += 64 * U) {
+        uint32_t a[U], b[U], c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 64 * u + lane;
+            const bool live = q < hi;
+            a[u] = live ? q_nt[q] : 0u;
+            b[u] = live ? q_nc[q] : 0u;
+            c[u] = live ? q_nh[q] : 0u;
         }
-        bt += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
-        bc += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
-        bh += (uint32_t)__builtin_amdgcn_readlane((int)ih, 63);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const uint32_t q = q0 + 64 * u + lane;
+            const uint32_t it = wave_incl_sum(a[u]), ic = wave_incl_sum(b[u]), ih = wave_incl_sum(c[u]);
+            if (q < hi) {
+                const uint64_t T = (uint64_t)bt + it - a[u];
+                t0[q] = T;
+                c0[q] = (uint64_t)bc + ic - b[u];
+                h0[q] = (uint64_t)bh + ih - c[u];
+                img_q_off[q] = T;
+            }
+            bt += (uint32_t)__builtin_amdgcn_readlane((int)it, 63);
+            bc += (uint32_t)__builtin_amdgcn_readlane((int)ic, 63);
+            bh += (uint32_t)__builtin_amdgcn_readlane((int)ih, 63);
+        }
     }
     if (t == 0) {
         uint32_t T = 0, Cn = 0, Hn = 0;
@@ -736,15 +762,17 @@ int grow(pgr_ctx *ctx, void *&p, size_t &have, size_t want) {
 // pair records of the queries from the shimmer pipeline's device result, without the host: then enqueue()
 int QueryFusedRun::enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count) {
     int rc;
+    const size_t nq = n_queries;
     if ((rc = grow(ctx, d_qrec, qrec_bytes, (size_t)cap * sizeof(pgr_frag_rec))) ||
-        (rc = grow(ctx, d_rec_off, rec_off_bytes, ((size_t)n_queries + 1) * 8)))
+        (rc = grow(ctx, d_rec_off, rec_off_bytes, (nq + 1) * 8)) || (rc = grow(ctx, d_cnt, cnt_bytes, nq * 24 + 16)))
         return rc;
-    launch_frag_recs_dev(ctx->stream, d_mm, d_off, n_queries, cap, d_count, 1, (uint64_t *)d_rec_off, (pgr_frag_rec *)d_qrec, cap);
-    return enqueue((const pgr_frag_rec *)d_qrec, (const uint64_t *)d_rec_off);
+    uint32_t *flags = (uint32_t *)d_cnt + 2 * nq + 4 * nq;  // (behind q_nsig | q_nt | q_nc | q_nh | q_nhit, as in enqueue)
+    launch_frag_recs_dev(ctx->stream, d_mm, d_off, n_queries, cap, d_count, 1, (uint64_t *)d_rec_off, (pgr_frag_rec *)d_qrec, cap, flags);
+    return enqueue((const pgr_frag_rec *)d_qrec, (const uint64_t *)d_rec_off, true);
 }
 
 // the per-query kernel, the offsets, the packing and the first download, all stream ordered; finish() after a synchronization
-int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off) {
+int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, bool flags_cleared) {
     hipStream_t st = ctx->stream;
     int rc;
     const size_t nq = n_queries, slots = nq * H;
@@ -795,7 +823,7 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off) {
         return PGR_OK;
     }
     first = std::min(est, cap);
-    hipError_t e = hipMemsetAsync(a.flags, 0, 12, st);
+    hipError_t e = flags_cleared ? hipSuccess : hipMemsetAsync(a.flags, 0, 12, st);
     if (e == hipSuccess) {
         hipLaunchKernelGGL(query_fused_kernel, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
         hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
