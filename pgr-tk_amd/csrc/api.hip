@@ -954,7 +954,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         a.cap = cap_par;
         a.tail_base = slots_total + cap_par;  // the contigs' tail slots sit between the overflow region and the exact regions
         serial_base = a.tail_base + (uint64_t)n * L1_TAIL_SLOT;  // (run_exact_islands grows the buffer behind this point)
-        PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));  // cursors (both stages), contig flags, tile flags
+        // cursors (both stages), contig flags, tile flags: cleared by the tile descriptor kernel when there are tiles
+        if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));
         if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
         l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));

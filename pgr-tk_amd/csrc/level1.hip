@@ -810,9 +810,14 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// one thread per tile: its descriptor.  The same threads clear the call's cursors, contig flags and tile flags (one block of
+// memory, api.hip) -- a memset in front of this kernel was a launch and a bubble of its own in every call.
 __global__ void tile_desc_kernel(L1Args a) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tile < 8) a.cursor[tile] = 0ull;
+    if (tile < a.n_contigs) a.contig_flags[tile] = 0u;
     if (tile >= a.n_tiles) return;
+    a.tile_flags[tile] = 0;
     const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);
     TileDesc d;
     d.word_off = a.b.word_off[c];
@@ -826,7 +831,8 @@ __global__ void tile_desc_kernel(L1Args a) {
 
 void launch_level1_tiles(hipStream_t st, const L1Args &a) {
     if (a.n_tiles == 0) return;
-    hipLaunchKernelGGL(tile_desc_kernel, dim3((a.n_tiles + 255) / 256), dim3(256), 0, st, a);
+    const uint32_t n_desc = a.n_tiles > a.n_contigs ? a.n_tiles : a.n_contigs;  // (>= 8: a tile per non-empty contig ... or not)
+    hipLaunchKernelGGL(tile_desc_kernel, dim3(((n_desc > 8 ? n_desc : 8) + 255) / 256), dim3(256), 0, st, a);
     if (a.sketch)
         hipLaunchKernelGGL((level1_tile_kernel<0, 0, true>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
     else if (a.w == 80 && a.k == 56)
