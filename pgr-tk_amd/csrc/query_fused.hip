@@ -16,15 +16,18 @@
 //                                          the ballot, best predecessor -> wave maximum), chain extraction by readlane walks
 //
 // and leaves chains in a fixed-size slot of its query.  Two small kernels turn the slots into the flat result (exclusive scans
-// of the per-query counts; packing), which the host downloads in one piece after ONE look at the totals.
+// of the per-query counts; packing), which the DMA engine downloads into a pinned host block.  The host looks at the totals
+// ONCE, after everything -- and when the index has seen a batch before, not even the shimmer pipeline in front of this stage
+// waits for the host (QueryFusedRun::enqueue_from_shimmers is called through pgr_ctx::post_enqueue).
 //
 // f32 arithmetic in the reference's operation order, no contraction (-ffp-contract=off), the same tie rules as
 // sparse_aln_kernel / sparse_aln_wave_kernel (index.hip): tests/test_gpu_query_fused.py compares the two paths with each other
 // and with the CPU restatement of the reference.
 //
-// The path DECLINES a batch it cannot hold (the flag is read with the totals): a query with more than QF_MAX_PAIRS pairs or
-// QF_H hits, a key with more than HITS_HEAVY records, a (query, target) group of more than 64 hits.  The caller then
-// takes the general path and the index remembers the refusal for its next calls.
+// The path DECLINES a batch it cannot hold (the flag is read with the totals): a query with more than P <= QF_MAX_PAIRS pairs or
+// QF_H_MAX hits, a key with more than HITS_HEAVY records, a (query, target) group of more than 64 hits in an LDS image without
+// the long-group arrays.  The caller then takes the general path and the index remembers the refusal for its next calls; a
+// query that only needs a larger slot (H) makes the stage run once more with it.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
