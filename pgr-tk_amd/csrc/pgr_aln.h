@@ -122,7 +122,7 @@ struct QueryFusedRun {
     QParams qp;
     AlnParams ap;
     uint32_t P = 0, H = 0;
-    bool enqueued = false, no_pinned = false;
+    bool enqueued = false, no_pinned = false, finish_called = false;
     QueryFusedRun(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries, uint64_t max_pairs, const QParams &qp, const AlnParams &ap);
     ~QueryFusedRun();
     QueryFusedRun(const QueryFusedRun &) = delete;

@@ -746,6 +746,8 @@ QueryFusedRun::QueryFusedRun(pgr_ctx *c, const pgr_index *i, uint32_t nq, uint64
 }
 
 QueryFusedRun::~QueryFusedRun() {
+    // an error between enqueue and finish: the DMA engine may still be writing the pinned block -- wait before it goes back to the pool
+    if (enqueued && !finish_called && block) (void)hipStreamSynchronize(ctx->stream);
     for (void *p : {d_cnt, d_offs, d_shp, d_sf, d_img, d_qrec, d_rec_off}) ctx->dfree(p);
     if (block) result_block_release(block);
 }
@@ -844,6 +846,7 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
 // behind a synchronization of the stream: the totals are in the mailbox.  declined: the batch is for the stage-by-stage path.
 int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *declined) {
     *declined = false;
+    finish_called = true;
     if (no_pinned || !enqueued) {
         *declined = true;
         return PGR_OK;
