@@ -64,11 +64,14 @@ __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint
 // stats[0] |= 1 not in (sid, frg_id) append order, stats[1] |= 1 not already in (h0, h1, sid, frg_id) order,
 // stats[2] = max(sid) + 1, stats[3] = max(h1) (h0 <= h1: bounds the radix passes of both key fields)
 __global__ __launch_bounds__(256) void raw_stats_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n,
-                                                        unsigned long long *__restrict__ stats) {
+                                                        unsigned long long *__restrict__ stats, uint64_t *__restrict__ h0_out,
+                                                        uint64_t *__restrict__ h1_out) {
     bool bad = false, bad_key = false;
     unsigned long long msid = 0, mh = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const pgr_frag_rec a = recs[i];
+        h0_out[i] = a.h0;  // the two hashes by themselves, in append order: sort keys without another pass over the 40-byte records
+        h1_out[i] = a.h1;
         msid = umax64(msid, (unsigned long long)a.sid + 1ull);
         mh = umax64(mh, a.h1);
         if (i + 1 < n) {
@@ -106,6 +109,102 @@ __global__ void gather_recs_kernel(const pgr_frag_rec *__restrict__ in, const ui
                                    pgr_frag_rec *__restrict__ out, uint64_t n) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[idx[i]];
+}
+
+// ---- sorting by ONE key.  Records appended in (sid, frg_id) order need the order (h0, h1, append position).  A stable sort by
+// h0 alone (half the radix passes) leaves every run of equal h0 in append order; what is missing is a stable sort by h1 INSIDE
+// the runs -- and nearly all runs are short: a shimmer that is smaller than both its neighbours is the h0 of two pairs (run of
+// 2), a key of a G-haplotype pangenome makes runs of ~2G.
+//   h1s[i] = h1 of the i-th record in h0 order
+__global__ void gather_h1_kernel(const uint32_t *__restrict__ idx, const uint64_t *__restrict__ h1_app, uint64_t n,
+                                 uint64_t *__restrict__ h1s) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) h1s[i] = h1_app[idx[i]];
+}
+//   runs of up to RUN_SMALL records: every record finds its run and its rank in it (h1, then position: stable) by itself.
+//   Longer runs: their first record finds the end (galloping + binary search) and puts (start, length) on a list for
+//   run_long_kernel; a run of more than RUN_LONG_MAX records raises counters[1] (the caller sorts by both keys instead).
+constexpr int RUN_SMALL = 16;
+constexpr uint32_t RUN_LONG_MAX = 4096;
+__global__ __launch_bounds__(256) void run_rank_kernel(const uint64_t *__restrict__ k, const uint64_t *__restrict__ h1s,
+                                                       const uint32_t *__restrict__ idx_in, uint64_t n, uint32_t *__restrict__ idx_out,
+                                                       uint2 *__restrict__ long_list, uint32_t *__restrict__ counters) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    const uint64_t key = live ? k[i] : 0;
+    bool leader = false;  // first record of a long run
+    uint32_t len = 0;
+    if (live) {
+        uint64_t s = i;
+        int steps = 0;
+        while (s > 0 && steps < RUN_SMALL && k[s - 1] == key) {
+            --s;
+            ++steps;
+        }
+        const bool start_found = s == 0 || k[s - 1] != key;
+        bool small = false;
+        uint64_t e = s + 1;
+        if (start_found) {
+            while (e < n && e - s <= (uint64_t)RUN_SMALL && k[e] == key) ++e;
+            small = e - s <= (uint64_t)RUN_SMALL;
+        }
+        if (small) {
+            const uint64_t mine = h1s[i];
+            uint32_t rank = 0;
+            for (uint64_t j = s; j < e; ++j) {
+                const uint64_t o = h1s[j];
+                rank += (o < mine || (o == mine && j < i)) ? 1u : 0u;
+            }
+            idx_out[s + rank] = idx_in[i];
+        } else if (start_found && s == i) {
+            uint64_t lo = e, step = 32;  // k[lo - 1] == key; first index behind the run lies in (lo - 1, n]
+            uint64_t hi = lo;
+            while (hi < n && k[hi] == key) {
+                lo = hi + 1;
+                hi = hi + step < n ? hi + step : n;
+                step <<= 1;
+            }
+            while (lo < hi) {  // k[lo - 1] == key, (hi == n or k[hi] != key)
+                const uint64_t mid = (lo + hi) >> 1;
+                if (k[mid] == key) lo = mid + 1;
+                else hi = mid;
+            }
+            const uint64_t L = lo - s;
+            if (L > (uint64_t)RUN_LONG_MAX) counters[1] = 1u;  // (benign race: every writer stores 1)
+            else {
+                leader = true;
+                len = (uint32_t)L;
+            }
+        }
+    }
+    const uint64_t m = __ballot(leader);
+    if (m) {  // one atomic per wavefront for its leaders
+        const uint32_t lane = threadIdx.x & 63;
+        uint32_t base = 0;
+        if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(counters, (uint32_t)__popcll(m));
+        base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+        if (leader) long_list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = make_uint2((uint32_t)i, len);
+    }
+}
+//   one workgroup per long run: the run's h1 in LDS, every record's rank by counting (O(L^2 / 256) steps: L is a few hundred for
+//   pangenome keys).
+__global__ __launch_bounds__(256) void run_long_kernel(const uint2 *__restrict__ long_list, const uint64_t *__restrict__ h1s,
+                                                       const uint32_t *__restrict__ idx_in, uint32_t *__restrict__ idx_out) {
+    __shared__ uint64_t h[RUN_LONG_MAX];
+    const uint2 r = long_list[blockIdx.x];
+    const uint64_t s = r.x;
+    const uint32_t L = r.y;
+    for (uint32_t j = threadIdx.x; j < L; j += 256) h[j] = h1s[s + j];
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < L; i += 256) {
+        const uint64_t mine = h[i];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < L; ++j) {
+            const uint64_t o = h[j];
+            rank += (o < mine || (o == mine && j < i)) ? 1u : 0u;
+        }
+        idx_out[s + rank] = idx_in[s + i];
+    }
 }
 
 __global__ void key_flags_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n, uint32_t *__restrict__ flags) {
@@ -409,12 +508,13 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
         ix->finalized = true;
         return PGR_OK;
     }
-    Tmp idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), flags(ctx), rank(ctx);
-    if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)))
+    Tmp idx_a(ctx), idx_b(ctx), keys_a(ctx), keys_b(ctx), h1_app(ctx), flags(ctx), rank(ctx);
+    if ((rc = idx_a.alloc(n * 4)) || (rc = idx_b.alloc(n * 4)) || (rc = keys_a.alloc(n * 8)) || (rc = keys_b.alloc(n * 8)) ||
+        (rc = h1_app.alloc(n * 8)))
         return rc;
     hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
-    // one look at the appended records: append order, key order, largest sid, largest hash
-    //   records appended in (sid, frg_id) order need only the two key passes of the stable LSD sort (64 of 176 key bits less);
+    // one look at the appended records: append order, key order, largest sid, largest hash (and h0 / h1 by themselves)
+    //   records appended in (sid, frg_id) order need no passes over the ids (64 of 176 key bits less);
     //   records already in full key order (concatenated key-range shards, csrc/exchange.hip) need no sort at all;
     //   the largest hash bounds the radix passes (shimmer hashes are minima of minima: a few bits below 2^56)
     Tmp d_stats(ctx);
@@ -422,7 +522,7 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     uint64_t stats[4] = {1, 1, 0, 0};
     PGR_HIP(ctx, hipMemsetAsync(d_stats.p, 0, 32, st));
     hipLaunchKernelGGL(raw_stats_kernel, dim3((uint32_t)std::min<uint64_t>(2048, (n + 255) / 256)), dim3(256), 0, st, ix->raw, n,
-                       d_stats.as<unsigned long long>());
+                       d_stats.as<unsigned long long>(), keys_a.as<uint64_t>(), h1_app.as<uint64_t>());
     PGR_HIP(ctx, hipMemcpyAsync(stats, d_stats.p, 32, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
     ix->sid_bound = stats[2];
@@ -432,12 +532,41 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
         PGR_HIP(ctx, hipMemcpyAsync(ix->recs, ix->raw, n * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, st));
     } else {
         const unsigned hb = full_sort ? 56u : std::max(1u, std::min(56u, bits_for(stats[3] + 1)));
-        const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
-        const unsigned bits[4] = {32, 32, hb, hb};
-        const int skip = (stats[0] || full_sort) ? 0 : 2;
-        if ((rc = sort_perm(ctx, ix->raw, n, fields + skip, bits + skip, 4 - skip, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
-                            keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
-            return rc;
+        bool sorted = false;
+        if (!stats[0] && !full_sort && !getenv("PGR_INDEX_TWO_KEY_SORT")) {
+            // append-ordered records: ONE stable radix sort by h0, then the runs of equal h0 are put in h1 order (see above)
+            const size_t tb = sort_pairs_temp_bytes(n);
+            Tmp h1s(ctx), longs(ctx), cnt(ctx);
+            if ((rc = ctx->ws_scan_tmp.ensure(ctx, tb)) || (rc = h1s.alloc(n * 8)) ||
+                (rc = longs.alloc((n / (RUN_SMALL + 1) + 64) * sizeof(uint2))) || (rc = cnt.alloc(16)))
+                return rc;
+            PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), idx_a.as<uint32_t>(),
+                                    idx_b.as<uint32_t>(), n, hb));
+            hipLaunchKernelGGL(gather_h1_kernel, grid_for(n), dim3(256), 0, st, idx_b.as<uint32_t>(), h1_app.as<uint64_t>(), n,
+                               h1s.as<uint64_t>());
+            PGR_HIP(ctx, hipMemsetAsync(cnt.p, 0, 16, st));
+            hipLaunchKernelGGL(run_rank_kernel, grid_for(n), dim3(256), 0, st, keys_b.as<uint64_t>(), h1s.as<uint64_t>(),
+                               idx_b.as<uint32_t>(), n, idx_a.as<uint32_t>(), longs.as<uint2>(), cnt.as<uint32_t>());
+            uint32_t c2[2] = {0, 0};
+            PGR_HIP(ctx, hipMemcpyAsync(c2, cnt.p, 8, hipMemcpyDeviceToHost, st));
+            PGR_HIP(ctx, hipStreamSynchronize(st));
+            if (!c2[1]) {
+                if (c2[0])
+                    hipLaunchKernelGGL(run_long_kernel, dim3(c2[0]), dim3(256), 0, st, longs.as<uint2>(), h1s.as<uint64_t>(),
+                                       idx_b.as<uint32_t>(), idx_a.as<uint32_t>());
+                sorted = true;
+            } else {  // a run of thousands of records with one h0 (a repeat family): the two-key sort below
+                hipLaunchKernelGGL(iota_kernel, grid_for(n), dim3(256), 0, st, idx_a.as<uint32_t>(), n);
+            }
+        }
+        if (!sorted) {
+            const int fields[4] = {0, 1, 2, 3};  // frg_id, sid, h1, h0 (least significant first)
+            const unsigned bits[4] = {32, 32, hb, hb};
+            const int skip = (stats[0] || full_sort) ? 0 : 2;
+            if ((rc = sort_perm(ctx, ix->raw, n, fields + skip, bits + skip, 4 - skip, idx_a.as<uint32_t>(), idx_b.as<uint32_t>(),
+                                keys_a.as<uint64_t>(), keys_b.as<uint64_t>())))
+                return rc;
+        }
         hipLaunchKernelGGL(gather_recs_kernel, grid_for(n), dim3(256), 0, st, ix->raw, idx_a.as<uint32_t>(), ix->recs, n);
     }
     // distinct keys -> key_off

@@ -523,3 +523,46 @@ def test_index_from_large_host_batch_pipelined(oracle, gpu_ctx):
         assert len(a) == len(b) > 1_000_000
         for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
             assert np.array_equal(a[f], b[f]), f
+
+
+def _records(gpu_ctx, sdb):
+    import ctypes as C
+    from pgrtk_amd import _ffi
+    p, n = C.c_void_p(), C.c_uint64()
+    gpu_ctx.check(_ffi.lib().pgr_index_download(gpu_ctx.handle, sdb._ix, C.byref(p), C.byref(n)))
+    return _ffi.take(p, int(n.value), _ffi.FRAG_REC)
+
+
+@pytest.mark.parametrize("shape", ["unique", "copies40", "copies3000", "mixed"])
+def test_index_sort_by_one_key_and_run_fixups(oracle, gpu_ctx, shape):
+    """pgr_index_finalize sorts append-ordered records by h0 alone and orders the runs of equal h0 by h1 afterwards: runs of up
+    to 16 records by themselves, up to 4096 one workgroup each, longer ones send the index to the two-key sort.  Every class
+    against the oracle's record order and against the two-key sort (PGR_INDEX_TWO_KEY_SORT=1)."""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(61)
+    if shape == "unique":
+        seqs = [seqgen.rnd(rng, 300_000) for _ in range(6)]
+    elif shape == "copies40":  # runs of ~80 records per h0
+        base = seqgen.rnd(rng, 60_000)
+        seqs = [base[int(rng.integers(0, 2000)):] for _ in range(40)] + [seqgen.rnd(rng, 50_000)]
+    elif shape == "copies3000":  # runs of ~6000: the fallback
+        base = seqgen.rnd(rng, 3_000)
+        seqs = [base] * 3000 + [seqgen.rnd(rng, 20_000)]
+    else:
+        base = seqgen.rnd(rng, 40_000)
+        seqs = [seqgen.rnd(rng, 100_000)] + [base] * 9 + [revcomp(base)] * 5 + [base[:20_000] * 3] + [seqgen.rnd(rng, 1000), b""]
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    ref = oix.records()
+    got = _records(gpu_ctx, sdb)
+    assert len(got) == len(ref)
+    for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+        assert np.array_equal(ref[f], got[f]), (shape, f)
+    os.environ["PGR_INDEX_TWO_KEY_SORT"] = "1"
+    try:
+        sdb2 = P.SeqIndexDB(ctx=gpu_ctx)
+        sdb2.load_from_seq_list([("s%d" % i, s) for i, s in enumerate(seqs)])
+        got2 = _records(gpu_ctx, sdb2)
+    finally:
+        del os.environ["PGR_INDEX_TWO_KEY_SORT"]
+    for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+        assert np.array_equal(got2[f], got[f]), (shape, f)

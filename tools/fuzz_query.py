@@ -118,13 +118,27 @@ def main():
     ctx = P.default_context(0)
     fails, chains = [], 0
     t0 = time.time()
-    for it in range(iters):
+    import signal
+
+    class Stop(Exception):
+        pass
+
+    def on_term(*_):  # `timeout` ends the run: report what was done
+        raise Stop()
+    signal.signal(signal.SIGTERM, on_term)
+    done = 0
+    try:
+      for it in range(iters):
         r = one_case(seed0 + it, ctx)
+        done = it + 1
         if isinstance(r, str):
             fails.append(r)
             print("FAIL", r, flush=True)
         else:
             chains += r[1]
+    except Stop:
+        print("(stopped by SIGTERM after %d of %d cases)" % (done, iters))
+        iters = done
     print("fuzz_query%s: %d cases (seeds %d..%d), %d chains compared, %d failures, %.0f s; batches by path: %d stage by stage, %d one "
           "wavefront per query, %d of those enqueued behind the shimmer pipeline" % (
               " short" if SHORT else "", iters, seed0, seed0 + iters - 1, chains, len(fails), time.time() - t0, PATHS[0],
