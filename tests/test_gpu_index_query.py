@@ -560,7 +560,7 @@ def test_index_sort_by_one_key_and_run_fixups(oracle, gpu_ctx, shape):
     os.environ["PGR_INDEX_TWO_KEY_SORT"] = "1"
     try:
         sdb2 = P.SeqIndexDB(ctx=gpu_ctx)
-        sdb2.load_from_seq_list([("s%d" % i, s) for i, s in enumerate(seqs)])
+        sdb2.load_from_seq_list([("s%d" % i, s) for i, s in enumerate(seqs)], w=80, k=56, r=4, min_span=64)
         got2 = _records(gpu_ctx, sdb2)
     finally:
         del os.environ["PGR_INDEX_TWO_KEY_SORT"]
