@@ -770,6 +770,9 @@ static int shmmrs_compute_small(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec
         if ((rc = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return bail(rc);
         launch_small_gather(st, (const pgr_mm128 *)ctx->ws_list_a.p, a.desc, d_counts, res->d_off, n, res->d_mm, cap_res);
         e = hipEventRecord(ctx->ev_end, st);
+        // (a consumer that does not wait for the host -- the query path -- enqueues its kernels here, see pgr_shmmrs_compute)
+        if (e == hipSuccess && ctx->post_enqueue && (rc = ctx->post_enqueue(res->d_mm, res->d_off, cap_res, res->d_off + n)))
+            return bail(rc);
         if (e == hipSuccess) e = hipMemcpyAsync(mbox, res->d_off, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipMemcpyAsync(mbox + n + 1, d_counts + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
