@@ -589,21 +589,31 @@ def target_100gbp(P, ctx, spec, args):
     1000 x 10 Mbp, contig ids 0 .. 9999) into ONE index on this GPU -- generation of the synthetic input on the device,
     shimmers, pair records, and the sort into the frag_map included (target: under 60 s on 8 GPUs)."""
     n_b, n_c, L = 10, 1000, 10_000_000
-    ctx.synchronize()
-    t0 = time.perf_counter()
-    ix = P.Index(spec, ctx=ctx)
-    for bi in range(n_b):
-        ids = list(range(bi * n_c, (bi + 1) * n_c))
-        b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=ctx, contig_ids=ids)
-        ix.add_resident(b, sids=ids)
-        del b
-    t1 = time.perf_counter()
-    ix.finalize()
-    ctx.synchronize()
-    t2 = time.perf_counter()
+
+    def once():
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        ix = P.Index(spec, ctx=ctx)
+        for bi in range(n_b):
+            ids = list(range(bi * n_c, (bi + 1) * n_c))
+            b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=ctx, contig_ids=ids)
+            ix.add_resident(b, sids=ids)
+            del b
+        t1 = time.perf_counter()
+        ix.finalize()
+        ctx.synchronize()
+        t2 = time.perf_counter()
+        return t0, t1, t2, ix.n_records, ix.n_keys
+    # twice: the first run allocates what it needs where the context's cache has no block of that size (the sort of 3 x 10^8
+    # records takes ~30 GB of temporaries: hipMalloc of that is 0.4-0.6 s, a fresh process pays 1.8 s in all), the second is the
+    # steady state of a streaming build
+    t0, t1, t2, n_rec, n_keys = once()
+    r0, r1, r2, _, _ = once()
     bp = n_b * n_c * L
     return {"bp": bp, "s": t2 - t0, "Gbp_per_s": bp / (t2 - t0) / 1e9, "batches_s": t1 - t0, "sort_into_frag_map_s": t2 - t1,
-            "index_records": ix.n_records, "index_keys": ix.n_keys, "n_gpus": 1,
+            "repeat": {"s": r2 - r0, "Gbp_per_s": bp / (r2 - r0) / 1e9, "batches_s": r1 - r0, "sort_into_frag_map_s": r2 - r1,
+                       "note": "the same again: every buffer comes from the context's cache"},
+            "index_records": n_rec, "index_keys": n_keys, "n_gpus": 1,
             "target": "BASELINE.json: >= 100 Gbp SHIMMER-indexed in under 60 s on 8 x MI355X",
             "what": "%d batches of %d x %d bp distinct synthetic contigs generated on the device, one index (sorted CSR) at the end" %
                     (n_b, n_c, L)}
