@@ -1719,7 +1719,17 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     // synchronization: pair records and offsets are derived on the device, the whole query is one host wait.  A batch that does
     // not fit the guess declines on the device and is done again below with what the host knows by then.
     const bool fused_on = ix->n && ix->fused_skip.load(std::memory_order_relaxed) == 0;
-    const uint32_t pairs_hint = ix->fused_pairs.load(std::memory_order_relaxed);
+    uint32_t pairs_hint = ix->fused_pairs.load(std::memory_order_relaxed);
+    if (!pairs_hint && fused_on && n_queries) {
+        // first batch on this index: guess the pairs of the longest query from the spec's shimmer density (level-1 minimizers
+        // 2 / (w + 1) per base, each of the two reductions keeps ~2 / (r + 1) of them) with room; a wrong guess costs a repeat
+        uint32_t max_len = 0;
+        for (uint32_t c = 0; c < b->n; ++c) max_len = std::max(max_len, b->h_len[c]);
+        const pgr_spec &sp = ix->spec;
+        const double keep = sp.r > 1 ? 2.0 / (double)(sp.r + 1) : 1.0;
+        const double dens = sp.sketch ? 1.0 / (double)(1ull << (4 + sp.r)) : 2.0 / (double)(sp.w + 1) * keep * keep;
+        pairs_hint = (uint32_t)std::min<double>((double)max_len * dens * 1.6 + 4.0, 1e9);
+    }
     std::unique_ptr<QueryFusedRun> chained;
     if (fused_on && pairs_hint && query_fused_eligible(n_queries, pairs_hint, max_aln_span) && !getenv("PGR_NO_QUERY_CHAINING")) {
         chained.reset(new QueryFusedRun(ctx, ix, n_queries, pairs_hint, fqp, fap));

@@ -81,7 +81,7 @@ def test_short_query_batches_take_the_fused_path_and_match(oracle, gpu_ctx, vari
     queries += [b"", seqgen.rnd(rng, 50), seqgen.rnd(rng, 5000), core[0][:9000], revcomp(core[1][100:7000]), b"N" * 3000,
                 core[2][:4000] + b"NNNN" + core[2][4000:8000]]
     got = sdb.query_fragments_to_hps(queries, *_args(kw))
-    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert gpu_ctx.last_query_prof()["path"] in (1, 2)
     assert _check_vs_oracle(oix, queries, got, kw) > 100
     assert _general(sdb, queries, kw) == got
     assert gpu_ctx.last_query_prof()["path"] == 0
@@ -128,7 +128,7 @@ def test_batches_that_do_not_fit_decline_and_fall_back(oracle, gpu_ctx):
     sdb2, oix2 = _build_pair(oracle, gpu_ctx, copies)
     q2 = [core[0][1000:9000], core[0][5000:9000], seqgen.rnd(rng, 3000)]
     got2 = sdb2.query_fragments_to_hps(q2, *_args(KW))
-    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert gpu_ctx.last_query_prof()["path"] in (1, 2)
     assert _check_vs_oracle(oix2, q2, got2, KW) > 5
     assert _general(sdb2, q2, KW) == got2
     # (c) more hits than the largest slot: declined on the device, answered by the stage-by-stage kernels
@@ -166,16 +166,17 @@ def test_many_short_queries_equal_the_stage_by_stage_path(oracle, gpu_ctx):
         q = src[a:a + int(rng.integers(2000, 10000))]
         queries.append(revcomp(q) if i % 2 else q)
     got = sdb.query_fragments_to_hps(queries, *_args(KW))
-    assert gpu_ctx.last_query_prof()["path"] == 1
+    assert gpu_ctx.last_query_prof()["path"] in (1, 2)
     assert _general(sdb, queries, KW) == got
     idx = [int(i) for i in rng.integers(0, 5000, 60)]
     assert _check_vs_oracle(oix, [queries[i] for i in idx], [got[i] for i in idx], KW) >= 60
 
 
 def test_second_batch_on_an_index_is_enqueued_behind_the_shimmer_pipeline(oracle, gpu_ctx):
-    """From the second batch on an index on, the per-query kernel runs behind the shimmer pipeline without a host wait in between
-    (pgr_query_prof.path == 2): pair records and their offsets are derived on the device from a guess of the queries' sizes.  Same
-    results; a batch that outgrows the guess is answered all the same."""
+    """The per-query kernel runs behind the shimmer pipeline without a host wait in between (pgr_query_prof.path == 2): pair
+    records and their offsets are derived on the device from a guess of the queries' sizes (the spec's shimmer density for the
+    first batch on an index, the previous batch afterwards).  Same results; a batch that outgrows the guess is answered all the
+    same (path 1: done again with the host's numbers)."""
     rng = np.random.default_rng(45)
     seqs = [seqgen.rnd(rng, 1_000_000) for _ in range(24)]
     sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
@@ -192,7 +193,7 @@ def test_second_batch_on_an_index_is_enqueued_behind_the_shimmer_pipeline(oracle
     try:
         q1 = batch(300, 2000, 9000)
         g1 = sdb.query_fragments_to_hps(q1, *_args(KW))
-        assert gpu_ctx.last_query_prof()["path"] == 1
+        assert gpu_ctx.last_query_prof()["path"] == 2  # (the first batch too: the guess comes from the spec's shimmer density)
         g1b = sdb.query_fragments_to_hps(q1, *_args(KW))
         assert gpu_ctx.last_query_prof()["path"] == 2 and g1b == g1
         assert _check_vs_oracle(oix, q1[:40], g1b[:40], KW) >= 40
