@@ -214,8 +214,8 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
         "counts": {k: int(prof[k]) for k in ("n_query_pairs", "n_signatures", "n_hits", "n_groups", "n_chains", "n_hps")},
         "stage_ms": {k: float(prof[k]) for k in ("shmmr_ms", "lookup_ms", "chain_ms", "result_ms", "total_ms")},
         "path": ("one wavefront per query behind the shimmers (csrc/query_fused.hip): lookup, count filters, grouping, chaining "
-                 "DP in one kernel" + ("; enqueued behind the shimmer pipeline without a host wait in between (second and later "
-                                       "batches on an index): stage_ms.shmmr_ms holds the device time of both, the call has ONE "
+                 "DP in one kernel" + ("; enqueued behind the shimmer pipeline without a host wait in between: "
+                                       "stage_ms.shmmr_ms holds the device time of both, the call has ONE "
                                        "synchronization" if int(prof.get("path", 0)) == 2 else
                                        "; stage_ms.chain_ms holds all of it, download included") if fused else
                  "one kernel per stage over the whole batch (csrc/index.hip)"),

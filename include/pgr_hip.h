@@ -284,8 +284,8 @@ typedef struct {
     float total_ms;
     /* 0: one kernel per stage over the whole batch (any batch).  1: one wavefront per query does every stage behind the pair
      * records (batches of short queries, csrc/query_fused.hip): lookup_ms and result_ms are 0, chain_ms holds that stage.
-     * 2: the same, enqueued behind the shimmer pipeline without a host wait in between (from the second batch on an index
-     * on): shmmr_ms holds the device time of both, the call has ONE synchronization.                                       */
+     * 2: the same, enqueued behind the shimmer pipeline without a host wait in between (the usual case; 1 when the guess
+     * of the queries' sizes was too small): shmmr_ms holds the device time of both, the call has ONE synchronization.      */
     uint32_t path;
     uint32_t _pad;
 } pgr_query_prof;
