@@ -57,9 +57,17 @@ def main():
     ctx = P.default_context(0)
     fails, bases = [], 0
     t0 = time.time()
+    import signal
+    stop = []
+    signal.signal(signal.SIGTERM, lambda *_: stop.append(1))  # `timeout` ends the run: finish the case, report what was done
+    done = 0
     with ThreadPoolExecutor(16) as pool:
         log = open(os.environ["FUZZ_LOG"], "w") if os.environ.get("FUZZ_LOG") else None
         for it in range(iters):
+            if stop:
+                print("(stopped by SIGTERM after %d of %d cases)" % (done, iters))
+                break
+            done = it + 1
             if log:  # the last line names the case a crash happened in
                 log.seek(0)
                 log.write("%d\n" % (seed0 + it))
@@ -73,6 +81,7 @@ def main():
                 print("FAIL", r, flush=True)
             else:
                 bases += r[1]
+    iters = done
     print("fuzz_parity: %d cases (seeds %d..%d), %.2f Gbp, %d failures, %.0f s" % (iters, seed0, seed0 + iters - 1, bases / 1e9,
                                                                                   len(fails), time.time() - t0))
     sys.exit(1 if fails else 0)
