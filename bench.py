@@ -38,6 +38,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 N_SIMD = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 PCIE_PEAK_GBPS = 63.0       # PCIe Gen5 x16, one direction
+QUERY_PROFILE = "r03_query"  # profiles/<dir> whose counters / kernel trace the query leg's replayed fields come from
 
 
 def committed(*parts):
@@ -61,6 +62,10 @@ def valu_issue(bp_per_launch, launch_ms):
     peak2 = N_SIMD * CLOCK_GHZ * 1e9 / 2.0  # the guide's figure: a wave64 VALU instruction issues over 2 cycles
     out = {"wave64_valu_insts_per_launch": insts, "valu_insts_per_bp": insts * 64.0 / bp_per_launch,
            "achieved_Ginst_per_s": ach / 1e9, "peak_Ginst_per_s": peak2 / 1e9, "frac_of_peak": ach / peak2,
+           "source": "REPLAYED counters: the instruction counts come from the committed PMC passes of this workload "
+                     "(profiles/traffic.json <- profiles/%s/pmc_summary.json), not from this run; the launch time they are "
+                     "divided by (avg_launch_ms) is measured live.  Instruction counts are a property of the code object: "
+                     "profile_consistency says whether the shipped kernel is still the profiled one" % t.get("profile"),
            "peak_note": "MI355X_MICROARCH.md: SIMD-32, 2 cycles per wave64 VALU instruction, 1024 SIMDs x 2.4 GHz; measured on this "
                         "chip (profiles/r03_ubench): 2.4 cycles only for add/sub/and/or/xor/not/mov/right shifts, 4.15-4.27 for every "
                         "other opcode (left shifts, 64-bit ops, multiplies, compares, selects, f64 min/max)"}
@@ -84,6 +89,23 @@ def valu_issue(bp_per_launch, launch_ms):
                     "cycle_weighted_bound_ms": bound_ms, "frac_of_cycle_weighted_bound": min(1.0, bound_ms / launch_ms),
                     "bound_sources": ["profiles/traffic.json", "profiles/" + t.get("valu_cycles", "r03_ubench/valu_cycles.json"),
                                       "profiles/" + t.get("isa_histogram", "r03_tile/isa_histogram.json")]})
+    return out
+
+
+def profile_consistency(tr, live_ms, bp_per_launch):
+    """does the committed profile still describe the kernel that just ran?  The rocprofv3 average launch duration of the
+    dominant kernel in profiles/<profile>/kernel_stats.csv against this run's HIP-event average (5 % tolerance: the boxes'
+    clocks differ by 1-2 %), and the code object's VALU instruction count against the committed opcode histogram"""
+    import csv
+    out = {"profile": tr.get("profile"), "live_avg_launch_ms": live_ms}
+    try:
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", tr["profile"], "kernel_stats.csv"))))
+        row = [r for r in rows if tr["kernel"] in r["Name"] and "80, 56, false" in r["Name"]][0]
+        ms = float(row["AverageNs"]) / 1e6
+        out.update({"committed_avg_launch_ms": ms, "drift": live_ms / ms - 1.0,
+                    "ok": bool(tr.get("bp_per_launch") == bp_per_launch and abs(live_ms / ms - 1.0) <= 0.05)})
+    except Exception as e:  # noqa: BLE001
+        out.update({"ok": False, "error": repr(e)[:200]})
     return out
 
 
@@ -193,8 +215,8 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
                 ok += 1
     n_hps = int(len(r["hps"]))
     algo = 24.0 * n_hps + 0.25 * prof["query_bases"] + 17.0 * prof["n_signatures"]
-    qk = committed("r03_query", "summary.json") or {}
-    qpmc = (committed("r03_query", "pmc_summary.json") or {}).get("per_query_batch", {})
+    qk = committed(QUERY_PROFILE, "summary.json") or {}
+    qpmc = (committed(QUERY_PROFILE, "pmc_summary.json") or {}).get("per_query_batch", {})
     fused = int(prof.get("path", 0)) in (1, 2)
     out = {
         "workload": "BASELINE.json configs[2]: %d x %d bp queries (50%% reverse complement) against the %d x %d bp index, "
@@ -222,18 +244,20 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
         "roofline": {
             "bound": "hbm", "achieved": algo / t_res / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": algo / t_res / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": algo,
-            "traffic": qpmc.get("hbm_bytes"),  # HBM bytes per batch by PMC (profiles/r03_query/pmc_summary.json), all kernels
+            "traffic": qpmc.get("hbm_bytes"),  # HBM bytes per batch by PMC, all kernels
+            "source": {"achieved, frac, algorithmic_bytes": "measured in this run",
+                       "traffic": "REPLAYED from profiles/%s/pmc_summary.json (PMC passes of the same batch), not from this run" % QUERY_PROFILE,
+                       "dominant_kernel, dominant_kernel_ms, kernel_ms_total, launches":
+                           "REPLAYED from profiles/%s/summary.json (rocprofv3 --kernel-trace of the same batch), not from this run" % QUERY_PROFILE},
             "algorithmic_bytes_formula": "24 B x hit pairs emitted + 0.25 B x query bases + 17 B x looked-up signatures "
                                          "(SURVEY.md 8d); signatures counted on the device",
             "dominant_kernel": qk.get("dominant_kernel"), "dominant_kernel_ms": qk.get("dominant_kernel_ms"),
             "kernel_ms_total": qk.get("kernel_ms_total"), "launches": qk.get("launches"),
-            "what_holds": ("latency and PCIe: the batch moves ~37 MB of HBM traffic (5 us at the roofline); %d kernel launches and ONE "
-                           "host wait.  The shimmers of 10 000 x 10 kbp take 0.45 ms (the tile kernel 0.26: a 10 kbp query fills 2.6 "
-                           "tiles), the per-query kernel 0.09 ms (a wavefront's chain of ~10 dependent memory accesses, ~6 000 "
-                           "wavefronts in flight), the 7 MB of chains cross PCIe in 0.14 ms (52 GB/s)" if fused else
-                           "latency: the batch moves ~37 MB (5 us of HBM time); %d kernel launches, 4 host round trips (one per "
-                           "data-dependent buffer size), the serial critical path of the chaining DP and the PCIe download of "
-                           "the chains take the rest") % (qk.get("launches") or 0),
+            "what_holds": ("latency and PCIe, not HBM: the batch's algorithmic bytes take microseconds at the roofline; the time is the "
+                           "chain of dependent launches (stage_ms, measured here), one host wait and the chains' way back over PCIe.  "
+                           "Per-kernel times: profiles/%s/kernel_stats.csv" % QUERY_PROFILE) if fused else
+                          ("latency: one kernel per stage over the whole batch, four host round trips (one per data-dependent "
+                           "buffer size), the serial critical path of the chaining DP and the PCIe download of the chains"),
         },
     }
     return out, ix
@@ -619,6 +643,19 @@ def target_100gbp(P, ctx, spec, args):
                     (n_b, n_c, L)}
 
 
+def self_spawn(n):
+    """re-run this command line under torch.distributed.run with n ranks on this node; returns its exit code"""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: starting %s" % (n, " ".join(cmd[1:9])), file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -640,16 +677,21 @@ def main():
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="plumbing test: run the process group + exchange code path even with one rank")
+    ap.add_argument("--exchange-timeout", type=int, default=120,
+                    help="N>1: seconds the library waits in ncclCommInitRank / for a collective before it aborts its communicator "
+                         "(context option exchange_timeout_s); the bench then falls back to the torch.distributed transport")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one process per GPU, rendezvous on 127.0.0.1)
+        sys.exit(self_spawn(args.gpus))
     import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         if rank == 0:
-            print("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" %
-                  (args.gpus, world), file=sys.stderr)
+            print("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world), file=sys.stderr)
         sys.exit(2)
     if args.single_device:
         local_rank = 0
@@ -670,6 +712,7 @@ def main():
     import pgrtk_amd as P
     from pgrtk_amd import exchange
     ctx = P.Context(local_rank)
+    ctx.set_option("exchange_timeout_s", args.exchange_timeout)
     spec_t = (80, 56, 4, 64)
     spec = P.make_spec(*spec_t)
     if args.strong:
@@ -687,6 +730,7 @@ def main():
     rec_buf = torch.empty((int(probe.n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64, device=dev)
     del probe
     xch = None
+    create_ok = 0
     do_exchange = use_dist and not args.no_exchange
     use_abi = do_exchange and args.exchange == "abi" and args.backend == "nccl"
     if use_abi:
@@ -698,16 +742,24 @@ def main():
         except Exception as e:  # noqa: BLE001
             print("rank %d: pgr_exchange_create failed (%r): torch.distributed transport instead" % (rank, e), file=sys.stderr)
             xch, ok = None, 0
-        flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+        create_ok = ok
+    if use_dist:
+        dist.barrier()  # creates the communicator here, not inside the first timed step
+        torch.cuda.synchronize()
+    state = {}
+    fallback = {"note": None}
+
+    def agree_or_fall_back(ok, what):
+        """all ranks learn whether the library's own RCCL transport worked on EVERY rank; if not, all switch to
+        torch.distributed together (a rank that timed out has aborted its communicator and says so in `what`)"""
+        nonlocal xch, use_abi
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:
             if xch is not None:
                 xch.close()
             xch, use_abi = None, False
-    if use_dist:
-        dist.barrier()  # creates the communicator here, not inside the first timed step
-        torch.cuda.synchronize()
-    state = {}
+            fallback["note"] = what
 
     def step():
         sh = batch.shmmrs(spec)
@@ -739,6 +791,21 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    if use_abi or (do_exchange and args.exchange == "abi" and args.backend == "nccl"):
+        agree_or_fall_back(bool(create_ok), "pgr_exchange_create did not succeed on every rank within %d s: torch.distributed "
+                                            "transport for the whole run" % args.exchange_timeout)
+    if use_abi:
+        # the first exchange over the library's communicator, outside the clock and under its watchdog: a collective that
+        # does not complete aborts the communicator on that rank, and every rank falls back together
+        try:
+            step()
+            ok = 1
+        except Exception as e:  # noqa: BLE001
+            print("rank %d: first pgr_exchange_shard_records failed (%r): torch.distributed transport instead" % (rank, e),
+                  file=sys.stderr)
+            ok = 0
+        agree_or_fall_back(bool(ok), "the first pgr_exchange_shard_records did not complete on every rank within %d s: "
+                                     "torch.distributed transport for the whole run" % args.exchange_timeout)
     for _ in range(args.warmup):
         step()
     sync()
@@ -799,6 +866,8 @@ def main():
             exch_check = {
                 "what": "key-range sharded merge: every pair record went to the rank owning its range of first hashes",
                 "transport": "pgr_exchange_shard_records (RCCL behind the C ABI)" if use_abi else "torch.distributed (%s)" % args.backend,
+                "rccl_ranks_in_the_librarys_communicator": xch.world if (use_abi and xch is not None) else 0,
+                "exchange_fallback": fallback["note"],
                 "records_sent_all_ranks": sum(v["n_sent"] for v in allv), "records_in_shards": n_tot,
                 "checksum_of_sent_records": ["%016x" % x for x in s_sent], "checksum_of_shard_records": ["%016x" % x for x in s_shard],
                 "content_match": bool(s_sent == s_shard and n_tot == sum(v["n_sent"] for v in allv)),
@@ -855,6 +924,10 @@ def main():
                 "bound": "valu", "kernel": "level1_tile_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": tr.get("hbm_bytes_per_launch") if tr.get("bp_per_launch") == bases_tiled else None,
+                "source": {"achieved, frac, avg_launch_ms": "measured in this run (HIP events around the kernel on its own stream)",
+                           "traffic": "REPLAYED from profiles/traffic.json <- profiles/%s/pmc_summary.json (separate --pmc passes of "
+                                      "this command), not from this run" % tr.get("profile")},
+                "profile_consistency": profile_consistency(tr, l1_ms, bases_tiled),
                 "algorithmic_bytes_per_bp": ALGO_BYTES_PER_BP, "bp_per_launch": bases_tiled,
                 "avg_launch_ms": l1_ms,
                 "valu_issue": valu_issue(bases_tiled, l1_ms),

@@ -77,6 +77,21 @@ void pgr_ctx_destroy(pgr_ctx *ctx);
 const char *pgr_last_error(const pgr_ctx *ctx); /* ctx may be NULL: last create error */
 void pgr_free(void *p);
 const char *pgr_version(void);
+/* Tuning and A/B switches of a context.  Defaults come from the environment ONCE, at pgr_ctx_create (PGR_<NAME IN UPPER
+ * CASE>=<integer>); afterwards only these two calls change or read them -- no entry point looks at the environment.
+ *   debug, debug_times        progress lines / a host-side timeline on stderr
+ *   no_small_path             never the one-workgroup-per-contig kernel for batches of short contigs
+ *   no_pipeline               never cut a large host batch into staged sub-batches
+ *   early_sync_bp             batches of at least this many bases read the level-1 flags before the list stage (2^30)
+ *   gpu_pack                  ASCII over PCIe + pack kernel instead of the CPU packer (the round-2 host path)
+ *   index_full_sort, index_two_key_sort    pgr_index_finalize: force the four-field / the two-key sort
+ *   no_fused_query, no_query_chaining, query_global_sort, fused_query_hits   query path variants
+ *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on ncclCommInitRank and on every wait for a collective
+ *                             (300; 0 = wait for ever); on a timeout the communicator is aborted and the call fails
+ *   no_island_relay           exact islands: the round-3 seam correction (one seam per host round), for A/B timing
+ * Unknown names: PGR_ERR_INVALID_ARG. */
+int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value);
+int pgr_ctx_get_option(const pgr_ctx *ctx, const char *name, int64_t *value);
 
 /* ------------------------------------------------------------------ B1: sequence_to_shmmrs
  * Replaces shmmrutils::sequence_to_shmmrs (pgr-db/src/shmmrutils.rs:657-669) as called

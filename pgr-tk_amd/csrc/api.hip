@@ -43,6 +43,24 @@ extern "C" const char *pgr_last_error(const pgr_ctx *ctx) { return ctx ? ctx->er
 
 extern "C" void pgr_free(void *p) { free(p); }
 
+namespace {
+struct OptionName {
+    const char *name;
+    int64_t pgr_ctx::Options::*field;
+};
+const std::vector<OptionName> &option_names() {
+    using O = pgr_ctx::Options;
+    static const std::vector<OptionName> v = {
+        {"debug", &O::debug}, {"debug_times", &O::debug_times}, {"gpu_pack", &O::gpu_pack}, {"no_small_path", &O::no_small_path},
+        {"no_pipeline", &O::no_pipeline}, {"early_sync_bp", &O::early_sync_bp}, {"index_full_sort", &O::index_full_sort},
+        {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
+        {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
+        {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
+        {"no_island_relay", &O::no_island_relay}};
+    return v;
+}
+}  // namespace
+
 extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     if (!out) return PGR_ERR_INVALID_ARG;
     *out = nullptr;
@@ -83,8 +101,38 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
         delete ctx;
         return PGR_ERR_DEVICE;
     }
+    for (const OptionName &o : option_names()) {
+        std::string env = "PGR_";
+        for (const char *c = o.name; *c; ++c) env += (char)toupper((unsigned char)*c);
+        if (const char *v = getenv(env.c_str())) {
+            char *end = nullptr;
+            const long long x = strtoll(v, &end, 10);
+            ctx->opt.*(o.field) = (end && end != v) ? (int64_t)x : 1;  // PGR_X=1, PGR_X=<number>, or a bare PGR_X= / PGR_X=on
+        }
+    }
     *out = ctx;
     return PGR_OK;
+}
+
+extern "C" int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!name) return ctx->fail(PGR_ERR_INVALID_ARG, "null option name");
+    for (const OptionName &o : option_names())
+        if (!strcmp(o.name, name)) {
+            ctx->opt.*(o.field) = value;
+            return PGR_OK;
+        }
+    return ctx->fail(PGR_ERR_INVALID_ARG, std::string("unknown option: ") + name);
+}
+
+extern "C" int pgr_ctx_get_option(const pgr_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return PGR_ERR_INVALID_ARG;
+    for (const OptionName &o : option_names())
+        if (!strcmp(o.name, name)) {
+            *value = ctx->opt.*(o.field);
+            return PGR_OK;
+        }
+    return PGR_ERR_INVALID_ARG;
 }
 
 extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
@@ -288,7 +336,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     if (st != ctx->stream && hipStreamWaitEvent(st, ctx->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
         return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
     const bool packed = src.planes != nullptr;
-    const bool gpu_pack = !packed && getenv("PGR_GPU_PACK") != nullptr;  // A/B switch: round-2 path (ASCII over PCIe + pack kernel)
+    const bool gpu_pack = !packed && ctx->opt.gpu_pack;  // A/B switch: round-2 path (ASCII over PCIe + pack kernel)
     if (gpu_pack) return batch_stage_ascii_gpu(ctx, b, n, src.seqs, src.lens, st, ev0, ev1, err);
     constexpr uint64_t PIECE = 1ull << 16;        // words per host job (2 MiB of ASCII / 0.75 MiB packed)
     constexpr uint64_t WIN_WORDS = 40 * PIECE;    // 84 Mbp = 30 MiB of planes + validity per window
@@ -369,7 +417,7 @@ static int batch_from_host(pgr_ctx *ctx, uint32_t n, const StageSrc &src, pgr_ba
     *out = nullptr;
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     pgr_batch *b = nullptr;
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const bool dbg = ctx->opt.debug != 0;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = batch_alloc(ctx, n, src.lens, &b);
     if (rc) return rc;
@@ -594,7 +642,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             s_out[todo[q]] = r_out[q];
             status[todo[q]] = r_stat[q];
         }
-        if (getenv("PGR_DEBUG"))
+        if (ctx->opt.debug)
             fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu\n", round, nq,
                     islands.size(), (unsigned long long)next_region);
         // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last)
@@ -621,7 +669,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             const bool has_prev = i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island;
             if (h.probe) {
                 if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
-                    if (getenv("PGR_DEBUG")) {
+                    if (ctx->opt.debug) {
                         const ChunkState &p = s_in[i], &q = s_out[i - 1];
                         fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
                                 "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
@@ -697,8 +745,12 @@ static int shmmrs_compute_small(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec
     // on one wavefront, then the list stage between barriers).  Measured on 10 kbp contigs: 0.045 ms + 58 ns per contig against
     // 0.13 ms + 34 ns per contig for the general pipeline -- the lines cross near 3500 contigs (35 Mbp).
     if (n == 0 || n > SMALL_MAX_CONTIGS || b->total_bases > SMALL_MAX_BASES || spec->sketch || spec->w < (uint32_t)L1_MIN_W ||
-        b->host_saw_invalid || getenv("PGR_NO_SMALL_PATH"))
+        b->host_saw_invalid || ctx->opt.no_small_path)
         return PGR_OK;
+    if (ctx->skip_small_once) {  // shmmr_batch_small has just run this kernel on these contigs and was handed them back
+        ctx->skip_small_once = false;
+        return PGR_OK;
+    }
     uint32_t max_len = 0;
     uint64_t total_slots = 0;
     for (uint32_t c = 0; c < n; ++c) {
@@ -821,7 +873,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!b || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
-    const bool dbg_t = getenv("PGR_DEBUG_TIMES") != nullptr;  // host-side timeline of the call on stderr
+    const bool dbg_t = ctx->opt.debug_times != 0;  // host-side timeline of the call on stderr
     const auto dbg_t0 = std::chrono::steady_clock::now();
     auto dbg_lap = [&](const char *what) {
         if (dbg_t)
@@ -933,8 +985,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     // big batches look at the level-1 status words once before the list stage is enqueued (one more round trip, ~45 us):
     // if a tile asked for the exact path the islands are fixed first and the list stage runs once.  Smaller batches run
     // optimistically and repeat stages 2-4 in the (rare) flagged case: cheaper than the round trip below ~1 Gbp.
-    uint64_t early_bp = 1ull << 30;
-    if (const char *e = getenv("PGR_EARLY_SYNC_BP")) early_bp = strtoull(e, nullptr, 10);
+    const uint64_t early_bp = (uint64_t)std::max<int64_t>(0, ctx->opt.early_sync_bp);
     // (a batch the host packer has counted non-ACGT bytes in is known to need islands: look at the flags before the list stage)
     const bool early_sync = b->total_bases >= early_bp || !serial.empty() || b->host_saw_invalid;
     const bool pad_fix = padding && !sketch && spec->r > 1;
@@ -1454,8 +1505,8 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
 // pinned windows and the pack kernel (copy stream) while sub-batch i is consumed (shimmers, records, download) on the
 // context's stream.  The PCIe transfer of the ASCII input is the longest stage (48 GB/s); the pipeline hides the rest
 // behind it.  consume(batch, c0, c1) gets contigs [c0, c1) of the call, resident on the GPU.
-bool pgr::worth_pipelining(uint32_t n, const uint64_t *lens) {
-    if (n < 2 || getenv("PGR_NO_PIPELINE")) return false;
+bool pgr::worth_pipelining(const pgr_ctx *ctx, uint32_t n, const uint64_t *lens) {
+    if (n < 2 || ctx->opt.no_pipeline) return false;
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
     return total_bp >= (512ull << 20);
@@ -1523,7 +1574,7 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
             destroy_all();
             return rc;
         }
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const bool dbg = ctx->opt.debug != 0;
     const auto t_start = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count(); };
     if (dbg) fprintf(stderr, "[pgr] pipelined call: %zu sub-batches, allocated at %.2f ms\n", subs.size(), since());
@@ -1535,7 +1586,7 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
     std::atomic<bool> cancel{false};
     // one event per sub-batch, recorded behind its last copy on the copy stream: the consumer's stream waits for it on the
     // device, the staging thread never blocks on a finished sub-batch and keeps its two windows rolling into the next one
-    const bool legacy = getenv("PGR_GPU_PACK") != nullptr && !src.planes;
+    const bool legacy = ctx->opt.gpu_pack && !src.planes;
     std::vector<hipEvent_t> ready(subs.size(), nullptr);
     for (auto &e : ready)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
@@ -1587,6 +1638,12 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
         }
         rc = consume(subs[i].b, subs[i].c0, subs[i].c1);
         if (dbg) fprintf(stderr, "[pgr]   sub-batch %zu consumed %.2f -> %.2f ms\n", i, tc0, since());
+        if (rc) {
+            // a consumer that failed before its own synchronization: this sub-batch's copies (the batch owns the pageable source
+            // of one of them) and kernels may still be in flight
+            (void)hipEventSynchronize(ready[i]);
+            (void)hipStreamSynchronize(ctx->stream);
+        }
         pgr_batch_destroy(subs[i].b);
         subs[i].b = nullptr;
     }
@@ -1614,7 +1671,7 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     bool first = true;
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const bool dbg = ctx->opt.debug != 0;
     // The download of sub-batch i runs on its own stream while sub-batch i + 1 computes: its list goes to one of two pinned
     // blocks asynchronously, the host copies it out (pool threads) when the next compute call has returned.
     struct Pending {
@@ -1728,7 +1785,7 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
 static int shmmr_batch_small(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, const StageSrc &src, const uint32_t *rids,
                              pgr_mm128 **out_mm, uint64_t **out_off, bool &handled) {
     handled = false;
-    if (spec->sketch || spec->w < (uint32_t)L1_MIN_W || n == 0 || n > SMALL_MAX_CONTIGS || getenv("PGR_NO_SMALL_PATH")) return PGR_OK;
+    if (spec->sketch || spec->w < (uint32_t)L1_MIN_W || n == 0 || n > SMALL_MAX_CONTIGS || ctx->opt.no_small_path) return PGR_OK;
     uint64_t total_bp = 0, total_words = 0, total_slots = 0;
     for (uint32_t i = 0; i < n; ++i) {
         if (src.lens[i] > SMALL_MAX_LEN) return PGR_OK;
@@ -1814,7 +1871,10 @@ static int shmmr_batch_small(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, con
     launch_small_shmmr(ctx->stream, a);
     if (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess)
         return ctx->fail(PGR_ERR_DEVICE, "small-batch kernel failed on the device");
-    if (counts[n]) return PGR_OK;  // a contig needs the exact state machine / a bigger list: general path
+    if (counts[n]) {  // a contig needs the exact state machine / a bigger list: general path, and not this kernel again
+        ctx->skip_small_once = true;
+        return PGR_OK;
+    }
     uint64_t *off = (uint64_t *)malloc(((size_t)n + 1) * sizeof(uint64_t));
     if (!off) return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     uint64_t tot = 0;
@@ -1846,7 +1906,7 @@ static int shmmr_batch_host(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, cons
         bool handled = false;
         if ((rc = shmmr_batch_small(ctx, spec, n, src, rids, out_mm, out_off, handled)) || handled) return rc;
     }
-    if (worth_pipelining(n, src.lens)) return shmmr_batch_pipelined(ctx, spec, n, src, rids, padding, out_mm, out_off);
+    if (worth_pipelining(ctx, n, src.lens)) return shmmr_batch_pipelined(ctx, spec, n, src, rids, padding, out_mm, out_off);
     pgr_batch *b = nullptr;
     if ((rc = batch_from_host(ctx, n, src, &b))) return rc;
     pgr_shmmrs *s = nullptr;

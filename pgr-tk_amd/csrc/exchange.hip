@@ -18,9 +18,14 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "pgr_ctx.h"
@@ -33,6 +38,7 @@ struct Rccl {
     ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
     ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
@@ -70,6 +76,7 @@ Rccl &rccl() {
         r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId");
         r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
+        r.CommAbort = (decltype(r.CommAbort))sym("ncclCommAbort");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.Send = (decltype(r.Send))sym("ncclSend");
         r.Recv = (decltype(r.Recv))sym("ncclRecv");
@@ -94,7 +101,43 @@ struct pgr_exchange {
     bool in_flight = false;
     std::vector<uint64_t> splitters;  // world - 1 key-range boundaries of the last pgr_exchange_shard_records that sampled
     bool have_splitters = false;
+    bool broken = false;  // a collective timed out and the communicator was aborted: every later call fails at once
 };
+
+// Watchdog (the reference has no failure detection of its own; a multi-process build needs one).
+// A peer that died, a fabric that never comes up or a rank that took another code path leaves ncclCommInitRank or a
+// collective waiting for ever; the context option exchange_timeout_s (PGR_EXCHANGE_TIMEOUT_S when the context is created;
+// default 300 s, 0 = wait for ever) bounds both.  On a timeout the
+// communicator is aborted (ncclCommAbort), the call returns PGR_ERR_DEVICE and the exchange refuses further work, so that a
+// host program can fall back to another transport or fail with a message instead of hanging.
+static double exchange_timeout_s(const pgr_ctx *ctx) { return ctx->opt.exchange_timeout_s < 0 ? 0.0 : (double)ctx->opt.exchange_timeout_s; }
+
+// wait for the exchange's stream, bounded
+static int exchange_sync(pgr_exchange *x, const char *what) {
+    pgr_ctx *ctx = x->ctx;
+    if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
+    const double limit = exchange_timeout_s(ctx);
+    if (limit <= 0) {
+        PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+        return PGR_OK;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t q = hipStreamQuery(x->stream);
+        if (q == hipSuccess) return PGR_OK;
+        if (q != hipErrorNotReady) return ctx->fail(PGR_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(q));
+        const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (el > limit) break;
+        if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 1000 : 50));  // spin first: steps are ms
+    }
+    x->broken = true;
+    if (x->comm && rccl().CommAbort) (void)rccl().CommAbort(x->comm);
+    x->comm = nullptr;
+    char msg[200];
+    snprintf(msg, sizeof msg, "%s did not complete within %.0f s (option exchange_timeout_s): communicator aborted, rank %d of %d", what,
+             limit, x->rank, x->world);
+    return ctx->fail(PGR_ERR_DEVICE, msg);
+}
 
 static_assert(PGR_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "pgr_hip.h and rccl.h disagree on the unique id size");
 
@@ -140,11 +183,46 @@ extern "C" int pgr_exchange_create(pgr_ctx *ctx, const uint8_t *id, int rank, in
     if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string("exchange setup: ") + hipGetErrorString(e)));
     ncclUniqueId u;
     memcpy(u.internal, id, PGR_UNIQUE_ID_BYTES);
-    ncclResult_t r = R.CommInitRank(&x->comm, world, u, rank);
-    if (r != ncclSuccess) {
-        x->comm = nullptr;
-        return bail(ctx->fail(PGR_ERR_DEVICE, std::string("ncclCommInitRank: ") + R.GetErrorString(r)));
+    // ncclCommInitRank blocks until all `world` ranks have called it: run it beside a clock (see exchange_timeout_s)
+    struct Init {
+        std::mutex m;
+        std::condition_variable cv;
+        bool done = false;
+        ncclResult_t r = ncclSuccess;
+        ncclComm_t comm = nullptr;
+    };
+    auto st = std::make_shared<Init>();
+    const int device = ctx->device;
+    std::thread worker([st, u, world, rank, device, &R] {
+        (void)hipSetDevice(device);
+        ncclComm_t c = nullptr;
+        const ncclResult_t r = R.CommInitRank(&c, world, u, rank);
+        std::lock_guard<std::mutex> g(st->m);
+        st->r = r;
+        st->comm = c;
+        st->done = true;
+        st->cv.notify_all();
+    });
+    const double limit = exchange_timeout_s(ctx);
+    {
+        std::unique_lock<std::mutex> g(st->m);
+        if (limit <= 0) st->cv.wait(g, [&] { return st->done; });
+        else st->cv.wait_for(g, std::chrono::duration<double>(limit), [&] { return st->done; });
+        if (!st->done) {
+            g.unlock();
+            worker.detach();  // still inside RCCL: it keeps its shared state alive, nothing of this call is touched again
+            char msg[160];
+            snprintf(msg, sizeof msg, "ncclCommInitRank did not return within %.0f s (option exchange_timeout_s): rank %d of %d", limit,
+                     rank, world);
+            return bail(ctx->fail(PGR_ERR_DEVICE, msg));
+        }
     }
+    worker.join();
+    if (st->r != ncclSuccess) {
+        x->comm = nullptr;
+        return bail(ctx->fail(PGR_ERR_DEVICE, std::string("ncclCommInitRank: ") + R.GetErrorString(st->r)));
+    }
+    x->comm = st->comm;
     *out = x;
     return PGR_OK;
 }
@@ -152,7 +230,7 @@ extern "C" int pgr_exchange_create(pgr_ctx *ctx, const uint8_t *id, int rank, in
 extern "C" void pgr_exchange_destroy(pgr_exchange *x) {
     if (!x) return;
     (void)hipSetDevice(x->ctx->device);
-    if (x->stream) (void)hipStreamSynchronize(x->stream);
+    if (x->stream && !x->broken) (void)hipStreamSynchronize(x->stream);
     if (x->comm) (void)rccl().CommDestroy(x->comm);
     if (x->ev_ready) (void)hipEventDestroy(x->ev_ready);
     if (x->ev_done) (void)hipEventDestroy(x->ev_done);
@@ -169,6 +247,7 @@ extern "C" int pgr_exchange_allgather_shmmrs_start(pgr_exchange *x, const pgr_mm
                                                    pgr_mm128 *d_out, uint64_t cap_per_rank) {
     if (!x) return PGR_ERR_INVALID_ARG;
     pgr_ctx *ctx = x->ctx;
+    if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is already in flight on this exchange (call pgr_exchange_wait)");
     if (!d_local || !d_out || cap_per_rank == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (n_local > cap_per_rank) return ctx->fail(PGR_ERR_INVALID_ARG, "this rank's shimmer list exceeds cap_per_rank");
@@ -194,7 +273,11 @@ extern "C" int pgr_exchange_wait(pgr_exchange *x, uint64_t *counts) {
     pgr_ctx *ctx = x->ctx;
     if (!x->in_flight) return ctx->fail(PGR_ERR_STATE, "no all-gather in flight");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
-    PGR_HIP(ctx, hipEventSynchronize(x->ev_done));
+    int rc = exchange_sync(x, "shimmer all-gather");  // (ev_done is the last thing on the exchange's stream)
+    if (rc) {
+        x->in_flight = false;
+        return rc;
+    }
     // later work on the compute stream (index build from the gathered lists, reuse of the buffers) is ordered behind it
     PGR_HIP(ctx, hipStreamWaitEvent(ctx->stream, x->ev_done, 0));
     x->in_flight = false;
@@ -215,6 +298,7 @@ extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs 
                                               uint64_t *n_gathered) {
     if (!x) return PGR_ERR_INVALID_ARG;
     pgr_ctx *ctx = x->ctx;
+    if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is already in flight on this exchange");
     if (s && s->n && !rids) return ctx->fail(PGR_ERR_INVALID_ARG, "null rid list");
     Rccl &R = rccl();
@@ -226,7 +310,8 @@ extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs 
     PGR_NCCL(ctx, R.AllGather(x->d_cnt, x->d_cnt + 1, 1, ncclUint64, x->comm, x->stream));
     PGR_HIP(ctx, hipMemcpyAsync(x->h_cnt + 1, x->d_cnt + 1, (size_t)x->world * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                 x->stream));
-    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    int rc;
+    if ((rc = exchange_sync(x, "count all-gather"))) return rc;
     uint64_t cap = 0, total = 0;
     for (int r = 0; r < x->world; ++r) {
         cap = std::max<uint64_t>(cap, x->h_cnt[1 + r]);
@@ -236,7 +321,6 @@ extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs 
     if (cap == 0) return PGR_OK;
     // phase 2: padded payload
     pgr::Tmp local(ctx), out(ctx);
-    int rc;
     if ((rc = local.alloc(cap * sizeof(pgr_mm128))) || (rc = out.alloc((size_t)x->world * cap * sizeof(pgr_mm128)))) return rc;
     if (n_local && (rc = pgr_shmmrs_copy_to_device_rids(ctx, s, local.as<pgr_mm128>(), cap, rids))) return rc;  // synchronizes
     std::vector<uint64_t> counts((size_t)x->world);
@@ -266,6 +350,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
                                           int reuse_splitters, uint64_t *splitters_out, uint64_t *n_received) {
     if (!x) return PGR_ERR_INVALID_ARG;
     pgr_ctx *ctx = x->ctx;
+    if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange (call pgr_exchange_wait)");
     if (!ix || (n && !d_recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (ix->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "index belongs to another context");
@@ -274,57 +359,84 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     const int world = x->world, me = x->rank;
     int rc;
     if (reuse_splitters && !x->have_splitters) return ctx->fail(PGR_ERR_STATE, "no splitters yet: the first call must sample");
+    // A failure that only THIS rank sees (out of memory, the 2^32 record limit, a partition error) must not leave the other
+    // ranks blocked in the next collective: every collective of this call carries an error word, and all ranks leave together.
+    constexpr uint64_t FAILED = ~0ull;
+    int local_rc = PGR_OK;
+    auto peers_failed = [&](const char *where) {
+        return local_rc ? local_rc
+                        : ctx->fail(PGR_ERR_STATE, std::string("pgr_exchange_shard_records: another rank failed ") + where +
+                                                       " (its own error message says why); nothing was exchanged");
+    };
     std::vector<uint64_t> splitters((size_t)std::max(world - 1, 1));
     if (reuse_splitters) {
         splitters = x->splitters;
     } else {
-    // ---- 1. pooled sample of first hashes -> splitters (the same on every rank)
-    std::vector<uint64_t> mine(1 + SHARD_SAMPLES, 0);
-    uint32_t n_s = 0;
-    if ((rc = pgr_shard_sample_keys(ctx, d_recs, n, SHARD_SAMPLES, mine.data() + 1, &n_s))) return rc;  // synchronizes
-    mine[0] = n_s;
-    pgr::Tmp d_smp(ctx), d_all(ctx);
-    if ((rc = d_smp.alloc(mine.size() * 8)) || (rc = d_all.alloc((size_t)world * mine.size() * 8))) return rc;
-    std::vector<uint64_t> all((size_t)world * mine.size());
-    PGR_HIP(ctx, hipMemcpyAsync(d_smp.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, x->stream));
-    PGR_NCCL(ctx, R.AllGather(d_smp.p, d_all.p, mine.size(), ncclUint64, x->comm, x->stream));
-    PGR_HIP(ctx, hipMemcpyAsync(all.data(), d_all.p, all.size() * 8, hipMemcpyDeviceToHost, x->stream));
-    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
-    std::vector<uint64_t> pool;
-    for (int r = 0; r < world; ++r) {
-        const uint64_t *blk = all.data() + (size_t)r * mine.size();
-        pool.insert(pool.end(), blk + 1, blk + 1 + std::min<uint64_t>(blk[0], SHARD_SAMPLES));
-    }
-    if (pgr_shard_splitters(pool.data(), pool.size(), world, splitters.data())) return ctx->fail(PGR_ERR_INTERNAL, "splitters");
-    x->splitters = splitters;
-    x->have_splitters = true;
+        // ---- 1. pooled sample of first hashes -> splitters (the same on every rank)
+        std::vector<uint64_t> mine(1 + SHARD_SAMPLES, 0);
+        uint32_t n_s = 0;
+        local_rc = pgr_shard_sample_keys(ctx, d_recs, n, SHARD_SAMPLES, mine.data() + 1, &n_s);  // synchronizes
+        mine[0] = local_rc ? FAILED : n_s;
+        pgr::Tmp d_smp(ctx), d_all(ctx);
+        if ((rc = d_smp.alloc(mine.size() * 8)) || (rc = d_all.alloc((size_t)world * mine.size() * 8))) return rc;
+        std::vector<uint64_t> all((size_t)world * mine.size());
+        PGR_HIP(ctx, hipMemcpyAsync(d_smp.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, x->stream));
+        PGR_NCCL(ctx, R.AllGather(d_smp.p, d_all.p, mine.size(), ncclUint64, x->comm, x->stream));
+        PGR_HIP(ctx, hipMemcpyAsync(all.data(), d_all.p, all.size() * 8, hipMemcpyDeviceToHost, x->stream));
+        if ((rc = exchange_sync(x, "sample all-gather"))) return rc;
+        std::vector<uint64_t> pool;
+        bool any_failed = false;
+        for (int r = 0; r < world; ++r) {
+            const uint64_t *blk = all.data() + (size_t)r * mine.size();
+            any_failed = any_failed || blk[0] == FAILED;
+            if (blk[0] != FAILED) pool.insert(pool.end(), blk + 1, blk + 1 + std::min<uint64_t>(blk[0], SHARD_SAMPLES));
+        }
+        if (any_failed) return peers_failed("while sampling its keys");
+        if (pgr_shard_splitters(pool.data(), pool.size(), world, splitters.data())) return ctx->fail(PGR_ERR_INTERNAL, "splitters");
+        x->splitters = splitters;
+        x->have_splitters = true;
     }
     if (splitters_out)
         for (int j = 0; j + 1 < world; ++j) splitters_out[j] = splitters[(size_t)j];
     // ---- 2. stable partition of this rank's records by destination
     pgr::Tmp d_part(ctx);
-    std::vector<uint64_t> send_cnt((size_t)world, 0);
-    if ((rc = d_part.alloc(std::max<uint64_t>(n, 1) * sizeof(pgr_frag_rec)))) return rc;
-    if ((rc = pgr_shard_partition(ctx, d_recs, n, splitters.data(), world, d_part.as<pgr_frag_rec>(), send_cnt.data()))) return rc;
-    // ---- 3. everybody's counts: M[src][dst]
+    std::vector<uint64_t> send_cnt((size_t)world + 1, 0);  // [world] = error word
+    if ((local_rc = d_part.alloc(std::max<uint64_t>(n, 1) * sizeof(pgr_frag_rec))) == PGR_OK)
+        local_rc = pgr_shard_partition(ctx, d_recs, n, splitters.data(), world, d_part.as<pgr_frag_rec>(), send_cnt.data());
+    send_cnt[(size_t)world] = local_rc ? FAILED : 0;
+    // ---- 3. everybody's counts: M[src][dst] (+ the error word of src)
+    const size_t row = (size_t)world + 1;
     pgr::Tmp d_cnt(ctx), d_mat(ctx);
-    if ((rc = d_cnt.alloc((size_t)world * 8)) || (rc = d_mat.alloc((size_t)world * world * 8))) return rc;
-    std::vector<uint64_t> mat((size_t)world * world);
-    PGR_HIP(ctx, hipMemcpyAsync(d_cnt.p, send_cnt.data(), (size_t)world * 8, hipMemcpyHostToDevice, x->stream));
-    PGR_NCCL(ctx, R.AllGather(d_cnt.p, d_mat.p, (size_t)world, ncclUint64, x->comm, x->stream));
+    if ((rc = d_cnt.alloc(row * 8)) || (rc = d_mat.alloc((size_t)world * row * 8))) return rc;
+    std::vector<uint64_t> mat((size_t)world * row);
+    PGR_HIP(ctx, hipMemcpyAsync(d_cnt.p, send_cnt.data(), row * 8, hipMemcpyHostToDevice, x->stream));
+    PGR_NCCL(ctx, R.AllGather(d_cnt.p, d_mat.p, row, ncclUint64, x->comm, x->stream));
     PGR_HIP(ctx, hipMemcpyAsync(mat.data(), d_mat.p, mat.size() * 8, hipMemcpyDeviceToHost, x->stream));
-    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    if ((rc = exchange_sync(x, "count all-gather"))) return rc;
+    for (int s = 0; s < world; ++s)
+        if (mat[(size_t)s * row + (size_t)world] == FAILED) return peers_failed("while partitioning its records");
     uint64_t recv_total = 0;
-    for (int s = 0; s < world; ++s) recv_total += mat[(size_t)s * world + me];
-    if (ix->n_raw + recv_total >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "index shard would hold 2^32 or more records");
-    if ((rc = pgr::index_grow_raw(ctx, ix, ix->n_raw + recv_total))) return rc;
+    for (int s = 0; s < world; ++s) recv_total += mat[(size_t)s * row + me];
+    // ---- 3b. room for what arrives: a rank that cannot take its range says so before anybody sends
+    if (ix->n_raw + recv_total >= (1ull << 32))
+        local_rc = ctx->fail(PGR_ERR_INVALID_ARG, "index shard would hold 2^32 or more records");
+    else
+        local_rc = pgr::index_grow_raw(ctx, ix, ix->n_raw + recv_total);
+    x->h_cnt[0] = local_rc ? FAILED : 0;
+    PGR_HIP(ctx, hipMemcpyAsync(x->d_cnt, x->h_cnt, sizeof(unsigned long long), hipMemcpyHostToDevice, x->stream));
+    PGR_NCCL(ctx, R.AllGather(x->d_cnt, x->d_cnt + 1, 1, ncclUint64, x->comm, x->stream));
+    PGR_HIP(ctx, hipMemcpyAsync(x->h_cnt + 1, x->d_cnt + 1, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost,
+                                x->stream));
+    if ((rc = exchange_sync(x, "ready all-gather"))) return rc;
+    for (int s = 0; s < world; ++s)
+        if (x->h_cnt[1 + s] == FAILED) return peers_failed("while making room for its key range");
     // ---- 4. the payload: blocks arrive in source-rank order, each in its sender's (sid, frg_id) order
     PGR_NCCL(ctx, R.GroupStart());
     uint64_t s_off = 0, r_off = 0;
     ncclResult_t nr = ncclSuccess;
     hipError_t he = hipSuccess;
     for (int p = 0; p < world; ++p) {
-        const uint64_t sc = send_cnt[(size_t)p], rcv = mat[(size_t)p * world + me];
+        const uint64_t sc = send_cnt[(size_t)p], rcv = mat[(size_t)p * row + me];
         if (p == me) {
             if (sc && he == hipSuccess)
                 he = hipMemcpyAsync(ix->raw + ix->n_raw + r_off, d_part.as<pgr_frag_rec>() + s_off, sc * sizeof(pgr_frag_rec),
@@ -342,7 +454,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     if (nr != ncclSuccess || ge != ncclSuccess)
         return ctx->fail(PGR_ERR_DEVICE, std::string("ncclSend/ncclRecv: ") + R.GetErrorString(nr != ncclSuccess ? nr : ge));
     if (he != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("local block copy: ") + hipGetErrorString(he));
-    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    if ((rc = exchange_sync(x, "record all-to-all"))) return rc;
     PGR_HIP(ctx, hipGetLastError());
     ix->n_raw += recv_total;
     ix->finalized = false;
@@ -358,6 +470,7 @@ extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *sh
     pgr_ctx *ctx = x->ctx;
     if (!shard || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (!shard->finalized) return ctx->fail(PGR_ERR_STATE, "shard index not finalized");
+    if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange");
     *out = nullptr;
     Rccl &R = rccl();
@@ -369,7 +482,7 @@ extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *sh
     PGR_NCCL(ctx, R.AllGather(x->d_cnt, x->d_cnt + 1, 1, ncclUint64, x->comm, x->stream));
     PGR_HIP(ctx, hipMemcpyAsync(x->h_cnt + 1, x->d_cnt + 1, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost,
                                 x->stream));
-    PGR_HIP(ctx, hipStreamSynchronize(x->stream));
+    if ((rc = exchange_sync(x, "count all-gather"))) return rc;
     uint64_t total = 0;
     for (int r = 0; r < world; ++r) total += x->h_cnt[1 + r];
     if (total >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "replicated index would hold 2^32 or more records");
@@ -388,11 +501,13 @@ extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *sh
         off += c;
     }
     const ncclResult_t ge = R.GroupEnd();
-    hipError_t he = hipStreamSynchronize(x->stream);
-    if (nr != ncclSuccess || ge != ncclSuccess || he != hipSuccess) {
+    if (nr != ncclSuccess || ge != ncclSuccess) {
         pgr_index_destroy(full);
-        return ctx->fail(PGR_ERR_DEVICE, std::string("index all-gather: ") +
-                                             (he != hipSuccess ? hipGetErrorString(he) : R.GetErrorString(nr != ncclSuccess ? nr : ge)));
+        return ctx->fail(PGR_ERR_DEVICE, std::string("index all-gather: ") + R.GetErrorString(nr != ncclSuccess ? nr : ge));
+    }
+    if ((rc = exchange_sync(x, "index all-gather"))) {
+        pgr_index_destroy(full);
+        return rc;
     }
     full->n_raw = total;
     full->next_sid = shard->next_sid;

@@ -62,7 +62,8 @@ __global__ void rec_key_kernel(const pgr_frag_rec *__restrict__ recs, const uint
 
 // one pass over the appended records (grid-stride, a few thousand workgroups: one atomic per workgroup and statistic):
 // stats[0] |= 1 not in (sid, frg_id) append order, stats[1] |= 1 not already in (h0, h1, sid, frg_id) order,
-// stats[2] = max(sid) + 1, stats[3] = max(h1) (h0 <= h1: bounds the radix passes of both key fields)
+// stats[2] = max(sid) + 1, stats[3] = max(h0, h1) over all records (bounds the radix passes of both key fields; records that come
+// in through pgr_index_add_records need not be canonical, so h0 <= h1 is NOT assumed)
 __global__ __launch_bounds__(256) void raw_stats_kernel(const pgr_frag_rec *__restrict__ recs, uint64_t n,
                                                         unsigned long long *__restrict__ stats, uint64_t *__restrict__ h0_out,
                                                         uint64_t *__restrict__ h1_out) {
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256) void raw_stats_kernel(const pgr_frag_rec *__re
         h0_out[i] = a.h0;  // the two hashes by themselves, in append order: sort keys without another pass over the 40-byte records
         h1_out[i] = a.h1;
         msid = umax64(msid, (unsigned long long)a.sid + 1ull);
-        mh = umax64(mh, a.h1);
+        mh = umax64(mh, umax64(a.h0, a.h1));
         if (i + 1 < n) {
             const pgr_frag_rec &b = recs[i + 1];
             const bool id_gt = a.sid > b.sid || (a.sid == b.sid && a.frg_id > b.frg_id);
@@ -443,7 +444,7 @@ extern "C" int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_bat
 }
 
 static int index_add_host(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const StageSrc &src, const uint32_t *sids) {
-    if (worth_pipelining(n, src.lens))  // stage the next ~Gbp while this one is turned into records (running sids keep order)
+    if (worth_pipelining(ctx, n, src.lens))  // stage the next ~Gbp while this one is turned into records (running sids keep order)
         return for_each_staged(ctx, n, src, [&](pgr_batch *sb, uint32_t c0, uint32_t) {
             return pgr_index_add_resident(ctx, ix, sb, sids ? sids + c0 : nullptr);
         });
@@ -526,14 +527,16 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     PGR_HIP(ctx, hipMemcpyAsync(stats, d_stats.p, 32, hipMemcpyDeviceToHost, st));
     PGR_HIP(ctx, hipStreamSynchronize(st));
     ix->sid_bound = stats[2];
-    const bool full_sort = getenv("PGR_INDEX_FULL_SORT") != nullptr;
+    const bool full_sort = ctx->opt.index_full_sort != 0;
     if (!stats[1] && !full_sort) {
         // already in (h0, h1, sid, frg_id) order
         PGR_HIP(ctx, hipMemcpyAsync(ix->recs, ix->raw, n * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, st));
     } else {
-        const unsigned hb = full_sort ? 56u : std::max(1u, std::min(56u, bits_for(stats[3] + 1)));
+        // the library's own hashes have 56 bits (MM128.x >> 8); external records may carry anything
+        const unsigned need = stats[3] >> 56 ? 64u : std::max(1u, bits_for(stats[3] + 1));
+        const unsigned hb = full_sort ? std::max(56u, need) : need;
         bool sorted = false;
-        if (!stats[0] && !full_sort && !getenv("PGR_INDEX_TWO_KEY_SORT")) {
+        if (!stats[0] && !full_sort && !ctx->opt.index_two_key_sort) {
             // append-ordered records: ONE stable radix sort by h0, then the runs of equal h0 are put in h1 order (see above)
             const size_t tb = sort_pairs_temp_bytes(n);
             Tmp h1s(ctx), longs(ctx), cnt(ctx);
@@ -1463,7 +1466,7 @@ int chain_hits(pgr_ctx *ctx, const uint64_t *d_key, const pgr_hitpair *d_hp, uin
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 hits in one batch");
     hipStream_t st = ctx->stream;
     int rc;
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const bool dbg = ctx->opt.debug != 0;
     const auto c0 = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg) return;
@@ -1685,7 +1688,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     if (max_aln_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be at least 1");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const bool dbg = getenv("PGR_DEBUG") != nullptr;
+    const bool dbg = ctx->opt.debug != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b2) {
         return (float)std::chrono::duration<double, std::milli>(b2 - a).count();
@@ -1709,7 +1712,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         qp.total_ms = ms(t1, t5);
         qp.path = (uint32_t)path;
         ctx->qprof = qp;
-        if (getenv("PGR_DEBUG_TIMES")) fprintf(stderr, "[pgr] query: result ready at %.1f us\n", qp.total_ms * 1e3);
+        if (ctx->opt.debug_times) fprintf(stderr, "[pgr] query: result ready at %.1f us\n", qp.total_ms * 1e3);
         if (dbg)
             fprintf(stderr, "[pgr] query batch %u (one wavefront per query%s): shimmers %.2f ms, the rest %.2f\n", n_queries,
                     path == 2 ? ", enqueued behind the shimmer pipeline" : "", qp.shmmr_ms, qp.chain_ms);
@@ -1731,7 +1734,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         pairs_hint = (uint32_t)std::min<double>((double)max_len * dens * 1.6 + 4.0, 1e9);
     }
     std::unique_ptr<QueryFusedRun> chained;
-    if (fused_on && pairs_hint && query_fused_eligible(n_queries, pairs_hint, max_aln_span) && !getenv("PGR_NO_QUERY_CHAINING")) {
+    if (fused_on && pairs_hint && query_fused_eligible(ctx, n_queries, pairs_hint, max_aln_span) && !ctx->opt.no_query_chaining) {
         chained.reset(new QueryFusedRun(ctx, ix, n_queries, pairs_hint, fqp, fap));
         QueryFusedRun *run = chained.get();
         ctx->post_enqueue = [run](const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count) {
@@ -1744,7 +1747,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     ctx->post_enqueue = nullptr;
     if (rc) return rc;
     const auto t2 = now();
-    if (getenv("PGR_DEBUG_TIMES")) fprintf(stderr, "[pgr] query: shimmers returned at %.1f us\n", ms(t1, t2) * 1e3);
+    if (ctx->opt.debug_times) fprintf(stderr, "[pgr] query: shimmers returned at %.1f us\n", ms(t1, t2) * 1e3);
     auto t3 = t2, t4 = t2;
     const uint64_t nq = pgr_shmmrs_n_pairs(s);
     qp.n_query_pairs = nq;
@@ -1778,7 +1781,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         pgr_shmmrs_destroy(s);
         s = nullptr;
         if (rc) return rc;
-        if (fused_on && !structural_decline && query_fused_eligible(n_queries, max_pairs, max_aln_span)) {
+        if (fused_on && !structural_decline && query_fused_eligible(ctx, n_queries, max_pairs, max_aln_span)) {
             QueryFusedRun run(ctx, ix, n_queries, max_pairs, fqp, fap);
             QueryFusedCounts fc;
             bool declined = false;
@@ -1853,7 +1856,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
                                (uint32_t *)nullptr, hoff.as<uint64_t>(), hkey.as<uint64_t>(), hhp.as<pgr_hitpair>());
             AlnParams ap{max_aln_span, penalty, has_max_gap, max_gap, oriented};
             HitSegments seg;
-            if (mb[2] <= SEG_SORT_MAX && !getenv("PGR_QUERY_GLOBAL_SORT")) {
+            if (mb[2] <= SEG_SORT_MAX && !ctx->opt.query_global_sort) {
                 seg.pair_off = (const uint64_t *)ctx->ws_rec_off.p;
                 seg.hit_off = hoff.as<uint64_t>();
                 seg.max_hits = mb[2];

@@ -108,7 +108,7 @@ struct QueryFusedCounts {
     uint64_t n_signatures = 0, n_hits = 0;
 };
 constexpr uint32_t QF_MAX_PAIRS = 128;  // shimmer pairs of one query
-bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span);
+bool query_fused_eligible(const pgr_ctx *ctx, uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span);
 
 // One batch through the per-query kernel.  enqueue*() puts the kernels and the first download on the context's stream (nothing
 // waits); finish() runs behind a synchronization of that stream and hands out the result -- or says `declined`.

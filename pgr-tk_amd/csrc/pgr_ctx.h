@@ -38,6 +38,25 @@ struct pgr_ctx {
     // pinned mailbox: the handful of device-side counts (+ result offsets) a call reads after its one synchronization
     void *mailbox = nullptr;
     size_t mailbox_cap = 0;
+    // Tuning and A/B switches.  Read from the environment ONCE, when the context is created (PGR_<NAME IN UPPER CASE>), and
+    // changed afterwards only through pgr_ctx_set_option: no call looks at the environment.
+    struct Options {
+        int64_t debug = 0;               // progress lines of the staging / island / query paths on stderr
+        int64_t debug_times = 0;         // host-side timeline of a call on stderr
+        int64_t gpu_pack = 0;            // A/B: the round-2 host path (ASCII over PCIe, packed by a kernel)
+        int64_t no_small_path = 0;       // never take the one-workgroup-per-contig kernel (csrc/small.hip)
+        int64_t no_pipeline = 0;         // never cut a large host batch into staged sub-batches
+        int64_t early_sync_bp = 1ll << 30;  // batches of at least this many bases look at the level-1 flags before the list stage
+        int64_t index_full_sort = 0;     // pgr_index_finalize: always the four-field sort
+        int64_t index_two_key_sort = 0;  // pgr_index_finalize: never the one-key sort + run fix-ups
+        int64_t no_fused_query = 0;      // never the one-wavefront-per-query kernel (csrc/query_fused.hip)
+        int64_t no_query_chaining = 0;   // do not enqueue the query stage behind the shimmer pipeline
+        int64_t query_global_sort = 0;   // group the hits of a batch with the global radix sort
+        int64_t fused_query_hits = 0;    // > 0: fixed slot size H of the per-query kernel
+        int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank and on every wait for a collective; 0 = wait for ever
+        int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
+    } opt;
+    bool skip_small_once = false;  // the host entry point's one-workgroup kernel handed the batch back: do not try it again
     bool want_host_copy = false;   // set by the host-buffer entry points: a small result rides along with the final round trip
     bool staged_unsynced = false;  // a batch was staged on `stream` and nobody has synchronized since
     // result-size estimate: final shimmers per base of the last pgr_shmmrs_compute with the spec `est_spec_key`
@@ -99,7 +118,7 @@ struct StageSrc {
 int shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
                                 pgr_frag_rec *d_out, uint64_t capacity);
 // host inputs of >= 512 Mbp: contigs [c0, c1) are staged on the copy stream while the previous range is consumed
-bool worth_pipelining(uint32_t n, const uint64_t *lens);
+bool worth_pipelining(const pgr_ctx *ctx, uint32_t n, const uint64_t *lens);
 int for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
                     const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume);
 // pinned host blocks a kernel writes a result into (ctx.hip): acquire returns nullptr when the host cannot pin more memory;

@@ -725,8 +725,8 @@ __global__ __launch_bounds__(64) void query_pack_kernel(const QfArgs a, const ui
 
 }  // namespace
 
-bool query_fused_eligible(uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span) {
-    if (getenv("PGR_NO_FUSED_QUERY")) return false;
+bool query_fused_eligible(const pgr_ctx *ctx, uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span) {
+    if (ctx->opt.no_fused_query) return false;
     // slots and the result image are sized by the number of queries (up to QF_H_MAX x ~90 B each)
     return n_queries >= 1 && n_queries <= (1u << 17) && max_pairs <= QF_MAX_PAIRS && max_aln_span >= 1 && max_aln_span <= 64;
 }
@@ -742,7 +742,8 @@ QueryFusedRun::QueryFusedRun(pgr_ctx *c, const pgr_index *i, uint32_t nq, uint64
         std::max<uint64_t>((uint64_t)((double)max_pairs * per_key * 1.5) + 8, ix->fused_hits.load(std::memory_order_relaxed));
     H = QF_H_MIN;
     while (H < QF_H_MAX && H < want_h) H <<= 1;
-    if (const char *e = getenv("PGR_FUSED_QUERY_HITS")) H = (uint32_t)std::min<long>(QF_H_MAX, std::max<long>(QF_H_MIN, atol(e))) & ~63u;
+    if (ctx->opt.fused_query_hits > 0)
+        H = (uint32_t)std::min<int64_t>(QF_H_MAX, std::max<int64_t>(QF_H_MIN, ctx->opt.fused_query_hits)) & ~63u;
 }
 
 QueryFusedRun::~QueryFusedRun() {

@@ -148,7 +148,7 @@ extern "C" int pgr_shard_partition(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uin
     PGR_HIP(ctx, sort_pairs(st, ctx->ws_scan_tmp.p, tb, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(), idx_a.as<uint32_t>(),
                             idx_b.as<uint32_t>(), n, bits_for((uint64_t)world)));
     launch_gather_recs(st, d_recs, idx_b.as<uint32_t>(), d_out, n);
-    hipLaunchKernelGGL(dest_offsets_kernel, dim3(1), dim3(256), 0, st, keys_b.as<uint64_t>(), n, (uint32_t)world,
+    hipLaunchKernelGGL(dest_offsets_kernel, grid_for((uint64_t)world + 1), dim3(256), 0, st, keys_b.as<uint64_t>(), n, (uint32_t)world,
                        d_off.as<uint64_t>());
     std::vector<uint64_t> off((size_t)world + 1);
     PGR_HIP(ctx, hipMemcpyAsync(off.data(), d_off.p, off.size() * 8, hipMemcpyDeviceToHost, st));

@@ -1,6 +1,7 @@
 // pgr-mdb counterpart (pgr-bin/src/bin/pgr-mdb.rs:26-111) in C++ above the C ABI of libpgrhip.so:
 //   pgr-mdb <filelist> <prefix> [-w 80] [-k 56] [-r 4] [-m 64] [--sketch] [--batch-bp N] [--reference-sid-quirk]
 //           [--ranks N [--devices 0,1,...]]
+//   pgr-mdb --synthetic NxL --seed S <prefix> [the same options] [--write-fasta <path>]
 // builds <prefix>.mdb + <prefix>.midx.  The reference iterates an AGC archive; AGC is not available here, so
 // <filelist> lists FASTA / FASTQ (.gz) files.  Index-only path (seq_db.rs:541-615): fragment id = pair ordinal in
 // the contig; the host owns sequence iteration and the .midx, the GPU computes shimmers and the frag_map.
@@ -67,6 +68,54 @@ static int add_contigs(pgr_ctx *ctx, pgr_index *ix, uint32_t n, const std::vecto
     return pgr_index_add_packed(ctx, ix, n, lens.data(), planes.data(), valid.data(), sids.data());
 }
 
+struct Synthetic {
+    bool on = false;
+    uint64_t n = 0, len = 0, seed = 0;
+    std::string fasta_out;
+    std::string name(uint64_t c) const { return "synth_" + std::to_string(seed) + "_" + std::to_string(c); }
+    std::string source() const { return "synthetic:" + std::to_string(n) + "x" + std::to_string(len) + ":seed=" + std::to_string(seed); }
+};
+static Synthetic synth;
+
+static inline uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// the host form of the generator, only for --write-fasta
+static bool write_synthetic_fasta(const Synthetic &sy) {
+    FILE *f = fopen(sy.fasta_out.c_str(), "w");
+    if (!f) return false;
+    std::vector<char> line;
+    bool ok = true;
+    for (uint64_t c = 0; ok && c < sy.n; ++c) {
+        ok = fprintf(f, ">%s\n", sy.name(c).c_str()) >= 0;
+        line.resize((size_t)sy.len + 1);
+        for (uint64_t i = 0; i < sy.len; i += 32) {
+            const uint64_t z = splitmix64(sy.seed ^ (c * 0x9E3779B97F4A7C15ull) ^ (i >> 5));
+            for (uint64_t j = 0; j < 32 && i + j < sy.len; ++j) line[(size_t)(i + j)] = "ACGT"[(z >> (2 * j)) & 3];
+        }
+        line[(size_t)sy.len] = '\n';
+        ok = ok && fwrite(line.data(), 1, line.size(), f) == line.size();
+    }
+    return (fclose(f) == 0) && ok;
+}
+
+// synthetic contigs ids[0..n) -> pair records of `ix`, sequence id = contig id
+static int add_synthetic(pgr_ctx *ctx, pgr_index *ix, const Synthetic &sy, const std::vector<uint64_t> &ids) {
+    std::vector<uint64_t> lens(ids.size(), sy.len);
+    std::vector<uint32_t> sids(ids.size());
+    for (size_t i = 0; i < ids.size(); ++i) sids[i] = (uint32_t)ids[i];
+    pgr_batch *b = nullptr;
+    int rc = pgr_batch_synthetic_ids(ctx, (uint32_t)ids.size(), lens.data(), sy.seed, ids.data(), &b);
+    if (rc) return rc;
+    rc = pgr_index_add_resident(ctx, ix, b, sids.data());
+    pgr_batch_destroy(b);
+    return rc;
+}
+
 static void die(pgr_ctx *ctx, const char *what, int rc) {
     fprintf(stderr, "pgr-mdb: %s failed (%d): %s\n", what, rc, ctx ? pgr_last_error(ctx) : pgr_last_error(nullptr));
     exit(1);
@@ -103,6 +152,19 @@ int main(int argc, char **argv) {
         else if (a == "--ranks") ranks = atoi(val("--ranks"));
         else if (a == "--force-exchange") force_exchange = true;
         else if (a == "--prepack") prepack = true;
+        else if (a == "--synthetic") {
+            const std::string v = val("--synthetic");
+            const size_t x = v.find_first_of("xX");
+            char *e0 = nullptr, *e1 = nullptr;
+            synth.n = strtoull(v.c_str(), &e0, 10);
+            synth.len = x == std::string::npos ? 0 : strtoull(v.c_str() + x + 1, &e1, 10);
+            if (x == std::string::npos || e0 != v.c_str() + x || !e1 || *e1 || !synth.n || !synth.len || synth.n > 0xFFFFFFFFull) {
+                fprintf(stderr, "pgr-mdb: --synthetic wants NxL (contigs x bases per contig), e.g. 10x1000000\n");
+                return 2;
+            }
+            synth.on = true;
+        } else if (a == "--seed") synth.seed = strtoull(val("--seed"), nullptr, 10);
+        else if (a == "--write-fasta") synth.fasta_out = val("--write-fasta");
         else if (a == "--devices") {
             std::string v = val("--devices");
             for (size_t p = 0; p <= v.size();) {
@@ -113,9 +175,15 @@ int main(int argc, char **argv) {
             }
         } else pos.push_back(a);
     }
-    if (pos.size() != 2 || ranks < 1) {
-        fprintf(stderr, "usage: pgr-mdb <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch] [--prepack] [--ranks N [--devices 0,1,..]]\n");
+    if (synth.on && pos.size() == 1) pos.insert(pos.begin(), std::string());  // no <filelist> with --synthetic
+    if (pos.size() != 2 || ranks < 1 || (synth.on && !pos[0].empty())) {
+        fprintf(stderr, "usage: pgr-mdb <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch] [--prepack] [--ranks N [--devices 0,1,..]]\n"
+                        "       pgr-mdb --synthetic NxL --seed S <prefix> [...] [--write-fasta <path>]\n");
         return 2;
+    }
+    if (synth.on && !synth.fasta_out.empty() && !write_synthetic_fasta(synth)) {
+        fprintf(stderr, "pgr-mdb: can't write %s\n", synth.fasta_out.c_str());
+        return 1;
     }
     if (sid_quirk && (ranks > 1 || force_exchange)) {
         // per-input sid restarts make sids ambiguous across files: the sharded build tells contigs apart by their sid, two
@@ -285,10 +353,13 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
         if ((rc = pgr_exchange_create(ctx, id, env.rank, env.world, &xch))) die(ctx, "pgr_exchange_create", rc);
     }
 
-    std::ifstream fl(pos[0]);
-    if (!fl) {
-        fprintf(stderr, "pgr-mdb: can't open %s\n", pos[0].c_str());
-        return 1;
+    std::ifstream fl;
+    if (!synth.on) {
+        fl.open(pos[0]);
+        if (!fl) {
+            fprintf(stderr, "pgr-mdb: can't open %s\n", pos[0].c_str());
+            return 1;
+        }
     }
     struct Midx {
         uint32_t sid;
@@ -298,7 +369,16 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
     std::vector<Midx> midx;
     uint32_t sid = 0;
     std::string path;
-    if (!xch) {
+    const uint64_t per_batch = synth.on ? std::max<uint64_t>(1, batch_bp / synth.len) : 0;  // synthetic contigs per GPU batch
+    if (synth.on)
+        for (uint64_t c = 0; c < synth.n; ++c) midx.push_back(Midx{(uint32_t)c, (size_t)synth.len, synth.name(c), synth.source()});
+    if (synth.on && !xch) {
+        for (uint64_t c = 0; c < synth.n; c += per_batch) {
+            std::vector<uint64_t> ids;
+            for (uint64_t q = c; q < std::min(synth.n, c + per_batch); ++q) ids.push_back(q);
+            if ((rc = add_synthetic(ctx, ix, synth, ids))) die(ctx, "pgr_batch_synthetic_ids / pgr_index_add_resident", rc);
+        }
+    } else if (!xch) {
         while (std::getline(fl, path)) {
             while (!path.empty() && (path.back() == '\r' || path.back() == ' ')) path.pop_back();
             if (path.empty()) continue;
@@ -328,7 +408,12 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
         std::vector<pgrhost::SeqRec> all;
         std::vector<uint64_t> lens_all;
         std::vector<uint32_t> sids_all;
-        while (std::getline(fl, path)) {
+        if (synth.on)
+            for (uint64_t c = 0; c < synth.n; ++c) {
+                lens_all.push_back(synth.len);
+                sids_all.push_back((uint32_t)c);
+            }
+        while (!synth.on && std::getline(fl, path)) {
             while (!path.empty() && (path.back() == '\r' || path.back() == ' ')) path.pop_back();
             if (path.empty()) continue;
             std::vector<pgrhost::SeqRec> recs = pgrhost::read_fastx(path);
@@ -365,15 +450,21 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
                 size_t j = i;
                 uint64_t tot = 0;
                 while (j < mine.size() && (j == i || tot + lens_all[mine[j]] <= batch_bp)) tot += lens_all[mine[j++]];
-                std::vector<const uint8_t *> ptrs;
-                std::vector<uint64_t> lens;
-                std::vector<uint32_t> sids;
-                for (size_t q = i; q < j; ++q) {
-                    ptrs.push_back((const uint8_t *)all[mine[q]].seq.data());
-                    lens.push_back(lens_all[mine[q]]);
-                    sids.push_back(sids_all[mine[q]]);
+                if (synth.on) {
+                    std::vector<uint64_t> ids;
+                    for (size_t q = i; q < j; ++q) ids.push_back((uint64_t)mine[q]);
+                    if ((rc = add_synthetic(ctx, part, synth, ids))) die(ctx, "pgr_batch_synthetic_ids / pgr_index_add_resident", rc);
+                } else {
+                    std::vector<const uint8_t *> ptrs;
+                    std::vector<uint64_t> lens;
+                    std::vector<uint32_t> sids;
+                    for (size_t q = i; q < j; ++q) {
+                        ptrs.push_back((const uint8_t *)all[mine[q]].seq.data());
+                        lens.push_back(lens_all[mine[q]]);
+                        sids.push_back(sids_all[mine[q]]);
+                    }
+                    if ((rc = add_contigs(ctx, part, (uint32_t)(j - i), ptrs, lens, sids, prepack))) die(ctx, "pgr_index_add_batch", rc);
                 }
-                if ((rc = add_contigs(ctx, part, (uint32_t)(j - i), ptrs, lens, sids, prepack))) die(ctx, "pgr_index_add_batch", rc);
                 i = j;
             }
             const uint64_t n_part = pgr_index_n_records(part);
@@ -386,7 +477,7 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
             pgr_index_destroy(part);
         }
         fprintf(stderr, "rank %d/%d (device %d): %zu of %zu contigs, %zu exchange rounds, %llu pair records sent, %llu in its key range\n",
-                env.rank, env.world, env.device, mine.size(), all.size(), n_rounds, (unsigned long long)sent_total,
+                env.rank, env.world, env.device, mine.size(), lens_all.size(), n_rounds, (unsigned long long)sent_total,
                 (unsigned long long)received_total);
     }
     const bool sharded = xch != nullptr;

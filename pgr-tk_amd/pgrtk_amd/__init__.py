@@ -8,8 +8,8 @@ from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PackedSeqs, PgrError, Spec,
 from .engine import (Batch, Index, PackedBases, Shmmrs, frag_recs_batch, make_spec, pack_ascii, records_checksum,  # noqa: F401
                      sequence_to_shmmrs, sequence_to_shmmrs_batch, sequence_to_shmmrs_batch_packed, time_shmmr_batch,
                      time_shmmr_batch_packed)
-from .seqindexdb import (SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, read_fastx, sparse_aln,  # noqa: F401
-                         sparse_aln_groups)
+from .seqindexdb import (SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, pgr_lib_version, read_fastx,  # noqa: F401
+                         sparse_aln, sparse_aln_groups)
 from . import cli, mapgraph  # noqa: F401
 from .helpers import (get_principle_bundle_bed_file_for_query, group_smps_by_principle_bundle_id, merge_regions, query_sdb, rc, rc_byte_seq, rc_u8_seq,  # noqa: F401
                       string_to_u8, u8_to_string)

@@ -74,6 +74,8 @@ _SIGS = [
     ("pgr_last_error", C.c_char_p, [_VP]),
     ("pgr_free", None, [_VP]),
     ("pgr_version", C.c_char_p, []),
+    ("pgr_ctx_set_option", C.c_int, [_VP, C.c_char_p, C.c_int64]),
+    ("pgr_ctx_get_option", C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     ("pgr_shmmr_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
                                   C.POINTER(C.c_uint32), C.c_int, _PVP, _PVP]),
     ("pgr_frag_recs_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
@@ -323,6 +325,32 @@ class Context:
 
     def synchronize(self):
         self.check(lib().pgr_ctx_synchronize(self._h))
+
+    def set_option(self, name, value=1):
+        """tuning / A-B switch of this context (include/pgr_hip.h: pgr_ctx_set_option)"""
+        self.check(lib().pgr_ctx_set_option(self._h, name.encode(), int(value)))
+
+    def get_option(self, name):
+        v = C.c_int64()
+        if lib().pgr_ctx_get_option(self._h, name.encode(), C.byref(v)) != 0:
+            raise KeyError(name)
+        return int(v.value)
+
+    def options(self, **kw):
+        """context manager: set options for the duration of a `with` block, then restore them"""
+        import contextlib
+
+        @contextlib.contextmanager
+        def cm():
+            old = {k: self.get_option(k) for k in kw}
+            try:
+                for k, v in kw.items():
+                    self.set_option(k, v)
+                yield self
+            finally:
+                for k, v in old.items():
+                    self.set_option(k, v)
+        return cm()
 
     def last_query_prof(self):
         """counts and stage times of the last query batch on this context (pgr_query_prof) as a dict"""

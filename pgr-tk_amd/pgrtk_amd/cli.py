@@ -1,6 +1,7 @@
 """Command-line counterparts of the reference's callers of the hot path:
 
   python -m pgrtk_amd.cli mdb   <filelist> <prefix> [-w 80 -k 56 -r 4 -m 64 --sketch]
+  python -m pgrtk_amd.cli mdb   --synthetic NxL --seed S <prefix> [...] [--write-fasta <path>]
         pgr-mdb (pgr-bin/src/bin/pgr-mdb.rs:26-111): builds <prefix>.mdb + <prefix>.midx.  The reference reads
         AGC archives; AGC is not available here, so <filelist> lists FASTA/FASTQ(.gz) files.  Index-only path
         (seq_db.rs:541-615): fragment id = pair ordinal in the contig.
@@ -49,11 +50,63 @@ def reverse_complement(seq):
 
 
 # ----------------------------------------------------------------------------- pgr-mdb
+def synthetic_contig(seed, contig, length):
+    """host form of the counter-based generator of BASELINE.md section 4 (the device form is pgr_batch_synthetic):
+    base(c,i) = (splitmix64(seed ^ c*0x9E3779B97F4A7C15 ^ (i>>5)) >> (2*(i&31))) & 3 -> ASCII bytes"""
+    m = (1 << 64) - 1
+    words = np.arange((length + 31) // 32, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = words ^ np.uint64(seed ^ ((contig * 0x9E3779B97F4A7C15) & m))
+        z = z + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    codes = ((z[:, None] >> (np.uint64(2) * np.arange(32, dtype=np.uint64))[None, :]) & np.uint64(3)).astype(np.uint8)
+    return np.frombuffer(b"ACGT", dtype=np.uint8)[codes.reshape(-1)[:length]].tobytes()
+
+
+def parse_synthetic(text):
+    """'NxL' -> (N, L)"""
+    n, _, ln = text.lower().partition("x")
+    if not (n.isdigit() and ln.isdigit() and int(n) > 0 and int(ln) > 0):
+        raise SystemExit("--synthetic wants NxL (contigs x bases per contig), e.g. 10x1000000")
+    return int(n), int(ln)
+
+
+def cmd_mdb_synthetic(args, spec):
+    """pgr-mdb on N synthetic contigs of L bases generated on the device (BASELINE.json
+    configs[0] is `--synthetic 10x1000000 --seed 1`); contig c is sequence c, named synth_<seed>_<c>"""
+    from .engine import Batch
+    n, ln = parse_synthetic(args.synthetic)
+    if args.write_fasta:
+        with open(args.write_fasta, "wb") as f:
+            for c in range(n):
+                f.write(b">synth_%d_%d\n" % (args.seed, c) + synthetic_contig(args.seed, c, ln) + b"\n")
+    ix = Index(spec)
+    per = max(1, args.batch_bp // ln)
+    for c in range(0, n, per):
+        ids = list(range(c, min(n, c + per)))
+        b = Batch.synthetic([ln] * len(ids), args.seed, ctx=ix.ctx, contig_ids=ids)
+        ix.add_resident(b, sids=ids)
+        b.close()
+    src = "synthetic:%dx%d:seed=%d" % (n, ln, args.seed)
+    return ix, [(c, ln, "synth_%d_%d" % (args.seed, c), src) for c in range(n)]
+
+
 def cmd_mdb(args):
     spec = make_spec(args.w, args.k, args.r, args.min_span, args.sketch)
-    ix = Index(spec)
-    paths = [l.strip() for l in open(args.filepath) if l.strip()]
-    midx = []
+    if args.synthetic:
+        if args.prefix is not None:
+            raise SystemExit("--synthetic takes <prefix> only (no <filelist>)")
+        args.prefix = args.filepath
+        ix, midx = cmd_mdb_synthetic(args, spec)
+        paths = []
+    else:
+        if args.prefix is None:
+            raise SystemExit("usage: mdb <filelist> <prefix>")
+        ix = Index(spec)
+        paths = [l.strip() for l in open(args.filepath) if l.strip()]
+        midx = []
     sid = 0
     for path in paths:
         recs = read_fastx(path)
@@ -312,7 +365,11 @@ def main(argv=None):
     sub = ap.add_subparsers(dest="cmd", required=True)
     m = sub.add_parser("mdb", help="pgr-mdb counterpart: FASTA list -> .mdb/.midx")
     m.add_argument("filepath")
-    m.add_argument("prefix")
+    m.add_argument("prefix", nargs="?", default=None)
+    m.add_argument("--synthetic", default=None, metavar="NxL",
+                   help="N contigs of L bases from the counter-based generator (generated on the device); no <filelist>")
+    m.add_argument("--seed", type=int, default=0)
+    m.add_argument("--write-fasta", dest="write_fasta", default=None, help="with --synthetic: also write the contigs as FASTA")
     m.add_argument("-w", type=int, default=80)
     m.add_argument("-k", type=int, default=56)
     m.add_argument("-r", type=int, default=4)

@@ -156,6 +156,11 @@ def get_shmmr_dots(seq0, seq1, w=80, k=56, r=4, min_span=16, ctx=None):
     return x, y
 
 
+def pgr_lib_version():
+    """pgrtk.pgr_lib_version (pgr-tk/src/lib.rs:22-26: the build's VERSION_STRING): the version of libpgrhip.so"""
+    return lib().pgr_version().decode()
+
+
 class SeqIndexDB:
     """FASTX / MEMORY backends of the reference's SeqIndexDB (pgr-db/src/ext.rs:152-249)."""
 
@@ -478,6 +483,19 @@ class SeqIndexDB:
                 for x in recs[s:e]:
                     f.write("F\t%016x_%016x\t%d\t%d\t%d\t%d\t%d\n" % (h0, h1, x["frg_id"], x["sid"], x["bgn"], x["end"],
                                                                       x["orient"]))
+
+    def write_midx_to_text_file(self, filepath):
+        """lib.rs:1337-1339 ("for backward compatibility"): the same file as write_mapg_idx"""
+        self.write_mapg_idx(filepath)
+
+    def write_frag_and_index_files(self, file_prefix):
+        """lib.rs:1374-1384: for a database that holds its sequences (FASTX / MEMORY backends: `seq_db.is_some()`) the
+        reference writes `<prefix>.sdx/.frg` (write_to_frag_files, the fragment-compressed sequences: SURVEY section 2 marks
+        that store out of scope) and `<prefix>.mdb/.midx` (write_shmmr_map_index) -- the call
+        `gen_frag_db.py` made to produce the golden `test_seqs_frag.mdb`.  The `.mdb/.midx` half is written here, with the
+        backend's global fragment ids; on the other backends the call does nothing, as in the reference."""
+        if self.backend in ("FASTX", "MEMORY"):
+            self.write_shmmr_map_index(file_prefix)
 
     # ------------------------------------------------------------------ .mdb / .midx (seq_db.rs:790-810, 1291-1326)
     def write_shmmr_map_index(self, prefix):

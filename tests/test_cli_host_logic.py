@@ -112,3 +112,30 @@ def test_output_names_follow_path_with_extension():
     assert w("dir.x/out", "bed") == "dir.x/out.bed"          # dots in directories do not count
     assert w(".out", "pdb") == ".out.pdb"                    # a leading dot is not an extension
     assert w("a/.out.b", "ctg.summary.tsv") == "a/.out.ctg.summary.tsv"
+
+
+def test_synthetic_generators_agree_with_the_oracle(oracle, tmp_path):
+    """pgr-mdb --synthetic: the host forms of the counter-based generator of BASELINE.md
+    section 4 -- cli.synthetic_contig and the C++ program's --write-fasta -- produce the oracle's bytes.  (The FASTA is
+    written before the program asks for a GPU; without one it then fails loudly: there is no CPU path.)"""
+    import subprocess
+    from pgrtk_amd import cli
+    for seed, c, n in [(1, 0, 1000), (2, 7, 33), (5, 123456, 100001), (1, 9, 1), (0, 0, 64)]:
+        assert cli.synthetic_contig(seed, c, n) == oracle.synth_contig(seed, c, n).tobytes()
+    assert cli.parse_synthetic("10x1000000") == (10, 1000000)
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgr-tk_amd", "bin", "pgr-mdb")
+    fa = str(tmp_path / "s.fa")
+    r = subprocess.run([exe, "--synthetic", "4x1234", "--seed", "3", "--write-fasta", fa, str(tmp_path / "p")],
+                       capture_output=True, text=True, timeout=120)
+    recs = oracle.read_fasta(fa)
+    assert [n for n, _ in recs] == [b"synth_3_%d" % c for c in range(4)]
+    assert all(s == oracle.synth_contig(3, c, 1234).tobytes() for c, (_, s) in enumerate(recs))
+    try:
+        import torch
+        has_gpu = torch.cuda.is_available()
+    except ImportError:
+        has_gpu = False
+    if not has_gpu:
+        assert r.returncode != 0 and "no CPU fallback" in r.stderr
+    r = subprocess.run([exe, "--synthetic", "4by12", str(tmp_path / "p")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 2

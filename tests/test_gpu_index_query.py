@@ -513,13 +513,9 @@ def test_index_from_large_host_batch_pipelined(oracle, gpu_ctx):
         ix.close()
         return r
     for sids in (None, [int(x) for x in rng.permutation(len(seqs)) + 5]):
-        os.environ.pop("PGR_NO_PIPELINE", None)
         a = build(sids)
-        os.environ["PGR_NO_PIPELINE"] = "1"
-        try:
+        with gpu_ctx.options(no_pipeline=1):
             b = build(sids)
-        finally:
-            os.environ.pop("PGR_NO_PIPELINE", None)
         assert len(a) == len(b) > 1_000_000
         for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
             assert np.array_equal(a[f], b[f]), f
@@ -537,7 +533,7 @@ def _records(gpu_ctx, sdb):
 def test_index_sort_by_one_key_and_run_fixups(oracle, gpu_ctx, shape):
     """pgr_index_finalize sorts append-ordered records by h0 alone and orders the runs of equal h0 by h1 afterwards: runs of up
     to 16 records by themselves, up to 4096 one workgroup each, longer ones send the index to the two-key sort.  Every class
-    against the oracle's record order and against the two-key sort (PGR_INDEX_TWO_KEY_SORT=1)."""
+    against the oracle's record order and against the two-key sort (context option index_two_key_sort)."""
     import pgrtk_amd as P
     rng = np.random.default_rng(61)
     if shape == "unique":
@@ -557,12 +553,9 @@ def test_index_sort_by_one_key_and_run_fixups(oracle, gpu_ctx, shape):
     assert len(got) == len(ref)
     for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
         assert np.array_equal(ref[f], got[f]), (shape, f)
-    os.environ["PGR_INDEX_TWO_KEY_SORT"] = "1"
-    try:
+    with gpu_ctx.options(index_two_key_sort=1):
         sdb2 = P.SeqIndexDB(ctx=gpu_ctx)
         sdb2.load_from_seq_list([("s%d" % i, s) for i, s in enumerate(seqs)], w=80, k=56, r=4, min_span=64)
         got2 = _records(gpu_ctx, sdb2)
-    finally:
-        del os.environ["PGR_INDEX_TWO_KEY_SORT"]
     for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
         assert np.array_equal(got2[f], got[f]), (shape, f)

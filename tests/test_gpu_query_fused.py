@@ -1,6 +1,6 @@
 """GPU parity of the one-wavefront-per-query path (csrc/query_fused.hip): batches of short queries run every stage behind the
 pair records -- lookup (seq_db.rs:1200-1228), count filters (aln.rs:147-242), grouping, aln::sparse_aln (aln.rs:12-142) -- in one
-kernel.  Checked against the CPU oracle AND against the stage-by-stage kernels (PGR_NO_FUSED_QUERY=1), with the path that ran
+kernel.  Checked against the CPU oracle AND against the stage-by-stage kernels (context option no_fused_query), with the path that ran
 read back from pgr_query_prof.path; batches the kernel cannot hold must decline and still give the oracle's answer."""
 import os
 
@@ -35,11 +35,8 @@ def _check_vs_oracle(oix, queries, got, kw):
 
 
 def _general(sdb, queries, kw):
-    os.environ["PGR_NO_FUSED_QUERY"] = "1"
-    try:
+    with sdb.ctx.options(no_fused_query=1):
         return sdb.query_fragments_to_hps(queries, *_args(kw))
-    finally:
-        del os.environ["PGR_NO_FUSED_QUERY"]
 
 
 def _short_queries(rng, seqs, n, lo=1500, hi=11000):
@@ -189,7 +186,7 @@ def test_second_batch_on_an_index_is_enqueued_behind_the_shimmer_pipeline(oracle
             q = src[a:a + int(rng.integers(lo, hi))]
             out.append(revcomp(q) if i % 2 else q)
         return out
-    os.environ["PGR_NO_SMALL_PATH"] = "1"  # (small batches of short contigs have a shimmer kernel of their own: not this test)
+    gpu_ctx.set_option("no_small_path", 1)  # (small batches of short contigs have a shimmer kernel of their own: not this test)
     try:
         q1 = batch(300, 2000, 9000)
         g1 = sdb.query_fragments_to_hps(q1, *_args(KW))
@@ -220,4 +217,4 @@ def test_second_batch_on_an_index_is_enqueued_behind_the_shimmer_pipeline(oracle
         g5 = sdb.query_fragments_to_hps([b"ACGT" * 10, b""], *_args(KW))
         assert g5 == [[], []]
     finally:
-        del os.environ["PGR_NO_SMALL_PATH"]
+        gpu_ctx.set_option("no_small_path", 0)

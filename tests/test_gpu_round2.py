@@ -52,13 +52,14 @@ def test_small_calls_take_the_optimistic_path_and_stay_exact(oracle, gpu_ctx):
 
 
 @pytest.mark.parametrize("early_bp", ["1000000", "100000000000"])
-def test_large_batch_with_islands_is_exact(oracle, gpu_ctx, monkeypatch, early_bp):
+def test_large_batch_with_islands_is_exact(oracle, gpu_ctx, request, early_bp):
     """80 Mbp through both orchestrations: with the early look at the level-1 flags before the list stage (what batches of
     >= 1 Gbp do) and optimistically (list stage enqueued at once, repeated after the islands).  Non-ACGT bytes (single N, a
     300 kbp N run), palindromic (AT)n and a homopolymer stretch turn tiles into islands of the exact state machine,
     everything else stays on the closed-form tiles.  All contigs compared with the checker (128-bit checksums + counts)."""
     import pgrtk_amd as P
-    monkeypatch.setenv("PGR_EARLY_SYNC_BP", early_bp)
+    gpu_ctx.set_option("early_sync_bp", int(early_bp))
+    request.addfinalizer(lambda: gpu_ctx.set_option("early_sync_bp", 1 << 30))
     n, L = 8, 10_000_000
     seqs = []
     for i in range(n):
@@ -456,9 +457,8 @@ def test_query_many_targets_per_query_grouping_paths(oracle, gpu_ctx, monkeypatc
     queries = [bytes(anc[o:o + 12_000]) for o in (0, 7_000, 20_000, 33_333, 47_999)]
     queries.append(seqgen.rc(queries[1]))
     got = ix.query_hps_raw(queries, 0.025)
-    monkeypatch.setenv("PGR_QUERY_GLOBAL_SORT", "1")
-    alt = ix.query_hps_raw(queries, 0.025)
-    monkeypatch.delenv("PGR_QUERY_GLOBAL_SORT")
+    with gpu_ctx.options(query_global_sort=1):
+        alt = ix.query_hps_raw(queries, 0.025)
     for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps"):
         assert np.array_equal(got[k], alt[k]), k
     oix = oracle.Index(oracle.spec())
@@ -483,13 +483,11 @@ def test_index_sort_shortcut_equals_full_sort(gpu_ctx, monkeypatch):
     sp = P.make_spec()
 
     def build(order, full):
-        if full:
-            monkeypatch.setenv("PGR_INDEX_FULL_SORT", "1")
         ix = P.Index(sp, ctx=gpu_ctx)
         for i in order:  # one call per sequence: the append order is `order`
             ix.add_seqs([seqs[i]], sids=[i])
-        ix.finalize()
-        monkeypatch.delenv("PGR_INDEX_FULL_SORT", raising=False)
+        with gpu_ctx.options(index_full_sort=int(full)):
+            ix.finalize()
         return ix.download()
     ref = build(range(6), True)
     assert len(ref) > 500 and len(np.unique(ref["sid"])) == 6

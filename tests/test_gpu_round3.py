@@ -346,9 +346,8 @@ def test_small_call_path_against_oracle_and_general_path(oracle, gpu_ctx, monkey
         spec = P.make_spec(w, k, r, ms)
         osp = oracle.spec(w, k, r, ms)
         small = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
-        monkeypatch.setenv("PGR_NO_SMALL_PATH", "1")
-        general = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
-        monkeypatch.delenv("PGR_NO_SMALL_PATH")
+        with gpu_ctx.options(no_small_path=1):
+            general = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
         for i, s in enumerate(seqs):
             ref = oracle.sequence_to_shmmrs(rids[i], s, osp)
             _same(ref, small[i], "small path, spec %s len %d" % (spec_t, len(s)))

@@ -29,11 +29,8 @@ def _check_batch(oracle, gpu_ctx, seqs, spec_t, padding=False, rids=None, what="
     got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding, ctx=gpu_ctx)
     batch = P.Batch.from_seqs(seqs, ctx=gpu_ctx)
     mm, off = batch.shmmrs(P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding).download()
-    os.environ["PGR_NO_SMALL_PATH"] = "1"
-    try:
+    with gpu_ctx.options(no_small_path=1):
         mm_g, off_g = batch.shmmrs(P.make_spec(w, k, r, ms, sk), rids=rids, padding=padding).download()
-    finally:
-        del os.environ["PGR_NO_SMALL_PATH"]
     osp = oracle.spec(w, k, r, ms, sk)
     assert len(got) == len(seqs) and len(off) == len(seqs) + 1 == len(off_g)
     for i, s in enumerate(seqs):
@@ -381,7 +378,7 @@ def test_batch_beyond_2_pow_32_bases(gpu_ctx):
 
 def test_pipelined_host_batch(oracle, gpu_ctx):
     """pgr_shmmr_batch cuts host inputs of >= 512 Mbp into sub-batches that are staged by a second thread / stream
-    while the previous one computes: same result as the single-batch path (PGR_NO_PIPELINE), rids and contig order
+    while the previous one computes: same result as the single-batch path (context option no_pipeline), rids and contig order
     kept, contigs with N and empty contigs inside, spot checks against the oracle"""
     import pgrtk_amd as P
     rng = np.random.default_rng(42)
@@ -397,13 +394,9 @@ def test_pipelined_host_batch(oracle, gpu_ctx):
     spec = P.make_spec(80, 56, 4, 64)
     rids = [int(x) for x in rng.integers(0, 2 ** 31, len(seqs))]
     for r in (None, rids):
-        os.environ.pop("PGR_NO_PIPELINE", None)
         a = P.sequence_to_shmmrs_batch(seqs, spec, rids=r, ctx=gpu_ctx)
-        os.environ["PGR_NO_PIPELINE"] = "1"
-        try:
+        with gpu_ctx.options(no_pipeline=1):
             b = P.sequence_to_shmmrs_batch(seqs, spec, rids=r, ctx=gpu_ctx)
-        finally:
-            os.environ.pop("PGR_NO_PIPELINE", None)
         assert len(a) == len(b) == len(seqs)
         for i in range(len(seqs)):
             _assert_same(b[i], a[i], "pipelined vs single batch, contig %d" % i)

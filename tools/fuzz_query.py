@@ -82,14 +82,12 @@ def one_case(seed, ctx):
     got = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
     PATHS[int(ctx.last_query_prof()["path"])] += 1
     if SHORT:
-        os.environ["PGR_NO_FUSED_QUERY"] = "1"
-        got2 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
-        del os.environ["PGR_NO_FUSED_QUERY"]
+        with ctx.options(no_fused_query=1):
+            got2 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
         # once more on the same index through the general shimmer pipeline: from the second batch on the per-query kernel is
         # enqueued behind it without a host wait (path 2)
-        os.environ["PGR_NO_SMALL_PATH"] = "1"
-        got3 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
-        del os.environ["PGR_NO_SMALL_PATH"]
+        with ctx.options(no_small_path=1):
+            got3 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
         PATHS[int(ctx.last_query_prof()["path"])] += 1
         if got3 != got:
             return "seed %d: the chained query path differs (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (

@@ -1,6 +1,6 @@
 """Where the time of the host-buffer entry points goes (pgr_shmmr_batch / pgr_shmmr_batch_packed): staging alone
 (pack or copy into the pinned windows + H2D), compute, download; then the pipelined calls with the library's own
-timeline (PGR_DEBUG=1).  Quoted in DESIGN.md section 5."""
+timeline (context option debug).  Quoted in DESIGN.md section 5."""
 import os
 import sys
 import time
@@ -51,7 +51,7 @@ for name, f in (("pgr_shmmr_batch (ASCII)", lambda: P.time_shmmr_batch(seqs, sp,
     ts = sorted(f()[0] for _ in range(3))
     print("%-40s %7.2f ms = %6.1f Gbp/s" % (name, ts[1] * 1e3, bp / ts[1] / 1e9))
 sys.stdout.flush()
-os.environ["PGR_DEBUG"] = "1"
+ctx.set_option("debug", 1)
 print("--- timeline of one pipelined packed call (planes only)", flush=True)
 P.time_shmmr_batch_packed(bare, sp, ctx=ctx)
 print("--- timeline of one pipelined ASCII call", flush=True)
