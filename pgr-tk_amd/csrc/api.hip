@@ -532,6 +532,10 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         ChunkDesc d;
         size_t island;
         bool full_cap = false, probe = false, retired = false;
+        bool final = false;     // the state this chunk started from is known to be the true one
+        ChunkState t_out;       // final: the true state at ce
+        uint32_t ring_src = 0;  // final: ring slot that holds the true ring at ce (this chunk's, or the one it passed through)
+        uint64_t n_push = 0, bmin = 0;  // of the last run: pushes at the steps [cs, ce), smallest x of those with branch 2 enabled
     };
     std::vector<HChunk> ch;
     std::vector<ChunkState> s_in, s_out;
@@ -552,11 +556,14 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
         zero_ranges.push_back(rng[0]);
         zero_ranges.push_back(rng[1]);
-        const uint64_t CS = is.pal ? 32768 : CS_SHORT;
+        // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
+        // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
+        const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : CS_SHORT;
         const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
         for (uint64_t j = 0; j < nch; ++j) {
             HChunk h;
             memset(&h.d, 0, sizeof(h.d));
+            memset(&h.t_out, 0, sizeof(h.t_out));
             h.island = ii;
             h.d.contig = c;
             h.d.cs = is.whole ? 0 : is.B + j * CS;
@@ -575,6 +582,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         if (is.E < L) {  // probe: what a warmed-up (regular) machine looks like at E
             HChunk h;
             memset(&h.d, 0, sizeof(h.d));
+            memset(&h.t_out, 0, sizeof(h.t_out));
             h.island = ii;
             h.probe = true;
             h.d.contig = c;
@@ -609,12 +617,13 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         }
         if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
         a.out = (L1Rec *)ctx->ws_l1.p;
-        if ((rc = ctx->ws_serial.ensure(ctx, nq * (sizeof(ChunkDesc) + 2 * sizeof(ChunkState) + sizeof(uint32_t)))))
+        if ((rc = ctx->ws_serial.ensure(ctx, nq * (sizeof(ChunkDesc) + 2 * sizeof(ChunkState) + 2 * sizeof(uint64_t) + sizeof(uint32_t)))))
             return rc;
         ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
         ChunkState *d_in = (ChunkState *)(d_desc + nq);
         ChunkState *d_out = d_in + nq;
-        uint32_t *d_stat = (uint32_t *)(d_out + nq);
+        uint64_t *d_info = (uint64_t *)(d_out + nq);
+        uint32_t *d_stat = (uint32_t *)(d_info + 2 * nq);
         Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
         if (!zero_ranges.empty()) {
             if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
@@ -625,9 +634,11 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
         // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
         if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
-        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p);
+        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
         std::vector<ChunkState> r_in(nq), r_out(nq);
         std::vector<uint32_t> r_stat(nq);
+        std::vector<uint64_t> r_info(2 * nq);
+        PGR_HIP(ctx, hipMemcpyAsync(r_info.data(), d_info, 2 * nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipMemcpyAsync(r_in.data(), d_in, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipMemcpyAsync(r_out.data(), d_out, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipMemcpyAsync(r_stat.data(), d_stat, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -641,13 +652,22 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             s_in[todo[q]] = r_in[q];
             s_out[todo[q]] = r_out[q];
             status[todo[q]] = r_stat[q];
+            ch[todo[q]].n_push = r_info[2 * q];
+            ch[todo[q]].bmin = r_info[2 * q + 1];
         }
         if (ctx->opt.debug)
             fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu\n", round, nq,
                     islands.size(), (unsigned long long)next_region);
-        // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last)
+        // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last).  A chunk is FINAL once the state
+        // it started from is known to be the true one: the island's first chunk (regular by construction), a chunk whose
+        // recorded state at cs equals the true state its final predecessor left at ce (the warm-up was right, or the state was
+        // installed), and a chunk without a push in [cs, ce) behind a final predecessor -- the machine does not move there
+        // (shmmrutils.rs:477-480: a skipped position touches neither ring nor mdist), so its end state is its predecessor's
+        // with the k-mer rolled on, and its (empty) output is right whatever state it ran with.  Only a chunk with a final
+        // predecessor is corrected, with that predecessor's true state and ring: a correction never builds on a stale state.
         std::vector<size_t> next;
         std::vector<size_t> rebuild;  // islands to rebuild (grown or turned into one whole-contig chunk)
+        const bool relay = !ctx->opt.no_island_relay;
         for (size_t i = 0; i < ch.size(); ++i) {
             HChunk &h = ch[i];
             if (h.retired) continue;
@@ -667,32 +687,94 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
                 again = true;
             }
             const bool has_prev = i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island;
-            if (h.probe) {
-                if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
-                    if (ctx->opt.debug) {
-                        const ChunkState &p = s_in[i], &q = s_out[i - 1];
-                        fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
-                                "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
-                                (unsigned long long)p.min_x, (unsigned long long)q.min_x, (unsigned long long)p.min_y,
-                                (unsigned long long)q.min_y, (unsigned long long)p.mdist, (unsigned long long)q.mdist,
-                                (unsigned long long)p.F0, (unsigned long long)q.F0, (unsigned long long)p.R0,
-                                (unsigned long long)q.R0, (unsigned long long)p.ring_sig, (unsigned long long)q.ring_sig);
-                    }
-                    // the machine is not back in its regular regime at E: grow the island
-                    const uint64_t L = b->h_len[is.contig];
-                    is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
-                    if (L - is.E < 2ull * tc) is.E = L;
-                    rebuild.push_back(h.island);
-                }
-            } else if (!is.whole && h.d.cs > is.B && has_prev) {
-                if (memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
+            auto grow = [&]() {
+                // the machine is not back in its regular regime at E: grow the island
+                const uint64_t L = b->h_len[is.contig];
+                is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
+                if (L - is.E < 2ull * tc) is.E = L;
+                rebuild.push_back(h.island);
+            };
+            if (!relay) {  // the round-3 scheme (A/B): every seam against whatever the chunk in front produced last
+                if (h.probe) {
+                    if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) grow();
+                } else if (!is.whole && h.d.cs > is.B && has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
                     h.d.override_state = 1;
                     h.d.in_state = s_out[i - 1];
-                    h.d.ring_in = (uint32_t)(i - 1);  // the ring the chunk in front left at its end
+                    h.d.ring_in = (uint32_t)(i - 1);
                     h.d.warm = 1024;
                     again = true;
                 }
+                if (again) next.push_back(i);
+                continue;
             }
+            if (h.probe) {
+                if (!has_prev) h.final = true;
+                else if (ch[i - 1].final && !h.final) {
+                    if (memcmp(&s_in[i], &ch[i - 1].t_out, sizeof(ChunkState)) != 0) {
+                        if (ctx->opt.debug) {
+                            const ChunkState &p = s_in[i], &q = ch[i - 1].t_out;
+                            fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
+                                    "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
+                                    (unsigned long long)p.min_x, (unsigned long long)q.min_x, (unsigned long long)p.min_y,
+                                    (unsigned long long)q.min_y, (unsigned long long)p.mdist, (unsigned long long)q.mdist,
+                                    (unsigned long long)p.F0, (unsigned long long)q.F0, (unsigned long long)p.R0,
+                                    (unsigned long long)q.R0, (unsigned long long)p.ring_sig, (unsigned long long)q.ring_sig);
+                        }
+                        grow();
+                    } else {
+                        h.final = true;
+                    }
+                }
+            } else if (is.whole || !has_prev || h.d.cs <= is.B) {  // the island's first chunk
+                h.final = true;
+                h.t_out = s_out[i];
+                h.ring_src = (uint32_t)i;
+            } else if (ch[i - 1].final) {
+                const HChunk &pv = ch[i - 1];
+                const ChunkState &t = pv.t_out;
+                const bool kmer_ok = s_in[i].F0 == t.F0 && s_in[i].F1 == t.F1 && s_in[i].R0 == t.R0 && s_in[i].R1 == t.R1;
+                if ((status[i] & 4u) && kmer_ok) {  // no push in [cs, ce): the state passes through
+                    h.final = true;
+                    h.t_out = t;
+                    h.t_out.F0 = s_out[i].F0;
+                    h.t_out.F1 = s_out[i].F1;
+                    h.t_out.R0 = s_out[i].R0;
+                    h.t_out.R1 = s_out[i].R1;
+                    h.ring_src = pv.ring_src;
+                } else if (memcmp(&s_in[i], &t, sizeof(ChunkState)) == 0) {
+                    h.final = true;
+                    h.t_out = s_out[i];
+                    h.ring_src = (uint32_t)i;
+                } else if (kmer_ok && !a.sketch && t.mdist > (uint64_t)(a.w - 1) && h.n_push >= a.w && h.bmin > t.min_x &&
+                           h.d.drain_end <= h.d.ce && !(status[i] & 1u)) {
+                    // The machine arrives STUCK: mdist is beyond w - 1 (a rescan measured the distance to a minimum from in
+                    // front of a stretch of skipped pushes, shmmrutils.rs:505-514), so no rescan can fire, and no push of this
+                    // chunk reaches down to min_mer (branch 2, :516-520) -- nothing is emitted, min_mer stays, mdist counts the
+                    // pushes, and with >= w pushes the ring at ce holds this chunk's own last w pushes: exactly what its run
+                    // from a warmed-up state left there.  Its output of that run is dropped.
+                    h.final = true;
+                    h.t_out = s_out[i];
+                    h.t_out.min_x = t.min_x;
+                    h.t_out.min_y = t.min_y;
+                    h.t_out.mdist = t.mdist + h.n_push;
+                    h.ring_src = (uint32_t)i;
+                    zero_ranges.push_back(h.d.seg);
+                    zero_ranges.push_back(h.d.seg + 1);
+                } else {
+                    if (ctx->opt.debug)
+                        fprintf(stderr, "[pgr]   chunk %zu [%llu, %llu) of contig %u runs again from the true state: mdist %llu (warm-up %llu), "
+                                "min_x %llx (%llx), %llu pushes, smallest branch-2 x %llx\n", i, (unsigned long long)h.d.cs,
+                                (unsigned long long)h.d.ce, is.contig, (unsigned long long)t.mdist, (unsigned long long)s_in[i].mdist,
+                                (unsigned long long)t.min_x, (unsigned long long)s_in[i].min_x, (unsigned long long)h.n_push,
+                                (unsigned long long)h.bmin);
+                    h.final = false;
+                    h.d.override_state = 1;
+                    h.d.in_state = t;
+                    h.d.ring_in = pv.ring_src;  // the ring the last chunk with a push left at its end
+                    h.d.warm = 1024;
+                    again = true;
+                }
+            }  // else: the chunk in front is not settled yet
             if (again) next.push_back(i);
         }
         if (!rebuild.empty()) {
@@ -720,6 +802,13 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         } else {
             todo.swap(next);
         }
+    }
+    if (!zero_ranges.empty()) {  // outputs dropped by the last round's verification (chunks a stuck machine passed through)
+        Tmp_list d_zr(ctx);
+        if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
+        PGR_HIP(ctx, hipStreamSynchronize(st));
     }
     return PGR_OK;
 }

@@ -333,7 +333,8 @@ __device__ __forceinline__ uint64_t ring_signature(const uint64_t *s_rx, uint32_
 __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkDesc *__restrict__ descs,
                                                           ChunkState *__restrict__ st_in,
                                                           ChunkState *__restrict__ st_out,
-                                                          uint32_t *__restrict__ status, uint64_t *__restrict__ rings) {
+                                                          uint32_t *__restrict__ status, uint64_t *__restrict__ rings,
+                                                          uint64_t *__restrict__ info) {
     __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
     const uint32_t lane = threadIdx.x;
     const ChunkDesc cd = descs[blockIdx.x];
@@ -414,6 +415,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     const long long drain_end = (long long)cd.drain_end > ce ? (long long)cd.drain_end : ce;
     const uint64_t emit_lo = cd.emit_lo_pos;
     bool out_captured = false;
+    bool any_push = false;  // a position of the by-step range [cs, ce) was pushed
     uint64_t sig_out = 0;
     ChunkState o_out;
     auto seam = [&]() {
@@ -464,6 +466,19 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         rg[128 + q1] = q1 < w ? s_ry[(rstart + q1) % w] : U64MAX;
         if (lane == 0) rg[256] = rlen;
     };
+    long long cblk = -1;  // first block (64 positions) of the 64 blocks held in the lanes' registers
+    uint32_t c_vh = 0, c_vl = 0;
+    uint2 c_ph = make_uint2(0, 0), c_pl = make_uint2(0, 0);
+    auto fetch_blocks = [&](long long blk) {
+        cblk = blk;
+        const long long wj = (blk + lane) << 1;
+        c_vh = wj < nwords ? vplane[wj] : 0u;
+        c_vl = wj + 1 < nwords ? vplane[wj + 1] : 0u;
+        c_ph = wj < nwords ? planes[wj] : make_uint2(0, 0);
+        c_pl = wj + 1 < nwords ? planes[wj + 1] : make_uint2(0, 0);
+    };
+    uint64_t n_push = 0;        // pushes at the steps [cs, ce)
+    uint64_t lane_bmin = U64MAX;  // per lane: smallest x of those pushes with branch 2 enabled (shmmrutils.rs:516-520)
     for (long long base = pk; base < drain_end; base += 64) {
         if (base >= ce && !out_captured) {
             // end of the by-step range: this is the state the next chunk / the island-end probe must match
@@ -481,9 +496,14 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         }
         const bool draining = base >= ce;  // island end: only elements below ce are still ours
         if (base == cs && cs > 0) seam();
-        const long long wj = base >> 5;
-        uint32_t v_hi = vplane[wj], v_lo = 0;
-        if (wj + 1 < nwords) v_lo = vplane[wj + 1];
+        // the step's four words come from the lanes' registers: lane j holds block cblk + j (one coalesced load per 4096
+        // positions instead of a dependent trip to memory per step -- a lone wavefront spent ~2 us per step on those)
+        {
+            const long long blk = base >> 6;
+            if (cblk < 0 || blk < cblk || blk >= cblk + 64) fetch_blocks(blk);
+        }
+        const int li = __builtin_amdgcn_readfirstlane((int)((base >> 6) - cblk));
+        const uint32_t v_hi = (uint32_t)__builtin_amdgcn_readlane((int)c_vh, li), v_lo = (uint32_t)__builtin_amdgcn_readlane((int)c_vl, li);
         const uint64_t V = ((uint64_t)v_hi << 32) | v_lo;
         const bool kmer_only = base < pm;
         if (kmer_only && V == 0) {
@@ -514,10 +534,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             base = nb - 64;
             continue;
         }
-        uint2 p_hi = planes[wj], p_lo = make_uint2(0, 0);
-        if (wj + 1 < nwords) p_lo = planes[wj + 1];
-        const uint64_t P0 = ((uint64_t)p_hi.x << 32) | p_lo.x;  // position base+i at bit 63-i
-        const uint64_t P1 = ((uint64_t)p_hi.y << 32) | p_lo.y;
+        const uint64_t P0 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c_ph.x, li) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)c_pl.x, li);  // position base+i at bit 63-i
+        const uint64_t P1 = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)c_ph.y, li) << 32) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)c_pl.y, li);
         const long long pos = base + lane;
         uint64_t f0, f1, r0, r1;
         if (V == U64MAX) {
@@ -561,6 +581,8 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         const uint64_t pos_lo = emit_lo, pos_hi = draining ? (uint64_t)ce : ~0ull;  // position filter
         const bool skip = (f0 == r0) && (f1 == r1);
         const bool pushed = !skip && pos >= (long long)k && pos < L;
+        // a block without a single push (inside an array of palindromic k-mers, shmmrutils.rs:477-480) touches nothing
+        if (!a.sketch && __ballot(pushed) == 0) continue;
         uint32_t st;
         uint64_t h;
         const uint64_t x = kmer_x(f0, f1, r0, r1, k, st, h);
@@ -581,6 +603,11 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
 
         const uint64_t pmask = __ballot(pushed);
         const bool b_en = (uint64_t)pos >= (uint64_t)(w + k) && (uint64_t)pos < Lb && pos < L;
+        if (emit_on && !draining) {
+            any_push = true;
+            n_push += __popcll(pmask);
+            if (pushed && b_en) lane_bmin = umin64(lane_bmin, x);
+        }
         uint32_t cur = 0;  // first unprocessed lane of this step
         // Tie runs (N runs, homopolymers: every push is a branch-2 event because x <= min_mer.x keeps holding)
         // are taken in one shot: if EVERY pushed lane of the step is a record low with respect to the running
@@ -743,7 +770,20 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 a.seg_cnt[cd.seg] = (uint32_t)n_out;
             }
         }
+        // bit 2: no position of [cs, ce) was pushed and nothing is drained behind ce -- the machine's state at ce IS its state at
+        // cs and the chunk emits nothing, whatever that state was: the host hands the state of the chunk in front straight
+        // to the chunk behind (a long array of palindromic k-mers costs no round of seam correction per chunk)
+        if (!a.sketch && !any_push && drain_end <= ce && cs < ce) stat |= 4u;
         status[blockIdx.x] = stat;
+    }
+    // what the host needs to pass a state THROUGH this chunk without running it again (api.hip: run_exact_islands): the pushes
+    // of [cs, ce) and the smallest x among those that could be a branch-2 event
+    {
+        const uint64_t bmin = wave_min64(lane_bmin);
+        if (lane == 0) {
+            info[2 * (size_t)blockIdx.x] = n_push;
+            info[2 * (size_t)blockIdx.x + 1] = bmin;
+        }
     }
 }
 
@@ -847,9 +887,9 @@ void launch_level1_tails(hipStream_t st, const L1Args &a) {
     hipLaunchKernelGGL(level1_tail_kernel, dim3((a.n_contigs + TAIL_WAVES - 1) / TAIL_WAVES), dim3(64 * TAIL_WAVES), 0, st, a);
 }
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
-                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings) {
+                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info) {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings);
+    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings, d_info);
 }
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges) {
     if (n_ranges == 0) return;

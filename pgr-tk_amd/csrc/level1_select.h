@@ -6,25 +6,8 @@
 #include "pgr_device.h"
 #include "pgr_internal.h"
 
-#ifndef PGR_FORCE_SHR64
-#define PGR_FORCE_SHR64 1
-#endif
-#ifndef PGR_TILE_V2
-#define PGR_TILE_V2 1  // 1: round-2 instruction selection (strand select from SGPR lane masks, multiplications in the hash,
-                       //    window-row minima folded into the prefix chains); 0: the round-1 code, kept for A/B timing
-#endif
-#ifndef PGR_TILE_V3
-#define PGR_TILE_V3 1  // 1: round-3 instruction selection on top of V2 (canonical low plane by v_min_f64, key mask folded into a
-                       //    v_bitop3_b32); 0: the round-2 code, kept for A/B timing
-#endif
-#ifndef PGR_KEY_NOEXP
-#define PGR_KEY_NOEXP PGR_TILE_V2  // 1: window keys are the bare 56-bit hash read as a (possibly denormal) non-negative double
-#endif
 #ifndef PGR_TILE_ATTR
 #define PGR_TILE_ATTR  // experiment hook: e.g. -DPGR_TILE_ATTR='__attribute__((amdgpu_waves_per_eu(4,4)))'
-#endif
-#ifndef PGR_ABLATE
-#define PGR_ABLATE 0  // timing experiments only (1: no window passes, 2: no u64hash); results are wrong when set
 #endif
 
 namespace pgr {
@@ -77,14 +60,15 @@ __device__ __forceinline__ ContigGeom contig_geom(uint32_t len, uint32_t w, uint
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
-// level1_tile_kernel.  Measured op costs on gfx950 (tools/ubench_valu.hip): add/xor/or/and/not/lshr ~2.7
-// cycles per wave64 instruction, everything else ~4.2, and a v_cndmask_b32 that is not fed by the
-// immediately preceding v_cmp ~20.  So the kernel is written select-free:
-//   * window minima / maxima run on v_min_f64 / v_max_f64: a 56-bit hash with bit 62 set is a positive
-//     normal double whose order equals the integer order (one 4.3-cycle op instead of cmp + 2 cndmask);
-//   * validity / core / window-range tests are 16-bit per-lane masks applied with v_bfe_i32 + v_bfi_b32;
-//   * the canonical strand is chosen with a sign mask of (r0 - f0) and v_bfi_b32 (measured alternatives with the
-//     same run time: v_cmp_lt_u64 + 4 x v_cndmask_b32 + v_addc; v_cmp_lt_u64 + v_subb mask + v_bfi).
+// level1_tile_kernel.  Written against the measured issue cost of every opcode it uses (profiles/r03_ubench/
+// valu_cycles.txt): ~2.4 cycles per wave64 instruction for add / sub / and / or / xor / not / right
+// shifts / mov, ~4.2 for everything else, more for a v_cndmask through vcc.  Hence:
+//   * window minima / maxima are single v_min_f64 / v_max_f64: a 56-bit hash read as a non-negative (possibly denormal)
+//     double orders like the integer;
+//   * validity / core / window-range tests are 16-bit per-lane masks applied with v_bfe_i32;
+//   * the canonical strand is ONE v_cmp_lt_u64 into an SGPR lane mask: selects read it, v_addc shifts it into a word.
+// (The round-1 / round-2 instruction selections that used to live here behind PGR_TILE_V2 / _V3 / PGR_KEY_NOEXP / PGR_ABLATE
+// are in the history: git show a409c78:pgr-tk_amd/csrc/level1_select.h.)
 namespace {
 
 __device__ __forceinline__ double dmin(double a, double b) {
@@ -95,11 +79,6 @@ __device__ __forceinline__ double dmin(double a, double b) {
 __device__ __forceinline__ double dmax(double a, double b) {
     double r;
     asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t bfi(uint32_t mask, uint32_t a, uint32_t b) {  // (mask & a) | (~mask & b)
-    uint32_t r;
-    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(r) : "v"(mask), "v"(a), "v"(b));
     return r;
 }
 // bit u of bits -> 0 / 0xffffffff.  Inline asm on purpose: written with __builtin_amdgcn_sbfe the optimiser
@@ -125,11 +104,6 @@ __device__ __forceinline__ uint32_t lane_range_mask(int t16, int lo, int hi) {
 }
 __device__ __forceinline__ int clamp_rel(long long v) { return v < 0 ? 0 : (v > L1_EXT ? L1_EXT : (int)v); }
 
-__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {  // (a & m) | o
-    uint32_t r;
-    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(m), "v"(o));
-    return r;
-}
 // low 64 bits of the 96-bit value (w2:w1:w0) >> S, S a compile-time constant in 0..63
 template <int S>
 __device__ __forceinline__ uint64_t shr96_lo64(uint32_t w2, uint32_t w1, uint32_t w0) {
@@ -142,13 +116,11 @@ __device__ __forceinline__ uint64_t shr96_lo64(uint32_t w2, uint32_t w1, uint32_
 // (v >> sh) & mask with the shift as ONE v_lshrrev_b64 (opaque: left alone the compiler lowers about a third of
 // them to v_alignbit_b32 + v_bfe_u32, 8.4 instead of 6.9 cycles)
 __device__ __forceinline__ uint64_t shr_mask(uint64_t v, uint32_t sh, uint64_t mask) {
-#if PGR_FORCE_SHR64
     if (sh != 0) {  // sh is a constant after unrolling; an SGPR operand keeps the asm generic
         uint64_t r;
         asm("v_lshrrev_b64 %0, %1, %2" : "=v"(r) : "s"(sh), "v"(v));
         return r & mask;
     }
-#endif
     return (v >> sh) & mask;
 }
 
@@ -182,10 +154,9 @@ __device__ __forceinline__ void shift_in_mask(uint32_t &acc, uint64_t mask) {
     asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(acc), "=s"(cy) : "s"(mask));
 }
 
-constexpr uint32_t KEY_EXP = 0x40000000u;   // bit 62: keys are positive normal doubles
 constexpr uint32_t KEY_INF = 0x7FE00000u;   // hi word of the "not a k-mer" sentinel (finite, above every key)
 // what a window end outside [jstart, jend] contributes to the max pass: below every key
-constexpr uint64_t NO_WINDOW = PGR_KEY_NOEXP ? 0xFFF0000000000000ull /* -inf */ : 0ull /* +0 */;
+constexpr uint64_t NO_WINDOW = 0xFFF0000000000000ull /* -inf */;
 
 }  // namespace
 
@@ -219,14 +190,10 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
     const uint64_t rA0 = shr96_lo64<RS1>(ra2, ra1, ra0), rB0 = shr96_lo64<RS0>(ra2, ra1, ra0);
     const uint64_t rA1 = shr96_lo64<RS1>(rb2, rb1, rb0), rB1 = shr96_lo64<RS0>(rb2, rb1, rb0);
 
-    // x[]: ordered keys: (hash & (2^56-1)) | 2^62 as a double; sentinel for "no k-mer here"
-#if PGR_TILE_V2
+    // x[]: ordered keys: hash & (2^56-1) read as a double; sentinel for "no k-mer here"
     uint32_t strand_rev = 0;  // strand bits in reversed order (bit 15 - u)
     uint64_t eq0[L1_G];       // per position: lanes whose low planes are equal (f0 == r0), SGPR pairs
     uint64_t pal0_any = 0;
-#else
-    uint32_t pal_min = 0xFFFFFFFFu;  // 0 iff some position may hold a palindromic k-mer
-#endif
 #pragma unroll
     for (int u = 0; u < L1_G; ++u) {
         const uint64_t f0 = shr_mask(u >= 8 ? fa0 : fb0, (uint32_t)((L1_G - 1 - u) & 7), kmask);
@@ -239,23 +206,17 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             r0 = rc_plane(f0, k);
             r1 = rc_plane(f1, k);
         }
-#if PGR_TILE_V2
         // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488): one compare into an SGPR lane
         // mask, four selects from it, and the strand bit shifted into the per-lane word by an add-with-carry
         const uint64_t rev = cmp_lt_u64(r0, f0);
-#if PGR_TILE_V3
         // the canonical low plane is min(f0, r0) (reverse iff r0 < f0, and equal planes are the same either way): both are k <= 56
         // bit patterns, i.e. non-negative finite doubles ordered like the integers (denormals preserved) -- ONE v_min_f64
         // (4.2 cycles) instead of two selects (8.3)
         const uint64_t m0 = (uint64_t)__double_as_longlong(dmin(__longlong_as_double((long long)f0), __longlong_as_double((long long)r0)));
         const uint32_t m0l = (uint32_t)m0, m0h = (uint32_t)(m0 >> 32);
-#else
-        const uint32_t m0l = sel(rev, (uint32_t)r0, (uint32_t)f0), m0h = sel(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
-#endif
         const uint32_t m1l = sel(rev, (uint32_t)r1, (uint32_t)f1), m1h = sel(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
         uint32_t m1x = m1l ^ 0xAD12CF59u;
         asm("" : "+v"(m1x));  // keep the constant out of the hash's first step (the optimiser would distribute it)
-#if PGR_TILE_V3 && PGR_KEY_NOEXP
         // h = A ^ B is only needed as the 56-bit key (the sketch threshold aside): low word one v_xor, high word
         // (Ahi ^ Bhi) & 0x00FFFFFF as ONE v_bitop3_b32 (3.65 cycles; v_xor + v_and: 4.9)
         const uint64_t hA = u64hash_mad(((uint64_t)m0h << 32) | m0l), hB = u64hash_mad(((uint64_t)m1h << 32) | m1x);
@@ -264,19 +225,6 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         asm("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x28" : "=v"(key_hi) : "v"((uint32_t)(hA >> 32)), "v"((uint32_t)(hB >> 32)), "s"(0x00FFFFFFu));
         shift_in_mask(strand_rev, rev);  // position u ends up at bit 15 - u
         const uint64_t key = ((uint64_t)key_hi << 32) | ((uint32_t)hA ^ (uint32_t)hB);
-#else
-        const uint64_t h = u64hash_mad(((uint64_t)m0h << 32) | m0l) ^ u64hash_mad(((uint64_t)m1h << 32) | m1x);
-        shift_in_mask(strand_rev, rev);  // position u ends up at bit 15 - u
-#endif
-#if PGR_TILE_V3 && PGR_KEY_NOEXP
-#elif PGR_KEY_NOEXP
-        // the 56-bit hash itself is a non-negative double (denormal when bits 52-55 are clear: f64 denormals are preserved,
-        // .amdhsa_float_denorm_mode_16_64 3), ordered like the integer: no exponent bit to or in (one 2.4-cycle v_and instead
-        // of a 4.2-cycle v_and_or per position).  "No window" is -inf instead of +0 so that a key of 0 stays exact.
-        const uint64_t key = ((uint64_t)((uint32_t)(h >> 32) & 0x00FFFFFFu) << 32) | (uint32_t)h;
-#else
-        const uint64_t key = ((uint64_t)and_or((uint32_t)(h >> 32), 0x00FFFFFFu, KEY_EXP) << 32) | (uint32_t)h;
-#endif
         uint64_t ok_mask = ~0ull;  // lanes whose position u holds a k-mer
         if (MASKED) {
             const uint32_t inval = bit_to_mask(~valid_mask, u);
@@ -312,50 +260,6 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
     }
     const uint32_t pal_min = pal_any ? 0u : 1u;
 
-#else
-        // canonical strand: reverse iff r0 < f0 (low plane only, shmmrutils.rs:485-488); both < 2^56
-        const uint64_t dfr = r0 - f0;
-        const uint32_t rev = (uint32_t)((int32_t)((uint32_t)(dfr >> 32)) >> 31);  // 0 / ~0
-        const uint32_t m0l = bfi(rev, (uint32_t)r0, (uint32_t)f0), m0h = bfi(rev, (uint32_t)(r0 >> 32), (uint32_t)(f0 >> 32));
-        const uint32_t m1l = bfi(rev, (uint32_t)r1, (uint32_t)f1), m1h = bfi(rev, (uint32_t)(r1 >> 32), (uint32_t)(f1 >> 32));
-#if PGR_ABLATE == 2
-        const uint64_t h = (((uint64_t)m0h << 32) | m0l) * 0x9E3779B97F4A7C15ull ^ ((((uint64_t)m1h << 32) | m1l) << 7);
-#else
-        uint32_t m1x = m1l ^ 0xAD12CF59u;
-        asm("" : "+v"(m1x));  // keep the constant out of the hash's first step (the optimiser would distribute it)
-        const uint64_t h = u64hash_sa(((uint64_t)m0h << 32) | m0l) ^ u64hash_sa(((uint64_t)m1h << 32) | m1x);
-#endif
-        strand_bits = bfi(1u << u, rev, strand_bits);
-        const uint64_t key = ((uint64_t)and_or((uint32_t)(h >> 32), 0x00FFFFFFu, KEY_EXP) << 32) | (uint32_t)h;
-        uint32_t inval = 0;
-        if (MASKED) {
-            inval = bit_to_mask(~valid_mask, u);
-            const uint64_t iv = (uint64_t)inval << 32;  // sentinel: only the high word decides
-            x[u] = __longlong_as_double((long long)((key & ~iv) | (((uint64_t)KEY_INF << 32) & iv)));
-        } else {
-            x[u] = __longlong_as_double((long long)key);
-        }
-        if (SKETCH) {
-            // exact skip test (shmmrutils.rs:603-606) and the sketch threshold on the full 64-bit hash (:621)
-            const bool skip = (f0 == r0) && (f1 == r1);
-            if (!skip && h < sketch_thr) emit |= 1u << u;
-        } else {
-            // palindromic k-mer (fmmer == rmmer, shmmrutils.rs:477-480) => r0 - f0 == 0 (already computed for
-            // the strand; alone it fires with probability 2^-(k/2) on random sequence) and the low words of the
-            // high plane agree: a cheap necessary test, a hit only routes the contig to the exact serial kernel
-            const uint32_t d = (uint32_t)dfr | (uint32_t)(dfr >> 32) | ((uint32_t)f1 ^ (uint32_t)r1) | inval;
-            pal_min = pal_min < d ? pal_min : d;
-        }
-    }
-
-#endif
-#if PGR_ABLATE == 1
-    if (true) {
-#pragma unroll
-        for (int u = 0; u < L1_G; ++u) emit |= (((uint32_t)__double_as_longlong(x[u]) & 0x3Fu) == 0u) ? (1u << u) : 0u;
-        emit &= valid_mask & core_mask;
-    } else
-#endif
     if (SKETCH) {
         emit &= valid_mask & core_mask;
     } else {
@@ -379,7 +283,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
         // w a multiple of 16 (the instantiated specs: 80, 48): the window of position u is the suffix of row t - w/16
         // from offset u + 1, then w/16 - 1 WHOLE rows, then this lane's prefix 0..u -- the same whole rows for every u,
         // so their minimum seeds the prefix chain and a window minimum is ONE v_min_f64 on top of the chain
-        constexpr bool FOLD = PGR_TILE_V2 && TW != 0 && (TW % 16) == 0;
+        constexpr bool FOLD = TW != 0 && (TW % 16) == 0;
         if (FOLD) {
             constexpr int NB = (TW ? TW : 16) / 16 - 1;  // whole rows inside every window of the lane
             double pre = big;
@@ -446,7 +350,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             s_row[t] = pm;
         }
         __syncthreads();
-        constexpr bool FOLD2 = PGR_TILE_V2 && TW != 0 && (TW % 16) == 0;
+        constexpr bool FOLD2 = TW != 0 && (TW % 16) == 0;
         if (FOLD2) {
             // E[u] = max(M[u .. u + w - 1]): this lane's suffix from u, w/16 - 1 whole rows (they seed the suffix chain),
             // and the prefix of row t + w/16 through offset u - 1

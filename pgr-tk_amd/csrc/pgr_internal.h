@@ -144,7 +144,7 @@ void launch_level1_tiles(hipStream_t st, const L1Args &a);
 void launch_level1_tails(hipStream_t st, const L1Args &a);
 // exact state machine, one wavefront per chunk; status bit0 = region overflow, bit1 = override impossible
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
-                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings);
+                          ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info);
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list);
 // seg_cnt[s] = 0 for s in [ranges[2i], ranges[2i+1])
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges);

@@ -295,3 +295,21 @@ def test_bundle_bed_for_query_helper(oracle, gpu_ctx):
         for p in reversed(og.group_smps_by_principle_bundle_id(dec[sid], 50, 100000)):
             ref.append((names[sid], 1000 * sid + p[0][0][2], 1000 * sid + p[-1][0][3] + 24, "%d:%d:%d:%d" % (p[0][1], p[0][2], p[0][3], p[-1][3])))
     assert got == ref and len(ref) >= len(haps)
+
+
+def test_adj_list_of_the_golden_frag_map_through_the_gpu(oracle, gpu_ctx, golden_dir):
+    """the pinned half of SURVEY.md section 8f rank 3: `pgr_index_adj_list` (GPU: multiplicities, 6-pass radix sort, 2-point
+    stencil) against the adjacency lists derived from the reference's own golden .mdb (tests/golden/test_seqs_adj_list.json,
+    made by make_adj_list_fixture.py from the file's bytes alone) -- edge for edge, in the reference's order; both on the
+    index loaded from the golden .mdb and on the index the product builds itself from test_seqs.fa."""
+    import os
+    import pgrtk_amd as P
+    from test_mapgraph_cpu import _adj_fixture
+    cases = _adj_fixture(golden_dir)
+    from_file = P.SeqIndexDB(ctx=gpu_ctx)
+    from_file.load_from_mdb_index(os.path.join(golden_dir, "test_seqs_frag"))
+    built = P.SeqIndexDB(ctx=gpu_ctx)
+    built.load_from_fastx(os.path.join(golden_dir, "test_seqs.fa"))
+    for mc, keeps, adj in cases:
+        assert from_file.get_smp_adj_list(mc, keeps) == adj, (mc, keeps)
+        assert built.get_smp_adj_list(mc, keeps) == adj, (mc, keeps)

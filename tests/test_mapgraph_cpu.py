@@ -155,3 +155,30 @@ def test_product_graph_walks_on_cpu(oracle):
     bad = np.zeros(1, dtype=_ffi.VERTEX)
     bad["h0"] = 1
     assert L.pgr_sort_adj_list_by_weighted_dfs(None, a.ctypes.data, len(a), bad.ctypes.data, C.byref(p), C.byref(n)) < 0
+
+
+def _adj_fixture(golden_dir):
+    """tests/golden/test_seqs_adj_list.json -> [(min_count, keeps, [(sid, (h0,h1,o), (h0,h1,o))])]"""
+    import json
+    import os
+    fx = json.load(open(os.path.join(golden_dir, "test_seqs_adj_list.json")))
+    keys = [tuple(k) for k in fx["keys"]]
+
+    def node(i):
+        return (keys[i >> 1][0], keys[i >> 1][1], i & 1)
+    return [(c["min_count"], c["keeps"], [(sid, node(v), node(w)) for sid, v, w in c["adj_list"]])
+            for c in fx["cases"]]
+
+
+def test_adj_list_of_the_golden_frag_map(oracle, golden_dir):
+    """SURVEY.md section 8f rank 3, the half that can be pinned: frag_map_to_adj_list (seq_db.rs:876-945) is a sort + a
+    2-point stencil, independent of petgraph and hash-map order.  Expected lists derived from the reference's own golden
+    .mdb by tests/golden/make_adj_list_fixture.py (a plain third reading, no product / oracle code); the oracle's
+    restatement must reproduce them exactly, edge order included."""
+    import os
+    import mapgraph as og
+    spec, fm = oracle.read_mdb(os.path.join(golden_dir, "test_seqs_frag.mdb"))
+    cases = _adj_fixture(golden_dir)
+    assert [(mc, len(adj)) for mc, _, adj in cases] == [(0, 1508), (2, 1462), (16, 1134), (16, 1148), (10 ** 6, 16)]
+    for mc, keeps, adj in cases:
+        assert og.frag_map_to_adj_list(fm, mc, keeps=keeps) == adj, (mc, keeps)

@@ -66,6 +66,21 @@ for _ in range(3):
 p = ctx.last_prof()
 print("GPU: %.1f ms (%s), %d shimmers from %d level-1 minimizers, %.1f Mbp through the exact islands" %
       (min(ts) * 1e3, " ".join("%.1f" % (t * 1e3) for t in ts), sh.count, p.n_level1, p.exact_bases / 1e6))
+with ctx.options(no_island_relay=1):  # A/B: the round-3 seam correction (one seam per host round)
+    b.shmmrs(sp)
+    ts3 = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        b.shmmrs(sp)
+        ts3.append(time.perf_counter() - t0)
+print("     with the round-3 seam correction (option no_island_relay): %.1f ms" % (min(ts3) * 1e3))
+if "--rounds" in sys.argv:  # the rounds of the island path on stderr
+    sys.stderr.flush()
+    with ctx.options(debug=1):
+        b.shmmrs(sp)
+    with ctx.options(debug=1, no_island_relay=1):
+        print("--- option no_island_relay", file=sys.stderr, flush=True)
+        b.shmmrs(sp)
 sums, off = sh.checksum(), sh.offsets()
 ok = True
 t0 = time.perf_counter()
