@@ -600,9 +600,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
     uint64_t next_region = region_base;
     for (int round = 0; !todo.empty(); ++round) {
         // Every round settles at least one seam or grows / merges an island, so the number of rounds is bounded by the number
-        // of chunks plus the growth steps.  Inside a long run of non-ACGT bytes the machine carries the k-mer from BEFORE the
-        // run (shmmrutils.rs:461-476), which no warm-up inside the run can reproduce: the true state then travels down the
-        // run one chunk per round (an 18 Mbp N run of a reference chromosome: ~550 rounds of ~0.15 ms).
+        // of chunks plus the growth steps; in practice it is 1-3: a state is handed through chunks that cannot change it on the
+        // host (see the verification below), and only a chunk whose predecessor's state is final runs again.
         if (round > 1024 + 4 * (int)ch.size()) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
         const size_t nq = todo.size();
         std::vector<ChunkDesc> descs(nq);
@@ -617,32 +616,33 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         }
         if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
         a.out = (L1Rec *)ctx->ws_l1.p;
-        if ((rc = ctx->ws_serial.ensure(ctx, nq * (sizeof(ChunkDesc) + 2 * sizeof(ChunkState) + 2 * sizeof(uint64_t) + sizeof(uint32_t)))))
-            return rc;
+        // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
+        const size_t desc_bytes = nq * sizeof(ChunkDesc);
+        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 2 * sizeof(uint64_t) + sizeof(uint32_t));
+        if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
         ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
         ChunkState *d_in = (ChunkState *)(d_desc + nq);
         ChunkState *d_out = d_in + nq;
         uint64_t *d_info = (uint64_t *)(d_out + nq);
         uint32_t *d_stat = (uint32_t *)(d_info + 2 * nq);
+        uint8_t *h_img = (uint8_t *)ctx->imail;
+        memcpy(h_img, descs.data(), desc_bytes);
         Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
         if (!zero_ranges.empty()) {
             if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
             PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
         }
-        PGR_HIP(ctx, hipMemcpyAsync(d_desc, descs.data(), nq * sizeof(ChunkDesc), hipMemcpyHostToDevice, st));
+        PGR_HIP(ctx, hipMemcpyAsync(d_desc, h_img, desc_bytes, hipMemcpyHostToDevice, st));
         PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
         // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
         if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
         launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
-        std::vector<ChunkState> r_in(nq), r_out(nq);
-        std::vector<uint32_t> r_stat(nq);
-        std::vector<uint64_t> r_info(2 * nq);
-        PGR_HIP(ctx, hipMemcpyAsync(r_info.data(), d_info, 2 * nq * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipMemcpyAsync(r_in.data(), d_in, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipMemcpyAsync(r_out.data(), d_out, nq * sizeof(ChunkState), hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipMemcpyAsync(r_stat.data(), d_stat, nq * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        PGR_HIP(ctx, hipMemcpyAsync(h_img + desc_bytes, d_in, down_bytes, hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));
+        const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
+        const uint64_t *r_info = (const uint64_t *)(r_out + nq);
+        const uint32_t *r_stat = (const uint32_t *)(r_info + 2 * nq);
         PGR_HIP(ctx, hipGetLastError());
         zero_ranges.clear();
         s_in.resize(ch.size());

@@ -169,6 +169,21 @@ int pgr_ctx::ensure_mailbox(size_t bytes) {
     return PGR_OK;
 }
 
+int pgr_ctx::ensure_imail(size_t bytes) {
+    if (bytes <= imail_cap && imail) return PGR_OK;
+    if (imail) (void)hipHostFree(imail);
+    imail = nullptr;
+    imail_cap = 0;
+    const size_t want = std::max<size_t>(bytes + bytes / 2, 1u << 16);
+    hipError_t e = hipHostMalloc(&imail, want, hipHostMallocDefault);
+    if (e != hipSuccess) {
+        imail = nullptr;
+        return fail(PGR_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    }
+    imail_cap = want;
+    return PGR_OK;
+}
+
 int pgr_ctx::d2h(void *dst, const void *src_dev, size_t bytes) {
     if (bytes == 0) return PGR_OK;
     if (bytes < (4u << 20)) {  // stream ordered like the pipelined path (the context's stream is non-blocking)
@@ -244,6 +259,9 @@ void pgr_ctx::release_all() {
     mailbox_cap = 0;
     if (qmail) (void)hipHostFree(qmail);
     qmail = nullptr;
+    if (imail) (void)hipHostFree(imail);
+    imail = nullptr;
+    imail_cap = 0;
 }
 
 // ------------------------------------------------------------------------------------------------

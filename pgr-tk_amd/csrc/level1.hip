@@ -609,40 +609,62 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             if (pushed && b_en) lane_bmin = umin64(lane_bmin, x);
         }
         uint32_t cur = 0;  // first unprocessed lane of this step
-        // Tie runs (N runs, homopolymers: every push is a branch-2 event because x <= min_mer.x keeps holding)
-        // are taken in one shot: if EVERY pushed lane of the step is a record low with respect to the running
-        // minimum and no rescan is due at the first push, all of them emit in order, the last one becomes
-        // min_mer and mdist = 0 -- exactly what 64 single-event iterations would do.
-        if (pmask && mdist != (uint64_t)(w - 1)) {
-            uint64_t pm = pushed ? x : U64MAX;  // exclusive prefix minimum over the pushed lanes
+        // All branch-2 events of the step at once.  A push is a branch-2 event (shmmrutils.rs:516-527) iff it is enabled and its
+        // x is <= the x of the last event -- and every event lowers that bound to its own x, so the bound a lane sees is
+        // min(min_mer.x, the enabled pushes in front of it): ONE exclusive prefix minimum decides all 64 lanes.  That is the
+        // whole story of the step when no rescan falls into it: a rescan fires at the push that finds mdist == w - 1, i.e. after
+        // w - 1 pushes without an event.  Tie runs (runs of N, homopolymers: every push is an event) and microsatellites (an
+        // event every period) used to cost one iteration of the loop below per event -- 16 us for a step of (AC)n.
+        if (pmask) {
+            uint64_t thr;  // exclusive prefix minimum over the enabled pushes, and min_mer.x
             {
-                uint64_t incl = pm;
+                uint64_t incl = (pushed && b_en) ? x : U64MAX;
 #pragma unroll
                 for (int d = 1; d < 64; d <<= 1) {
                     const uint64_t o = shfl64(incl, (int)lane - d < 0 ? (int)lane : (int)lane - d);
                     if ((int)lane >= d) incl = umin64(incl, o);
                 }
                 const uint64_t prev = shfl64(incl, lane == 0 ? 0 : (int)lane - 1);
-                pm = lane == 0 ? U64MAX : prev;
+                thr = umin64(lane == 0 ? U64MAX : prev, min_x);
             }
-            const bool rec = pushed && b_en && x <= umin64(pm, min_x);
-            if (__ballot(rec) == pmask) {
-                const uint32_t tot = __popcll(pmask);
-                if (pushed) {
-                    const uint32_t rk = __popcll(pmask & lt_mask);
-                    if (tot - rk <= w) {
-                        const uint32_t slot = (rend + rk) % w;
-                        s_rx[slot] = x;
-                        s_ry[slot] = y;
-                    }
-                    if (emit_on && !draining) {
-                        const uint64_t o = n_out + rk;
-                        if (o < cap) {
-                            out[o] = l1rec_from_xy(x, y);
-                        }
-                    }
+            const bool is_b = pushed && b_en && x <= thr;
+            const uint64_t bm = __ballot(is_b);
+            const uint32_t tot = __popcll(pmask);
+            const uint32_t rk = __popcll(pmask & lt_mask);  // rank of this lane among the pushes of the step
+            bool safe;
+            if (mdist > (uint64_t)(w - 1)) {
+                safe = bm != 0;  // stuck beyond w - 1: only an event moves the machine (none: the loop below adds the pushes)
+            } else {
+                const uint32_t t_r = (uint32_t)((uint64_t)(w - 1) - mdist);  // the push of rank t_r finds mdist == w - 1 unless an event came first
+                if (bm) {
+                    const int fb = (int)__ffsll((unsigned long long)bm) - 1;
+                    safe = (uint32_t)__popcll(pmask & ((1ull << fb) - 1ull)) < t_r;
+                } else {
+                    safe = false;  // no event: one iteration of the loop below
                 }
-                if (emit_on && !draining) n_out += tot;
+            }
+            if (safe && w < 65) {  // a rescan between two events of the step, or behind the last one, needs w - 1 pushes in between
+                const uint64_t below = bm & lt_mask;
+                const int pb = below ? 63 - (int)__clzll((long long)below) : -1;
+                const uint32_t prk = pb >= 0 ? (uint32_t)__popcll(pmask & ((1ull << pb) - 1ull)) : 0u;
+                const bool viol = is_b && pb >= 0 && rk - prk >= w;
+                const int lb = 63 - (int)__clzll((long long)bm);
+                const uint32_t after = (uint32_t)__popcll(pmask & ~((2ull << lb) - 1ull));  // pushes behind the last event
+                safe = __ballot(viol) == 0 && after < w;
+            }
+            if (safe) {
+                if (pushed && tot - rk <= w) {
+                    const uint32_t slot = (rend + rk) % w;
+                    s_rx[slot] = x;
+                    s_ry[slot] = y;
+                }
+                if (emit_on && !draining) {
+                    if (is_b) {
+                        const uint64_t o = n_out + __popcll(bm & lt_mask);
+                        if (o < cap) out[o] = l1rec_from_xy(x, y);
+                    }
+                    n_out += __popcll(bm);
+                }
                 rend = (rend + tot) % w;
                 if (rlen + tot >= w) {
                     rlen = w;
@@ -650,10 +672,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 } else {
                     rlen += tot;
                 }
-                const int last = 63 - (int)__clzll((long long)pmask);
+                const int last = 63 - (int)__clzll((long long)bm);
                 min_x = shfl64(x, last);
                 min_y = shfl64(y, last);
-                mdist = 0;
+                mdist = (uint64_t)__popcll(pmask & ~((2ull << last) - 1ull));
                 cur = 64;
                 __syncthreads();
             }

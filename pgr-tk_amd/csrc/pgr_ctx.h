@@ -95,6 +95,11 @@ struct pgr_ctx {
     // a second, small pinned mailbox for a consumer whose kernels run behind the shimmer pipeline's (which owns `mailbox`)
     void *qmail = nullptr;
     int ensure_qmail();
+    // pinned block of the exact-island rounds (api.hip: run_exact_islands): descriptors up, states / status words down, one
+    // DMA each way per round (four pageable copies cost ~25 us each)
+    void *imail = nullptr;
+    size_t imail_cap = 0;
+    int ensure_imail(size_t bytes);
     // set by a caller of pgr_shmmrs_compute around the call: invoked (general pipeline only) with the device list, its offsets
     // [n+1], the list's capacity and the device address of the true count, right before the pipeline's one synchronization
     std::function<int(const pgr_mm128 *, const uint64_t *, uint64_t, const uint64_t *)> post_enqueue;
