@@ -41,7 +41,9 @@ extern "C" const char *pgr_version(void) { return "pgr-hip 0.3.0 (gfx950)"; }
 
 extern "C" const char *pgr_last_error(const pgr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-extern "C" void pgr_free(void *p) { free(p); }
+// results of the library: plain malloc'd blocks, or (large shimmer lists) pinned blocks that go back to a process-wide pool --
+// the DMA engine writes them directly, and a host that calls batch after batch pays for pinning and page faults once
+extern "C" void pgr_free(void *p) { pgr::result_block_release(p); }
 
 namespace {
 struct OptionName {
@@ -372,15 +374,15 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         HostPool::instance().parallel_for(jobs.size(), [&](size_t i) {
             const Job &j = jobs[i];
             if (!packed) {
-                const uint64_t bad = pack_words(src.seqs[j.c], src.lens[j.c], j.wl0, j.wl1, pin_planes + j.out, pin_valid + j.out);
+                const uint64_t bad = pack_words_stream(src.seqs[j.c], src.lens[j.c], j.wl0, j.wl1, pin_planes + j.out, pin_valid + j.out);
                 if (bad) {
                     __atomic_fetch_add(&b->h_n_invalid[j.c], (uint32_t)bad, __ATOMIC_RELAXED);
                     win_bad.fetch_add(bad, std::memory_order_relaxed);
                 }
             } else {
                 const uint64_t g = src.word0 + b->h_word_off[j.c] + j.wl0;  // word of the caller's arrays
-                memcpy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
-                if (src.valid) memcpy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
+                stream_copy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
+                if (src.valid) stream_copy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
             }
         });
         // the validity plane only travels when it says something: a window of ASCII in which the packer met no non-ACGT byte
@@ -1450,10 +1452,20 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     *out_mm = nullptr;
     *out_off = nullptr;
-    pgr_mm128 *mm = (pgr_mm128 *)host_result_alloc(std::max<uint64_t>(s->count, 1) * sizeof(pgr_mm128));
+    // a list of >= 1 MiB goes into a pinned block of the pool: ONE DMA, no staging windows, no host copy (pgr_free returns
+    // the block to the pool); if the host cannot pin more memory, a pageable block filled through the staging windows
+    const size_t bytes = (size_t)s->count * sizeof(pgr_mm128);
+    pgr_mm128 *mm = nullptr;
+    bool direct = false;
+    if (bytes >= (1u << 20) && !s->host_copy) {
+        size_t cap = 0;
+        mm = (pgr_mm128 *)pinned_result_acquire(bytes, &cap);
+        direct = mm != nullptr;
+    }
+    if (!mm) mm = (pgr_mm128 *)host_result_alloc(std::max<uint64_t>(s->count, 1) * sizeof(pgr_mm128));
     uint64_t *off = (uint64_t *)malloc(((size_t)s->n + 1) * sizeof(uint64_t));
     if (!mm || !off) {
-        free(mm);
+        result_block_release(mm);
         free(off);
         return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
     }
@@ -1461,9 +1473,16 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
     if (s->count && s->host_copy) {
         memcpy(mm, s->host_copy, s->count * sizeof(pgr_mm128));
     } else if (s->count) {
-        const int rc = ctx->d2h(mm, s->d_mm, s->count * sizeof(pgr_mm128));
+        int rc = PGR_OK;
+        if (direct) {
+            if (hipMemcpyAsync(mm, s->d_mm, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                hipStreamSynchronize(ctx->stream) != hipSuccess)
+                rc = ctx->fail(PGR_ERR_DEVICE, "result download failed");
+        } else {
+            rc = ctx->d2h(mm, s->d_mm, bytes);
+        }
         if (rc) {
-            free(mm);
+            result_block_release(mm);
             free(off);
             return rc;
         }
@@ -1607,8 +1626,11 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
     const uint64_t *lens = src.lens;
     for (uint32_t i = 0; i < n && !src.planes; ++i)
         if (lens[i] && !src.seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
-    // sub-batch size: big enough to keep the pinned-window pipeline efficient (>= 256 Mbp), small enough that the
-    // last sub-batch's processing, which nothing overlaps, stays a few percent of the call
+    // Sub-batch sizes.  Nothing computes before the first sub-batch is staged and nothing overlaps the processing of the last
+    // one, so the call ramps up and down: 64 Mbp first, doubling to the steady size (>= 256 Mbp keeps the per-sub-batch costs of
+    // the consumer -- launches, one synchronization, the result's way back -- behind the staging), and halving towards the end
+    // (never more than half of what is left, down to 48 Mbp).  Round 3 cut equal pieces of 256 Mbp: 2.3 ms went by before the
+    // first kernel ran and 1.7 ms after the last byte was staged (rocprofv3 timeline of a 1.04 Gbp call).
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
     const uint64_t SUB_BP = std::min<uint64_t>(std::max<uint64_t>(total_bp / 8, 256ull << 20), 1ull << 30);
@@ -1618,29 +1640,20 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
         uint64_t word0 = 0;  // first word of contig c0 in the caller's packed arrays
     };
     std::vector<Sub> subs;
-    for (uint32_t c = 0; c < n;) {
-        uint32_t e = c;
-        uint64_t tot = 0;
-        while (e < n && (e == c || tot + lens[e] <= SUB_BP)) tot += lens[e++];
-        Sub sb;
-        sb.c0 = c;
-        sb.c1 = e;
-        subs.push_back(sb);
-        c = e;
-    }
-    // the last sub-batch's processing is the only part of the call nothing overlaps: keep it small (its tail of <= 48 Mbp
-    // becomes a sub-batch of its own)
-    if (!subs.empty() && subs.back().c1 - subs.back().c0 >= 2) {
-        Sub &last = subs.back();
-        uint32_t cut = last.c1;
-        uint64_t tail_bp = 0;
-        while (cut - 1 > last.c0 && tail_bp + lens[cut - 1] <= (48ull << 20)) tail_bp += lens[--cut];
-        if (cut < last.c1 && tail_bp > 0) {
-            Sub tail;
-            tail.c0 = cut;
-            tail.c1 = last.c1;
-            last.c1 = cut;
-            subs.push_back(tail);
+    {
+        uint64_t target = 64ull << 20, left = total_bp;
+        for (uint32_t c = 0; c < n;) {
+            const uint64_t want = std::max<uint64_t>(48ull << 20, std::min<uint64_t>(std::min(target, SUB_BP), left / 2));
+            uint32_t e = c;
+            uint64_t tot = 0;
+            while (e < n && (e == c || tot + lens[e] <= want)) tot += lens[e++];
+            Sub sb;
+            sb.c0 = c;
+            sb.c1 = e;
+            subs.push_back(sb);
+            c = e;
+            left -= tot;
+            target *= 2;
         }
     }
     {
@@ -1761,8 +1774,12 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
     uint64_t total_bp = 0;
     for (uint32_t i = 0; i < n; ++i) total_bp += lens[i];
     const bool dbg = ctx->opt.debug != 0;
-    // The download of sub-batch i runs on its own stream while sub-batch i + 1 computes: its list goes to one of two pinned
-    // blocks asynchronously, the host copies it out (pool threads) when the next compute call has returned.
+    // The download of sub-batch i runs on its own stream while sub-batch i + 1 computes.  The result block is PINNED memory
+    // of the process-wide pool (pgr_free puts it back): the DMA engine writes every sub-batch's list where it belongs, no
+    // staging block and no host copy -- round 3 went through two pinned blocks and copied 50 MB per Gbp with the pool's
+    // threads (which the ASCII packer needs), into a fresh malloc whose page faults and munmap cost another ~2 ms per call.
+    // `direct` == false (the host cannot pin more memory): the round-3 route.
+    bool direct = true;
     struct Pending {
         pgr_shmmrs *s = nullptr;
         uint64_t dst = 0;  // first element in mm
@@ -1775,7 +1792,7 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
         pend.s = nullptr;
         int r = PGR_OK;
         if (hipEventSynchronize(ctx->d2h_ev[pend.slot]) != hipSuccess) r = ctx->fail(PGR_ERR_DEVICE, "result download failed");
-        if (!r && ps->count) {
+        if (!r && ps->count && !direct) {
             const uint8_t *srcp = (const uint8_t *)ctx->pinned_out + (size_t)pend.slot * ctx->d2h_slot_bytes;
             uint8_t *dstp = (uint8_t *)(mm + pend.dst);
             const size_t len = ps->count * sizeof(pgr_mm128);
@@ -1797,9 +1814,11 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
             fprintf(stderr, "[pgr]     compute %.2f ms (%.1f Mbp, %llu shimmers)\n",
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), b->total_bases / 1e6,
                     (unsigned long long)s->count);
-        if ((r = finish_pending())) {  // (before mm may move)
-            pgr_shmmrs_destroy(s);
-            return r;
+        if (total + s->count > cap || !direct) {
+            if ((r = finish_pending())) {  // (before mm may move / the staging block is reused)
+                pgr_shmmrs_destroy(s);
+                return r;
+            }
         }
         if (total + s->count > cap) {
             // the first sub-batch predicts the rest (shimmer density is a property of the spec)
@@ -1807,34 +1826,49 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
             if (first && b->total_bases)
                 guess = (uint64_t)((double)s->count * ((double)total_bp / (double)b->total_bases) * 1.1) + 4096;
             cap = std::max<uint64_t>(total + s->count, guess);
-            // (grown by allocate + copy: the block is huge-page advised, realloc would hand back plain pages)
-            pgr_mm128 *nm = (pgr_mm128 *)host_result_alloc(cap * sizeof(pgr_mm128));
+            pgr_mm128 *nm = nullptr;
+            if (direct) {
+                size_t got = 0;
+                nm = (pgr_mm128 *)pinned_result_acquire(cap * sizeof(pgr_mm128), &got);
+                if (nm) cap = got / sizeof(pgr_mm128);
+                else if (!mm) direct = false;  // nothing pinned yet: the pageable route for the whole call
+                else {
+                    pgr_shmmrs_destroy(s);
+                    return ctx->fail(PGR_ERR_NOMEM, "cannot pin a larger result block");
+                }
+            }
+            // (pageable: grown by allocate + copy: the block is huge-page advised, realloc would hand back plain pages)
+            if (!nm) nm = (pgr_mm128 *)host_result_alloc(cap * sizeof(pgr_mm128));
             if (!nm) {
                 pgr_shmmrs_destroy(s);
                 return ctx->fail(PGR_ERR_NOMEM, "host allocation failed");
             }
             if (total) memcpy(nm, mm, total * sizeof(pgr_mm128));
-            free(mm);
+            result_block_release(mm);
             mm = nm;
         }
         first = false;
         for (uint32_t c = c0; c < c1; ++c) off[c] = total + s->h_off[c - c0];
         const size_t bytes = s->count * sizeof(pgr_mm128);
-        // two pinned blocks of the largest sub-batch result seen so far (growing them waits for nothing: none is pending here)
-        if (bytes > ctx->d2h_slot_bytes || !ctx->pinned_out) {
-            const size_t want = std::max<size_t>(bytes + bytes / 4, 1u << 20);
-            if ((r = ctx->ensure_pinned_out(2 * want))) {
-                pgr_shmmrs_destroy(s);
-                return r;
+        uint8_t *dst = (uint8_t *)(mm + total);
+        if (!direct) {
+            // two pinned blocks of the largest sub-batch result seen so far (growing them waits for nothing: none is pending here)
+            if (bytes > ctx->d2h_slot_bytes || !ctx->pinned_out) {
+                const size_t want = std::max<size_t>(bytes + bytes / 4, 1u << 20);
+                if ((r = ctx->ensure_pinned_out(2 * want))) {
+                    pgr_shmmrs_destroy(s);
+                    return r;
+                }
+                ctx->d2h_slot_bytes = ctx->pinned_out_cap / 2;
             }
-            ctx->d2h_slot_bytes = ctx->pinned_out_cap / 2;
+            dst = (uint8_t *)ctx->pinned_out + (size_t)slot * ctx->d2h_slot_bytes;
+        } else if ((r = finish_pending())) {  // the download before this one: its device list can go now (it is over long ago)
+            pgr_shmmrs_destroy(s);
+            return r;
         }
-        if (bytes) {
-            if (hipMemcpyAsync((uint8_t *)ctx->pinned_out + (size_t)slot * ctx->d2h_slot_bytes, s->d_mm, bytes, hipMemcpyDeviceToHost,
-                               ctx->d2h_stream) != hipSuccess) {
-                pgr_shmmrs_destroy(s);
-                return ctx->fail(PGR_ERR_DEVICE, "result download failed");
-            }
+        if (bytes && hipMemcpyAsync(dst, s->d_mm, bytes, hipMemcpyDeviceToHost, ctx->d2h_stream) != hipSuccess) {
+            pgr_shmmrs_destroy(s);
+            return ctx->fail(PGR_ERR_DEVICE, "result download failed");
         }
         if (hipEventRecord(ctx->d2h_ev[slot], ctx->d2h_stream) != hipSuccess) {
             (void)hipStreamSynchronize(ctx->d2h_stream);
@@ -1855,7 +1889,7 @@ static int shmmr_batch_pipelined(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n,
         pend.s = nullptr;
     }
     if (rc) {
-        free(mm);
+        result_block_release(mm);
         free(off);
         return rc;
     }

@@ -33,5 +33,8 @@ class HostPool {
 // words [w0, w1) of ONE contig (seq, len) -> planes[0 .. w1-w0), valid[0 .. w1-w0); returns the number of non-ACGT bytes.
 // Bits past the contig's end are zero in all three planes.
 uint64_t pack_words(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid);
+// into a pinned staging window: non-temporal stores + store fence
+uint64_t pack_words_stream(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid);
+void stream_copy(void *dst, const void *src, size_t n);
 
 }  // namespace pgr

@@ -1,16 +1,20 @@
 #!/bin/bash
-# A/B builds of libpgrhip.so with extra compile flags (kernel experiments):
-#   tools/build_variant.sh <name> "<extra flags>"   -> pgr-tk_amd/lib/variants/libpgrhip_<name>.so
-# Run a variant with  PGR_HIP_LIB=pgr-tk_amd/lib/variants/libpgrhip_<name>.so python bench.py ...
+# A/B builds of the tile kernel: compiles csrc/level1.hip (and small.hip, which shares level1_select.h) with extra flags and links
+# them with the shipped objects into pgr-tk_amd/lib/variants/libpgrhip_<name>.so (used through PGR_HIP_LIB=<path>).
+#   tools/build_variant.sh <name> [extra hipcc flags ...]
 set -e
-NAME=$1; FLAGS=$2
-R=$(cd "$(dirname "$0")/.." && pwd)/pgr-tk_amd
-B=$R/build_$NAME; mkdir -p $B $R/lib/variants
-for f in level1 level2 pack scan ctx api index mapgraph exchange shard small query_fused; do
-  /opt/rocm/bin/hipcc -O3 -Wall -Wno-unused-function -Wno-unused-variable -Wno-pass-failed -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off $FLAGS -c $R/csrc/$f.hip -o $B/$f.o &
+cd "$(dirname "$0")/../pgr-tk_amd"
+name=$1; shift
+mkdir -p build/var_$name lib/variants
+FLAGS="-O3 -Wall -Wno-unused-function -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off"
+for f in level1 small; do
+  /opt/rocm/bin/hipcc $FLAGS "$@" -c csrc/$f.hip -o build/var_$name/$f.o &
 done
-g++ -O3 -std=c++17 -fPIC -pthread -c $R/csrc/hostpack.cpp -o $B/hostpack.o &
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o $R/lib/variants/libpgrhip_$NAME.so $B/*.o -ldl
-rm -rf $B
-ls -la $R/lib/variants/libpgrhip_$NAME.so
+objs=""
+for o in build/*.o; do
+  b=$(basename $o)
+  if [ -f build/var_$name/$b ]; then objs="$objs build/var_$name/$b"; else objs="$objs $o"; fi
+done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -pthread -o lib/variants/libpgrhip_$name.so $objs -ldl
+echo lib/variants/libpgrhip_$name.so
