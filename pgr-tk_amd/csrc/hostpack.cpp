@@ -108,6 +108,10 @@ HostPool::~HostPool() {
 
 unsigned HostPool::workers() const { return (unsigned)impl->th.size(); }
 
+// (Measured and rejected, tools/host_threads_sweep.py: binding the workers to the CPUs of the GPU's NUMA node.  The pinned
+// windows live there, but the caller's ASCII does not have to -- processes whose input sat on the other socket packed at
+// 78-92 Gbp/s bound against 121-137 unbound; packed input, which the workers only copy, did not care: 164-170 either way.)
+
 HostPool &HostPool::instance() {
     // one pool per process, created at first use; the calling thread always takes part in its own loops, so the pool
     // holds host_cpus() - 1 workers (at most 31)
@@ -132,11 +136,15 @@ void HostPool::parallel_for(size_t n, const std::function<void(size_t)> &fn, uns
     auto g = std::make_shared<Group>();  // shared: a helper that starts after the caller has finished finds nothing to do
     g->n = n;
     g->fn = fn;
-    auto body = [g] {
+    // items are taken `grain` at a time: the counter's cache line travels between the cores (two sockets on the GPU boxes,
+    // ~150 ns per hop), and 10 000 small items -- a query batch: one item per 10 kbp query -- spent 1.2 ms on it
+    const size_t grain = std::max<size_t>(1, n / ((size_t)(helpers + 1) * 16));
+    auto body = [g, grain] {
         size_t mine = 0;
-        for (size_t i; (i = g->next.fetch_add(1)) < g->n;) {
-            g->fn(i);
-            ++mine;
+        for (size_t i0; (i0 = g->next.fetch_add(grain)) < g->n;) {
+            const size_t i1 = std::min(g->n, i0 + grain);
+            for (size_t i = i0; i < i1; ++i) g->fn(i);
+            mine += i1 - i0;
         }
         if (mine && g->done.fetch_add(mine) + mine == g->n) {
             std::lock_guard<std::mutex> lk(g->m);
@@ -300,6 +308,8 @@ uint64_t pack_words(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, 
 
 // the same into a pinned staging window: non-temporal stores, fenced before the caller hands the window to the DMA engine
 uint64_t pack_words_stream(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid) {
+    // (short pieces -- the contigs of a query batch -- end in partial write-combining lines: regular stores there)
+    if (w1 - w0 < 2048) return pack_words(seq, len, w0, w1, planes, valid);
     uint64_t bad;
     if (have_avx512()) bad = pack_words_avx512<true>(seq, len, w0, w1, planes, valid);
     else if (have_avx2()) bad = pack_words_avx2<true>(seq, len, w0, w1, planes, valid);
