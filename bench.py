@@ -263,15 +263,17 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
     return out, ix
 
 
-def query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores):
-    """the CPU restatement on a BOUNDED sample of configs[2]: index of the first S contigs (built by the checker itself,
-    thread pool), 512 queries cut from them, one task per query on `cores` threads (= the rayon loop of
-    pgr-query.rs:135-138).  The same queries go through the GPU against a GPU index of the same S contigs and the chain
-    CONTENT (targets, chains, hit pairs, f32 scores) must be identical."""
+def query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores, gpu_index=None):
+    """the CPU restatement on the benchmark's OWN index: the frag_map of all the workload's contigs built by the checker
+    itself (thread pool, one task per contig), 8192 queries of configs[2]'s kind cut from them, one task per query on `cores`
+    threads (= the rayon loop of pgr-query.rs:135-138).  The same queries go through the GPU index of the same contigs and
+    the chain CONTENT (targets, chains, hit pairs, f32 scores) must be identical.  Workloads beyond 12 Gbp (not the
+    default) fall back to an index of the first 64 contigs on both sides."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import numpy as np
     import oracle as O
-    S = min(64, len(contig_ids))
+    full = len(contig_ids) * args.contig_len <= 12_000_000_000 and gpu_index is not None
+    S = len(contig_ids) if full else min(64, len(contig_ids))
     nq, qlen = 8192, 10_000
     sp = O.spec(*spec_t)
     oix = O.Index(sp)
@@ -290,10 +292,15 @@ def query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores):
     for _ in range(3):  # a batch is ~0.1 s: the best of three
         ref, d = O.query_batch_threads(oix, qlist, 0.025, cores)
         dt = d if dt is None else min(dt, d)
-    gb = P.Batch.synthetic([args.contig_len] * S, seed=args.seed, ctx=ctx, contig_ids=contig_ids[:S])
-    gix = P.Index(spec, ctx=ctx)
-    gix.add_resident(gb, sids=contig_ids[:S])
-    gix.finalize()
+    n_rec_cpu = int(len(oix.records())) if not full else None
+    del oix
+    if full:
+        gix = gpu_index
+    else:
+        gb = P.Batch.synthetic([args.contig_len] * S, seed=args.seed, ctx=ctx, contig_ids=contig_ids[:S])
+        gix = P.Index(spec, ctx=ctx)
+        gix.add_resident(gb, sids=contig_ids[:S])
+        gix.finalize()
     r = gix.query_hps_raw(qs, 0.025)
     n_same = 0
     for qi in range(nq):
@@ -302,7 +309,9 @@ def query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores):
     return {
         "value": nq / dt, "unit": "queries/s", "hit_pairs_per_s": sum(len(h) for q in ref for _, ch in q for _, h in ch) / dt,
         "cores": cores, "kind": "port",
-        "sample": "%d queries x %d bp against an index of %d x %d bp contigs of the same workload (best of 3 runs: %.3f s, one "
+        "index": "the benchmark's own: all %d x %d bp contigs, %d records on the GPU side" % (S, args.contig_len, gix.n_records) if full
+                 else "a sample: the first %d contigs (%s records)" % (S, n_rec_cpu),
+        "sample": "%d queries x %d bp against the CPU restatement's index of %d x %d bp contigs (best of 3 runs: %.3f s, one "
                   "task per query on %d threads; index built by the checker in %.1f s)" % (nq, qlen, S, args.contig_len, dt, cores, t_ix),
         "queries_compared": nq, "queries_with_identical_chains": n_same, "content_match": n_same == nq,
     }
@@ -969,9 +978,9 @@ def main():
         if world == 1 and args.queries > 0 and dist_query is None:
             try:
                 out["query"], _ix = query_bench(P, ctx, batch, spec, args, contig_ids)
-                del _ix
                 if not args.no_cpu_baseline:
-                    out["query"]["cpu_baseline"] = query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores)
+                    out["query"]["cpu_baseline"] = query_cpu_baseline(P, ctx, spec, spec_t, args, contig_ids, cores, gpu_index=_ix)
+                del _ix
             except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
                 out.setdefault("query", {})["error"] = repr(e)[:300]
         if world == 1 and not args.no_extras:

@@ -178,3 +178,28 @@ def test_index_sorts_non_canonical_external_records(gpu_ctx):
         got = ix.download()
         for f in ("h0", "h1", "sid", "frg_id", "bgn", "end"):
             assert np.array_equal(got[f], want[f]), f
+
+
+def test_eight_ranks_strong_scaling_plumbing_on_one_device():
+    """world = 8 before an 8-GPU node ever runs it: `bench.py --gpus 8 --strong` (self-spawned, gloo, every rank on this box's one
+    GPU) partitions ONE contig set with the greedy partitioner, every rank computes its shard, the records travel by key range
+    through an 8 x 8 all-to-all, eight shards are sorted and all-gathered into the replicated query index.  Every rank's
+    contigs are checked against the CPU restatement, the exchanged record set against what was sent.  (The same command at
+    full size -- 1000 x 10 Mbp, 30.4 M records -- is kept under profiles/r04_dist/.)"""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--single-device", "--strong", "--steps", "1",
+           "--warmup", "1", "--contigs", "67", "--contig-len", "1500000", "--queries", "240"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 67 * 1_500_000
+    ex = line["exchange"]
+    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True and len(ex["records_per_shard"]) == 8
+    assert ex["records_sent_all_ranks"] == ex["records_in_shards"] == sum(ex["records_per_shard"]) > 250_000
+    assert ex["largest_shard_over_mean"] < 1.25
+    cb = line["cpu_baseline"]
+    assert cb["content_match_all_ranks"] is True and cb["contigs_checked_all_ranks"] == 67
+    q = line["query"]
+    assert "error" not in q and q["queries_with_best_chain_on_source"] >= 236 and q["index_records"] == ex["records_in_shards"]
