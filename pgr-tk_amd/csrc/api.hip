@@ -522,14 +522,16 @@ struct Island {
 };
 
 static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
-                             const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base) {
+                             const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base,
+                             const std::vector<uint32_t> &empty_seg_ranges) {
     hipStream_t st = ctx->stream;
     // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
     // (one per chunk) -- never below 4096: a chunk owns the segment-table entry of the tile it starts in (tc <= 4096)
     uint64_t island_bases = 0;
     for (const Island &is : islands) island_bases += is.E - is.B;
     const uint64_t CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(4096, ((island_bases / 4096 + 4095) / 4096) * 4096));
-    std::vector<uint32_t> zero_ranges;  // segment ranges of (re)built islands, cleared by ONE kernel before the next chunk launch
+    // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
+    std::vector<uint32_t> zero_ranges(empty_seg_ranges);
     struct HChunk {
         ChunkDesc d;
         size_t island;
@@ -577,7 +579,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             h.d.warm = 256;
             // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
             // (ties, shmmrutils.rs:516-527), the sparse region estimate would overflow and the chunk run twice
-            h.full_cap = nch >= 8;
+            // (so is an island around non-ACGT bytes, however short: it may be one of the two ends of a long gap)
+            h.full_cap = nch >= 8 || !is.pal;
             todo.push_back(ch.size());
             ch.push_back(h);
         }
@@ -620,13 +623,13 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         a.out = (L1Rec *)ctx->ws_l1.p;
         // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
         const size_t desc_bytes = nq * sizeof(ChunkDesc);
-        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 2 * sizeof(uint64_t) + sizeof(uint32_t));
+        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 3 * sizeof(uint64_t) + sizeof(uint32_t));
         if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
         ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
         ChunkState *d_in = (ChunkState *)(d_desc + nq);
         ChunkState *d_out = d_in + nq;
         uint64_t *d_info = (uint64_t *)(d_out + nq);
-        uint32_t *d_stat = (uint32_t *)(d_info + 2 * nq);
+        uint32_t *d_stat = (uint32_t *)(d_info + 3 * nq);
         uint8_t *h_img = (uint8_t *)ctx->imail;
         memcpy(h_img, descs.data(), desc_bytes);
         Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
@@ -644,7 +647,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         PGR_HIP(ctx, hipStreamSynchronize(st));
         const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
         const uint64_t *r_info = (const uint64_t *)(r_out + nq);
-        const uint32_t *r_stat = (const uint32_t *)(r_info + 2 * nq);
+        const uint32_t *r_stat = (const uint32_t *)(r_info + 3 * nq);
         PGR_HIP(ctx, hipGetLastError());
         zero_ranges.clear();
         s_in.resize(ch.size());
@@ -654,12 +657,30 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             s_in[todo[q]] = r_in[q];
             s_out[todo[q]] = r_out[q];
             status[todo[q]] = r_stat[q];
-            ch[todo[q]].n_push = r_info[2 * q];
-            ch[todo[q]].bmin = r_info[2 * q + 1];
+            ch[todo[q]].n_push = r_info[3 * q];
+            ch[todo[q]].bmin = r_info[3 * q + 1];
         }
-        if (ctx->opt.debug)
-            fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu\n", round, nq,
-                    islands.size(), (unsigned long long)next_region);
+        if (ctx->opt.debug) {
+            uint32_t worst = 0;
+            size_t wq = 0;
+            uint64_t steps = 0;
+            uint64_t worst_t = 0;
+            for (size_t q = 0; q < nq; ++q) {
+                steps += r_stat[q] >> 8;
+                if ((r_info[3 * q + 2] & 0xFFFFFFFFull) > (worst_t & 0xFFFFFFFFull)) {
+                    worst_t = r_info[3 * q + 2];
+                    worst = r_stat[q] >> 8;
+                    wq = q;
+                }
+            }
+            fprintf(stderr, "[pgr]   slowest chunk: %.1f us (%.1f us before its first step), warm %u override %u drain_end %llu\n",
+                    (worst_t & 0xFFFFFFFFull) / 100.0, (worst_t >> 32) / 100.0, descs[wq].warm,
+                    descs[wq].override_state, (unsigned long long)descs[wq].drain_end);
+            fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu; %llu steps of 64 positions, "
+                    "the longest chunk %u (chunk [%llu, %llu) of contig %u%s)\n", round, nq, islands.size(),
+                    (unsigned long long)next_region, (unsigned long long)steps, worst, (unsigned long long)descs[wq].cs,
+                    (unsigned long long)descs[wq].ce, descs[wq].contig, descs[wq].seg == 0xFFFFFFFFu ? ", a probe" : "");
+        }
         // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last).  A chunk is FINAL once the state
         // it started from is known to be the true one: the island's first chunk (regular by construction), a chunk whose
         // recorded state at cs equals the true state its final predecessor left at ce (the warm-up was right, or the state was
@@ -1119,6 +1140,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path.  Synchronizes.
     auto run_islands = [&](uint64_t need_word) -> int {
         std::vector<Island> islands;
+        std::vector<uint32_t> gap_segs;  // [first, last + 1) segment ranges of tiles deep inside runs of non-ACGT bytes: emptied
         for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false, true});
         if (tiled && bases_tiled && need_word) {
             std::vector<uint32_t> flags(n), n_invalid(n);
@@ -1133,6 +1155,29 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
                 const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
                 const uint64_t L = b->h_len[c];
+                // The inside of a long run of non-ACGT bytes (the gaps of a reference chromosome: up to 30 Mbp) needs no
+                // machine at all.  Every position there pushes the same stale k-mer (shmmrutils.rs:461-476), so the level-1
+                // list holds one element per position, all with one x -- ties keep them through both reductions
+                // (:359-415) and the min_span stencil drops every one of them for having a neighbour with its x (:545-550).
+                // What an element further than 2 r^2 list places from both ends of such a run contributes to the rest of
+                // the list is nothing: tiles whose whole extended range is invalid AND whose two neighbours on either side
+                // are too (>= 7 kbp of the run kept at each end) are left out -- their segments stay empty, the islands on
+                // both sides end inside the run, where a warmed-up machine is exact.  (Round 3 pushed 40.9 Mbp of such
+                // positions of a chromosome-like contig through the chunk kernel and the list stage: half of its 2.4 ms.)
+                for (uint32_t t = 0; t < nt; ++t) {
+                    bool deep = nt >= 5 && t >= 2 && t + 2 < nt;
+                    for (uint32_t q = deep ? t - 2 : t; deep && q <= t + 2; ++q) deep = (tf[t0 + q] & 4) != 0;
+                    if (deep) tf[t0 + t] |= 8;  // (bit 3: host only)
+                }
+                for (uint32_t t = 0; t < nt; ++t)
+                    if (tf[t0 + t] & 8) {
+                        uint32_t e = t;
+                        while (e + 1 < nt && (tf[t0 + e + 1] & 8)) ++e;
+                        gap_segs.push_back(t0 + c + t);      // segment index of tile t of contig c
+                        gap_segs.push_back(t0 + c + e + 1);
+                        for (uint32_t q = t; q <= e; ++q) tf[t0 + q] = 0;  // not flagged: no island over them
+                        t = e;
+                    }
                 uint32_t n_flag = 0;
                 for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
                 if (n_flag == 0) continue;
@@ -1182,7 +1227,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
                 as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
             }
-            int r = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base);
+            int r = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base, gap_segs);
             if (r) return r;
             a.out = as.out;
             prof.exact_bases = 0;

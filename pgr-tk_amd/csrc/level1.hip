@@ -336,6 +336,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                                                           uint32_t *__restrict__ status, uint64_t *__restrict__ rings,
                                                           uint64_t *__restrict__ info) {
     __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
+    const uint64_t t_begin = wall_clock64();
     const uint32_t lane = threadIdx.x;
     const ChunkDesc cd = descs[blockIdx.x];
     const uint32_t c = cd.contig;
@@ -364,14 +365,34 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     long long pm = cs - (long long)cd.warm;
     if (pm < 0) pm = 0;
     long long pk = pm;
-    // last valid position below x (x > 0) when the tile table can tell: the scanned entry of the tile that holds x - 1 is the
-    // last valid position up to the END of that tile; if it lies below x it is the answer (-1: none), otherwise unknown (-2)
+    // last valid position below x (x > 0; -1: none; -2: no table).  The scanned entry of the tile that holds x - 1 is the last
+    // valid position up to the END of that tile: below x it is the answer.  Otherwise the tile has a valid base at or behind x
+    // (the chunk starts in the tile a gap ends in): the wavefront looks at the 4096 positions below x itself, and if they hold
+    // none the tile of x - 4097 ends below x, so its entry answers.  (Round 3 returned "unknown" there and the caller walked
+    // the gap 4096 positions per step: 1.7 ms for the 18 Mbp gap of a chromosome, the whole chunk kernel's time.)
     const uint64_t *__restrict__ tile_lv = a.tile_lv ? a.tile_lv + a.tile_first[c] : nullptr;
+    auto table_lv = [&](long long x) -> long long {  // entry of the tile holding x - 1, as a position (-1: none up to its end)
+        const uint64_t e = tile_lv[(x - 1) / (long long)a.tc];
+        return ((uint32_t)(e >> 32) == c + 1) ? (long long)(uint32_t)e - 1 : -1;
+    };
     auto last_valid_below = [&](long long x) -> long long {
         if (!tile_lv) return -2;
-        const uint64_t e = tile_lv[(x - 1) / (long long)a.tc];
-        const long long lv = ((uint32_t)(e >> 32) == c + 1) ? (long long)(uint32_t)e - 1 : -1;
-        return lv < x ? lv : -2;
+        const long long lv = table_lv(x);
+        if (lv < x) return lv;
+        // lane l: block of 64 positions ending at or below x, l blocks back
+        const long long b0 = ((x - 1) >> 6) - (long long)lane;
+        long long best = -1;
+        if (b0 >= 0) {
+            const long long w2 = b0 << 1;
+            uint64_t m = ((uint64_t)vplane[w2] << 32) | (w2 + 1 < nwords ? (uint64_t)vplane[w2 + 1] : 0ull);  // position 64 b0 + i at bit 63 - i
+            const long long first = b0 << 6;
+            if (first + 64 > x) m &= ~(U64MAX >> (uint32_t)(x - first));  // keep positions below x (1 <= x - first <= 63 here)
+            if (m) best = first + 63 - (long long)__builtin_ctzll(m);
+        }
+        const uint64_t any = __ballot(best >= 0);
+        if (any) return shfl64((uint64_t)best, (int)__ffsll((unsigned long long)any) - 1);  // the nearest block wins
+        const long long y = (((x - 1) >> 6) - 63) << 6;  // nothing valid in [y, x)
+        return y > 0 ? table_lv(y) : -1;
     };
     if (pm > 0) {
         // look back (64 blocks of 64 positions per step) until k valid bases precede pm
@@ -405,6 +426,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         if (pk < 0) pk = 0;
     }
 
+    const uint64_t t_lookback = wall_clock64() - t_begin;
     uint64_t F0 = 0, F1 = 0, R0 = 0, R1 = 0;  // rolling k-mer planes (uniform)
     uint32_t rlen = 0, rstart = 0, rend = 0;  // ring state (uniform)
     uint64_t min_x = U64MAX, min_y = U64MAX;
@@ -479,7 +501,9 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     };
     uint64_t n_push = 0;        // pushes at the steps [cs, ce)
     uint64_t lane_bmin = U64MAX;  // per lane: smallest x of those pushes with branch 2 enabled (shmmrutils.rs:516-520)
+    uint32_t n_steps = 0;  // loop iterations (diagnostics: status bits 8..31)
     for (long long base = pk; base < drain_end; base += 64) {
+        ++n_steps;
         if (base >= ce && !out_captured) {
             // end of the by-step range: this is the state the next chunk / the island-end probe must match
             leave_ring();
@@ -796,15 +820,16 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         // cs and the chunk emits nothing, whatever that state was: the host hands the state of the chunk in front straight
         // to the chunk behind (a long array of palindromic k-mers costs no round of seam correction per chunk)
         if (!a.sketch && !any_push && drain_end <= ce && cs < ce) stat |= 4u;
-        status[blockIdx.x] = stat;
+        status[blockIdx.x] = stat | ((n_steps > 0xFFFFFFu ? 0xFFFFFFu : n_steps) << 8);
     }
     // what the host needs to pass a state THROUGH this chunk without running it again (api.hip: run_exact_islands): the pushes
     // of [cs, ce) and the smallest x among those that could be a branch-2 event
     {
         const uint64_t bmin = wave_min64(lane_bmin);
         if (lane == 0) {
-            info[2 * (size_t)blockIdx.x] = n_push;
-            info[2 * (size_t)blockIdx.x + 1] = bmin;
+            info[3 * (size_t)blockIdx.x] = n_push;
+            info[3 * (size_t)blockIdx.x + 1] = bmin;
+            info[3 * (size_t)blockIdx.x + 2] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (t_lookback << 32);  // 100 MHz ticks (diagnostics)
         }
     }
 }
@@ -857,16 +882,20 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
     long long hi = (long long)(td.tile_local + 1) * a.tc + (long long)(a.w - 1) + 64;
     if (lo < 0) lo = 0;
     if (hi > L) hi = L;
-    bool bad = false;
-    for (long long wj = lo >> 5; wj <= (hi - 1) >> 5 && !bad; ++wj) {
+    bool bad = false, any_valid = false;
+    for (long long wj = lo >> 5; wj <= (hi - 1) >> 5 && !(bad && any_valid); ++wj) {
         uint32_t m = 0xFFFFFFFFu;  // bits of this word inside [lo, hi)
         const long long w0 = wj << 5;
         if (w0 < lo) m &= 0xFFFFFFFFu >> (uint32_t)(lo - w0);
         if (w0 + 32 > hi) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - hi);
-        bad = (v[wj] & m) != m;
+        const uint32_t x = v[wj] & m;
+        bad = bad || x != m;
+        any_valid = any_valid || x != 0u;
     }
     if (bad) {
-        a.tile_flags[tile] |= 2;  // (bit 0: the tile kernel, which has finished, saw a palindromic k-mer)
+        // bit 0: the tile kernel, which has finished, saw a palindromic k-mer; bit 1: a non-ACGT byte in the extended range;
+        // bit 2: NOTHING but non-ACGT bytes there -- the inside of a gap (api.hip: run_islands leaves such tiles out)
+        a.tile_flags[tile] |= any_valid ? 2 : 6;
         atomicOr(a.cursor + 2, 2ull);
     }
 }
