@@ -41,7 +41,7 @@ for line in open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ubenc
     line = line.strip()
     if line.startswith("KERNEL(") and "REP8_" in line:
         kn = line[len("KERNEL("):].split(",")[0].strip()
-        asm = line.split('REP8_', 1)[1].split('("', 1)[1].split('")', 1)[0]
+        asm = line.split('REP8_', 1)[1].split('("', 1)[1].split('")', 1)[0]  # (REP8_32 / _64 / _32C / _64C)
         names[kn] = [p.strip().split()[0] for p in asm.split("\\n")]
     elif line.startswith("KERNEL(k_mad_u64_u32_asm"):
         names["k_mad_u64_u32_asm"] = ["v_mad_u64_u32"]
@@ -62,9 +62,23 @@ for kn, c in last.items():
     variant = {"k_lshlrev_b32_vgpr": "v_lshlrev_b32 (shift in a VGPR)", "k_lshrrev_b32_vgpr": "v_lshrrev_b32 (shift in a VGPR)",
                "k_lshlrev_b32_e64": "v_lshlrev_b32 (VOP3 encoding)", "k_lshrrev_b32_e64": "v_lshrrev_b32 (VOP3 encoding)",
                "k_lshlrev_b32_by1": "v_lshlrev_b32 (by 1)", "k_ashrrev_i32_vgpr": "v_ashrrev_i32 (shift in a VGPR)",
+               "k_fma_f32_3src": "v_fma_f32 (three distinct VGPR sources)",
+               **{"k_%s_3src" % n: "v_%s (three distinct VGPR sources)" % n for n in
+                  ("bfi_b32", "and_or_b32", "or3_b32", "add3_u32", "xad_u32", "bitop3_b32", "min3_u32", "mad_u32_u24", "alignbit",
+                   "lshl_add_u32", "xor3_b32", "perm_b32")},
                "k_mad_u64_u32": None}.get(kn, "")
     if variant is None:
         continue  # (the C++ expression form of round 2; k_mad_u64_u32_asm is the instruction itself)
+    # Round 4: an opcode whose cost depends on the operand pattern.  v_fma_f32 and v_bitop3_b32 issue at the fast rate with
+    # three distinct sources and 1.3 cycles slower when ONE VGPR feeds two source operands (how round 3 had measured them);
+    # every other three-source integer opcode costs the full slot either way.  The kernels use distinct sources: that is
+    # the cost of the opcode, the other form is kept as a variant.
+    if kn in ("k_fma_f32_3src", "k_bitop3_b32_3src"):
+        table[ops[0]] = round(cyc, 3)
+        continue
+    if kn in ("k_fma_f32", "k_bitop3_b32"):
+        variants[ops[0] + " (one VGPR feeding two source operands)"] = round(cyc, 3)
+        continue
     if variant:
         variants[variant] = round(cyc, 3)
         continue

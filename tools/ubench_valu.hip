@@ -54,6 +54,33 @@ KERNEL(k_lshrrev_b32, DECL32, REP8_32("v_lshrrev_b32 %0, 3, %0") FIN32)
 KERNEL(k_lshlrev_b32, DECL32, REP8_32("v_lshlrev_b32 %0, 3, %0") FIN32)
 KERNEL(k_sub_u32, DECL32, REP8_32("v_sub_u32 %0, %0, %1") FIN32)
 KERNEL(k_fma_f32, DECL32, REP8_32("v_fma_f32 %0, %0, %1, %1") FIN32)
+// round 4: the guide's "2 cycles per wave64 instruction" against 3.7 for this v_fma_f32 -- is it the operand pattern (%1 twice)?
+// Three distinct VGPR sources, the VOP2 forms, and the packed form the fp32 peak is quoted on.
+#define REP8_32C(INS) \
+    asm volatile(INS : "+v"(a0) : "v"(b), "v"(c)); asm volatile(INS : "+v"(a1) : "v"(b), "v"(c)); asm volatile(INS : "+v"(a2) : "v"(b), "v"(c)); asm volatile(INS : "+v"(a3) : "v"(b), "v"(c)); \
+    asm volatile(INS : "+v"(a4) : "v"(b), "v"(c)); asm volatile(INS : "+v"(a5) : "v"(b), "v"(c)); asm volatile(INS : "+v"(a6) : "v"(b), "v"(c)); asm volatile(INS : "+v"(a7) : "v"(b), "v"(c));
+#define REP8_64C(INS) \
+    asm volatile(INS : "+v"(q0) : "v"(b), "v"(c)); asm volatile(INS : "+v"(q1) : "v"(b), "v"(c)); asm volatile(INS : "+v"(q2) : "v"(b), "v"(c)); asm volatile(INS : "+v"(q3) : "v"(b), "v"(c)); \
+    asm volatile(INS : "+v"(q4) : "v"(b), "v"(c)); asm volatile(INS : "+v"(q5) : "v"(b), "v"(c)); asm volatile(INS : "+v"(q6) : "v"(b), "v"(c)); asm volatile(INS : "+v"(q7) : "v"(b), "v"(c));
+KERNEL(k_fma_f32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_fma_f32 %0, %0, %1, %2") FIN32)
+KERNEL(k_fmac_f32, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_fmac_f32 %0, %1, %2") FIN32)
+KERNEL(k_mul_f32, DECL32, REP8_32("v_mul_f32 %0, %0, %1") FIN32)
+KERNEL(k_add_f32, DECL32, REP8_32("v_add_f32 %0, %0, %1") FIN32)
+KERNEL(k_pk_fma_f32, DECL64; uint64_t c = ((uint64_t)seed << 9) | 5, REP8_64C("v_pk_fma_f32 %0, %0, %1, %2") FIN64)
+KERNEL(k_pk_mul_f32, DECL64, REP8_64("v_pk_mul_f32 %0, %0, %1") FIN64)
+KERNEL(k_fma_f64, DECL64; uint64_t c = ((uint64_t)seed << 9) | 5, REP8_64C("v_fma_f64 %0, %0, %1, %2") FIN64)
+// ... and the three-source integer opcodes, which round 3 had measured with one VGPR feeding two source operands as well
+KERNEL(k_bfi_b32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_bfi_b32 %0, %1, %0, %2") FIN32)
+KERNEL(k_and_or_b32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_and_or_b32 %0, %0, %1, %2") FIN32)
+KERNEL(k_or3_b32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_or3_b32 %0, %0, %1, %2") FIN32)
+KERNEL(k_add3_u32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_add3_u32 %0, %0, %1, %2") FIN32)
+KERNEL(k_xad_u32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_xad_u32 %0, %0, %1, %2") FIN32)
+KERNEL(k_bitop3_b32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x96") FIN32)
+KERNEL(k_min3_u32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_min3_u32 %0, %0, %1, %2") FIN32)
+KERNEL(k_mad_u32_u24_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_mad_u32_u24 %0, %0, %1, %2") FIN32)
+KERNEL(k_alignbit_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_alignbit_b32 %0, %0, %1, %2") FIN32)
+KERNEL(k_lshl_add_u32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_lshl_add_u32 %0, %0, %1, %2") FIN32)
+KERNEL(k_perm_b32_3src, DECL32; uint32_t c = seed * 7 + 3, REP8_32C("v_perm_b32 %0, %0, %1, %2") FIN32)
 KERNEL(k_bfi_b32, DECL32, REP8_32("v_bfi_b32 %0, %1, %0, %1") FIN32)
 KERNEL(k_bfe_i32, DECL32, REP8_32("v_bfe_i32 %0, %0, 3, 1") FIN32)
 KERNEL(k_and_or_b32, DECL32, REP8_32("v_and_or_b32 %0, %0, %1, %1") FIN32)
@@ -199,6 +226,11 @@ int main() {
     std::vector<Case> cases = {
         {"v_add_u32", k_add_u32, 8}, {"v_xor_b32", k_xor_b32, 8}, {"v_or_b32", k_or_b32, 8}, {"v_and_b32", k_and_b32, 8}, {"v_not_b32", k_not_b32, 8},
         {"v_lshrrev_b32", k_lshrrev_b32, 8}, {"v_lshlrev_b32", k_lshlrev_b32, 8}, {"v_sub_u32", k_sub_u32, 8}, {"v_fma_f32", k_fma_f32, 8},
+        {"v_fma_f32 (3 sources)", k_fma_f32_3src, 8}, {"v_fmac_f32", k_fmac_f32, 8}, {"v_mul_f32", k_mul_f32, 8}, {"v_add_f32", k_add_f32, 8},
+        {"v_pk_fma_f32", k_pk_fma_f32, 8}, {"v_pk_mul_f32", k_pk_mul_f32, 8}, {"v_fma_f64", k_fma_f64, 8},
+        {"bfi 3src", k_bfi_b32_3src, 8}, {"and_or 3src", k_and_or_b32_3src, 8}, {"or3 3src", k_or3_b32_3src, 8}, {"add3 3src", k_add3_u32_3src, 8},
+        {"xad 3src", k_xad_u32_3src, 8}, {"bitop3 3src", k_bitop3_b32_3src, 8}, {"min3 3src", k_min3_u32_3src, 8}, {"mad_u32_u24 3src", k_mad_u32_u24_3src, 8},
+        {"alignbit 3src", k_alignbit_3src, 8}, {"lshl_add_u32 3src", k_lshl_add_u32_3src, 8}, {"perm 3src", k_perm_b32_3src, 8},
         {"v_bfi_b32", k_bfi_b32, 8}, {"v_bfe_i32", k_bfe_i32, 8}, {"v_and_or_b32", k_and_or_b32, 8},
         {"v_cmp_eq_u32 + v_addc (pair)", k_cmp_eq_u32, 8}, {"v_add_co_u32", k_add_co_only, 8},
         {"v_cmp_lt_u64 + lshl_add_u64 (pair)", k_cmp_lt_u64_only, 8}, {"v_cmp_eq_u64 + lshl_add_u64 (pair)", k_cmp_eq_u64_only, 8},
