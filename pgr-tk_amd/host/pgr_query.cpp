@@ -232,15 +232,17 @@ int main(int argc, char **argv) {
             for (Region &r : kv.second) {
                 std::sort(r.aln.begin(), r.aln.end());
                 const uint32_t q_bgn = r.aln.front().qb, q_end = r.aln.back().qe;
-                char tname[1024];
-                snprintf(tname, sizeof tname, "%s::%s_%u_%u_%u", base.c_str(), si.name.c_str(), r.bgn, r.end, r.orientation);
+                // (a std::string: contig names of assemblies can be long, a fixed buffer would cut them silently)
+                const std::string tname_s = base + "::" + si.name + "_" + std::to_string(r.bgn) + "_" + std::to_string(r.end) + "_" +
+                                            std::to_string(r.orientation);
+                const char *tname = tname_s.c_str();
                 if (bed_summary)
                     fprintf(hit, "%s\t%u\t%u\t%s\t#AAAAAA\t%u\t%zu\t%zu\t%zu\t%s\t%u\t%u\t%s\n", si.name.c_str(), r.bgn, r.end,
                             q_name.c_str(), r.orientation, q_len, r.aln.size(), qi, si.src.c_str(), q_bgn, q_end, tname);
                 else
                     fprintf(hit, "%03zu\t%s\t%u\t%u\t%zu\t%zu\t%s\t%s\t%u\t%u\t%u\t%s\n", qi, q_name.c_str(), q_bgn, q_end, q_len,
                             r.aln.size(), si.src.c_str(), si.name.c_str(), r.bgn, r.end, r.orientation, tname);
-                fa.push_back(Fa{kv.first, r.bgn, r.end, r.orientation, tname});
+                fa.push_back(Fa{kv.first, r.bgn, r.end, r.orientation, tname_s});
             }
         }
         fclose(hit);
