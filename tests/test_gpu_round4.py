@@ -203,3 +203,4 @@ def test_eight_ranks_strong_scaling_plumbing_on_one_device():
     assert cb["content_match_all_ranks"] is True and cb["contigs_checked_all_ranks"] == 67
     q = line["query"]
     assert "error" not in q and q["queries_with_best_chain_on_source"] >= 236 and q["index_records"] == ex["records_in_shards"]
+
