@@ -251,7 +251,9 @@ struct FusedLdsT {
     uint64_t soff[FUSED_SEGS];      // physical offset
     uint32_t scid[FUSED_SEGS];      // contig of the segment's records
     uint32_t n_seg;
-    uint32_t wide;  // the block spans more than 254 contigs: the packed keys cannot tell them apart
+    uint32_t wide;    // the block spans more than 254 contigs: the packed keys cannot tell them apart
+    uint32_t wide64;  // ... more than 125: the packed keys are not all positive normal doubles (reduce_round_wave)
+    uint32_t ccnt[(EMAX + 57) / 58 + 1];  // survivors per chunk of 58 list places (reduce_round_wave)
     unsigned long long base_out;
 };
 
@@ -364,6 +366,84 @@ __device__ __forceinline__ bool reduce_keep_packed(const FusedLds &L, const uint
     return a + b + 1 >= r;
 }
 
+// ---- One reduction (reduce_shmmr with r = 4, shmmrutils.rs:359-415) over an LDS list, neighbours from REGISTERS.
+// The closed form of the machine -- an element survives iff it is a minimum (ties included) of some full r-window of its contig's
+// list -- is the level-1 selection again with w = 4: M[j] = min(P[j-3 .. j]), E[i] = max(M[i .. i+3]), survive iff E[i] == P[i].
+// A wavefront takes 58 consecutive list places (+ 3 on both sides) with place p in lane p - first + 3; neighbours come by DPP
+// wave shifts, the two minima / maxima by doubling (2 + 2 instructions), and the packed keys (ordinal + 1) << 56 | hash -- ordinal
+// <= 124 -- are positive normal doubles ordered like the integers, so they are v_min_f64 / v_max_f64 (0 = "no element" /
+// "no window" is +0.0, below every key).  A window that crosses a contig boundary, or the list's end, has a minimum whose
+// ordinal differs from the ordinal of its last element (ordinals do not decrease along the list; an empty place is 0): it counts
+// as no window.  reduce_keep_packed did the same with 6 dependent LDS reads, 12 64-bit compares and their selects per element.
+__device__ __forceinline__ double dpp_shr1(double v) {  // lane l <- lane l - 1 (lane 0: +0.0)
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x138, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x138, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double dpp_shl1(double v) {  // lane l <- lane l + 1 (lane 63: +0.0)
+    const uint64_t b = (uint64_t)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)b, 0x130, 0xf, 0xf, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(b >> 32), 0x130, 0xf, 0xf, false);
+    return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo));
+}
+__device__ __forceinline__ double f64min(double a, double b) {
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ double f64max(double a, double b) {
+    double r;
+    asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+constexpr int RW_CORE = 58;  // list places a wavefront decides per step (64 lanes - 2 x 3 neighbours)
+template <int ITMAX, class FusedLds>
+__device__ __forceinline__ void reduce_round_wave(FusedLds &L, const uint16_t *cur, int n, uint16_t *dstl, uint32_t *total) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));  // wave-uniform: scalar chunk indices
+    const uint64_t lt = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+    const int n_chunks = (n + RW_CORE - 1) / RW_CORE;
+    uint64_t bal[ITMAX];
+    uint16_t elem[ITMAX];
+#pragma unroll
+    for (int it = 0; it < ITMAX; ++it) {
+        const int c = it * (FUSED_T / 64) + (int)wv;
+        bal[it] = 0;
+        elem[it] = 0;
+        if (c >= n_chunks) continue;  // (wave-uniform)
+        const int p = c * RW_CORE + (int)lane - 3;
+        const bool inside = p >= 0 && p < n;
+        const int e = inside ? (cur ? (int)cur[p] : p) : 0;
+        elem[it] = (uint16_t)e;
+        const double P = inside ? __longlong_as_double((long long)L.x[e]) : 0.0;
+        const double m2 = f64min(P, dpp_shr1(P));
+        const double m4 = f64min(m2, dpp_shr1(dpp_shr1(m2)));
+        // window [l-3, l] lies in one contig (and holds four elements) iff its minimum carries this lane's ordinal
+        const uint32_t hm = (uint32_t)((uint64_t)__double_as_longlong(m4) >> 32), hp = (uint32_t)((uint64_t)__double_as_longlong(P) >> 32);
+        const double M = ((hm ^ hp) >> 24) == 0u ? m4 : 0.0;
+        const double e2 = f64max(M, dpp_shl1(M));
+        const double E = f64max(e2, dpp_shl1(dpp_shl1(e2)));
+        const bool keep = inside && lane >= 3 && lane < 3 + RW_CORE &&
+                          (uint64_t)__double_as_longlong(E) == (uint64_t)__double_as_longlong(P);
+        bal[it] = __ballot(keep);
+        if (lane == 0) L.ccnt[c] = (uint32_t)__popcll(bal[it]);
+    }
+    __syncthreads();
+    // exclusive prefix of the chunk counts (lane c holds chunk c: one wave scan), then the survivors' list in order
+    const uint32_t mine = (int)lane < n_chunks ? L.ccnt[lane] : 0u;
+    const uint32_t incl = wave_incl_sum(mine);
+#pragma unroll
+    for (int it = 0; it < ITMAX; ++it) {
+        const int c = it * (FUSED_T / 64) + (int)wv;
+        if (c >= n_chunks) continue;
+        const uint32_t base = c ? (uint32_t)__builtin_amdgcn_readlane((int)incl, c - 1) : 0u;
+        if ((bal[it] >> lane) & 1ull) dstl[base + (uint32_t)__popcll(bal[it] & lt)] = elem[it];
+    }
+    *total = n_chunks ? (uint32_t)__builtin_amdgcn_readlane((int)incl, n_chunks - 1) : 0u;
+}
+
 }  // namespace
 
 // FusedArgsPub (pgr_internal.h): l1 = unordered level-1 segments; seg_dst = exclusive scan of seg_cnt
@@ -400,7 +480,10 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     uint64_t done = lo;  // logical elements below `done` are loaded
     uint32_t cid0 = 0;   // contig of the block's first element (the first staged segment holds it)
     bool first_batch = true;
-    if (t == 0) L.wide = 0;
+    if (t == 0) {
+        L.wide = 0;
+        L.wide64 = 0;
+    }
     while (done < hi) {
         if (t < FUSED_SEGS + 1) {
             const uint32_t sg = seg0 + t;
@@ -418,33 +501,37 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
         }
         // elements covered by the staged descriptors: [sdst[0], sdst[64]) intersected with [done, hi)
         const uint64_t cover_hi = L.sdst[FUSED_SEGS] < hi ? L.sdst[FUSED_SEGS] : hi;
-        // a lane's elements g, g + 256, ... lie in non-decreasing segments: one binary search for the first, then the
-        // segment index only moves forward (segments hold ~200 elements: 0-2 steps instead of 6 dependent LDS reads)
-        int s_lo = 0;
-        bool first = true;
-        for (uint64_t g = done + t; g < cover_hi; g += FUSED_T) {
-            if (first) {
-                int s_hi = FUSED_SEGS;  // largest s with sdst[s] <= g
-                while (s_hi - s_lo > 1) {
-                    const int mid = (s_lo + s_hi) >> 1;
-                    if (L.sdst[mid] <= g) s_lo = mid;
-                    else s_hi = mid;
-                }
-                first = false;
-            } else {
-                while (s_lo + 1 < FUSED_SEGS && L.sdst[s_lo + 1] <= g) ++s_lo;
-            }
-            // 12-byte record -> MM128: x = key << 8 | k, y = contig << 32 | pos << 1 | strand
-            const L1Rec m = a.l1[L.soff[s_lo] + (g - L.sdst[s_lo])];
-            const uint32_t cid = L.scid[s_lo];
+        // One wavefront per staged segment, lane i its element i, i + 64, ...: a segment is a tile's ~100 minimizers, contiguous in
+        // the level-1 buffer, so the copy needs no search (round 3: every lane looked its elements up in the descriptors -- a
+        // binary search + 64-bit offset arithmetic per element, a third of the kernel's VALU instructions).
+        {
+            const uint32_t lane = t & 63;
+            const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
+            for (int sg = wv; sg < FUSED_SEGS; sg += FUSED_T / 64) {
+                const uint64_t s_lo = L.sdst[sg], s_hi = L.sdst[sg + 1];
+                if (s_lo >= cover_hi) break;  // (logical starts do not decrease)
+                const uint64_t g0 = s_lo > done ? s_lo : done, g1 = s_hi < cover_hi ? s_hi : cover_hi;
+                if (g1 <= g0) continue;  // empty segment, or one that lies below `done`
+                const L1Rec *__restrict__ src = a.l1 + (L.soff[sg] + (g0 - s_lo));
+                const uint32_t cid = L.scid[sg];
+                const uint32_t cnt = (uint32_t)(g1 - g0), d0 = (uint32_t)(g0 - lo);
 #if PGR_L2_PACKED
-            const uint32_t ord = cid - cid0;
-            if (ord > 254u) L.wide = 1;  // benign race: every writer stores 1
-            L.x[g - lo] = ((uint64_t)(ord & 0xFFu) << 56) | ((uint64_t)m.key_hi << 32) | m.key_lo;
-#else
-            L.x[g - lo] = ((((uint64_t)m.key_hi << 32) | m.key_lo) << 8) | (uint64_t)a.k;
+                const uint32_t ord = cid - cid0;
+                if (ord > 253u) L.wide = 1;    // benign race: every writer stores 1
+                if (ord > 124u) L.wide64 = 1;  // (the same)
+                const uint32_t top = ((ord + 1u) & 0xFFu) << 24;
 #endif
-            L.y[g - lo] = ((uint64_t)cid << 32) | m.ypos;
+                for (uint32_t i = lane; i < cnt; i += 64) {
+                    // 12-byte record -> MM128: x = key << 8 | k, y = contig << 32 | pos << 1 | strand
+                    const L1Rec m = src[i];
+#if PGR_L2_PACKED
+                    L.x[d0 + i] = ((uint64_t)(top | m.key_hi) << 32) | m.key_lo;
+#else
+                    L.x[d0 + i] = ((((uint64_t)m.key_hi << 32) | m.key_lo) << 8) | (uint64_t)a.k;
+#endif
+                    L.y[d0 + i] = ((uint64_t)cid << 32) | m.ypos;
+                }
+            }
         }
         done = cover_hi > done ? cover_hi : done;
         seg0 += FUSED_SEGS;
@@ -471,7 +558,23 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     // ---- reduce x2 (shmmrutils.rs:533-535) on index lists, then the min_span stencil (:536-555)
     const uint16_t *cur = nullptr;  // nullptr = identity list over [0, ne)
     int n_cur = ne;
-    if (a.do_reduce) {
+#if PGR_L2_PACKED
+    const bool wave_rounds = a.do_reduce && a.r == 4 && packed && L.wide64 == 0;
+#else
+    const bool wave_rounds = false;
+#endif
+    if (wave_rounds) {
+        constexpr int ITMAX = ((EMAX + RW_CORE - 1) / RW_CORE + FUSED_T / 64 - 1) / (FUSED_T / 64);
+        static_assert((EMAX + RW_CORE - 1) / RW_CORE <= 64, "one wave scan over the chunk counts");
+        for (int round = 0; round < 2; ++round) {
+            uint16_t *dstl = round == 0 ? L.s1 : L.s2;
+            uint32_t tot;
+            reduce_round_wave<ITMAX, FusedLds>(L, cur, n_cur, dstl, &tot);
+            __syncthreads();
+            cur = dstl;
+            n_cur = (int)tot;
+        }
+    } else if (a.do_reduce) {
         for (int round = 0; round < 2; ++round) {
             uint16_t *dstl = round == 0 ? L.s1 : L.s2;
             const int C = (n_cur + FUSED_T - 1) / FUSED_T;
