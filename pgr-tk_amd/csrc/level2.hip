@@ -606,39 +606,53 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
             n_cur = (int)tot;
         }
     }
-    // span filter over `cur`; survivors that are core elements are emitted in order
+    // span filter (shmmrutils.rs:536-555) over `cur`; survivors that are core elements are emitted in order.  The same
+    // wave-per-chunk scheme as the reductions: 62 list places per step, the two neighbours' key, position and contig by DPP.
     const int c_lo = (int)(core_lo - lo), c_hi = (int)(core_hi - lo);
-    const int C = (n_cur + FUSED_T - 1) / FUSED_T;
-    bool keep[FUSED_CMAX];
-    uint32_t rank[FUSED_CMAX];
+    constexpr int SF_CORE = 62;
+    constexpr int SF_ITMAX = ((EMAX + SF_CORE - 1) / SF_CORE + FUSED_T / 64 - 1) / (FUSED_T / 64);
+    const uint32_t lane = t & 63;
+    const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)(t >> 6));
+    const uint64_t lt = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+    const int n_chunks = (n_cur + SF_CORE - 1) / SF_CORE;
+    uint64_t bal[SF_ITMAX], kx[SF_ITMAX], ky[SF_ITMAX];
 #pragma unroll
-    for (int j = 0; j < FUSED_CMAX; ++j) {
-        const int k = j * FUSED_T + (int)t;
-        bool kp = false;
-        if (j < C && k < n_cur) {
-            const int e = cur ? cur[k] : k;
-            if (e >= c_lo && e < c_hi) {
-                const uint64_t ye = L.y[e];
-                const uint32_t cid = (uint32_t)(ye >> 32);
-                const bool has_p = k > 0, has_n = k + 1 < n_cur;
-                const int ep = has_p ? (cur ? cur[k - 1] : k - 1) : 0;
-                const int en = has_n ? (cur ? cur[k + 1] : k + 1) : 0;
-                const bool first = !has_p || (uint32_t)(L.y[ep] >> 32) != cid;
-                const bool last = !has_n || (uint32_t)(L.y[en] >> 32) != cid;
-                kp = true;
-                if (!first && !last) {
-                    const uint32_t pp = (uint32_t)((L.y[ep] & 0xFFFFFFFFull) >> 1),
-                                   mp = (uint32_t)((ye & 0xFFFFFFFFull) >> 1),
-                                   np = (uint32_t)((L.y[en] & 0xFFFFFFFFull) >> 1);
-                    kp = (uint32_t)(mp - pp) > a.min_span && (uint32_t)(np - mp) > a.min_span && L.x[ep] != L.x[e] &&
-                         L.x[e] != L.x[en];
-                }
-            }
+    for (int it = 0; it < SF_ITMAX; ++it) {
+        const int c = it * (FUSED_T / 64) + (int)wv;
+        bal[it] = 0;
+        kx[it] = ky[it] = 0;
+        if (c >= n_chunks) continue;  // (wave-uniform)
+        const int p = c * SF_CORE + (int)lane - 1;
+        const bool inside = p >= 0 && p < n_cur;
+        const int e = inside ? (cur ? (int)cur[p] : p) : 0;
+        const uint64_t px = inside ? L.x[e] : 0ull, py = inside ? L.y[e] : ~0ull;  // (contig ~0: no neighbour shares it)
+        kx[it] = px;
+        ky[it] = py;
+        const uint32_t xl = (uint32_t)px, xh = (uint32_t)(px >> 32), yl = (uint32_t)py, cid = (uint32_t)(py >> 32);
+        // previous / next list place (lane 0 / 63 of the step: not core lanes)
+        const uint32_t p_xl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xl, 0x138, 0xf, 0xf, false);
+        const uint32_t p_xh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x138, 0xf, 0xf, false);
+        const uint32_t p_yl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)yl, 0x138, 0xf, 0xf, false);
+        const uint32_t p_cid = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cid, 0x138, 0xf, 0xf, false);
+        const uint32_t n_xl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xl, 0x130, 0xf, 0xf, false);
+        const uint32_t n_xh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)xh, 0x130, 0xf, 0xf, false);
+        const uint32_t n_yl = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)yl, 0x130, 0xf, 0xf, false);
+        const uint32_t n_cid = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)cid, 0x130, 0xf, 0xf, false);
+        bool kp = inside && lane >= 1 && lane <= SF_CORE && e >= c_lo && e < c_hi;
+        // (a place outside the list carries contig ~0, so "no previous / next element" and "another contig" are one test)
+        const bool first = p_cid != cid, last = n_cid != cid;
+        if (!first && !last) {
+            const uint32_t pp = p_yl >> 1, mp = yl >> 1, np = n_yl >> 1;
+            kp = kp && (uint32_t)(mp - pp) > a.min_span && (uint32_t)(np - mp) > a.min_span && (p_xl != xl || p_xh != xh) &&
+                 (n_xl != xl || n_xh != xh);
         }
-        keep[j] = kp;
+        bal[it] = __ballot(kp);
+        if (lane == 0) L.ccnt[c] = (uint32_t)__popcll(bal[it]);
     }
-    uint32_t tot;
-    strided_ranks<FUSED_CMAX, FusedLds>(L, keep, C, rank, &tot);
+    __syncthreads();
+    const uint32_t mine = (int)lane < n_chunks ? L.ccnt[lane] : 0u;
+    const uint32_t incl = wave_incl_sum(mine);
+    const uint32_t tot = n_chunks ? (uint32_t)__builtin_amdgcn_readlane((int)incl, n_chunks - 1) : 0u;
     if (t == 0) {
         // fixed slot per workgroup; only blocks with more survivors than the slot use the shared cursor
         // (same-address atomics saturate at ~88/us on gfx950)
@@ -658,19 +672,21 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     const unsigned long long base = L.base_out;
     if (base != ~0ull) {
 #pragma unroll
-        for (int j = 0; j < FUSED_CMAX; ++j)
-            if (keep[j]) {
-                const int k = j * FUSED_T + (int)t;
-                const int e = cur ? cur[k] : k;
+        for (int it = 0; it < SF_ITMAX; ++it) {
+            const int c = it * (FUSED_T / 64) + (int)wv;
+            if (c >= n_chunks) continue;
+            const uint32_t cb = c ? (uint32_t)__builtin_amdgcn_readlane((int)incl, c - 1) : 0u;  // (all lanes: uniform)
+            if ((bal[it] >> lane) & 1ull) {
                 pgr_mm128 m;
 #if PGR_L2_PACKED
-                m.x = (L.x[e] << 8) | (uint64_t)a.k;  // the ordinal byte falls off the top
+                m.x = (kx[it] << 8) | (uint64_t)a.k;  // the ordinal byte falls off the top
 #else
-                m.x = L.x[e];
+                m.x = kx[it];
 #endif
-                m.y = L.y[e];
-                a.out[base + rank[j]] = m;
+                m.y = ky[it];
+                a.out[base + cb + (uint32_t)__popcll(bal[it] & lt)] = m;
             }
+        }
     }
 }
 
