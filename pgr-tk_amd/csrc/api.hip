@@ -58,7 +58,7 @@ const std::vector<OptionName> &option_names() {
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
-        {"no_island_relay", &O::no_island_relay}};
+        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}};
     return v;
 }
 }  // namespace
@@ -556,7 +556,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         const uint64_t L = b->h_len[c];
         const uint32_t nt = tile_first[c + 1] - tile_first[c];
         const uint32_t seg0 = tile_first[c] + c;
-        uint32_t rng[2] = {seg0 + (uint32_t)(is.B / tc), seg0 + (uint32_t)((is.E + tc - 1) / tc)};
+        // (a contig that is one tile may be longer than a tile core: clamped)
+        uint32_t rng[2] = {seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, is.B / tc), seg0 + (uint32_t)std::min<uint64_t>(nt, (is.E + tc - 1) / tc)};
         if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
         zero_ranges.push_back(rng[0]);
         zero_ranges.push_back(rng[1]);
@@ -1007,7 +1008,11 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint32_t w_eff = sketch ? 1u : spec->w;
     // tile core: extended tile minus both halos, rounded down to the 64-position step of the exact kernel so
     // that islands of exact tiles start and end on step boundaries
-    const uint32_t tc = ((L1_EXT - 2 * (w_eff - 1)) / 64) * 64;
+    // (batches of short contigs -- reads --: tiles of one wavefront's 1024 positions, pgr_internal.h)
+    const bool short_tiles = tiled && n && b->total_bases / n <= (uint64_t)L1_SHORT_MEAN_LEN && w_eff <= (uint32_t)L1_SHORT_MAX_W &&
+                             !ctx->opt.no_short_tiles;
+    const uint32_t ext = short_tiles ? (uint32_t)L1_EXT_SHORT : (uint32_t)L1_EXT;
+    const uint32_t tc = ((ext - 2 * (w_eff - 1)) / 64) * 64;
 
     // ---- host plan: tiles for the closed form, list for the serial kernel
     std::vector<uint32_t> tile_first((size_t)n + 1);
@@ -1017,7 +1022,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         tile_first[c] = (uint32_t)n_tiles64;
         const uint64_t L = b->h_len[c];
         if (L == 0) continue;
-        n_tiles64 += (L + tc - 1) / tc;  // every contig owns tile segments (the chunk kernel reuses them)
+        n_tiles64 += l1_tiles_of(L, tc, ext);  // every contig owns tile segments (the chunk kernel reuses them)
         if (tiled) bases_tiled += L;  // contigs with non-ACGT bytes too: only islands around them are replaced
         else serial.push_back(c);     // w < 17: the whole contig goes through the exact kernel
     }
@@ -1083,6 +1088,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     a.k = spec->k;
     a.r = spec->r;
     a.tc = tc;
+    a.ext = ext;
     a.sketch = sketch ? 1u : 0u;
     a.cursor = d_cursor;
     a.seg_off = (uint64_t *)ctx->ws_seg_off.p;
@@ -1196,7 +1202,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                     uint32_t ta = t > 0 ? t - 1 : 0, tb = t;
                     while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
                     if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
-                    Island is{c, (uint64_t)ta * tc, std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
+                    Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
                     for (uint32_t q = ta; q <= tb; ++q) is.pal = is.pal || (tf[t0 + q] & 1);
                     if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
                     if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {

@@ -24,12 +24,15 @@ namespace pgr {
 
 // TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
 // instantiated with constants so that every row offset, shift and mask is an immediate.
-template <int TW, int TK, bool SKETCH>
-__global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a) {
-    __shared__ double s_suf[L1_G][L1_BLOCK];  // suffix-min per row, later prefix-max
-    __shared__ double s_row[L1_BLOCK];        // row min, later row max
-    __shared__ uint2 s_words[L1_WORDS];
-    __shared__ uint32_t s_wsum[L1_BLOCK / 64];
+template <int TW, int TK, bool SKETCH, int BLK>
+__global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a) {
+    constexpr int EXT = BLK * L1_G;                 // positions per extended tile
+    constexpr int WORDS = (EXT + 96) / 32 + 5;      // plane words staged per tile (tile + k-mer look-back)
+    static_assert(WORDS <= BLK, "one lane per staged word");
+    __shared__ double s_suf[L1_G][BLK];  // suffix-min per row, later prefix-max
+    __shared__ double s_row[BLK];        // row min, later row max
+    __shared__ uint2 s_words[WORDS];
+    __shared__ uint32_t s_wsum[BLK / 64];
     __shared__ unsigned long long s_base;
     __shared__ int s_skip;
 #ifdef PGR_LDS_PAD
@@ -46,15 +49,16 @@ __global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1A
     const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
     const ContigGeom g = contig_geom(td.len, w, k);
     const long long c0 = (long long)tile_local * a.tc;
-    long long c1 = c0 + a.tc;
-    if (c1 > g.L) c1 = g.L;
-    const long long e0 = c0 - (long long)(w - 1);  // first extended position (may be negative)
+    const long long c1 = l1_core_end(c0, g.L, a.tc, (uint32_t)EXT);
+    // first extended position: the core's look-back, except in front of a contig's first tile (pgr_internal.h: a contig of up
+    // to EXT positions is one tile whatever its core -- a 1 kbp read is one wavefront's 1024 positions)
+    const long long e0 = tile_local ? c0 - (long long)(w - 1) : 0;
 
     // ---- stage the 2-bit planes of the tile (+ k-mer look-back) in LDS
     const long long wbase = (e0 - 96) >> 5;  // floor
     const long long nwords = (g.L + 31) >> 5;
     const uint2 *__restrict__ planes = a.b.planes + td.word_off;
-    if (t < L1_WORDS) {
+    if (t < WORDS) {
         const long long wi = wbase + t;
         uint2 v = make_uint2(0u, 0u);
         if (wi >= 0 && wi < nwords) v = planes[wi];
@@ -65,13 +69,13 @@ __global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1A
 
     // ---- per-lane masks over this lane's 16 positions (tile-extended coordinates 16t .. 16t+15)
     const int t16 = (int)t * L1_G;
-    const uint32_t core_mask = lane_range_mask(t16, clamp_rel(c0 - e0), clamp_rel(c1 - e0));
+    const uint32_t core_mask = lane_range_mask(t16, clamp_rel<EXT>(c0 - e0), clamp_rel<EXT>(c1 - e0));
     // interior tile (uniform): all 4096 extended positions are real k-mers and every window end is in range
-    const bool interior = e0 >= (long long)k && e0 + L1_EXT <= g.L && e0 >= g.jstart && e0 + L1_EXT - 1 <= g.jend;
+    const bool interior = e0 >= (long long)k && e0 + EXT <= g.L && e0 >= g.jstart && e0 + EXT - 1 <= g.jend;
     uint32_t valid_mask = 0xFFFFu, mwin_mask = 0xFFFFu;
     if (!interior) {
-        valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
-        mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
+        valid_mask = lane_range_mask(t16, clamp_rel<EXT>((long long)k - e0), clamp_rel<EXT>(g.L - e0));
+        mwin_mask = lane_range_mask(t16, clamp_rel<EXT>(g.jstart - e0), clamp_rel<EXT>(g.jend + 1 - e0));
     }
 
     // ---- hash + select.  Waves whose 64x16 positions are all inside the contig and inside the window-end
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1A
     // tile_select unless SKETCH, two in the compaction below) and is done.  Never wavefront 0: thread 0 writes the tile's
     // segment record even when the contig is shorter than k and no position of the tile is a k-mer.  A separate exit: the live path's registers are
     // not shared with it.
-    if (!interior && t >= 64 && __all(valid_mask == 0u && mwin_mask == 0u)) {
+    if (BLK > 64 && !interior && t >= 64 && __all(valid_mask == 0u && mwin_mask == 0u)) {
         if (!SKETCH) {
             const double big = mk_double(0u, KEY_INF);
 #pragma unroll
@@ -106,10 +110,10 @@ __global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1A
     }
     const bool wave_full = interior || __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
     if (wave_full)
-        tile_select<TW, TK, SKETCH, false>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
+        tile_select<TW, TK, SKETCH, false, BLK>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
                                           core_mask, x, strand_bits, emit);
     else
-        tile_select<TW, TK, SKETCH, true>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
+        tile_select<TW, TK, SKETCH, true, BLK>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
                                          core_mask, x, strand_bits, emit);
 
     // ---- ordered compaction: block scan of per-lane counts, one cursor bump per tile
@@ -121,12 +125,12 @@ __global__ __launch_bounds__(L1_BLOCK) PGR_TILE_ATTR void level1_tile_kernel(L1A
     __syncthreads();
     uint32_t wave_base = 0;
 #pragma unroll
-    for (int i = 0; i < L1_BLOCK / 64 - 1; ++i)
+    for (int i = 0; i < BLK / 64 - 1; ++i)
         if ((uint32_t)i < wv) wave_base += s_wsum[i];
     if (t == 0) {
         uint32_t total = 0;
 #pragma unroll
-        for (int i = 0; i < L1_BLOCK / 64; ++i) total += s_wsum[i];
+        for (int i = 0; i < BLK / 64; ++i) total += s_wsum[i];
         // Every tile owns a fixed slot of a.slot elements (no atomics: one shared cursor saturates at ~88
         // same-address atomics/us, which would cap the kernel at ~29 ms for 2.5 M tiles).  Only tiles denser
         // than the slot (low-complexity sequence: ties emit every position) allocate from the overflow cursor.
@@ -371,8 +375,11 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     // none the tile of x - 4097 ends below x, so its entry answers.  (Round 3 returned "unknown" there and the caller walked
     // the gap 4096 positions per step: 1.7 ms for the 18 Mbp gap of a chromosome, the whole chunk kernel's time.)
     const uint64_t *__restrict__ tile_lv = a.tile_lv ? a.tile_lv + a.tile_first[c] : nullptr;
+    const long long n_tiles_c = a.tile_lv ? (long long)(a.tile_first[c + 1] - a.tile_first[c]) : 0;
     auto table_lv = [&](long long x) -> long long {  // entry of the tile holding x - 1, as a position (-1: none up to its end)
-        const uint64_t e = tile_lv[(x - 1) / (long long)a.tc];
+        long long ti = (x - 1) / (long long)a.tc;
+        if (ti > n_tiles_c - 1) ti = n_tiles_c - 1;  // (a contig that is one tile may be longer than a tile core)
+        const uint64_t e = tile_lv[ti];
         return ((uint32_t)(e >> 32) == c + 1) ? (long long)(uint32_t)e - 1 : -1;
     };
     auto last_valid_below = [&](long long x) -> long long {
@@ -855,8 +862,7 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
     const uint32_t c = td.contig;
     const long long L = td.len;
     {
-        long long c1 = (long long)(td.tile_local + 1) * a.tc;
-        if (c1 > L) c1 = L;
+        const long long c1 = l1_core_end((long long)td.tile_local * a.tc, L, a.tc, a.ext);
         if (a.b.n_invalid[c] == 0) {  // every base valid
             a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)c1;
             return;
@@ -865,8 +871,7 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
     const uint32_t *__restrict__ v = a.b.valid + td.word_off;
     {   // last valid position of the tile's core [c0, c1)
         const long long c0 = (long long)td.tile_local * a.tc;
-        long long c1 = c0 + a.tc;
-        if (c1 > L) c1 = L;
+        const long long c1 = l1_core_end(c0, L, a.tc, a.ext);
         long long last = -1;
         for (long long wj = (c1 - 1) >> 5; wj >= (c0 >> 5) && last < 0; --wj) {
             uint32_t m = 0xFFFFFFFFu;
@@ -879,7 +884,7 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
         a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)(last + 1);
     }
     long long lo = (long long)td.tile_local * a.tc - (long long)(a.w - 1) - (long long)(a.k - 1) - 64;
-    long long hi = (long long)(td.tile_local + 1) * a.tc + (long long)(a.w - 1) + 64;
+    long long hi = l1_core_end((long long)td.tile_local * a.tc, L, a.tc, a.ext) + (long long)(a.w - 1) + 64;
     if (lo < 0) lo = 0;
     if (hi > L) hi = L;
     bool bad = false, any_valid = false;
@@ -924,14 +929,24 @@ void launch_level1_tiles(hipStream_t st, const L1Args &a) {
     if (a.n_tiles == 0) return;
     const uint32_t n_desc = a.n_tiles > a.n_contigs ? a.n_tiles : a.n_contigs;  // (>= 8: a tile per non-empty contig ... or not)
     hipLaunchKernelGGL(tile_desc_kernel, dim3(((n_desc > 8 ? n_desc : 8) + 255) / 256), dim3(256), 0, st, a);
+    if (a.ext == (uint32_t)L1_EXT_SHORT) {  // batches of short contigs: one wavefront per tile
+        const dim3 g(a.n_tiles), bl(L1_BLOCK_SHORT);
+        if (a.sketch)
+            hipLaunchKernelGGL((level1_tile_kernel<0, 0, true, L1_BLOCK_SHORT>), g, bl, 0, st, a);
+        else if (a.w == 80 && a.k == 56)
+            hipLaunchKernelGGL((level1_tile_kernel<80, 56, false, L1_BLOCK_SHORT>), g, bl, 0, st, a);
+        else
+            hipLaunchKernelGGL((level1_tile_kernel<0, 0, false, L1_BLOCK_SHORT>), g, bl, 0, st, a);
+        return;
+    }
     if (a.sketch)
-        hipLaunchKernelGGL((level1_tile_kernel<0, 0, true>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((level1_tile_kernel<0, 0, true, L1_BLOCK>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
     else if (a.w == 80 && a.k == 56)
-        hipLaunchKernelGGL((level1_tile_kernel<80, 56, false>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((level1_tile_kernel<80, 56, false, L1_BLOCK>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
     else if (a.w == 48 && a.k == 56)
-        hipLaunchKernelGGL((level1_tile_kernel<48, 56, false>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((level1_tile_kernel<48, 56, false, L1_BLOCK>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
     else
-        hipLaunchKernelGGL((level1_tile_kernel<0, 0, false>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
+        hipLaunchKernelGGL((level1_tile_kernel<0, 0, false, L1_BLOCK>), dim3(a.n_tiles), dim3(L1_BLOCK), 0, st, a);
 }
 void launch_level1_tails(hipStream_t st, const L1Args &a) {
     if (a.n_contigs == 0) return;

@@ -102,7 +102,8 @@ __device__ __forceinline__ uint32_t lane_range_mask(int t16, int lo, int hi) {
     b = b < 0 ? 0 : (b > 16 ? 16 : b);
     return (b > a) ? (((1u << b) - 1u) & ~((1u << a) - 1u)) : 0u;
 }
-__device__ __forceinline__ int clamp_rel(long long v) { return v < 0 ? 0 : (v > L1_EXT ? L1_EXT : (int)v); }
+template <int EXT>
+__device__ __forceinline__ int clamp_rel(long long v) { return v < 0 ? 0 : (v > EXT ? EXT : (int)v); }
 
 // low 64 bits of the 96-bit value (w2:w1:w0) >> S, S a compile-time constant in 0..63
 template <int S>
@@ -162,9 +163,9 @@ constexpr uint64_t NO_WINDOW = 0xFFF0000000000000ull /* -inf */;
 
 // Hash and select this lane's 16 positions.  MASKED = false: every position of the wave is a real k-mer
 // and every window end is inside [jstart, jend] (interior of a contig) -> no masking instructions.
-template <int TW, int TK, bool SKETCH, bool MASKED>
+template <int TW, int TK, bool SKETCH, bool MASKED, int BLK>
 __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_t k, uint32_t t, long long q,
-                                            long long wbase, const uint2 *s_words, double (*s_suf)[L1_BLOCK],
+                                            long long wbase, const uint2 *s_words, double (*s_suf)[BLK],
                                             double *s_row, int *s_skip, uint32_t valid_mask, uint32_t mwin_mask,
                                             uint32_t core_mask, double (&x)[L1_G], uint32_t &strand_bits,
                                             uint32_t &emit) {
@@ -359,10 +360,10 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
 #pragma unroll
             for (int i = 1; i <= NB; ++i) {
                 const int ti = (int)t + i;
-                sm = dmax(sm, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
+                sm = dmax(sm, s_row[ti > BLK - 1 ? BLK - 1 : ti]);
             }
             int te = (int)t + NB + 1;
-            te = te > L1_BLOCK - 1 ? L1_BLOCK - 1 : te;
+            te = te > BLK - 1 ? BLK - 1 : te;
             uint32_t neq = 0;  // bit u set iff E[u] < x[u]  (E <= x always: every window minimum is <= x)
 #pragma unroll
             for (int u = L1_G - 1; u >= 0; --u) {
@@ -378,7 +379,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
             for (int i = 1; i <= re_lo; ++i) {
                 if (i == re_lo) qlo = acc;
                 const int ti = (int)t + i;
-                acc = dmax(acc, s_row[ti > L1_BLOCK - 1 ? L1_BLOCK - 1 : ti]);
+                acc = dmax(acc, s_row[ti > BLK - 1 ? BLK - 1 : ti]);
             }
             double sm = none;
             uint32_t neq = 0;  // bit u set iff E[u] < x[u]  (E <= x always: every window minimum is <= x)
@@ -389,7 +390,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
                 const int re = d >> 4;
                 const int off = d & 15;
                 int te = (int)t + re;
-                te = te > L1_BLOCK - 1 ? L1_BLOCK - 1 : te;
+                te = te > BLK - 1 ? BLK - 1 : te;
                 double ev = dmax(sm, s_suf[off][te]);
                 ev = dmax(ev, re == re_lo ? qlo : acc);
                 shift_in_lt(neq, ev, x[u]);  // u runs 15..0, so bit u ends up at position u

@@ -20,6 +20,23 @@ constexpr int L1_G = 16;                 // consecutive positions owned by one l
 constexpr int L1_EXT = L1_BLOCK * L1_G;  // positions per tile including both halos
 constexpr int L1_WORDS = (L1_EXT + 96) / 32 + 5;  // plane words staged per tile (tile + k-mer look-back)
 constexpr int L1_MIN_W = 17;             // window sizes below this use the serial kernel
+// Batches of short contigs (reads) run the same kernel with ONE wavefront per tile of 1024 positions: a 1 kbp read in a
+// 4096-position tile keeps two of four wavefronts busy and the other two hold its 35 KB of LDS while they wait at the barriers.
+constexpr int L1_BLOCK_SHORT = 64;
+constexpr int L1_EXT_SHORT = L1_BLOCK_SHORT * L1_G;
+constexpr int L1_SHORT_MEAN_LEN = 2048;  // mean contig length of a batch at or below which the one-wavefront tiles are used
+constexpr int L1_SHORT_MAX_W = 128;      // ... for windows up to this (tile core = 1024 - 2 (w - 1) positions)
+// Tiles of a contig of L positions, tile core tc, extended tile ext: a contig of up to ext - L1_G positions is ONE tile (its
+// last core position needs no halo behind it: nothing is selected beyond the contig's end.  Not the tile's last lane: the
+// max pass reads the rows behind a lane clamped to the last row, which is that lane's own); otherwise tile t owns the core
+// [t tc, min((t+1) tc, L)).  The first tile's extended range starts at position 0 (there is nothing in front of it), every
+// other tile's at its core - (w - 1).
+__host__ __device__ inline uint64_t l1_tiles_of(uint64_t L, uint32_t tc, uint32_t ext) {
+    return L == 0 ? 0 : (L <= ext - L1_G ? 1 : (L + tc - 1) / tc);
+}
+__host__ __device__ inline long long l1_core_end(long long c0, long long L, uint32_t tc, uint32_t ext) {
+    return (L <= (long long)(ext - L1_G) || c0 + (long long)tc > L) ? L : c0 + (long long)tc;
+}
 constexpr uint64_t U64MAX = 0xFFFFFFFFFFFFFFFFull;
 
 // ------------------------------------------------------------------ device-resident batch
@@ -122,6 +139,7 @@ struct L1Args {
     const uint32_t *tile_first;  // [n+1] device
     TileDesc *desc;              // [n_tiles] scratch, filled by launch_level1_tiles
     uint32_t w, k, r, tc, sketch;
+    uint32_t ext;                // positions per extended tile: L1_EXT, or L1_EXT_SHORT for batches of short contigs
     L1Rec *out;                  // level-1 segments: [0, n_tiles*slot) fixed tile slots, then the overflow region
     uint32_t slot;               // elements per tile slot
     uint64_t ovf_base;           // first element of the overflow region (= n_tiles * slot)

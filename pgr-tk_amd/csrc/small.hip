@@ -156,12 +156,12 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
         }
         __syncthreads();
         const int t16 = (int)t * L1_G;
-        const uint32_t core_mask = lane_range_mask(t16, clamp_rel(c0 - e0), clamp_rel(c1 - e0));
+        const uint32_t core_mask = lane_range_mask(t16, clamp_rel<L1_EXT>(c0 - e0), clamp_rel<L1_EXT>(c1 - e0));
         const bool interior = e0 >= (long long)k && e0 + L1_EXT <= g.L && e0 >= g.jstart && e0 + L1_EXT - 1 <= g.jend;
         uint32_t valid_mask = 0xFFFFu, mwin_mask = 0xFFFFu;
         if (!interior) {
-            valid_mask = lane_range_mask(t16, clamp_rel((long long)k - e0), clamp_rel(g.L - e0));
-            mwin_mask = lane_range_mask(t16, clamp_rel(g.jstart - e0), clamp_rel(g.jend + 1 - e0));
+            valid_mask = lane_range_mask(t16, clamp_rel<L1_EXT>((long long)k - e0), clamp_rel<L1_EXT>(g.L - e0));
+            mwin_mask = lane_range_mask(t16, clamp_rel<L1_EXT>(g.jstart - e0), clamp_rel<L1_EXT>(g.jend + 1 - e0));
         }
         double x[L1_G];
         uint32_t strand_bits = 0, emit = 0;
@@ -170,10 +170,10 @@ __global__ __launch_bounds__(L1_BLOCK) void small_shmmr_kernel(SmallArgs a) {
         // and a short contig's few tiles are latency, not throughput)
         const bool wave_full = interior || __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
         if (wave_full)
-            tile_select<TW, TK, false, false>(la, w, k, t, q, wbase, L.words, L.suf, L.row, &L.skip, valid_mask, mwin_mask, core_mask, x,
+            tile_select<TW, TK, false, false, L1_BLOCK>(la, w, k, t, q, wbase, L.words, L.suf, L.row, &L.skip, valid_mask, mwin_mask, core_mask, x,
                                              strand_bits, emit);
         else
-            tile_select<TW, TK, false, true>(la, w, k, t, q, wbase, L.words, L.suf, L.row, &L.skip, valid_mask, mwin_mask, core_mask, x,
+            tile_select<TW, TK, false, true, L1_BLOCK>(la, w, k, t, q, wbase, L.words, L.suf, L.row, &L.skip, valid_mask, mwin_mask, core_mask, x,
                                             strand_bits, emit);
         // ordered append to the level-1 list
         const uint32_t cnt = __popc(emit);

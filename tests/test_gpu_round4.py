@@ -204,3 +204,63 @@ def test_eight_ranks_strong_scaling_plumbing_on_one_device():
     q = line["query"]
     assert "error" not in q and q["queries_with_best_chain_on_source"] >= 236 and q["index_records"] == ex["records_in_shards"]
 
+
+
+def _same(ref, got, what=""):
+    assert len(ref) == len(got), "%s: %d vs %d shimmers" % (what, len(ref), len(got))
+    assert np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"]), what
+
+
+def test_one_wavefront_tiles_for_batches_of_short_contigs(oracle, gpu_ctx):
+    """csrc/level1.hip: a batch whose mean contig length is <= 2048 (reads) runs the level-1 kernel with ONE wavefront per
+    tile of 1024 positions; a contig of up to ext - 16 positions is one tile whose extended range starts at position 0.
+    Lengths around every boundary of that geometry (one tile / two tiles, tile core, k, w), several specs incl. the sketch
+    variant, non-ACGT bytes and palindromic k-mers (islands of the exact machine on the short geometry), a long contig in
+    the batch; compared with the oracle and with the same call on the 4096-position tiles."""
+    import pgrtk_amd as P
+    import seqgen
+    rng = np.random.default_rng(404)
+    for spec_t in ((80, 56, 4, 64, False), (48, 56, 4, 12, False), (33, 31, 3, 8, False), (128, 56, 2, 64, False), (17, 9, 2, 0, False),
+                   (80, 56, 1, 64, False), (80, 21, 2, 16, True)):
+        w, k, r, ms, sk = spec_t
+        tc = (1024 - 2 * ((1 if sk else w) - 1)) // 64 * 64
+        lens = [0, 1, k - 1, k, k + 1, k + w - 2, k + w - 1, k + w, 2 * w + k, 3 * w, 500, 999, 1000, 1001, 1007, 1008, 1009, 1023, 1024,
+                1025, tc - 1, tc, tc + 1, 2 * tc - w, 2 * tc - 1, 2 * tc, 2 * tc + 1, 2 * tc + w + k, 3 * tc, 3000, 4017, 5000]
+        lens = [n for n in lens if n >= 0]
+        seqs = [seqgen.rnd(rng, n) for n in lens] * 3
+        # adversarial short contigs: N runs, lower case, bytes 0..3, low complexity, palindromic stretches, tandem repeats
+        for mode in range(seqgen.N_MODES):
+            for L in (300, 900, 1008, 1100, 1700, 2600):
+                seqs.append(seqgen.adversarial(rng, mode, L))
+        seqs.append(seqgen.rnd(rng, 400) + b"N" * 700 + seqgen.rnd(rng, 500))
+        seqs.append(b"N" * 1008)
+        seqs.append(b"AT" * 504)
+        seqs.append(b"A" * 1000)
+        seqs.append(seqgen.rnd(rng, 30_000))  # one long contig among the reads (mean stays below 2048)
+        seqs.append(seqgen.rnd(rng, 9_000) + b"N" * 3000 + b"AT" * 90 + seqgen.rnd(rng, 9_000))
+        assert sum(len(s) for s in seqs) / len(seqs) <= 2048
+        rids = [int(v) for v in rng.integers(0, 2 ** 31, len(seqs))]
+        spec = P.make_spec(w, k, r, ms, sketch=sk) if sk else P.make_spec(w, k, r, ms)
+        osp = oracle.spec(w, k, r, ms, sketch=sk) if sk else oracle.spec(w, k, r, ms)
+        with gpu_ctx.options(no_small_path=1):
+            short = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
+            with gpu_ctx.options(no_short_tiles=1):
+                long_ = P.sequence_to_shmmrs_batch(seqs, spec, rids=rids, ctx=gpu_ctx)
+        for i, s in enumerate(seqs):
+            ref = oracle.sequence_to_shmmrs(rids[i], s, osp)
+            _same(ref, short[i], "one-wavefront tiles, spec %s contig %d len %d" % (spec_t, i, len(s)))
+            _same(ref, long_[i], "4096-position tiles, spec %s contig %d len %d" % (spec_t, i, len(s)))
+    # resident batch of 20 000 reads of ragged length (past the small path's 4096 contigs): whole-contig checksums
+    n = 20_000
+    lens = [int(v) for v in rng.integers(700, 1400, n)]
+    b = P.Batch.synthetic(lens, seed=43, ctx=gpu_ctx)
+    spec_t = (80, 56, 4, 64)
+    sh = b.shmmrs(P.make_spec(*spec_t))
+    with gpu_ctx.options(no_short_tiles=1):
+        sh4 = b.shmmrs(P.make_spec(*spec_t))
+    assert sh.count == sh4.count and np.array_equal(sh.checksum(), sh4.checksum()) and np.array_equal(sh.offsets(), sh4.offsets())
+    sums, off = sh.checksum(), sh.offsets()
+    import bench
+    for c in range(0, n, 97):
+        ref = oracle.sequence_to_shmmrs(c, bench.synth_contig_ascii(43, c, lens[c]), oracle.spec(*spec_t))
+        assert int(off[c + 1] - off[c]) == len(ref) and np.array_equal(sums[c], oracle.shmmr_checksum(ref)), c
