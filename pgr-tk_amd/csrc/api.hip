@@ -1014,17 +1014,43 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const uint32_t ext = short_tiles ? (uint32_t)L1_EXT_SHORT : (uint32_t)L1_EXT;
     const uint32_t tc = ((ext - 2 * (w_eff - 1)) / 64) * 64;
 
-    // ---- host plan: tiles for the closed form, list for the serial kernel
-    std::vector<uint32_t> tile_first((size_t)n + 1);
+    // ---- host plan: tiles for the closed form, list for the serial kernel.  (The table lives in the context: a million reads
+    // are 4 MB that a fresh vector would fault in page by page on every call; big batches fill it on the pool's threads.)
+    std::vector<uint32_t> &tile_first = ctx->h_tile_first;
+    tile_first.resize((size_t)n + 1);
     std::vector<uint32_t> serial;
     uint64_t n_tiles64 = 0, bases_tiled = 0;
-    for (uint32_t c = 0; c < n; ++c) {
-        tile_first[c] = (uint32_t)n_tiles64;
-        const uint64_t L = b->h_len[c];
-        if (L == 0) continue;
-        n_tiles64 += l1_tiles_of(L, tc, ext);  // every contig owns tile segments (the chunk kernel reuses them)
-        if (tiled) bases_tiled += L;  // contigs with non-ACGT bytes too: only islands around them are replaced
-        else serial.push_back(c);     // w < 17: the whole contig goes through the exact kernel
+    if (tiled && n >= (1u << 17)) {
+        constexpr uint32_t PIECE = 1u << 14;
+        const uint32_t n_pieces = (n + PIECE - 1) / PIECE;
+        std::vector<uint64_t> piece_tiles((size_t)n_pieces + 1, 0);
+        HostPool::instance().parallel_for(n_pieces, [&](size_t p) {
+            const uint32_t c0 = (uint32_t)p * PIECE, c1 = std::min<uint32_t>(n, c0 + PIECE);
+            uint64_t t = 0;
+            for (uint32_t c = c0; c < c1; ++c) t += l1_tiles_of(b->h_len[c], tc, ext);
+            piece_tiles[p + 1] = t;
+        });
+        for (uint32_t p = 0; p < n_pieces; ++p) piece_tiles[p + 1] += piece_tiles[p];
+        n_tiles64 = piece_tiles[n_pieces];
+        bases_tiled = b->total_bases;
+        if (n_tiles64 + n + 1 < (1ull << 31))
+            HostPool::instance().parallel_for(n_pieces, [&](size_t p) {
+                const uint32_t c0 = (uint32_t)p * PIECE, c1 = std::min<uint32_t>(n, c0 + PIECE);
+                uint64_t t = piece_tiles[p];
+                for (uint32_t c = c0; c < c1; ++c) {
+                    tile_first[c] = (uint32_t)t;
+                    t += l1_tiles_of(b->h_len[c], tc, ext);
+                }
+            });
+    } else {
+        for (uint32_t c = 0; c < n; ++c) {
+            tile_first[c] = (uint32_t)n_tiles64;
+            const uint64_t L = b->h_len[c];
+            if (L == 0) continue;
+            n_tiles64 += l1_tiles_of(L, tc, ext);  // every contig owns tile segments (the chunk kernel reuses them)
+            if (tiled) bases_tiled += L;  // contigs with non-ACGT bytes too: only islands around them are replaced
+            else serial.push_back(c);     // w < 17: the whole contig goes through the exact kernel
+        }
     }
     if (n_tiles64 + n + 1 >= (1ull << 31)) return ctx->fail(PGR_ERR_INVALID_ARG, "batch too large (tile count)");
     tile_first[n] = (uint32_t)n_tiles64;
@@ -1036,12 +1062,12 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     const double dens = sketch ? 1.0 / (double)(1ull << (4 + spec->r)) : 2.0 / (double)(spec->w + 1);
     const uint32_t slot = std::min<uint32_t>(tc, (((uint32_t)((double)tc * dens * 2.0) + 64 + 63) / 64) * 64);
     const uint64_t slots_total = (uint64_t)n_tiles * slot;
-    uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 300ull * n;
+    uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 32ull * n;  // (a contig's tail has its own slot)
     // low-complexity / N-rich input overflows the fixed tile slots by far more than that: remember what the last call with
     // this spec needed per base (a genome comes as many similar batches) instead of running stage 1 twice every time
     const double l1_key = (double)spec->w * 1e3 + spec->k + (sketch ? 0.5 : 0.0);
     if (ctx->est_l1_key == l1_key && ctx->est_ovf_ratio > 0)
-        cap_par = std::max<uint64_t>(cap_par, (uint64_t)((double)bases_tiled * ctx->est_ovf_ratio * 1.1) + 65536 + 300ull * n);
+        cap_par = std::max<uint64_t>(cap_par, (uint64_t)((double)bases_tiled * ctx->est_ovf_ratio * 1.1) + 65536 + 32ull * n);
 
     constexpr size_t N_CURSOR = 8;  // [0..2] level 1 (L1Args::cursor), [4..5] fused list stage
     constexpr size_t N_STATUS = 10;
@@ -1133,7 +1159,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         if (tiled && bases_tiled) launch_level1_tiles(st, a);
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-        launch_level1_tails(st, a);
+        if (!(tiled && bases_tiled)) launch_level1_tails(st, a);  // (otherwise every contig's last tile has run its tail)
         if (tiled && bases_tiled) {  // flags tiles with a non-ACGT byte in reach, records every tile's last valid position
             L1Args am = a;
             am.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
@@ -1247,7 +1273,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     pgr_shmmrs *res = new pgr_shmmrs();
     res->ctx = ctx;
     res->n = n;
-    res->h_off.assign((size_t)n + 1, 0);
+    // (the offsets of a million reads are 8 MB: the block of a destroyed result of this context is used again)
+    if ((size_t)n + 1 >= (1u << 17) && ctx->spare_off.capacity() >= (size_t)n + 1) res->h_off.swap(ctx->spare_off);
+    res->h_off.resize((size_t)n + 1);
     auto bail = [&](int code) {
         pgr_shmmrs_destroy(res);
         return code;
@@ -1264,7 +1292,9 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     // estimates: level-1 count from the density (low-complexity sequence exceeds it: retried with the true count),
     // final count from this context's last result with the same spec (first call: a third of the level-1 estimate)
     const uint64_t l1_bound = slots_total + cap_par + b->total_bases / 4 + 4096ull * n + 4096;  // what stage 1 can emit at all
-    const uint64_t l1_est = std::min<uint64_t>(l1_bound, (uint64_t)((double)b->total_bases * dens * 1.06) + 2048ull * n + 8192);
+    // (per contig: the first window and the tail emit a few elements on top of the density -- NOT thousands: 2048 per contig made
+    // the list stage of 10^6 reads a grid of 2 x 10^6 workgroups for 25 x 10^3 of work, 0.6 of its 0.8 ms, and 8 GB of slots)
+    const uint64_t l1_est = std::min<uint64_t>(l1_bound, (uint64_t)((double)b->total_bases * dens * 1.06) + 16ull * n + 8192);
     uint32_t n_blocks = (uint32_t)((l1_est + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
     uint64_t cap2 = (uint64_t)((double)l1_est * 0.01) + 65536;
     const double spec_key = (double)spec->w * 1e9 + spec->k * 1e6 + spec->r * 1e4 + spec->min_span + (sketch ? 0.5 : 0.0) + (padding ? 0.25 : 0.0);
@@ -1494,6 +1524,7 @@ extern "C" void pgr_shmmrs_destroy(pgr_shmmrs *s) {
     if (!s) return;
     s->ctx->dfree(s->d_mm);
     s->ctx->dfree(s->d_block);
+    if (s->h_off.capacity() >= (1u << 17) && s->h_off.capacity() > s->ctx->spare_off.capacity()) s->h_off.swap(s->ctx->spare_off);
     delete s;
 }
 

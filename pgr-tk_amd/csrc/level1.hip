@@ -22,6 +22,10 @@
 
 namespace pgr {
 
+__device__ __forceinline__ void tail_of_contig(const L1Args &a, uint32_t c, uint32_t len, const uint2 *__restrict__ planes,
+                                               const uint2 *lds_words, long long lds_wbase, uint32_t lane, uint32_t sidx,
+                                               uint64_t *s_x, uint32_t *s_st, uint32_t *s_emit, unsigned long long *s_base_p);
+
 // TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
 // instantiated with constants so that every row offset, shift and mask is an immediate.
 template <int TW, int TK, bool SKETCH, int BLK>
@@ -106,6 +110,7 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
         if ((t & 63) == 63) s_wsum[t >> 6] = 0;
         __syncthreads();
         __syncthreads();
+        if (c1 == g.L) __syncthreads();  // (the barrier in front of the contig's tail, below)
         return;
     }
     const bool wave_full = interior || __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
@@ -176,6 +181,17 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
             }
         }
     }
+    // ---- the contig's last tile also runs its tail (the positions behind jend: rescans only) on its first wavefront, in the
+    // rows the output has just been read from.  (A kernel of its own -- one latency-bound wavefront per contig -- was 0.87 ms
+    // for 10^6 reads, a third of this kernel's time there; here its loads hide behind the other workgroups' arithmetic.)
+    if (c1 == g.L) {  // (uniform)
+        if (BLK > 64) __syncthreads();  // the other wavefronts have read their columns
+        if (t < 64) {
+            double *flat = &s_suf[0][0];
+            tail_of_contig(a, c, td.len, planes, s_words, wbase, t, tile + 1 + c, (uint64_t *)flat, (uint32_t *)(flat + 256),
+                           (uint32_t *)(flat + 384), &s_base);
+        }
+    }
 }
 
 // one wavefront per contig: positions after jend, rescans only (shmmrutils.rs:503-515 with :516-520 false)
@@ -185,27 +201,16 @@ __device__ __forceinline__ void tail_wave_sync() {  // orders the LDS accesses o
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 }
 
-// TAIL_WAVES contigs per workgroup, one wavefront each (nothing is shared between them: the barriers are wave barriers).  With
-// one single-wave workgroup per contig the chip held ~7 of these latency-bound wavefronts per CU (counters: 90 % of their
-// cycles waiting, 1.8 wavefronts per SIMD): 10^6 reads spent 3.6 ms here.
-constexpr int TAIL_WAVES = 4;
-__global__ __launch_bounds__(64 * TAIL_WAVES) void level1_tail_kernel(L1Args a) {
-    __shared__ uint64_t s_x_all[TAIL_WAVES][256];
-    __shared__ uint32_t s_st_all[TAIL_WAVES][256];
-    __shared__ uint32_t s_emit_all[TAIL_WAVES][256];
-    __shared__ unsigned long long s_base_all[TAIL_WAVES];
-    const uint32_t wv = threadIdx.x >> 6;
-    uint64_t *s_x = s_x_all[wv];
-    uint32_t *s_st = s_st_all[wv], *s_emit = s_emit_all[wv];
-    unsigned long long &s_base = s_base_all[wv];
-
-    const uint32_t c = blockIdx.x * TAIL_WAVES + wv;
-    if (c >= a.n_contigs) return;
-    const uint32_t lane = threadIdx.x & 63;
-    const uint32_t sidx = a.tile_first[c + 1] + c;
-    if (c == 0 && lane == 0) a.seg_cnt[a.n_tiles + a.n_contigs] = 0;  // sentinel of the scan over the segment counts
+// The tail of contig c on ONE wavefront (s_x[256], s_st[256], s_emit[256], s_base: LDS of that wavefront alone); sidx: the
+// contig's tail segment; planes: the contig's plane words; lds_words: the words from lds_wbase on that the caller holds in
+// LDS (nullptr: none).  Called by the tile kernel for the contig's last tile (whose staged words cover the tail's k-mers
+// unless w > 96 and the tile is a sliver), and by level1_tail_kernel for specs without a tile path.
+__device__ __forceinline__ void tail_of_contig(const L1Args &a, uint32_t c, uint32_t len, const uint2 *__restrict__ planes,
+                                               const uint2 *lds_words, long long lds_wbase, uint32_t lane, uint32_t sidx,
+                                               uint64_t *s_x, uint32_t *s_st, uint32_t *s_emit, unsigned long long *s_base_p) {
+    unsigned long long &s_base = *s_base_p;
     const uint32_t w = a.w, k = a.k;
-    const ContigGeom g = contig_geom(a.b.len[c], w, k);
+    const ContigGeom g = contig_geom(len, w, k);
     const long long n_tail = (a.sketch || g.jend < g.jstart) ? 0 : (g.L - 1 - g.jend);
     if (n_tail <= 0) {
         if (lane == 0) {
@@ -217,11 +222,21 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void level1_tail_kernel(L1Args a) 
     }
     const long long lo = g.jend - (long long)w + 1;  // first position of the window ending at jend (>= k)
     const int n = (int)(g.L - lo);                   // <= w + (w-k) <= 256
-    const uint2 *__restrict__ planes = a.b.planes + a.b.word_off[c];
     const long long nwords = (g.L + 31) >> 5;
+    const bool from_lds = lds_words != nullptr && (lo >> 5) - 2 >= lds_wbase;  // (uniform)
     for (int i = lane; i < n; i += 64) {
         uint64_t f0, f1;
-        kmer_at(planes, nwords, lo + i, k, f0, f1);
+        if (from_lds) {  // kmer_at on the staged words (words outside the contig are staged as zeros)
+            const long long p = lo + i;
+            const int j = (int)((p >> 5) - lds_wbase);
+            const uint32_t sh = 31u - (uint32_t)(p & 31);
+            const uint2 w0 = lds_words[j], w1 = lds_words[j - 1], w2 = lds_words[j - 2];
+            const uint64_t kmask = U64MAX >> (64 - k);
+            f0 = (((uint64_t)funnel(w2.x, w1.x, sh) << 32) | funnel(w1.x, w0.x, sh)) & kmask;
+            f1 = (((uint64_t)funnel(w2.y, w1.y, sh) << 32) | funnel(w1.y, w0.y, sh)) & kmask;
+        } else {
+            kmer_at(planes, nwords, lo + i, k, f0, f1);
+        }
         const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
         uint32_t st;
         uint64_t h;
@@ -308,6 +323,24 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void level1_tail_kernel(L1Args a) 
             a.out[base + i] = l1rec_from_xy(s_x[idx], ((uint64_t)(lo + idx) << 1) | (s_st[idx] & 1u));
         }
     }
+}
+
+// TAIL_WAVES contigs per workgroup, one wavefront each (nothing is shared between them: the barriers are wave barriers).  With
+// one single-wave workgroup per contig the chip held ~7 of these latency-bound wavefronts per CU (counters: 90 % of their
+// cycles waiting, 1.8 wavefronts per SIMD): 10^6 reads spent 3.6 ms here.
+constexpr int TAIL_WAVES = 4;
+__global__ __launch_bounds__(64 * TAIL_WAVES) void level1_tail_kernel(L1Args a) {
+    __shared__ uint64_t s_x_all[TAIL_WAVES][256];
+    __shared__ uint32_t s_st_all[TAIL_WAVES][256];
+    __shared__ uint32_t s_emit_all[TAIL_WAVES][256];
+    __shared__ unsigned long long s_base_all[TAIL_WAVES];
+    const uint32_t wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * TAIL_WAVES + wv;
+    if (c >= a.n_contigs) return;
+    const uint32_t lane = threadIdx.x & 63;
+    if (c == 0 && lane == 0) a.seg_cnt[a.n_tiles + a.n_contigs] = 0;  // sentinel of the scan over the segment counts
+    tail_of_contig(a, c, a.b.len[c], a.b.planes + a.b.word_off[c], nullptr, 0, lane, a.tile_first[c + 1] + c, s_x_all[wv], s_st_all[wv],
+                   s_emit_all[wv], &s_base_all[wv]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -911,7 +944,16 @@ __global__ void mark_invalid_tiles_kernel(L1Args a) {
 __global__ void tile_desc_kernel(L1Args a) {
     const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
     if (tile < 8) a.cursor[tile] = 0ull;
-    if (tile < a.n_contigs) a.contig_flags[tile] = 0u;
+    if (tile < a.n_contigs) {
+        a.contig_flags[tile] = 0u;
+        if (a.b.len[tile] == 0) {  // no tile, hence nobody to run the tail: its (empty) segment
+            const uint32_t sidx = a.tile_first[tile + 1] + tile;
+            a.seg_off[sidx] = 0;
+            a.seg_cnt[sidx] = 0;
+            a.seg_cid[sidx] = tile;
+        }
+    }
+    if (tile == 0) a.seg_cnt[a.n_tiles + a.n_contigs] = 0;  // sentinel of the scan over the segment counts
     if (tile >= a.n_tiles) return;
     a.tile_flags[tile] = 0;
     const uint32_t c = find_contig(a.tile_first, a.n_contigs, tile);

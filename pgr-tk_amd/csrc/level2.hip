@@ -507,29 +507,51 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
         {
             const uint32_t lane = t & 63;
             const int wv = __builtin_amdgcn_readfirstlane((int)(t >> 6));
-            for (int sg = wv; sg < FUSED_SEGS; sg += FUSED_T / 64) {
-                const uint64_t s_lo = L.sdst[sg], s_hi = L.sdst[sg + 1];
-                if (s_lo >= cover_hi) break;  // (logical starts do not decrease)
-                const uint64_t g0 = s_lo > done ? s_lo : done, g1 = s_hi < cover_hi ? s_hi : cover_hi;
-                if (g1 <= g0) continue;  // empty segment, or one that lies below `done`
-                const L1Rec *__restrict__ src = a.l1 + (L.soff[sg] + (g0 - s_lo));
-                const uint32_t cid = L.scid[sg];
-                const uint32_t cnt = (uint32_t)(g1 - g0), d0 = (uint32_t)(g0 - lo);
+            // LOAD_U segments at a time: their first 64 records are in flight together before any goes to LDS (a batch of reads
+            // is ~25 minimizers per segment: one dependent global load per segment left the wavefront waiting ~1 us for each)
+            constexpr int LOAD_U = 4;
+            auto put = [&](uint32_t at, const L1Rec &m, uint32_t cid, uint32_t top) {
+                // 12-byte record -> MM128: x = key << 8 | k, y = contig << 32 | pos << 1 | strand
 #if PGR_L2_PACKED
-                const uint32_t ord = cid - cid0;
-                if (ord > 253u) L.wide = 1;    // benign race: every writer stores 1
-                if (ord > 124u) L.wide64 = 1;  // (the same)
-                const uint32_t top = ((ord + 1u) & 0xFFu) << 24;
-#endif
-                for (uint32_t i = lane; i < cnt; i += 64) {
-                    // 12-byte record -> MM128: x = key << 8 | k, y = contig << 32 | pos << 1 | strand
-                    const L1Rec m = src[i];
-#if PGR_L2_PACKED
-                    L.x[d0 + i] = ((uint64_t)(top | m.key_hi) << 32) | m.key_lo;
+                L.x[at] = ((uint64_t)(top | m.key_hi) << 32) | m.key_lo;
 #else
-                    L.x[d0 + i] = ((((uint64_t)m.key_hi << 32) | m.key_lo) << 8) | (uint64_t)a.k;
+                L.x[at] = ((((uint64_t)m.key_hi << 32) | m.key_lo) << 8) | (uint64_t)a.k;
 #endif
-                    L.y[d0 + i] = ((uint64_t)cid << 32) | m.ypos;
+                L.y[at] = ((uint64_t)cid << 32) | m.ypos;
+            };
+            for (int sgb = wv; sgb < FUSED_SEGS; sgb += LOAD_U * (FUSED_T / 64)) {
+                if (L.sdst[sgb] >= cover_hi) break;  // (logical starts do not decrease)
+                const L1Rec *src[LOAD_U];
+                uint32_t cnt[LOAD_U], d0[LOAD_U], cid[LOAD_U], top[LOAD_U];
+                L1Rec m[LOAD_U];
+#pragma unroll
+                for (int u = 0; u < LOAD_U; ++u) {
+                    const int sg = sgb + u * (FUSED_T / 64);
+                    cnt[u] = 0;
+                    src[u] = a.l1;
+                    d0[u] = cid[u] = top[u] = 0;
+                    if (sg < FUSED_SEGS) {
+                        const uint64_t s_lo = L.sdst[sg], s_hi = L.sdst[sg + 1];
+                        const uint64_t g0 = s_lo > done ? s_lo : done, g1 = s_hi < cover_hi ? s_hi : cover_hi;
+                        if (g1 > g0) {  // (not an empty segment, one below `done` or one behind the block)
+                            src[u] = a.l1 + (L.soff[sg] + (g0 - s_lo));
+                            cid[u] = L.scid[sg];
+                            cnt[u] = (uint32_t)(g1 - g0);
+                            d0[u] = (uint32_t)(g0 - lo);
+#if PGR_L2_PACKED
+                            const uint32_t ord = cid[u] - cid0;
+                            if (ord > 253u) L.wide = 1;    // benign race: every writer stores 1
+                            if (ord > 124u) L.wide64 = 1;  // (the same)
+                            top[u] = ((ord + 1u) & 0xFFu) << 24;
+#endif
+                        }
+                    }
+                    if (lane < cnt[u]) m[u] = src[u][lane];
+                }
+#pragma unroll
+                for (int u = 0; u < LOAD_U; ++u) {
+                    if (lane < cnt[u]) put(d0[u] + lane, m[u], cid[u], top[u]);
+                    for (uint32_t i = lane + 64; i < cnt[u]; i += 64) put(d0[u] + i, src[u][i], cid[u], top[u]);
                 }
             }
         }

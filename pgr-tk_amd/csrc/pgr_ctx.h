@@ -57,6 +57,8 @@ struct pgr_ctx {
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B
     } opt;
+    std::vector<uint32_t> h_tile_first;  // pgr_shmmrs_compute: first tile of every contig (host copy, kept between calls)
+    std::vector<uint64_t> spare_off;     // offsets block of the last destroyed big result (used again by the next one)
     bool skip_small_once = false;  // the host entry point's one-workgroup kernel handed the batch back: do not try it again
     bool want_host_copy = false;   // set by the host-buffer entry points: a small result rides along with the final round trip
     bool staged_unsynced = false;  // a batch was staged on `stream` and nobody has synchronized since
