@@ -22,9 +22,164 @@
 
 namespace pgr {
 
+// one wavefront per contig: positions after jend, rescans only (shmmrutils.rs:503-515 with :516-520 false)
+__device__ __forceinline__ void tail_wave_sync() {  // orders the LDS accesses of ONE wavefront (its part of the workgroup's LDS is its own)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+}
+
+// The tail of contig c on ONE wavefront (s_x[256], s_st[256], s_emit[256], s_base: LDS of that wavefront alone); sidx: the
+// contig's tail segment; planes: the contig's plane words; lds_words: the words from lds_wbase on that the caller holds in
+// LDS (nullptr: none); tk: the tile's own keys (nullptr: none).  Called by the tile kernel for the contig's last tile -- the
+// tail's w + (w - k) positions are positions of that tile unless it is a sliver of the contig (then its staged words still cover
+// the tail's k-mers unless w > 96) --, and by level1_tail_kernel for specs without a tile path.
+struct TileKeys {           // what the tile kernel has left in LDS: the keys of its extended positions (position e0 + 16 t + u at
+    const double *keys;     // keys[u * blk + t], 56 bits) and the strand bits of lane t's 16 positions (strands[2 t]).  May overlap
+    const uint32_t *strands;  // s_x / s_st / s_emit: everything is read before anything is written.
+    int blk;
+    long long e0;
+};
 __device__ __forceinline__ void tail_of_contig(const L1Args &a, uint32_t c, uint32_t len, const uint2 *__restrict__ planes,
-                                               const uint2 *lds_words, long long lds_wbase, uint32_t lane, uint32_t sidx,
-                                               uint64_t *s_x, uint32_t *s_st, uint32_t *s_emit, unsigned long long *s_base_p);
+                                               const uint2 *lds_words, long long lds_wbase, const TileKeys *tk, uint32_t lane,
+                                               uint32_t sidx, uint64_t *s_x, uint32_t *s_st, uint32_t *s_emit,
+                                               unsigned long long *s_base_p) {
+    unsigned long long &s_base = *s_base_p;
+    const uint32_t w = a.w, k = a.k;
+    const ContigGeom g = contig_geom(len, w, k);
+    const long long n_tail = (a.sketch || g.jend < g.jstart) ? 0 : (g.L - 1 - g.jend);
+    if (n_tail <= 0) {
+        if (lane == 0) {
+            a.seg_off[sidx] = 0;
+            a.seg_cnt[sidx] = 0;
+            a.seg_cid[sidx] = c;
+        }
+        return;
+    }
+    const long long lo = g.jend - (long long)w + 1;  // first position of the window ending at jend (>= k)
+    const int n = (int)(g.L - lo);                   // <= w + (w-k) <= 256
+    const long long nwords = (g.L + 31) >> 5;
+    const bool from_tile = tk != nullptr && lo >= tk->e0;                                          // (uniform)
+    const bool from_lds = !from_tile && lds_words != nullptr && (lo >> 5) - 2 >= lds_wbase;  // (uniform)
+    uint64_t xq[4];
+    {
+        uint32_t sq[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            xq[q] = U64MAX;
+            sq[q] = 0;
+            if (64 * q >= n) continue;  // (uniform)
+            const int i = (int)lane + 64 * q;
+            if (i >= n) continue;
+            const long long p = lo + i;
+            if (from_tile) {  // hashed by the tile already.  (A palindromic k-mer there has flagged the tile: an island replaces this tail)
+                const int rel = (int)(p - tk->e0);
+                const uint64_t kb = (uint64_t)__double_as_longlong(tk->keys[(rel & 15) * tk->blk + (rel >> 4)]);
+                xq[q] = ((kb & 0x00FFFFFFFFFFFFFFull) << 8) | (uint64_t)k;
+                sq[q] = (tk->strands[2 * (rel >> 4)] >> (rel & 15)) & 1u;
+                continue;
+            }
+            uint64_t f0, f1;
+            if (from_lds) {  // kmer_at on the staged words (words outside the contig are staged as zeros)
+                const int j = (int)((p >> 5) - lds_wbase);
+                const uint32_t sh = 31u - (uint32_t)(p & 31);
+                const uint2 w0 = lds_words[j], w1 = lds_words[j - 1], w2 = lds_words[j - 2];
+                const uint64_t kmask = U64MAX >> (64 - k);
+                f0 = (((uint64_t)funnel(w2.x, w1.x, sh) << 32) | funnel(w1.x, w0.x, sh)) & kmask;
+                f1 = (((uint64_t)funnel(w2.y, w1.y, sh) << 32) | funnel(w1.y, w0.y, sh)) & kmask;
+            } else {
+                kmer_at(planes, nwords, p, k, f0, f1);
+            }
+            const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
+            uint64_t h;
+            const uint64_t xv = kmer_x(f0, f1, r0, r1, k, sq[q], h);
+            // a palindromic k-mer here means the contig is re-done by the serial kernel anyway
+            xq[q] = (f0 == r0 && f1 == r1) ? U64MAX : xv;
+        }
+        tail_wave_sync();  // (the tile's keys have been read: their rows become s_x / s_st / s_emit)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = (int)lane + 64 * q;
+            if (i < n) {
+                s_x[i] = xq[q];
+                s_st[i] = sq[q];
+            }
+        }
+    }
+    tail_wave_sync();
+    // The tiny machine, wave-parallel: every lane keeps its (at most 4) elements i = lane + 64 q in registers, the state
+    // (mdist, n_emit) is wave-uniform, a rescan is one min-reduction + one ballot per slice instead of two serial walks over the
+    // window in LDS (~20 us of dependent LDS latency per contig -- 10 000 queries or 10^6 reads feel that).
+    int n_emit = 0;
+    {
+        const uint64_t lt = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
+        auto window_min = [&](int lo2, int hi2) {
+            uint64_t v = U64MAX;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = (int)lane + 64 * q;
+                if (i >= lo2 && i <= hi2) v = umin64(v, xq[q]);
+            }
+            return wave_min64(v);
+        };
+        // elements of [lo2, hi2] equal to m2, in index order: recorded when `record`; returns the index of the last one
+        auto equal_to = [&](int lo2, int hi2, uint64_t m2, bool record) {
+            int last = lo2;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = (int)lane + 64 * q;
+                const bool e = i >= lo2 && i <= hi2 && xq[q] == m2;
+                const uint64_t bal = __ballot(e);
+                if (bal == 0) continue;
+                if (record) {
+                    const int pos = n_emit + (int)__popcll(bal & lt);
+                    if (e && pos < 256) s_emit[pos] = (uint32_t)i;
+                    n_emit = n_emit + (int)__popcll(bal) > 256 ? 256 : n_emit + (int)__popcll(bal);
+                }
+                last = 64 * q + 63 - (int)__clzll((long long)bal);
+            }
+            return last;
+        };
+        // right-most arg-min of the window ending at jend
+        const uint64_t mn = window_min(0, (int)w - 1);
+        const int mi = equal_to(0, (int)w - 1, mn, false);
+        int mdist = (int)w - 1 - mi;
+        for (int j = (int)w; j < n; ++j) {
+            if (mdist == (int)w - 1) {
+                const int wl = j - (int)w + 1;
+                const uint64_t m2 = window_min(wl, j);
+                mdist = j - equal_to(wl, j, m2, true);
+            } else {
+                ++mdist;
+            }
+        }
+    }
+    if (lane == 0) {
+        // a tail emits 0-3 minimizers: they go to the contig's own slot; the shared cursor (a same-address atomic WITH return:
+        // ~280 per us on this chip, 3.6 ms for 10^6 reads) only when there are more
+        unsigned long long ob = 0, at = a.tail_base + (unsigned long long)c * L1_TAIL_SLOT;
+        bool ok = true;
+        if (n_emit > (int)L1_TAIL_SLOT) {
+            ob = atomicAdd(a.cursor, (unsigned long long)n_emit);
+            ok = ob + n_emit <= a.cap;
+            at = a.ovf_base + ob;
+            if (!ok) atomicExch(a.cursor + 1, 1ull);
+        }
+        s_base = ok ? at : ~0ull;
+        a.seg_off[sidx] = at;
+        a.seg_cnt[sidx] = ok ? (uint32_t)n_emit : 0u;
+        a.seg_cid[sidx] = c;
+    }
+    tail_wave_sync();
+    const unsigned long long base = s_base;
+    if (base != ~0ull) {
+        for (int i = lane; i < n_emit; i += 64) {
+            const uint32_t idx = s_emit[i];
+            a.out[base + i] = l1rec_from_xy(s_x[idx], ((uint64_t)(lo + idx) << 1) | (s_st[idx] & 1u));
+        }
+    }
+}
+
 
 // TW / TK: compile-time window and k-mer size (0 = take them from the arguments).  The common specs are
 // instantiated with constants so that every row offset, shift and mask is an immediate.
@@ -185,142 +340,14 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
     // rows the output has just been read from.  (A kernel of its own -- one latency-bound wavefront per contig -- was 0.87 ms
     // for 10^6 reads, a third of this kernel's time there; here its loads hide behind the other workgroups' arithmetic.)
     if (c1 == g.L) {  // (uniform)
+        ((uint32_t *)s_row)[2 * t] = strand_bits;  // (s_row is free since the max pass)
         if (BLK > 64) __syncthreads();  // the other wavefronts have read their columns
+        else tail_wave_sync();
         if (t < 64) {
             double *flat = &s_suf[0][0];
-            tail_of_contig(a, c, td.len, planes, s_words, wbase, t, tile + 1 + c, (uint64_t *)flat, (uint32_t *)(flat + 256),
+            const TileKeys tk{flat, (const uint32_t *)s_row, BLK, e0};
+            tail_of_contig(a, c, td.len, planes, s_words, wbase, &tk, t, tile + 1 + c, (uint64_t *)flat, (uint32_t *)(flat + 256),
                            (uint32_t *)(flat + 384), &s_base);
-        }
-    }
-}
-
-// one wavefront per contig: positions after jend, rescans only (shmmrutils.rs:503-515 with :516-520 false)
-__device__ __forceinline__ void tail_wave_sync() {  // orders the LDS accesses of ONE wavefront (its part of the workgroup's LDS is its own)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-}
-
-// The tail of contig c on ONE wavefront (s_x[256], s_st[256], s_emit[256], s_base: LDS of that wavefront alone); sidx: the
-// contig's tail segment; planes: the contig's plane words; lds_words: the words from lds_wbase on that the caller holds in
-// LDS (nullptr: none).  Called by the tile kernel for the contig's last tile (whose staged words cover the tail's k-mers
-// unless w > 96 and the tile is a sliver), and by level1_tail_kernel for specs without a tile path.
-__device__ __forceinline__ void tail_of_contig(const L1Args &a, uint32_t c, uint32_t len, const uint2 *__restrict__ planes,
-                                               const uint2 *lds_words, long long lds_wbase, uint32_t lane, uint32_t sidx,
-                                               uint64_t *s_x, uint32_t *s_st, uint32_t *s_emit, unsigned long long *s_base_p) {
-    unsigned long long &s_base = *s_base_p;
-    const uint32_t w = a.w, k = a.k;
-    const ContigGeom g = contig_geom(len, w, k);
-    const long long n_tail = (a.sketch || g.jend < g.jstart) ? 0 : (g.L - 1 - g.jend);
-    if (n_tail <= 0) {
-        if (lane == 0) {
-            a.seg_off[sidx] = 0;
-            a.seg_cnt[sidx] = 0;
-            a.seg_cid[sidx] = c;
-        }
-        return;
-    }
-    const long long lo = g.jend - (long long)w + 1;  // first position of the window ending at jend (>= k)
-    const int n = (int)(g.L - lo);                   // <= w + (w-k) <= 256
-    const long long nwords = (g.L + 31) >> 5;
-    const bool from_lds = lds_words != nullptr && (lo >> 5) - 2 >= lds_wbase;  // (uniform)
-    for (int i = lane; i < n; i += 64) {
-        uint64_t f0, f1;
-        if (from_lds) {  // kmer_at on the staged words (words outside the contig are staged as zeros)
-            const long long p = lo + i;
-            const int j = (int)((p >> 5) - lds_wbase);
-            const uint32_t sh = 31u - (uint32_t)(p & 31);
-            const uint2 w0 = lds_words[j], w1 = lds_words[j - 1], w2 = lds_words[j - 2];
-            const uint64_t kmask = U64MAX >> (64 - k);
-            f0 = (((uint64_t)funnel(w2.x, w1.x, sh) << 32) | funnel(w1.x, w0.x, sh)) & kmask;
-            f1 = (((uint64_t)funnel(w2.y, w1.y, sh) << 32) | funnel(w1.y, w0.y, sh)) & kmask;
-        } else {
-            kmer_at(planes, nwords, lo + i, k, f0, f1);
-        }
-        const uint64_t r0 = rc_plane(f0, k), r1 = rc_plane(f1, k);
-        uint32_t st;
-        uint64_t h;
-        const uint64_t xv = kmer_x(f0, f1, r0, r1, k, st, h);
-        // a palindromic k-mer here means the contig is re-done by the serial kernel anyway
-        s_x[i] = (f0 == r0 && f1 == r1) ? U64MAX : xv;
-        s_st[i] = st;
-    }
-    tail_wave_sync();
-    // The tiny machine, wave-parallel: every lane keeps its (at most 4) elements i = lane + 64 q in registers, the state
-    // (mdist, n_emit) is wave-uniform, a rescan is one min-reduction + one ballot per slice instead of two serial walks over the
-    // window in LDS (~20 us of dependent LDS latency per contig -- 10 000 queries or 10^6 reads feel that).
-    int n_emit = 0;
-    {
-        uint64_t xq[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int i = (int)lane + 64 * q;
-            xq[q] = i < n ? s_x[i] : U64MAX;
-        }
-        const uint64_t lt = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
-        auto window_min = [&](int lo2, int hi2) {
-            uint64_t v = U64MAX;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = (int)lane + 64 * q;
-                if (i >= lo2 && i <= hi2) v = umin64(v, xq[q]);
-            }
-            return wave_min64(v);
-        };
-        // elements of [lo2, hi2] equal to m2, in index order: recorded when `record`; returns the index of the last one
-        auto equal_to = [&](int lo2, int hi2, uint64_t m2, bool record) {
-            int last = lo2;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int i = (int)lane + 64 * q;
-                const bool e = i >= lo2 && i <= hi2 && xq[q] == m2;
-                const uint64_t bal = __ballot(e);
-                if (bal == 0) continue;
-                if (record) {
-                    const int pos = n_emit + (int)__popcll(bal & lt);
-                    if (e && pos < 256) s_emit[pos] = (uint32_t)i;
-                    n_emit = n_emit + (int)__popcll(bal) > 256 ? 256 : n_emit + (int)__popcll(bal);
-                }
-                last = 64 * q + 63 - (int)__clzll((long long)bal);
-            }
-            return last;
-        };
-        // right-most arg-min of the window ending at jend
-        const uint64_t mn = window_min(0, (int)w - 1);
-        const int mi = equal_to(0, (int)w - 1, mn, false);
-        int mdist = (int)w - 1 - mi;
-        for (int j = (int)w; j < n; ++j) {
-            if (mdist == (int)w - 1) {
-                const int wl = j - (int)w + 1;
-                const uint64_t m2 = window_min(wl, j);
-                mdist = j - equal_to(wl, j, m2, true);
-            } else {
-                ++mdist;
-            }
-        }
-    }
-    if (lane == 0) {
-        // a tail emits 0-3 minimizers: they go to the contig's own slot; the shared cursor (a same-address atomic WITH return:
-        // ~280 per us on this chip, 3.6 ms for 10^6 reads) only when there are more
-        unsigned long long ob = 0, at = a.tail_base + (unsigned long long)c * L1_TAIL_SLOT;
-        bool ok = true;
-        if (n_emit > (int)L1_TAIL_SLOT) {
-            ob = atomicAdd(a.cursor, (unsigned long long)n_emit);
-            ok = ob + n_emit <= a.cap;
-            at = a.ovf_base + ob;
-            if (!ok) atomicExch(a.cursor + 1, 1ull);
-        }
-        s_base = ok ? at : ~0ull;
-        a.seg_off[sidx] = at;
-        a.seg_cnt[sidx] = ok ? (uint32_t)n_emit : 0u;
-        a.seg_cid[sidx] = c;
-    }
-    tail_wave_sync();
-    const unsigned long long base = s_base;
-    if (base != ~0ull) {
-        for (int i = lane; i < n_emit; i += 64) {
-            const uint32_t idx = s_emit[i];
-            a.out[base + i] = l1rec_from_xy(s_x[idx], ((uint64_t)(lo + idx) << 1) | (s_st[idx] & 1u));
         }
     }
 }
@@ -339,7 +366,7 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void level1_tail_kernel(L1Args a) 
     if (c >= a.n_contigs) return;
     const uint32_t lane = threadIdx.x & 63;
     if (c == 0 && lane == 0) a.seg_cnt[a.n_tiles + a.n_contigs] = 0;  // sentinel of the scan over the segment counts
-    tail_of_contig(a, c, a.b.len[c], a.b.planes + a.b.word_off[c], nullptr, 0, lane, a.tile_first[c + 1] + c, s_x_all[wv], s_st_all[wv],
+    tail_of_contig(a, c, a.b.len[c], a.b.planes + a.b.word_off[c], nullptr, 0, nullptr, lane, a.tile_first[c + 1] + c, s_x_all[wv], s_st_all[wv],
                    s_emit_all[wv], &s_base_all[wv]);
 }
 

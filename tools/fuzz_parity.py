@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity campaign (GPU box): random ShmmrSpec x adversarial sequence mix x ragged lengths, the whole
 sequence_to_shmmrs output of the HIP path compared with the CPU oracle, bit exact.  Not part of the pytest suite (it is
-open ended); prints the seed of every failing case.   usage: fuzz_parity.py [iterations] [seed0] [max_len]"""
+open ended); prints the seed of every failing case.   usage: fuzz_parity.py [iterations] [seed0] [max_len] [general]
+("general": the one-workgroup kernel for small batches is switched off -- with a small max_len the batches are batches of reads
+and run the level-1 kernel on its one-wavefront tiles)"""
 import os
 import sys
 import time
@@ -55,6 +57,8 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     max_len = int(sys.argv[3]) if len(sys.argv) > 3 else 2_000_000
     ctx = P.default_context(0)
+    if len(sys.argv) > 4 and sys.argv[4] == "general":
+        ctx.set_option("no_small_path", 1)
     fails, bases = [], 0
     t0 = time.time()
     import signal
