@@ -352,8 +352,8 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     b->h_n_invalid.assign(std::max<uint32_t>(n, 1), 0);
     uint32_t c = 0;
     struct Job {
-        uint32_t c;
-        uint64_t wl0, wl1;  // words of contig c
+        uint32_t c0, c1;    // c1 == c0 + 1: words [wl0, wl1) of contig c0; otherwise the WHOLE contigs c0 .. c1 - 1, back to back
+        uint64_t wl0, wl1;
         uint64_t out;       // first word inside the window
     };
     std::vector<Job> jobs;
@@ -361,30 +361,55 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         const uint64_t w1 = std::min(b->total_words, w0 + win_words);
         uint64_t *pin_planes = (uint64_t *)((uint8_t *)ctx->pinned + (size_t)slot * win_words * 12);
         uint32_t *pin_valid = (uint32_t *)(pin_planes + win_words);
+        const auto tw0 = std::chrono::steady_clock::now();
         if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess)  // this window's previous trip is over
             return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+        const auto tw1 = std::chrono::steady_clock::now();
         while (c < n && b->h_word_off[c + 1] <= w0) ++c;
         jobs.clear();
-        for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1; ++cc) {
+        // short contigs (reads) are handed out in groups of ~PIECE / 4 words: one job per read was a million vector entries and a
+        // million calls through the pool per Gbp -- the staging thread spent longer listing them than the pool packing them
+        for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1;) {
             const uint64_t cw0 = b->h_word_off[cc], cw1 = b->h_word_off[cc + 1];
+            if (cw0 >= w0 && cw1 <= w1 && cw1 - cw0 < PIECE / 4) {
+                uint32_t ce = cc + 1;
+                while (ce < n && b->h_word_off[ce + 1] <= w1 && b->h_word_off[ce + 1] - b->h_word_off[ce] < PIECE / 4 &&
+                       b->h_word_off[ce] - cw0 < PIECE / 4)
+                    ++ce;
+                jobs.push_back(Job{cc, ce, 0, b->h_word_off[ce] - cw0, cw0 - w0});
+                cc = ce;
+                continue;
+            }
             const uint64_t lo = std::max(cw0, w0), hi = std::min(cw1, w1);
-            for (uint64_t o = lo; o < hi; o += PIECE) jobs.push_back(Job{cc, o - cw0, std::min(hi, o + PIECE) - cw0, o - w0});
+            for (uint64_t o = lo; o < hi; o += PIECE) jobs.push_back(Job{cc, cc + 1, o - cw0, std::min(hi, o + PIECE) - cw0, o - w0});
+            ++cc;
         }
         std::atomic<uint64_t> win_bad{0};
+        const auto tw2 = std::chrono::steady_clock::now();
         HostPool::instance().parallel_for(jobs.size(), [&](size_t i) {
             const Job &j = jobs[i];
             if (!packed) {
-                const uint64_t bad = pack_words_stream(src.seqs[j.c], src.lens[j.c], j.wl0, j.wl1, pin_planes + j.out, pin_valid + j.out);
-                if (bad) {
-                    __atomic_fetch_add(&b->h_n_invalid[j.c], (uint32_t)bad, __ATOMIC_RELAXED);
-                    win_bad.fetch_add(bad, std::memory_order_relaxed);
+                uint64_t job_bad = 0;
+                if (j.c1 == j.c0 + 1) {
+                    job_bad = pack_words_stream(src.seqs[j.c0], src.lens[j.c0], j.wl0, j.wl1, pin_planes + j.out, pin_valid + j.out);
+                    if (job_bad) __atomic_fetch_add(&b->h_n_invalid[j.c0], (uint32_t)job_bad, __ATOMIC_RELAXED);
+                } else {
+                    for (uint32_t cq = j.c0; cq < j.c1; ++cq) {
+                        const uint64_t o = j.out + (b->h_word_off[cq] - b->h_word_off[j.c0]);
+                        const uint64_t bad = pack_words_stream(src.seqs[cq], src.lens[cq], 0, b->h_word_off[cq + 1] - b->h_word_off[cq],
+                                                               pin_planes + o, pin_valid + o);
+                        if (bad) b->h_n_invalid[cq] = (uint32_t)bad;  // (the whole contig is this job's)
+                        job_bad += bad;
+                    }
                 }
+                if (job_bad) win_bad.fetch_add(job_bad, std::memory_order_relaxed);
             } else {
-                const uint64_t g = src.word0 + b->h_word_off[j.c] + j.wl0;  // word of the caller's arrays
+                const uint64_t g = src.word0 + b->h_word_off[j.c0] + j.wl0;  // word of the caller's arrays (contigs are back to back there too)
                 stream_copy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
                 if (src.valid) stream_copy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
             }
         });
+        const auto tw3 = std::chrono::steady_clock::now();
         // the validity plane only travels when it says something: a window of ASCII in which the packer met no non-ACGT byte
         // (the usual case) and packed input without a validity plane put 0.25 B per base on the link, the plane is written on
         // the device from the contig lengths
@@ -396,6 +421,12 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         if (packed || !has_valid) launch_sanitize_packed(st, b->d, n, w0, w1, has_valid ? 1 : 0);
         if (hipEventRecord(done[slot], st) != hipSuccess) return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         used[slot] = true;
+        if (ctx->opt.debug > 1) {
+            auto us = [](auto a, auto b2) { return std::chrono::duration<double, std::micro>(b2 - a).count(); };
+            const auto tw4 = std::chrono::steady_clock::now();
+            fprintf(stderr, "[pgr]     window of %.1f Mbp: waited %.0f us for its previous trip, %zu jobs listed in %.0f us, filled in %.0f us (%.1f GB/s of planes), enqueued in %.0f us\n",
+                    (double)(w1 - w0) * 32e-6, us(tw0, tw1), jobs.size(), us(tw1, tw2), us(tw2, tw3), (double)(w1 - w0) * 8e-3 / us(tw2, tw3), us(tw3, tw4));
+        }
     }
     // per-contig counts of non-ACGT bytes (host-packed input: counted by the packer; packed input: by the kernel above)
     if (!packed)

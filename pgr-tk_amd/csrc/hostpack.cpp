@@ -176,6 +176,13 @@ struct Lut {
     }
 };
 const Lut g_lut;
+struct Rev64 {  // vpermb index: byte j of each 32-byte half -> byte 31 - j of that half
+    alignas(64) uint8_t idx[64];
+    Rev64() {
+        for (int j = 0; j < 64; ++j) idx[j] = (uint8_t)((j & 32) | (31 - (j & 31)));
+    }
+};
+const Rev64 g_rev64;
 
 inline void pack32_scalar(const uint8_t *s, uint32_t nb, uint32_t &lo, uint32_t &hi, uint32_t &v) {
     lo = hi = v = 0;
@@ -255,36 +262,61 @@ __attribute__((target("avx2,popcnt"))) uint64_t pack_words_avx2(const uint8_t *s
     return bad;
 }
 
+// one step = 64 (half-reversed) bytes -> two plane words.  `present`: the bytes of the step that exist (all of them except in a
+// contig's last words: a masked load brings zeros for the rest, which must not count as the base with code 0), as bit
+// positions AFTER the reversal of the two 32-byte halves
+__attribute__((target("avx512f,avx512bw,avx512vbmi,popcnt"), always_inline)) inline void pack64_avx512(const __m512i v, uint64_t present,
+                                                                                                   uint64_t &lo, uint64_t &hi,
+                                                                                                   uint64_t &ok) {
+    const __m512i c20 = _mm512_set1_epi8(0x20), cA = _mm512_set1_epi8('a'), cC = _mm512_set1_epi8('c'), cG = _mm512_set1_epi8('g'),
+                  cT = _mm512_set1_epi8('t'), c4 = _mm512_set1_epi8(4), b0 = _mm512_set1_epi8(1), b1 = _mm512_set1_epi8(2),
+                  b2 = _mm512_set1_epi8(4);
+    const __m512i lc = _mm512_or_si512(v, c20);
+    const uint64_t letter = _mm512_cmpeq_epi8_mask(lc, cA) | _mm512_cmpeq_epi8_mask(lc, cC) | _mm512_cmpeq_epi8_mask(lc, cG) |
+                            _mm512_cmpeq_epi8_mask(lc, cT);
+    const uint64_t small = _mm512_cmplt_epu8_mask(v, c4);  // bytes 0..3 are their own code
+    ok = (letter | small) & present;
+    const uint64_t t0 = _mm512_test_epi8_mask(v, b0), t1 = _mm512_test_epi8_mask(v, b1), t2 = _mm512_test_epi8_mask(v, b2);
+    // letters: high bit = bit 2, low bit = bit 1 ^ bit 2 (see the AVX2 path)
+    hi = ((small & t1) | (~small & t2)) & ok;
+    lo = ((small & t0) | (~small & (t1 ^ t2))) & ok;
+}
+
 // 64 bases per step on CPUs with AVX-512 BW + VBMI (Zen 4/5, Ice Lake and later): one vpermb reverses the bytes of both
 // 32-byte halves, every per-byte test lands in a 64-bit mask register, the planes are mask arithmetic
 template <bool NT>
 __attribute__((target("avx512f,avx512bw,avx512vbmi,popcnt"))) uint64_t pack_words_avx512(const uint8_t *seq, uint64_t len, uint64_t w0,
                                                                                           uint64_t w1, uint64_t *planes,
                                                                                           uint32_t *valid) {
-    alignas(64) uint8_t ridx[64];
-    for (int j = 0; j < 64; ++j) ridx[j] = (uint8_t)((j & 32) | (31 - (j & 31)));
-    const __m512i rev = _mm512_load_si512((const void *)ridx);
-    const __m512i c20 = _mm512_set1_epi8(0x20), cA = _mm512_set1_epi8('a'), cC = _mm512_set1_epi8('c'), cG = _mm512_set1_epi8('g'),
-                  cT = _mm512_set1_epi8('t'), c4 = _mm512_set1_epi8(4), b0 = _mm512_set1_epi8(1), b1 = _mm512_set1_epi8(2),
-                  b2 = _mm512_set1_epi8(4);
+    const __m512i rev = _mm512_load_si512((const void *)g_rev64.idx);
     uint64_t bad = 0;
     uint64_t w = w0;
     const uint64_t full_end = std::min<uint64_t>(w1, len / 32);
     for (; w + 2 <= full_end; w += 2) {
         const __m512i v = _mm512_permutexvar_epi8(rev, _mm512_loadu_si512((const void *)(seq + w * 32)));
-        const __m512i lc = _mm512_or_si512(v, c20);
-        const uint64_t letter = _mm512_cmpeq_epi8_mask(lc, cA) | _mm512_cmpeq_epi8_mask(lc, cC) | _mm512_cmpeq_epi8_mask(lc, cG) |
-                                _mm512_cmpeq_epi8_mask(lc, cT);
-        const uint64_t small = _mm512_cmplt_epu8_mask(v, c4);  // bytes 0..3 are their own code
-        const uint64_t ok = letter | small;
-        const uint64_t t0 = _mm512_test_epi8_mask(v, b0), t1 = _mm512_test_epi8_mask(v, b1), t2 = _mm512_test_epi8_mask(v, b2);
-        // letters: high bit = bit 2, low bit = bit 1 ^ bit 2 (see the AVX2 path)
-        const uint64_t hi = ((small & t1) | (~small & t2)) & ok, lo = ((small & t0) | (~small & (t1 ^ t2))) & ok;
+        uint64_t lo, hi, ok;
+        pack64_avx512(v, ~0ull, lo, hi, ok);
         put_words<NT>(planes, valid, w - w0, (lo & 0xFFFFFFFFull) | (hi << 32), (uint32_t)ok);
         put_words<NT>(planes, valid, w - w0 + 1, (lo >> 32) | (hi & 0xFFFFFFFF00000000ull), (uint32_t)(ok >> 32));
         bad += 64u - (uint32_t)__builtin_popcountll(ok);
     }
-    if (w < w1) bad += pack_words_avx2<NT>(seq, len, w, w1, planes + (w - w0), valid + (w - w0));
+    // the last words of the range (an odd word, the contig's partial last word, words behind its end) with masked loads: a
+    // batch of reads is all last words -- a 1 kbp read took the AVX2 path for its 31st word and the byte loop for its 32nd
+    for (; w < w1; w += 2) {
+        const uint64_t first = w * 32;
+        const uint32_t nb = first >= len ? 0u : (uint32_t)std::min<uint64_t>(w + 1 < w1 ? 64 : 32, len - first);
+        const uint32_t n_lo = std::min(nb, 32u), n_hi = nb - n_lo;
+        const __mmask64 ld = nb >= 64 ? ~0ull : ((1ull << nb) - 1ull);
+        const __m512i v = _mm512_permutexvar_epi8(rev, _mm512_maskz_loadu_epi8(ld, (const void *)(seq + first)));
+        // byte j of a half sits at bit 31 - j of that half
+        const uint64_t p_lo = n_lo ? (0xFFFFFFFFull << (32 - n_lo)) & 0xFFFFFFFFull : 0ull;
+        const uint64_t p_hi = n_hi ? (0xFFFFFFFFull << (32 - n_hi)) & 0xFFFFFFFFull : 0ull;
+        uint64_t lo, hi, ok;
+        pack64_avx512(v, p_lo | (p_hi << 32), lo, hi, ok);
+        put_words<NT>(planes, valid, w - w0, (lo & 0xFFFFFFFFull) | (hi << 32), (uint32_t)ok);
+        if (w + 1 < w1) put_words<NT>(planes, valid, w - w0 + 1, (lo >> 32) | (hi & 0xFFFFFFFF00000000ull), (uint32_t)(ok >> 32));
+        bad += nb - (uint32_t)__builtin_popcountll(ok);
+    }
     return bad;
 }
 

@@ -41,6 +41,8 @@ def cases():
     for n in (31, 32, 33, 63, 64, 65, 1000, 65536 * 32 + 17):  # the last one crosses a job boundary of the packer
         out.append(rng.choice(np.frombuffer(b"ACGTacgtNn\x00\x01\x02\x03*-", dtype=np.uint8), n).tobytes())
     out.append(rng.integers(0, 256, 5000, dtype=np.uint8).tobytes())
+    for n in range(0, 200):  # every length around the 32- and 64-byte steps (the AVX-512 path's masked last words), any byte value
+        out.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes() if n % 3 else rng.choice(np.frombuffer(b"ACGTN\x00\x03", dtype=np.uint8), n).tobytes())
     return out
 
 
@@ -69,6 +71,15 @@ def test_pack_ascii_matches_the_base_table():
 def test_pack_ascii_scalar_path_matches_too():
     """the same with the AVX2 path switched off (PGR_NO_AVX2 is read once per process)"""
     env = dict(os.environ, PGR_NO_AVX2="1", PGR_HOST_THREADS="2")
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_hostpack_cpu as t; import pgrtk_amd as P; "
+            "t.check(P); print('ok')") % (os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "tests"))
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stderr[-2000:]
+
+
+def test_pack_ascii_avx2_path_matches_too():
+    """the same with only the AVX-512 path switched off (on a CPU that has it: the 32-byte AVX2 steps + the byte loop)"""
+    env = dict(os.environ, PGR_NO_AVX512="1", PGR_HOST_THREADS="2")
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); import test_hostpack_cpu as t; import pgrtk_amd as P; "
             "t.check(P); print('ok')") % (os.path.join(ROOT, "pgr-tk_amd"), os.path.join(ROOT, "tests"))
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
