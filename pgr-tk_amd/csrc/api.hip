@@ -343,7 +343,13 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     constexpr uint64_t PIECE = 1ull << 16;        // words per host job (2 MiB of ASCII / 0.75 MiB packed)
     constexpr uint64_t WIN_WORDS = 40 * PIECE;    // 84 Mbp = 30 MiB of planes + validity per window
     // (a pipe keeps ONE window layout for all its batches: a window of the previous batch may still be on its way)
-    const uint64_t win_words = pipe ? WIN_WORDS : std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
+    // A batch of its own (a query batch: 100 Mbp) goes in about six windows, not in one and a bit: nothing computes before its
+    // last byte is on the device, and the DMA of a window only starts when the window is full -- with 84 Mbp windows the call waited
+    // for the copy of 21 MB (0.4 ms) after the fill of the first window instead of copying behind the fill
+    const uint64_t win_words = pipe ? WIN_WORDS
+                                    : std::min<uint64_t>(std::max<uint64_t>({(uint64_t)1, std::min<uint64_t>(b->total_words, 4 * PIECE),
+                                                                             (b->total_words + 5) / 6}),
+                                                         WIN_WORDS);
     if (ctx->ensure_pinned(2 * win_words * 12)) return fail(PGR_ERR_NOMEM, "staging buffers: " + ctx->err);
     hipEvent_t done[2] = {ev0, ev1};
     StagePipe local;
@@ -369,12 +375,14 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         jobs.clear();
         // short contigs (reads) are handed out in groups of ~PIECE / 4 words: one job per read was a million vector entries and a
         // million calls through the pool per Gbp -- the staging thread spent longer listing them than the pool packing them
+        // (at least ~4 groups per thread and window: the small windows of a query batch would be two rounds and a bit otherwise)
+        const uint64_t GROUP = std::max<uint64_t>(2048, std::min<uint64_t>(PIECE / 4, (w1 - w0) / (4ull * (HostPool::instance().workers() + 1))));
         for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1;) {
             const uint64_t cw0 = b->h_word_off[cc], cw1 = b->h_word_off[cc + 1];
-            if (cw0 >= w0 && cw1 <= w1 && cw1 - cw0 < PIECE / 4) {
+            if (cw0 >= w0 && cw1 <= w1 && cw1 - cw0 < GROUP) {
                 uint32_t ce = cc + 1;
-                while (ce < n && b->h_word_off[ce + 1] <= w1 && b->h_word_off[ce + 1] - b->h_word_off[ce] < PIECE / 4 &&
-                       b->h_word_off[ce] - cw0 < PIECE / 4)
+                while (ce < n && b->h_word_off[ce + 1] <= w1 && b->h_word_off[ce + 1] - b->h_word_off[ce] < GROUP &&
+                       b->h_word_off[ce] - cw0 < GROUP)
                     ++ce;
                 jobs.push_back(Job{cc, ce, 0, b->h_word_off[ce] - cw0, cw0 - w0});
                 cc = ce;

@@ -41,5 +41,7 @@ with ctx.options(no_pipeline=1):
 qb = P.Batch.from_seqs(qs, ctx=ctx)
 print("resident   : median %.3f ms, min %.3f" % med(lambda: ix.time_query_resident(qb, 0.025)[0]))
 sys.stdout.flush()
-with ctx.options(debug=1):
+with ctx.options(debug=2, debug_times=1):
+    t0 = time.perf_counter()
     ix.time_query_host(qs, 0.025)
+    print('traced call %.3f ms' % ((time.perf_counter() - t0) * 1e3))
