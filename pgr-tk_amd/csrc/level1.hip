@@ -340,6 +340,7 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
     // rows the output has just been read from.  (A kernel of its own -- one latency-bound wavefront per contig -- was 0.87 ms
     // for 10^6 reads, a third of this kernel's time there; here its loads hide behind the other workgroups' arithmetic.)
     if (c1 == g.L) {  // (uniform)
+        asm volatile("s_nop 14");  // (marks everything from here on as cold for tools/isa_histogram.py: one tile in 2562 of a 10 Mbp contig)
         ((uint32_t *)s_row)[2 * t] = strand_bits;  // (s_row is free since the max pass)
         if (BLK > 64) __syncthreads();  // the other wavefronts have read their columns
         else tail_wave_sync();

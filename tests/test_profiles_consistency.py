@@ -42,7 +42,7 @@ def test_valu_busy_is_recomputable_from_the_counters():
     b = _load(TILE, "bench.json")
     t = _load("traffic.json")
     pm = _load(TILE, "pmc_summary.json")
-    k = [x for x in pm if "level1_tile_kernel<80, 56, false>" in x][0]
+    k = [x for x in pm if "level1_tile_kernel<80, 56, false, 256>" in x][0]
     assert abs(pm[k]["SQ_INSTS_VALU"]["mean_per_launch"] - t["valu_wave_insts_per_launch"]) < 1e-6 * t["valu_wave_insts_per_launch"]
     assert abs(pm[k]["SQ_ACTIVE_INST_VALU2"]["mean_per_launch"] - t["valu2_wave_insts_per_launch"]) < 1.0
     c = b["roofline"]["valu_issue"]["busy_by_counters"]
@@ -60,7 +60,7 @@ def test_valu_busy_is_recomputable_from_the_counters():
 def test_rocprof_average_agrees_with_the_bench_line():
     b = _load(TILE, "bench.json")
     rows = list(csv.DictReader(open(os.path.join(P, TILE, "kernel_stats.csv"))))
-    tile = [r for r in rows if "level1_tile_kernel<80, 56, false>" in r["Name"]][0]
+    tile = [r for r in rows if "level1_tile_kernel<80, 56, false, 256>" in r["Name"]][0]
     avg_ms, min_ms = float(tile["AverageNs"]) / 1e6, float(tile["MinNs"]) / 1e6
     live = b["roofline"]["avg_launch_ms"]
     assert abs(avg_ms - live) < 0.03 * live  # the profiler's average (incl. the first launches at ramping clocks) within 3 %

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Opcode histogram of a kernel in libpgrhip.so, weighted by measured issue cost -> the VALU-issue lower bound.
 
-    tools/isa_histogram.py [--so pgr-tk_amd/lib/libpgrhip.so] [--kernel level1_tile_kernelILi80ELi56ELb0]
+    tools/isa_histogram.py [--so pgr-tk_amd/lib/libpgrhip.so] [--kernel level1_tile_kernelILi80ELi56ELb0ELi256E]
                            [--costs profiles/r03_ubench/valu_cycles.json] [--out profiles/<name>/isa_histogram.json]
 
 What it does (works without a GPU: the code object is in the shared library):
@@ -11,7 +11,8 @@ What it does (works without a GPU: the code object is in the shared library):
        * blocks of the boundary variant of the tile kernel (they hold the v_bfe_i32 mask expansions that only
          `tile_select<..., MASKED = true>` contains) weigh --masked-weight (default 0: a 10 Mbp contig has 2 boundary
          tiles in 1245);
-       * blocks the source marks cold with `s_nop 15` weigh 0;
+       * blocks the source marks cold with `s_nop 15` weigh 0, and so does everything behind an `s_nop 14` (the contig's tail at the
+         end of the tile kernel, run by one tile per contig);
        * the body of a backward branch (the output loop `while (em)`) weighs --loop-trips (default 2.45 = expected
          maximum over 64 lanes of the number of level-1 minimizers among a lane's 16 positions at density 2/(w+1));
        * everything else weighs 1;
@@ -108,7 +109,7 @@ def basic_blocks(ins):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--so", default=os.path.join(ROOT, "pgr-tk_amd", "lib", "libpgrhip.so"))
-    ap.add_argument("--kernel", default="level1_tile_kernelILi80ELi56ELb0")
+    ap.add_argument("--kernel", default="level1_tile_kernelILi80ELi56ELb0ELi256E")
     ap.add_argument("--costs", default=os.path.join(ROOT, "profiles", "r03_ubench", "valu_cycles.json"))
     ap.add_argument("--masked-weight", type=float, default=0.0)
     ap.add_argument("--loop-trips", type=float, default=2.45)
@@ -126,11 +127,22 @@ def main():
     blocks, targets, addr_idx = basic_blocks(ins)
     # loop bodies: a backward branch at instruction i to target t -> blocks in [t, i] repeat
     loops = []
+    def is_exit(j):  # straight-line code that ends the program: a shared exit block the compiler placed in front, not a loop head
+        while j < len(ins):
+            if ins[j][1] == "s_endpgm":
+                return True
+            if ins[j][1].startswith(("s_cbranch", "s_branch")):
+                return False
+            j += 1
+        return False
     for i, t in targets.items():
-        if t in addr_idx and addr_idx[t] <= i:
+        if t in addr_idx and addr_idx[t] <= i and not is_exit(addr_idx[t]):
             loops.append((addr_idx[t], i))
     hist = collections.Counter()
     n_blocks_masked = 0
+    # `s_nop 14`: the source marks the start of a cold REGION that runs to the end of the kernel (the contig's tail, run by the last
+    # tile of a contig only: 1 tile in 2562 of a 10 Mbp contig)
+    cold_from = min([i for i in range(len(ins)) if ins[i][1] == "s_nop" and ins[i][2].strip() == "14"], default=len(ins))
     for s, e in blocks:
         ops = [ins[i][1] for i in range(s, e)]
         w = 1.0
@@ -139,6 +151,8 @@ def main():
             n_blocks_masked += 1
         if any(ins[i][1] == "s_nop" and ins[i][2].strip() == "15" for i in range(s, e)):
             w = 0.0  # marked cold in the source (the exact palindrome test behind a wave-uniform, practically never taken branch)
+        if s >= cold_from:
+            w = 0.0
         for ls, le in loops:
             if s >= ls and e - 1 <= le:
                 w *= a.loop_trips
