@@ -264,3 +264,30 @@ def test_one_wavefront_tiles_for_batches_of_short_contigs(oracle, gpu_ctx):
     for c in range(0, n, 97):
         ref = oracle.sequence_to_shmmrs(c, bench.synth_contig_ascii(43, c, lens[c]), oracle.spec(*spec_t))
         assert int(off[c + 1] - off[c]) == len(ref) and np.array_equal(sums[c], oracle.shmmr_checksum(ref)), c
+
+
+def test_many_dense_short_contigs_take_the_retry_paths(oracle, gpu_ctx):
+    """20 000 low-complexity reads (homopolymers, (AC)n, two-letter noise: ties emit every position, shmmrutils.rs:516-527): the
+    level-1 overflow region and the list stage's grid are sized from the density of random sequence plus a small allowance per
+    contig, so this batch overflows both and runs again with the true counts -- still bit exact, and the next call (which
+    remembers what this one needed) as well."""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(91)
+    seqs = []
+    for i in range(20_000):
+        L = int(rng.integers(150, 1200))
+        m = i % 4
+        if m == 0:
+            seqs.append(b"A" * L)
+        elif m == 1:
+            seqs.append((b"AC" * (L // 2 + 1))[:L])
+        elif m == 2:
+            seqs.append(bytes(rng.choice(np.frombuffer(b"AC", dtype=np.uint8), L)))
+        else:
+            seqs.append(bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), L)))
+    spec_t = (80, 56, 4, 64)
+    for attempt in range(2):
+        got = P.sequence_to_shmmrs_batch(seqs, P.make_spec(*spec_t), ctx=gpu_ctx)
+        for i in range(0, len(seqs), 7):
+            ref = oracle.sequence_to_shmmrs(i, seqs[i], oracle.spec(*spec_t))
+            _same(ref, got[i], "attempt %d contig %d len %d" % (attempt, i, len(seqs[i])))

@@ -37,7 +37,7 @@ for _ in range(3):
     ts.append(time.perf_counter() - t0)
 p = ctx.last_prof()
 if "--rounds" in sys.argv:
-    with ctx.options(debug=1):
+    with ctx.options(debug=1, debug_times=1):
         b.shmmrs(sp)
 print("GPU: %.1f ms (best of 3: %s), %d shimmers, %.1f Mbp through the exact islands" %
       (min(ts) * 1e3, " ".join("%.1f" % (t * 1e3) for t in ts), sh.count, p.exact_bases / 1e6))
