@@ -638,10 +638,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             f1 = (((F1 << lane) << 1) | (P1 >> (63 - lane))) & kmask;
             r0 = (((R0 >> lane) >> 1) | (__brevll((~P0) >> (63 - lane)) >> (64 - k))) & kmask;
             r1 = (((R1 >> lane) >> 1) | (__brevll((~P1) >> (63 - lane)) >> (64 - k))) & kmask;
-            F0 = shfl64(f0, 63);
-            F1 = shfl64(f1, 63);
-            R0 = shfl64(r0, 63);
-            R1 = shfl64(r1, 63);
+            F0 = readlane64(f0, 63);
+            F1 = readlane64(f1, 63);
+            R0 = readlane64(r0, 63);
+            R1 = readlane64(r1, 63);
         } else if (V == 0) {
             // no valid base in the block (inside a run of N): the k-mer stays what it was for all 64 positions
             f0 = F0;
@@ -710,14 +710,8 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         if (pmask) {
             uint64_t thr;  // exclusive prefix minimum over the enabled pushes, and min_mer.x
             {
-                uint64_t incl = (pushed && b_en) ? x : U64MAX;
-#pragma unroll
-                for (int d = 1; d < 64; d <<= 1) {
-                    const uint64_t o = shfl64(incl, (int)lane - d < 0 ? (int)lane : (int)lane - d);
-                    if ((int)lane >= d) incl = umin64(incl, o);
-                }
-                const uint64_t prev = shfl64(incl, lane == 0 ? 0 : (int)lane - 1);
-                thr = umin64(lane == 0 ? U64MAX : prev, min_x);
+                const uint64_t incl = wave_incl_min64((pushed && b_en) ? x : U64MAX);
+                thr = umin64(wave_shr1_ones(incl), min_x);
             }
             const bool is_b = pushed && b_en && x <= thr;
             const uint64_t bm = __ballot(is_b);
@@ -765,8 +759,8 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                     rlen += tot;
                 }
                 const int last = 63 - (int)__clzll((long long)bm);
-                min_x = shfl64(x, last);
-                min_y = shfl64(y, last);
+                min_x = readlane64(x, last);
+                min_y = readlane64(y, last);
                 mdist = (uint64_t)__popcll(pmask & ~((2ull << last) - 1ull));
                 cur = 64;
                 __syncthreads();
@@ -810,7 +804,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 break;
             }
             if (iB < iR) {  // branch 2 (shmmrutils.rs:516-527)
-                const uint64_t ex = shfl64(x, iB), ey = shfl64(y, iB);
+                const uint64_t ex = readlane64(x, iB), ey = readlane64(y, iB);
                 if (emit_on && !draining) {  // the element of a B event sits at the step itself
                     if (lane == 0 && n_out < cap) {
                         out[n_out] = l1rec_from_xy(ex, ey);

@@ -125,6 +125,50 @@ __device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
     hi = __shfl_xor(hi, m, 64);
     return ((uint64_t)hi << 32) | lo;
 }
+// value of lane `src` (the same for the whole wave: a constant or a ballot result) -- v_readlane_b32, no trip through the LDS
+// crossbar like ds_bpermute_b32 (a lone wavefront waits ~100 cycles for each of those)
+__device__ __forceinline__ uint64_t readlane64(uint64_t v, int src) {
+    const int l = __builtin_amdgcn_readfirstlane(src);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, l);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), l);
+    return ((uint64_t)hi << 32) | lo;
+}
+// one DPP step on both halves of a 64-bit value; lanes without a source keep all ones
+__device__ __forceinline__ uint64_t dpp_u64_ones(uint64_t v, const int ctrl, const int row_mask) {
+    uint32_t lo, hi;
+    switch (ctrl) {  // (the control word is an immediate of the instruction)
+#define PGR_DPP_CASE(C, RM)                                                                                        \
+    case C:                                                                                                        \
+        lo = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)v, C, RM, 0xf, false);                       \
+        hi = (uint32_t)__builtin_amdgcn_update_dpp(-1, (int)(uint32_t)(v >> 32), C, RM, 0xf, false);               \
+        break;
+        PGR_DPP_CASE(0x111, 0xf)
+        PGR_DPP_CASE(0x112, 0xf)
+        PGR_DPP_CASE(0x114, 0xf)
+        PGR_DPP_CASE(0x118, 0xf)
+        PGR_DPP_CASE(0x142, 0xa)
+        PGR_DPP_CASE(0x143, 0xc)
+        PGR_DPP_CASE(0x138, 0xf)
+#undef PGR_DPP_CASE
+    default:
+        lo = hi = 0xFFFFFFFFu;
+    }
+    (void)row_mask;
+    return ((uint64_t)hi << 32) | lo;
+}
+// inclusive prefix minimum over the wave (DPP row shifts + the two row broadcasts, as wave_incl_sum)
+__device__ __forceinline__ uint64_t wave_incl_min64(uint64_t v) {
+    v = umin64(v, dpp_u64_ones(v, 0x111, 0xf));  // row_shr:1
+    v = umin64(v, dpp_u64_ones(v, 0x112, 0xf));  // row_shr:2
+    v = umin64(v, dpp_u64_ones(v, 0x114, 0xf));  // row_shr:4
+    v = umin64(v, dpp_u64_ones(v, 0x118, 0xf));  // row_shr:8
+    v = umin64(v, dpp_u64_ones(v, 0x142, 0xa));  // row_bcast:15 -> rows 1, 3
+    v = umin64(v, dpp_u64_ones(v, 0x143, 0xc));  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// lane l <- lane l - 1 (lane 0: all ones)
+__device__ __forceinline__ uint64_t wave_shr1_ones(uint64_t v) { return dpp_u64_ones(v, 0x138, 0xf); }
+
 __device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) v = umin64(v, shfl_xor64(v, m));
