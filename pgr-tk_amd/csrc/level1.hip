@@ -383,11 +383,22 @@ __global__ __launch_bounds__(64 * TAIL_WAVES) void level1_tail_kernel(L1Args a) 
 // w pushes); the state at cs is recorded next to the previous chunk's state at its ce so that the host can
 // verify every seam and re-run the rare chunk whose assumption failed with the true state (`override`).
 // Emissions are attributed by the step (position) at which the reference emits them.
+// x mod w for ring-buffer slots: x < w + 128 always (a slot < w plus a lane or push rank), so for w >= 64 it is at most two
+// conditional subtractions -- an integer division by a run-time w is ~30 dependent instructions, and the exact machine is one
+// latency-bound wavefront that does several per event
+__device__ __forceinline__ uint32_t ring_mod(uint32_t x, uint32_t w) {
+    if (w >= 64u) {  // (uniform)
+        x -= x >= w ? w : 0u;
+        x -= x >= w ? w : 0u;
+        return x;
+    }
+    return x % w;
+}
 __device__ __forceinline__ uint64_t ring_signature(const uint64_t *s_rx, uint32_t rstart, uint32_t rlen, uint32_t w,
                                                    uint32_t lane) {
     uint64_t sig = 0;
     for (uint32_t q = lane; q < w; q += 64) {
-        const uint64_t v = s_rx[(rstart + q) % w];
+        const uint64_t v = s_rx[ring_mod(rstart + q, w)];
         sig ^= (v + 0x9E3779B97F4A7C15ull * (q + 1)) * (2ull * q + 1);
     }
 #pragma unroll
@@ -550,10 +561,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         if (cd.ring_out == 0xFFFFFFFFu || a.sketch) return;
         uint64_t *rg = rings + (size_t)cd.ring_out * CHUNK_RING_WORDS;
         const uint32_t q0 = lane, q1 = lane + 64;
-        rg[q0] = q0 < w ? s_rx[(rstart + q0) % w] : U64MAX;
-        rg[q1] = q1 < w ? s_rx[(rstart + q1) % w] : U64MAX;
-        rg[128 + q0] = q0 < w ? s_ry[(rstart + q0) % w] : U64MAX;
-        rg[128 + q1] = q1 < w ? s_ry[(rstart + q1) % w] : U64MAX;
+        rg[q0] = q0 < w ? s_rx[ring_mod(rstart + q0, w)] : U64MAX;
+        rg[q1] = q1 < w ? s_rx[ring_mod(rstart + q1, w)] : U64MAX;
+        rg[128 + q0] = q0 < w ? s_ry[ring_mod(rstart + q0, w)] : U64MAX;
+        rg[128 + q1] = q1 < w ? s_ry[ring_mod(rstart + q1, w)] : U64MAX;
         if (lane == 0) rg[256] = rlen;
     };
     long long cblk = -1;  // first block (64 positions) of the 64 blocks held in the lanes' registers
@@ -740,7 +751,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             }
             if (safe) {
                 if (pushed && tot - rk <= w) {
-                    const uint32_t slot = (rend + rk) % w;
+                    const uint32_t slot = ring_mod(rend + rk, w);
                     s_rx[slot] = x;
                     s_ry[slot] = y;
                 }
@@ -751,7 +762,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                     }
                     n_out += __popcll(bm);
                 }
-                rend = (rend + tot) % w;
+                rend = ring_mod(rend + tot, w);
                 if (rlen + tot >= w) {
                     rlen = w;
                     rstart = rend;
@@ -786,12 +797,12 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             if ((range >> lane) & 1) {
                 const uint32_t rk = __popcll(range & lt_mask);
                 if (tot - rk <= w) {
-                    const uint32_t slot = (rend + rk) % w;
+                    const uint32_t slot = ring_mod(rend + rk, w);
                     s_rx[slot] = x;
                     s_ry[slot] = y;
                 }
             }
-            rend = (rend + tot) % w;
+            rend = ring_mod(rend + tot, w);
             if (rlen + tot >= w) {
                 rlen = w;
                 rstart = rend;
@@ -816,7 +827,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 mdist = 0;
             } else {  // rescan (shmmrutils.rs:503-515)
                 const uint32_t q0 = lane, q1 = lane + 64;
-                const uint32_t s0 = (rstart + q0) % w, s1 = (rstart + q1) % w;
+                const uint32_t s0 = ring_mod(rstart + q0, w), s1 = ring_mod(rstart + q1, w);
                 const uint64_t x0 = (q0 < w) ? s_rx[s0] : U64MAX;
                 const uint64_t x1 = (q1 < w) ? s_rx[s1] : U64MAX;
                 const uint64_t mn = wave_min64(umin64(x0, x1));
@@ -844,7 +855,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                 }
                 const uint32_t qlast = m1 ? (64 + 63 - (uint32_t)__clzll((long long)m1)) : (63 - (uint32_t)__clzll((long long)m0));
                 min_x = mn;
-                min_y = s_ry[(rstart + qlast) % w];
+                min_y = s_ry[ring_mod(rstart + qlast, w)];
                 const uint64_t ppos = (uint64_t)(base + iR);
                 mdist = ppos - ((min_y & 0xFFFFFFFFull) >> 1);
             }

@@ -169,11 +169,9 @@ __device__ __forceinline__ uint64_t wave_incl_min64(uint64_t v) {
 // lane l <- lane l - 1 (lane 0: all ones)
 __device__ __forceinline__ uint64_t wave_shr1_ones(uint64_t v) { return dpp_u64_ones(v, 0x138, 0xf); }
 
-__device__ __forceinline__ uint64_t wave_min64(uint64_t v) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v = umin64(v, shfl_xor64(v, m));
-    return v;
-}
+// minimum over the wave, in every lane: the inclusive prefix minimum's last lane (6 DPP steps + one v_readlane pair; the butterfly
+// over ds_bpermute_b32 was 12 trips through the LDS crossbar -- a lone wavefront of the exact machine waits for each)
+__device__ __forceinline__ uint64_t wave_min64(uint64_t v) { return readlane64(wave_incl_min64(v), 63); }
 // inclusive prefix sum over the wave: DPP row shifts inside the rows of 16 lanes, then the two row broadcasts
 // (6 v_add_u32_dpp instead of 6 x (ds_bpermute + compare + select + add))
 __device__ __forceinline__ uint32_t wave_incl_sum(uint32_t v) {
