@@ -58,7 +58,7 @@ const std::vector<OptionName> &option_names() {
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
-        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}};
+        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}};
     return v;
 }
 }  // namespace
@@ -94,6 +94,8 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->d2h_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->pre_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
     for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->cev[i]);
     if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
@@ -150,6 +152,9 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->d2h_ev)
         if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : ctx->pre_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -643,6 +648,12 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         if ((rc = build(ii))) return rc;
 
     uint64_t next_region = region_base;
+    const auto t_isl0 = std::chrono::steady_clock::now();
+    auto isl_lap = [&](const char *what, int round) {
+        if (ctx->opt.debug_times)
+            fprintf(stderr, "[pgr]     islands round %d %-34s at %7.1f us\n", round, what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_isl0).count());
+    };
     for (int round = 0; !todo.empty(); ++round) {
         // Every round settles at least one seam or grows / merges an island, so the number of rounds is bounded by the number
         // of chunks plus the growth steps; in practice it is 1-3: a state is handed through chunks that cannot change it on the
@@ -682,9 +693,12 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
         // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
         if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
+        isl_lap("chunks listed, buffers ready", round);
         launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
         PGR_HIP(ctx, hipMemcpyAsync(h_img + desc_bytes, d_in, down_bytes, hipMemcpyDeviceToHost, st));
+        isl_lap("chunk kernel enqueued", round);
         PGR_HIP(ctx, hipStreamSynchronize(st));
+        isl_lap("states back on the host", round);
         const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
         const uint64_t *r_info = (const uint64_t *)(r_out + nq);
         const uint32_t *r_stat = (const uint32_t *)(r_info + 3 * nq);
@@ -1179,6 +1193,74 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     bool islands_done = false;
     bool l2_cursor_clean = false;  // the list stage's cursor words were cleared by stage 1's memset
 
+    // islands of exact tiles from the flags: flags[c] bit 0 = a tile of contig c saw a palindromic k-mer, n_invalid[c] = its non-ACGT
+    // bytes, tf[tile] = tile flags (bit 0 palindromic k-mer, bit 1 non-ACGT byte in reach, bit 2 nothing but such bytes; bit 3 is set here)
+    auto list_islands = [&](const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, std::vector<Island> &islands,
+                            std::vector<uint32_t> &gap_segs) {
+        for (uint32_t c = 0; c < n; ++c) {
+            if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
+            const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
+            const uint64_t L = b->h_len[c];
+            // The inside of a long run of non-ACGT bytes (the gaps of a reference chromosome: up to 30 Mbp) needs no
+            // machine at all.  Every position there pushes the same stale k-mer (shmmrutils.rs:461-476), so the level-1
+            // list holds one element per position, all with one x -- ties keep them through both reductions
+            // (:359-415) and the min_span stencil drops every one of them for having a neighbour with its x (:545-550).
+            // What an element further than 2 r^2 list places from both ends of such a run contributes to the rest of
+            // the list is nothing: tiles whose whole extended range is invalid AND whose two neighbours on either side
+            // are too (>= 7 kbp of the run kept at each end) are left out -- their segments stay empty, the islands on
+            // both sides end inside the run, where a warmed-up machine is exact.  (Round 3 pushed 40.9 Mbp of such
+            // positions of a chromosome-like contig through the chunk kernel and the list stage: half of its 2.4 ms.)
+            for (uint32_t t = 0, run = 0; t < nt; ++t) {  // tile t - 2 is deep when tiles t - 4 .. t are all inside a gap
+                run = (tf[t0 + t] & 4) ? run + 1 : 0;
+                if (run >= 5) tf[t0 + t - 2] |= 8;  // (bit 3: host only)
+            }
+            for (uint32_t t = 0; t < nt; ++t)
+                if (tf[t0 + t] & 8) {
+                    uint32_t e = t;
+                    while (e + 1 < nt && (tf[t0 + e + 1] & 8)) ++e;
+                    gap_segs.push_back(t0 + c + t);      // segment index of tile t of contig c
+                    gap_segs.push_back(t0 + c + e + 1);
+                    for (uint32_t q = t; q <= e; ++q) tf[t0 + q] = 0;  // not flagged: no island over them
+                    t = e;
+                }
+            uint32_t n_flag = 0;
+            for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
+            if (n_flag == 0) continue;
+            if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
+            if (3ull * n_flag > nt) {  // mostly irregular: one island
+                bool pal = false;
+                for (uint32_t t = 0; t < nt; ++t) pal = pal || (tf[t0 + t] & 1);
+                islands.push_back(Island{c, 0, L, false, pal});
+                continue;
+            }
+            for (uint32_t t = 0; t < nt;) {
+                if (!tf[t0 + t]) {
+                    ++t;
+                    continue;
+                }
+                uint32_t ta = t > 0 ? t - 1 : 0, tb = t;
+                while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
+                if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
+                Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
+                for (uint32_t q = ta; q <= tb; ++q) is.pal = is.pal || (tf[t0 + q] & 1);
+                if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
+                if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
+                    islands.back().E = std::max(islands.back().E, is.E);
+                    islands.back().pal = islands.back().pal || is.pal;
+                } else {
+                    islands.push_back(is);
+                }
+                t = tb + 1;
+            }
+        }
+    };
+    // Islands around non-ACGT bytes, listed while the tile kernel runs: a batch the host packer has counted such bytes in gets the
+    // tile flags (all but the palindrome bit, which the tile kernel sets) on the host as soon as mark_invalid_tiles has run -- the
+    // copy, the listing (and the cumulative last-valid table) used to sit between the tile kernel and the chunk kernel, 0.15 ms
+    // of a chromosome-like contig's 1.2.  Used when the tile kernel reports no palindromic k-mer; otherwise listed again.
+    std::vector<Island> pre_islands;
+    std::vector<uint32_t> pre_gap_segs;
+    bool pre_listed = false;
     // ---- stage 1
     auto stage1 = [&]() -> int {
         uint64_t serial_total = 0;
@@ -1196,24 +1278,47 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
         l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-        if (tiled && bases_tiled) launch_level1_tiles(st, a);
+        pre_listed = false;
+        if (tiled && bases_tiled) {
+            launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p);
+            const bool pre = b->host_saw_invalid && !b->h_n_invalid.empty() && n_tiles && !ctx->opt.no_pre_islands;
+            if (pre) {
+                const size_t tb = scan_max_temp_bytes(n_tiles);
+                if ((r = ctx->ws_scan_tmp.ensure(ctx, tb)) || (r = ctx->ensure_imail(n_tiles))) return r;
+                PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
+                PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[0], st));
+                PGR_HIP(ctx, hipStreamWaitEvent(ctx->pre_stream, ctx->pre_ev[0], 0));
+                PGR_HIP(ctx, hipMemcpyAsync(ctx->imail, d_tflags, n_tiles, hipMemcpyDeviceToHost, ctx->pre_stream));
+                PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[1], ctx->pre_stream));
+            }
+            launch_level1_tiles(st, a);
+            if (pre) {
+                PGR_HIP(ctx, hipEventSynchronize(ctx->pre_ev[1]));
+                std::vector<uint32_t> no_flags(n, 0u);
+                pre_islands.clear();
+                pre_gap_segs.clear();
+                list_islands(no_flags.data(), b->h_n_invalid.data(), (uint8_t *)ctx->imail, pre_islands, pre_gap_segs);
+                pre_listed = true;
+                dbg_lap("islands around non-ACGT bytes listed");
+            }
+        }
         PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
         if (!(tiled && bases_tiled)) launch_level1_tails(st, a);  // (otherwise every contig's last tile has run its tail)
-        if (tiled && bases_tiled) {  // flags tiles with a non-ACGT byte in reach, records every tile's last valid position
-            L1Args am = a;
-            am.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
-            launch_mark_invalid_tiles(st, am);
-        }
         islands_done = false;
         return PGR_OK;
     };
     // ---- islands of exact tiles: around palindromic k-mers (skipped pushes, flagged by the tile kernel) and
     // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path.  Synchronizes.
     auto run_islands = [&](uint64_t need_word) -> int {
+        dbg_lap("islands: level-1 flags seen");
         std::vector<Island> islands;
         std::vector<uint32_t> gap_segs;  // [first, last + 1) segment ranges of tiles deep inside runs of non-ACGT bytes: emptied
         for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false, true});
-        if (tiled && bases_tiled && need_word) {
+        const bool use_pre = pre_listed && !(need_word & 1ull) && serial.empty();  // (no tile saw a palindromic k-mer)
+        if (use_pre) {
+            islands = pre_islands;
+            gap_segs = pre_gap_segs;
+        } else if (tiled && bases_tiled && need_word) {
             std::vector<uint32_t> flags(n), n_invalid(n);
             std::vector<uint8_t> tf(n_tiles);
             if (n) {
@@ -1222,63 +1327,8 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
             }
             PGR_HIP(ctx, hipMemcpyAsync(tf.data(), d_tflags, n_tiles, hipMemcpyDeviceToHost, st));
             PGR_HIP(ctx, hipStreamSynchronize(st));
-            for (uint32_t c = 0; c < n; ++c) {
-                if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
-                const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
-                const uint64_t L = b->h_len[c];
-                // The inside of a long run of non-ACGT bytes (the gaps of a reference chromosome: up to 30 Mbp) needs no
-                // machine at all.  Every position there pushes the same stale k-mer (shmmrutils.rs:461-476), so the level-1
-                // list holds one element per position, all with one x -- ties keep them through both reductions
-                // (:359-415) and the min_span stencil drops every one of them for having a neighbour with its x (:545-550).
-                // What an element further than 2 r^2 list places from both ends of such a run contributes to the rest of
-                // the list is nothing: tiles whose whole extended range is invalid AND whose two neighbours on either side
-                // are too (>= 7 kbp of the run kept at each end) are left out -- their segments stay empty, the islands on
-                // both sides end inside the run, where a warmed-up machine is exact.  (Round 3 pushed 40.9 Mbp of such
-                // positions of a chromosome-like contig through the chunk kernel and the list stage: half of its 2.4 ms.)
-                for (uint32_t t = 0; t < nt; ++t) {
-                    bool deep = nt >= 5 && t >= 2 && t + 2 < nt;
-                    for (uint32_t q = deep ? t - 2 : t; deep && q <= t + 2; ++q) deep = (tf[t0 + q] & 4) != 0;
-                    if (deep) tf[t0 + t] |= 8;  // (bit 3: host only)
-                }
-                for (uint32_t t = 0; t < nt; ++t)
-                    if (tf[t0 + t] & 8) {
-                        uint32_t e = t;
-                        while (e + 1 < nt && (tf[t0 + e + 1] & 8)) ++e;
-                        gap_segs.push_back(t0 + c + t);      // segment index of tile t of contig c
-                        gap_segs.push_back(t0 + c + e + 1);
-                        for (uint32_t q = t; q <= e; ++q) tf[t0 + q] = 0;  // not flagged: no island over them
-                        t = e;
-                    }
-                uint32_t n_flag = 0;
-                for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
-                if (n_flag == 0) continue;
-                if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
-                if (3ull * n_flag > nt) {  // mostly irregular: one island
-                    bool pal = false;
-                    for (uint32_t t = 0; t < nt; ++t) pal = pal || (tf[t0 + t] & 1);
-                    islands.push_back(Island{c, 0, L, false, pal});
-                    continue;
-                }
-                for (uint32_t t = 0; t < nt;) {
-                    if (!tf[t0 + t]) {
-                        ++t;
-                        continue;
-                    }
-                    uint32_t ta = t > 0 ? t - 1 : 0, tb = t;
-                    while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
-                    if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
-                    Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
-                    for (uint32_t q = ta; q <= tb; ++q) is.pal = is.pal || (tf[t0 + q] & 1);
-                    if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
-                    if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
-                        islands.back().E = std::max(islands.back().E, is.E);
-                        islands.back().pal = islands.back().pal || is.pal;
-                    } else {
-                        islands.push_back(is);
-                    }
-                    t = tb + 1;
-                }
-            }
+            dbg_lap("islands: tile flags on the host");
+            list_islands(flags.data(), n_invalid.data(), tf.data(), islands, gap_segs);
         }
         {
             std::vector<uint32_t> cs;
@@ -1289,17 +1339,19 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (!islands.empty()) {
             L1Args as = a;
             as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
-            if (tiled && bases_tiled && n_tiles) {
+            if (tiled && bases_tiled && n_tiles && !use_pre) {  // (use_pre: done in front of the tile kernel)
                 // per-tile "last valid position" (written by mark_invalid_tiles) -> cumulative: the chunks' k-mer look-back
                 // and forward roll cross a run of N of any length in one step
                 const size_t tb = scan_max_temp_bytes(n_tiles);
                 int r2;
                 if ((r2 = ctx->ws_scan_tmp.ensure(ctx, tb))) return r2;
                 PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
-                as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
             }
+            if (tiled && bases_tiled && n_tiles) as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
+            dbg_lap("islands: listed");
             int r = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base, gap_segs);
             if (r) return r;
+            dbg_lap("islands: exact");
             a.out = as.out;
             prof.exact_bases = 0;
             for (const auto &is : islands) prof.exact_bases += is.E - is.B;  // final extents (islands may have grown)

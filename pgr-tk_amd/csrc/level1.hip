@@ -202,8 +202,28 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
     const uint32_t t = threadIdx.x;
     const uint32_t tile = blockIdx.x;
     const TileDesc td = a.desc[tile];
-    if (td.skip) return;  // this contig goes through the exact chunk kernel (non-ACGT bytes): uniform exit
     const uint32_t c = td.contig;
+    // A tile with a non-ACGT byte in reach (mark_invalid_tiles_kernel, which runs in front of this kernel, says so in the tile's
+    // descriptor) is replaced by an island of the exact machine or, deep inside a gap, emptied (api.hip: run_islands): nothing of
+    // it is computed here.  (The 40 Mbp of gaps of a chromosome-like contig were 10 000 tiles of "poly-A": every position a tie,
+    // 3904 records each.)
+    if (td.skip) {  // (uniform)
+        asm volatile("s_nop 15");  // (cold for tools/isa_histogram.py)
+        if (t == 0) {
+            asm volatile("s_nop 15");
+            const uint32_t sidx = tile + c;
+            a.seg_off[sidx] = 0;
+            a.seg_cnt[sidx] = 0;
+            a.seg_cid[sidx] = c;
+            if (l1_core_end((long long)td.tile_local * a.tc, (long long)td.len, a.tc, (uint32_t)EXT) == (long long)td.len) {
+                asm volatile("s_nop 15");
+                a.seg_off[sidx + 1] = 0;  // the contig's tail segment: the island that replaces this tile reaches the contig's end
+                a.seg_cnt[sidx + 1] = 0;
+                a.seg_cid[sidx + 1] = c;
+            }
+        }
+        return;
+    }
     const uint32_t tile_local = td.tile_local;
     const uint32_t w = TW ? (uint32_t)TW : a.w, k = TK ? (uint32_t)TK : a.k;
     const ContigGeom g = contig_geom(td.len, w, k);
@@ -309,7 +329,7 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
         a.seg_cid[sidx] = c;
         if (s_skip) {
             atomicOr(a.contig_flags + c, 1u);
-            a.tile_flags[tile] = 1;
+            a.tile_flags[tile] |= 1;
             atomicOr(a.cursor + 2, 1ull);  // batch-wide "some tile needs the exact path" word (read once by the host)
         }
     }
@@ -919,55 +939,76 @@ __global__ void zero_seg_ranges_kernel(L1Args a, const uint32_t *__restrict__ ra
     for (uint32_t s = s0 + threadIdx.x; s < s1; s += blockDim.x) a.seg_cnt[s] = 0;
 }
 
-// one lane per tile (of contigs that contain non-ACGT bytes): does the tile's extended range (core +- (w-1),
-// k-mer look-back, one 64-position step of slack) contain a byte that is not a base?
-__global__ void mark_invalid_tiles_kernel(L1Args a) {
-    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tile >= a.n_tiles) return;
-    const TileDesc td = a.desc[tile];
-    const uint32_t c = td.contig;
-    const long long L = td.len;
-    {
-        const long long c1 = l1_core_end((long long)td.tile_local * a.tc, L, a.tc, a.ext);
-        if (a.b.n_invalid[c] == 0) {  // every base valid
-            a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)c1;
-            return;
-        }
+// one lane per tile: does the tile's extended range (core +- (w-1), k-mer look-back, one 64-position step of slack) contain a
+// byte that is not a base, and where is the last valid position of its core?  Tiles of clean contigs (the usual case) are done
+// with one look at the contig's count.  The tiles of a contig WITH such bytes are scanned by the whole wavefront, one tile after
+// the other, every lane two or three words of the tile's ~135 (a lane walking its own tile word by word made every load of
+// the wavefront a gather of 64 cache lines); eight tiles per wavefront keep that serial part short.  Runs IN FRONT of the tile
+// kernel, which leaves flagged tiles alone.
+constexpr uint32_t MARK_TPW = 8;  // tiles per wavefront: a wavefront's dirty tiles are scanned one after the other (~1.5 us each)
+__global__ __launch_bounds__(256) void mark_invalid_tiles_kernel(L1Args a) {
+    const uint32_t lane = threadIdx.x & 63;
+    const uint32_t tile = (blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6)) * MARK_TPW + lane;
+    const bool live = lane < MARK_TPW && tile < a.n_tiles;
+    TileDesc td;
+    td.word_off = 0;
+    td.len = td.contig = td.tile_local = 0;
+    if (live) td = a.desc[tile];
+    bool dirty = false;
+    if (live) {
+        const long long c1 = l1_core_end((long long)td.tile_local * a.tc, (long long)td.len, a.tc, a.ext);
+        if (a.b.n_invalid[td.contig] == 0) a.tile_lv[tile] = ((uint64_t)(td.contig + 1) << 32) | (uint64_t)c1;  // every base valid
+        else dirty = true;
     }
-    const uint32_t *__restrict__ v = a.b.valid + td.word_off;
-    {   // last valid position of the tile's core [c0, c1)
-        const long long c0 = (long long)td.tile_local * a.tc;
-        const long long c1 = l1_core_end(c0, L, a.tc, a.ext);
-        long long last = -1;
-        for (long long wj = (c1 - 1) >> 5; wj >= (c0 >> 5) && last < 0; --wj) {
-            uint32_t m = 0xFFFFFFFFu;
+    uint64_t todo = __ballot(dirty);
+    while (todo) {  // (uniform)
+        const int j = __builtin_amdgcn_readfirstlane((int)__ffsll((unsigned long long)todo) - 1);
+        todo &= todo - 1;
+        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)td.contig, j);
+        const long long L = (long long)(uint32_t)__builtin_amdgcn_readlane((int)td.len, j);
+        const long long tl = (long long)(uint32_t)__builtin_amdgcn_readlane((int)td.tile_local, j);
+        const uint64_t woff = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(td.word_off >> 32), j) << 32) |
+                              (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)td.word_off, j);
+        const uint32_t *__restrict__ v = a.b.valid + woff;
+        const long long c0 = tl * a.tc, c1 = l1_core_end(c0, L, a.tc, a.ext);
+        long long lo = c0 - (long long)(a.w - 1) - (long long)(a.k - 1) - 64;
+        long long hi = c1 + (long long)(a.w - 1) + 64;
+        if (lo < 0) lo = 0;
+        if (hi > L) hi = L;
+        bool bad = false, any_valid = false;
+        long long last = -1;  // last valid position of the core [c0, c1) among this lane's words
+        for (long long wj = (lo >> 5) + lane; wj <= (hi - 1) >> 5; wj += 64) {
             const long long w0 = wj << 5;
-            if (w0 < c0) m &= 0xFFFFFFFFu >> (uint32_t)(c0 - w0);
-            if (w0 + 32 > c1) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - c1);
-            const uint32_t bits = v[wj] & m;  // position w0 + i at bit 31 - i
-            if (bits) last = w0 + 31 - (long long)__builtin_ctz(bits);
+            uint32_t m = 0xFFFFFFFFu;  // bits of this word inside [lo, hi)  (position w0 + i at bit 31 - i)
+            if (w0 < lo) m &= 0xFFFFFFFFu >> (uint32_t)(lo - w0);
+            if (w0 + 32 > hi) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - hi);
+            const uint32_t word = v[wj];
+            const uint32_t x = word & m;
+            bad = bad || x != m;
+            any_valid = any_valid || x != 0u;
+            uint32_t mc = 0u;  // bits inside the core
+            if (w0 + 32 > c0 && w0 < c1) {
+                mc = 0xFFFFFFFFu;
+                if (w0 < c0) mc &= 0xFFFFFFFFu >> (uint32_t)(c0 - w0);
+                if (w0 + 32 > c1) mc &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - c1);
+            }
+            const uint32_t bits = word & mc;
+            if (bits) last = w0 + 31 - (long long)__builtin_ctz(bits);  // (this lane's words ascend)
         }
-        a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)(last + 1);
-    }
-    long long lo = (long long)td.tile_local * a.tc - (long long)(a.w - 1) - (long long)(a.k - 1) - 64;
-    long long hi = l1_core_end((long long)td.tile_local * a.tc, L, a.tc, a.ext) + (long long)(a.w - 1) + 64;
-    if (lo < 0) lo = 0;
-    if (hi > L) hi = L;
-    bool bad = false, any_valid = false;
-    for (long long wj = lo >> 5; wj <= (hi - 1) >> 5 && !(bad && any_valid); ++wj) {
-        uint32_t m = 0xFFFFFFFFu;  // bits of this word inside [lo, hi)
-        const long long w0 = wj << 5;
-        if (w0 < lo) m &= 0xFFFFFFFFu >> (uint32_t)(lo - w0);
-        if (w0 + 32 > hi) m &= 0xFFFFFFFFu << (uint32_t)(w0 + 32 - hi);
-        const uint32_t x = v[wj] & m;
-        bad = bad || x != m;
-        any_valid = any_valid || x != 0u;
-    }
-    if (bad) {
-        // bit 0: the tile kernel, which has finished, saw a palindromic k-mer; bit 1: a non-ACGT byte in the extended range;
-        // bit 2: NOTHING but non-ACGT bytes there -- the inside of a gap (api.hip: run_islands leaves such tiles out)
-        a.tile_flags[tile] |= any_valid ? 2 : 6;
-        atomicOr(a.cursor + 2, 2ull);
+        const bool w_bad = __ballot(bad) != 0, w_any = __ballot(any_valid) != 0;
+        // the largest `last` of the wave: all ones minus the value through the wave minimum
+        const uint64_t inv = wave_min64(~(uint64_t)(last + 1));
+        const long long w_last = (long long)(~inv) - 1;
+        if ((int)lane == j) {
+            a.tile_lv[tile] = ((uint64_t)(c + 1) << 32) | (uint64_t)(w_last + 1);
+            if (w_bad) {
+                // bit 0: the tile kernel, which has finished, saw a palindromic k-mer; bit 1: a non-ACGT byte in the extended range;
+                // bit 2: NOTHING but non-ACGT bytes there -- the inside of a gap (api.hip: run_islands leaves such tiles out)
+                a.tile_flags[tile] |= w_any ? 2 : 6;
+                a.desc[tile].skip = 1u;  // (the tile kernel leaves this tile alone)
+                atomicOr(a.cursor + 2, 2ull);
+            }
+        }
     }
 }
 
@@ -1000,10 +1041,20 @@ __global__ void tile_desc_kernel(L1Args a) {
     a.desc[tile] = d;
 }
 
-void launch_level1_tiles(hipStream_t st, const L1Args &a) {
+void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);
+void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv) {
     if (a.n_tiles == 0) return;
     const uint32_t n_desc = a.n_tiles > a.n_contigs ? a.n_tiles : a.n_contigs;  // (>= 8: a tile per non-empty contig ... or not)
     hipLaunchKernelGGL(tile_desc_kernel, dim3(((n_desc > 8 ? n_desc : 8) + 255) / 256), dim3(256), 0, st, a);
+    {   // flags tiles with a non-ACGT byte in reach (the tile kernel skips them), records every tile's last valid position
+        L1Args am = a;
+        am.tile_lv = tile_lv;
+        launch_mark_invalid_tiles(st, am);
+    }
+}
+// (behind launch_level1_pre on the same stream)
+void launch_level1_tiles(hipStream_t st, const L1Args &a) {
+    if (a.n_tiles == 0) return;
     if (a.ext == (uint32_t)L1_EXT_SHORT) {  // batches of short contigs: one wavefront per tile
         const dim3 g(a.n_tiles), bl(L1_BLOCK_SHORT);
         if (a.sketch)
@@ -1038,7 +1089,7 @@ void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_r
 }
 void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a) {
     if (a.n_tiles == 0) return;
-    hipLaunchKernelGGL(mark_invalid_tiles_kernel, dim3((a.n_tiles + 255) / 256), dim3(256), 0, st, a);
+    hipLaunchKernelGGL(mark_invalid_tiles_kernel, dim3((a.n_tiles + 4 * MARK_TPW - 1) / (4 * MARK_TPW)), dim3(256), 0, st, a);
 }
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list) {
     if (n_list == 0) return;

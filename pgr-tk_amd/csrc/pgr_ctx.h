@@ -55,6 +55,7 @@ struct pgr_ctx {
         int64_t fused_query_hits = 0;    // > 0: fixed slot size H of the per-query kernel
         int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank and on every wait for a collective; 0 = wait for ever
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
+        int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B
     } opt;
     std::vector<uint32_t> h_tile_first;  // pgr_shmmrs_compute: first tile of every contig (host copy, kept between calls)
@@ -74,6 +75,8 @@ struct pgr_ctx {
     // third stream + events: the result of sub-batch i goes to the host while sub-batch i + 1 computes (pipelined host calls)
     hipStream_t d2h_stream = nullptr;
     hipEvent_t d2h_ev[2] = {nullptr, nullptr};
+    hipEvent_t pre_ev[2] = {nullptr, nullptr};  // pgr_shmmrs_compute: tile flags known / on the host, while the tiles still run
+    hipStream_t pre_stream = nullptr;           // (their copy: a stream of its own, the download stream may be busy with a result)
     size_t d2h_slot_bytes = 0;  // half of pinned_out when the pipelined download uses it as two blocks
 
     // workspaces

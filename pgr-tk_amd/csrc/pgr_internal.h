@@ -106,7 +106,7 @@ struct TileDesc {  // one per tile, written by tile_desc_kernel (saves every wor
     uint32_t len;         // contig length
     uint32_t contig;      // contig index
     uint32_t tile_local;  // tile ordinal inside the contig
-    uint32_t skip;        // 1: the contig is handled by the exact chunk kernel, the tile kernel exits
+    uint32_t skip;        // 1: a non-ACGT byte in the tile's reach (set by mark_invalid_tiles_kernel): the tile kernel leaves it to the islands
     uint32_t _pad[2];
 };
 // exact-machine chunks (level1_chunk_kernel)
@@ -158,7 +158,8 @@ struct L1Args {
     // before the exact-machine chunks run: their k-mer look-back crosses a multi-Mbp run of N in one step with it.
     uint64_t *tile_lv;
 };
-void launch_level1_tiles(hipStream_t st, const L1Args &a);
+void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv);  // tile descriptors, flags of tiles with a non-ACGT byte in reach (tile_lv: [n_tiles] last valid positions)
+void launch_level1_tiles(hipStream_t st, const L1Args &a);                    // the tiles (and the contigs' tails), behind launch_level1_pre
 void launch_level1_tails(hipStream_t st, const L1Args &a);
 // exact state machine, one wavefront per chunk; status bit0 = region overflow, bit1 = override impossible
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
@@ -167,7 +168,7 @@ void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_
 // seg_cnt[s] = 0 for s in [ranges[2i], ranges[2i+1])
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges);
 // tile_flags |= 1 for tiles (of the listed contigs) whose extended range contains a non-ACGT byte
-void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // needs a.desc (after launch_level1_tiles)
+void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // (called by launch_level1_tiles between the descriptors and the tiles)
 // inclusive max-scan of a.tile_lv in place (rocPRIM); temp from scan_max_temp_bytes
 size_t scan_max_temp_bytes(uint32_t n);
 hipError_t scan_max_inplace(hipStream_t st, void *temp, size_t temp_bytes, uint64_t *v, uint32_t n);
