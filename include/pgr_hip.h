@@ -91,6 +91,7 @@ const char *pgr_version(void);
  *   no_island_relay           exact islands: the round-3 seam correction (one seam per host round), for A/B timing
  *   no_short_tiles            batches of short contigs (mean length <= 2048): 4096-position tiles all the same, for A/B timing
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing
+ *   island_chunk_min          > 0: shortest chunk of the exact machine in positions (default 1024; 4096 = the round-3 minimum), for A/B
  * Unknown names: PGR_ERR_INVALID_ARG. */
 int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value);
 int pgr_ctx_get_option(const pgr_ctx *ctx, const char *name, int64_t *value);

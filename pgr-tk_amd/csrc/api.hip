@@ -58,7 +58,7 @@ const std::vector<OptionName> &option_names() {
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
-        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}};
+        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"island_chunk_min", &O::island_chunk_min}};
     return v;
 }
 }  // namespace
@@ -570,10 +570,15 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
                              const std::vector<uint32_t> &empty_seg_ranges) {
     hipStream_t st = ctx->stream;
     // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
-    // (one per chunk) -- never below 4096: a chunk owns the segment-table entry of the tile it starts in (tc <= 4096)
+    // (one per chunk), down to 1024 positions: a round costs what its slowest chunk costs -- ~3 us per step of 64 positions,
+    // 225 us for the 4096-position chunks that were the minimum while a chunk had to own the segment-table entry of the tile it
+    // starts in.  The lists of the chunks that start in one tile are put together behind the last round (below).
     uint64_t island_bases = 0;
     for (const Island &is : islands) island_bases += is.E - is.B;
-    const uint64_t CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(4096, ((island_bases / 4096 + 4095) / 4096) * 4096));
+    const uint64_t CS_MIN = ctx->opt.island_chunk_min > 0 ? (uint64_t)((ctx->opt.island_chunk_min + 63) / 64 * 64) : 1024;
+    // (~2.5 wavefronts per SIMD: below that a round waits for dependent instructions, above it the SIMDs are busy -- a step is
+    // ~1.5 us of issue -- and shorter chunks only add warm-up steps)
+    const uint64_t CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(CS_MIN, ((island_bases / 2560 + 1023) / 1024) * 1024));
     // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
     std::vector<uint32_t> zero_ranges(empty_seg_ranges);
     struct HChunk {
@@ -584,6 +589,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         ChunkState t_out;       // final: the true state at ce
         uint32_t ring_src = 0;  // final: ring slot that holds the true ring at ce (this chunk's, or the one it passed through)
         uint64_t n_push = 0, bmin = 0;  // of the last run: pushes at the steps [cs, ce), smallest x of those with branch 2 enabled
+        uint64_t n_out = 0;             // of the last run: elements in the chunk's region
+        bool dropped = false;           // its output is not part of the list (a stuck machine passed through it)
     };
     std::vector<HChunk> ch;
     std::vector<ChunkState> s_in, s_out;
@@ -674,13 +681,13 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         a.out = (L1Rec *)ctx->ws_l1.p;
         // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
         const size_t desc_bytes = nq * sizeof(ChunkDesc);
-        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 3 * sizeof(uint64_t) + sizeof(uint32_t));
+        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 4 * sizeof(uint64_t) + sizeof(uint32_t));
         if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
         ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
         ChunkState *d_in = (ChunkState *)(d_desc + nq);
         ChunkState *d_out = d_in + nq;
         uint64_t *d_info = (uint64_t *)(d_out + nq);
-        uint32_t *d_stat = (uint32_t *)(d_info + 3 * nq);
+        uint32_t *d_stat = (uint32_t *)(d_info + 4 * nq);
         uint8_t *h_img = (uint8_t *)ctx->imail;
         memcpy(h_img, descs.data(), desc_bytes);
         Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
@@ -701,7 +708,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         isl_lap("states back on the host", round);
         const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
         const uint64_t *r_info = (const uint64_t *)(r_out + nq);
-        const uint32_t *r_stat = (const uint32_t *)(r_info + 3 * nq);
+        const uint32_t *r_stat = (const uint32_t *)(r_info + 4 * nq);
         PGR_HIP(ctx, hipGetLastError());
         zero_ranges.clear();
         s_in.resize(ch.size());
@@ -711,8 +718,10 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             s_in[todo[q]] = r_in[q];
             s_out[todo[q]] = r_out[q];
             status[todo[q]] = r_stat[q];
-            ch[todo[q]].n_push = r_info[3 * q];
-            ch[todo[q]].bmin = r_info[3 * q + 1];
+            ch[todo[q]].n_push = r_info[4 * q];
+            ch[todo[q]].bmin = r_info[4 * q + 1];
+            ch[todo[q]].n_out = r_info[4 * q + 3];
+            ch[todo[q]].dropped = false;
         }
         if (ctx->opt.debug) {
             uint32_t worst = 0;
@@ -721,8 +730,8 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             uint64_t worst_t = 0;
             for (size_t q = 0; q < nq; ++q) {
                 steps += r_stat[q] >> 8;
-                if ((r_info[3 * q + 2] & 0xFFFFFFFFull) > (worst_t & 0xFFFFFFFFull)) {
-                    worst_t = r_info[3 * q + 2];
+                if ((r_info[4 * q + 2] & 0xFFFFFFFFull) > (worst_t & 0xFFFFFFFFull)) {
+                    worst_t = r_info[4 * q + 2];
                     worst = r_stat[q] >> 8;
                     wq = q;
                 }
@@ -835,8 +844,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
                     h.t_out.min_y = t.min_y;
                     h.t_out.mdist = t.mdist + h.n_push;
                     h.ring_src = (uint32_t)i;
-                    zero_ranges.push_back(h.d.seg);
-                    zero_ranges.push_back(h.d.seg + 1);
+                    h.dropped = true;
                 } else {
                     if (ctx->opt.debug)
                         fprintf(stderr, "[pgr]   chunk %zu [%llu, %llu) of contig %u runs again from the true state: mdist %llu (warm-up %llu), "
@@ -880,13 +888,52 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             todo.swap(next);
         }
     }
-    if (!zero_ranges.empty()) {  // outputs dropped by the last round's verification (chunks a stuck machine passed through)
+    if (!zero_ranges.empty()) {  // (segment ranges of islands built in the last round: none in practice)
         Tmp_list d_zr(ctx);
         if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
         PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
         PGR_HIP(ctx, hipStreamSynchronize(st));
     }
+    isl_lap("seams verified", -1);
+    // ---- the lists of the chunks that start in one tile become that tile's segment: copied back to back into a fresh region
+    // (the chunks of an island are contiguous in `ch`, in position order; their counts came back with the states)
+    {
+        std::vector<uint64_t> img;  // copies (3 words each), then segment entries (3 words each)
+        std::vector<uint64_t> segs;
+        uint32_t cur_seg = 0xFFFFFFFFu;
+        for (const HChunk &h : ch) {
+            if (h.retired || h.probe || h.d.seg == 0xFFFFFFFFu) continue;
+            if (h.d.seg != cur_seg) {
+                cur_seg = h.d.seg;
+                segs.push_back((uint64_t)cur_seg | ((uint64_t)h.d.contig << 32));
+                segs.push_back(next_region);
+                segs.push_back(0);
+            }
+            if (h.dropped || h.n_out == 0) continue;
+            img.push_back(h.d.region_off);
+            img.push_back(next_region);
+            img.push_back(h.n_out);
+            segs[segs.size() - 1] += h.n_out;
+            next_region += h.n_out;
+        }
+        const size_t n_copies = img.size() / 3, n_set = segs.size() / 3;
+        if (n_set) {
+            for (size_t i = 0; i < n_set; ++i)
+                if (segs[3 * i + 2] > 0xFFFFFFFFull) return ctx->fail(PGR_ERR_INTERNAL, "a tile's exact list exceeds 2^32 elements");
+            img.insert(img.end(), segs.begin(), segs.end());
+            const size_t bytes = img.size() * sizeof(uint64_t);
+            if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st)) || (rc = ctx->ws_serial.ensure(ctx, bytes)) ||
+                (rc = ctx->ensure_imail(bytes)))
+                return rc;
+            a.out = (L1Rec *)ctx->ws_l1.p;
+            memcpy(ctx->imail, img.data(), bytes);  // (pinned, and untouched until this context's next island call: no wait here)
+            PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_serial.p, ctx->imail, bytes, hipMemcpyHostToDevice, st));
+            launch_assemble_chunks(st, a, (const uint64_t *)ctx->ws_serial.p, (uint32_t)n_copies,
+                                   (const uint64_t *)ctx->ws_serial.p + 3 * n_copies, (uint32_t)n_set);
+        }
+    }
+    isl_lap("tile lists assembled (enqueued)", -1);
     return PGR_OK;
 }
 
@@ -1238,7 +1285,11 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                     ++t;
                     continue;
                 }
-                uint32_t ta = t > 0 ? t - 1 : 0, tb = t;
+                // (no tile in front of the first flagged one: tile t - 1 is clean, so nothing irregular lies within its reach -- which
+                // ends w - 1 + 64 positions INTO tile t --, and the machine that starts 256 positions in front of tile t is regular
+                // at its first step by construction; behind tiles deep inside a gap it starts inside the run, where a warmed-up
+                // machine is exact)
+                uint32_t ta = t, tb = t;
                 while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
                 if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
                 Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};

@@ -899,15 +899,11 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     }
     if (lane == 0) {
         st_out[blockIdx.x] = o_out;
-        if (cd.seg != 0xFFFFFFFFu) {
-            a.seg_off[cd.seg] = cd.region_off;
-            a.seg_cid[cd.seg] = c;
-            if (n_out > cap || n_out > 0xFFFFFFFFull) {
-                stat |= 1u;  // region too small: the host re-runs this chunk with a full-size region
-                a.seg_cnt[cd.seg] = 0;
-            } else {
-                a.seg_cnt[cd.seg] = (uint32_t)n_out;
-            }
+        // (the chunk's list stays in its region: the host puts the lists of the chunks that start in one tile together behind
+        // the last round -- api.hip: run_exact_islands -- so chunks may be shorter than a tile)
+        if (cd.seg != 0xFFFFFFFFu && (n_out > cap || n_out > 0xFFFFFFFFull)) {
+            stat |= 1u;  // region too small: the host re-runs this chunk with a full-size region
+            n_out = 0;
         }
         // bit 2: no position of [cs, ce) was pushed and nothing is drained behind ce -- the machine's state at ce IS its state at
         // cs and the chunk emits nothing, whatever that state was: the host hands the state of the chunk in front straight
@@ -920,9 +916,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     {
         const uint64_t bmin = wave_min64(lane_bmin);
         if (lane == 0) {
-            info[3 * (size_t)blockIdx.x] = n_push;
-            info[3 * (size_t)blockIdx.x + 1] = bmin;
-            info[3 * (size_t)blockIdx.x + 2] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (t_lookback << 32);  // 100 MHz ticks (diagnostics)
+            info[4 * (size_t)blockIdx.x] = n_push;
+            info[4 * (size_t)blockIdx.x + 1] = bmin;
+            info[4 * (size_t)blockIdx.x + 2] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (t_lookback << 32);  // 100 MHz ticks (diagnostics)
+            info[4 * (size_t)blockIdx.x + 3] = cd.seg != 0xFFFFFFFFu ? n_out : 0ull;  // elements in the chunk's region
         }
     }
 }
@@ -1082,6 +1079,25 @@ void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_de
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info) {
     if (n_chunks == 0) return;
     hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings, d_info);
+}
+// the lists of the chunks that start in one tile, put together: copy i moves list[3i + 2] records from element list[3i] to
+// element list[3i + 1] of the level-1 buffer (a fresh region: source and destination never overlap); one wavefront per copy
+__global__ __launch_bounds__(64) void assemble_chunks_kernel(L1Rec *__restrict__ buf, const uint64_t *__restrict__ list) {
+    const uint64_t src = list[3 * (size_t)blockIdx.x], dst = list[3 * (size_t)blockIdx.x + 1], cnt = list[3 * (size_t)blockIdx.x + 2];
+    for (uint64_t i = threadIdx.x; i < cnt; i += 64) buf[dst + i] = buf[src + i];
+}
+// segment-table entries of the assembled tiles: segs[3i] = segment | contig << 32, segs[3i + 1] = first element, segs[3i + 2] = count
+__global__ void set_segs_kernel(L1Args a, const uint64_t *__restrict__ segs, uint32_t n) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sg = (uint32_t)segs[3 * (size_t)i];
+    a.seg_off[sg] = segs[3 * (size_t)i + 1];
+    a.seg_cnt[sg] = (uint32_t)segs[3 * (size_t)i + 2];
+    a.seg_cid[sg] = (uint32_t)(segs[3 * (size_t)i] >> 32);
+}
+void launch_assemble_chunks(hipStream_t st, const L1Args &a, const uint64_t *d_copies, uint32_t n_copies, const uint64_t *d_segs, uint32_t n_segs) {
+    if (n_copies) hipLaunchKernelGGL(assemble_chunks_kernel, dim3(n_copies), dim3(64), 0, st, a.out, d_copies);
+    if (n_segs) hipLaunchKernelGGL(set_segs_kernel, dim3((n_segs + 255) / 256), dim3(256), 0, st, a, d_segs, n_segs);
 }
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges) {
     if (n_ranges == 0) return;

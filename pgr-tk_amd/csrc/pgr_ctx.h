@@ -55,6 +55,7 @@ struct pgr_ctx {
         int64_t fused_query_hits = 0;    // > 0: fixed slot size H of the per-query kernel
         int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank and on every wait for a collective; 0 = wait for ever
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
+        int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B
     } opt;

@@ -167,6 +167,7 @@ void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_de
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list);
 // seg_cnt[s] = 0 for s in [ranges[2i], ranges[2i+1])
 void launch_zero_seg_ranges(hipStream_t st, const L1Args &a, const uint32_t *d_ranges, uint32_t n_ranges);
+void launch_assemble_chunks(hipStream_t st, const L1Args &a, const uint64_t *d_copies, uint32_t n_copies, const uint64_t *d_segs, uint32_t n_segs);
 // tile_flags |= 1 for tiles (of the listed contigs) whose extended range contains a non-ACGT byte
 void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);  // (called by launch_level1_tiles between the descriptors and the tiles)
 // inclusive max-scan of a.tile_lv in place (rocPRIM); temp from scan_max_temp_bytes
