@@ -291,3 +291,47 @@ def test_many_dense_short_contigs_take_the_retry_paths(oracle, gpu_ctx):
         for i in range(0, len(seqs), 7):
             ref = oracle.sequence_to_shmmrs(i, seqs[i], oracle.spec(*spec_t))
             _same(ref, got[i], "attempt %d contig %d len %d" % (attempt, i, len(seqs[i])))
+
+
+def test_island_options_agree_with_the_oracle(oracle, gpu_ctx):
+    """the exact islands' variants (context options): chunks shorter than a tile / the round-3 minimum of 4096
+    positions, islands listed beside the tile kernel / behind it, the state relay on / off -- on contigs with gaps, isolated N,
+    palindromic arrays and low-complexity stretches, through the host entry point (the packer counts the non-ACGT bytes: the
+    islands are listed while the tiles run) and as a resident batch; every variant bit-identical to the oracle."""
+    import pgrtk_amd as P
+    import seqgen
+    rng = np.random.default_rng(606)
+
+    def contig(L):
+        parts, n = [], 0
+        while n < L:
+            r = rng.random()
+            if r < 0.55:
+                p = seqgen.rnd(rng, int(rng.integers(2_000, 60_000)))
+            elif r < 0.7:
+                p = b"N" * int(rng.integers(1, 30_000))
+            elif r < 0.8:
+                p = (b"AT", b"ACGT", b"GAATTC")[int(rng.integers(0, 3))] * int(rng.integers(50, 3000))
+            elif r < 0.9:
+                p = seqgen.rnd(rng, int(rng.integers(100, 9000)), b"AC")
+            else:
+                p = seqgen.rnd(rng, 500) + b"N" + seqgen.rnd(rng, 700)
+            parts.append(p)
+            n += len(p)
+        return b"".join(parts)[:L]
+    seqs = [contig(700_000), contig(150_000), seqgen.rnd(rng, 50_000), b"N" * 40_000 + seqgen.rnd(rng, 30_000) + b"N" * 9_000, contig(20_000)]
+    spec_t = (80, 56, 4, 64)
+    spec, osp = P.make_spec(*spec_t), oracle.spec(*spec_t)
+    refs = [oracle.sequence_to_shmmrs(i, s, osp) for i, s in enumerate(seqs)]
+    variants = [{}, {"no_pre_islands": 1}, {"island_chunk_min": 4096}, {"island_chunk_min": 1024, "no_island_relay": 1},
+                {"island_chunk_min": 32768}, {"no_short_tiles": 1, "no_small_path": 1}]
+    for opt in variants:
+        with gpu_ctx.options(**dict(opt, no_small_path=1)):
+            got = P.sequence_to_shmmrs_batch(seqs, spec, ctx=gpu_ctx)  # host entry point
+            b = P.Batch.from_seqs(seqs, ctx=gpu_ctx)
+            sh = b.shmmrs(spec)
+        for i in range(len(seqs)):
+            _same(refs[i], got[i], "host entry, options %s, contig %d" % (opt, i))
+        sums, off = sh.checksum(), sh.offsets()
+        for i in range(len(seqs)):
+            assert int(off[i + 1] - off[i]) == len(refs[i]) and np.array_equal(sums[i], oracle.shmmr_checksum(refs[i])), (opt, i)
