@@ -1291,9 +1291,15 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 // machine is exact)
                 uint32_t ta = t, tb = t;
                 while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
-                if (tb + 1 < nt) ++tb;  // a clean neighbour on the right
+                bool any_pal = false;
+                for (uint32_t q = ta; q <= tb; ++q) any_pal = any_pal || (tf[t0 + q] & 1);
+                // a clean neighbour on the right for the machine to find back into its regular regime -- behind skipped pushes
+                // (palindromic k-mers) it may arrive stuck; behind a non-ACGT byte it cannot: the byte lies >= w + k + 64
+                // positions in front of the first clean tile (or that tile would be flagged), every position pushes, and the
+                // ring holds only pushes from behind the byte when the island ends.  The probe at the island's end checks it.
+                if (tb + 1 < nt && any_pal) ++tb;
                 Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
-                for (uint32_t q = ta; q <= tb; ++q) is.pal = is.pal || (tf[t0 + q] & 1);
+                is.pal = any_pal;
                 if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
                 if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
                     islands.back().E = std::max(islands.back().E, is.E);
