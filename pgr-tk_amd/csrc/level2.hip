@@ -555,8 +555,20 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
                 }
             }
         }
+        const bool stalled = cover_hi <= done;  // 64 segments without an element of [done, hi): the inside of a gap (emptied tiles)
         done = cover_hi > done ? cover_hi : done;
         seg0 += FUSED_SEGS;
+        if (stalled && seg0 < a.n_segs) {
+            // the workgroup at the end of an 18 Mbp gap used to stage its 4600 empty segments 64 at a time (~2 us a round, the
+            // whole list stage of a chromosome waiting for it): the last segment that starts at or below `done`, by bisection
+            uint32_t s_lo = seg0, s_hi = a.n_segs;  // seg_dst[seg0] <= done < total = seg_dst[n_segs]
+            while (s_hi - s_lo > 1) {
+                const uint32_t mid = (s_lo + s_hi) >> 1;
+                if (a.seg_dst[mid] <= done) s_lo = mid;
+                else s_hi = mid;
+            }
+            seg0 = s_lo;
+        }
         __syncthreads();
         if (seg0 >= a.n_segs && done < hi) break;  // cannot happen: seg_dst[n_segs] == total >= hi
     }
