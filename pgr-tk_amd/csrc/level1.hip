@@ -3,16 +3,20 @@
 // Replaces the per-base loop of shmmrutils::sequence_to_shmmrs1 (pgr-db/src/shmmrutils.rs:454-530)
 // and the sketch loop of sequence_to_shmmrs2 (:580-630).
 //
-// Three kernels:
-//   level1_tile_kernel   position-parallel closed form: one workgroup of 256
-//                        lanes per tile of 4096 positions (core + 2*(w-1) halo); every lane owns 16
-//                        consecutive positions in registers.
-//   level1_tail_kernel   the last (w-k) positions of a contig, where the reference only rescans
-//                        (branch 2 disabled, shmmrutils.rs:516-520): one wavefront per contig.
-//   level1_chunk_kernel  the exact ring-buffer state machine, event driven, one wavefront per 32 kbp chunk
-//                        with verified seams.  Used for contigs the closed form does not cover: non-ACGT
-//                        bytes, reverse-complement-palindromic k-mers (skipped pushes, shmmrutils.rs:477-480),
-//                        w < 17.
+// Kernels, in launch order:
+//   tile_desc_kernel           one thread per tile: its descriptor; clears the call's cursors and flags.
+//   mark_invalid_tiles_kernel  flags tiles with a non-ACGT byte in reach (in the descriptor: the tile kernel leaves them to the
+//                              islands) and records every tile's last valid position.
+//   level1_tile_kernel<W,K,SKETCH,BLK>  position-parallel closed form: one workgroup of BLK = 256 lanes per
+//                              tile of 4096 positions (core + 2*(w-1) halo) -- or BLK = 64, one wavefront per tile of 1024, for
+//                              batches of short contigs --; every lane owns 16 consecutive positions in registers.  The last
+//                              tile of a contig also runs the contig's tail (tail_of_contig): the last (w-k) positions, where
+//                              the reference only rescans (branch 2 disabled, shmmrutils.rs:516-520).
+//   level1_tail_kernel         the same tails, one wavefront per contig, for specs without a tile path (w < 17).
+//   level1_chunk_kernel        the exact ring-buffer state machine, event driven, one wavefront per chunk (1-32 kbp) with verified
+//                              seams.  Runs on islands around what the closed form does not cover: non-ACGT bytes,
+//                              reverse-complement-palindromic k-mers (skipped pushes, shmmrutils.rs:477-480); whole contigs for w < 17.
+//   assemble_chunks_kernel, set_segs_kernel   the lists of the chunks that start in one tile become that tile's segment.
 //
 // Integer / byte work only: no MFMA.  The tile kernel is VALU bound (two 64-bit mix hashes per position).
 #include "pgr_device.h"
