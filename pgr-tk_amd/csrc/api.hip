@@ -409,11 +409,12 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
                 } else {
                     for (uint32_t cq = j.c0; cq < j.c1; ++cq) {
                         const uint64_t o = j.out + (b->h_word_off[cq] - b->h_word_off[j.c0]);
-                        const uint64_t bad = pack_words_stream(src.seqs[cq], src.lens[cq], 0, b->h_word_off[cq + 1] - b->h_word_off[cq],
-                                                               pin_planes + o, pin_valid + o);
+                        const uint64_t bad = pack_words_stream_nofence(src.seqs[cq], src.lens[cq], 0, b->h_word_off[cq + 1] - b->h_word_off[cq],
+                                                                       pin_planes + o, pin_valid + o);
                         if (bad) b->h_n_invalid[cq] = (uint32_t)bad;  // (the whole contig is this job's)
                         job_bad += bad;
                     }
+                    stream_fence();
                 }
                 if (job_bad) win_bad.fetch_add(job_bad, std::memory_order_relaxed);
             } else {

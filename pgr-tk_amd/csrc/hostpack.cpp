@@ -350,6 +350,15 @@ uint64_t pack_words_stream(const uint8_t *seq, uint64_t len, uint64_t w0, uint64
     return bad;
 }
 
+// one contig of a GROUP of short contigs that a job packs back to back into the window: non-temporal stores whatever the
+// contig's length (the group's destination is one contiguous range), no fence -- the job ends with stream_fence()
+uint64_t pack_words_stream_nofence(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid) {
+    if (have_avx512()) return pack_words_avx512<true>(seq, len, w0, w1, planes, valid);
+    if (have_avx2()) return pack_words_avx2<true>(seq, len, w0, w1, planes, valid);
+    return pack_words_scalar(seq, len, w0, w1, planes, valid);
+}
+void stream_fence() { _mm_sfence(); }
+
 // memcpy into a pinned staging window with non-temporal stores (any alignment: the unaligned head and tail go through memcpy)
 __attribute__((target("avx2"))) static void stream_copy_avx2(uint8_t *d, const uint8_t *s, size_t n) {
     size_t i = 0;

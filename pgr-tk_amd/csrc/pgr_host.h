@@ -35,6 +35,8 @@ class HostPool {
 uint64_t pack_words(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid);
 // into a pinned staging window: non-temporal stores + store fence
 uint64_t pack_words_stream(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid);
+uint64_t pack_words_stream_nofence(const uint8_t *seq, uint64_t len, uint64_t w0, uint64_t w1, uint64_t *planes, uint32_t *valid);
+void stream_fence();
 void stream_copy(void *dst, const void *src, size_t n);
 
 }  // namespace pgr
