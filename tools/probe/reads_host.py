@@ -37,6 +37,6 @@ call()
 call()
 ts = sorted(call() for _ in range(5))
 print("pgr_shmmr_batch, %d x %d bp from host ASCII: %.2f ms (median of 5; best %.2f) = %.1f Gbp/s" % (n, L, ts[2] * 1e3, ts[0] * 1e3, n * L / ts[2] / 1e9))
-with ctx.options(debug=2):
+with ctx.options(debug=1):
     t = call()
 print('traced call %.2f ms' % (t * 1e3))
