@@ -382,6 +382,8 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         // million calls through the pool per Gbp -- the staging thread spent longer listing them than the pool packing them
         // (at least ~4 groups per thread and window: the small windows of a query batch would be two rounds and a bit otherwise)
         const uint64_t GROUP = std::max<uint64_t>(2048, std::min<uint64_t>(PIECE / 4, (w1 - w0) / (4ull * (HostPool::instance().workers() + 1))));
+        // (pieces of long contigs likewise: 42 pieces of 2 MiB for 16 threads were three rounds, the last one a third full)
+        const uint64_t PIECE_W = std::max<uint64_t>(8192, std::min<uint64_t>(PIECE, (((w1 - w0) / (4ull * (HostPool::instance().workers() + 1)) + 2047) / 2048) * 2048));
         for (uint32_t cc = c; cc < n && b->h_word_off[cc] < w1;) {
             const uint64_t cw0 = b->h_word_off[cc], cw1 = b->h_word_off[cc + 1];
             if (cw0 >= w0 && cw1 <= w1 && cw1 - cw0 < GROUP) {
@@ -394,7 +396,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
                 continue;
             }
             const uint64_t lo = std::max(cw0, w0), hi = std::min(cw1, w1);
-            for (uint64_t o = lo; o < hi; o += PIECE) jobs.push_back(Job{cc, cc + 1, o - cw0, std::min(hi, o + PIECE) - cw0, o - w0});
+            for (uint64_t o = lo; o < hi; o += PIECE_W) jobs.push_back(Job{cc, cc + 1, o - cw0, std::min(hi, o + PIECE_W) - cw0, o - w0});
             ++cc;
         }
         std::atomic<uint64_t> win_bad{0};
