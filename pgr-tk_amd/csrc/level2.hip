@@ -235,7 +235,7 @@ constexpr int FUSED_B = 1024;
 constexpr int FUSED_EMAX_BIG = FUSED_B + 2 * 288;   // r <= 12
 constexpr int FUSED_EMAX_SMALL = FUSED_B + 2 * 32;  // r <= 4 (the common spec): 22 KB of LDS, 7 workgroups / CU
 
-constexpr int FUSED_SEGS = 64;  // segment descriptors staged per round
+constexpr int FUSED_SEGS = 128;  // segment descriptors staged per round (a block of a read batch spans ~90 segments)
 
 template <int EMAX>
 struct FusedLdsT {
