@@ -1337,7 +1337,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
         if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));
         if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
         l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
-        PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
+        if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
         pre_listed = false;
         if (tiled && bases_tiled) {
             launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p);
@@ -1351,6 +1351,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
                 PGR_HIP(ctx, hipMemcpyAsync(ctx->imail, d_tflags, n_tiles, hipMemcpyDeviceToHost, ctx->pre_stream));
                 PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[1], ctx->pre_stream));
             }
+            PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));  // (prof.level1_ms is the tile kernel alone: descriptors and flags are in front of it)
             launch_level1_tiles(st, a);
             if (pre) {
                 PGR_HIP(ctx, hipEventSynchronize(ctx->pre_ev[1]));
