@@ -652,6 +652,60 @@ def target_100gbp(P, ctx, spec, args):
                     (n_b, n_c, L)}
 
 
+def pipelined_leg(P, ctx, batch, spec, rec_buf, contig_ids, steps, warmup, torch, sync_state):
+    """The same step through pgr_pipe_*: two batches in flight, the list stage + pair records of batch i on the back stream beside
+    the tiles of batch i + 1 (the software-pipelined loop of load_index_from_reader, seq_db.rs:541-571).  >= 4 back-to-back
+    batches; the last two jobs' content against the synchronous step's (128-bit checksums of lists and records)."""
+    import numpy as np
+    bufs = [rec_buf, torch.empty_like(rec_buf)]
+    pipe = P.Pipe(spec, ctx=ctx)
+    steps = max(4, steps)
+    lv1 = []
+
+    def run(k, keep):
+        last = []
+        for i in range(k):
+            if pipe.in_flight == 2:
+                sh, n = pipe.collect()
+                lv1.append(ctx.last_prof().level1_ms)
+                last.append((sh, n, (i - 2) & 1))
+                last = last[-keep:] if keep else []
+            pipe.submit(batch, sids=contig_ids, rec_ptr=bufs[i & 1].data_ptr(), rec_capacity=rec_buf.shape[0])
+        j = k - pipe.in_flight
+        while pipe.in_flight:
+            sh, n = pipe.collect()
+            lv1.append(ctx.last_prof().level1_ms)
+            last.append((sh, n, j & 1))
+            j += 1
+        return last[-keep:] if keep else []
+    run(max(2, warmup), 0)
+    torch.cuda.synchronize()
+    ctx.synchronize()
+    del lv1[:]
+    t0 = time.perf_counter()
+    last = run(steps, 2)
+    ctx.synchronize()
+    dt = time.perf_counter() - t0
+    ok = True
+    ref_sh, ref_n = sync_state["sh"], sync_state["n_pairs"]
+    ref_sum = ref_sh.checksum()
+    ref_rec = P.records_checksum(rec_buf.data_ptr(), ref_n, ctx=ctx) if (steps & 1) == 0 else None  # (bufs[0] was rewritten by the pipe with the same records)
+    for sh, n, slot in last:
+        ok = ok and n == ref_n and sh.count == ref_sh.count and bool(np.array_equal(sh.checksum(), ref_sum))
+        rec = P.records_checksum(bufs[slot].data_ptr(), n, ctx=ctx)
+        if ref_rec is None:
+            ref_rec = rec
+        ok = ok and rec == ref_rec
+    pipe.close()
+    bp = batch.total_bases
+    return {"value_pipelined": bp * steps / dt / 1e9, "ms_per_step_pipelined": dt / steps * 1e3, "batches": steps, "in_flight": 2,
+            "level1_tile_ms_beside_the_list_stage": float(np.mean(lv1)) if lv1 else None,
+            "content_match_vs_synchronous_step": bool(ok),
+            "what": "pgr_pipe_submit / pgr_pipe_collect over %d back-to-back batches (the same resident 10 Gbp batch), shimmer lists "
+                    "+ pair records per batch as in `value`; tiles on the context's stream, list stage + pair records on a second "
+                    "stream behind an event" % steps}
+
+
 def self_spawn(n):
     """re-run this command line under torch.distributed.run with n ranks on this node; returns its exit code"""
     import socket
@@ -959,6 +1013,12 @@ def main():
                 out["cpu_baseline"]["content_match_all_ranks"] = bool(rc_ and all(c.get("content_match") for c in rc_))
         if dist_query is not None:
             out["query"] = dist_query
+        if world == 1 and not do_exchange:
+            try:
+                out["pipelined"] = pipelined_leg(P, ctx, batch, spec, rec_buf, contig_ids, args.steps, args.warmup, torch, state)
+                out["value_pipelined"] = out["pipelined"]["value_pipelined"]
+            except Exception as e:  # noqa: BLE001
+                out["pipelined"] = {"error": repr(e)[:300]}
         if world == 1 and not do_exchange:
             try:  # what the N > 1 merge costs when there is nothing to exchange: the same records into an index
                 reps = []

@@ -92,7 +92,18 @@ const char *pgr_version(void);
  *   no_short_tiles            batches of short contigs (mean length <= 2048): 4096-position tiles all the same, for A/B timing
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing
  *   island_chunk_min          > 0: shortest chunk of the exact machine in positions (default 1024; 4096 = the round-3 minimum), for A/B
+ *   back_priority             pgr_pipe: stream priority of the back stream (1 = highest, 0 = default, -1 = lowest), read when the
+ *                             context's first pipe is created
+ *   lds_match                 pgr_pipe: the back stream's kernels occupy exactly the tile kernel's LDS per workgroup, or none, for A/B
+ *   pipe_staged_records       pgr_pipe: index jobs always stage their records and copy them in when collected, for A/B
  * Unknown names: PGR_ERR_INVALID_ARG. */
+/* Device memory of a context.  Results, batches and indexes come from a caching allocator (a released block is kept for the next
+ * request of its size: the steady state of a loop over batches allocates nothing); pgr_ctx_trim gives the cached blocks (not
+ * the live ones, not the workspaces) back to the device -- after a phase whose buffers the next one has no use for.
+ * pgr_ctx_mem_stats: bytes the allocator holds now (live + cached) and the most it has held since the context was created or
+ * the peak was last reset (reset_peak != 0 starts a new measurement). */
+int pgr_ctx_trim(pgr_ctx *ctx);
+int pgr_ctx_mem_stats(pgr_ctx *ctx, uint64_t *held_bytes, uint64_t *peak_bytes, int reset_peak);
 int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value);
 int pgr_ctx_get_option(const pgr_ctx *ctx, const char *name, int64_t *value);
 
@@ -196,6 +207,33 @@ int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s, const uint
                                    int query_side, pgr_frag_rec *d_out, uint64_t capacity,
                                    uint64_t *n_out);
 
+/* ------------------------------------------------------------------ a software pipeline over resident batches
+ * The reference's loaders call get_shmmrs_from_seqs batch after batch (load_index_from_reader, pgr-db/src/seq_db.rs:541-571:
+ * read <= 129 contigs, compute, insert, repeat).  pgr_shmmrs_compute is that call, and it returns when its batch is done:
+ * the list stage, the pair records and the host's round trip of batch i sit between the tile kernels of batches i and
+ * i + 1.  A pgr_pipe takes the batches of such a loop WITHOUT waiting: submit enqueues the whole pass -- level-1 tiles on the
+ * context's stream; behind an event, on a second (higher-priority) stream: the list stage and the index-side pair records
+ * (seq_db.rs:381-400) -- and returns; collect hands back the oldest submitted job once it is done.  Two jobs may be in flight
+ * (a third submit fails with PGR_ERR_STATE): the HBM-bound tail of batch i runs beside the VALU-bound tiles of batch i + 1.
+ *   sids     sids[i] = sequence id of contig i in the records (NULL: i, or the index's running sid when ix != NULL); copied
+ *   ix       != NULL: the pair records are appended to this index in submission order when the job is collected
+ *            (load_index_from_seq_vec's insertion order, seq_db.rs:605-612); the index must not be finalized, queried or
+ *            written to by anything else while one of its jobs is in flight
+ *   d_recs   != NULL (ix == NULL): the pair records go to this DEVICE buffer of recs_capacity records
+ * collect:  *out (may be NULL: the list is released) = the job's shimmer lists, as from pgr_shmmrs_compute;
+ *           *n_pairs (may be NULL) = pair records written.  PGR_ERR_STATE when nothing is in flight.
+ * The batch must stay alive, and unchanged, until its job has been collected.  Results are bit-identical to
+ * pgr_shmmrs_compute + pgr_shmmrs_to_frag_recs_device: a job whose first, optimistic pass meets a flagged tile (non-ACGT byte,
+ * palindromic k-mer) or an undersized buffer is finished synchronously when it is collected.
+ * pgr_ctx_last_prof after a collect describes that job.  Destroying a pipe waits for its jobs and drops their results. */
+typedef struct pgr_pipe pgr_pipe;
+int pgr_pipe_create(pgr_ctx *ctx, const pgr_spec *spec, pgr_pipe **out);
+int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *sids, pgr_index *ix, pgr_frag_rec *d_recs,
+                    uint64_t recs_capacity);
+int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs);
+int pgr_pipe_in_flight(const pgr_pipe *p);
+void pgr_pipe_destroy(pgr_pipe *p);
+
 /* ------------------------------------------------------------------ profiling hooks
  * HIP-event timing of the kernels of the LAST pgr_shmmrs_compute on the context's stream. */
 typedef struct {
@@ -224,6 +262,9 @@ int pgr_index_add_batch(pgr_ctx *ctx, pgr_index *ix, uint32_t n_seqs, const uint
 int pgr_index_add_packed(pgr_ctx *ctx, pgr_index *ix, uint32_t n_seqs, const uint64_t *lens, const uint64_t *planes,
                          const uint32_t *valid, const uint32_t *sids);
 int pgr_index_add_resident(pgr_ctx *ctx, pgr_index *ix, const pgr_batch *b, const uint32_t *sids);
+/* room for n_records appended records in all (a host that knows what it is going to index -- total bases x ~0.00304 pair
+ * records per base at (80, 56, 4, 64) -- saves the index its grow-and-copy steps; records already appended are kept) */
+int pgr_index_reserve(pgr_ctx *ctx, pgr_index *ix, uint64_t n_records);
 /* merge pair records computed elsewhere (other GPUs, after the RCCL all-gather) */
 int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs, uint64_t n,
                           int recs_on_device);

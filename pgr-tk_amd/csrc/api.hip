@@ -1,13 +1,5 @@
-// api.hip -- host side of libpgrhip.so: context, resident batches, orchestration of the
-// sequence_to_shmmrs pipeline, and the C ABI declared in include/pgr_hip.h.
-//
-// Pipeline of one pgr_shmmrs_compute:
-//   level1_tile_kernel  (dominant)  -> unordered per-tile segments of level-1 minimizers
-//   level1_tail_kernel              -> per-contig tail segment (rescan-only positions)
-//   level1_chunk_kernel             -> exact state machine (chunked, verified seams) for contigs the
-//                                      closed form cannot do
-//   scan(seg counts) + gather       -> ordered per-contig level-1 lists
-//   select(reduce) x2, select(min_span) -> final MM128 lists (+ rid patch)
+// api.hip -- host side of libpgrhip.so: context, resident batches, results, the host-buffer entry points of the C ABI declared
+// in include/pgr_hip.h.  The orchestration of a pass of the sequence_to_shmmrs pipeline is csrc/pipeline.hip.
 #include <algorithm>
 #include <chrono>
 #include <atomic>
@@ -21,18 +13,13 @@
 #include <map>
 
 #include "pgr_ctx.h"
+#include "pgr_index.h"
 #include "pgr_small.h"
 
 using namespace pgr;
 
 namespace {
-struct Tmp_list {  // small RAII device allocation from the context's caching allocator
-    pgr_ctx *ctx;
-    void *p = nullptr;
-    explicit Tmp_list(pgr_ctx *c) : ctx(c) {}
-    ~Tmp_list() { ctx->dfree(p); }
-    int alloc(size_t bytes) { return ctx->dmalloc(&p, bytes < 16 ? 16 : bytes); }
-};
+using Tmp_list = pgr::Tmp;  // small RAII device allocation from the context's caching allocator
 }  // namespace
 
 static std::string g_create_error;
@@ -58,7 +45,9 @@ const std::vector<OptionName> &option_names() {
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
-        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"island_chunk_min", &O::island_chunk_min}};
+        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"island_chunk_min", &O::island_chunk_min},
+        {"back_priority", &O::back_priority}, {"pipe_staged_records", &O::pipe_staged_records},
+        {"lds_match", &O::lds_match}};
     return v;
 }
 }  // namespace
@@ -118,6 +107,34 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     return PGR_OK;
 }
 
+extern "C" int pgr_ctx_trim(pgr_ctx *ctx) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->back_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->back_stream));
+    for (auto &kv : ctx->free_blocks) {
+        (void)hipFree(kv.second.p);
+        ctx->drop_events(kv.second);
+        ctx->live_bytes -= kv.first;
+    }
+    ctx->free_blocks.clear();
+    ctx->cached_bytes = 0;
+    for (pgr::Lane *l : ctx->spare_lanes) {
+        pgr::lane_release(ctx, *l);
+        delete l;
+    }
+    ctx->spare_lanes.clear();
+    return PGR_OK;
+}
+
+extern "C" int pgr_ctx_mem_stats(pgr_ctx *ctx, uint64_t *held_bytes, uint64_t *peak_bytes, int reset_peak) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (held_bytes) *held_bytes = ctx->live_bytes;
+    if (peak_bytes) *peak_bytes = ctx->peak_bytes;
+    if (reset_peak) ctx->peak_bytes = ctx->live_bytes;
+    return PGR_OK;
+}
+
 extern "C" int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!name) return ctx->fail(PGR_ERR_INVALID_ARG, "null option name");
@@ -143,6 +160,7 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream);
     ctx->release_all();
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -154,6 +172,7 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto &ev : ctx->pre_ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
     if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);
@@ -549,398 +568,8 @@ extern "C" int pgr_batch_synthetic_ids(pgr_ctx *ctx, uint32_t n, const uint64_t 
     return batch_synthetic(ctx, n, lens, seed, 0, contig_ids, out);
 }
 
-// ------------------------------------------------------------------------------------------------
-// ------------------------------------------------------------------------------------------------
-// Exact state machine (level1_chunk_kernel) over ISLANDS: position ranges [B, E) of a contig (tile aligned, or
-// the whole contig) that replace the closed-form tiles near an irregularity (non-ACGT byte, palindromic
-// k-mer) or everything when the spec has no tile path (w < 17).  Inside an island the chunks of 32 kbp are
-// seamed by emission step and every seam is verified against the previous chunk's end state; the island's
-// left edge trusts the warm-up (everything before it is regular by construction: islands keep a clean tile
-// on both sides), its right edge is verified with a probe (warm-up only) at E and the island grows when the
-// machine has not yet returned to its regular regime there.
-struct Island {
-    uint32_t contig;
-    uint64_t B, E;
-    bool whole;  // one chunk for the whole contig (last resort)
-    // a tile of the island saw a palindromic k-mer: inside a stretch of skipped pushes a chunk needs the true state of the
-    // chunk in front (one seam per round), so such islands keep long chunks; islands around non-ACGT bytes verify at the
-    // first try and are cut short for parallelism
-    bool pal = true;
-};
 
-static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
-                             const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base,
-                             const std::vector<uint32_t> &empty_seg_ranges) {
-    hipStream_t st = ctx->stream;
-    // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
-    // (one per chunk), down to 1024 positions: a round costs what its slowest chunk costs -- ~3 us per step of 64 positions,
-    // 225 us for the 4096-position chunks that were the minimum while a chunk had to own the segment-table entry of the tile it
-    // starts in.  The lists of the chunks that start in one tile are put together behind the last round (below).
-    uint64_t island_bases = 0;
-    for (const Island &is : islands) island_bases += is.E - is.B;
-    const uint64_t CS_MIN = ctx->opt.island_chunk_min > 0 ? (uint64_t)((ctx->opt.island_chunk_min + 63) / 64 * 64) : 1024;
-    // (~2.5 wavefronts per SIMD: below that a round waits for dependent instructions, above it the SIMDs are busy -- a step is
-    // ~1.5 us of issue -- and shorter chunks only add warm-up steps)
-    const uint64_t CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(CS_MIN, ((island_bases / 2560 + 1023) / 1024) * 1024));
-    // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
-    std::vector<uint32_t> zero_ranges(empty_seg_ranges);
-    struct HChunk {
-        ChunkDesc d;
-        size_t island;
-        bool full_cap = false, probe = false, retired = false;
-        bool final = false;     // the state this chunk started from is known to be the true one
-        ChunkState t_out;       // final: the true state at ce
-        uint32_t ring_src = 0;  // final: ring slot that holds the true ring at ce (this chunk's, or the one it passed through)
-        uint64_t n_push = 0, bmin = 0;  // of the last run: pushes at the steps [cs, ce), smallest x of those with branch 2 enabled
-        uint64_t n_out = 0;             // of the last run: elements in the chunk's region
-        bool dropped = false;           // its output is not part of the list (a stuck machine passed through it)
-    };
-    std::vector<HChunk> ch;
-    std::vector<ChunkState> s_in, s_out;
-    std::vector<uint32_t> status;
-    std::vector<size_t> todo;
-    auto cap_of = [&](uint64_t len, bool full) -> uint64_t {
-        return full ? len + a.w + 320 : std::min<uint64_t>(len + a.w + 320, len / 4 + 1024);
-    };
-    int rc;
-    // (re)build the chunks of one island; its tile (and tail) segments become empty first
-    auto build = [&](size_t ii) -> int {
-        const Island &is = islands[ii];
-        const uint32_t c = is.contig;
-        const uint64_t L = b->h_len[c];
-        const uint32_t nt = tile_first[c + 1] - tile_first[c];
-        const uint32_t seg0 = tile_first[c] + c;
-        // (a contig that is one tile may be longer than a tile core: clamped)
-        uint32_t rng[2] = {seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, is.B / tc), seg0 + (uint32_t)std::min<uint64_t>(nt, (is.E + tc - 1) / tc)};
-        if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
-        zero_ranges.push_back(rng[0]);
-        zero_ranges.push_back(rng[1]);
-        // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
-        // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
-        const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : CS_SHORT;
-        const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
-        for (uint64_t j = 0; j < nch; ++j) {
-            HChunk h;
-            memset(&h.d, 0, sizeof(h.d));
-            memset(&h.t_out, 0, sizeof(h.t_out));
-            h.island = ii;
-            h.d.contig = c;
-            h.d.cs = is.whole ? 0 : is.B + j * CS;
-            h.d.ce = is.whole ? L : std::min<uint64_t>(is.E, is.B + (j + 1) * CS);
-            h.d.emit_lo_pos = (j == 0) ? is.B : 0;
-            h.d.drain_end = h.d.ce;
-            if (j + 1 == nch && is.E < L) h.d.drain_end = std::min<uint64_t>(L, is.E + 320);
-            h.d.seg = seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, h.d.cs / tc);
-            h.d.warm = 256;
-            // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
-            // (ties, shmmrutils.rs:516-527), the sparse region estimate would overflow and the chunk run twice
-            // (so is an island around non-ACGT bytes, however short: it may be one of the two ends of a long gap)
-            h.full_cap = nch >= 8 || !is.pal;
-            todo.push_back(ch.size());
-            ch.push_back(h);
-        }
-        if (is.E < L) {  // probe: what a warmed-up (regular) machine looks like at E
-            HChunk h;
-            memset(&h.d, 0, sizeof(h.d));
-            memset(&h.t_out, 0, sizeof(h.t_out));
-            h.island = ii;
-            h.probe = true;
-            h.d.contig = c;
-            h.d.cs = h.d.ce = h.d.drain_end = is.E;
-            h.d.seg = 0xFFFFFFFFu;
-            h.d.warm = 256;
-            todo.push_back(ch.size());
-            ch.push_back(h);
-        }
-        return PGR_OK;
-    };
-    for (size_t ii = 0; ii < islands.size(); ++ii)
-        if ((rc = build(ii))) return rc;
-
-    uint64_t next_region = region_base;
-    const auto t_isl0 = std::chrono::steady_clock::now();
-    auto isl_lap = [&](const char *what, int round) {
-        if (ctx->opt.debug_times)
-            fprintf(stderr, "[pgr]     islands round %d %-34s at %7.1f us\n", round, what,
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_isl0).count());
-    };
-    for (int round = 0; !todo.empty(); ++round) {
-        // Every round settles at least one seam or grows / merges an island, so the number of rounds is bounded by the number
-        // of chunks plus the growth steps; in practice it is 1-3: a state is handed through chunks that cannot change it on the
-        // host (see the verification below), and only a chunk whose predecessor's state is final runs again.
-        if (round > 1024 + 4 * (int)ch.size()) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
-        const size_t nq = todo.size();
-        std::vector<ChunkDesc> descs(nq);
-        for (size_t q = 0; q < nq; ++q) {
-            HChunk &h = ch[todo[q]];
-            h.d.ring_out = h.probe ? 0xFFFFFFFFu : (uint32_t)todo[q];
-            if (!h.d.override_state) h.d.ring_in = 0xFFFFFFFFu;
-            h.d.region_off = next_region;
-            h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
-            next_region += h.d.region_cap;
-            descs[q] = h.d;
-        }
-        if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
-        a.out = (L1Rec *)ctx->ws_l1.p;
-        // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
-        const size_t desc_bytes = nq * sizeof(ChunkDesc);
-        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 4 * sizeof(uint64_t) + sizeof(uint32_t));
-        if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
-        ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
-        ChunkState *d_in = (ChunkState *)(d_desc + nq);
-        ChunkState *d_out = d_in + nq;
-        uint64_t *d_info = (uint64_t *)(d_out + nq);
-        uint32_t *d_stat = (uint32_t *)(d_info + 4 * nq);
-        uint8_t *h_img = (uint8_t *)ctx->imail;
-        memcpy(h_img, descs.data(), desc_bytes);
-        Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
-        if (!zero_ranges.empty()) {
-            if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
-            PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-            launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
-        }
-        PGR_HIP(ctx, hipMemcpyAsync(d_desc, h_img, desc_bytes, hipMemcpyHostToDevice, st));
-        PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
-        // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
-        if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
-        isl_lap("chunks listed, buffers ready", round);
-        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
-        PGR_HIP(ctx, hipMemcpyAsync(h_img + desc_bytes, d_in, down_bytes, hipMemcpyDeviceToHost, st));
-        isl_lap("chunk kernel enqueued", round);
-        PGR_HIP(ctx, hipStreamSynchronize(st));
-        isl_lap("states back on the host", round);
-        const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
-        const uint64_t *r_info = (const uint64_t *)(r_out + nq);
-        const uint32_t *r_stat = (const uint32_t *)(r_info + 4 * nq);
-        PGR_HIP(ctx, hipGetLastError());
-        zero_ranges.clear();
-        s_in.resize(ch.size());
-        s_out.resize(ch.size());
-        status.resize(ch.size());
-        for (size_t q = 0; q < nq; ++q) {
-            s_in[todo[q]] = r_in[q];
-            s_out[todo[q]] = r_out[q];
-            status[todo[q]] = r_stat[q];
-            ch[todo[q]].n_push = r_info[4 * q];
-            ch[todo[q]].bmin = r_info[4 * q + 1];
-            ch[todo[q]].n_out = r_info[4 * q + 3];
-            ch[todo[q]].dropped = false;
-        }
-        if (ctx->opt.debug) {
-            uint32_t worst = 0;
-            size_t wq = 0;
-            uint64_t steps = 0;
-            uint64_t worst_t = 0;
-            for (size_t q = 0; q < nq; ++q) {
-                steps += r_stat[q] >> 8;
-                if ((r_info[4 * q + 2] & 0xFFFFFFFFull) > (worst_t & 0xFFFFFFFFull)) {
-                    worst_t = r_info[4 * q + 2];
-                    worst = r_stat[q] >> 8;
-                    wq = q;
-                }
-            }
-            fprintf(stderr, "[pgr]   slowest chunk: %.1f us (%.1f us before its first step), warm %u override %u drain_end %llu\n",
-                    (worst_t & 0xFFFFFFFFull) / 100.0, (worst_t >> 32) / 100.0, descs[wq].warm,
-                    descs[wq].override_state, (unsigned long long)descs[wq].drain_end);
-            fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu; %llu steps of 64 positions, "
-                    "the longest chunk %u (chunk [%llu, %llu) of contig %u%s)\n", round, nq, islands.size(),
-                    (unsigned long long)next_region, (unsigned long long)steps, worst, (unsigned long long)descs[wq].cs,
-                    (unsigned long long)descs[wq].ce, descs[wq].contig, descs[wq].seg == 0xFFFFFFFFu ? ", a probe" : "");
-        }
-        // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last).  A chunk is FINAL once the state
-        // it started from is known to be the true one: the island's first chunk (regular by construction), a chunk whose
-        // recorded state at cs equals the true state its final predecessor left at ce (the warm-up was right, or the state was
-        // installed), and a chunk without a push in [cs, ce) behind a final predecessor -- the machine does not move there
-        // (shmmrutils.rs:477-480: a skipped position touches neither ring nor mdist), so its end state is its predecessor's
-        // with the k-mer rolled on, and its (empty) output is right whatever state it ran with.  Only a chunk with a final
-        // predecessor is corrected, with that predecessor's true state and ring: a correction never builds on a stale state.
-        std::vector<size_t> next;
-        std::vector<size_t> rebuild;  // islands to rebuild (grown or turned into one whole-contig chunk)
-        const bool relay = !ctx->opt.no_island_relay;
-        for (size_t i = 0; i < ch.size(); ++i) {
-            HChunk &h = ch[i];
-            if (h.retired) continue;
-            Island &is = islands[h.island];
-            if (status[i] & 2u) {  // the true state could not be installed: the contig as one chunk
-                if (!is.whole) {
-                    is.whole = true;
-                    is.B = 0;
-                    is.E = b->h_len[is.contig];
-                    rebuild.push_back(h.island);
-                }
-                continue;
-            }
-            bool again = false;
-            if (status[i] & 1u) {  // region overflow
-                h.full_cap = true;
-                again = true;
-            }
-            const bool has_prev = i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island;
-            auto grow = [&]() {
-                // the machine is not back in its regular regime at E: grow the island
-                const uint64_t L = b->h_len[is.contig];
-                is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
-                if (L - is.E < 2ull * tc) is.E = L;
-                rebuild.push_back(h.island);
-            };
-            if (!relay) {  // the round-3 scheme (A/B): every seam against whatever the chunk in front produced last
-                if (h.probe) {
-                    if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) grow();
-                } else if (!is.whole && h.d.cs > is.B && has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
-                    h.d.override_state = 1;
-                    h.d.in_state = s_out[i - 1];
-                    h.d.ring_in = (uint32_t)(i - 1);
-                    h.d.warm = 1024;
-                    again = true;
-                }
-                if (again) next.push_back(i);
-                continue;
-            }
-            if (h.probe) {
-                if (!has_prev) h.final = true;
-                else if (ch[i - 1].final && !h.final) {
-                    if (memcmp(&s_in[i], &ch[i - 1].t_out, sizeof(ChunkState)) != 0) {
-                        if (ctx->opt.debug) {
-                            const ChunkState &p = s_in[i], &q = ch[i - 1].t_out;
-                            fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
-                                    "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
-                                    (unsigned long long)p.min_x, (unsigned long long)q.min_x, (unsigned long long)p.min_y,
-                                    (unsigned long long)q.min_y, (unsigned long long)p.mdist, (unsigned long long)q.mdist,
-                                    (unsigned long long)p.F0, (unsigned long long)q.F0, (unsigned long long)p.R0,
-                                    (unsigned long long)q.R0, (unsigned long long)p.ring_sig, (unsigned long long)q.ring_sig);
-                        }
-                        grow();
-                    } else {
-                        h.final = true;
-                    }
-                }
-            } else if (is.whole || !has_prev || h.d.cs <= is.B) {  // the island's first chunk
-                h.final = true;
-                h.t_out = s_out[i];
-                h.ring_src = (uint32_t)i;
-            } else if (ch[i - 1].final) {
-                const HChunk &pv = ch[i - 1];
-                const ChunkState &t = pv.t_out;
-                const bool kmer_ok = s_in[i].F0 == t.F0 && s_in[i].F1 == t.F1 && s_in[i].R0 == t.R0 && s_in[i].R1 == t.R1;
-                if ((status[i] & 4u) && kmer_ok) {  // no push in [cs, ce): the state passes through
-                    h.final = true;
-                    h.t_out = t;
-                    h.t_out.F0 = s_out[i].F0;
-                    h.t_out.F1 = s_out[i].F1;
-                    h.t_out.R0 = s_out[i].R0;
-                    h.t_out.R1 = s_out[i].R1;
-                    h.ring_src = pv.ring_src;
-                } else if (memcmp(&s_in[i], &t, sizeof(ChunkState)) == 0) {
-                    h.final = true;
-                    h.t_out = s_out[i];
-                    h.ring_src = (uint32_t)i;
-                } else if (kmer_ok && !a.sketch && t.mdist > (uint64_t)(a.w - 1) && h.n_push >= a.w && h.bmin > t.min_x &&
-                           h.d.drain_end <= h.d.ce && !(status[i] & 1u)) {
-                    // The machine arrives STUCK: mdist is beyond w - 1 (a rescan measured the distance to a minimum from in
-                    // front of a stretch of skipped pushes, shmmrutils.rs:505-514), so no rescan can fire, and no push of this
-                    // chunk reaches down to min_mer (branch 2, :516-520) -- nothing is emitted, min_mer stays, mdist counts the
-                    // pushes, and with >= w pushes the ring at ce holds this chunk's own last w pushes: exactly what its run
-                    // from a warmed-up state left there.  Its output of that run is dropped.
-                    h.final = true;
-                    h.t_out = s_out[i];
-                    h.t_out.min_x = t.min_x;
-                    h.t_out.min_y = t.min_y;
-                    h.t_out.mdist = t.mdist + h.n_push;
-                    h.ring_src = (uint32_t)i;
-                    h.dropped = true;
-                } else {
-                    if (ctx->opt.debug)
-                        fprintf(stderr, "[pgr]   chunk %zu [%llu, %llu) of contig %u runs again from the true state: mdist %llu (warm-up %llu), "
-                                "min_x %llx (%llx), %llu pushes, smallest branch-2 x %llx\n", i, (unsigned long long)h.d.cs,
-                                (unsigned long long)h.d.ce, is.contig, (unsigned long long)t.mdist, (unsigned long long)s_in[i].mdist,
-                                (unsigned long long)t.min_x, (unsigned long long)s_in[i].min_x, (unsigned long long)h.n_push,
-                                (unsigned long long)h.bmin);
-                    h.final = false;
-                    h.d.override_state = 1;
-                    h.d.in_state = t;
-                    h.d.ring_in = pv.ring_src;  // the ring the last chunk with a push left at its end
-                    h.d.warm = 1024;
-                    again = true;
-                }
-            }  // else: the chunk in front is not settled yet
-            if (again) next.push_back(i);
-        }
-        if (!rebuild.empty()) {
-            std::sort(rebuild.begin(), rebuild.end());
-            rebuild.erase(std::unique(rebuild.begin(), rebuild.end()), rebuild.end());
-            for (auto &h : ch)
-                if (std::binary_search(rebuild.begin(), rebuild.end(), h.island)) h.retired = true;
-            next.erase(std::remove_if(next.begin(), next.end(), [&](size_t i) { return ch[i].retired; }), next.end());
-            todo.swap(next);
-            for (size_t ii : rebuild) {
-                // merge with later islands of the same contig that the grown island now touches
-                for (size_t jj = 0; jj < islands.size(); ++jj)
-                    if (jj != ii && islands[jj].contig == islands[ii].contig && islands[jj].B < islands[ii].E + tc &&
-                        islands[jj].B >= islands[ii].B && islands[jj].E > islands[ii].B && !islands[jj].whole &&
-                        islands[jj].E != 0) {
-                        islands[ii].E = std::max(islands[ii].E, islands[jj].E);
-                        islands[ii].pal = islands[ii].pal || islands[jj].pal;
-                        for (auto &h : ch)
-                            if (h.island == jj) h.retired = true;
-                        islands[jj].E = islands[jj].B = 0;  // absorbed
-                    }
-                todo.erase(std::remove_if(todo.begin(), todo.end(), [&](size_t i) { return ch[i].retired; }), todo.end());
-                if ((rc = build(ii))) return rc;
-            }
-        } else {
-            todo.swap(next);
-        }
-    }
-    if (!zero_ranges.empty()) {  // (segment ranges of islands built in the last round: none in practice)
-        Tmp_list d_zr(ctx);
-        if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
-        PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
-        PGR_HIP(ctx, hipStreamSynchronize(st));
-    }
-    isl_lap("seams verified", -1);
-    // ---- the lists of the chunks that start in one tile become that tile's segment: copied back to back into a fresh region
-    // (the chunks of an island are contiguous in `ch`, in position order; their counts came back with the states)
-    {
-        std::vector<uint64_t> img;  // copies (3 words each), then segment entries (3 words each)
-        std::vector<uint64_t> segs;
-        uint32_t cur_seg = 0xFFFFFFFFu;
-        for (const HChunk &h : ch) {
-            if (h.retired || h.probe || h.d.seg == 0xFFFFFFFFu) continue;
-            if (h.d.seg != cur_seg) {
-                cur_seg = h.d.seg;
-                segs.push_back((uint64_t)cur_seg | ((uint64_t)h.d.contig << 32));
-                segs.push_back(next_region);
-                segs.push_back(0);
-            }
-            if (h.dropped || h.n_out == 0) continue;
-            img.push_back(h.d.region_off);
-            img.push_back(next_region);
-            img.push_back(h.n_out);
-            segs[segs.size() - 1] += h.n_out;
-            next_region += h.n_out;
-        }
-        const size_t n_copies = img.size() / 3, n_set = segs.size() / 3;
-        if (n_set) {
-            for (size_t i = 0; i < n_set; ++i)
-                if (segs[3 * i + 2] > 0xFFFFFFFFull) return ctx->fail(PGR_ERR_INTERNAL, "a tile's exact list exceeds 2^32 elements");
-            img.insert(img.end(), segs.begin(), segs.end());
-            const size_t bytes = img.size() * sizeof(uint64_t);
-            if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st)) || (rc = ctx->ws_serial.ensure(ctx, bytes)) ||
-                (rc = ctx->ensure_imail(bytes)))
-                return rc;
-            a.out = (L1Rec *)ctx->ws_l1.p;
-            memcpy(ctx->imail, img.data(), bytes);  // (pinned, and untouched until this context's next island call: no wait here)
-            PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_serial.p, ctx->imail, bytes, hipMemcpyHostToDevice, st));
-            launch_assemble_chunks(st, a, (const uint64_t *)ctx->ws_serial.p, (uint32_t)n_copies,
-                                   (const uint64_t *)ctx->ws_serial.p + 3 * n_copies, (uint32_t)n_set);
-        }
-    }
-    isl_lap("tile lists assembled (enqueued)", -1);
-    return PGR_OK;
-}
-
-static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
+int pgr::check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
     if (!spec) return ctx->fail(PGR_ERR_INVALID_ARG, "null spec");
     // shmmrutils.rs:443-445 / :575-576
     if (spec->k == 0 || spec->k > 56) return ctx->fail(PGR_ERR_BAD_SPEC, "spec.k must be in 1..56");
@@ -949,724 +578,6 @@ static int check_spec(pgr_ctx *ctx, const pgr_spec *spec) {
     return PGR_OK;
 }
 
-// One pass of the hot path over a resident batch of SHORT contigs (query batches, reads, fragmented assemblies): the
-// one-workgroup-per-contig kernel of csrc/small.hip replaces tiles + tails + segment scans + the fused list kernel -- 4 launches
-// and one synchronization instead of ~15 dependent operations.  handled == false: not eligible, or a contig was handed back
-// (non-ACGT byte, palindromic k-mer, low-complexity list): the caller runs the general pipeline.
-static int shmmrs_compute_small(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *rids, pgr_shmmrs **out,
-                                bool &handled) {
-    handled = false;
-    const uint32_t n = b->n;
-    // Small batches only: the kernel trades throughput for latency (a workgroup walks its contig serially: tiles, then the tail
-    // on one wavefront, then the list stage between barriers).  Measured on 10 kbp contigs: 0.045 ms + 58 ns per contig against
-    // 0.13 ms + 34 ns per contig for the general pipeline -- the lines cross near 3500 contigs (35 Mbp).
-    if (n == 0 || n > SMALL_MAX_CONTIGS || b->total_bases > SMALL_MAX_BASES || spec->sketch || spec->w < (uint32_t)L1_MIN_W ||
-        b->host_saw_invalid || ctx->opt.no_small_path)
-        return PGR_OK;
-    if (ctx->skip_small_once) {  // shmmr_batch_small has just run this kernel on these contigs and was handed them back
-        ctx->skip_small_once = false;
-        return PGR_OK;
-    }
-    uint32_t max_len = 0;
-    uint64_t total_slots = 0;
-    for (uint32_t c = 0; c < n; ++c) {
-        if (b->h_len[c] > SMALL_MAX_LEN) return PGR_OK;
-        max_len = std::max(max_len, b->h_len[c]);
-        total_slots += b->h_len[c] / 32 + 64;
-    }
-    if (total_slots >= (1ull << 32)) return PGR_OK;
-    hipStream_t st = ctx->stream;
-    std::vector<SmallContig> &desc = ctx->keep_small_desc;  // source of an async H2D copy: lives in the context
-    desc.resize(n);
-    uint64_t s_off = 0;
-    for (uint32_t c = 0; c < n; ++c) {
-        desc[c].word_off = b->h_word_off[c];
-        desc[c].len = b->h_len[c];
-        desc[c].rid = rids ? rids[c] : c;
-        desc[c].out_off = (uint32_t)s_off;
-        desc[c].out_cap = b->h_len[c] / 32 + 64;
-        s_off += desc[c].out_cap;
-    }
-    constexpr size_t N_STATUS = 10;  // (same result layout as the general path: status words in front of the offsets)
-    int rc;
-    if ((rc = ctx->ws_small_desc.ensure(ctx, (size_t)n * sizeof(SmallContig))) ||
-        (rc = ctx->ws_small_cnt.ensure(ctx, 2 * ((size_t)n + 1) * sizeof(uint32_t))) ||
-        (rc = ctx->ws_list_a.ensure(ctx, (size_t)total_slots * sizeof(pgr_mm128))) ||
-        (rc = ctx->ws_scan_tmp.ensure(ctx, scan_counts_temp_bytes(n + 1))) ||
-        (rc = ctx->ensure_mailbox(((size_t)n + 2) * sizeof(uint64_t))))
-        return rc;
-    uint32_t *d_counts = (uint32_t *)ctx->ws_small_cnt.p, *d_clean = d_counts + (n + 1);
-    pgr_shmmrs *res = new pgr_shmmrs();
-    res->ctx = ctx;
-    res->n = n;
-    auto bail = [&](int code) {
-        pgr_shmmrs_destroy(res);
-        return code;
-    };
-    if ((rc = ctx->dmalloc((void **)&res->d_block, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
-    res->d_off = res->d_block + N_STATUS;
-    const double dens = 2.0 / (double)(spec->w + 1);
-    const double spec_key = (double)spec->w * 1e9 + spec->k * 1e6 + spec->r * 1e4 + spec->min_span;
-    const double ratio = (ctx->est_spec_key == spec_key && ctx->est_final_ratio > 0) ? ctx->est_final_ratio * 1.15 : dens / 3.0 + 1e-4;
-    uint64_t cap_res = std::max<uint64_t>((uint64_t)((double)b->total_bases * ratio) + 64ull * n + 1024, 16);
-    uint64_t *mbox = (uint64_t *)ctx->mailbox;
-    hipError_t e = hipEventRecord(ctx->ev[0], st);
-    if (e == hipSuccess) e = hipMemcpyAsync(ctx->ws_small_desc.p, desc.data(), (size_t)n * sizeof(SmallContig), hipMemcpyHostToDevice, st);
-    if (e == hipSuccess) e = hipMemsetAsync(d_counts + n, 0, sizeof(uint32_t), st);  // the fallback flag word
-    if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string("small path set-up: ") + hipGetErrorString(e)));
-    SmallArgs a;
-    a.planes = b->d.planes;
-    a.valid = b->d.valid;
-    a.l1_cap = small_l1_cap(max_len, spec->w);
-    a.desc = (const SmallContig *)ctx->ws_small_desc.p;
-    a.n = n;
-    a.w = spec->w;
-    a.k = spec->k;
-    a.r = spec->r;
-    a.min_span = spec->min_span;
-    a.tc = ((L1_EXT - 2 * (spec->w - 1)) / 64) * 64;
-    a.out = (pgr_mm128 *)ctx->ws_list_a.p;
-    a.counts = d_counts;
-    a.flags = d_counts + n;
-    launch_small_shmmr(st, a);
-    launch_small_counts(st, d_counts, n, d_clean);
-    if (scan_counts(st, ctx->ws_scan_tmp.p, scan_counts_temp_bytes(n + 1), d_clean, res->d_off, n + 1) != hipSuccess)
-        return bail(ctx->fail(PGR_ERR_DEVICE, "scan failed"));
-    for (int attempt = 0;; ++attempt) {
-        ctx->dfree(res->d_mm);
-        res->d_mm = nullptr;
-        if ((rc = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return bail(rc);
-        launch_small_gather(st, (const pgr_mm128 *)ctx->ws_list_a.p, a.desc, d_counts, res->d_off, n, res->d_mm, cap_res);
-        e = hipEventRecord(ctx->ev_end, st);
-        // (a consumer that does not wait for the host -- the query path -- enqueues its kernels here, see pgr_shmmrs_compute)
-        if (e == hipSuccess && ctx->post_enqueue && (rc = ctx->post_enqueue(res->d_mm, res->d_off, cap_res, res->d_off + n)))
-            return bail(rc);
-        if (e == hipSuccess) e = hipMemcpyAsync(mbox, res->d_off, ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipMemcpyAsync(mbox + n + 1, d_counts + n, sizeof(uint32_t), hipMemcpyDeviceToHost, st);
-        if (e == hipSuccess) e = hipStreamSynchronize(st);
-        if (e == hipSuccess) e = hipGetLastError();
-        if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string("small path: ") + hipGetErrorString(e)));
-        if ((uint32_t)mbox[n + 1]) {  // a contig needs the general pipeline
-            pgr_shmmrs_destroy(res);
-            return PGR_OK;
-        }
-        if (mbox[n] <= cap_res || attempt > 0) break;
-        cap_res = mbox[n] + 16;  // more survivors than estimated: gather again into a bigger buffer
-    }
-    res->h_off.assign(mbox, mbox + n + 1);
-    res->count = mbox[n];
-    res->rid_is_index = rids == nullptr;
-    ctx->staged_unsynced = false;
-    ctx->want_host_copy = false;
-    if (b->total_bases) {
-        ctx->est_spec_key = spec_key;
-        ctx->est_final_ratio = (double)res->count / (double)b->total_bases;
-    }
-    pgr_prof prof;
-    memset(&prof, 0, sizeof(prof));
-    (void)hipEventElapsedTime(&prof.total_ms, ctx->ev[0], ctx->ev_end);
-    prof.level1_ms = prof.total_ms;  // (one kernel does levels 1 and 2)
-    prof.bases_tiled = b->total_bases;
-    prof.n_tiles = n;
-    ctx->prof = prof;
-    *out = res;
-    handled = true;
-    return PGR_OK;
-}
-
-// One pass of the hot path over a resident batch.  Everything is enqueued on the context's stream with sizes that are
-// upper bounds or estimates; the host reads the true counts ONCE at the end (one hipStreamSynchronize per call in the
-// common case) and repeats a stage only when an estimate turned out too small:
-//   stage 1  level-1 tiles + tails (+ exact islands when a tile flagged a palindromic k-mer / non-ACGT byte)
-//   stage 2  scan of the segment counts (the level-1 total stays on the device)
-//   stage 3  fused reduce x2 + min_span (grid = upper bound, surplus workgroups exit on the device-side total)
-//   stage 4  scan of the block counts, ordered gather into the result, per-contig offsets, rid patch
-// Batches of >= 64 Mbp synchronize once more after stage 1 (a 30 us round trip is nothing there and a flagged batch
-// does not run stages 2-4 twice); smaller ones (the reference's real callers: <= 129 contigs per call, seq_db.rs:561, and
-// single queries, ext.rs:252) run optimistically and redo stages 2-4 after the islands in the rare flagged case.
-extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *rids,
-                                  int padding, pgr_shmmrs **out) {
-    if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!b || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    *out = nullptr;
-    const bool dbg_t = ctx->opt.debug_times != 0;  // host-side timeline of the call on stderr
-    const auto dbg_t0 = std::chrono::steady_clock::now();
-    auto dbg_lap = [&](const char *what) {
-        if (dbg_t)
-            fprintf(stderr, "[pgr] shmmrs_compute %-28s at %7.1f us\n", what,
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - dbg_t0).count());
-    };
-    int rc = check_spec(ctx, spec);
-    if (rc) return rc;
-    if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
-    if (!(padding && !spec->sketch && spec->r > 1)) {  // batches of short contigs: one workgroup per contig, 4 launches
-        bool handled = false;
-        if ((rc = shmmrs_compute_small(ctx, b, spec, rids, out, handled)) || handled) return rc;
-    }
-    hipStream_t st = ctx->stream;
-    const uint32_t n = b->n;
-    const bool sketch = spec->sketch != 0;
-    const bool tiled = sketch || spec->w >= (uint32_t)L1_MIN_W;
-    const uint32_t w_eff = sketch ? 1u : spec->w;
-    // tile core: extended tile minus both halos, rounded down to the 64-position step of the exact kernel so
-    // that islands of exact tiles start and end on step boundaries
-    // (batches of short contigs -- reads --: tiles of one wavefront's 1024 positions, pgr_internal.h)
-    const bool short_tiles = tiled && n && b->total_bases / n <= (uint64_t)L1_SHORT_MEAN_LEN && w_eff <= (uint32_t)L1_SHORT_MAX_W &&
-                             !ctx->opt.no_short_tiles;
-    const uint32_t ext = short_tiles ? (uint32_t)L1_EXT_SHORT : (uint32_t)L1_EXT;
-    const uint32_t tc = ((ext - 2 * (w_eff - 1)) / 64) * 64;
-
-    // ---- host plan: tiles for the closed form, list for the serial kernel.  (The table lives in the context: a million reads
-    // are 4 MB that a fresh vector would fault in page by page on every call; big batches fill it on the pool's threads.)
-    std::vector<uint32_t> &tile_first = ctx->h_tile_first;
-    tile_first.resize((size_t)n + 1);
-    std::vector<uint32_t> serial;
-    uint64_t n_tiles64 = 0, bases_tiled = 0;
-    if (tiled && n >= (1u << 17)) {
-        constexpr uint32_t PIECE = 1u << 14;
-        const uint32_t n_pieces = (n + PIECE - 1) / PIECE;
-        std::vector<uint64_t> piece_tiles((size_t)n_pieces + 1, 0);
-        HostPool::instance().parallel_for(n_pieces, [&](size_t p) {
-            const uint32_t c0 = (uint32_t)p * PIECE, c1 = std::min<uint32_t>(n, c0 + PIECE);
-            uint64_t t = 0;
-            for (uint32_t c = c0; c < c1; ++c) t += l1_tiles_of(b->h_len[c], tc, ext);
-            piece_tiles[p + 1] = t;
-        });
-        for (uint32_t p = 0; p < n_pieces; ++p) piece_tiles[p + 1] += piece_tiles[p];
-        n_tiles64 = piece_tiles[n_pieces];
-        bases_tiled = b->total_bases;
-        if (n_tiles64 + n + 1 < (1ull << 31))
-            HostPool::instance().parallel_for(n_pieces, [&](size_t p) {
-                const uint32_t c0 = (uint32_t)p * PIECE, c1 = std::min<uint32_t>(n, c0 + PIECE);
-                uint64_t t = piece_tiles[p];
-                for (uint32_t c = c0; c < c1; ++c) {
-                    tile_first[c] = (uint32_t)t;
-                    t += l1_tiles_of(b->h_len[c], tc, ext);
-                }
-            });
-    } else {
-        for (uint32_t c = 0; c < n; ++c) {
-            tile_first[c] = (uint32_t)n_tiles64;
-            const uint64_t L = b->h_len[c];
-            if (L == 0) continue;
-            n_tiles64 += l1_tiles_of(L, tc, ext);  // every contig owns tile segments (the chunk kernel reuses them)
-            if (tiled) bases_tiled += L;  // contigs with non-ACGT bytes too: only islands around them are replaced
-            else serial.push_back(c);     // w < 17: the whole contig goes through the exact kernel
-        }
-    }
-    if (n_tiles64 + n + 1 >= (1ull << 31)) return ctx->fail(PGR_ERR_INVALID_ARG, "batch too large (tile count)");
-    tile_first[n] = (uint32_t)n_tiles64;
-    const uint32_t n_tiles = (uint32_t)n_tiles64;
-    const uint32_t n_segs = n_tiles + n;
-
-    // level-1 buffer: one fixed slot per tile (2x the expected count: density 2/(w+1), sketch 2^-(4+r)) and
-    // a cursor-allocated overflow region for dense tiles and the per-contig tails
-    const double dens = sketch ? 1.0 / (double)(1ull << (4 + spec->r)) : 2.0 / (double)(spec->w + 1);
-    const uint32_t slot = std::min<uint32_t>(tc, (((uint32_t)((double)tc * dens * 2.0) + 64 + 63) / 64) * 64);
-    const uint64_t slots_total = (uint64_t)n_tiles * slot;
-    uint64_t cap_par = (uint64_t)((double)bases_tiled * dens * 0.02) + 65536 + 32ull * n;  // (a contig's tail has its own slot)
-    // low-complexity / N-rich input overflows the fixed tile slots by far more than that: remember what the last call with
-    // this spec needed per base (a genome comes as many similar batches) instead of running stage 1 twice every time
-    const double l1_key = (double)spec->w * 1e3 + spec->k + (sketch ? 0.5 : 0.0);
-    if (ctx->est_l1_key == l1_key && ctx->est_ovf_ratio > 0)
-        cap_par = std::max<uint64_t>(cap_par, (uint64_t)((double)bases_tiled * ctx->est_ovf_ratio * 1.1) + 65536 + 32ull * n);
-
-    constexpr size_t N_CURSOR = 8;  // [0..2] level 1 (L1Args::cursor), [4..5] fused list stage
-    constexpr size_t N_STATUS = 10;
-    if ((rc = ctx->ws_tile_first.ensure(ctx, ((size_t)n + 1) * sizeof(uint32_t))) ||
-        (rc = ctx->ws_seg_off.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_tile_desc.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(TileDesc))) ||
-        (rc = ctx->ws_seg_cnt.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
-        (rc = ctx->ws_seg_cid.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint32_t))) ||
-        (rc = ctx->ws_seg_dst.ensure(ctx, ((size_t)n_segs + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_tile_lv.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(uint64_t))) ||
-        // one block that a single memset clears per call: cursors | contig flags | tile flags  (+ the status words)
-        (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
-                                             std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
-        (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ws_off_b.ensure(ctx, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t))))
-        return rc;
-    unsigned long long *d_cursor = (unsigned long long *)ctx->ws_cursor.p;
-    uint32_t *d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
-    uint8_t *d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
-    const size_t zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
-    uint64_t *mbox = (uint64_t *)ctx->mailbox;  // pinned: [0, N_STATUS) status, then the n+1 result offsets
-    // (through the pinned mailbox -- free until this call's results come back into it, and the stream orders the two: a copy
-    // from pageable memory is staged by the runtime, ~15 us during which nothing else is enqueued)
-    memcpy(mbox, tile_first.data(), ((size_t)n + 1) * sizeof(uint32_t));
-    PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, mbox, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    dbg_lap("plan + tile table uploaded");
-    uint32_t *d_rids = nullptr;
-    if (rids && n) {
-        if ((rc = ctx->ws_rids.ensure(ctx, (size_t)n * sizeof(uint32_t)))) return rc;
-        PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rids.p, rids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        d_rids = (uint32_t *)ctx->ws_rids.p;
-    }
-
-    L1Args a;
-    a.b = b->d;
-    a.n_contigs = n;
-    a.n_tiles = n_tiles;
-    a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
-    a.desc = (TileDesc *)ctx->ws_tile_desc.p;
-    a.tile_flags = d_tflags;
-    a.tile_lv = nullptr;  // set once mark_invalid_tiles has filled it and run_islands has made it cumulative
-    a.w = w_eff;
-    a.k = spec->k;
-    a.r = spec->r;
-    a.tc = tc;
-    a.ext = ext;
-    a.sketch = sketch ? 1u : 0u;
-    a.cursor = d_cursor;
-    a.seg_off = (uint64_t *)ctx->ws_seg_off.p;
-    a.seg_cnt = (uint32_t *)ctx->ws_seg_cnt.p;
-    a.seg_cid = (uint32_t *)ctx->ws_seg_cid.p;
-    a.contig_flags = d_cflags;
-
-    pgr_prof prof;
-    memset(&prof, 0, sizeof(prof));
-    prof.n_tiles = n_tiles;
-    prof.bases_tiled = bases_tiled;
-    // big batches look at the level-1 status words once before the list stage is enqueued (one more round trip, ~45 us):
-    // if a tile asked for the exact path the islands are fixed first and the list stage runs once.  Smaller batches run
-    // optimistically and repeat stages 2-4 in the (rare) flagged case: cheaper than the round trip below ~1 Gbp.
-    const uint64_t early_bp = (uint64_t)std::max<int64_t>(0, ctx->opt.early_sync_bp);
-    // (a batch the host packer has counted non-ACGT bytes in is known to need islands: look at the flags before the list stage)
-    const bool early_sync = b->total_bases >= early_bp || !serial.empty() || b->host_saw_invalid;
-    const bool pad_fix = padding && !sketch && spec->r > 1;
-    const bool do_reduce = !sketch && spec->r > 1;
-    const uint32_t halo = do_reduce ? 2 * spec->r * spec->r : 1;
-    const uint32_t slot2 = do_reduce ? 256u : FUSED_BLOCK_ELEMS;
-    uint64_t serial_base = 0;  // first element of the serial regions inside the level-1 buffer
-    bool islands_done = false;
-    bool l2_cursor_clean = false;  // the list stage's cursor words were cleared by stage 1's memset
-
-    // islands of exact tiles from the flags: flags[c] bit 0 = a tile of contig c saw a palindromic k-mer, n_invalid[c] = its non-ACGT
-    // bytes, tf[tile] = tile flags (bit 0 palindromic k-mer, bit 1 non-ACGT byte in reach, bit 2 nothing but such bytes; bit 3 is set here)
-    auto list_islands = [&](const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, std::vector<Island> &islands,
-                            std::vector<uint32_t> &gap_segs) {
-        for (uint32_t c = 0; c < n; ++c) {
-            if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
-            const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
-            const uint64_t L = b->h_len[c];
-            // The inside of a long run of non-ACGT bytes (the gaps of a reference chromosome: up to 30 Mbp) needs no
-            // machine at all.  Every position there pushes the same stale k-mer (shmmrutils.rs:461-476), so the level-1
-            // list holds one element per position, all with one x -- ties keep them through both reductions
-            // (:359-415) and the min_span stencil drops every one of them for having a neighbour with its x (:545-550).
-            // What an element further than 2 r^2 list places from both ends of such a run contributes to the rest of
-            // the list is nothing: tiles whose whole extended range is invalid AND whose two neighbours on either side
-            // are too (>= 7 kbp of the run kept at each end) are left out -- their segments stay empty, the islands on
-            // both sides end inside the run, where a warmed-up machine is exact.  (Round 3 pushed 40.9 Mbp of such
-            // positions of a chromosome-like contig through the chunk kernel and the list stage: half of its 2.4 ms.)
-            for (uint32_t t = 0, run = 0; t < nt; ++t) {  // tile t - 2 is deep when tiles t - 4 .. t are all inside a gap
-                run = (tf[t0 + t] & 4) ? run + 1 : 0;
-                if (run >= 5) tf[t0 + t - 2] |= 8;  // (bit 3: host only)
-            }
-            for (uint32_t t = 0; t < nt; ++t)
-                if (tf[t0 + t] & 8) {
-                    uint32_t e = t;
-                    while (e + 1 < nt && (tf[t0 + e + 1] & 8)) ++e;
-                    gap_segs.push_back(t0 + c + t);      // segment index of tile t of contig c
-                    gap_segs.push_back(t0 + c + e + 1);
-                    for (uint32_t q = t; q <= e; ++q) tf[t0 + q] = 0;  // not flagged: no island over them
-                    t = e;
-                }
-            uint32_t n_flag = 0;
-            for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
-            if (n_flag == 0) continue;
-            if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
-            if (3ull * n_flag > nt) {  // mostly irregular: one island
-                bool pal = false;
-                for (uint32_t t = 0; t < nt; ++t) pal = pal || (tf[t0 + t] & 1);
-                islands.push_back(Island{c, 0, L, false, pal});
-                continue;
-            }
-            for (uint32_t t = 0; t < nt;) {
-                if (!tf[t0 + t]) {
-                    ++t;
-                    continue;
-                }
-                // (no tile in front of the first flagged one: tile t - 1 is clean, so nothing irregular lies within its reach -- which
-                // ends w - 1 + 64 positions INTO tile t --, and the machine that starts 256 positions in front of tile t is regular
-                // at its first step by construction; behind tiles deep inside a gap it starts inside the run, where a warmed-up
-                // machine is exact)
-                uint32_t ta = t, tb = t;
-                while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
-                bool any_pal = false;
-                for (uint32_t q = ta; q <= tb; ++q) any_pal = any_pal || (tf[t0 + q] & 1);
-                // a clean neighbour on the right for the machine to find back into its regular regime -- behind skipped pushes
-                // (palindromic k-mers) it may arrive stuck; behind a non-ACGT byte it cannot: the byte lies >= w + k + 64
-                // positions in front of the first clean tile (or that tile would be flagged), every position pushes, and the
-                // ring holds only pushes from behind the byte when the island ends.  The probe at the island's end checks it.
-                if (tb + 1 < nt && any_pal) ++tb;
-                Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
-                is.pal = any_pal;
-                if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
-                if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
-                    islands.back().E = std::max(islands.back().E, is.E);
-                    islands.back().pal = islands.back().pal || is.pal;
-                } else {
-                    islands.push_back(is);
-                }
-                t = tb + 1;
-            }
-        }
-    };
-    // Islands around non-ACGT bytes, listed while the tile kernel runs: a batch the host packer has counted such bytes in gets the
-    // tile flags (all but the palindrome bit, which the tile kernel sets) on the host as soon as mark_invalid_tiles has run -- the
-    // copy, the listing (and the cumulative last-valid table) used to sit between the tile kernel and the chunk kernel, 0.15 ms
-    // of a chromosome-like contig's 1.2.  Used when the tile kernel reports no palindromic k-mer; otherwise listed again.
-    std::vector<Island> pre_islands;
-    std::vector<uint32_t> pre_gap_segs;
-    bool pre_listed = false;
-    // ---- stage 1
-    auto stage1 = [&]() -> int {
-        uint64_t serial_total = 0;
-        for (uint32_t c : serial) serial_total += (uint64_t)b->h_len[c] / 4 + 4096;
-        int r;
-        if ((r = ctx->ws_l1.ensure(ctx, (slots_total + cap_par + serial_total + (uint64_t)n * L1_TAIL_SLOT + 1) * sizeof(L1Rec)))) return r;
-        a.out = (L1Rec *)ctx->ws_l1.p;
-        a.slot = slot;
-        a.ovf_base = slots_total;
-        a.cap = cap_par;
-        a.tail_base = slots_total + cap_par;  // the contigs' tail slots sit between the overflow region and the exact regions
-        serial_base = a.tail_base + (uint64_t)n * L1_TAIL_SLOT;  // (run_exact_islands grows the buffer behind this point)
-        // cursors (both stages), contig flags, tile flags: cleared by the tile descriptor kernel when there are tiles
-        if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));
-        if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
-        l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
-        if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
-        pre_listed = false;
-        if (tiled && bases_tiled) {
-            launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p);
-            const bool pre = b->host_saw_invalid && !b->h_n_invalid.empty() && n_tiles && !ctx->opt.no_pre_islands;
-            if (pre) {
-                const size_t tb = scan_max_temp_bytes(n_tiles);
-                if ((r = ctx->ws_scan_tmp.ensure(ctx, tb)) || (r = ctx->ensure_imail(n_tiles))) return r;
-                PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
-                PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[0], st));
-                PGR_HIP(ctx, hipStreamWaitEvent(ctx->pre_stream, ctx->pre_ev[0], 0));
-                PGR_HIP(ctx, hipMemcpyAsync(ctx->imail, d_tflags, n_tiles, hipMemcpyDeviceToHost, ctx->pre_stream));
-                PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[1], ctx->pre_stream));
-            }
-            PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));  // (prof.level1_ms is the tile kernel alone: descriptors and flags are in front of it)
-            launch_level1_tiles(st, a);
-            if (pre) {
-                PGR_HIP(ctx, hipEventSynchronize(ctx->pre_ev[1]));
-                std::vector<uint32_t> no_flags(n, 0u);
-                pre_islands.clear();
-                pre_gap_segs.clear();
-                list_islands(no_flags.data(), b->h_n_invalid.data(), (uint8_t *)ctx->imail, pre_islands, pre_gap_segs);
-                pre_listed = true;
-                dbg_lap("islands around non-ACGT bytes listed");
-            }
-        }
-        PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
-        if (!(tiled && bases_tiled)) launch_level1_tails(st, a);  // (otherwise every contig's last tile has run its tail)
-        islands_done = false;
-        return PGR_OK;
-    };
-    // ---- islands of exact tiles: around palindromic k-mers (skipped pushes, flagged by the tile kernel) and
-    // non-ACGT bytes (flagged by mark_invalid_tiles); whole contigs when the spec has no tile path.  Synchronizes.
-    auto run_islands = [&](uint64_t need_word) -> int {
-        dbg_lap("islands: level-1 flags seen");
-        std::vector<Island> islands;
-        std::vector<uint32_t> gap_segs;  // [first, last + 1) segment ranges of tiles deep inside runs of non-ACGT bytes: emptied
-        for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false, true});
-        const bool use_pre = pre_listed && !(need_word & 1ull) && serial.empty();  // (no tile saw a palindromic k-mer)
-        if (use_pre) {
-            islands = pre_islands;
-            gap_segs = pre_gap_segs;
-        } else if (tiled && bases_tiled && need_word) {
-            std::vector<uint32_t> flags(n), n_invalid(n);
-            std::vector<uint8_t> tf(n_tiles);
-            if (n) {
-                PGR_HIP(ctx, hipMemcpyAsync(flags.data(), d_cflags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-                PGR_HIP(ctx, hipMemcpyAsync(n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            }
-            PGR_HIP(ctx, hipMemcpyAsync(tf.data(), d_tflags, n_tiles, hipMemcpyDeviceToHost, st));
-            PGR_HIP(ctx, hipStreamSynchronize(st));
-            dbg_lap("islands: tile flags on the host");
-            list_islands(flags.data(), n_invalid.data(), tf.data(), islands, gap_segs);
-        }
-        {
-            std::vector<uint32_t> cs;
-            for (const auto &is : islands) cs.push_back(is.contig);
-            std::sort(cs.begin(), cs.end());
-            prof.n_serial_contigs = std::unique(cs.begin(), cs.end()) - cs.begin();
-        }
-        if (!islands.empty()) {
-            L1Args as = a;
-            as.w = sketch ? 1u : spec->w;  // the exact machine follows the spec literally (sketch ignores w)
-            if (tiled && bases_tiled && n_tiles && !use_pre) {  // (use_pre: done in front of the tile kernel)
-                // per-tile "last valid position" (written by mark_invalid_tiles) -> cumulative: the chunks' k-mer look-back
-                // and forward roll cross a run of N of any length in one step
-                const size_t tb = scan_max_temp_bytes(n_tiles);
-                int r2;
-                if ((r2 = ctx->ws_scan_tmp.ensure(ctx, tb))) return r2;
-                PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
-            }
-            if (tiled && bases_tiled && n_tiles) as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
-            dbg_lap("islands: listed");
-            int r = run_exact_islands(ctx, b, as, islands, tile_first, tc, serial_base, gap_segs);
-            if (r) return r;
-            dbg_lap("islands: exact");
-            a.out = as.out;
-            prof.exact_bases = 0;
-            for (const auto &is : islands) prof.exact_bases += is.E - is.B;  // final extents (islands may have grown)
-        }
-        islands_done = true;
-        return PGR_OK;
-    };
-
-    // ---- stages 2-4.  n_blocks: grid of the fused kernel; cap2: its overflow region; cap_res: result capacity
-    pgr_shmmrs *res = new pgr_shmmrs();
-    res->ctx = ctx;
-    res->n = n;
-    // (the offsets of a million reads are 8 MB: the block of a destroyed result of this context is used again)
-    if ((size_t)n + 1 >= (1u << 17) && ctx->spare_off.capacity() >= (size_t)n + 1) res->h_off.swap(ctx->spare_off);
-    res->h_off.resize((size_t)n + 1);
-    auto bail = [&](int code) {
-        pgr_shmmrs_destroy(res);
-        return code;
-    };
-// a failing HIP call behind this point must release `res` (and its device blocks) on its way out
-#define PGR_HIP_BAIL(expr)                                                                                        \
-    do {                                                                                                          \
-        hipError_t _e = (expr);                                                                                   \
-        if (_e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(_e))); \
-    } while (0)
-    // the pipeline's status words sit right in front of the result offsets: ONE copy brings both to the mailbox
-    if ((rc = ctx->dmalloc((void **)&res->d_block, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t)))) return bail(rc);
-    res->d_off = res->d_block + N_STATUS;
-    // estimates: level-1 count from the density (low-complexity sequence exceeds it: retried with the true count),
-    // final count from this context's last result with the same spec (first call: a third of the level-1 estimate)
-    const uint64_t l1_bound = slots_total + cap_par + b->total_bases / 4 + 4096ull * n + 4096;  // what stage 1 can emit at all
-    // (per contig: the first window and the tail emit a few elements on top of the density -- NOT thousands: 2048 per contig made
-    // the list stage of 10^6 reads a grid of 2 x 10^6 workgroups for 25 x 10^3 of work, 0.6 of its 0.8 ms, and 8 GB of slots)
-    const uint64_t l1_est = std::min<uint64_t>(l1_bound, (uint64_t)((double)b->total_bases * dens * 1.06) + 16ull * n + 8192);
-    uint32_t n_blocks = (uint32_t)((l1_est + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
-    uint64_t cap2 = (uint64_t)((double)l1_est * 0.01) + 65536;
-    const double spec_key = (double)spec->w * 1e9 + spec->k * 1e6 + spec->r * 1e4 + spec->min_span + (sketch ? 0.5 : 0.0) + (padding ? 0.25 : 0.0);
-    const double ratio = (ctx->est_spec_key == spec_key && ctx->est_final_ratio > 0) ? ctx->est_final_ratio * 1.15 : dens / 3.0 + 1e-4;
-    uint64_t cap_res = std::max<uint64_t>((uint64_t)((double)b->total_bases * ratio) + 64ull * n + 1024, 16);
-    pgr_mm128 *d_list = nullptr;  // ordered final list (before the padding artefact)
-    uint64_t *d_loff = nullptr;
-    uint64_t *d_total1 = (uint64_t *)ctx->ws_seg_dst.p + n_segs;
-    std::vector<uint64_t> l1_off;  // only needed for the padding artefact
-    auto stage2 = [&]() -> int {
-        const size_t tb = scan_counts_temp_bytes(n_segs + 1);
-        int r;
-        if ((r = ctx->ws_scan_tmp.ensure(ctx, tb))) return r;
-        PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb, (const uint32_t *)ctx->ws_seg_cnt.p,
-                                 (uint64_t *)ctx->ws_seg_dst.p, n_segs + 1));
-        if (pad_fix)
-            launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
-                                  (uint64_t *)ctx->ws_off_a.p);
-        return PGR_OK;
-    };
-    auto stage3 = [&]() -> int {
-        int r;
-        if ((r = ctx->ws_blk_cnt.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))) ||
-            (r = ctx->ws_blk_base.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
-            (r = ctx->ws_blk_off.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint64_t))) ||
-            (r = ctx->ws_start_rank.ensure(ctx, ((size_t)n_blocks + 1) * sizeof(uint32_t))))
-            return r;
-        // fixed output slot per fused workgroup (expected survivors: ~12 % after two reductions + min_span), plus
-        // a cursor-allocated overflow region
-        const uint64_t slots2 = (uint64_t)n_blocks * slot2;
-        if ((r = ctx->ws_list_a.ensure(ctx, (slots2 + cap2 + 1) * sizeof(pgr_mm128)))) return r;
-        if (!l2_cursor_clean) PGR_HIP(ctx, hipMemsetAsync(d_cursor + 4, 0, 2 * sizeof(unsigned long long), st));
-        l2_cursor_clean = false;  // (a repeat of this stage alone clears it again)
-        if (n_blocks == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_blk_cnt.p, 0, sizeof(uint32_t), st));
-        FusedArgsPub fa;
-        fa.l1 = (const L1Rec *)ctx->ws_l1.p;
-        fa.seg_cid = (const uint32_t *)ctx->ws_seg_cid.p;
-        fa.k = spec->k;
-        fa.seg_off = (const uint64_t *)ctx->ws_seg_off.p;
-        fa.seg_cnt = (const uint32_t *)ctx->ws_seg_cnt.p;
-        fa.seg_dst = (const uint64_t *)ctx->ws_seg_dst.p;
-        fa.n_segs = n_segs;
-        fa.total = d_total1;
-        fa.r = spec->r;
-        fa.padding = padding ? 1u : 0u;
-        fa.min_span = spec->min_span;
-        fa.do_reduce = do_reduce ? 1u : 0u;
-        fa.halo = halo;
-        fa.out = (pgr_mm128 *)ctx->ws_list_a.p;
-        fa.slot = slot2;
-        fa.ovf_base = slots2;
-        fa.cap = cap2;
-        fa.cursor = d_cursor + 4;
-        fa.blk_off = (uint64_t *)ctx->ws_blk_off.p;
-        fa.blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
-        fa.blk_first_seg = (uint32_t *)ctx->ws_start_rank.p;
-        launch_fused_select_pub(st, fa, n_blocks);
-        return PGR_OK;
-    };
-    bool scanned4 = false;
-    uint64_t host_copy_elems = 0;
-    auto stage4 = [&]() -> int {
-        int r;
-        if (!scanned4) {  // (a repeat of stage 4 alone only re-gathers into a bigger result buffer)
-            const size_t tb2 = scan_counts_temp_bytes(n_blocks + 1);
-            if ((r = ctx->ws_scan_tmp.ensure(ctx, tb2))) return r;
-            PGR_HIP(ctx, scan_counts(st, ctx->ws_scan_tmp.p, tb2, (const uint32_t *)ctx->ws_blk_cnt.p,
-                                     (uint64_t *)ctx->ws_blk_base.p, n_blocks + 1));
-            scanned4 = true;
-        }
-        const uint64_t *d_nfinal = (const uint64_t *)ctx->ws_blk_base.p + n_blocks;
-        if (!pad_fix) {  // common case: gather straight into the result buffer
-            ctx->dfree(res->d_mm);
-            res->d_mm = nullptr;
-            if ((r = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return r;
-            d_list = res->d_mm;
-            d_loff = res->d_off;
-        } else {
-            if ((r = ctx->ws_list_b.ensure(ctx, cap_res * sizeof(pgr_mm128)))) return r;
-            d_list = (pgr_mm128 *)ctx->ws_list_b.p;
-            d_loff = (uint64_t *)ctx->ws_off_b.p + N_STATUS;
-        }
-        launch_gather_segments(st, (const pgr_mm128 *)ctx->ws_list_a.p, (const uint64_t *)ctx->ws_blk_off.p,
-                               (const uint32_t *)ctx->ws_blk_cnt.p, (const uint64_t *)ctx->ws_blk_base.p, n_blocks, d_list,
-                               cap_res);
-        launch_offsets_by_rid(st, d_list, d_nfinal, cap_res, n, d_loff, d_cursor, d_total1, d_loff - N_STATUS);  // + status words
-        if (d_rids) launch_patch_rid(st, d_list, d_nfinal, cap_res, d_rids, n);
-        PGR_HIP(ctx, hipEventRecord(ctx->ev_end, st));
-        // a consumer of the result that does not want to wait for the host (the query path: pair records, lookup, chaining)
-        // enqueues its kernels here, behind stage 4 and in front of the one synchronization; a repeated pass calls it again.
-        // (In front of the copies to the host as well: a DMA between two kernels costs ~20 us of bubbles.)
-        if (ctx->post_enqueue && !pad_fix && (r = ctx->post_enqueue(d_list, d_loff, cap_res, d_nfinal))) return r;
-        PGR_HIP(ctx, hipMemcpyAsync(mbox, d_loff - N_STATUS, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-        // a small result that the caller wants on the host anyway (pgr_shmmr_batch) rides along with this round trip
-        host_copy_elems = 0;
-        if (ctx->want_host_copy && !pad_fix && cap_res * sizeof(pgr_mm128) <= (256u << 10) &&
-            ctx->ensure_pinned_out(256u << 10) == PGR_OK) {
-            PGR_HIP(ctx, hipMemcpyAsync(ctx->pinned_out, d_list, cap_res * sizeof(pgr_mm128), hipMemcpyDeviceToHost, st));
-            host_copy_elems = cap_res;
-        }
-        return PGR_OK;
-    };
-
-    PGR_HIP_BAIL(hipEventRecord(ctx->ev[0], st));
-    int from = 1;  // first stage to (re)run
-    uint64_t n_final = 0;
-    uint64_t l1_alloc_seen = 0;  // elements the level-1 kernels took from the overflow region
-    for (int attempt = 0;; ++attempt) {
-        if (attempt > 8) return bail(ctx->fail(PGR_ERR_INTERNAL, "shimmer pipeline: buffers kept overflowing"));
-        if (from <= 1) {
-            if ((rc = stage1())) return bail(rc);
-            if (early_sync) {
-                PGR_HIP_BAIL(hipMemcpyAsync(mbox, d_cursor, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
-                if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
-                    return bail(ctx->fail(PGR_ERR_DEVICE, "level-1 kernels failed on the device"));
-                l1_alloc_seen = mbox[0];
-                if (mbox[1] || mbox[0] > cap_par) {  // cursor region too small: grow and redo
-                    cap_par = (uint64_t)((double)mbox[0] * 1.1) + 65536;
-                    continue;
-                }
-                if ((mbox[2] || !serial.empty()) && (rc = run_islands(mbox[2]))) return bail(rc);
-                islands_done = true;
-            }
-            PGR_HIP_BAIL(hipEventRecord(ctx->ev[3], st));
-        }
-        if (from <= 2 && (rc = stage2())) return bail(rc);
-        if (from <= 3) {
-            scanned4 = false;
-            if ((rc = stage3())) return bail(rc);
-        }
-        if ((rc = stage4())) return bail(rc);
-        if (pad_fix) {
-            l1_off.resize((size_t)n + 1);
-            PGR_HIP_BAIL(hipMemcpyAsync(l1_off.data(), ctx->ws_off_a.p, ((size_t)n + 1) * sizeof(uint64_t),
-                                        hipMemcpyDeviceToHost, st));
-        }
-        dbg_lap("all stages enqueued");
-        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
-            return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
-        dbg_lap("synchronized");
-        // ---- the one look at the device-side counts
-        const uint64_t l1_alloc = mbox[0], l1_ovf = mbox[1], need_islands = mbox[2], l2_alloc = mbox[4], l2_ovf = mbox[5];
-        const uint64_t total1 = mbox[8];
-        n_final = mbox[9];
-        l1_alloc_seen = l1_alloc;
-        if (l1_ovf || l1_alloc > cap_par) {  // (only possible without the early synchronization)
-            cap_par = (uint64_t)((double)l1_alloc * 1.1) + 65536;
-            from = 1;
-            continue;
-        }
-        if (!islands_done && (need_islands || !serial.empty())) {
-            if ((rc = run_islands(need_islands))) return bail(rc);
-            PGR_HIP_BAIL(hipEventRecord(ctx->ev[3], st));
-            from = 2;
-            continue;
-        }
-        prof.n_level1 = total1;
-        if (total1 > (uint64_t)n_blocks * FUSED_BLOCK_ELEMS) {  // denser than the estimate: the grid missed the tail
-            n_blocks = (uint32_t)((total1 + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
-            cap2 = std::max<uint64_t>(cap2, (uint64_t)((double)total1 * 0.01) + 65536);
-            from = 3;
-            continue;
-        }
-        if (l2_ovf || l2_alloc > cap2) {
-            cap2 = (uint64_t)((double)l2_alloc * 1.05) + 65536;
-            from = 3;
-            continue;
-        }
-        if (n_final > cap_res) {  // more survivors than estimated: bigger result buffer, gather again
-            cap_res = n_final + 16;
-            from = 4;
-            continue;
-        }
-        break;
-    }
-    memcpy(res->h_off.data(), mbox + N_STATUS, ((size_t)n + 1) * sizeof(uint64_t));
-    res->count = n_final;
-    if (host_copy_elems >= n_final && host_copy_elems) res->host_copy = (const pgr_mm128 *)ctx->pinned_out;
-    ctx->want_host_copy = false;
-    res->rid_is_index = (d_rids == nullptr) && !pad_fix;
-    if (b->total_bases) {
-        ctx->est_spec_key = spec_key;
-        ctx->est_final_ratio = (double)n_final / (double)b->total_bases;
-    }
-    if (bases_tiled) {
-        ctx->est_l1_key = l1_key;
-        ctx->est_ovf_ratio = (double)l1_alloc_seen / (double)bases_tiled;
-    }
-    if (pad_fix) {
-        // reference artefact: reduce_shmmr on an EMPTY list with padding emits its sentinels
-        // (shmmrutils.rs:367-380), which survive as exactly two {MAX,MAX} after the second pass + filter
-        std::vector<uint64_t> final_off((size_t)n + 1);
-        uint64_t add = 0;
-        for (uint32_t c = 0; c < n; ++c) {
-            final_off[c] = res->h_off[c] + add;
-            if (l1_off[c + 1] == l1_off[c]) add += 2;
-        }
-        final_off[n] = res->h_off[n] + add;
-        res->count = final_off[n];
-        if ((rc = ctx->dmalloc((void **)&res->d_mm, std::max<uint64_t>(res->count, 1) * sizeof(pgr_mm128)))) return bail(rc);
-        if (hipMemcpyAsync(res->d_off, final_off.data(), ((size_t)n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice,
-                           st) != hipSuccess)
-            return bail(ctx->fail(PGR_ERR_DEVICE, "H2D of the result offsets failed"));
-        launch_copy_or_sentinel(st, d_list, d_loff, res->d_off, n, res->d_mm);
-        res->h_off = final_off;
-        if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
-            return bail(ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device"));
-    }
-#undef PGR_HIP_BAIL
-    hipEvent_t ev_end = ctx->ev_end;  // recorded at the end of stage 4, complete since the synchronization above
-    ctx->staged_unsynced = false;
-    (void)hipEventElapsedTime(&prof.level1_ms, ctx->ev[1], ctx->ev[2]);
-    (void)hipEventElapsedTime(&prof.level1_aux_ms, ctx->ev[2], ctx->ev[3]);
-    (void)hipEventElapsedTime(&prof.level2_ms, ctx->ev[3], ev_end);
-    (void)hipEventElapsedTime(&prof.total_ms, ctx->ev[0], ev_end);
-    ctx->prof = prof;
-    *out = res;
-    dbg_lap("done");
-    return PGR_OK;
-}
 
 extern "C" uint64_t pgr_shmmrs_count(const pgr_shmmrs *s) { return s ? s->count : 0; }
 extern "C" const pgr_mm128 *pgr_shmmrs_device_ptr(const pgr_shmmrs *s) { return s ? s->d_mm : nullptr; }

@@ -331,6 +331,28 @@ extern "C" void pgr_index_destroy(pgr_index *ix) {
 extern "C" uint64_t pgr_index_n_keys(const pgr_index *ix) { return ix ? ix->n_keys : 0; }
 extern "C" uint64_t pgr_index_n_records(const pgr_index *ix) { return ix ? (ix->finalized ? ix->n : ix->n_raw) : 0; }
 
+extern "C" int pgr_index_reserve(pgr_ctx *ctx, pgr_index *ix, uint64_t n_records) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
+    if (n_records <= ix->cap_raw) return PGR_OK;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    pgr_frag_rec *np = nullptr;
+    int rc = ctx->dmalloc((void **)&np, n_records * sizeof(pgr_frag_rec));  // (exactly what was asked for: no head-room on top)
+    if (rc) return rc;
+    if (ix->n_raw) {
+        hipError_t e = hipMemcpyAsync(np, ix->raw, ix->n_raw * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            ctx->dfree(np);
+            return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));
+        }
+    }
+    ctx->dfree(ix->raw);
+    ix->raw = np;
+    ix->cap_raw = n_records;
+    return PGR_OK;
+}
+
 extern "C" int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag_rec *recs, uint64_t n, int on_device) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix || (n && !recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");

@@ -141,13 +141,14 @@ __global__ __launch_bounds__(1024) void pair_offsets_kernel(const uint64_t *__re
 __global__ __launch_bounds__(256) void frag_recs_dev_kernel(const pgr_mm128 *__restrict__ mm, const uint64_t *__restrict__ off,
                                                             const uint64_t *__restrict__ rec_off, uint32_t n, uint64_t cap,
                                                             const uint64_t *__restrict__ total_ptr, int query_side,
-                                                            pgr_frag_rec *__restrict__ out, uint64_t out_cap) {
+                                                            const uint32_t *__restrict__ sids, pgr_frag_rec *__restrict__ out,
+                                                            uint64_t out_cap, const uint64_t *__restrict__ base_ptr) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t total = *total_ptr < cap ? *total_ptr : cap;
     if (i + 1 >= total) return;
     const uint32_t c = (uint32_t)(mm[i].y >> 32);  // (the rid field is the contig index: the caller did not override rids)
     if (c >= n || i < off[c] || i + 1 >= off[c + 1]) return;  // last shimmer of the contig starts no pair
-    const uint64_t o = rec_off[c] + (i - off[c]);
+    const uint64_t o = (base_ptr ? *base_ptr : 0ull) + rec_off[c] + (i - off[c]);  // (base_ptr: the cursor of the records' destination)
     if (o >= out_cap) return;
     const pgr_mm128 s0 = mm[i], s1 = mm[i + 1];
     const uint64_t h0 = s0.x >> 8, h1 = s1.x >> 8;
@@ -156,7 +157,7 @@ __global__ __launch_bounds__(256) void frag_recs_dev_kernel(const pgr_mm128 *__r
     r.h0 = keep ? h0 : h1;
     r.h1 = keep ? h1 : h0;
     r.frg_id = (uint32_t)(i - off[c]);
-    r.sid = c;
+    r.sid = sids ? sids[c] : c;
     r.bgn = (uint32_t)((s0.y & 0xFFFFFFFFull) >> 1) + 1;
     r.end = (uint32_t)((s1.y & 0xFFFFFFFFull) >> 1) + 1;
     r.orient = keep ? 0u : 1u;
@@ -166,11 +167,25 @@ __global__ __launch_bounds__(256) void frag_recs_dev_kernel(const pgr_mm128 *__r
 
 void launch_frag_recs_dev(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t cap,
                           const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap,
-                          uint32_t *clear3) {
-    hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), 0, st, off, n_contigs, rec_off, clear3);
+                          uint32_t *clear3, const uint32_t *sids, const uint64_t *base_ptr, uint32_t lds_match) {
+    uint32_t pad = 0;
+    hipFuncAttributes at;
+    if (lds_match && hipFuncGetAttributes(&at, (const void *)pair_offsets_kernel) == hipSuccess && at.sharedSizeBytes < lds_match)
+        pad = lds_match - (uint32_t)at.sharedSizeBytes;
+    hipLaunchKernelGGL(pair_offsets_kernel, dim3(1), dim3(1024), pad, st, off, n_contigs, rec_off, clear3);
     if (cap < 2) return;
     hipLaunchKernelGGL(frag_recs_dev_kernel, dim3((uint32_t)((cap + 255) / 256)), dim3(256), 0, st, mm, off, rec_off, n_contigs, cap,
-                       total_ptr, query_side, out, out_cap);
+                       total_ptr, query_side, sids, out, out_cap, base_ptr);
+}
+
+// cursor += *count; the value before goes to *before (a consumer that places its output behind its predecessor's without the host)
+__global__ void cursor_bump_kernel(uint64_t *cursor, const uint64_t *count, uint64_t *before) {
+    const uint64_t c = *cursor;
+    *before = c;
+    *cursor = c + *count;
+}
+void launch_cursor_bump(hipStream_t st, uint64_t *cursor, const uint64_t *count, uint64_t *before) {
+    hipLaunchKernelGGL(cursor_bump_kernel, dim3(1), dim3(1), 0, st, cursor, count, before);
 }
 
 }  // namespace pgr
@@ -780,10 +795,18 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
     if (n_blocks == 0) return;
     hipLaunchKernelGGL(block_first_seg_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, a.seg_dst, a.n_segs,
                        n_blocks, a.halo, a.blk_first_seg, a.blk_cnt);
+    // (dynamic LDS on top of the static block: the workgroup then occupies exactly a.lds_match bytes of its CU)
+    auto pad_for = [&](const void *f) -> uint32_t {
+        hipFuncAttributes at;
+        if (!a.lds_match || hipFuncGetAttributes(&at, f) != hipSuccess || at.sharedSizeBytes >= a.lds_match) return 0u;
+        return a.lds_match - (uint32_t)at.sharedSizeBytes;
+    };
     if (a.halo <= 32)
-        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL>), dim3(n_blocks), dim3(FUSED_T),
+                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_SMALL>), st, a);
     else
-        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG>), dim3(n_blocks), dim3(FUSED_T),
+                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_BIG>), st, a);
 }
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
                            uint64_t *off, const unsigned long long *cursor, const uint64_t *total1, uint64_t *status) {

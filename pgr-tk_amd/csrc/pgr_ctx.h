@@ -1,9 +1,11 @@
 // pgr_ctx.h -- the context object behind the C ABI: one GPU, one stream, grow-only workspaces and a
 // small caching device allocator (so the steady state of repeated calls does no hipMalloc/hipFree).
 #pragma once
+#include <algorithm>
 #include <functional>
 #include <map>
 #include <string>
+#include <vector>
 
 #include "pgr_internal.h"
 #include "pgr_host.h"
@@ -16,6 +18,22 @@ struct DevBuf {
     int ensure(pgr_ctx *ctx, size_t bytes);                        // contents NOT preserved
     int ensure_keep(pgr_ctx *ctx, size_t bytes, hipStream_t st);   // contents preserved
     void release(pgr_ctx *ctx);
+};
+// Everything one pass of the shimmer pipeline keeps between its stages: the workspaces, the pinned mailbox its counts come
+// back into, the events that time it, the host-side tables that are sources of asynchronous copies.  The context holds ONE
+// such set in its own members (every synchronous call uses it); a pgr_pipe (csrc/pipeline.hip) owns two more and swaps the
+// one of the job it is working on into the context's members for the duration of that work (pgr_ctx::swap_lane), so that
+// two passes can be in flight -- the list stage of batch i on the back stream beside the tiles of batch i + 1.
+struct Lane {
+    DevBuf ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial, ws_scan_tmp, ws_list_a,
+        ws_list_b, ws_off_a, ws_off_b, ws_blk_cnt, ws_blk_base, ws_start_rank, ws_rids, ws_rec_off, ws_blk_off, ws_tile_desc,
+        ws_tile_flags, ws_seg_cid, ws_tile_lv, ws_recs;
+    void *mailbox = nullptr;
+    size_t mailbox_cap = 0;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_end = nullptr;
+    std::vector<uint32_t> h_tile_first;
+    std::vector<uint64_t> keep_rec_off;
 };
 }  // namespace pgr
 
@@ -58,6 +76,9 @@ struct pgr_ctx {
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B
+        int64_t lds_match = 0;           // pgr_pipe: 1 = the back stream's kernels occupy the tile kernel's LDS size or none (padded list kernel, LDS-free scans), for A/B
+        int64_t pipe_staged_records = 0; // pgr_pipe: never place an index job's records through the device cursor (always stage + copy), for A/B
+        int64_t back_priority = 0;       // pgr_pipe: priority of the back stream (list stages): 1 = the device's highest, 0 = the default, -1 = the lowest
     } opt;
     std::vector<uint32_t> h_tile_first;  // pgr_shmmrs_compute: first tile of every contig (host copy, kept between calls)
     std::vector<uint64_t> spare_off;     // offsets block of the last destroyed big result (used again by the next one)
@@ -83,12 +104,43 @@ struct pgr_ctx {
     // workspaces
     pgr::DevBuf ws_ascii, ws_tile_first, ws_seg_off, ws_seg_cnt, ws_seg_dst, ws_cursor, ws_flags, ws_l1, ws_serial,
         ws_scan_tmp, ws_list_a, ws_list_b, ws_off_a, ws_off_b, ws_blk_cnt, ws_blk_base, ws_start_rank, ws_rids,
-        ws_rec_off, ws_blk_off, ws_tile_desc, ws_tile_flags, ws_seg_cid, ws_tile_lv, ws_small_desc, ws_small_cnt;
+        ws_rec_off, ws_blk_off, ws_tile_desc, ws_tile_flags, ws_seg_cid, ws_tile_lv, ws_small_desc, ws_small_cnt,
+        ws_recs;  // (ws_recs: pair records of a pipelined job on their way into an index)
 
-    // caching allocator for result buffers: size -> free blocks
-    std::multimap<size_t, void *> free_blocks;
-    std::map<void *, size_t> live_blocks;
+    // caching allocator for result buffers: size -> free blocks.
+    // One stream: a freed block may still be in use by work that is queued on the context's stream, and whoever takes it next
+    // queues behind that work on the same stream -- no waiting, no events.  With a pgr_pipe the back stream runs beside the
+    // context's stream (`multi_stream`): a block that is freed then remembers where both streams stood at that moment (an
+    // event each; the back stream's only for blocks that were handed out for it, so that the context's stream never waits for
+    // a list stage it has nothing to do with) and whoever takes it for the OTHER stream makes that stream wait for the event --
+    // event-ordered frees.
+    struct FreeBlock {
+        void *p = nullptr;
+        hipEvent_t ev_front = nullptr, ev_back = nullptr;  // recorded on stream / back_stream when the block was freed
+        bool on_back = false;  // last used for work on the back stream: handed to the back stream's requests first, and to the
+                               // context's stream only when nothing else fits (it would wait for a list stage: a bubble)
+    };
+    struct LiveBlock {
+        size_t bytes = 0;
+        bool on_back = false;  // handed out for work on the back stream (or marked: block_on_back): a free records that stream too
+    };
+    std::multimap<size_t, FreeBlock> free_blocks;
+    std::map<void *, LiveBlock> live_blocks;
     size_t cached_bytes = 0;
+    size_t live_bytes = 0, peak_bytes = 0;  // bytes handed out + cached (what the allocator holds of the device), its high-water mark
+    bool multi_stream = false;
+    int n_pipes = 0;
+    bool back_shares_queue = false;  // no candidate for the back stream ran beside the context's stream (ctx.hip: enable_multi_stream)
+    std::vector<pgr::Lane *> spare_lanes;  // lanes of destroyed pipes (their workspaces stay allocated for the next pipe)
+    hipStream_t back_stream = nullptr;   // list stages of a pgr_pipe (created with the first pipe; higher priority than `stream`)
+    hipStream_t alloc_stream = nullptr;  // the stream the NEXT dmalloc's block will be used on (nullptr: `stream`)
+    std::vector<hipEvent_t> ev_pool;
+    hipEvent_t take_event();
+    void wait_and_recycle(FreeBlock &fb, hipStream_t user);
+    void drop_events(FreeBlock &fb);
+    void block_on_back(void *p);  // a block of the context's stream that the back stream works on as well (an index's records)
+    int enable_multi_stream();  // creates back_stream; synchronizes once so that earlier frees need no events
+    void swap_lane(pgr::Lane &l);
 
     int fail(int code, const std::string &msg) {
         err = msg;
@@ -126,6 +178,8 @@ struct StageSrc {
     const uint32_t *valid = nullptr;
     uint64_t word0 = 0;
 };
+// shmmrutils.rs:443-445 / :575-576: the reference's assert!s as an error code
+int check_spec(pgr_ctx *ctx, const pgr_spec *spec);
 // pair records of a resident result into d_out (capacity >= pgr_shmmrs_n_pairs), stream ordered: returns without waiting
 int shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_t *sids, int query_side,
                                 pgr_frag_rec *d_out, uint64_t capacity);
@@ -133,6 +187,7 @@ int shmmrs_to_frag_recs_enqueue(pgr_ctx *ctx, const pgr_shmmrs *s, const uint32_
 bool worth_pipelining(const pgr_ctx *ctx, uint32_t n, const uint64_t *lens);
 int for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
                     const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume);
+void lane_release(pgr_ctx *ctx, Lane &l);  // frees a lane's workspaces, mailbox and events (pipeline.hip)
 // pinned host blocks a kernel writes a result into (ctx.hip): acquire returns nullptr when the host cannot pin more memory;
 // result_block_release takes any result block of the library -- pinned ones go back to the pool, the others to free()
 void *pinned_result_acquire(size_t min_bytes, size_t *cap);

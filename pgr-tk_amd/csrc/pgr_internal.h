@@ -161,6 +161,8 @@ struct L1Args {
 void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv);  // tile descriptors, flags of tiles with a non-ACGT byte in reach (tile_lv: [n_tiles] last valid positions)
 void launch_level1_tiles(hipStream_t st, const L1Args &a);                    // the tiles (and the contigs' tails), behind launch_level1_pre
 void launch_level1_tails(hipStream_t st, const L1Args &a);
+constexpr uint32_t LDS_GRANULE = 512;  // gfx950 hands out LDS in 512-byte units
+uint32_t level1_tile_lds_bytes(const L1Args &a);  // LDS a workgroup of the tile kernel for `a` occupies (0: unknown)
 // exact state machine, one wavefront per chunk; status bit0 = region overflow, bit1 = override impossible
 void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info);
@@ -185,7 +187,11 @@ void launch_frag_recs(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, 
 // garbage-tolerant (every index checked).  rid field = contig index.
 void launch_frag_recs_dev(hipStream_t st, const pgr_mm128 *mm, const uint64_t *off, uint32_t n_contigs, uint64_t cap,
                           const uint64_t *total_ptr, int query_side, uint64_t *rec_off, pgr_frag_rec *out, uint64_t out_cap,
-                          uint32_t *clear3 = nullptr);  // clear3: three 32-bit words zeroed on the way (the consumer's flags)
+                          uint32_t *clear3 = nullptr,   // clear3: three 32-bit words zeroed on the way (the consumer's flags)
+                          const uint32_t *sids = nullptr,   // sids[n_contigs] (device): the records' sequence ids; NULL: the contig index
+                          const uint64_t *base_ptr = nullptr,  // device: first record goes to out[*base_ptr] (NULL: out[0])
+                          uint32_t lds_match = 0);  // > 0: LDS per workgroup of the kernels that use any (see FusedArgsPub)
+void launch_cursor_bump(hipStream_t st, uint64_t *cursor, const uint64_t *count, uint64_t *before);  // *before = *cursor; *cursor += *count
 
 void launch_contig_offsets(hipStream_t st, const uint64_t *seg_dst, const uint32_t *tile_first, uint32_t n,
                            uint32_t n_segs, uint64_t *off);
@@ -213,6 +219,7 @@ struct FusedArgsPub {
     uint64_t *blk_off;
     uint32_t *blk_cnt;
     uint32_t *blk_first_seg;  // [n_blocks] scratch
+    uint32_t lds_match = 0;   // > 0: every workgroup occupies exactly this much LDS (the tile kernel's, when the two run side by side)
 };
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);
 // n_ptr: device, number of elements (clamped to cap)
@@ -235,6 +242,10 @@ void launch_copy_map_rid(hipStream_t st, const pgr_mm128 *in, uint64_t n, const 
 size_t scan_counts_temp_bytes(uint32_t n_plus_1);
 hipError_t scan_counts(hipStream_t st, void *temp, size_t temp_bytes, const uint32_t *in, uint64_t *out,
                        uint32_t n_plus_1);
+// the same without LDS (wave scans, partial sums through `temp`): for a stream that runs beside the tile kernel (level1.hip:
+// level1_tile_lds_bytes says why).  temp: scan_counts_nolds_temp_bytes(n_plus_1)
+size_t scan_counts_nolds_temp_bytes(uint32_t n_plus_1);
+hipError_t scan_counts_nolds(hipStream_t st, void *temp, size_t temp_bytes, const uint32_t *in, uint64_t *out, uint32_t n_plus_1);
 size_t sort_pairs_temp_bytes(uint64_t n);
 hipError_t sort_pairs(hipStream_t st, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit);

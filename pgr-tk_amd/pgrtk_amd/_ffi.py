@@ -74,6 +74,8 @@ _SIGS = [
     ("pgr_last_error", C.c_char_p, [_VP]),
     ("pgr_free", None, [_VP]),
     ("pgr_version", C.c_char_p, []),
+    ("pgr_ctx_trim", C.c_int, [_VP]),
+    ("pgr_ctx_mem_stats", C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     ("pgr_ctx_set_option", C.c_int, [_VP, C.c_char_p, C.c_int64]),
     ("pgr_ctx_get_option", C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     ("pgr_shmmr_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
@@ -122,12 +124,18 @@ _SIGS = [
     ("pgr_index_add_shmmrs", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
     ("pgr_shmmrs_to_frag_recs_device", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.c_int, _VP, C.c_uint64,
                                                  C.POINTER(C.c_uint64)]),
+    ("pgr_pipe_create", C.c_int, [_VP, C.POINTER(Spec), _PVP]),
+    ("pgr_pipe_submit", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), _VP, _VP, C.c_uint64]),
+    ("pgr_pipe_collect", C.c_int, [_VP, _PVP, C.POINTER(C.c_uint64)]),
+    ("pgr_pipe_in_flight", C.c_int, [_VP]),
+    ("pgr_pipe_destroy", None, [_VP]),
     ("pgr_ctx_last_prof", C.c_int, [_VP, C.POINTER(Prof)]),
     ("pgr_ctx_synchronize", C.c_int, [_VP]),
     ("pgr_index_create", C.c_int, [_VP, C.POINTER(Spec), _PVP]),
     ("pgr_index_destroy", None, [_VP]),
     ("pgr_index_add_batch", C.c_int, [_VP, _VP, C.c_uint32, _PVP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]),
     ("pgr_index_add_resident", C.c_int, [_VP, _VP, _VP, C.POINTER(C.c_uint32)]),
+    ("pgr_index_reserve", C.c_int, [_VP, _VP, C.c_uint64]),
     ("pgr_index_add_records", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
     ("pgr_index_finalize", C.c_int, [_VP, _VP]),
     ("pgr_index_n_keys", C.c_uint64, [_VP]),
@@ -325,6 +333,16 @@ class Context:
 
     def synchronize(self):
         self.check(lib().pgr_ctx_synchronize(self._h))
+
+    def trim(self):
+        """give the allocator's cached blocks back to the device"""
+        self.check(lib().pgr_ctx_trim(self._h))
+
+    def mem_stats(self, reset_peak=False):
+        """-> (bytes the allocator holds now, its high-water mark)"""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.check(lib().pgr_ctx_mem_stats(self._h, C.byref(a), C.byref(b), int(reset_peak)))
+        return int(a.value), int(b.value)
 
     def set_option(self, name, value=1):
         """tuning / A-B switch of this context (include/pgr_hip.h: pgr_ctx_set_option)"""

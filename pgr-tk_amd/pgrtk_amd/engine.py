@@ -196,6 +196,53 @@ class Shmmrs:
             pass
 
 
+class Pipe:
+    """pgr_pipe: a software pipeline over resident batches -- submit() enqueues a whole pass (tiles on the context's stream, list
+    stage + pair records on the back stream) and returns, collect() hands back the oldest job; two may be in flight.  The loop
+    of load_index_from_reader (seq_db.rs:541-571) with the tail of batch i beside the tiles of batch i + 1."""
+
+    def __init__(self, spec, ctx=None):
+        self.ctx = ctx or default_context()
+        self.spec = spec
+        h = C.c_void_p()
+        self.ctx.check(lib().pgr_pipe_create(self.ctx.handle, C.byref(spec), C.byref(h)))
+        self._h = h
+        self._keep = []  # batches (and indexes) of the jobs in flight, oldest first
+
+    @property
+    def in_flight(self):
+        return int(lib().pgr_pipe_in_flight(self._h))
+
+    def submit(self, batch, sids=None, index=None, rec_ptr=None, rec_capacity=0):
+        keep, sp = _u32_array(sids, batch.n)
+        self.ctx.check(lib().pgr_pipe_submit(self._h, batch._h, sp, index._h if index is not None else None,
+                                             C.c_void_p(rec_ptr) if rec_ptr else None, int(rec_capacity)))
+        self._keep.append((batch, index))
+
+    def collect(self, want_shmmrs=True):
+        """-> (Shmmrs or None, number of pair records written)"""
+        h = C.c_void_p()
+        npairs = C.c_uint64()
+        n = self._keep[0][0].n if self._keep else 0
+        rc = lib().pgr_pipe_collect(self._h, C.byref(h) if want_shmmrs else None, C.byref(npairs))
+        if self._keep:
+            self._keep.pop(0)
+        self.ctx.check(rc)
+        return (Shmmrs(self.ctx, h, n) if want_shmmrs else None), int(npairs.value)
+
+    def close(self):
+        if self._h:
+            lib().pgr_pipe_destroy(self._h)
+            self._h = C.c_void_p()
+            self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def records_checksum(device_ptr, n, ctx=None):
     """order-independent 128-bit content checksum of n pair records at a DEVICE pointer -> (a, b)"""
     ctx = ctx or default_context()
@@ -327,6 +374,9 @@ class Index:
     @property
     def device_records(self):
         return lib().pgr_index_device_records(self._h)
+
+    def reserve(self, n_records):
+        self.ctx.check(lib().pgr_index_reserve(self.ctx.handle, self._h, int(n_records)))
 
     def add_resident(self, batch, sids=None):
         keep, sp = _u32_array(sids, batch.n)

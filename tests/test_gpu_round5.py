@@ -1,0 +1,130 @@
+"""Round-5 parity tests (run with -m gpu on a MI355X): the software pipeline over resident batches (pgr_pipe_*, the loop of
+load_index_from_reader, pgr-db/src/seq_db.rs:541-571, with two batches in flight) against the synchronous calls and the CPU
+restatement."""
+import numpy as np
+import pytest
+
+import seqgen
+
+pytestmark = pytest.mark.gpu
+
+SPEC = (80, 56, 4, 64, False)
+
+
+def _same_mm(ref, got, what):
+    assert len(ref) == len(got), "%s: %d vs %d shimmers" % (what, len(ref), len(got))
+    assert np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"]), what
+
+
+def _batches(rng):
+    """batches of the kinds the pipeline has to tell apart: clean (the optimistic pass is the result), flagged (non-ACGT bytes,
+    palindromic k-mers: finished synchronously at collect), low complexity (undersized estimates), ragged and empty contigs"""
+    out = []
+    out.append([seqgen.rnd(rng, L) for L in (300_000, 120_000, 64, 0, 5_000, 250_123)])
+    out.append([seqgen.adversarial(rng, m, 40_000) for m in range(seqgen.N_MODES)])
+    out.append([seqgen.rnd(rng, 200_000) for _ in range(5)])
+    out.append([seqgen.rnd(rng, 90_000, b"AC"), seqgen.rnd(rng, 150_000), b"", seqgen.rnd(rng, 135)])
+    out.append([seqgen.rnd(rng, 50_000) + b"N" * 20_000 + seqgen.rnd(rng, 50_000), seqgen.rnd(rng, 100_000)])
+    out.append([seqgen.rnd(rng, 400_000)])
+    out.append([seqgen.rnd(rng, int(L)) for L in rng.integers(1, 3000, 300)])
+    return out
+
+
+def test_two_batches_in_flight_equal_the_synchronous_calls_and_the_oracle(oracle, gpu_ctx):
+    """every job of the pipe (shimmer lists + index-side pair records into the caller's buffer, with caller sids) is bit-identical
+    to pgr_shmmrs_compute + pgr_shmmrs_to_frag_recs_device on the same batch and to the CPU restatement; submission order =
+    collection order; a third submit and a collect on an empty pipe fail with PGR_ERR_STATE"""
+    import torch
+    import pgrtk_amd as P
+    from pgrtk_amd import exchange
+    rng = np.random.default_rng(505)
+    spec = P.make_spec(*SPEC)
+    osp = oracle.spec(*SPEC)
+    sets = _batches(rng)
+    batches = [P.Batch.from_seqs(s, ctx=gpu_ctx) for s in sets]
+    sids = [[1000 * bi + 7 * i for i in range(len(s))] for bi, s in enumerate(sets)]
+    bufs = [torch.zeros((200_000, exchange.REC_WORDS), dtype=torch.int64, device="cuda:0") for _ in range(2)]
+    pipe = P.Pipe(spec, ctx=gpu_ctx)
+    with pytest.raises(P.PgrError):
+        pipe.collect()
+    results = []
+
+    def take(bi):
+        sh, n_pairs = pipe.collect()
+        mm, off = sh.download()
+        recs = bufs[bi & 1][:n_pairs].cpu().numpy().view(P.FRAG_REC).reshape(-1).copy()
+        results.append((mm, off, recs))
+
+    for bi, b in enumerate(batches):
+        if pipe.in_flight == 2:
+            with pytest.raises(P.PgrError):
+                pipe.submit(b, sids=sids[bi], rec_ptr=bufs[bi & 1].data_ptr(), rec_capacity=bufs[0].shape[0])
+            take(bi - 2)
+        pipe.submit(b, sids=sids[bi], rec_ptr=bufs[bi & 1].data_ptr(), rec_capacity=bufs[0].shape[0])
+    while pipe.in_flight:
+        take(len(results))
+    assert len(results) == len(sets)
+    n_flagged = 0
+    for bi, (s, b) in enumerate(zip(sets, batches)):
+        mm, off, recs = results[bi]
+        sh = b.shmmrs(spec)
+        mm_s, off_s = sh.download()
+        assert np.array_equal(off, off_s) and np.array_equal(mm["x"], mm_s["x"]) and np.array_equal(mm["y"], mm_s["y"]), "batch %d" % bi
+        tmp = torch.zeros((max(sh.n_pairs, 1), exchange.REC_WORDS), dtype=torch.int64, device="cuda:0")
+        n_s = sh.frag_recs_into(tmp.data_ptr(), tmp.shape[0], sids=sids[bi])
+        recs_s = tmp[:n_s].cpu().numpy().view(P.FRAG_REC).reshape(-1)
+        assert len(recs) == n_s and recs.tobytes() == recs_s.tobytes(), "pair records of batch %d" % bi
+        n_flagged += gpu_ctx.last_prof().n_serial_contigs > 0
+        ro = 0
+        for i, q in enumerate(s):
+            ref = oracle.sequence_to_shmmrs(i, q, osp)
+            _same_mm(ref, mm[int(off[i]):int(off[i + 1])], "batch %d contig %d vs oracle" % (bi, i))
+            fr = oracle.frag_recs(ref, sids[bi][i])
+            got = recs[ro:ro + len(fr)]
+            for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+                assert np.array_equal(fr[f], got[f]), "batch %d contig %d field %s" % (bi, i, f)
+            ro += len(fr)
+        assert ro == len(recs)
+    assert n_flagged >= 2  # (the flagged batches did go through the exact machine)
+    pipe.close()
+
+
+def test_pipelined_index_build_equals_the_synchronous_build(oracle, gpu_ctx):
+    """records of pipelined jobs join the index in submission order (seq_db.rs:605-612), with the index's running sid
+    (seq_db.rs:543-553) or the caller's: the finalized CSR equals the one pgr_index_add_resident builds, and the oracle's"""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(506)
+    spec = P.make_spec(*SPEC)
+    base = seqgen.rnd(rng, 150_000)
+    sets = []
+    for bi in range(7):  # shared sequence between batches: keys with records from several batches
+        s = [base[int(o):int(o) + 60_000] + seqgen.rnd(rng, 20_000) for o in rng.integers(0, 90_000, 4)]
+        if bi == 3:
+            s[1] = s[1][:30_000] + b"N" * 500 + s[1][30_000:]
+        sets.append(s)
+    batches = [P.Batch.from_seqs(s, ctx=gpu_ctx) for s in sets]
+    for explicit in (False, True):
+        sid_of = (lambda bi, i: 4 * bi + i) if not explicit else (lambda bi, i: 100 + 10 * bi + i)
+        ix_p, ix_s = P.Index(spec, ctx=gpu_ctx), P.Index(spec, ctx=gpu_ctx)
+        pipe = P.Pipe(spec, ctx=gpu_ctx)
+        for bi, b in enumerate(batches):
+            if pipe.in_flight == 2:
+                pipe.collect(want_shmmrs=False)
+            pipe.submit(b, sids=[sid_of(bi, i) for i in range(b.n)] if explicit else None, index=ix_p)
+        while pipe.in_flight:
+            pipe.collect(want_shmmrs=False)
+        pipe.close()
+        for bi, b in enumerate(batches):
+            ix_s.add_resident(b, sids=[sid_of(bi, i) for i in range(b.n)] if explicit else None)
+        ix_p.finalize()
+        ix_s.finalize()
+        rp, rs = ix_p.download(), ix_s.download()
+        assert len(rp) == len(rs) > 500 and rp.tobytes() == rs.tobytes() and ix_p.n_keys == ix_s.n_keys
+        oix = oracle.Index(oracle.spec(*SPEC))
+        for bi, s in enumerate(sets):
+            for i, q in enumerate(s):
+                oix.add_seq(sid_of(bi, i), q)
+        oix.finalize()
+        ro = oix.records()
+        for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+            assert np.array_equal(ro[f], rp[f]), f
