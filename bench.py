@@ -617,39 +617,112 @@ def shapes_bench(P, ctx, spec, spec_t, cores, check):
     return out
 
 
-def target_100gbp(P, ctx, spec, args):
+def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=True):
     """BASELINE.json's target as a number: wall time to SHIMMER-index 100 Gbp of DISTINCT synthetic contigs (10 batches of
     1000 x 10 Mbp, contig ids 0 .. 9999) into ONE index on this GPU -- generation of the synthetic input on the device,
-    shimmers, pair records, and the sort into the frag_map included (target: under 60 s on 8 GPUs)."""
+    shimmers, pair records, and the sort into the frag_map included (target: under 60 s on 8 GPUs).
+    In a FRESH context (what a one-shot pgr-mdb run sees: pgr-mdb.rs:53-111), after the bench's own context has given its
+    cached blocks back; batches through pgr_pipe_* (two in flight), the index's append buffer reserved from the spec's density.
+    Content: every batch's shimmer lists stay on the device until the clock has stopped; >= 64 contigs sampled from ids
+    1000 .. 9999 (and 8 from 0 .. 999) are compared with the CPU restatement by their 128-bit checksums, and the index's
+    order-independent record checksum must equal the sum over the batches of the checksums of the pair records derived from
+    those lists."""
+    import numpy as np
+    import torch
     n_b, n_c, L = 10, 1000, 10_000_000
+    ctx.synchronize()
+    # (NOT ctx.trim(): device memory that a process has given back with hipFree is slow to get again -- measured here: a fresh
+    # context right after a trim of ~100 GB took 2.2 s for its first pass where a fresh process takes 0.30 s -- while memory
+    # the process has never touched comes at once (tools/probe/malloc_probe.hip: 16 GiB in 0.2 ms).  The one-shot number is
+    # therefore taken in a process of its own, below.)
+    fresh = P.Context(ctx.device)
+    M = (1 << 64) - 1
 
-    def once():
-        ctx.synchronize()
+    def once(keep):
+        fresh.synchronize()
+        fresh.mem_stats(reset_peak=True)
         t0 = time.perf_counter()
-        ix = P.Index(spec, ctx=ctx)
+        ix = P.Index(spec, ctx=fresh)
+        ix.reserve(int(n_b * n_c * L * 0.003036 * 1.01) + 4096)  # pair records per base at (80, 56, 4, 64), SURVEY 8
+        pipe = P.Pipe(spec, ctx=fresh)
+        kept = []
         for bi in range(n_b):
             ids = list(range(bi * n_c, (bi + 1) * n_c))
-            b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=ctx, contig_ids=ids)
-            ix.add_resident(b, sids=ids)
+            b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=fresh, contig_ids=ids)
+            if pipe.in_flight == 2:
+                kept.append(pipe.collect(want_shmmrs=keep))
+            pipe.submit(b, sids=ids, index=ix)
             del b
+        while pipe.in_flight:
+            kept.append(pipe.collect(want_shmmrs=keep))
         t1 = time.perf_counter()
         ix.finalize()
-        ctx.synchronize()
+        fresh.synchronize()
         t2 = time.perf_counter()
-        return t0, t1, t2, ix.n_records, ix.n_keys
-    # twice: the first run allocates what it needs where the context's cache has no block of that size (the sort of 3 x 10^8
-    # records takes ~30 GB of temporaries: hipMalloc of that is 0.4-0.6 s, a fresh process pays 1.8 s in all), the second is the
-    # steady state of a streaming build
-    t0, t1, t2, n_rec, n_keys = once()
-    r0, r1, r2, _, _ = once()
+        pipe.close()
+        return t0, t1, t2, ix, kept, fresh.mem_stats()[1]
+    t0, t1, t2, ix, _, peak0 = once(False)
+    n_rec, n_keys = ix.n_records, ix.n_keys
+    del ix
+    r0, r1, r2, ix, kept, peak1 = once(check)
     bp = n_b * n_c * L
-    return {"bp": bp, "s": t2 - t0, "Gbp_per_s": bp / (t2 - t0) / 1e9, "batches_s": t1 - t0, "sort_into_frag_map_s": t2 - t1,
-            "repeat": {"s": r2 - r0, "Gbp_per_s": bp / (r2 - r0) / 1e9, "batches_s": r1 - r0, "sort_into_frag_map_s": r2 - r1,
-                       "note": "the same again: every buffer comes from the context's cache"},
-            "index_records": n_rec, "index_keys": n_keys, "n_gpus": 1,
-            "target": "BASELINE.json: >= 100 Gbp SHIMMER-indexed in under 60 s on 8 x MI355X",
-            "what": "%d batches of %d x %d bp distinct synthetic contigs generated on the device, one index (sorted CSR) at the end" %
-                    (n_b, n_c, L)}
+    out = {"bp": bp, "s": t2 - t0, "Gbp_per_s": bp / (t2 - t0) / 1e9, "batches_s": t1 - t0, "sort_into_frag_map_s": t2 - t1,
+           "context": "fresh context inside the bench process (created for this leg, beside the bench's own)",
+           "peak_device_bytes_of_the_allocator": peak0,
+           "repeat": {"s": r2 - r0, "Gbp_per_s": bp / (r2 - r0) / 1e9, "batches_s": r1 - r0, "sort_into_frag_map_s": r2 - r1,
+                      "peak_device_bytes_of_the_allocator": peak1,
+                      "note": "the same again in that context: every buffer comes from its cache"},
+           "index_records": n_rec, "index_keys": n_keys, "n_gpus": 1,
+           "target": "BASELINE.json: >= 100 Gbp SHIMMER-indexed in under 60 s on 8 x MI355X",
+           "what": "%d batches of %d x %d bp distinct synthetic contigs generated on the device, through pgr_pipe_submit / "
+                   "pgr_pipe_collect into one index (sorted CSR at the end)" % (n_b, n_c, L)}
+    if check:
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import oracle as O
+            rng = np.random.default_rng(100)
+            sample = sorted(set(int(v) for v in rng.choice(np.arange(n_c, n_b * n_c), 64, replace=False)) |
+                            set(int(v) for v in rng.choice(n_c, 8, replace=False)))
+            cnt, ref, _ = O.synth_checksums_ids_threads(O.spec(*spec_t), sample, args.seed, L, cores)
+            ok_lists, n_pairs_all, acc = True, 0, [0, 0]
+            tmp = None
+            for bi, (sh, n_pairs) in enumerate(kept):
+                sums, off = sh.checksum(), sh.offsets()
+                for j, cid in enumerate(sample):
+                    if bi * n_c <= cid < (bi + 1) * n_c:
+                        c = cid - bi * n_c
+                        ok_lists = ok_lists and int(off[c + 1] - off[c]) == int(cnt[j]) and bool(np.array_equal(sums[c], ref[j]))
+                if tmp is None or tmp.shape[0] < sh.n_pairs:
+                    tmp = torch.empty((int(sh.n_pairs * 1.05) + 16, 5), dtype=torch.int64, device="cuda:%d" % fresh.device)
+                n = sh.frag_recs_into(tmp.data_ptr(), tmp.shape[0], sids=list(range(bi * n_c, (bi + 1) * n_c)))
+                ok_lists = ok_lists and n == n_pairs
+                cs = P.records_checksum(tmp.data_ptr(), n, ctx=fresh)
+                acc = [(acc[0] + cs[0]) & M, (acc[1] + cs[1]) & M]
+                n_pairs_all += n
+            ics = ix.records_checksum()
+            out["contigs_checked"] = len(sample)
+            out["contigs_checked_with_id_1000_or_above"] = sum(1 for c in sample if c >= n_c)
+            out["content_match"] = bool(ok_lists)
+            out["index_holds_exactly_the_records_of_the_checked_lists"] = bool(n_pairs_all == ix.n_records and [int(ics[0]), int(ics[1])] == acc)
+            out["check"] = ("128-bit order-sensitive checksum per sampled contig, GPU lists of the timed build vs CPU restatement; "
+                            "order-independent 128-bit checksum of the index's records vs the sum over the batches of the checksums "
+                            "of the pair records of those lists")
+        except Exception as e:  # noqa: BLE001
+            out["content_check_error"] = repr(e)[:300]
+    del kept, ix
+    fresh.close()
+    try:  # the one-shot case (pgr-mdb.rs:53-111: one process per file list): the same build in a process of its own
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "t100_pipe_probe.py"), "pipe", str(n_b), "--json"],
+                           capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        out["fresh_process"] = {"first_pass": j["passes"][0], "repeat": j["passes"][-1], "context_create_s": j["context_create_s"],
+                                "same_records_as_this_process": j["passes"][0]["records"] == n_rec,
+                                "what": "tools/t100_pipe_probe.py pipe %d --json in a new process (while this one still holds its memory)" % n_b}
+    except Exception as e:  # noqa: BLE001
+        out["fresh_process"] = {"error": repr(e)[:300]}
+    return out
 
 
 def pipelined_leg(P, ctx, batch, spec, rec_buf, contig_ids, steps, warmup, torch, sync_state):
@@ -1047,7 +1120,7 @@ def main():
             for name, fn in (("latency", lambda: latency_bench(P, ctx, spec, args)),
                              ("pcie_inclusive", lambda: pcie_bench(P, ctx, spec, args)),
                              ("shapes", lambda: shapes_bench(P, ctx, spec, spec_t, cores, not args.no_cpu_baseline)),
-                             ("target_100Gbp", lambda: target_100gbp(P, ctx, spec, args))):
+                             ("target_100Gbp", lambda: target_100gbp(P, ctx, spec, args, spec_t, cores, not args.no_cpu_baseline))):
                 try:
                     out[name] = fn()
                 except Exception as e:  # noqa: BLE001

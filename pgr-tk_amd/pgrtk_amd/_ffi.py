@@ -301,6 +301,7 @@ class Context:
 
     def __init__(self, device=0):
         self._h = C.c_void_p()
+        self.device = int(device)
         rc = lib().pgr_ctx_create(device, C.byref(self._h))
         if rc != 0:
             msg = lib().pgr_last_error(None)

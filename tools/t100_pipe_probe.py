@@ -9,8 +9,10 @@ sys.path.insert(0, os.path.join(ROOT, "pgr-tk_amd"))
 import torch  # noqa: F401,E402
 import pgrtk_amd as P  # noqa: E402
 
-mode = sys.argv[1] if len(sys.argv) > 1 else "pipe"
-n_b = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+as_json = "--json" in sys.argv
+argv = [a for a in sys.argv[1:] if a != "--json"]
+mode = argv[0] if len(argv) > 0 else "pipe"
+n_b = int(argv[1]) if len(argv) > 1 else 10
 n_c, L = 1000, 10_000_000
 t_ctx = time.perf_counter()
 ctx = P.Context(0)
@@ -65,10 +67,19 @@ def once():
     return t1 - t0, t2 - t1, ix.n_records, ix.n_keys, ix
 
 
-print("%s: context created in %.3f s" % (mode, t_ctx), flush=True)
+if not as_json:
+    print("%s: context created in %.3f s" % (mode, t_ctx), flush=True)
+res = []
 for what in ("fresh context", "again", "again"):
+    ctx.mem_stats(reset_peak=True)
     a, b, nr, nk, ix = once()
     cs = ix.records_checksum()
     del ix
-    print("%s, %s: %d Gbp in %.3f s (batches %.3f s, sort into the frag_map %.3f s), %d records, %d keys, checksum %016x %016x"
-          % (mode, what, n_b * n_c * L // 10**9, a + b, a, b, nr, nk, cs[0], cs[1]), flush=True)
+    res.append({"what": what, "s": a + b, "batches_s": a, "sort_into_frag_map_s": b, "records": nr, "keys": nk,
+                "records_checksum": ["%016x" % cs[0], "%016x" % cs[1]], "peak_device_bytes_of_the_allocator": ctx.mem_stats()[1]})
+    if not as_json:
+        print("%s, %s: %d Gbp in %.3f s (batches %.3f s, sort into the frag_map %.3f s), %d records, %d keys, checksum %016x %016x"
+              % (mode, what, n_b * n_c * L // 10**9, a + b, a, b, nr, nk, cs[0], cs[1]), flush=True)
+if as_json:
+    import json
+    print(json.dumps({"mode": mode, "bp": n_b * n_c * L, "context_create_s": t_ctx, "passes": res}), flush=True)
