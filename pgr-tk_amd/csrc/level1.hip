@@ -465,6 +465,10 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     long long pm = cs - (long long)cd.warm;
     if (pm < 0) pm = 0;
     long long pk = pm;
+    // A chunk that runs again from the true state with the ring of the chunk in front (ChunkDesc::ring_in) and NO warm-up takes the
+    // rolling k-mer from that state as well: nothing in front of cs is looked at (a re-run of 1024 positions was 33 steps of 64 with
+    // its 1024 warm-up positions, 16 now)
+    const bool install_kmer = cd.override_state && cd.ring_in != 0xFFFFFFFFu && !a.sketch && cd.warm == 0 && cs > 0;
     // last valid position below x (x > 0; -1: none; -2: no table).  The scanned entry of the tile that holds x - 1 is the last
     // valid position up to the END of that tile: below x it is the answer.  Otherwise the tile has a valid base at or behind x
     // (the chunk starts in the tile a gap ends in): the wavefront looks at the 4096 positions below x itself, and if they hold
@@ -497,7 +501,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
         const long long y = (((x - 1) >> 6) - 63) << 6;  // nothing valid in [y, x)
         return y > 0 ? table_lv(y) : -1;
     };
-    if (pm > 0) {
+    if (pm > 0 && !install_kmer) {
         // look back (64 blocks of 64 positions per step) until k valid bases precede pm
         uint32_t have = 0;
         long long hi = pm;  // blocks [hi - 64(lane+1), hi - 64 lane)
@@ -562,6 +566,12 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             const uint64_t sig = ring_signature(s_rx, rstart, rlen, w, lane);
             if (cd.override_state) {
                 const ChunkState t = cd.in_state;
+                if (install_kmer) {
+                    F0 = t.F0;
+                    F1 = t.F1;
+                    R0 = t.R0;
+                    R1 = t.R1;
+                }
                 if (t.F0 != F0 || t.F1 != F1 || t.R0 != R0 || t.R1 != R1 || (!a.sketch && t.ring_sig != sig))
                     stat |= 2u;  // warm-up could not even rebuild the k-mer / ring: whole-contig re-run
                 min_x = t.min_x;

@@ -89,6 +89,9 @@ struct pgr_ctx {
     double est_spec_key = -1.0, est_final_ratio = 0.0;
     // overflow-region need of the level-1 kernels per tiled base, last call with the spec `est_l1_key`
     double est_l1_key = -1.0, est_ovf_ratio = 0.0;
+    // ... level-1 minimizers per base and the list kernel's overflow need per base of that call, and whether it needed islands
+    double est_l1_dens = 0.0, est_l2_ovf = 0.0;
+    bool est_flagged = false;
     std::vector<pgr::SmallContig> keep_small_desc;  // source of the async H2D copy of shmmrs_compute_small
     std::vector<uint64_t> keep_rec_off;  // source of the async H2D copy of shmmrs_to_frag_recs_enqueue
     // second stream + events: staging of sub-batch i+1 (H2D + pack) while sub-batch i computes on `stream`

@@ -336,7 +336,7 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
                     h.d.override_state = 1;
                     h.d.in_state = t;
                     h.d.ring_in = pv.ring_src;  // the ring the last chunk with a push left at its end
-                    h.d.warm = 1024;
+                    h.d.warm = 0;               // (ring, minimizer state and rolling k-mer all come from the chunk in front)
                     again = true;
                 }
             }  // else: the chunk in front is not settled yet
@@ -631,6 +631,7 @@ struct ShmmrJob {
     int attempt = 0;
     uint64_t n_final = 0;
     uint64_t l1_alloc_seen = 0;  // elements the level-1 kernels took from the overflow region
+    uint64_t l2_alloc_seen = 0;  // ... the list kernel from its overflow region
 
     std::vector<uint32_t> &tile_first() const { return ctx->h_tile_first; }
     ~ShmmrJob() {
@@ -782,7 +783,9 @@ int ShmmrJob::plan() {
     // optimistically and repeat stages 2-4 in the (rare) flagged case: cheaper than the round trip below ~1 Gbp.
     const uint64_t early_bp = (uint64_t)std::max<int64_t>(0, ctx->opt.early_sync_bp);
     // (a batch the host packer has counted non-ACGT bytes in is known to need islands: look at the flags before the list stage)
-    early_sync = b->total_bases >= early_bp || !serial.empty() || b->host_saw_invalid;
+    // (and so is a batch of a spec whose last batch on this context needed islands: a genome comes as many similar batches)
+    early_sync = b->total_bases >= early_bp || !serial.empty() || b->host_saw_invalid ||
+                 (ctx->est_flagged && ctx->est_l1_key == l1_key && b->total_bases >= (4u << 20));
     pad_fix = padding && !sketch && spec.r > 1;
     do_reduce = !sketch && spec.r > 1;
     halo = do_reduce ? 2 * spec.r * spec.r : 1;
@@ -928,15 +931,19 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         islands = pre_islands;
         gap_segs = pre_gap_segs;
     } else if (tiled && bases_tiled && need_word) {
-        std::vector<uint32_t> flags(n), n_invalid(n);
-        std::vector<uint8_t> tf(n_tiles);
-        if (n) {
-            PGR_HIP(ctx, hipMemcpyAsync(flags.data(), d_cflags, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            PGR_HIP(ctx, hipMemcpyAsync(n_invalid.data(), b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        }
-        PGR_HIP(ctx, hipMemcpyAsync(tf.data(), d_tflags, n_tiles, hipMemcpyDeviceToHost, st));
+        // contig flags and tile flags are neighbours in the cursor block: two copies into the pinned image (three pageable ones
+        // were 67 us of a 60 Mbp call's 660)
+        const size_t nc = std::max<size_t>(n, 1) * sizeof(uint32_t);
+        const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15;
+        int r0;
+        if ((r0 = ctx->ensure_imail(inv_off + nc))) return r0;
+        uint8_t *img = (uint8_t *)ctx->imail;
+        PGR_HIP(ctx, hipMemcpyAsync(img, d_cflags, flag_bytes, hipMemcpyDeviceToHost, st));
+        if (n) PGR_HIP(ctx, hipMemcpyAsync(img + inv_off, b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));
         dbg_lap("islands: tile flags on the host");
+        std::vector<uint8_t> tf(img + nc, img + nc + n_tiles);  // (list_islands marks tiles in its copy; run_exact_islands reuses the image)
+        std::vector<uint32_t> flags((const uint32_t *)img, (const uint32_t *)img + n), n_invalid((const uint32_t *)(img + inv_off), (const uint32_t *)(img + inv_off) + n);
         list_islands(flags.data(), n_invalid.data(), tf.data(), islands, gap_segs);
     }
     {
@@ -986,9 +993,13 @@ int ShmmrJob::begin_result() {
     const uint64_t l1_bound = slots_total + cap_par + b->total_bases / 4 + 4096ull * n + 4096;  // what stage 1 can emit at all
     // (per contig: the first window and the tail emit a few elements on top of the density -- NOT thousands: 2048 per contig made
     // the list stage of 10^6 reads a grid of 2 x 10^6 workgroups for 25 x 10^3 of work, 0.6 of its 0.8 ms, and 8 GB of slots)
-    const uint64_t l1_est = std::min<uint64_t>(l1_bound, (uint64_t)((double)b->total_bases * dens * 1.06) + 16ull * n + 8192);
+    uint64_t l1_est = std::min<uint64_t>(l1_bound, (uint64_t)((double)b->total_bases * dens * 1.06) + 16ull * n + 8192);
+    // (low-complexity sequence is denser than that: what the last call with this spec saw per base, like the result's size)
+    if (ctx->est_l1_key == l1_key && ctx->est_l1_dens > dens)
+        l1_est = std::min<uint64_t>(l1_bound, std::max<uint64_t>(l1_est, (uint64_t)((double)b->total_bases * ctx->est_l1_dens * 1.04) + 16ull * n + 8192));
     n_blocks = (uint32_t)((l1_est + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
     cap2 = (uint64_t)((double)l1_est * 0.01) + 65536;
+    if (ctx->est_l1_key == l1_key && ctx->est_l2_ovf > 0) cap2 = std::max<uint64_t>(cap2, (uint64_t)((double)b->total_bases * ctx->est_l2_ovf * 1.1) + 65536);
     spec_key = (double)spec.w * 1e9 + spec.k * 1e6 + spec.r * 1e4 + spec.min_span + (sketch ? 0.5 : 0.0) + (padding ? 0.25 : 0.0);
     const double ratio = (ctx->est_spec_key == spec_key && ctx->est_final_ratio > 0) ? ctx->est_final_ratio * 1.15 : dens / 3.0 + 1e-4;
     cap_res = std::max<uint64_t>((uint64_t)((double)b->total_bases * ratio) + 64ull * n + 1024, 16);
@@ -1156,6 +1167,7 @@ int ShmmrJob::decide(bool &done) {
     const uint64_t total1 = mbox[8];
     n_final = mbox[9];
     l1_alloc_seen = l1_alloc;
+    l2_alloc_seen = l2_alloc;
     if (l1_ovf || l1_alloc > cap_par) {  // (only possible without the early look)
         cap_par = (uint64_t)((double)l1_alloc * 1.1) + 65536;
         from = 1;
@@ -1203,6 +1215,11 @@ int ShmmrJob::finish(pgr_shmmrs **out) {
     if (bases_tiled) {
         ctx->est_l1_key = l1_key;
         ctx->est_ovf_ratio = (double)l1_alloc_seen / (double)bases_tiled;
+    }
+    if (b->total_bases) {
+        ctx->est_l1_dens = (double)prof.n_level1 / (double)b->total_bases;
+        ctx->est_l2_ovf = (double)l2_alloc_seen / (double)b->total_bases;
+        ctx->est_flagged = prof.n_serial_contigs != 0 && serial.empty();
     }
     if (pad_fix) {
         // reference artefact: reduce_shmmr on an EMPTY list with padding emits its sentinels
