@@ -128,3 +128,55 @@ def test_pipelined_index_build_equals_the_synchronous_build(oracle, gpu_ctx):
         ro = oix.records()
         for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
             assert np.array_equal(ro[f], rp[f]), f
+
+
+def test_order_independent_bundle_facts_of_the_product(oracle, gpu_ctx, golden_dir):
+    """SURVEY.md section 8f rank 3 (MAP-graph + principal bundles): the facts seq_db.rs:1064-1186 / ext.rs:552-650, 976-1014
+    guarantee whatever petgraph, BinaryHeap and FxHash iterate like (tests/bundle_invariants.py B1-B5, D1-D3) hold for the
+    PRODUCT's bundles, on the reference's golden frag_map and on BASELINE.json configs[3] -- and, separately, the product agrees
+    with the oracle on the bundles as a set of vertex-key sets and on their count.  Which vertices share a bundle when branches
+    tie, the order among bundles of equal length and the ids are order dependent: unpinnable here."""
+    import os
+    import mapgraph as og
+    import bundle_invariants as bi
+    import pgrtk_amd as P
+    # --- the golden fixture graph
+    spec, fm = oracle.read_mdb(os.path.join(golden_dir, "test_seqs_frag.mdb"))
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_mdb_index(os.path.join(golden_dir, "test_seqs_frag"))
+    seqs = oracle.read_fasta(os.path.join(golden_dir, "test_seqs.fa"))
+    sp = oracle.spec(*spec[:4])
+    smps = []
+    for i, (_name, s) in enumerate(seqs):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), i, query_side=True)
+        smps.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    covered = 0
+    for mc, cutoff in [(0, 0), (0, 3), (2, 1), (16, 0)]:
+        adj = sdb.get_smp_adj_list(mc)
+        pb = sdb.get_principal_bundles(mc, cutoff)
+        bi.check_bundles(adj, pb, cutoff)
+        with_id, dec = sdb.get_principal_bundle_decomposition(mc, cutoff)
+        covered += bi.check_with_id_and_decomposition(pb, with_id, dec, smps)
+        ref = og.get_principal_bundles(fm, mc, cutoff)
+        assert len(pb) == len(ref)
+        assert {frozenset((v[0], v[1]) for v in p) for p in pb} == {frozenset((v[0], v[1]) for v in p) for p in ref}
+    assert covered > 1000
+    # --- BASELINE.json configs[3]: 96 AMY1A-like haplotypes, pgr-pbundle-decomp's defaults
+    haps = seqgen.amy1a_like(seed=4, n_hap=96, L=200_000)
+    spec_t = (48, 56, 4, 12)
+    sdb = P.SeqIndexDB(ctx=gpu_ctx)
+    sdb.load_from_seq_list([("h%03d" % i, s) for i, s in enumerate(haps)], w=spec_t[0], k=spec_t[1], r=spec_t[2], min_span=spec_t[3])
+    osp = oracle.spec(*spec_t)
+    smps = []
+    for i, s in enumerate(haps):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, osp), i, query_side=True)
+        smps.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    adj = sdb.get_smp_adj_list(0)
+    pb = sdb.get_principal_bundles(0, 8)
+    keys = bi.check_bundles(adj, pb, 8)
+    with_id, dec = sdb.get_principal_bundle_decomposition(0, 8)
+    covered = bi.check_with_id_and_decomposition(pb, with_id, dec, smps)
+    total = sum(len(s) for _sid, s in smps)
+    assert len(pb) > 10 and covered > 0.9 * total  # (nearly every shimmer pair of every haplotype lies in a principal bundle)
+    print("\nconfigs[3]: %d bundles over %d vertex keys; %d of %d shimmer pairs of the 96 haplotypes decompose into bundles" %
+          (len(pb), len(keys), covered, total))

@@ -182,3 +182,37 @@ def test_adj_list_of_the_golden_frag_map(oracle, golden_dir):
     assert [(mc, len(adj)) for mc, _, adj in cases] == [(0, 1508), (2, 1462), (16, 1134), (16, 1148), (10 ** 6, 16)]
     for mc, keeps, adj in cases:
         assert og.frag_map_to_adj_list(fm, mc, keeps=keeps) == adj, (mc, keeps)
+
+
+def test_order_independent_bundle_facts_on_the_golden_frag_map(oracle, golden_dir):
+    """what seq_db.rs:1064-1186 / ext.rs:552-650, 976-1014 guarantee whatever petgraph / BinaryHeap / FxHash iterate like
+    (tests/bundle_invariants.py: B1-B5, D1-D3), checked on the reference's own golden frag_map and its pinned adjacency lists
+    (tests/golden/test_seqs_adj_list.json) -- the order-DEPENDENT part (which vertices share a bundle at a tie, bundle order
+    among equal lengths, ids) stays unpinned: product == oracle only"""
+    import os
+    import bundle_invariants as bi
+    og = __import__("mapgraph")
+    spec, fm = oracle.read_mdb(os.path.join(golden_dir, "test_seqs_frag.mdb"))
+    seqs = oracle.read_fasta(os.path.join(golden_dir, "test_seqs.fa"))
+    sp = oracle.spec(*spec[:4])
+    smps = []
+    for i, (_name, s) in enumerate(seqs):
+        q = oracle.frag_recs(oracle.sequence_to_shmmrs(0, s, sp), i, query_side=True)
+        smps.append((i, [(int(r["h0"]), int(r["h1"]), int(r["bgn"]), int(r["end"]), int(r["orient"])) for r in q]))
+    n_checked = 0
+    for mc, keeps, adj in _adj_fixture(golden_dir):  # (the pinned half: derived from the reference's golden .mdb)
+        assert og.frag_map_to_adj_list(fm, mc, keeps=keeps) == adj
+        if not adj:
+            continue
+        for cutoff in (0, 1, 3):
+            pb, filtered = og.get_principal_bundles_from_adj_list(fm, adj, cutoff)
+            keys = bi.check_bundles(adj, pb, cutoff)
+            # the filtered list is the list restricted to a key set that contains every bundle key (:1101-1112)
+            fk = {(v[0], v[1]) for _s, v, _w in filtered} | {(w[0], w[1]) for _s, _v, w in filtered}
+            assert filtered == [e for e in adj if (e[1][0], e[1][1]) in fk and (e[2][0], e[2][1]) in fk]
+            assert {k for k in keys if k in fk} == fk  # every key with an edge inside g0 ends up in a bundle (B5)
+            if keeps is None:
+                with_id, vmap = og.get_principal_bundles_with_id(fm, smps, mc, cutoff)
+                dec = og.get_principal_bundle_decomposition(vmap, smps)
+                n_checked += bi.check_with_id_and_decomposition(pb, with_id, dec, smps)
+    assert n_checked > 500
