@@ -849,6 +849,7 @@ def main():
     from pgrtk_amd import exchange
     ctx = P.Context(local_rank)
     ctx.set_option("exchange_timeout_s", args.exchange_timeout)
+    ctx.set_option("exchange_collective_timeout_s", args.exchange_timeout)  # (the bench would rather fall back than wait half an hour)
     spec_t = (80, 56, 4, 64)
     spec = P.make_spec(*spec_t)
     if args.strong:

@@ -75,10 +75,16 @@ typedef struct pgr_index pgr_index;   /* ShmmrToFrags as a GPU/host CSR         
 int pgr_ctx_create(int device, pgr_ctx **out);
 void pgr_ctx_destroy(pgr_ctx *ctx);
 const char *pgr_last_error(const pgr_ctx *ctx); /* ctx may be NULL: last create error */
+/* Every block the library hands out (*out_mm, *out_off, records, results ...) is released with pgr_free and ONLY with pgr_free:
+ * large results are pinned blocks of a process-wide pool (the DMA engine wrote them directly), not malloc'd memory -- free()
+ * on one of them is undefined behaviour. */
 void pgr_free(void *p);
 const char *pgr_version(void);
 /* Tuning and A/B switches of a context.  Defaults come from the environment ONCE, at pgr_ctx_create (PGR_<NAME IN UPPER
  * CASE>=<integer>); afterwards only these two calls change or read them -- no entry point looks at the environment.
+ * (Process wide, read once at first use by the host-side packer and its thread pool -- csrc/hostpack.cpp --, not per context:
+ * PGR_HOST_THREADS=<n> threads of the pool instead of the CPUs the process may use; PGR_NO_AVX2 / PGR_NO_AVX512 force the
+ * narrower packers.)
  *   debug, debug_times        progress lines / a host-side timeline on stderr
  *   no_small_path             never the one-workgroup-per-contig kernel for batches of short contigs
  *   no_pipeline               never cut a large host batch into staged sub-batches
@@ -86,8 +92,11 @@ const char *pgr_version(void);
  *   gpu_pack                  ASCII over PCIe + pack kernel instead of the CPU packer (the round-2 host path)
  *   index_full_sort, index_two_key_sort    pgr_index_finalize: force the four-field / the two-key sort
  *   no_fused_query, no_query_chaining, query_global_sort, fused_query_hits   query path variants
- *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on ncclCommInitRank and on every wait for a collective
- *                             (300; 0 = wait for ever); on a timeout the communicator is aborted and the call fails
+ *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on ncclCommInitRank, the rendezvous of the ranks (300; 0 = wait for
+ *                             ever); on a timeout the communicator is aborted and the call fails
+ *   exchange_collective_timeout_s   the same for every wait for a collective -- which is also a wait for the slowest rank to get
+ *                             there, so it is generous (1800; 0 = wait for ever).  A value that is not a number leaves a numeric
+ *                             option at its default (a line on stderr says so).
  *   no_island_relay           exact islands: the round-3 seam correction (one seam per host round), for A/B timing
  *   no_short_tiles            batches of short contigs (mean length <= 2048): 4096-position tiles all the same, for A/B timing
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing

@@ -45,6 +45,7 @@ const std::vector<OptionName> &option_names() {
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
+        {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"island_chunk_min", &O::island_chunk_min},
         {"back_priority", &O::back_priority}, {"pipe_staged_records", &O::pipe_staged_records},
         {"lds_match", &O::lds_match}};
@@ -100,7 +101,16 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
         if (const char *v = getenv(env.c_str())) {
             char *end = nullptr;
             const long long x = strtoll(v, &end, 10);
-            ctx->opt.*(o.field) = (end && end != v) ? (int64_t)x : 1;  // PGR_X=1, PGR_X=<number>, or a bare PGR_X= / PGR_X=on
+            const bool number = end && end != v && *end == '\0';
+            // switches: PGR_X=1, PGR_X=<number>, or a bare PGR_X= / PGR_X=on.  Options that ARE a number (a time-out, a size)
+            // keep their default when the value is not one: "PGR_EXCHANGE_TIMEOUT_S=5m" must not become a 1-second time-out
+            static const char *const numeric[] = {"early_sync_bp", "fused_query_hits", "exchange_timeout_s", "exchange_collective_timeout_s",
+                                                  "island_chunk_min", "back_priority"};
+            bool is_numeric = false;
+            for (const char *nm : numeric) is_numeric = is_numeric || !strcmp(nm, o.name);
+            if (number) ctx->opt.*(o.field) = (int64_t)x;
+            else if (!is_numeric) ctx->opt.*(o.field) = 1;
+            else fprintf(stderr, "[pgr] %s=%s is not a number: the option keeps its default (%lld)\n", env.c_str(), v, (long long)(ctx->opt.*(o.field)));
         }
     }
     *out = ctx;
@@ -231,7 +241,9 @@ static int batch_alloc(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, pgr_batch
     PGR_HIP(ctx, hipMemsetAsync(b->d.n_invalid, 0, std::max<uint32_t>(n, 1) * sizeof(uint32_t), ctx->stream));
     // no synchronization: the source vectors live as long as the batch and everything that reads the device arrays is
     // ordered behind these copies on the context's stream (the staging thread of the pipelined path waits for `ready`)
-    if (hipEventRecord(ctx->ev_alloc, ctx->stream) != hipSuccess) {
+    // (an event of the batch's own: the staging thread of a pipelined call waits for THIS batch's copies while the calling thread
+    // allocates the next sub-batches)
+    if (hipEventCreateWithFlags(&b->ev_alloc, hipEventDisableTiming) != hipSuccess || hipEventRecord(b->ev_alloc, ctx->stream) != hipSuccess) {
         pgr_batch_destroy(b);
         return ctx->fail(PGR_ERR_DEVICE, "event record failed");
     }
@@ -247,6 +259,7 @@ extern "C" void pgr_batch_destroy(pgr_batch *b) {
     ctx->dfree(b->d.word_off);
     ctx->dfree(b->d.len);
     ctx->dfree(b->d.n_invalid);
+    if (b->ev_alloc) (void)hipEventDestroy(b->ev_alloc);
     delete b;
 }
 
@@ -266,14 +279,17 @@ static int batch_stage_ascii_gpu(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const u
     // (two batches staged back to back) must be over before the host overwrites them
     if (ctx->staged_unsynced && hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
-    if (st != ctx->stream && hipStreamWaitEvent(st, ctx->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
+    if (st != ctx->stream && b->ev_alloc && hipStreamWaitEvent(st, b->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
         return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
     // ASCII stream: word wi of the batch <-> bytes [32*wi, 32*wi+32).  Two pinned windows of 32 MiB: while window
     // i is on its way to the GPU (H2D + pack kernel) the host threads fill window i+1.
     const uint64_t WIN_WORDS = 1ull << 20;  // 32 MiB of ASCII per window
     const uint64_t win_words = std::min<uint64_t>(std::max<uint64_t>(b->total_words, 1), WIN_WORDS);
-    if (ctx->ensure_pinned(2 * win_words * 32) || ctx->ws_ascii.ensure(ctx, 2 * win_words * 32))
-        return fail(PGR_ERR_NOMEM, "staging buffers: " + ctx->err);
+    {   // (this may be the staging thread: the context's error string belongs to the calling thread)
+        std::string why;
+        if (ctx->ensure_pinned(2 * win_words * 32, &why) || ctx->ws_ascii.ensure(ctx, 2 * win_words * 32, &why))
+            return fail(PGR_ERR_NOMEM, "staging buffers: " + why);
+    }
     hipEvent_t done[2] = {ev0, ev1};
     bool used[2] = {false, false};
     const unsigned hw = std::thread::hardware_concurrency();
@@ -359,7 +375,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     // (two batches staged back to back) must be over before the host overwrites them
     if (ctx->staged_unsynced && hipStreamSynchronize(ctx->stream) != hipSuccess)
         return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
-    if (st != ctx->stream && hipStreamWaitEvent(st, ctx->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
+    if (st != ctx->stream && b->ev_alloc && hipStreamWaitEvent(st, b->ev_alloc, 0) != hipSuccess)  // batch_alloc's copies (main stream)
         return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
     const bool packed = src.planes != nullptr;
     const bool gpu_pack = !packed && ctx->opt.gpu_pack;  // A/B switch: round-2 path (ASCII over PCIe + pack kernel)
@@ -374,7 +390,10 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
                                     : std::min<uint64_t>(std::max<uint64_t>({(uint64_t)1, std::min<uint64_t>(b->total_words, 4 * PIECE),
                                                                              (b->total_words + 5) / 6}),
                                                          WIN_WORDS);
-    if (ctx->ensure_pinned(2 * win_words * 12)) return fail(PGR_ERR_NOMEM, "staging buffers: " + ctx->err);
+    {
+        std::string why;  // (this may be the staging thread: the context's error string belongs to the calling thread)
+        if (ctx->ensure_pinned(2 * win_words * 12, &why)) return fail(PGR_ERR_NOMEM, "staging buffers: " + why);
+    }
     hipEvent_t done[2] = {ev0, ev1};
     StagePipe local;
     bool *used = pipe ? pipe->used : local.used;
@@ -1190,6 +1209,12 @@ static int shmmr_batch_host(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, cons
         bool handled = false;
         if ((rc = shmmr_batch_small(ctx, spec, n, src, rids, out_mm, out_off, handled)) || handled) return rc;
     }
+    // (skip_small_once, set by shmmr_batch_small when its kernel handed the batch back, belongs to THIS call: whatever way the
+    // general path leaves, the next call on the context starts without it)
+    struct ClearSkip {
+        pgr_ctx *c;
+        ~ClearSkip() { c->skip_small_once = false; }
+    } clear_skip{ctx};
     if (worth_pipelining(ctx, n, src.lens)) return shmmr_batch_pipelined(ctx, spec, n, src, rids, padding, out_mm, out_off);
     pgr_batch *b = nullptr;
     if ((rc = batch_from_host(ctx, n, src, &b))) return rc;

@@ -12,7 +12,7 @@
 
 namespace pgr {
 
-int DevBuf::ensure(pgr_ctx *ctx, size_t bytes) {
+int DevBuf::ensure(pgr_ctx *ctx, size_t bytes, std::string *err) {
     if (bytes <= cap && p) return PGR_OK;
     if (p) {
         (void)hipFree(p);
@@ -28,7 +28,12 @@ int DevBuf::ensure(pgr_ctx *ctx, size_t bytes) {
     }
     if (e != hipSuccess) {
         p = nullptr;
-        return ctx->fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
+        const std::string msg = std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e);
+        if (err) {
+            *err = msg;
+            return PGR_ERR_NOMEM;
+        }
+        return ctx->fail(PGR_ERR_NOMEM, msg);
     }
     cap = want;
     return PGR_OK;
@@ -309,7 +314,7 @@ void pgr_ctx::swap_lane(pgr::Lane &l) {
     keep_rec_off.swap(l.keep_rec_off);
 }
 
-int pgr_ctx::ensure_pinned(size_t bytes) {
+int pgr_ctx::ensure_pinned(size_t bytes, std::string *err_out) {
     if (bytes <= pinned_cap && pinned) return PGR_OK;
     if (pinned) (void)hipHostFree(pinned);
     pinned = nullptr;
@@ -317,7 +322,12 @@ int pgr_ctx::ensure_pinned(size_t bytes) {
     hipError_t e = hipHostMalloc(&pinned, bytes, hipHostMallocDefault);
     if (e != hipSuccess) {
         pinned = nullptr;
-        return fail(PGR_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+        const std::string msg = std::string("hipHostMalloc: ") + hipGetErrorString(e);
+        if (err_out) {
+            *err_out = msg;
+            return PGR_ERR_NOMEM;
+        }
+        return fail(PGR_ERR_NOMEM, msg);
     }
     pinned_cap = bytes;
     return PGR_OK;

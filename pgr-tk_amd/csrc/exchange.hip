@@ -111,12 +111,18 @@ struct pgr_exchange {
 // communicator is aborted (ncclCommAbort), the call returns PGR_ERR_DEVICE and the exchange refuses further work, so that a
 // host program can fall back to another transport or fail with a message instead of hanging.
 static double exchange_timeout_s(const pgr_ctx *ctx) { return ctx->opt.exchange_timeout_s < 0 ? 0.0 : (double)ctx->opt.exchange_timeout_s; }
+// (a wait for a collective is also a wait for the slowest peer to ARRIVE at it: its own, longer bound -- never shorter than the
+// one for the rendezvous, unless that one was set to "for ever")
+static double exchange_collective_timeout_s(const pgr_ctx *ctx) {
+    const double c = ctx->opt.exchange_collective_timeout_s < 0 ? 0.0 : (double)ctx->opt.exchange_collective_timeout_s;
+    return c;
+}
 
 // wait for the exchange's stream, bounded
 static int exchange_sync(pgr_exchange *x, const char *what) {
     pgr_ctx *ctx = x->ctx;
     if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
-    const double limit = exchange_timeout_s(ctx);
+    const double limit = exchange_collective_timeout_s(ctx);
     if (limit <= 0) {
         PGR_HIP(ctx, hipStreamSynchronize(x->stream));
         return PGR_OK;
@@ -134,7 +140,7 @@ static int exchange_sync(pgr_exchange *x, const char *what) {
     if (x->comm && rccl().CommAbort) (void)rccl().CommAbort(x->comm);
     x->comm = nullptr;
     char msg[200];
-    snprintf(msg, sizeof msg, "%s did not complete within %.0f s (option exchange_timeout_s): communicator aborted, rank %d of %d", what,
+    snprintf(msg, sizeof msg, "%s did not complete within %.0f s (option exchange_collective_timeout_s): communicator aborted, rank %d of %d", what,
              limit, x->rank, x->world);
     return ctx->fail(PGR_ERR_DEVICE, msg);
 }
@@ -368,6 +374,16 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
                         : ctx->fail(PGR_ERR_STATE, std::string("pgr_exchange_shard_records: another rank failed ") + where +
                                                        " (its own error message says why); nothing was exchanged");
     };
+    // Every device block of this call is taken BEFORE the first collective, and a failure to get one is this rank's error word
+    // like any other local failure.  (The two blocks of the sample all-gather themselves -- 33 KB and world x 33 KB -- are the
+    // exception: without them this rank cannot say anything; that, a failing enqueue of a copy or a collective -- a broken device
+    // or communicator -- and nothing else is left to the watchdog.  pgr_shard_splitters runs on the same pooled sample on every
+    // rank: it fails everywhere or nowhere.)
+    const size_t row = (size_t)world + 1;
+    pgr::Tmp d_part(ctx), d_cnt(ctx), d_mat(ctx);
+    int alloc_rc = d_cnt.alloc(row * 8);  // (the small ones first: with them this rank can at least say that it failed)
+    if (!alloc_rc) alloc_rc = d_mat.alloc((size_t)world * row * 8);
+    if (!alloc_rc) alloc_rc = d_part.alloc(std::max<uint64_t>(n, 1) * sizeof(pgr_frag_rec));
     std::vector<uint64_t> splitters((size_t)std::max(world - 1, 1));
     if (reuse_splitters) {
         splitters = x->splitters;
@@ -375,7 +391,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
         // ---- 1. pooled sample of first hashes -> splitters (the same on every rank)
         std::vector<uint64_t> mine(1 + SHARD_SAMPLES, 0);
         uint32_t n_s = 0;
-        local_rc = pgr_shard_sample_keys(ctx, d_recs, n, SHARD_SAMPLES, mine.data() + 1, &n_s);  // synchronizes
+        local_rc = alloc_rc ? alloc_rc : pgr_shard_sample_keys(ctx, d_recs, n, SHARD_SAMPLES, mine.data() + 1, &n_s);  // synchronizes
         mine[0] = local_rc ? FAILED : n_s;
         pgr::Tmp d_smp(ctx), d_all(ctx);
         if ((rc = d_smp.alloc(mine.size() * 8)) || (rc = d_all.alloc((size_t)world * mine.size() * 8))) return rc;
@@ -399,15 +415,12 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     if (splitters_out)
         for (int j = 0; j + 1 < world; ++j) splitters_out[j] = splitters[(size_t)j];
     // ---- 2. stable partition of this rank's records by destination
-    pgr::Tmp d_part(ctx);
     std::vector<uint64_t> send_cnt((size_t)world + 1, 0);  // [world] = error word
-    if ((local_rc = d_part.alloc(std::max<uint64_t>(n, 1) * sizeof(pgr_frag_rec))) == PGR_OK)
-        local_rc = pgr_shard_partition(ctx, d_recs, n, splitters.data(), world, d_part.as<pgr_frag_rec>(), send_cnt.data());
+    if (alloc_rc && (!d_cnt.p || !d_mat.p)) return alloc_rc;  // (not even the count blocks: this rank cannot take part; see above)
+    local_rc = alloc_rc ? alloc_rc
+                        : pgr_shard_partition(ctx, d_recs, n, splitters.data(), world, d_part.as<pgr_frag_rec>(), send_cnt.data());
     send_cnt[(size_t)world] = local_rc ? FAILED : 0;
     // ---- 3. everybody's counts: M[src][dst] (+ the error word of src)
-    const size_t row = (size_t)world + 1;
-    pgr::Tmp d_cnt(ctx), d_mat(ctx);
-    if ((rc = d_cnt.alloc(row * 8)) || (rc = d_mat.alloc((size_t)world * row * 8))) return rc;
     std::vector<uint64_t> mat((size_t)world * row);
     PGR_HIP(ctx, hipMemcpyAsync(d_cnt.p, send_cnt.data(), row * 8, hipMemcpyHostToDevice, x->stream));
     PGR_NCCL(ctx, R.AllGather(d_cnt.p, d_mat.p, row, ncclUint64, x->comm, x->stream));

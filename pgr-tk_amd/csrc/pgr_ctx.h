@@ -15,7 +15,7 @@ namespace pgr {
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
-    int ensure(pgr_ctx *ctx, size_t bytes);                        // contents NOT preserved
+    int ensure(pgr_ctx *ctx, size_t bytes, std::string *err = nullptr);  // contents NOT preserved; err != NULL: the message goes there, not into the context
     int ensure_keep(pgr_ctx *ctx, size_t bytes, hipStream_t st);   // contents preserved
     void release(pgr_ctx *ctx);
 };
@@ -42,7 +42,7 @@ struct pgr_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_end = nullptr;
-    hipEvent_t ev_alloc = nullptr;  // after the H2D copies of the last batch_alloc (the staging stream waits for it)
+    hipEvent_t ev_alloc = nullptr;  // (unused since every batch has an event of its own: pgr_batch::ev_alloc)
     std::string err;
     pgr_prof prof = {};
     pgr_query_prof qprof = {};
@@ -71,7 +71,9 @@ struct pgr_ctx {
         int64_t no_query_chaining = 0;   // do not enqueue the query stage behind the shimmer pipeline
         int64_t query_global_sort = 0;   // group the hits of a batch with the global radix sort
         int64_t fused_query_hits = 0;    // > 0: fixed slot size H of the per-query kernel
-        int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank and on every wait for a collective; 0 = wait for ever
+        int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank (all ranks must arrive); 0 = wait for ever
+        int64_t exchange_collective_timeout_s = 1800;  // bound on every wait for a collective -- which includes waiting for a SLOWER peer to
+                                                       // get there (an imbalanced rank is not a dead one): generous; 0 = wait for ever
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
@@ -151,7 +153,7 @@ struct pgr_ctx {
     }
     int dmalloc(void **out, size_t bytes);
     void dfree(void *p);
-    int ensure_pinned(size_t bytes);
+    int ensure_pinned(size_t bytes, std::string *err = nullptr);  // err != NULL: the message goes there (a thread other than the caller's)
     int ensure_pinned_out(size_t bytes);
     int ensure_mailbox(size_t bytes);
     // a second, small pinned mailbox for a consumer whose kernels run behind the shimmer pipeline's (which owns `mailbox`)

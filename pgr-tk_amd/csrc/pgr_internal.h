@@ -66,6 +66,7 @@ struct pgr_batch {
     std::vector<uint32_t> h_len;       // [n]
     std::vector<uint32_t> h_n_invalid; // [n] non-ACGT bytes counted by the host packer (source of an async H2D copy)
     bool host_saw_invalid = false;     // the host packer counted at least one
+    hipEvent_t ev_alloc = nullptr;     // behind the H2D copies of the batch's tables (batch_alloc), on the context's stream
 };
 
 struct pgr_shmmrs {

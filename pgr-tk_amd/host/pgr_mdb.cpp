@@ -117,7 +117,13 @@ static int add_synthetic(pgr_ctx *ctx, pgr_index *ix, const Synthetic &sy, const
 }
 
 static void die(pgr_ctx *ctx, const char *what, int rc) {
-    fprintf(stderr, "pgr-mdb: %s failed (%d): %s\n", what, rc, ctx ? pgr_last_error(ctx) : pgr_last_error(nullptr));
+    const char *msg = ctx ? pgr_last_error(ctx) : pgr_last_error(nullptr);
+    fprintf(stderr, "pgr-mdb: %s failed (%d): %s\n", what, rc, msg);
+    if (msg && strstr(msg, "did not") && strstr(msg, "within"))  // the library's watchdog: a peer that is slow is not a peer that is gone
+        fprintf(stderr, "pgr-mdb: a rank waited longer than its time-out for the others.  If the ranks are merely unbalanced (one much "
+                        "larger share of the contigs) raise PGR_EXCHANGE_COLLECTIVE_TIMEOUT_S (seconds; 0 = wait for ever) -- "
+                        "PGR_EXCHANGE_TIMEOUT_S bounds the rendezvous of the ranks at start-up; a rank that has died says so in its "
+                        "own last line above.\n");
     exit(1);
 }
 

@@ -104,3 +104,20 @@ def test_shard_splitters_are_quantiles_of_the_pooled_sample():
             sizes = np.bincount(dest, minlength=world)
             assert sizes.max() - sizes.min() <= 2  # the pool itself is cut into equal parts
     assert len(exchange.shard_splitters([np.zeros(0, dtype=np.uint64)], 4)) == 3  # empty pool: still world - 1 splitters
+
+
+def test_stream_packers_against_the_byte_table(tmp_path):
+    """the non-temporal-store packers the staging windows are filled with (pack_words_stream, pack_words_stream_nofence,
+    stream_copy: csrc/hostpack.cpp) against a scalar reading of shmmrutils.rs:426-436, through a C++ harness built here with
+    g++ (no GPU, no HIP): every byte class, ragged lengths, sub-ranges of a contig's words, unaligned destinations, nothing
+    written outside the destination; with the AVX-512 / AVX2 / scalar variants the CPU offers"""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    csrc = os.path.join(root, "pgr-tk_amd", "csrc")
+    exe = str(tmp_path / "hostpack_stream_harness")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", csrc, os.path.join(root, "tests", "hostpack_stream_harness.cpp"),
+                    os.path.join(csrc, "hostpack.cpp"), "-o", exe], check=True, timeout=300)
+    for env_extra in ({}, {"PGR_NO_AVX512": "1"}, {"PGR_NO_AVX2": "1"}):
+        r = subprocess.run([exe, "3000"], capture_output=True, text=True, timeout=300, env=dict(os.environ, **env_extra))
+        assert r.returncode == 0, (env_extra, r.stdout, r.stderr)
+        assert "3000 cases, 0 failures" in r.stdout
