@@ -103,6 +103,7 @@ const char *pgr_version(void);
  *   island_chunk_min          > 0: shortest chunk of the exact machine in positions (default 1024; 4096 = the round-3 minimum), for A/B
  *   back_priority             pgr_pipe: stream priority of the back stream (1 = highest, 0 = default, -1 = lowest), read when the
  *                             context's first pipe is created
+ *   no_direct_h2d             packed input in pinned host memory is copied through the staging windows all the same, for A/B
  *   lds_match                 pgr_pipe: the back stream's kernels occupy exactly the tile kernel's LDS per workgroup, or none, for A/B
  *   pipe_staged_records       pgr_pipe: index jobs always stage their records and copy them in when collected, for A/B
  * Unknown names: PGR_ERR_INVALID_ARG. */
@@ -154,6 +155,13 @@ int pgr_frag_recs_batch(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n_seqs,
 uint64_t pgr_packed_words(uint32_t n_seqs, const uint64_t *lens);
 int pgr_pack_ascii(uint32_t n_seqs, const uint8_t *const *seqs, const uint64_t *lens, int n_threads, uint64_t *planes,
                    uint32_t *valid, uint64_t *n_invalid);
+/* A host that keeps its packed sequences in long-lived buffers pins them ONCE: pgr_host_register (hipHostRegister; the buffer
+ * must stay where it is until pgr_host_unregister, which must come before the host frees it; memory from hipHostMalloc needs
+ * neither).  The packed entry points recognise pinned planes (and validity plane) and let the DMA engine read them where they
+ * lie: no copy into the library's staging windows, the link is the only stage left.  The validity plane is read on the host and
+ * crosses the link only for stretches that hold a byte that is not a base.  (Errors: pgr_last_error(NULL).) */
+int pgr_host_register(void *p, size_t bytes);
+int pgr_host_unregister(void *p);
 /* B1 with packed input: everything else as pgr_shmmr_batch */
 int pgr_shmmr_batch_packed(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n_seqs, const uint64_t *lens,
                            const uint64_t *planes, const uint32_t *valid, const uint32_t *rids, int padding,

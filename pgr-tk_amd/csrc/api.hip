@@ -48,7 +48,7 @@ const std::vector<OptionName> &option_names() {
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"island_chunk_min", &O::island_chunk_min},
         {"back_priority", &O::back_priority}, {"pipe_staged_records", &O::pipe_staged_records},
-        {"lds_match", &O::lds_match}};
+        {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d}};
     return v;
 }
 }  // namespace
@@ -114,6 +114,28 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
         }
     }
     *out = ctx;
+    return PGR_OK;
+}
+
+extern "C" int pgr_host_register(void *p, size_t bytes) {
+    if (!p || !bytes) return PGR_ERR_INVALID_ARG;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_create_error = std::string("hipHostRegister: ") + hipGetErrorString(e);
+        return e == hipErrorOutOfMemory ? PGR_ERR_NOMEM : PGR_ERR_DEVICE;
+    }
+    return PGR_OK;
+}
+
+extern "C" int pgr_host_unregister(void *p) {
+    if (!p) return PGR_ERR_INVALID_ARG;
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        g_create_error = std::string("hipHostUnregister: ") + hipGetErrorString(e);
+        return PGR_ERR_DEVICE;
+    }
     return PGR_OK;
 }
 
@@ -365,6 +387,34 @@ struct StagePipe {
     bool used[2] = {false, false};
     int slot = 0;
 };
+
+// is this host address pinned (hipHostMalloc / hipHostRegister / pgr_host_register)?  The DMA engine reads such memory directly.
+static bool host_ptr_is_pinned(const void *p) {
+    if (!p) return false;
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();  // (an ordinary host pointer is an "invalid value" to this call)
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+// validity words [wl0, wl1) of a contig of `len` bases (v[0] = word wl0): does every base say "valid"?  (bits past the contig's end
+// do not count)
+static bool valid_words_all_set(const uint32_t *v, uint64_t wl0, uint64_t wl1, uint64_t len) {
+    if (wl1 <= wl0) return true;
+    const uint64_t nw = (len + 31) / 32;
+    const uint64_t full_end = std::min(wl1, (len % 32) ? nw - 1 : nw);  // words below this one are whole
+    uint32_t acc = 0xFFFFFFFFu;
+    for (uint64_t w = wl0; w < full_end; ++w) acc &= v[w - wl0];
+    if (acc != 0xFFFFFFFFu) return false;
+    if (wl1 == nw && (len % 32) && nw - 1 >= wl0) {
+        const uint32_t tail = ~(0xFFFFFFFFu >> (uint32_t)(len % 32));
+        if ((v[nw - 1 - wl0] & tail) != tail) return false;
+    }
+    return true;
+}
 static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &src, hipStream_t st, hipEvent_t ev0,
                        hipEvent_t ev1, std::string &err, StagePipe *pipe = nullptr) {
     auto fail = [&](int code, const std::string &m) {
@@ -386,11 +436,20 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     // A batch of its own (a query batch: 100 Mbp) goes in about six windows, not in one and a bit: nothing computes before its
     // last byte is on the device, and the DMA of a window only starts when the window is full -- with 84 Mbp windows the call waited
     // for the copy of 21 MB (0.4 ms) after the fill of the first window instead of copying behind the fill
-    const uint64_t win_words = pipe ? WIN_WORDS
-                                    : std::min<uint64_t>(std::max<uint64_t>({(uint64_t)1, std::min<uint64_t>(b->total_words, 4 * PIECE),
-                                                                             (b->total_words + 5) / 6}),
-                                                         WIN_WORDS);
-    {
+    // Packed input in PINNED host memory (hipHostMalloc / hipHostRegister / pgr_host_register): the DMA engine reads the caller's
+    // planes where they lie -- no copy into the staging windows (the host copy ran at 45-49 GB/s beside a 56 GB/s link and made
+    // the pre-packed route slower than the ASCII one, whose packer writes a quarter of what it reads).  All of it is queued at once
+    // (windows of 8 MiB only so that a validity plane is looked at, and sent where it says something, beside the copies): nothing
+    // the passes over the staged sub-batches need goes through a copy engine (pipeline.hip: the tile table and the rids are read
+    // out of the pinned mailbox by a kernel), so a full queue holds nobody up.
+    const bool src_pinned = packed && b->total_words && host_ptr_is_pinned(src.planes + src.word0) &&
+                            (!src.valid || host_ptr_is_pinned(src.valid + src.word0)) && !ctx->opt.no_direct_h2d;
+    const uint64_t win_words = src_pinned ? (src.valid ? (1ull << 20) : std::max<uint64_t>(b->total_words, 1))
+                               : pipe     ? WIN_WORDS
+                                          : std::min<uint64_t>(std::max<uint64_t>({(uint64_t)1, std::min<uint64_t>(b->total_words, 4 * PIECE),
+                                                                                   (b->total_words + 5) / 6}),
+                                                               WIN_WORDS);
+    if (!src_pinned) {
         std::string why;  // (this may be the staging thread: the context's error string belongs to the calling thread)
         if (ctx->ensure_pinned(2 * win_words * 12, &why)) return fail(PGR_ERR_NOMEM, "staging buffers: " + why);
     }
@@ -406,13 +465,20 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
         uint64_t out;       // first word inside the window
     };
     std::vector<Job> jobs;
+    struct SanRange {
+        uint64_t w0, w1;
+        int has_valid;
+    };
+    std::vector<SanRange> san;
     for (uint64_t w0 = 0; w0 < b->total_words; w0 += win_words, slot ^= 1) {
         const uint64_t w1 = std::min(b->total_words, w0 + win_words);
-        uint64_t *pin_planes = (uint64_t *)((uint8_t *)ctx->pinned + (size_t)slot * win_words * 12);
-        uint32_t *pin_valid = (uint32_t *)(pin_planes + win_words);
+        uint64_t *pin_planes = src_pinned ? nullptr : (uint64_t *)((uint8_t *)ctx->pinned + (size_t)slot * win_words * 12);
+        uint32_t *pin_valid = src_pinned ? nullptr : (uint32_t *)(pin_planes + win_words);
         const auto tw0 = std::chrono::steady_clock::now();
-        if (used[slot] && hipEventSynchronize(done[slot]) != hipSuccess)  // this window's previous trip is over
+        if (!src_pinned && used[slot] && hipEventSynchronize(done[slot]) != hipSuccess)  // this window's previous trip is over
             return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
+        if (src_pinned && hipMemcpyAsync(b->d.planes + w0, src.planes + src.word0 + w0, (w1 - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess)
+            return fail(PGR_ERR_DEVICE, "H2D copy of the caller's planes failed");
         const auto tw1 = std::chrono::steady_clock::now();
         while (c < n && b->h_word_off[c + 1] <= w0) ++c;
         jobs.clear();
@@ -459,20 +525,43 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
                 if (job_bad) win_bad.fetch_add(job_bad, std::memory_order_relaxed);
             } else {
                 const uint64_t g = src.word0 + b->h_word_off[j.c0] + j.wl0;  // word of the caller's arrays (contigs are back to back there too)
-                stream_copy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
-                if (src.valid) stream_copy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
+                if (!src_pinned) stream_copy(pin_planes + j.out, src.planes + g, (j.wl1 - j.wl0) * sizeof(uint64_t));
+                // the validity plane is READ here (0.125 B per base) and travels only if it says something: a host that keeps one
+                // for sequences without a single N pays nothing for it on the link
+                if (src.valid && !win_bad.load(std::memory_order_relaxed)) {
+                    bool all_set = true;
+                    if (j.c1 == j.c0 + 1) all_set = valid_words_all_set(src.valid + g, j.wl0, j.wl1, src.lens[j.c0]);
+                    else
+                        for (uint32_t cq = j.c0; cq < j.c1 && all_set; ++cq)
+                            all_set = valid_words_all_set(src.valid + src.word0 + b->h_word_off[cq], 0, b->h_word_off[cq + 1] - b->h_word_off[cq], src.lens[cq]);
+                    if (!all_set) win_bad.store(1, std::memory_order_relaxed);
+                }
             }
         });
+        if (packed && src.valid && win_bad.load() && !src_pinned)  // (rare: this window's validity words do go)
+            HostPool::instance().parallel_for(jobs.size(), [&](size_t i) {
+                const Job &j = jobs[i];
+                const uint64_t g = src.word0 + b->h_word_off[j.c0] + j.wl0;
+                stream_copy(pin_valid + j.out, src.valid + g, (j.wl1 - j.wl0) * sizeof(uint32_t));
+            });
         const auto tw3 = std::chrono::steady_clock::now();
         // the validity plane only travels when it says something: a window of ASCII in which the packer met no non-ACGT byte
         // (the usual case) and packed input without a validity plane put 0.25 B per base on the link, the plane is written on
         // the device from the contig lengths
-        const bool has_valid = packed ? src.valid != nullptr : win_bad.load() != 0;
-        if (hipMemcpyAsync(b->d.planes + w0, pin_planes, (w1 - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess ||
-            (has_valid &&
-             hipMemcpyAsync(b->d.valid + w0, pin_valid, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess))
+        const bool has_valid = packed ? (src.valid != nullptr && win_bad.load() != 0) : win_bad.load() != 0;
+        // (pinned caller memory: the planes' copy was enqueued in front of the jobs, straight from the caller's array)
+        const void *valid_src = src_pinned ? (const void *)(src.valid + src.word0 + w0) : (const void *)pin_valid;
+        if ((!src_pinned &&
+             hipMemcpyAsync(b->d.planes + w0, pin_planes, (w1 - w0) * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) ||
+            (has_valid && hipMemcpyAsync(b->d.valid + w0, valid_src, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, st) != hipSuccess))
             return fail(PGR_ERR_DEVICE, "H2D copy of the packed window failed");
-        if (packed || !has_valid) launch_sanitize_packed(st, b->d, n, w0, w1, has_valid ? 1 : 0);
+        // The clean-up kernel of the window's words does NOT go between this window's copy and the next one's: a copy engine
+        // and a compute queue hand over with a signal each way, ~10-20 us of nothing per window -- with 8 MiB windows the link
+        // ran at 42 GB/s instead of 57.  The ranges are remembered and cleaned behind the batch's last copy.
+        if (packed || !has_valid) {
+            if (!san.empty() && san.back().w1 == w0 && san.back().has_valid == (has_valid ? 1 : 0)) san.back().w1 = w1;
+            else san.push_back(SanRange{w0, w1, has_valid ? 1 : 0});
+        }
         if (hipEventRecord(done[slot], st) != hipSuccess) return fail(PGR_ERR_DEVICE, "H2D pipeline failed");
         used[slot] = true;
         if (ctx->opt.debug > 1) {
@@ -482,6 +571,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
                     (double)(w1 - w0) * 32e-6, us(tw0, tw1), jobs.size(), us(tw1, tw2), us(tw2, tw3), (double)(w1 - w0) * 8e-3 / us(tw2, tw3), us(tw3, tw4));
         }
     }
+    for (const SanRange &r : san) launch_sanitize_packed(st, b->d, n, r.w0, r.w1, r.has_valid);
     // per-contig counts of non-ACGT bytes (host-packed input: counted by the packer; packed input: by the kernel above)
     if (!packed)
         for (uint32_t i = 0; i < n; ++i) b->host_saw_invalid = b->host_saw_invalid || b->h_n_invalid[i] != 0;
@@ -491,7 +581,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
     // On the context's own stream nothing waits here: the consumer is ordered behind the copies and synchronizes once at
     // its end; the staging thread of the pipelined path (own stream) hands over finished batches.
     if (pipe) return PGR_OK;
-    if (st != ctx->stream) {
+    if (st != ctx->stream || src_pinned) {  // (the DMA engine is still reading the CALLER's memory: not behind this call's return)
         if (hipStreamSynchronize(st) != hipSuccess || hipGetLastError() != hipSuccess)
             return fail(PGR_ERR_DEVICE, "staging failed on the device");
     } else {
@@ -808,6 +898,8 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
     {
         uint64_t target = 64ull << 20, left = total_bp;
         for (uint32_t c = 0; c < n;) {
+            // (measured in round 5: a coarser ramp-down -- 128 Mbp floor, the remainder joined to its predecessor -- changes nothing:
+            // one long last pass instead of four short ones, 5.9-6.1 ms either way)
             const uint64_t want = std::max<uint64_t>(48ull << 20, std::min<uint64_t>(std::min(target, SUB_BP), left / 2));
             uint32_t e = c;
             uint64_t tot = 0;
@@ -863,13 +955,19 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
             return ctx->fail(PGR_ERR_DEVICE, "event creation failed");
         }
     StagePipe pipe;
+    // Pinned packed input goes to the copy engine sub-batch by sub-batch, nothing holding it back (batch_stage) -- but the engine
+    // takes its work in the order it was queued, downloads of results included: sub-batch j is queued only when sub-batch j - 2
+    // has been consumed (its result's download is in the queue by then), so that a download waits for ONE staging copy, not
+    // for all that are left (measured: the second sub-batch's consumer sat 4.5 ms behind the whole call's copies).
+    const bool throttle = src.planes && host_ptr_is_pinned(src.planes + src.word0) && !ctx->opt.no_direct_h2d;
+    size_t n_consumed = 0;  // (guarded by mu)
     std::thread stager([&]() {
         (void)hipSetDevice(ctx->device);
         for (size_t i = 0; i < subs.size() && !cancel.load(); ++i) {
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return n_alloc > i || cancel.load(); });
-                if (n_alloc <= i) return;
+                cv.wait(lk, [&] { return (n_alloc > i && (!throttle || n_consumed + 2 > i)) || cancel.load(); });
+                if (n_alloc <= i || cancel.load()) return;
             }
             std::string err;
             StageSrc ss = src;
@@ -917,6 +1015,11 @@ int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
             break;
         }
         rc = consume(subs[i].b, subs[i].c0, subs[i].c1);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            n_consumed = i + 1;
+            cv.notify_all();
+        }
         if (dbg) fprintf(stderr, "[pgr]   sub-batch %zu consumed %.2f -> %.2f ms\n", i, tc0, since());
         if (rc) {
             // a consumer that failed before its own synchronization: this sub-batch's copies (the batch owns the pageable source

@@ -131,6 +131,18 @@ void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, cons
     hipLaunchKernelGGL(pack_ascii_kernel, dim3(blocks), dim3(256), 0, st, d_ascii, w0, b, n, w1);
 }
 
+// a small table from PINNED host memory into device memory by the compute queue itself (coalesced reads over the link): a copy
+// engine takes its work in the order it was queued, and a table that a pass needs at its start would wait behind every staging
+// copy of the sub-batches queued in front of it (4 ms of a 7 ms call, api.hip: batch_stage)
+__global__ void copy_words_kernel(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src, uint64_t n) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+void launch_copy_words(hipStream_t st, uint32_t *dst, const uint32_t *pinned_src, uint64_t n_words) {
+    if (n_words == 0) return;
+    hipLaunchKernelGGL(copy_words_kernel, dim3((uint32_t)((n_words + 255) / 256)), dim3(256), 0, st, dst, pinned_src, n_words);
+}
+
 void launch_sanitize_packed(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t w0, uint64_t w1, int has_valid) {
     if (w1 <= w0) return;
     const uint32_t blocks = (uint32_t)((w1 - w0 + 255) / 256);

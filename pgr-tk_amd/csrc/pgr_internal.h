@@ -90,6 +90,8 @@ void launch_pack_ascii(hipStream_t st, const uint8_t *d_ascii, uint64_t w0, cons
 // packed host input: clean words [w0, w1) (bits past the contig end, plane bits of invalid positions) and count the
 // non-ACGT positions per contig; has_valid == 0: every base is valid, the validity plane is written from the lengths
 void launch_sanitize_packed(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t w0, uint64_t w1, int has_valid);
+// dst[0 .. n_words) = pinned_src[0 .. n_words): a table out of pinned host memory, read by a kernel (not by a copy engine)
+void launch_copy_words(hipStream_t st, uint32_t *dst, const uint32_t *pinned_src, uint64_t n_words);
 void launch_synth(hipStream_t st, const BatchDev &b, uint32_t n, uint64_t total_words, uint64_t seed,
                   uint64_t contig0, const uint64_t *d_ids /* NULL: contig0 + index */);
 

@@ -737,22 +737,25 @@ int ShmmrJob::plan() {
                                              std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
         (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_off_b.ensure(ctx, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t))) ||
-        (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t))))
+        // pinned: the pass's status words + result offsets come back into it; behind them the tile table and the rids on their way up
+        (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t) + (2 * (size_t)n + 2) * sizeof(uint32_t))))
         return rc;
     d_cursor = (unsigned long long *)ctx->ws_cursor.p;
     d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
     d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
     zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
     mbox = (uint64_t *)ctx->mailbox;
-    // (through the pinned mailbox -- free until this call's results come back into it, and the stream orders the two: a copy
-    // from pageable memory is staged by the runtime, ~15 us during which nothing else is enqueued)
-    memcpy(mbox, tf.data(), ((size_t)n + 1) * sizeof(uint32_t));
-    PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_tile_first.p, mbox, ((size_t)n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    // (through the pinned mailbox, read by a KERNEL of this stream: a copy engine would take these few kB in the order of its
+    // queue -- behind every staging copy a pipelined host call has queued for the sub-batches to come)
+    uint32_t *up = (uint32_t *)(mbox + N_STATUS + (size_t)n + 1);
+    memcpy(up, tf.data(), ((size_t)n + 1) * sizeof(uint32_t));
+    launch_copy_words(st, (uint32_t *)ctx->ws_tile_first.p, up, (uint64_t)n + 1);
     dbg_lap("plan + tile table uploaded");
     d_rids = nullptr;
     if (rids && n) {
         if ((rc = ctx->ws_rids.ensure(ctx, (size_t)n * sizeof(uint32_t)))) return rc;
-        PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_rids.p, rids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        memcpy(up + n + 1, rids, (size_t)n * sizeof(uint32_t));
+        launch_copy_words(st, (uint32_t *)ctx->ws_rids.p, up + n + 1, n);
         d_rids = (uint32_t *)ctx->ws_rids.p;
     }
 
@@ -1107,7 +1110,8 @@ int ShmmrJob::stage4() {
     // pass calls it again.  (In front of the copies to the host as well: a DMA between two kernels costs ~20 us of bubbles.)
     if (ctx->post_enqueue && !pad_fix && (r = ctx->post_enqueue(d_list, d_loff, cap_res, d_nfinal))) return r;
     if (post && !pad_fix && (r = post(st, d_list, d_loff, cap_res, d_nfinal))) return r;
-    PGR_HIP(ctx, hipMemcpyAsync(mbox, d_loff - N_STATUS, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+    // (status words + offsets into the pinned mailbox by a kernel of this stream, not by a copy engine: see plan())
+    launch_copy_words(st, (uint32_t *)mbox, (const uint32_t *)(d_loff - N_STATUS), 2 * (N_STATUS + (uint64_t)n + 1));
     // a small result that the caller wants on the host anyway (pgr_shmmr_batch) rides along with this round trip
     host_copy_elems = 0;
     if (ctx->want_host_copy && !optimistic && !pad_fix && cap_res * sizeof(pgr_mm128) <= (256u << 10) &&

@@ -5,7 +5,7 @@ include/pgr_hip.h).  There is no CPU path: without the built library and a gfx95
 calls raise.
 """
 from ._ffi import FRAG_REC, HITPAIR, MM128, Context, PackedSeqs, PgrError, Spec, default_context  # noqa: F401
-from .engine import (Batch, Index, PackedBases, Pipe, Shmmrs, frag_recs_batch, make_spec, pack_ascii, records_checksum,  # noqa: F401
+from .engine import (Batch, Index, PackedBases, PinnedArrays, Pipe, Shmmrs, frag_recs_batch, make_spec, pack_ascii, records_checksum,  # noqa: F401
                      sequence_to_shmmrs, sequence_to_shmmrs_batch, sequence_to_shmmrs_batch_packed, time_shmmr_batch,
                      time_shmmr_batch_packed)
 from .seqindexdb import (SeqIndexDB, get_shmmr_dots, get_shmmr_pairs_from_seq, pgr_lib_version, read_fastx,  # noqa: F401

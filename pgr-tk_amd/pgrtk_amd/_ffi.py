@@ -74,6 +74,8 @@ _SIGS = [
     ("pgr_last_error", C.c_char_p, [_VP]),
     ("pgr_free", None, [_VP]),
     ("pgr_version", C.c_char_p, []),
+    ("pgr_host_register", C.c_int, [_VP, C.c_size_t]),
+    ("pgr_host_unregister", C.c_int, [_VP]),
     ("pgr_ctx_trim", C.c_int, [_VP]),
     ("pgr_ctx_mem_stats", C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     ("pgr_ctx_set_option", C.c_int, [_VP, C.c_char_p, C.c_int64]),

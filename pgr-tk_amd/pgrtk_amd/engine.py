@@ -49,6 +49,29 @@ class PackedBases:
                 C.c_void_p(self.valid.ctypes.data) if self.valid is not None and self.valid.size else None)
 
 
+class PinnedArrays:
+    """context manager: numpy arrays pinned for the DMA engine while the block runs (pgr_host_register / pgr_host_unregister)"""
+
+    def __init__(self, *arrays):
+        self.arrays = [a for a in arrays if a is not None and a.size]
+        self.done = []
+
+    def __enter__(self):
+        for a in self.arrays:
+            rc = lib().pgr_host_register(C.c_void_p(a.ctypes.data), a.nbytes)
+            if rc != 0:
+                self.__exit__(None, None, None)
+                raise _ffi.PgrError(rc, (lib().pgr_last_error(None) or b"pgr_host_register failed").decode())
+            self.done.append(a)
+        return self
+
+    def __exit__(self, *exc):
+        for a in self.done:
+            lib().pgr_host_unregister(C.c_void_p(a.ctypes.data))
+        self.done = []
+        return False
+
+
 def pack_ascii(seqs, n_threads=0):
     """pgr_pack_ascii: the library's threaded CPU packer (no GPU involved) -> (PackedBases, number of non-ACGT bytes)"""
     arrs, ptrs, lens, n = _ffi.seq_ptrs(seqs)
