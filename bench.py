@@ -662,6 +662,22 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     # context right after a trim of ~100 GB took 2.2 s for its first pass where a fresh process takes 0.30 s -- while memory
     # the process has never touched comes at once (tools/probe/malloc_probe.hip: 16 GiB in 0.2 ms).  The one-shot number is
     # therefore taken in a process of its own, below.)
+    # FIRST the one-shot case, before this process releases anything: device memory that was released a moment ago is slow to
+    # get again for ANY process (the child of an earlier version of this leg, started right after the in-process leg had given
+    # 53 GB back, took 1.8 s for the same build)
+    fresh_process = None
+    try:  # the one-shot case (pgr-mdb.rs:53-111: one process per file list): the same build in a process of its own
+        import subprocess
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "t100_pipe_probe.py"), "pipe", str(n_b), "--json"],
+                           capture_output=True, text=True, timeout=600)
+        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+        j = json.loads(line)
+        fresh_process = {"first_pass": j["passes"][0], "repeat": j["passes"][-1], "context_create_s": j["context_create_s"],
+                                "first_touch_of_4GiB_ms": j.get("first_touch_of_4GiB_ms"),
+                                "same_records_as_this_process": j["passes"][0]["records"],
+                                "what": "tools/t100_pipe_probe.py pipe %d --json in a new process (while this one still holds its memory)" % n_b}
+    except Exception as e:  # noqa: BLE001
+        fresh_process = {"error": repr(e)[:300]}
     fresh = P.Context(ctx.device)
     M = (1 << 64) - 1
 
@@ -738,17 +754,10 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
             out["content_check_error"] = repr(e)[:300]
     del kept, ix
     fresh.close()
-    try:  # the one-shot case (pgr-mdb.rs:53-111: one process per file list): the same build in a process of its own
-        import subprocess
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "t100_pipe_probe.py"), "pipe", str(n_b), "--json"],
-                           capture_output=True, text=True, timeout=600)
-        line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-        j = json.loads(line)
-        out["fresh_process"] = {"first_pass": j["passes"][0], "repeat": j["passes"][-1], "context_create_s": j["context_create_s"],
-                                "same_records_as_this_process": j["passes"][0]["records"] == n_rec,
-                                "what": "tools/t100_pipe_probe.py pipe %d --json in a new process (while this one still holds its memory)" % n_b}
-    except Exception as e:  # noqa: BLE001
-        out["fresh_process"] = {"error": repr(e)[:300]}
+    if fresh_process is not None:
+        if "same_records_as_this_process" in fresh_process:
+            fresh_process["same_records_as_this_process"] = bool(fresh_process["same_records_as_this_process"] == n_rec)
+        out["fresh_process"] = fresh_process
     return out
 
 
@@ -806,6 +815,77 @@ def pipelined_leg(P, ctx, batch, spec, rec_buf, contig_ids, steps, warmup, torch
                     "stream behind an event" % steps}
 
 
+def overlapped_exchange_leg(P, exchange, ctx, xch, use_abi, spec, args, contig_ids, lens, rec_buf, torch, dist, dev, tdev, world, ref_shard_cs,
+                            ref_n_shard, result):
+    """N > 1: the exchange + shard sort of step i BESIDE the tile kernels of step i + 1.  The compute moves to a second context of
+    this process (its own streams, its own copy of the resident batch); the exchange and the index keep the first one and run
+    on a worker thread: sample -> splitters -> partition -> all-to-all -> sort of the rank's key range, while the main thread
+    is inside the next step's shimmer pipeline.  Every rank issues its collectives in the same order (one worker at a time).
+    Content: the last step's shard must have the checksum and the size of the timed loop's shard.  Fills `result` (the caller
+    gives this leg a deadline: a collective that never completes must not cost the headline line)."""
+    import threading
+    ctx2 = P.Context(ctx.device)
+    batch2 = P.Batch.synthetic(lens, seed=args.seed, ctx=ctx2, contig_ids=contig_ids)
+    bufs = [rec_buf, torch.empty_like(rec_buf)]
+    box = {}
+
+    def merge(buf, n):
+        try:
+            torch.cuda.set_device(ctx.device)  # (a new thread starts on device 0)
+            ix = P.Index(spec, ctx=ctx)
+            if use_abi:
+                xch.shard_records(buf.data_ptr(), n, ix)
+            else:
+                exchange.shard_records_torch(ctx, buf.data_ptr(), n, ix)
+            ix.finalize()
+            box["shard"] = ix
+        except Exception as e:  # noqa: BLE001
+            box["error"] = repr(e)[:300]
+
+    def run(k):
+        worker = None
+        for i in range(k):
+            sh = batch2.shmmrs(spec)
+            n = sh.frag_recs_into(bufs[i & 1].data_ptr(), bufs[i & 1].shape[0], sids=contig_ids)
+            del sh
+            if worker is not None:
+                worker.join()
+            if "error" in box:
+                raise RuntimeError(box["error"])
+            worker = threading.Thread(target=merge, args=(bufs[i & 1], n))
+            worker.start()
+        if worker is not None:
+            worker.join()
+        if "error" in box:
+            raise RuntimeError(box["error"])
+    run(max(2, args.warmup))
+    ctx.synchronize()
+    ctx2.synchronize()
+    dist.barrier()
+    k = max(4, args.steps)
+    t0 = time.perf_counter()
+    run(k)
+    ctx.synchronize()
+    ctx2.synchronize()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    t = torch.tensor([dt], dtype=torch.float64, device=tdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    shard = box["shard"]
+    same = [int(v) for v in shard.records_checksum()] == [int(v) for v in ref_shard_cs] and int(shard.n_records) == int(ref_n_shard)
+    ok = torch.tensor([1 if same else 0], dtype=torch.int32, device=tdev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    bp = torch.tensor([float(batch2.total_bases)], dtype=torch.float64, device=tdev)
+    dist.all_reduce(bp, op=dist.ReduceOp.SUM)
+    result.update({"value_overlapped": float(bp.item()) * k / float(t.item()) / 1e9, "ms_per_step_overlapped": float(t.item()) / k * 1e3,
+                   "steps": k, "content_match_vs_timed_loop": bool(int(ok.item())),
+                   "what": "the same step, the merge of step i (record all-to-all by key range + sort of the rank's range) on a worker "
+                           "thread and the first context beside the shimmer pipeline of step i + 1 on a second context; slowest rank, "
+                           "all ranks' bases / time, the last merge inside the clock"})
+    del batch2, box
+    ctx2.close()
+
+
 def self_spawn(n):
     """re-run this command line under torch.distributed.run with n ranks on this node; returns its exit code"""
     import socket
@@ -840,6 +920,7 @@ def main():
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="plumbing test: run the process group + exchange code path even with one rank")
+    ap.add_argument("--no-overlap-leg", action="store_true", help="N>1: skip the leg that runs step i's merge beside step i+1's tiles")
     ap.add_argument("--exchange-timeout", type=int, default=120,
                     help="N>1: seconds the library waits in ncclCommInitRank / for a collective before it aborts its communicator "
                          "(context option exchange_timeout_s); the bench then falls back to the torch.distributed transport")
@@ -1054,6 +1135,26 @@ def main():
                                           torch, local_rank, all_ids)
         except Exception as e:  # noqa: BLE001
             dist_query = {"error": repr(e)[:300]}
+    # the merge of step i beside the tiles of step i + 1 -- last thing before the line, under a deadline (a collective that hangs
+    # in here must not cost the headline: the line is printed all the same and the process leaves without the usual teardown)
+    overlapped, leg_hung = None, False
+    if do_exchange and state.get("shard") is not None and not args.no_overlap_leg:
+        import threading
+        overlapped = {}
+        ref_cs, ref_n = state["shard"].records_checksum(), state["shard"].n_records
+
+        def leg():
+            try:
+                overlapped_exchange_leg(P, exchange, ctx, xch, use_abi, spec, args, contig_ids, lens, rec_buf, torch, dist, dev, tdev, world,
+                                        ref_cs, ref_n, overlapped)
+            except Exception as e:  # noqa: BLE001
+                overlapped["error"] = repr(e)[:300]
+        th = threading.Thread(target=leg, daemon=True)
+        th.start()
+        th.join(timeout=max(90.0, 4.0 * args.exchange_timeout if use_abi else 90.0))
+        if th.is_alive():
+            leg_hung = True
+            overlapped = {"error": "the overlapped leg did not finish within its deadline on rank %d" % rank}
     if rank == 0:
         l1_ms = sum(p[0] for p in profs) / k
         aux_ms = sum(p[1] for p in profs) / k
@@ -1101,6 +1202,10 @@ def main():
             },
             "stage_ms": {"level1_tile": l1_ms, "level1_tail_serial": aux_ms, "level2": l2_ms, "compute_total": tot_ms},
         }
+        if overlapped is not None:
+            out["overlapped"] = overlapped
+            if "value_overlapped" in overlapped:
+                out["value_overlapped"] = overlapped["value_overlapped"]
         if do_exchange:
             out["exchange_ms"] = x_ms   # sample + splitters + partition + counts + all-to-all (max over ranks, mean over steps)
             out["merge_ms"] = m_ms      # sort of the rank's key range -> CSR + lookup tables (pgr_index_finalize)
@@ -1159,6 +1264,9 @@ def main():
         except Exception:
             pass
         print(json.dumps(out), flush=True)
+    if leg_hung:  # (a collective of the overlapped leg is stuck on this rank: no barrier, no teardown -- the line is out)
+        sys.stdout.flush()
+        os._exit(0)
     if use_dist:
         dist.barrier()
         state.clear()

@@ -222,3 +222,38 @@ def test_packed_input_from_pinned_host_memory_and_the_validity_check(oracle, gpu
                 for what, g in (("pageable", got_plain[i]), ("pinned", got_pinned[i]), ("pinned, through the windows", got_windows[i]),
                                 ("resident batch from pinned planes", mm[int(off[i]):int(off[i + 1])])):
                     _same_mm(r, g, "contig %d %s" % (i, what))
+
+
+def _bench_line(extra, nproc, timeout=900):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc)] + extra
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    return json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
+
+
+def test_merge_of_step_i_beside_the_tiles_of_step_i_plus_1():
+    """bench.py's overlapped leg (N > 1): the exchange + shard sort of a step on a worker thread and the first context while the
+    next step's shimmer pipeline runs on a second context.  Two ranks on this box's one GPU over gloo, and one rank through the
+    library's own RCCL communicator (world = 1): the last shard of the leg has the checksum and the size of the timed loop's."""
+    line = _bench_line(["--backend", "gloo", "--single-device", "--steps", "3", "--warmup", "1", "--contigs", "40", "--contig-len", "2000000",
+                        "--queries", "0"], 2)
+    ov = line["overlapped"]
+    assert "error" not in ov, ov
+    assert ov["content_match_vs_timed_loop"] is True and line["value_overlapped"] > 0 and ov["steps"] >= 4
+    assert line["exchange"]["content_match"] is True
+    line = _bench_line(["--force-dist", "--steps", "3", "--warmup", "1", "--contigs", "60", "--contig-len", "2000000", "--queries", "0",
+                        "--no-cpu-baseline"], 1)
+    ov = line["overlapped"]
+    assert "error" not in ov, ov
+    assert ov["content_match_vs_timed_loop"] is True
+    assert line["exchange"]["rccl_ranks_in_the_librarys_communicator"] == 1

@@ -14,6 +14,18 @@ argv = [a for a in sys.argv[1:] if a != "--json"]
 mode = argv[0] if len(argv) > 0 else "pipe"
 n_b = int(argv[1]) if len(argv) > 1 else 10
 n_c, L = 1000, 10_000_000
+# what fresh device memory costs this process right now (4 GiB allocated and written once): milliseconds on a quiet device, a
+# tenth of a second and more when another process or context has just released tens of GB (the driver hands such memory out
+# only once it has been cleared)
+torch.cuda.init()
+torch.cuda.synchronize()
+_t = time.perf_counter()
+_x = torch.empty(4 << 30, dtype=torch.uint8, device="cuda:0")
+_x.zero_()
+torch.cuda.synchronize()
+first_touch_ms = (time.perf_counter() - _t) * 1e3
+del _x
+torch.cuda.empty_cache()
 t_ctx = time.perf_counter()
 ctx = P.Context(0)
 spec = P.make_spec()
@@ -68,7 +80,7 @@ def once():
 
 
 if not as_json:
-    print("%s: context created in %.3f s" % (mode, t_ctx), flush=True)
+    print("%s: context created in %.3f s; first touch of 4 GiB of device memory %.1f ms" % (mode, t_ctx, first_touch_ms), flush=True)
 res = []
 for what in ("fresh context", "again", "again"):
     ctx.mem_stats(reset_peak=True)
@@ -82,4 +94,4 @@ for what in ("fresh context", "again", "again"):
               % (mode, what, n_b * n_c * L // 10**9, a + b, a, b, nr, nk, cs[0], cs[1]), flush=True)
 if as_json:
     import json
-    print(json.dumps({"mode": mode, "bp": n_b * n_c * L, "context_create_s": t_ctx, "passes": res}), flush=True)
+    print(json.dumps({"mode": mode, "bp": n_b * n_c * L, "context_create_s": t_ctx, "first_touch_of_4GiB_ms": first_touch_ms, "passes": res}), flush=True)
