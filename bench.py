@@ -38,7 +38,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 N_SIMD = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 PCIE_PEAK_GBPS = 63.0       # PCIe Gen5 x16, one direction
-QUERY_PROFILE = "r04_query"  # profiles/<dir> whose counters / kernel trace the query leg's replayed fields come from
+QUERY_PROFILE = "r05_query"  # profiles/<dir> whose counters / kernel trace the query leg's replayed fields come from
 
 
 def committed(*parts):
@@ -920,6 +920,7 @@ def main():
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="plumbing test: run the process group + exchange code path even with one rank")
+    ap.add_argument("--no-pipelined-leg", action="store_true", help="skip the pgr_pipe_* leg (value_pipelined): profiling runs of the synchronous step")
     ap.add_argument("--no-overlap-leg", action="store_true", help="N>1: skip the leg that runs step i's merge beside step i+1's tiles")
     ap.add_argument("--exchange-timeout", type=int, default=120,
                     help="N>1: seconds the library waits in ncclCommInitRank / for a collective before it aborts its communicator "
@@ -1219,7 +1220,7 @@ def main():
                 out["cpu_baseline"]["content_match_all_ranks"] = bool(rc_ and all(c.get("content_match") for c in rc_))
         if dist_query is not None:
             out["query"] = dist_query
-        if world == 1 and not do_exchange:
+        if world == 1 and not do_exchange and not args.no_pipelined_leg:
             try:
                 out["pipelined"] = pipelined_leg(P, ctx, batch, spec, rec_buf, contig_ids, args.steps, args.warmup, torch, state)
                 out["value_pipelined"] = out["pipelined"]["value_pipelined"]

@@ -24,7 +24,7 @@ using Tmp_list = pgr::Tmp;  // small RAII device allocation from the context's c
 
 static std::string g_create_error;
 
-extern "C" const char *pgr_version(void) { return "pgr-hip 0.3.0 (gfx950)"; }
+extern "C" const char *pgr_version(void) { return "pgr-hip 0.4.0 (gfx950)"; }
 
 extern "C" const char *pgr_last_error(const pgr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 

@@ -379,11 +379,34 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
     if (synth.on)
         for (uint64_t c = 0; c < synth.n; ++c) midx.push_back(Midx{(uint32_t)c, (size_t)synth.len, synth.name(c), synth.source()});
     if (synth.on && !xch) {
+        // the loader's loop as a software pipeline: two batches in flight, the list stage and the pair
+        // records of batch i beside the tiles of batch i + 1; the append buffer sized from the spec's density up front
+        if (spec.w == 80 && spec.k == 56 && spec.r == 4 && !spec.sketch)
+            (void)pgr_index_reserve(ctx, ix, (uint64_t)((double)synth.n * (double)synth.len * 0.00304 * 1.02) + 4096);
+        pgr_pipe *pipe = nullptr;
+        if ((rc = pgr_pipe_create(ctx, &spec, &pipe))) die(ctx, "pgr_pipe_create", rc);
+        std::vector<pgr_batch *> alive;  // a batch outlives its job
+        auto collect_one = [&]() {
+            if ((rc = pgr_pipe_collect(pipe, nullptr, nullptr))) die(ctx, "pgr_pipe_collect", rc);
+            pgr_batch_destroy(alive.front());
+            alive.erase(alive.begin());
+        };
         for (uint64_t c = 0; c < synth.n; c += per_batch) {
-            std::vector<uint64_t> ids;
-            for (uint64_t q = c; q < std::min(synth.n, c + per_batch); ++q) ids.push_back(q);
-            if ((rc = add_synthetic(ctx, ix, synth, ids))) die(ctx, "pgr_batch_synthetic_ids / pgr_index_add_resident", rc);
+            std::vector<uint64_t> ids, lens;
+            std::vector<uint32_t> sids;
+            for (uint64_t q = c; q < std::min(synth.n, c + per_batch); ++q) {
+                ids.push_back(q);
+                lens.push_back(synth.len);
+                sids.push_back((uint32_t)q);
+            }
+            pgr_batch *b = nullptr;
+            if ((rc = pgr_batch_synthetic_ids(ctx, (uint32_t)ids.size(), lens.data(), synth.seed, ids.data(), &b))) die(ctx, "pgr_batch_synthetic_ids", rc);
+            if (pgr_pipe_in_flight(pipe) == 2) collect_one();
+            if ((rc = pgr_pipe_submit(pipe, b, sids.data(), ix, nullptr, 0))) die(ctx, "pgr_pipe_submit", rc);
+            alive.push_back(b);
         }
+        while (pgr_pipe_in_flight(pipe) > 0) collect_one();
+        pgr_pipe_destroy(pipe);
     } else if (!xch) {
         while (std::getline(fl, path)) {
             while (!path.empty() && (path.back() == '\r' || path.back() == ' ')) path.pop_back();

@@ -14,4 +14,4 @@ from . import cli, mapgraph  # noqa: F401
 from .helpers import (get_principle_bundle_bed_file_for_query, group_smps_by_principle_bundle_id, merge_regions, query_sdb, rc, rc_byte_seq, rc_u8_seq,  # noqa: F401
                       string_to_u8, u8_to_string)
 
-__version__ = "0.3.0"
+__version__ = "0.4.0"

@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --queries 0 --no-extras"   # only full-size launches of every kernel (the first launches run at ramping clocks: enough steps for the average to mean something)
+B="python $R/bench.py --steps 10 --warmup 3 --no-cpu-baseline --queries 0 --no-extras --no-pipelined-leg"   # only full-size launches of every kernel (the first launches run at ramping clocks: enough steps for the average to mean something)
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o p -- $B > $O/trace.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $B > $O/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $B > $O/pmc_write.log 2>&1
@@ -26,5 +26,7 @@ rocprofv3 --kernel-trace --output-format csv -d $O/q_trace -o q -- python $R/too
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/q_pmc_fetch -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/q_pmc_write -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/q_pmc_sq -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_sq.log 2>&1
+# the software pipeline (pgr_pipe_*): kernel trace of the pipelined leg alone -- which kernels run beside the tile kernel, and what it costs it
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe_trace -o p -- python $R/tools/probe/pipe_probe.py 1000 8 > $O/pipe_trace.log 2>&1
 python $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 ls -R $O | head -40
