@@ -920,6 +920,7 @@ def main():
                     help="plumbing test on a 1-GPU box: every rank uses cuda:0 (use with --backend gloo)")
     ap.add_argument("--force-dist", action="store_true",
                     help="plumbing test: run the process group + exchange code path even with one rank")
+    ap.add_argument("--two-calls", action="store_true", help="the step as two C calls (pgr_shmmrs_compute + pgr_shmmrs_to_frag_recs_device), as in round 4")
     ap.add_argument("--no-pipelined-leg", action="store_true", help="skip the pgr_pipe_* leg (value_pipelined): profiling runs of the synchronous step")
     ap.add_argument("--no-overlap-leg", action="store_true", help="N>1: skip the leg that runs step i's merge beside step i+1's tiles")
     ap.add_argument("--exchange-timeout", type=int, default=120,
@@ -1008,8 +1009,14 @@ def main():
             fallback["note"] = what
 
     def step():
-        sh = batch.shmmrs(spec)
-        n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=contig_ids)  # this rank's pair records
+        # shimmer lists + this rank's pair records: ONE call and one wait (pgr_shmmrs_compute_recs; --two-calls: the round-4 step,
+        # pgr_shmmrs_compute then pgr_shmmrs_to_frag_recs_device -- same kernels but for the records' offsets, which the fused call
+        # derives on the device)
+        if args.two_calls:
+            sh = batch.shmmrs(spec)
+            n = sh.frag_recs_into(rec_buf.data_ptr(), rec_buf.shape[0], sids=contig_ids)
+        else:
+            sh, n = batch.shmmrs_and_recs(spec, rec_buf.data_ptr(), rec_buf.shape[0], sids=contig_ids)
         p = ctx.last_prof()
         x_ms = m_ms = 0.0
         if do_exchange:

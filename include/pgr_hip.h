@@ -224,6 +224,12 @@ int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s, const uint
                                    int query_side, pgr_frag_rec *d_out, uint64_t capacity,
                                    uint64_t *n_out);
 
+/* pgr_shmmrs_compute + pgr_shmmrs_to_frag_recs_device (index side) in one call with one wait: the pair records are derived on the
+ * device behind the list stage and written to d_recs (DEVICE memory, recs_capacity records; *n_pairs = records written).
+ * PGR_ERR_INVALID_ARG when the buffer is too small (nothing is returned then). */
+int pgr_shmmrs_compute_recs(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *sids, pgr_frag_rec *d_recs,
+                            uint64_t recs_capacity, pgr_shmmrs **out, uint64_t *n_pairs);
+
 /* ------------------------------------------------------------------ a software pipeline over resident batches
  * The reference's loaders call get_shmmrs_from_seqs batch after batch (load_index_from_reader, pgr-db/src/seq_db.rs:541-571:
  * read <= 129 contigs, compute, insert, repeat).  pgr_shmmrs_compute is that call, and it returns when its batch is done:

@@ -176,13 +176,15 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
             PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
             launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
         }
-        PGR_HIP(ctx, hipMemcpyAsync(d_desc, h_img, desc_bytes, hipMemcpyHostToDevice, st));
+        // (descriptors up and states down by kernels of this stream, not by a copy engine -- which would take them in the order of
+        // its queue, behind the staging copies of a pipelined host call: pipeline.hip plan())
+        launch_copy_words(st, (uint32_t *)d_desc, (const uint32_t *)h_img, desc_bytes / 4);
         PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
         // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
         if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
         isl_lap("chunks listed, buffers ready", round);
         launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
-        PGR_HIP(ctx, hipMemcpyAsync(h_img + desc_bytes, d_in, down_bytes, hipMemcpyDeviceToHost, st));
+        launch_copy_words(st, (uint32_t *)(h_img + desc_bytes), (const uint32_t *)d_in, down_bytes / 4);
         isl_lap("chunk kernel enqueued", round);
         PGR_HIP(ctx, hipStreamSynchronize(st));
         isl_lap("states back on the host", round);
@@ -896,11 +898,11 @@ int ShmmrJob::stage1() {
         const bool pre = b->host_saw_invalid && !b->h_n_invalid.empty() && n_tiles && !ctx->opt.no_pre_islands;
         if (pre) {
             const size_t tb = scan_max_temp_bytes(n_tiles);
-            if ((r = ctx->ws_scan_tmp.ensure(ctx, tb)) || (r = ctx->ensure_imail(n_tiles))) return r;
+            if ((r = ctx->ws_scan_tmp.ensure(ctx, tb)) || (r = ctx->ensure_imail((size_t)n_tiles + 4))) return r;
             PGR_HIP(ctx, scan_max_inplace(st, ctx->ws_scan_tmp.p, tb, (uint64_t *)ctx->ws_tile_lv.p, n_tiles));
             PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[0], st));
             PGR_HIP(ctx, hipStreamWaitEvent(ctx->pre_stream, ctx->pre_ev[0], 0));
-            PGR_HIP(ctx, hipMemcpyAsync(ctx->imail, d_tflags, n_tiles, hipMemcpyDeviceToHost, ctx->pre_stream));
+            launch_copy_words(ctx->pre_stream, (uint32_t *)ctx->imail, (const uint32_t *)d_tflags, ((uint64_t)n_tiles + 3) / 4);  // (d_tflags: 4-byte aligned, 64 bytes of slack behind it)
             PGR_HIP(ctx, hipEventRecord(ctx->pre_ev[1], ctx->pre_stream));
         }
         PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));  // (prof.level1_ms is the tile kernel alone: descriptors and flags are in front of it)
@@ -1131,7 +1133,7 @@ int ShmmrJob::enqueue_pass() {
     if (from <= 1) {
         if ((rc = stage1())) return rc;
         if (early_sync && !optimistic) {
-            PGR_HIP(ctx, hipMemcpyAsync(mbox, d_cursor, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, sf));
+            launch_copy_words(sf, (uint32_t *)mbox, (const uint32_t *)d_cursor, 8);  // (by a kernel: see plan())
             if (hipStreamSynchronize(sf) != hipSuccess || hipGetLastError() != hipSuccess)
                 return ctx->fail(PGR_ERR_DEVICE, "level-1 kernels failed on the device");
             l1_alloc_seen = mbox[0];
@@ -1300,6 +1302,71 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     job.dbg_t = ctx->opt.debug_times != 0;
     job.dbg_t0 = std::chrono::steady_clock::now();
     return job.run_sync(out);  // (a failing pass releases the result and its device blocks with the job)
+}
+
+// B1 + seq_to_index in ONE call and ONE wait: the index-side pair records (seq_db.rs:381-400) are derived on the device behind the
+// list stage (counts and offsets never visit the host) and land in the caller's device buffer; what pgr_shmmrs_compute followed
+// by pgr_shmmrs_to_frag_recs_device does in two calls, two waits and two pageable table copies.
+extern "C" int pgr_shmmrs_compute_recs(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const uint32_t *sids, pgr_frag_rec *d_recs,
+                                       uint64_t recs_capacity, pgr_shmmrs **out, uint64_t *n_pairs) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (!b || !out || !n_pairs) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    *n_pairs = 0;
+    int rc = check_spec(ctx, spec);
+    if (rc) return rc;
+    if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    {   // batches of short contigs: the one-launch kernel, then the records from its (host-known) offsets
+        bool handled = false;
+        if ((rc = shmmrs_compute_small(ctx, b, spec, nullptr, out, handled))) return rc;
+        if (handled) {
+            rc = pgr_shmmrs_to_frag_recs_device(ctx, *out, sids, 0, d_recs, recs_capacity, n_pairs);
+            if (rc) {
+                pgr_shmmrs_destroy(*out);
+                *out = nullptr;
+            }
+            return rc;
+        }
+    }
+    if ((rc = ctx->ensure_qmail())) return rc;
+    uint64_t *qm = (uint64_t *)ctx->qmail;
+    qm[0] = 0;
+    const uint32_t n = b->n;
+    ShmmrJob job;
+    job.ctx = ctx;
+    job.b = b;
+    job.spec = *spec;
+    job.rids = nullptr;
+    job.padding = 0;
+    job.sf = job.sb = ctx->stream;
+    job.dbg_t = ctx->opt.debug_times != 0;
+    job.dbg_t0 = std::chrono::steady_clock::now();
+    ShmmrJob *jp = &job;
+    job.post = [ctx, jp, n, sids, d_recs, recs_capacity, qm](hipStream_t st, const pgr_mm128 *d_list, const uint64_t *d_off, uint64_t cap,
+                                                             const uint64_t *d_count) -> int {
+        int r;
+        if ((r = ctx->ws_rec_off.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t)))) return r;
+        uint32_t *d_sids = nullptr;
+        if (sids && n) {  // (through the rids' place in the pinned mailbox, read by a kernel: ShmmrJob::plan)
+            if ((r = ctx->ws_rids.ensure(ctx, (size_t)n * sizeof(uint32_t)))) return r;
+            uint32_t *up = (uint32_t *)(jp->mbox + N_STATUS + (size_t)n + 1) + n + 1;
+            memcpy(up, sids, (size_t)n * sizeof(uint32_t));
+            launch_copy_words(st, (uint32_t *)ctx->ws_rids.p, up, n);
+            d_sids = (uint32_t *)ctx->ws_rids.p;
+        }
+        launch_frag_recs_dev(st, d_list, d_off, n, cap, d_count, 0, (uint64_t *)ctx->ws_rec_off.p, d_recs, recs_capacity, nullptr, d_sids);
+        launch_copy_words(st, (uint32_t *)qm, (const uint32_t *)((const uint64_t *)ctx->ws_rec_off.p + n), 2);
+        return PGR_OK;
+    };
+    if ((rc = job.run_sync(out))) return rc;
+    *n_pairs = qm[0];
+    if (*n_pairs > recs_capacity || (*n_pairs && !d_recs)) {
+        pgr_shmmrs_destroy(*out);
+        *out = nullptr;
+        return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the pair records");
+    }
+    return PGR_OK;
 }
 
 // ------------------------------------------------------------------------------------------------

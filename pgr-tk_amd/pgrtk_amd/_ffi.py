@@ -126,6 +126,7 @@ _SIGS = [
     ("pgr_index_add_shmmrs", C.c_int, [_VP, _VP, _VP, C.c_uint64, C.c_int]),
     ("pgr_shmmrs_to_frag_recs_device", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), C.c_int, _VP, C.c_uint64,
                                                  C.POINTER(C.c_uint64)]),
+    ("pgr_shmmrs_compute_recs", C.c_int, [_VP, _VP, C.POINTER(Spec), C.POINTER(C.c_uint32), _VP, C.c_uint64, _PVP, C.POINTER(C.c_uint64)]),
     ("pgr_pipe_create", C.c_int, [_VP, C.POINTER(Spec), _PVP]),
     ("pgr_pipe_submit", C.c_int, [_VP, _VP, C.POINTER(C.c_uint32), _VP, _VP, C.c_uint64]),
     ("pgr_pipe_collect", C.c_int, [_VP, _PVP, C.POINTER(C.c_uint64)]),

@@ -137,6 +137,15 @@ class Batch:
         self.ctx.check(lib().pgr_shmmrs_compute(self.ctx.handle, self._h, C.byref(spec), rp, int(padding), C.byref(h)))
         return Shmmrs(self.ctx, h, self.n)
 
+    def shmmrs_and_recs(self, spec, rec_ptr, rec_capacity, sids=None):
+        """pgr_shmmrs_compute_recs: the shimmer lists and, into caller-owned DEVICE memory, the index-side pair records, in one
+        call and one wait -> (Shmmrs, number of records)"""
+        keep, sp = _u32_array(sids, self.n)
+        h, n_out = C.c_void_p(), C.c_uint64()
+        self.ctx.check(lib().pgr_shmmrs_compute_recs(self.ctx.handle, self._h, C.byref(spec), sp, C.c_void_p(rec_ptr), int(rec_capacity),
+                                                     C.byref(h), C.byref(n_out)))
+        return Shmmrs(self.ctx, h, self.n), int(n_out.value)
+
     def close(self):
         if self._h:
             lib().pgr_batch_destroy(self._h)

@@ -75,6 +75,15 @@ def test_two_batches_in_flight_equal_the_synchronous_calls_and_the_oracle(oracle
         recs_s = tmp[:n_s].cpu().numpy().view(P.FRAG_REC).reshape(-1)
         assert len(recs) == n_s and recs.tobytes() == recs_s.tobytes(), "pair records of batch %d" % bi
         n_flagged += gpu_ctx.last_prof().n_serial_contigs > 0
+        # the fused call (pgr_shmmrs_compute_recs): the same lists and records in one call and one wait
+        tmp2 = torch.zeros_like(tmp)
+        sh_f, n_f = b.shmmrs_and_recs(spec, tmp2.data_ptr(), tmp2.shape[0], sids=sids[bi])
+        mm_f, off_f = sh_f.download()
+        assert n_f == n_s and np.array_equal(off_f, off_s) and mm_f.tobytes() == mm_s.tobytes(), "fused call, batch %d" % bi
+        assert tmp2[:n_f].cpu().numpy().tobytes() == tmp[:n_s].cpu().numpy().tobytes(), "fused call records, batch %d" % bi
+        if n_s > 1:
+            with pytest.raises(P.PgrError):
+                b.shmmrs_and_recs(spec, tmp2.data_ptr(), n_s - 1, sids=sids[bi])
         ro = 0
         for i, q in enumerate(s):
             ref = oracle.sequence_to_shmmrs(i, q, osp)
