@@ -105,6 +105,8 @@ const char *pgr_version(void);
  *                             context's first pipe is created
  *   no_direct_h2d             packed input in pinned host memory is copied through the staging windows all the same, for A/B
  *   lds_match                 pgr_pipe: the back stream's kernels occupy exactly the tile kernel's LDS per workgroup, or none, for A/B
+ *   pipe_small_list           pgr_pipe: the list kernel of a pipelined job runs 512-element workgroups (14 KB of LDS), for A/B
+ *   front_priority            1: the context's stream gets the device's highest priority (environment only: read at pgr_ctx_create), for A/B
  *   pipe_staged_records       pgr_pipe: index jobs always stage their records and copy them in when collected, for A/B
  * Unknown names: PGR_ERR_INVALID_ARG. */
 /* Device memory of a context.  Results, batches and indexes come from a caching allocator (a released block is kept for the next

@@ -48,7 +48,8 @@ const std::vector<OptionName> &option_names() {
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"island_chunk_min", &O::island_chunk_min},
         {"back_priority", &O::back_priority}, {"pipe_staged_records", &O::pipe_staged_records},
-        {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d}};
+        {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d},
+        {"pipe_small_list", &O::pipe_small_list}, {"front_priority", &O::front_priority}};
     return v;
 }
 }  // namespace
@@ -79,22 +80,6 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     }
     pgr_ctx *ctx = new pgr_ctx();
     ctx->device = device;
-    e = hipSetDevice(device);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->d2h_ev[i], hipEventDisableTiming);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->pre_ev[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking);
-    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->cev[i]);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
-    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_alloc);
-    if (e != hipSuccess) {
-        g_create_error = std::string("context setup: ") + hipGetErrorString(e);
-        delete ctx;
-        return PGR_ERR_DEVICE;
-    }
     for (const OptionName &o : option_names()) {
         std::string env = "PGR_";
         for (const char *c = o.name; *c; ++c) env += (char)toupper((unsigned char)*c);
@@ -112,6 +97,28 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
             else if (!is_numeric) ctx->opt.*(o.field) = 1;
             else fprintf(stderr, "[pgr] %s=%s is not a number: the option keeps its default (%lld)\n", env.c_str(), v, (long long)(ctx->opt.*(o.field)));
         }
+    }
+    e = hipSetDevice(device);
+    if (e == hipSuccess && ctx->opt.front_priority > 0) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, hi);
+    } else if (e == hipSuccess) {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    }
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->d2h_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->d2h_ev[i], hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&ctx->pre_ev[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre_stream, hipStreamNonBlocking);
+    for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&ctx->cev[i]);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_end);
+    if (e == hipSuccess) e = hipEventCreate(&ctx->ev_alloc);
+    if (e != hipSuccess) {
+        g_create_error = std::string("context setup: ") + hipGetErrorString(e);
+        delete ctx;
+        return PGR_ERR_DEVICE;
     }
     *out = ctx;
     return PGR_OK;

@@ -465,14 +465,16 @@ __device__ __forceinline__ void reduce_round_wave(FusedLds &L, const uint16_t *c
 // ([n_segs+1]); out = fixed block slots + overflow region; cursor[0] overflow allocated, [1] overflow flag.
 using FusedArgs = FusedArgsPub;
 
-template <int EMAX>
+// FB: list elements a workgroup owns (FUSED_B = 1024; 512 for the workgroups of a pipelined job: 14 KB of LDS, which fit BESIDE the
+// four tile workgroups of a CU -- 4 x 36 352 of 163 840 bytes leave 18 432)
+template <int EMAX, int FB>
 __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     using FusedLds = FusedLdsT<EMAX>;
     constexpr int FUSED_CMAX = FusedLds::CMAX;
     __shared__ FusedLds L;
     const uint32_t t = threadIdx.x;
     const uint64_t total = *a.total;
-    const uint64_t core_lo = (uint64_t)blockIdx.x * FUSED_B;
+    const uint64_t core_lo = (uint64_t)blockIdx.x * FB;
     if (core_lo >= total) {  // the grid is an upper bound (sized before the level-1 count is known): nothing to do here
         if (t == 0) {
             a.blk_off[blockIdx.x] = 0;
@@ -480,7 +482,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
         }
         return;
     }
-    uint64_t core_hi = core_lo + FUSED_B;
+    uint64_t core_hi = core_lo + FB;
     if (core_hi > total) core_hi = total;
     const uint64_t lo = core_lo >= a.halo ? core_lo - a.halo : 0;
     uint64_t hi = core_hi + a.halo;
@@ -741,11 +743,11 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
 
 // first segment of every fused workgroup: largest s with seg_dst[s] <= max(0, b*FUSED_B - halo)
 __global__ void block_first_seg_kernel(const uint64_t *__restrict__ seg_dst, uint32_t n_segs, uint32_t n_blocks,
-                                       uint32_t halo, uint32_t *__restrict__ blk_first_seg, uint32_t *__restrict__ blk_cnt) {
+                                       uint32_t halo, uint32_t *__restrict__ blk_first_seg, uint32_t *__restrict__ blk_cnt, uint32_t fb) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b == 0) blk_cnt[n_blocks] = 0;  // sentinel of the scan over the block counts (saves a memset per call)
     if (b >= n_blocks) return;
-    const uint64_t core_lo = (uint64_t)b * FUSED_B;
+    const uint64_t core_lo = (uint64_t)b * fb;
     const uint64_t lo = core_lo >= halo ? core_lo - halo : 0;
     uint32_t s_lo = 0, s_hi = n_segs;
     while (s_hi - s_lo > 1) {
@@ -794,19 +796,21 @@ __global__ void patch_rid_kernel(pgr_mm128 *__restrict__ mm, const uint64_t *__r
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks) {
     if (n_blocks == 0) return;
     hipLaunchKernelGGL(block_first_seg_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, st, a.seg_dst, a.n_segs,
-                       n_blocks, a.halo, a.blk_first_seg, a.blk_cnt);
+                       n_blocks, a.halo, a.blk_first_seg, a.blk_cnt, a.block_elems == 512u && a.halo <= 32 ? 512u : (uint32_t)FUSED_B);
     // (dynamic LDS on top of the static block: the workgroup then occupies exactly a.lds_match bytes of its CU)
     auto pad_for = [&](const void *f) -> uint32_t {
         hipFuncAttributes at;
         if (!a.lds_match || hipFuncGetAttributes(&at, f) != hipSuccess || at.sharedSizeBytes >= a.lds_match) return 0u;
         return a.lds_match - (uint32_t)at.sharedSizeBytes;
     };
-    if (a.halo <= 32)
-        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL>), dim3(n_blocks), dim3(FUSED_T),
-                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_SMALL>), st, a);
+    if (a.halo <= 32 && a.block_elems == 512u)
+        hipLaunchKernelGGL((fused_select_kernel<512 + 2 * 32, 512>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+    else if (a.halo <= 32)
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>), dim3(n_blocks), dim3(FUSED_T),
+                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>), st, a);
     else
-        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG>), dim3(n_blocks), dim3(FUSED_T),
-                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_BIG>), st, a);
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG, FUSED_B>), dim3(n_blocks), dim3(FUSED_T),
+                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_BIG, FUSED_B>), st, a);
 }
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
                            uint64_t *off, const unsigned long long *cursor, const uint64_t *total1, uint64_t *status) {

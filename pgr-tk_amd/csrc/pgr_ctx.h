@@ -78,6 +78,8 @@ struct pgr_ctx {
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B
+        int64_t pipe_small_list = 0;     // pgr_pipe: 1 = the list kernel runs 512-element workgroups (14 KB of LDS: they fit beside a CU's four tile workgroups), for A/B
+        int64_t front_priority = 0;      // 1: the context's stream is created with the device's highest priority (read at pgr_ctx_create only), for A/B
         int64_t no_direct_h2d = 0;       // packed input in pinned host memory goes through the staging windows all the same, for A/B
         int64_t lds_match = 0;           // pgr_pipe: 1 = the back stream's kernels occupy the tile kernel's LDS size or none (padded list kernel, LDS-free scans), for A/B
         int64_t pipe_staged_records = 0; // pgr_pipe: never place an index job's records through the device cursor (always stage + copy), for A/B

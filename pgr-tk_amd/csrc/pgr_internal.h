@@ -222,6 +222,7 @@ struct FusedArgsPub {
     uint64_t *blk_off;
     uint32_t *blk_cnt;
     uint32_t *blk_first_seg;  // [n_blocks] scratch
+    uint32_t block_elems = 1024;  // list elements per workgroup: FUSED_BLOCK_ELEMS, or 512 (halo <= 32 only): small workgroups for a pipe's back stream
     uint32_t lds_match = 0;   // > 0: every workgroup occupies exactly this much LDS (the tile kernel's, when the two run side by side)
 };
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);

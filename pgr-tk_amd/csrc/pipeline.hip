@@ -607,6 +607,7 @@ struct ShmmrJob {
     pgr_prof prof;
     bool early_sync = false, pad_fix = false, do_reduce = false;
     uint32_t halo = 0, slot2 = 0;
+    uint32_t fb = FUSED_BLOCK_ELEMS;  // list elements per workgroup of the fused kernel (512 for a pipelined job: see level2.hip)
     uint64_t serial_base = 0;  // first element of the serial regions inside the level-1 buffer
     bool islands_done = false;
     bool l2_cursor_clean = false;  // the list stage's cursor words were cleared by stage 1's memset
@@ -794,7 +795,11 @@ int ShmmrJob::plan() {
     pad_fix = padding && !sketch && spec.r > 1;
     do_reduce = !sketch && spec.r > 1;
     halo = do_reduce ? 2 * spec.r * spec.r : 1;
-    slot2 = do_reduce ? 256u : FUSED_BLOCK_ELEMS;
+    // (512-element workgroups for a pipelined job, measured and NOT the default: 14 KB of LDS fit beside a CU's four tile workgroups,
+    // but the dispatcher gives them tile slots all the same -- the tile kernel beside them took 20.6 ms instead of 20.1 with the
+    // 1024-element workgroups; with the context's stream at the highest priority they do not run beside the tiles at all)
+    fb = (sf != sb && do_reduce && halo <= 32 && ctx->opt.pipe_small_list) ? 512u : FUSED_BLOCK_ELEMS;
+    slot2 = do_reduce ? fb / 4 : fb;
     serial_base = 0;
     islands_done = false;
     l2_cursor_clean = false;
@@ -1002,7 +1007,7 @@ int ShmmrJob::begin_result() {
     // (low-complexity sequence is denser than that: what the last call with this spec saw per base, like the result's size)
     if (ctx->est_l1_key == l1_key && ctx->est_l1_dens > dens)
         l1_est = std::min<uint64_t>(l1_bound, std::max<uint64_t>(l1_est, (uint64_t)((double)b->total_bases * ctx->est_l1_dens * 1.04) + 16ull * n + 8192));
-    n_blocks = (uint32_t)((l1_est + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
+    n_blocks = (uint32_t)((l1_est + fb - 1) / fb);
     cap2 = (uint64_t)((double)l1_est * 0.01) + 65536;
     if (ctx->est_l1_key == l1_key && ctx->est_l2_ovf > 0) cap2 = std::max<uint64_t>(cap2, (uint64_t)((double)b->total_bases * ctx->est_l2_ovf * 1.1) + 65536);
     spec_key = (double)spec.w * 1e9 + spec.k * 1e6 + spec.r * 1e4 + spec.min_span + (sketch ? 0.5 : 0.0) + (padding ? 0.25 : 0.0);
@@ -1079,6 +1084,7 @@ int ShmmrJob::stage3() {
     fa.blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
     fa.blk_first_seg = (uint32_t *)ctx->ws_start_rank.p;
     fa.lds_match = lds_match;
+    fa.block_elems = fb;
     launch_fused_select_pub(st, fa, n_blocks);
     return PGR_OK;
 }
@@ -1186,8 +1192,8 @@ int ShmmrJob::decide(bool &done) {
         return PGR_OK;
     }
     prof.n_level1 = total1;
-    if (total1 > (uint64_t)n_blocks * FUSED_BLOCK_ELEMS) {  // denser than the estimate: the grid missed the tail
-        n_blocks = (uint32_t)((total1 + FUSED_BLOCK_ELEMS - 1) / FUSED_BLOCK_ELEMS);
+    if (total1 > (uint64_t)n_blocks * fb) {  // denser than the estimate: the grid missed the tail
+        n_blocks = (uint32_t)((total1 + fb - 1) / fb);
         cap2 = std::max<uint64_t>(cap2, (uint64_t)((double)total1 * 0.01) + 65536);
         from = 3;
         return PGR_OK;

@@ -19,6 +19,7 @@ SIDS = list(range(n_c)) if os.environ.get("PROBE_SIDS") else None
 for prio in [int(v) for v in os.environ.get("PROBE_PRIOS", "1,0,-1").split(",")]:
     os.environ["PGR_BACK_PRIORITY"] = str(prio)
     ctx = P.Context(0)
+    print("   options: front_priority %d, pipe_small_list %d, lds_match %d" % (ctx.get_option("front_priority"), ctx.get_option("pipe_small_list"), ctx.get_option("lds_match")), flush=True)
     b = P.Batch.synthetic([L] * n_c, seed=2, ctx=ctx)
     probe = b.shmmrs(spec)
     bufs = [torch.empty((int(probe.n_pairs * 1.05) + 16, exchange.REC_WORDS), dtype=torch.int64, device="cuda:0") for _ in range(2)]
