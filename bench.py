@@ -665,6 +665,8 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     # FIRST the one-shot case, before this process releases anything: device memory that was released a moment ago is slow to
     # get again for ANY process (the child of an earlier version of this leg, started right after the in-process leg had given
     # 53 GB back, took 1.8 s for the same build)
+    free_b, total_b = torch.cuda.mem_get_info(ctx.device)
+    held_b = ctx.mem_stats()[0]
     fresh_process = None
     try:  # the one-shot case (pgr-mdb.rs:53-111: one process per file list): the same build in a process of its own
         import subprocess
@@ -711,6 +713,8 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     bp = n_b * n_c * L
     out = {"bp": bp, "s": t2 - t0, "Gbp_per_s": bp / (t2 - t0) / 1e9, "batches_s": t1 - t0, "sort_into_frag_map_s": t2 - t1,
            "context": "fresh context inside the bench process (created for this leg, beside the bench's own)",
+           "device_memory_free_before_this_leg_bytes": int(free_b), "device_memory_total_bytes": int(total_b),
+           "held_by_the_benchs_own_context_bytes": int(held_b),
            "peak_device_bytes_of_the_allocator": peak0,
            "repeat": {"s": r2 - r0, "Gbp_per_s": bp / (r2 - r0) / 1e9, "batches_s": r1 - r0, "sort_into_frag_map_s": r2 - r1,
                       "peak_device_bytes_of_the_allocator": peak1,

@@ -7,7 +7,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TILE, QUERY, UBENCH = "r04_tile", "r04_query", "r04_ubench"   # the round's evidence directories
+TILE, QUERY, UBENCH = "r05_tile", "r05_query", "r04_ubench"   # the round's evidence directories
 
 
 def _load(*parts):
