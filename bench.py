@@ -658,13 +658,11 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     import torch
     n_b, n_c, L = 10, 1000, 10_000_000
     ctx.synchronize()
-    # (NOT ctx.trim(): device memory that a process has given back with hipFree is slow to get again -- measured here: a fresh
-    # context right after a trim of ~100 GB took 2.2 s for its first pass where a fresh process takes 0.30 s -- while memory
-    # the process has never touched comes at once (tools/probe/malloc_probe.hip: 16 GiB in 0.2 ms).  The one-shot number is
-    # therefore taken in a process of its own, below.)
-    # FIRST the one-shot case, before this process releases anything: device memory that was released a moment ago is slow to
-    # get again for ANY process (the child of an earlier version of this leg, started right after the in-process leg had given
-    # 53 GB back, took 1.8 s for the same build)
+    # (NOT ctx.trim().  In a process that has allocated and released many GiB, every so-many-th large hipMalloc blocks for up to
+    # seconds while the driver clears released memory (tools/probe/big_malloc_probe.py: torch alone shows it; the gaps and the
+    # waits both grow with the number of large allocations) -- the fresh context's first 12-13 GB allocation below may be that
+    # one.  The one-shot number is therefore taken in a process of its own, FIRST, before this process releases anything more
+    # (the child of an earlier version of this leg, started right after the in-process leg had given 53 GB back, took 1.8 s).)
     free_b, total_b = torch.cuda.mem_get_info(ctx.device)
     held_b = ctx.mem_stats()[0]
     fresh_process = None
@@ -689,6 +687,7 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
         t0 = time.perf_counter()
         ix = P.Index(spec, ctx=fresh)
         ix.reserve(int(n_b * n_c * L * 0.003036 * 1.01) + 4096)  # pair records per base at (80, 56, 4, 64), SURVEY 8
+        calls = [("pgr_index_reserve", time.perf_counter() - t0)]
         pipe = P.Pipe(spec, ctx=fresh)
         kept = []
         for bi in range(n_b):
@@ -696,8 +695,11 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
             b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=fresh, contig_ids=ids)
             if pipe.in_flight == 2:
                 kept.append(pipe.collect(want_shmmrs=keep))
+            ts = time.perf_counter()
             pipe.submit(b, sids=ids, index=ix)
+            calls.append(("pgr_pipe_submit of batch %d" % bi, time.perf_counter() - ts))
             del b
+        slowest_call.append(max(calls, key=lambda c: c[1]))
         while pipe.in_flight:
             kept.append(pipe.collect(want_shmmrs=keep))
         t1 = time.perf_counter()
@@ -706,6 +708,7 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
         t2 = time.perf_counter()
         pipe.close()
         return t0, t1, t2, ix, kept, fresh.mem_stats()[1]
+    slowest_call = []
     t0, t1, t2, ix, _, peak0 = once(False)
     n_rec, n_keys = ix.n_records, ix.n_keys
     del ix
@@ -716,6 +719,11 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
            "device_memory_free_before_this_leg_bytes": int(free_b), "device_memory_total_bytes": int(total_b),
            "held_by_the_benchs_own_context_bytes": int(held_b),
            "peak_device_bytes_of_the_allocator": peak0,
+           "slowest_enqueueing_call": {"call": slowest_call[0][0], "s": slowest_call[0][1],
+                                       "note": "the calls that only enqueue (and allocate): a first pass of seconds instead of 0.25 s is "
+                                               "ONE of them waiting in a 12-13 GB hipMalloc while the driver clears memory this process "
+                                               "released earlier (every so-many-th large hipMalloc of a process that keeps allocating and "
+                                               "freeing GiBs: profiles/r05_target/big_malloc_probe.txt, torch alone shows it; DESIGN 5)"},
            "repeat": {"s": r2 - r0, "Gbp_per_s": bp / (r2 - r0) / 1e9, "batches_s": r1 - r0, "sort_into_frag_map_s": r2 - r1,
                       "peak_device_bytes_of_the_allocator": peak1,
                       "note": "the same again in that context: every buffer comes from its cache"},
