@@ -108,6 +108,10 @@ const char *pgr_version(void);
  *   pipe_small_list           pgr_pipe: the list kernel of a pipelined job runs 512-element workgroups (14 KB of LDS), for A/B
  *   front_priority            1: the context's stream gets the device's highest priority (environment only: read at pgr_ctx_create), for A/B
  *   pipe_staged_records       pgr_pipe: index jobs always stage their records and copy them in when collected, for A/B
+ *   direct_query_result       batches of short queries: the per-query kernel writes the host's result block itself (single pass, sections
+ *                             placed from the previous batch's counts); an experiment, measured slower than two passes + download
+ *   direct_query_lds_kb       ... with this much LDS per workgroup (fewer queries resident at once); -1: its block in device memory
+ *                             (timing only: no result is delivered).  direct_query_results_delivered: a counter (read only)
  * Unknown names: PGR_ERR_INVALID_ARG. */
 /* Device memory of a context.  Results, batches and indexes come from a caching allocator (a released block is kept for the next
  * request of its size: the steady state of a loop over batches allocates nothing); pgr_ctx_trim gives the cached blocks (not

@@ -42,7 +42,7 @@ const std::vector<OptionName> &option_names() {
     static const std::vector<OptionName> v = {
         {"debug", &O::debug}, {"debug_times", &O::debug_times}, {"gpu_pack", &O::gpu_pack}, {"no_small_path", &O::no_small_path},
         {"no_pipeline", &O::no_pipeline}, {"early_sync_bp", &O::early_sync_bp}, {"index_full_sort", &O::index_full_sort},
-        {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query},
+        {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query}, {"direct_query_result", &O::direct_query_result}, {"direct_query_results_delivered", &O::direct_query_results_delivered}, {"direct_query_lds_kb", &O::direct_query_lds_kb},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s},
@@ -90,7 +90,7 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
             // switches: PGR_X=1, PGR_X=<number>, or a bare PGR_X= / PGR_X=on.  Options that ARE a number (a time-out, a size)
             // keep their default when the value is not one: "PGR_EXCHANGE_TIMEOUT_S=5m" must not become a 1-second time-out
             static const char *const numeric[] = {"early_sync_bp", "fused_query_hits", "exchange_timeout_s", "exchange_collective_timeout_s",
-                                                  "island_chunk_min", "back_priority"};
+                                                  "island_chunk_min", "back_priority", "direct_query_lds_kb"};
             bool is_numeric = false;
             for (const char *nm : numeric) is_numeric = is_numeric || !strcmp(nm, o.name);
             if (number) ctx->opt.*(o.field) = (int64_t)x;

@@ -134,6 +134,10 @@ struct QueryFusedRun {
 private:
     void *d_cnt = nullptr, *d_offs = nullptr, *d_shp = nullptr, *d_sf = nullptr, *d_img = nullptr, *d_qrec = nullptr, *d_rec_off = nullptr;
     size_t cnt_bytes = 0, offs_bytes = 0, shp_bytes = 0, sf_bytes = 0, img_bytes = 0, qrec_bytes = 0, rec_off_bytes = 0;
+    void *d_desc = nullptr;  // the look-back's descriptors (single-pass form)
+    size_t desc_bytes = 0;
+    bool direct = false, direct_failed = false;  // single pass: the kernel writes the host's block itself
+    uint64_t cap_t = 0, cap_c = 0, cap_h = 0;    // ... whose sections hold this many targets / chains / hit pairs
     uint8_t *block = nullptr;  // pinned host block of the result
     size_t cap = 0, first = 0;
     const pgr_frag_rec *qrec_used = nullptr;

@@ -68,6 +68,9 @@ struct pgr_ctx {
         int64_t index_full_sort = 0;     // pgr_index_finalize: always the four-field sort
         int64_t index_two_key_sort = 0;  // pgr_index_finalize: never the one-key sort + run fix-ups
         int64_t no_fused_query = 0;      // never the one-wavefront-per-query kernel (csrc/query_fused.hip)
+        int64_t direct_query_lds_kb = 0;     // experiment: LDS per workgroup of the single-pass query kernel (fewer queries resident at once); -1: its block in device memory (timing only)
+        int64_t direct_query_results_delivered = 0;  // (a counter, read with pgr_ctx_get_option: batches whose result the single-pass kernel wrote)
+        int64_t direct_query_result = 0;     // experiment: that kernel writes the host's result block itself (single pass; measured slower)
         int64_t no_query_chaining = 0;   // do not enqueue the query stage behind the shimmer pipeline
         int64_t query_global_sort = 0;   // group the hits of a batch with the global radix sort
         int64_t fused_query_hits = 0;    // > 0: fixed slot size H of the per-query kernel

@@ -48,6 +48,7 @@ namespace {
 // batches with queries of more than 64 pairs can have)
 constexpr uint32_t QF_P_MIN = 64, QF_H_MIN = 64, QF_H_MAX = 512;
 constexpr uint32_t QF_DECLINE = 1u, QF_MORE_HITS = 2u;  // flags[0]: the batch does not fit at all / fits with a larger H
+constexpr uint32_t QF_LOOKBACK_TIMEOUT = 4u;            // (with QF_DECLINE) the single-pass form gave up waiting for a predecessor
 
 struct QfArgs {
     const pgr_frag_rec *qrec;
@@ -73,6 +74,12 @@ struct QfArgs {
     uint32_t *q_nt, *q_nc, *q_nh, *q_nhit;
     unsigned long long *q_nsig;
     uint32_t *flags;  // [0] QF_DECLINE | QF_MORE_HITS, [1] groups the reference never finishes, [2] most hits of one query
+    // the single-pass form (query_fused_kernel<true>): every query's wavefront finds where its targets / chains / hit pairs start
+    // by looking back over its predecessors' descriptors and writes them straight into the host's pinned block
+    uint64_t *desc;        // 3 words per query, 3 per tile of 64 queries (status in the top two bits), a counter per tile: zero before the launch
+    uint8_t *host;         // the pinned block, laid out by qf_layout(n_queries, cap_t, cap_c, cap_h)
+    uint64_t cap_t, cap_c, cap_h;
+    uint64_t *words;       // the pinned mailbox (the totals, written by the last query's wavefront)
 };
 
 // dynamic LDS: h0[P] h1[P] lo[P] (u64) | nrec[P] pc[P] hoff[P] (u32) | hit[H] (24 B) | hsid[H] ssid[H] perm[H] (u32)
@@ -383,19 +390,20 @@ __device__ __forceinline__ void lookup_range_short(uint64_t h0, uint64_t h1, con
     lookup_range(h0, h1, a.recs, a.key_off, a.n_keys, a.lut, a.lut_bits, a.lut_shift, a.keys, lo_out, hi_out);
 }
 
-__global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t qf_dyn[];
+// One query, the whole wavefront: chains into the query's slot; the counts come back wave-uniform (all zero for a query the
+// path cannot hold: the batch's flags say why).
+__device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, const uint32_t q, const int lane, uint32_t &nt,
+                                             uint32_t &nc, uint32_t &nh, uint32_t &n_hits_out, unsigned long long &nsig) {
     const uint32_t P = a.P, H = a.H;
     uint64_t *L_h0 = reinterpret_cast<uint64_t *>(qf_dyn), *L_h1 = L_h0 + P, *L_lo = L_h1 + P;
     uint32_t *L_nrec = reinterpret_cast<uint32_t *>(L_lo + P), *L_pc = L_nrec + P, *L_hoff = L_pc + P;
     pgr_hitpair *hit = reinterpret_cast<pgr_hitpair *>(L_hoff + P);
     uint32_t *hsid = reinterpret_cast<uint32_t *>(hit + H), *ssid = hsid + H, *perm = ssid + H;
-    const uint32_t q = blockIdx.x;
-    const int lane = (int)threadIdx.x;
     const uint64_t p0 = a.pair_off[q];
     const uint64_t np64 = a.pair_off[q + 1] - p0;
-    uint32_t nt = 0, nc = 0, nh = 0, m = 0;
-    unsigned long long nsig = 0;
+    uint32_t m = 0;
+    nt = nc = nh = n_hits_out = 0;
+    nsig = 0;
     bool decline = np64 > (uint64_t)P;
     const int np = decline ? 0 : (int)np64;
     // ---- lookup of every pair
@@ -442,17 +450,12 @@ __global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
     const bool any_decline = __ballot(decline) != 0;
     if (any_decline || m > H) {
         if (lane == 0) {
-            if (any_decline) atomicOr(a.flags, QF_DECLINE);
-            else {
-                atomicOr(a.flags, QF_MORE_HITS);
-                atomicMax(a.flags + 2, m);
-            }
-            a.q_nt[q] = 0;
-            a.q_nc[q] = 0;
-            a.q_nh[q] = 0;
-            a.q_nhit[q] = 0;
-            a.q_nsig[q] = 0;
+            uint32_t was;
+            if (any_decline) was = atomicOr(a.flags, QF_DECLINE);
+            else was = atomicMax(a.flags + 2, m) | atomicOr(a.flags, QF_MORE_HITS);
+            asm volatile("" ::"v"(was));  // returned = done in memory before anything this wavefront publishes later
         }
+        nsig = 0;
         return;
     }
     wave_sync();
@@ -548,13 +551,231 @@ __global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
     }
     for (int d = 32; d >= 1; d >>= 1) nsig += shfl_xor64(nsig, d);
     if (lane == 0) {
-        if (decline) atomicOr(a.flags, QF_DECLINE);
-        if (n_stuck) atomicAdd(a.flags + 1, n_stuck);
-        a.q_nt[q] = decline ? 0 : nt;
-        a.q_nc[q] = decline ? 0 : nc;
-        a.q_nh[q] = decline ? 0 : nh;
-        a.q_nhit[q] = n_hits;
-        a.q_nsig[q] = nsig;
+        uint32_t was = 0;
+        if (decline) was = atomicOr(a.flags, QF_DECLINE);
+        if (n_stuck) was |= atomicAdd(a.flags + 1, n_stuck);
+        asm volatile("" ::"v"(was));  // (as above)
+    }
+    if (decline) nt = nc = nh = 0;
+    n_hits_out = n_hits;
+}
+
+inline __host__ __device__ size_t qf_up8(size_t v) { return (v + 7) & ~(size_t)7; }
+
+// flat result = q_off | t_off | c_off | hps | c_score | t_sid (every section 8-byte aligned), the layout pgr_hps_result points into
+struct QfLayout {
+    size_t o_toff, o_coff, o_hps, o_cscore, o_tsid, bytes;
+};
+inline __host__ __device__ QfLayout qf_layout(uint64_t nq, uint64_t nt, uint64_t nc, uint64_t nh) {
+    QfLayout l;
+    l.o_toff = (nq + 1) * 8;
+    l.o_coff = l.o_toff + (nt + 1) * 8;
+    l.o_hps = l.o_coff + (nc + 1) * 8;
+    l.o_cscore = l.o_hps + nh * sizeof(pgr_hitpair);
+    l.o_tsid = qf_up8(l.o_cscore + nc * 4);
+    l.bytes = qf_up8(l.o_tsid + nt * 4);
+    return l;
+}
+
+// descriptor words of the look-back: status in bits 63:62 (0 not there yet, 1 this query's own counts, 2 the counts of all
+// queries up to and including this one); [0] targets | chains << 31, [1] hit pairs | hits << 31, [2] looked-up signatures
+constexpr uint64_t QF_ST_OWN = 1ull << 62, QF_ST_INCL = 2ull << 62, QF_VAL = (1ull << 62) - 1;
+constexpr uint32_t QF_LOOKBACK_SPINS = 1u << 15;  // x (three loads + a sleep): tens of milliseconds, then the batch is declined
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d, 64);
+    return v;
+}
+
+struct QfSums {
+    uint32_t t, c, h, hit;
+    unsigned long long sig;
+};
+__device__ __forceinline__ QfSums qf_add(const QfSums &x, const QfSums &y) {
+    return QfSums{x.t + y.t, x.c + y.c, x.h + y.h, x.hit + y.hit, x.sig + y.sig};
+}
+// Everything the descriptors carry is IN their words, and every reader checks the status of what it read: relaxed atomics
+// (device scope: they pass the XCDs' L2s).  Release / acquire at device scope would write back / invalidate the XCD's whole L2
+// per operation -- the first version of this kernel did, and took 1.15 ms instead of 0.1.
+__device__ __forceinline__ void qf_desc_store(uint64_t *D, uint64_t status, const QfSums &v) {
+    __hip_atomic_store(D + 0, status | (uint64_t)v.t | ((uint64_t)v.c << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(D + 1, status | (uint64_t)v.h | ((uint64_t)v.hit << 31), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(D + 2, status | (v.sig & QF_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void qf_desc_load(const uint64_t *S, uint64_t &w0, uint64_t &w1, uint64_t &w2) {
+    w0 = __hip_atomic_load(S + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w1 = __hip_atomic_load(S + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    w2 = __hip_atomic_load(S + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// (a writer between its three stores shows mixed states: 0 = look again)
+__device__ __forceinline__ uint32_t qf_desc_status(uint64_t w0, uint64_t w1, uint64_t w2) {
+    const uint32_t s0 = (uint32_t)(w0 >> 62), s1 = (uint32_t)(w1 >> 62), s2 = (uint32_t)(w2 >> 62);
+    return (s0 == s1 && s1 == s2) ? s0 : 0u;
+}
+// the fields of the lanes with `take`, added up over the wavefront
+__device__ __forceinline__ QfSums qf_wave_sums(bool take, uint64_t w0, uint64_t w1, uint64_t w2) {
+    QfSums r;
+    r.t = wave_sum_u32(take ? (uint32_t)(w0 & 0x7FFFFFFFull) : 0u);
+    r.c = wave_sum_u32(take ? (uint32_t)((w0 >> 31) & 0x7FFFFFFFull) : 0u);
+    r.h = wave_sum_u32(take ? (uint32_t)(w1 & 0x7FFFFFFFull) : 0u);
+    r.hit = wave_sum_u32(take ? (uint32_t)((w1 >> 31) & 0x7FFFFFFFull) : 0u);
+    unsigned long long sv = take ? (w2 & QF_VAL) : 0ull;
+    for (int d = 32; d >= 1; d >>= 1) sv += shfl_xor64(sv, d);
+    r.sig = sv;
+    return r;
+}
+
+// DIRECT = false: counts per query; query_offsets_kernel + query_pack_kernel + a download make the flat result.
+// DIRECT = true: single pass.  The wavefront publishes its counts, learns the counts of all queries in front of it (below:
+// workgroups start in index order, so every predecessor is running or done) and copies its slot to where it belongs in the
+// HOST's block -- the writes cross PCIe while other queries still chain (tools/probe/host_write_probe.hip: 10 000 wavefronts
+// x 768 B contiguous reach the link's 50 GB/s and hide behind arithmetic; this kernel's small pieces do not: see enqueue()).
+template <bool DIRECT>
+__global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t qf_dyn[];
+    const uint32_t q = blockIdx.x;
+    const int lane = (int)threadIdx.x;
+    uint32_t nt, nc, nh, nhit;
+    unsigned long long nsig;
+    qf_one_query(a, qf_dyn, q, lane, nt, nc, nh, nhit, nsig);
+    if (!DIRECT) {
+        if (lane == 0) {
+            a.q_nt[q] = nt;
+            a.q_nc[q] = nc;
+            a.q_nh[q] = nh;
+            a.q_nhit[q] = nhit;
+            a.q_nsig[q] = nsig;
+        }
+        return;
+    }
+    // ---- where this query's entries start: counts of all queries in front of it.  Queries are taken in TILES of 64: the
+    // wavefront that finishes last in a tile adds the tile's counts up and chains them to the tiles in front (a look-back over
+    // tile descriptors, 64 tiles = 4096 queries per step); every wavefront then needs the running total of the tile in front
+    // and the counts of the earlier queries of its own tile.  (A look-back over the queries themselves moved 64 queries per
+    // memory round trip: 1.15 ms for 10 000 queries.)  Every wait is for a workgroup with a smaller index.
+    const uint32_t n = a.n_queries, n_tiles = (n + 63) >> 6, tile = q >> 6, tile_lo = tile << 6;
+    const uint32_t tile_n = n - tile_lo < 64u ? n - tile_lo : 64u;
+    uint64_t *D = a.desc + 3 * (size_t)q;
+    uint64_t *TD = a.desc + 3 * (size_t)n;
+    uint32_t *TC = (uint32_t *)(TD + 3 * (size_t)n_tiles);
+    QfSums own{nt, nc, nh, nhit, nsig};
+    uint32_t spins = 0;
+    bool gave_up = false;
+    uint32_t last = 0;
+    if (lane == 0) {  // (a flag of this query was set with a returning atomic: it is in memory)
+        qf_desc_store(D, QF_ST_OWN, own);
+        last = __hip_atomic_fetch_add(TC + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == tile_n - 1 ? 1u : 0u;
+    }
+    last = (uint32_t)__builtin_amdgcn_readfirstlane((int)last);
+    QfSums front{0, 0, 0, 0, 0};  // the tiles in front
+    if (last) {  // every query of the tile has published its counts (or is about to: the counter is not ordered behind them)
+        uint64_t w0 = 0, w1 = 0, w2 = 0;
+        for (;;) {
+            if ((uint32_t)lane < tile_n) qf_desc_load(a.desc + 3 * (size_t)(tile_lo + lane), w0, w1, w2);
+            if (!__ballot((uint32_t)lane < tile_n && qf_desc_status(w0, w1, w2) == 0u)) break;
+            if (++spins > QF_LOOKBACK_SPINS) {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        QfSums agg = qf_wave_sums((uint32_t)lane < tile_n, w0, w1, w2);
+        if (lane == 0 && tile + 1 < n_tiles) qf_desc_store(TD + 3 * (size_t)tile, QF_ST_OWN, agg);
+        for (long long base = tile; base > 0;) {  // tiles base-1, base-2, ... 0 are not in the sums yet
+            const long long idx = base - 1 - lane;
+            const bool valid = idx >= 0;
+            w0 = w1 = w2 = 0;
+            if (valid) qf_desc_load(TD + 3 * (size_t)idx, w0, w1, w2);
+            const uint32_t st = qf_desc_status(w0, w1, w2);
+            const uint64_t incl = __ballot(valid && st == 2u), none = __ballot(valid && st == 0u);
+            const int n_valid = base < 64 ? (int)base : 64;
+            const int lim = incl ? __builtin_ctzll(incl) + 1 : n_valid;  // lanes [0, lim): own counts up to the nearest running total
+            const uint64_t need = lim >= 64 ? U64MAX : ((1ull << lim) - 1);
+            if (none & need) {
+                if (++spins > QF_LOOKBACK_SPINS) {
+                    gave_up = true;
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                continue;
+            }
+            front = qf_add(front, qf_wave_sums(lane < lim, w0, w1, w2));
+            if (incl) break;
+            base -= 64;
+        }
+        if (lane == 0 && tile + 1 < n_tiles)  // (also after giving up: the tiles behind must not wait as well)
+            qf_desc_store(TD + 3 * (size_t)tile, QF_ST_INCL, qf_add(front, agg));
+    } else if (tile > 0) {
+        for (;;) {
+            uint64_t w0, w1, w2;
+            qf_desc_load(TD + 3 * (size_t)(tile - 1), w0, w1, w2);
+            if (qf_desc_status(w0, w1, w2) == 2u) {
+                front = qf_wave_sums(lane == 0, w0, w1, w2);
+                break;
+            }
+            if (++spins > QF_LOOKBACK_SPINS) {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    QfSums before = front;  // + the earlier queries of this tile
+    if (q > tile_lo) {
+        const bool valid = (uint32_t)lane < q - tile_lo;
+        for (;;) {
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (valid) qf_desc_load(a.desc + 3 * (size_t)(tile_lo + lane), w0, w1, w2);
+            if (!__ballot(valid && qf_desc_status(w0, w1, w2) == 0u)) {
+                before = qf_add(before, qf_wave_sums(valid, w0, w1, w2));
+                break;
+            }
+            if (++spins > QF_LOOKBACK_SPINS) {
+                gave_up = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    if (gave_up && lane == 0) atomicOr(a.flags, QF_DECLINE | QF_LOOKBACK_TIMEOUT);
+    const uint32_t eT = before.t, eC = before.c, eH = before.h, eHit = before.hit;
+    const unsigned long long eS = before.sig;
+    const QfLayout l = qf_layout(a.n_queries, a.cap_t, a.cap_c, a.cap_h);
+    uint64_t *q_off = (uint64_t *)a.host, *t_off = (uint64_t *)(a.host + l.o_toff), *c_off = (uint64_t *)(a.host + l.o_coff);
+    const uint64_t T0 = eT, C0 = eC, H0 = eH;
+    const bool fits = T0 + nt <= a.cap_t && C0 + nc <= a.cap_c && H0 + nh <= a.cap_h;  // (if not, the totals tell the host)
+    if (lane == 0) q_off[q] = T0;
+    if (fits) {
+        pgr_hitpair *hps = (pgr_hitpair *)(a.host + l.o_hps);
+        float *c_score = (float *)(a.host + l.o_cscore);
+        uint32_t *t_sid = (uint32_t *)(a.host + l.o_tsid);
+        const size_t sb = (size_t)q * a.H;
+        wave_sync();  // the slot's entries were written by other lanes of this wavefront
+        for (uint32_t i = lane; i < nt; i += 64) {
+            t_sid[T0 + i] = a.s_tsid[sb + i];
+            t_off[T0 + i] = C0 + a.s_tcoff[sb + i];
+        }
+        for (uint32_t i = lane; i < nc; i += 64) {
+            c_score[C0 + i] = a.s_cscore[sb + i];
+            c_off[C0 + i] = H0 + a.s_choff[sb + i];
+        }
+        const uint64_t *src = (const uint64_t *)(a.s_hp + sb);
+        uint64_t *dst = (uint64_t *)(hps + H0);
+        for (uint32_t i = lane; i < nh * 3; i += 64) dst[i] = src[i];
+    }
+    if (q + 1 == a.n_queries && lane == 0) {  // every query's counts are in: the totals
+        const uint64_t NT = T0 + nt, NC = C0 + nc, NH = H0 + nh;
+        q_off[a.n_queries] = NT;
+        if (NT <= a.cap_t) t_off[NT] = NC;
+        if (NC <= a.cap_c) c_off[NC] = NH;
+        a.words[0] = NT;
+        a.words[1] = NC;
+        a.words[2] = NH;
+        a.words[3] = eS + nsig;
+        a.words[4] = (uint64_t)eHit + nhit;
+        a.words[5] = __hip_atomic_load(a.flags + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.words[6] = __hip_atomic_load(a.flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.words[8] = __hip_atomic_load(a.flags + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -673,23 +894,6 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
     }
 }
 
-inline __host__ __device__ size_t qf_up8(size_t v) { return (v + 7) & ~(size_t)7; }
-
-// flat result = q_off | t_off | c_off | hps | c_score | t_sid (every section 8-byte aligned), the layout pgr_hps_result points into
-struct QfLayout {
-    size_t o_toff, o_coff, o_hps, o_cscore, o_tsid, bytes;
-};
-inline __host__ __device__ QfLayout qf_layout(uint64_t nq, uint64_t nt, uint64_t nc, uint64_t nh) {
-    QfLayout l;
-    l.o_toff = (nq + 1) * 8;
-    l.o_coff = l.o_toff + (nt + 1) * 8;
-    l.o_hps = l.o_coff + (nc + 1) * 8;
-    l.o_cscore = l.o_hps + nh * sizeof(pgr_hitpair);
-    l.o_tsid = qf_up8(l.o_cscore + nc * 4);
-    l.bytes = qf_up8(l.o_tsid + nt * 4);
-    return l;
-}
-
 // slots -> the flat result (a device image sized for full slots; the host downloads the part that is used)
 __global__ __launch_bounds__(64) void query_pack_kernel(const QfArgs a, const uint64_t *__restrict__ t0, const uint64_t *__restrict__ c0,
                                                         const uint64_t *__restrict__ h0, const uint64_t *__restrict__ words,
@@ -749,7 +953,7 @@ QueryFusedRun::QueryFusedRun(pgr_ctx *c, const pgr_index *i, uint32_t nq, uint64
 QueryFusedRun::~QueryFusedRun() {
     // an error between enqueue and finish: the DMA engine may still be writing the pinned block -- wait before it goes back to the pool
     if (enqueued && !finish_called && block) (void)hipStreamSynchronize(ctx->stream);
-    for (void *p : {d_cnt, d_offs, d_shp, d_sf, d_img, d_qrec, d_rec_off}) ctx->dfree(p);
+    for (void *p : {d_cnt, d_offs, d_shp, d_sf, d_img, d_qrec, d_rec_off, d_desc}) ctx->dfree(p);
     if (block) result_block_release(block);
 }
 
@@ -785,10 +989,30 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
     if ((rc = ctx->ensure_qmail())) return rc;
     uint64_t *mb = (uint64_t *)ctx->qmail;  // pinned: the kernels write the totals here
     const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
+    // EXPERIMENT (context option direct_query_result, off by default: measured SLOWER).  Single pass (query_fused_kernel<true>)
+    // when an earlier batch on this index has shown how many targets, chains and hit pairs a query has: the sections of the
+    // host's block are placed for that + 10 %, the kernel writes them itself.  A batch that needs more says so in its totals
+    // and is done again in the two-pass form (finish()).  10 000 x 10 kbp queries (profiles/r05_query/single_pass.txt): the
+    // kernel takes 141 us with the block in device memory (two-pass: 95 + 13 + 10), 300 us writing the host's block (7.5 MB in
+    // 4-24 byte pieces of five sections per query: the link takes them at ~30 GB/s, and nearly all queries are resident at once
+    // and finish together, so the writes do not hide behind the chaining) -- against 95 + 13 + 10 + 136 us for two passes and
+    // the download.  Fewer queries resident at once (direct_query_lds_kb) only makes it longer.
+    const float h_t = ix->fused_per_q[0].load(std::memory_order_relaxed), h_c = ix->fused_per_q[1].load(std::memory_order_relaxed),
+                h_h = ix->fused_per_q[2].load(std::memory_order_relaxed);
+    direct = !direct_failed && ctx->opt.direct_query_result && h_h >= 0.0f && h_t >= 0.0f && h_c >= 0.0f;
+    if (direct) {
+        auto room = [&](float per_q, uint64_t most) { return std::min<uint64_t>(most, (uint64_t)((double)nq * per_q * 1.10) + 512); };
+        cap_t = room(h_t, slots / 2);
+        cap_c = room(h_c, slots);
+        cap_h = room(h_h, slots);
+    }
     // d_cnt: q_nsig | q_nt | q_nc | q_nh | q_nhit | flags ; d_offs: t0 | c0 | h0 ; d_sf: s_cscore | s_choff | s_tsid | s_tcoff
-    if ((rc = grow(ctx, d_cnt, cnt_bytes, nq * 24 + 16)) || (rc = grow(ctx, d_offs, offs_bytes, nq * 24)) ||
-        (rc = grow(ctx, d_shp, shp_bytes, slots * sizeof(pgr_hitpair))) || (rc = grow(ctx, d_sf, sf_bytes, slots * 16)) ||
-        (rc = grow(ctx, d_img, img_bytes, lmax.bytes)))
+    if ((rc = grow(ctx, d_cnt, cnt_bytes, nq * 24 + 16)) || (rc = grow(ctx, d_shp, shp_bytes, slots * sizeof(pgr_hitpair))) ||
+        (rc = grow(ctx, d_sf, sf_bytes, slots * 16)))
+        return rc;
+    const size_t n_qtiles = (nq + 63) / 64, desc_need = (nq + n_qtiles) * 24 + n_qtiles * 4;
+    if (direct ? (rc = grow(ctx, d_desc, desc_bytes, desc_need))
+               : ((rc = grow(ctx, d_offs, offs_bytes, nq * 24)) || (rc = grow(ctx, d_img, img_bytes, lmax.bytes))))
         return rc;
     QfArgs a;
     a.qrec = qrec;
@@ -812,26 +1036,50 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
     a.q_nh = a.q_nc + nq;
     a.q_nhit = a.q_nh + nq;
     a.flags = a.q_nhit + nq;
+    a.desc = nullptr;
+    a.host = nullptr;
+    a.cap_t = a.cap_c = a.cap_h = 0;
+    a.words = nullptr;
     a.s_hp = (pgr_hitpair *)d_shp;
     a.s_cscore = (float *)d_sf;
     a.s_choff = (uint32_t *)d_sf + slots;
     a.s_tsid = (uint32_t *)d_sf + 2 * slots;
     a.s_tcoff = (uint32_t *)d_sf + 3 * slots;
-    uint64_t *t0 = (uint64_t *)d_offs, *c0 = t0 + nq, *h0 = c0 + nq;
     // The host block of the result is pinned: the DMA engine writes it, the caller reads it, no staging copy.  How much to
     // download is known on the device only: the copy is enqueued for an estimate (what the last batch on this index needed
     // per query + 5 %; first time: a quarter of the slots) and the rest follows when the totals say there is more.
     const float bytes_hint = ix->fused_bytes_per_q.load(std::memory_order_relaxed);
-    const size_t est = std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.05) + 32768
-                                                            : (nq + 1) * 8 + slots * 10 + 4096);
+    const size_t est = direct ? qf_layout(nq, cap_t, cap_c, cap_h).bytes
+                              : std::min(lmax.bytes, bytes_hint > 0 ? (size_t)(nq * (double)bytes_hint * 1.05) + 32768
+                                                                     : (nq + 1) * 8 + slots * 10 + 4096);
+    if (block && direct && cap < est) {
+        result_block_release(block);
+        block = nullptr;
+    }
     if (!block && !(block = (uint8_t *)pinned_result_acquire(est, &cap))) {
         no_pinned = true;  // the host cannot pin more memory: the stage-by-stage path needs none
         return PGR_OK;
     }
     first = std::min(est, cap);
     hipError_t e = flags_cleared ? hipSuccess : hipMemsetAsync(a.flags, 0, 12, st);
-    if (e == hipSuccess) {
-        hipLaunchKernelGGL(query_fused_kernel, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
+    if (e == hipSuccess && direct) {
+        a.desc = (uint64_t *)d_desc;
+        a.host = block;
+        if (ctx->opt.direct_query_lds_kb < 0) {  // EXPERIMENT (timing only, the result is not delivered): the block in device memory
+            if ((rc = grow(ctx, d_img, img_bytes, est))) return rc;
+            a.host = (uint8_t *)d_img;
+        }
+        a.cap_t = cap_t;
+        a.cap_c = cap_c;
+        a.cap_h = cap_h;
+        a.words = mb;
+        e = hipMemsetAsync(d_desc, 0, desc_need, st);
+        if (e == hipSuccess)
+            hipLaunchKernelGGL(query_fused_kernel<true>, dim3(n_queries), dim3(64),
+                               std::max<size_t>(qf_lds_bytes(P, H, a.long_groups != 0), (size_t)std::max<int64_t>(0, ctx->opt.direct_query_lds_kb) << 10), st, a);
+    } else if (e == hipSuccess) {
+        uint64_t *t0 = (uint64_t *)d_offs, *c0 = t0 + nq, *h0 = c0 + nq;
+        hipLaunchKernelGGL(query_fused_kernel<false>, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
         hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
                            n_queries, t0, c0, h0, (uint64_t *)d_img, mb);
         hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, (uint8_t *)d_img);
@@ -855,15 +1103,31 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
     hipStream_t st = ctx->stream;
     const size_t nq = n_queries;
     uint64_t *mb = (uint64_t *)ctx->qmail;
-    for (int round = 0;; ++round) {
+    bool grew = false;
+    for (;;) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
-        if ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || round))) {
+        const bool lookback_gave_up = direct && (mb[5] & QF_LOOKBACK_TIMEOUT);
+        if (!lookback_gave_up &&
+            ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || grew)))) {
             *declined = true;
             return PGR_OK;
         }
-        if (mb[5] & QF_MORE_HITS) {  // every query fits a larger slot: once more with it
-            while (H < mb[8]) H <<= 1;
+        const bool more_hits = !lookback_gave_up && (mb[5] & QF_MORE_HITS);
+        // the single-pass form placed the sections for fewer targets / chains / hit pairs than the batch has (or gave up
+        // waiting): the two-pass form takes it
+        const bool redo_two_pass = direct && !more_hits && (lookback_gave_up || mb[0] > cap_t || mb[1] > cap_c || mb[2] > cap_h);
+        if (redo_two_pass && ctx->opt.debug)
+            fprintf(stderr, "[pgr] query batch: single-pass result %s (%llu / %llu / %llu of %llu / %llu / %llu): two passes\n",
+                    lookback_gave_up ? "gave up in its look-back" : "needs more room", (unsigned long long)mb[0], (unsigned long long)mb[1],
+                    (unsigned long long)mb[2], (unsigned long long)cap_t, (unsigned long long)cap_c, (unsigned long long)cap_h);
+        if (more_hits || redo_two_pass) {  // every query fits a larger slot: once more with it
+            if (more_hits) {
+                grew = true;
+                while (H < mb[8]) H <<= 1;
+            } else {
+                direct_failed = true;
+            }
             int rc = enqueue(qrec_used, pair_off_used);
             if (rc) return rc;
             if (no_pinned) {
@@ -876,9 +1140,9 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
         break;
     }
     const uint64_t NT = mb[0], NC = mb[1], NH = mb[2];
-    const QfLayout l = qf_layout(nq, NT, NC, NH);
+    const QfLayout l = direct ? qf_layout(nq, cap_t, cap_c, cap_h) : qf_layout(nq, NT, NC, NH);
     const size_t need = l.bytes;
-    if (need > first) {  // more than the estimate
+    if (!direct && need > first) {  // more than the estimate
         hipError_t e;
         if (need > cap) {
             result_block_release(block);
@@ -893,7 +1157,11 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query result download: ") + hipGetErrorString(e));
     }
-    ix->fused_bytes_per_q.store((float)((double)need / (double)nq), std::memory_order_relaxed);
+    if (direct) ++ctx->opt.direct_query_results_delivered;
+    if (!direct) ix->fused_bytes_per_q.store((float)((double)need / (double)nq), std::memory_order_relaxed);
+    ix->fused_per_q[0].store((float)((double)NT / (double)nq), std::memory_order_relaxed);
+    ix->fused_per_q[1].store((float)((double)NC / (double)nq), std::memory_order_relaxed);
+    ix->fused_per_q[2].store((float)((double)NH / (double)nq), std::memory_order_relaxed);
     ix->fused_hits.store(H > QF_H_MIN ? H : 0, std::memory_order_relaxed);
     counts->n_signatures = mb[3];
     counts->n_hits = mb[4];

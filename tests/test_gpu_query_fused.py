@@ -218,3 +218,48 @@ def test_second_batch_on_an_index_is_enqueued_behind_the_shimmer_pipeline(oracle
         assert g5 == [[], []]
     finally:
         gpu_ctx.set_option("no_small_path", 0)
+
+
+def test_single_pass_result_option_gives_the_same_answer(oracle, gpu_ctx):
+    """Context option direct_query_result (an experiment, off by default: query_fused_kernel<true> finds every query's place
+    by a look-back over tiles of 64 queries and writes the host's block itself, sections placed from the previous batch's
+    counts): the same answer as the default two-pass form -- second batch on an index (single pass), a batch with more hits
+    than the previous one promised (sections too small: done again in two passes), a ragged batch (empty and N-only queries,
+    a tile of 64 that is not full), and 1 and 65 queries (one tile, two tiles)."""
+    rng = np.random.default_rng(46)
+    seqs = [seqgen.rnd(rng, 1_000_000) for _ in range(24)]
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+
+    def batch(n, lo, hi):
+        out = []
+        for i in range(n):
+            src = seqs[int(rng.integers(0, 24))]
+            a = int(rng.integers(0, len(src) - hi))
+            q = src[a:a + int(rng.integers(lo, hi))]
+            out.append(revcomp(q) if i % 2 else q)
+        return out
+    misses = [seqgen.rnd(rng, 5000) for _ in range(700)]          # no hit at all: the next batch's sections are sized for nothing
+    q_hits = batch(700, 2000, 9000)
+    ragged = batch(333, 1500, 9500) + [b"", seqgen.rnd(rng, 300), b"N" * 2000]
+    gpu_ctx.set_option("no_small_path", 1)
+    try:
+        ref_hits = sdb.query_fragments_to_hps(q_hits, *_args(KW))
+        ref_ragged = sdb.query_fragments_to_hps(ragged, *_args(KW))
+        ref_small = [sdb.query_fragments_to_hps(q_hits[:n], *_args(KW)) for n in (1, 65)]
+        assert _check_vs_oracle(oix, q_hits[:30], ref_hits[:30], KW) >= 30
+        delivered = lambda: gpu_ctx.get_option("direct_query_results_delivered")  # noqa: E731
+        with gpu_ctx.options(direct_query_result=1):
+            d0 = delivered()
+            assert sdb.query_fragments_to_hps(q_hits, *_args(KW)) == ref_hits      # single pass (the counts of the batches above)
+            assert sdb.query_fragments_to_hps(q_hits, *_args(KW)) == ref_hits
+            assert sdb.query_fragments_to_hps(ragged, *_args(KW)) == ref_ragged
+            assert all(len(r) == 0 for r in sdb.query_fragments_to_hps(misses, *_args(KW)))
+            assert delivered() == d0 + 4
+            assert sdb.query_fragments_to_hps(q_hits, *_args(KW)) == ref_hits      # sections placed for no hits: two passes after all
+            assert delivered() == d0 + 4
+            assert sdb.query_fragments_to_hps(q_hits, *_args(KW)) == ref_hits
+            for n, ref in zip((1, 65), ref_small):
+                assert sdb.query_fragments_to_hps(q_hits[:n], *_args(KW)) == ref
+            assert delivered() == d0 + 7
+    finally:
+        gpu_ctx.set_option("no_small_path", 0)
