@@ -45,22 +45,21 @@ struct Island {
     bool pal = true;
 };
 
-static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
-                             const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base,
-                             const std::vector<uint32_t> &empty_seg_ranges) {
-    hipStream_t st = ctx->stream;
-    // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
-    // (one per chunk), down to 1024 positions: a round costs what its slowest chunk costs -- ~3 us per step of 64 positions,
-    // 225 us for the 4096-position chunks that were the minimum while a chunk had to own the segment-table entry of the tile it
-    // starts in.  The lists of the chunks that start in one tile are put together behind the last round (below).
-    uint64_t island_bases = 0;
-    for (const Island &is : islands) island_bases += is.E - is.B;
-    const uint64_t CS_MIN = ctx->opt.island_chunk_min > 0 ? (uint64_t)((ctx->opt.island_chunk_min + 63) / 64 * 64) : 1024;
-    // (~2.5 wavefronts per SIMD: below that a round waits for dependent instructions, above it the SIMDs are busy -- a step is
-    // ~1.5 us of issue -- and shorter chunks only add warm-up steps)
-    const uint64_t CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(CS_MIN, ((island_bases / 2560 + 1023) / 1024) * 1024));
-    // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
-    std::vector<uint32_t> zero_ranges(empty_seg_ranges);
+// One run of the exact machine over a list of islands, in two halves so that the first round's chunk kernel can be enqueued
+// BEFORE the host has anything to wait for (ShmmrJob::stage1: the islands around non-ACGT bytes are known while the tile
+// kernel still runs): begin() builds the chunks and enqueues round 0, finish() waits, verifies the seams, runs the chunks
+// that need the true state again (rounds 1 ..) and puts the tiles' lists together.  `a` (its .out may move) and `islands`
+// (they may grow) are the run's own copies: the caller reads them back.
+struct IslandRun {
+    pgr_ctx *ctx;
+    const pgr_batch *b;
+    L1Args a;
+    std::vector<Island> islands;
+    const std::vector<uint32_t> &tile_first;
+    uint32_t tc;
+    hipStream_t st;
+    uint64_t CS_SHORT = 1024;
+    std::vector<uint32_t> zero_ranges;  // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
     struct HChunk {
         ChunkDesc d;
         size_t island;
@@ -76,299 +75,371 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
     std::vector<ChunkState> s_in, s_out;
     std::vector<uint32_t> status;
     std::vector<size_t> todo;
-    auto cap_of = [&](uint64_t len, bool full) -> uint64_t {
-        return full ? len + a.w + 320 : std::min<uint64_t>(len + a.w + 320, len / 4 + 1024);
-    };
-    int rc;
-    // (re)build the chunks of one island; its tile (and tail) segments become empty first
-    auto build = [&](size_t ii) -> int {
-        const Island &is = islands[ii];
-        const uint32_t c = is.contig;
-        const uint64_t L = b->h_len[c];
-        const uint32_t nt = tile_first[c + 1] - tile_first[c];
-        const uint32_t seg0 = tile_first[c] + c;
-        // (a contig that is one tile may be longer than a tile core: clamped)
-        uint32_t rng[2] = {seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, is.B / tc), seg0 + (uint32_t)std::min<uint64_t>(nt, (is.E + tc - 1) / tc)};
-        if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
-        zero_ranges.push_back(rng[0]);
-        zero_ranges.push_back(rng[1]);
-        // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
-        // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
-        const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : CS_SHORT;
-        const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
-        for (uint64_t j = 0; j < nch; ++j) {
-            HChunk h;
-            memset(&h.d, 0, sizeof(h.d));
-            memset(&h.t_out, 0, sizeof(h.t_out));
-            h.island = ii;
-            h.d.contig = c;
-            h.d.cs = is.whole ? 0 : is.B + j * CS;
-            h.d.ce = is.whole ? L : std::min<uint64_t>(is.E, is.B + (j + 1) * CS);
-            h.d.emit_lo_pos = (j == 0) ? is.B : 0;
-            h.d.drain_end = h.d.ce;
-            if (j + 1 == nch && is.E < L) h.d.drain_end = std::min<uint64_t>(L, is.E + 320);
-            h.d.seg = seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, h.d.cs / tc);
-            h.d.warm = 256;
-            // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
-            // (ties, shmmrutils.rs:516-527), the sparse region estimate would overflow and the chunk run twice
-            // (so is an island around non-ACGT bytes, however short: it may be one of the two ends of a long gap)
-            h.full_cap = nch >= 8 || !is.pal;
-            todo.push_back(ch.size());
-            ch.push_back(h);
-        }
-        if (is.E < L) {  // probe: what a warmed-up (regular) machine looks like at E
-            HChunk h;
-            memset(&h.d, 0, sizeof(h.d));
-            memset(&h.t_out, 0, sizeof(h.t_out));
-            h.island = ii;
-            h.probe = true;
-            h.d.contig = c;
-            h.d.cs = h.d.ce = h.d.drain_end = is.E;
-            h.d.seg = 0xFFFFFFFFu;
-            h.d.warm = 256;
-            todo.push_back(ch.size());
-            ch.push_back(h);
-        }
-        return PGR_OK;
-    };
-    for (size_t ii = 0; ii < islands.size(); ++ii)
-        if ((rc = build(ii))) return rc;
+    uint64_t next_region;
+    std::chrono::steady_clock::time_point t_isl0;
+    int round = 0;
+    // of the round that is enqueued
+    size_t nq = 0, desc_bytes = 0;
+    std::vector<ChunkDesc> descs;
+    std::unique_ptr<Tmp_list> d_zr;  // (the source vector and this block live until the synchronization at the end of the round)
+    bool enqueued = false;
+    // round 0 may run on a stream of its own (beside the tile kernel: begin(side)): the chunk kernel touches nothing the tile
+    // kernel touches -- its regions lie behind the tiles' part of the level-1 buffer, which must not have to grow for this
+    hipStream_t st_chunks = nullptr;
 
-    uint64_t next_region = region_base;
-    const auto t_isl0 = std::chrono::steady_clock::now();
-    auto isl_lap = [&](const char *what, int round) {
+    IslandRun(pgr_ctx *ctx_, const pgr_batch *b_, const L1Args &a_, const std::vector<Island> &islands_, const std::vector<uint32_t> &tile_first_,
+              uint32_t tc_, uint64_t region_base, const std::vector<uint32_t> &empty_seg_ranges)
+        : ctx(ctx_), b(b_), a(a_), islands(islands_), tile_first(tile_first_), tc(tc_), st(ctx_->stream), zero_ranges(empty_seg_ranges),
+          next_region(region_base) {
+        // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
+        // (one per chunk), down to 1024 positions: a round costs what its slowest chunk costs -- ~3 us per step of 64 positions,
+        // 225 us for the 4096-position chunks that were the minimum while a chunk had to own the segment-table entry of the tile it
+        // starts in.  The lists of the chunks that start in one tile are put together behind the last round (finish()).
+        uint64_t island_bases = 0;
+        for (const Island &is : islands) island_bases += is.E - is.B;
+        const uint64_t CS_MIN = ctx->opt.island_chunk_min > 0 ? (uint64_t)((ctx->opt.island_chunk_min + 63) / 64 * 64) : 1024;
+        // (~2.5 wavefronts per SIMD: below that a round waits for dependent instructions, above it the SIMDs are busy -- a step is
+        // ~1.5 us of issue -- and shorter chunks only add warm-up steps)
+        CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(CS_MIN, ((island_bases / 2560 + 1023) / 1024) * 1024));
+    }
+    // (a run that is dropped with its first round still on the side stream -- the flags added islands, or the pass starts over:
+    // whoever uses the workspaces, the pinned image and the regions next must find them idle)
+    ~IslandRun() {
+        if (enqueued && st_chunks && st_chunks != st) (void)hipStreamSynchronize(st_chunks);
+    }
+    IslandRun(const IslandRun &) = delete;
+    IslandRun &operator=(const IslandRun &) = delete;
+    uint64_t cap_of(uint64_t len, bool full) const { return full ? len + a.w + 320 : std::min<uint64_t>(len + a.w + 320, len / 4 + 1024); }
+    void isl_lap(const char *what, int r) const {
         if (ctx->opt.debug_times)
-            fprintf(stderr, "[pgr]     islands round %d %-34s at %7.1f us\n", round, what,
+            fprintf(stderr, "[pgr]     islands round %d %-34s at %7.1f us\n", r, what,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_isl0).count());
-    };
-    for (int round = 0; !todo.empty(); ++round) {
-        // Every round settles at least one seam or grows / merges an island, so the number of rounds is bounded by the number
-        // of chunks plus the growth steps; in practice it is 1-3: a state is handed through chunks that cannot change it on the
-        // host (see the verification below), and only a chunk whose predecessor's state is final runs again.
-        if (round > 1024 + 4 * (int)ch.size()) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
-        const size_t nq = todo.size();
-        std::vector<ChunkDesc> descs(nq);
+    }
+    int build(size_t ii);
+    int enqueue_round();
+    int process_round();
+    int begin(hipStream_t side = nullptr);
+    int finish();
+};
+
+// (re)build the chunks of one island; its tile (and tail) segments become empty first
+int IslandRun::build(size_t ii) {
+    const Island &is = islands[ii];
+    const uint32_t c = is.contig;
+    const uint64_t L = b->h_len[c];
+    const uint32_t nt = tile_first[c + 1] - tile_first[c];
+    const uint32_t seg0 = tile_first[c] + c;
+    // (a contig that is one tile may be longer than a tile core: clamped)
+    uint32_t rng[2] = {seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, is.B / tc), seg0 + (uint32_t)std::min<uint64_t>(nt, (is.E + tc - 1) / tc)};
+    if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
+    zero_ranges.push_back(rng[0]);
+    zero_ranges.push_back(rng[1]);
+    // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
+    // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
+    const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : CS_SHORT;
+    const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
+    for (uint64_t j = 0; j < nch; ++j) {
+        HChunk h;
+        memset(&h.d, 0, sizeof(h.d));
+        memset(&h.t_out, 0, sizeof(h.t_out));
+        h.island = ii;
+        h.d.contig = c;
+        h.d.cs = is.whole ? 0 : is.B + j * CS;
+        h.d.ce = is.whole ? L : std::min<uint64_t>(is.E, is.B + (j + 1) * CS);
+        h.d.emit_lo_pos = (j == 0) ? is.B : 0;
+        h.d.drain_end = h.d.ce;
+        if (j + 1 == nch && is.E < L) h.d.drain_end = std::min<uint64_t>(L, is.E + 320);
+        h.d.seg = seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, h.d.cs / tc);
+        h.d.warm = 256;
+        // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
+        // (ties, shmmrutils.rs:516-527), the sparse region estimate would overflow and the chunk run twice
+        // (so is an island around non-ACGT bytes, however short: it may be one of the two ends of a long gap)
+        h.full_cap = nch >= 8 || !is.pal;
+        todo.push_back(ch.size());
+        ch.push_back(h);
+    }
+    if (is.E < L) {  // probe: what a warmed-up (regular) machine looks like at E
+        HChunk h;
+        memset(&h.d, 0, sizeof(h.d));
+        memset(&h.t_out, 0, sizeof(h.t_out));
+        h.island = ii;
+        h.probe = true;
+        h.d.contig = c;
+        h.d.cs = h.d.ce = h.d.drain_end = is.E;
+        h.d.seg = 0xFFFFFFFFu;
+        h.d.warm = 256;
+        todo.push_back(ch.size());
+        ch.push_back(h);
+    }
+    return PGR_OK;
+}
+
+// chunk descriptors up, the chunk kernel, states and counts down (into the pinned image): enqueued, nothing waits
+int IslandRun::enqueue_round() {
+    int rc;
+    nq = todo.size();
+    descs.assign(nq, ChunkDesc());
+    for (size_t q = 0; q < nq; ++q) {
+        HChunk &h = ch[todo[q]];
+        h.d.ring_out = h.probe ? 0xFFFFFFFFu : (uint32_t)todo[q];
+        if (!h.d.override_state) h.d.ring_in = 0xFFFFFFFFu;
+        h.d.region_off = next_region;
+        h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
+        next_region += h.d.region_cap;
+        descs[q] = h.d;
+    }
+    if (st_chunks != st && ctx->ws_l1.cap < (next_region + 1) * sizeof(L1Rec)) st_chunks = st;  // (the buffer grows: in stream order)
+    if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
+    a.out = (L1Rec *)ctx->ws_l1.p;
+    const hipStream_t sc = st_chunks;
+    // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
+    desc_bytes = nq * sizeof(ChunkDesc);
+    const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 4 * sizeof(uint64_t) + sizeof(uint32_t));
+    if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
+    ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
+    ChunkState *d_in = (ChunkState *)(d_desc + nq);
+    ChunkState *d_out = d_in + nq;
+    uint64_t *d_info = (uint64_t *)(d_out + nq);
+    uint32_t *d_stat = (uint32_t *)(d_info + 4 * nq);
+    uint8_t *h_img = (uint8_t *)ctx->imail;
+    memcpy(h_img, descs.data(), desc_bytes);
+    d_zr.reset(new Tmp_list(ctx));
+    if (!zero_ranges.empty()) {
+        if ((rc = d_zr->alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
+        PGR_HIP(ctx, hipMemcpyAsync(d_zr->p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr->p, (uint32_t)(zero_ranges.size() / 2));
+    }
+    // (descriptors up and states down by kernels of this stream, not by a copy engine -- which would take them in the order of
+    // its queue, behind the staging copies of a pipelined host call: pipeline.hip plan())
+    launch_copy_words(sc, (uint32_t *)d_desc, (const uint32_t *)h_img, desc_bytes / 4);
+    PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), sc));
+    // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
+    if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), sc))) return rc;
+    isl_lap("chunks listed, buffers ready", round);
+    launch_level1_chunks(sc, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
+    launch_copy_words(sc, (uint32_t *)(h_img + desc_bytes), (const uint32_t *)d_in, down_bytes / 4);
+    isl_lap(sc == st ? "chunk kernel enqueued" : "chunk kernel enqueued (side stream)", round);
+    enqueued = true;
+    return PGR_OK;
+}
+
+// behind the synchronization: the states of the round's chunks are in the pinned image.  Verifies the seams; todo = the next round
+int IslandRun::process_round() {
+    int rc;
+    enqueued = false;
+    const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 4 * sizeof(uint64_t) + sizeof(uint32_t));
+    (void)down_bytes;
+    uint8_t *h_img = (uint8_t *)ctx->imail;
+    const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
+    const uint64_t *r_info = (const uint64_t *)(r_out + nq);
+    const uint32_t *r_stat = (const uint32_t *)(r_info + 4 * nq);
+    PGR_HIP(ctx, hipGetLastError());
+    zero_ranges.clear();
+    d_zr.reset();
+    s_in.resize(ch.size());
+    s_out.resize(ch.size());
+    status.resize(ch.size());
+    for (size_t q = 0; q < nq; ++q) {
+        s_in[todo[q]] = r_in[q];
+        s_out[todo[q]] = r_out[q];
+        status[todo[q]] = r_stat[q];
+        ch[todo[q]].n_push = r_info[4 * q];
+        ch[todo[q]].bmin = r_info[4 * q + 1];
+        ch[todo[q]].n_out = r_info[4 * q + 3];
+        ch[todo[q]].dropped = false;
+    }
+    if (ctx->opt.debug) {
+        uint32_t worst = 0;
+        size_t wq = 0;
+        uint64_t steps = 0;
+        uint64_t worst_t = 0;
         for (size_t q = 0; q < nq; ++q) {
-            HChunk &h = ch[todo[q]];
-            h.d.ring_out = h.probe ? 0xFFFFFFFFu : (uint32_t)todo[q];
-            if (!h.d.override_state) h.d.ring_in = 0xFFFFFFFFu;
-            h.d.region_off = next_region;
-            h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
-            next_region += h.d.region_cap;
-            descs[q] = h.d;
-        }
-        if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
-        a.out = (L1Rec *)ctx->ws_l1.p;
-        // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
-        const size_t desc_bytes = nq * sizeof(ChunkDesc);
-        const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 4 * sizeof(uint64_t) + sizeof(uint32_t));
-        if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
-        ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
-        ChunkState *d_in = (ChunkState *)(d_desc + nq);
-        ChunkState *d_out = d_in + nq;
-        uint64_t *d_info = (uint64_t *)(d_out + nq);
-        uint32_t *d_stat = (uint32_t *)(d_info + 4 * nq);
-        uint8_t *h_img = (uint8_t *)ctx->imail;
-        memcpy(h_img, descs.data(), desc_bytes);
-        Tmp_list d_zr(ctx);  // (the source vector and this block live until the synchronization at the end of the round)
-        if (!zero_ranges.empty()) {
-            if ((rc = d_zr.alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
-            PGR_HIP(ctx, hipMemcpyAsync(d_zr.p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-            launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr.p, (uint32_t)(zero_ranges.size() / 2));
-        }
-        // (descriptors up and states down by kernels of this stream, not by a copy engine -- which would take them in the order of
-        // its queue, behind the staging copies of a pipelined host call: pipeline.hip plan())
-        launch_copy_words(st, (uint32_t *)d_desc, (const uint32_t *)h_img, desc_bytes / 4);
-        PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), st));
-        // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
-        if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), st))) return rc;
-        isl_lap("chunks listed, buffers ready", round);
-        launch_level1_chunks(st, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
-        launch_copy_words(st, (uint32_t *)(h_img + desc_bytes), (const uint32_t *)d_in, down_bytes / 4);
-        isl_lap("chunk kernel enqueued", round);
-        PGR_HIP(ctx, hipStreamSynchronize(st));
-        isl_lap("states back on the host", round);
-        const ChunkState *r_in = (const ChunkState *)(h_img + desc_bytes), *r_out = r_in + nq;
-        const uint64_t *r_info = (const uint64_t *)(r_out + nq);
-        const uint32_t *r_stat = (const uint32_t *)(r_info + 4 * nq);
-        PGR_HIP(ctx, hipGetLastError());
-        zero_ranges.clear();
-        s_in.resize(ch.size());
-        s_out.resize(ch.size());
-        status.resize(ch.size());
-        for (size_t q = 0; q < nq; ++q) {
-            s_in[todo[q]] = r_in[q];
-            s_out[todo[q]] = r_out[q];
-            status[todo[q]] = r_stat[q];
-            ch[todo[q]].n_push = r_info[4 * q];
-            ch[todo[q]].bmin = r_info[4 * q + 1];
-            ch[todo[q]].n_out = r_info[4 * q + 3];
-            ch[todo[q]].dropped = false;
-        }
-        if (ctx->opt.debug) {
-            uint32_t worst = 0;
-            size_t wq = 0;
-            uint64_t steps = 0;
-            uint64_t worst_t = 0;
-            for (size_t q = 0; q < nq; ++q) {
-                steps += r_stat[q] >> 8;
-                if ((r_info[4 * q + 2] & 0xFFFFFFFFull) > (worst_t & 0xFFFFFFFFull)) {
-                    worst_t = r_info[4 * q + 2];
-                    worst = r_stat[q] >> 8;
-                    wq = q;
-                }
+            steps += r_stat[q] >> 8;
+            if ((r_info[4 * q + 2] & 0xFFFFFFFFull) > (worst_t & 0xFFFFFFFFull)) {
+                worst_t = r_info[4 * q + 2];
+                worst = r_stat[q] >> 8;
+                wq = q;
             }
-            fprintf(stderr, "[pgr]   slowest chunk: %.1f us (%.1f us before its first step), warm %u override %u drain_end %llu\n",
-                    (worst_t & 0xFFFFFFFFull) / 100.0, (worst_t >> 32) / 100.0, descs[wq].warm,
-                    descs[wq].override_state, (unsigned long long)descs[wq].drain_end);
-            fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu; %llu steps of 64 positions, "
-                    "the longest chunk %u (chunk [%llu, %llu) of contig %u%s)\n", round, nq, islands.size(),
-                    (unsigned long long)next_region, (unsigned long long)steps, worst, (unsigned long long)descs[wq].cs,
-                    (unsigned long long)descs[wq].ce, descs[wq].contig, descs[wq].seg == 0xFFFFFFFFu ? ", a probe" : "");
         }
-        // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last).  A chunk is FINAL once the state
-        // it started from is known to be the true one: the island's first chunk (regular by construction), a chunk whose
-        // recorded state at cs equals the true state its final predecessor left at ce (the warm-up was right, or the state was
-        // installed), and a chunk without a push in [cs, ce) behind a final predecessor -- the machine does not move there
-        // (shmmrutils.rs:477-480: a skipped position touches neither ring nor mdist), so its end state is its predecessor's
-        // with the k-mer rolled on, and its (empty) output is right whatever state it ran with.  Only a chunk with a final
-        // predecessor is corrected, with that predecessor's true state and ring: a correction never builds on a stale state.
-        std::vector<size_t> next;
-        std::vector<size_t> rebuild;  // islands to rebuild (grown or turned into one whole-contig chunk)
-        const bool relay = !ctx->opt.no_island_relay;
-        for (size_t i = 0; i < ch.size(); ++i) {
-            HChunk &h = ch[i];
-            if (h.retired) continue;
-            Island &is = islands[h.island];
-            if (status[i] & 2u) {  // the true state could not be installed: the contig as one chunk
-                if (!is.whole) {
-                    is.whole = true;
-                    is.B = 0;
-                    is.E = b->h_len[is.contig];
-                    rebuild.push_back(h.island);
-                }
-                continue;
+        fprintf(stderr, "[pgr]   slowest chunk: %.1f us (%.1f us before its first step), warm %u override %u drain_end %llu\n",
+                (worst_t & 0xFFFFFFFFull) / 100.0, (worst_t >> 32) / 100.0, descs[wq].warm,
+                descs[wq].override_state, (unsigned long long)descs[wq].drain_end);
+        fprintf(stderr, "[pgr] exact islands round %d: %zu chunks run, %zu islands, region end %llu; %llu steps of 64 positions, "
+                "the longest chunk %u (chunk [%llu, %llu) of contig %u%s)\n", round, nq, islands.size(),
+                (unsigned long long)next_region, (unsigned long long)steps, worst, (unsigned long long)descs[wq].cs,
+                (unsigned long long)descs[wq].ce, descs[wq].contig, descs[wq].seg == 0xFFFFFFFFu ? ", a probe" : "");
+    }
+    // ---- verify seams (chunks of an island are contiguous in `ch`, the probe comes last).  A chunk is FINAL once the state
+    // it started from is known to be the true one: the island's first chunk (regular by construction), a chunk whose
+    // recorded state at cs equals the true state its final predecessor left at ce (the warm-up was right, or the state was
+    // installed), and a chunk without a push in [cs, ce) behind a final predecessor -- the machine does not move there
+    // (shmmrutils.rs:477-480: a skipped position touches neither ring nor mdist), so its end state is its predecessor's
+    // with the k-mer rolled on, and its (empty) output is right whatever state it ran with.  Only a chunk with a final
+    // predecessor is corrected, with that predecessor's true state and ring: a correction never builds on a stale state.
+    std::vector<size_t> next;
+    std::vector<size_t> rebuild;  // islands to rebuild (grown or turned into one whole-contig chunk)
+    const bool relay = !ctx->opt.no_island_relay;
+    for (size_t i = 0; i < ch.size(); ++i) {
+        HChunk &h = ch[i];
+        if (h.retired) continue;
+        Island &is = islands[h.island];
+        if (status[i] & 2u) {  // the true state could not be installed: the contig as one chunk
+            if (!is.whole) {
+                is.whole = true;
+                is.B = 0;
+                is.E = b->h_len[is.contig];
+                rebuild.push_back(h.island);
             }
-            bool again = false;
-            if (status[i] & 1u) {  // region overflow
-                h.full_cap = true;
+            continue;
+        }
+        bool again = false;
+        if (status[i] & 1u) {  // region overflow
+            h.full_cap = true;
+            again = true;
+        }
+        const bool has_prev = i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island;
+        auto grow = [&]() {
+            // the machine is not back in its regular regime at E: grow the island
+            const uint64_t L = b->h_len[is.contig];
+            is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
+            if (L - is.E < 2ull * tc) is.E = L;
+            rebuild.push_back(h.island);
+        };
+        if (!relay) {  // the round-3 scheme (A/B): every seam against whatever the chunk in front produced last
+            if (h.probe) {
+                if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) grow();
+            } else if (!is.whole && h.d.cs > is.B && has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
+                h.d.override_state = 1;
+                h.d.in_state = s_out[i - 1];
+                h.d.ring_in = (uint32_t)(i - 1);
+                h.d.warm = 1024;
                 again = true;
             }
-            const bool has_prev = i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island;
-            auto grow = [&]() {
-                // the machine is not back in its regular regime at E: grow the island
-                const uint64_t L = b->h_len[is.contig];
-                is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
-                if (L - is.E < 2ull * tc) is.E = L;
-                rebuild.push_back(h.island);
-            };
-            if (!relay) {  // the round-3 scheme (A/B): every seam against whatever the chunk in front produced last
-                if (h.probe) {
-                    if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) grow();
-                } else if (!is.whole && h.d.cs > is.B && has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
-                    h.d.override_state = 1;
-                    h.d.in_state = s_out[i - 1];
-                    h.d.ring_in = (uint32_t)(i - 1);
-                    h.d.warm = 1024;
-                    again = true;
-                }
-                if (again) next.push_back(i);
-                continue;
-            }
-            if (h.probe) {
-                if (!has_prev) h.final = true;
-                else if (ch[i - 1].final && !h.final) {
-                    if (memcmp(&s_in[i], &ch[i - 1].t_out, sizeof(ChunkState)) != 0) {
-                        if (ctx->opt.debug) {
-                            const ChunkState &p = s_in[i], &q = ch[i - 1].t_out;
-                            fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
-                                    "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
-                                    (unsigned long long)p.min_x, (unsigned long long)q.min_x, (unsigned long long)p.min_y,
-                                    (unsigned long long)q.min_y, (unsigned long long)p.mdist, (unsigned long long)q.mdist,
-                                    (unsigned long long)p.F0, (unsigned long long)q.F0, (unsigned long long)p.R0,
-                                    (unsigned long long)q.R0, (unsigned long long)p.ring_sig, (unsigned long long)q.ring_sig);
-                        }
-                        grow();
-                    } else {
-                        h.final = true;
+            if (again) next.push_back(i);
+            continue;
+        }
+        if (h.probe) {
+            if (!has_prev) h.final = true;
+            else if (ch[i - 1].final && !h.final) {
+                if (memcmp(&s_in[i], &ch[i - 1].t_out, sizeof(ChunkState)) != 0) {
+                    if (ctx->opt.debug) {
+                        const ChunkState &p = s_in[i], &q = ch[i - 1].t_out;
+                        fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "
+                                "F0 %llx/%llx R0 %llx/%llx sig %llx/%llx\n", is.contig, (unsigned long long)is.E,
+                                (unsigned long long)p.min_x, (unsigned long long)q.min_x, (unsigned long long)p.min_y,
+                                (unsigned long long)q.min_y, (unsigned long long)p.mdist, (unsigned long long)q.mdist,
+                                (unsigned long long)p.F0, (unsigned long long)q.F0, (unsigned long long)p.R0,
+                                (unsigned long long)q.R0, (unsigned long long)p.ring_sig, (unsigned long long)q.ring_sig);
                     }
+                    grow();
+                } else {
+                    h.final = true;
                 }
-            } else if (is.whole || !has_prev || h.d.cs <= is.B) {  // the island's first chunk
+            }
+        } else if (is.whole || !has_prev || h.d.cs <= is.B) {  // the island's first chunk
+            h.final = true;
+            h.t_out = s_out[i];
+            h.ring_src = (uint32_t)i;
+        } else if (ch[i - 1].final) {
+            const HChunk &pv = ch[i - 1];
+            const ChunkState &t = pv.t_out;
+            const bool kmer_ok = s_in[i].F0 == t.F0 && s_in[i].F1 == t.F1 && s_in[i].R0 == t.R0 && s_in[i].R1 == t.R1;
+            if ((status[i] & 4u) && kmer_ok) {  // no push in [cs, ce): the state passes through
+                h.final = true;
+                h.t_out = t;
+                h.t_out.F0 = s_out[i].F0;
+                h.t_out.F1 = s_out[i].F1;
+                h.t_out.R0 = s_out[i].R0;
+                h.t_out.R1 = s_out[i].R1;
+                h.ring_src = pv.ring_src;
+            } else if (memcmp(&s_in[i], &t, sizeof(ChunkState)) == 0) {
                 h.final = true;
                 h.t_out = s_out[i];
                 h.ring_src = (uint32_t)i;
-            } else if (ch[i - 1].final) {
-                const HChunk &pv = ch[i - 1];
-                const ChunkState &t = pv.t_out;
-                const bool kmer_ok = s_in[i].F0 == t.F0 && s_in[i].F1 == t.F1 && s_in[i].R0 == t.R0 && s_in[i].R1 == t.R1;
-                if ((status[i] & 4u) && kmer_ok) {  // no push in [cs, ce): the state passes through
-                    h.final = true;
-                    h.t_out = t;
-                    h.t_out.F0 = s_out[i].F0;
-                    h.t_out.F1 = s_out[i].F1;
-                    h.t_out.R0 = s_out[i].R0;
-                    h.t_out.R1 = s_out[i].R1;
-                    h.ring_src = pv.ring_src;
-                } else if (memcmp(&s_in[i], &t, sizeof(ChunkState)) == 0) {
-                    h.final = true;
-                    h.t_out = s_out[i];
-                    h.ring_src = (uint32_t)i;
-                } else if (kmer_ok && !a.sketch && t.mdist > (uint64_t)(a.w - 1) && h.n_push >= a.w && h.bmin > t.min_x &&
-                           h.d.drain_end <= h.d.ce && !(status[i] & 1u)) {
-                    // The machine arrives STUCK: mdist is beyond w - 1 (a rescan measured the distance to a minimum from in
-                    // front of a stretch of skipped pushes, shmmrutils.rs:505-514), so no rescan can fire, and no push of this
-                    // chunk reaches down to min_mer (branch 2, :516-520) -- nothing is emitted, min_mer stays, mdist counts the
-                    // pushes, and with >= w pushes the ring at ce holds this chunk's own last w pushes: exactly what its run
-                    // from a warmed-up state left there.  Its output of that run is dropped.
-                    h.final = true;
-                    h.t_out = s_out[i];
-                    h.t_out.min_x = t.min_x;
-                    h.t_out.min_y = t.min_y;
-                    h.t_out.mdist = t.mdist + h.n_push;
-                    h.ring_src = (uint32_t)i;
-                    h.dropped = true;
-                } else {
-                    if (ctx->opt.debug)
-                        fprintf(stderr, "[pgr]   chunk %zu [%llu, %llu) of contig %u runs again from the true state: mdist %llu (warm-up %llu), "
-                                "min_x %llx (%llx), %llu pushes, smallest branch-2 x %llx\n", i, (unsigned long long)h.d.cs,
-                                (unsigned long long)h.d.ce, is.contig, (unsigned long long)t.mdist, (unsigned long long)s_in[i].mdist,
-                                (unsigned long long)t.min_x, (unsigned long long)s_in[i].min_x, (unsigned long long)h.n_push,
-                                (unsigned long long)h.bmin);
-                    h.final = false;
-                    h.d.override_state = 1;
-                    h.d.in_state = t;
-                    h.d.ring_in = pv.ring_src;  // the ring the last chunk with a push left at its end
-                    h.d.warm = 0;               // (ring, minimizer state and rolling k-mer all come from the chunk in front)
-                    again = true;
-                }
-            }  // else: the chunk in front is not settled yet
-            if (again) next.push_back(i);
-        }
-        if (!rebuild.empty()) {
-            std::sort(rebuild.begin(), rebuild.end());
-            rebuild.erase(std::unique(rebuild.begin(), rebuild.end()), rebuild.end());
-            for (auto &h : ch)
-                if (std::binary_search(rebuild.begin(), rebuild.end(), h.island)) h.retired = true;
-            next.erase(std::remove_if(next.begin(), next.end(), [&](size_t i) { return ch[i].retired; }), next.end());
-            todo.swap(next);
-            for (size_t ii : rebuild) {
-                // merge with later islands of the same contig that the grown island now touches
-                for (size_t jj = 0; jj < islands.size(); ++jj)
-                    if (jj != ii && islands[jj].contig == islands[ii].contig && islands[jj].B < islands[ii].E + tc &&
-                        islands[jj].B >= islands[ii].B && islands[jj].E > islands[ii].B && !islands[jj].whole &&
-                        islands[jj].E != 0) {
-                        islands[ii].E = std::max(islands[ii].E, islands[jj].E);
-                        islands[ii].pal = islands[ii].pal || islands[jj].pal;
-                        for (auto &h : ch)
-                            if (h.island == jj) h.retired = true;
-                        islands[jj].E = islands[jj].B = 0;  // absorbed
-                    }
-                todo.erase(std::remove_if(todo.begin(), todo.end(), [&](size_t i) { return ch[i].retired; }), todo.end());
-                if ((rc = build(ii))) return rc;
+            } else if (kmer_ok && !a.sketch && t.mdist > (uint64_t)(a.w - 1) && h.n_push >= a.w && h.bmin > t.min_x &&
+                       h.d.drain_end <= h.d.ce && !(status[i] & 1u)) {
+                // The machine arrives STUCK: mdist is beyond w - 1 (a rescan measured the distance to a minimum from in
+                // front of a stretch of skipped pushes, shmmrutils.rs:505-514), so no rescan can fire, and no push of this
+                // chunk reaches down to min_mer (branch 2, :516-520) -- nothing is emitted, min_mer stays, mdist counts the
+                // pushes, and with >= w pushes the ring at ce holds this chunk's own last w pushes: exactly what its run
+                // from a warmed-up state left there.  Its output of that run is dropped.
+                h.final = true;
+                h.t_out = s_out[i];
+                h.t_out.min_x = t.min_x;
+                h.t_out.min_y = t.min_y;
+                h.t_out.mdist = t.mdist + h.n_push;
+                h.ring_src = (uint32_t)i;
+                h.dropped = true;
+            } else {
+                if (ctx->opt.debug)
+                    fprintf(stderr, "[pgr]   chunk %zu [%llu, %llu) of contig %u runs again from the true state: mdist %llu (warm-up %llu), "
+                            "min_x %llx (%llx), %llu pushes, smallest branch-2 x %llx\n", i, (unsigned long long)h.d.cs,
+                            (unsigned long long)h.d.ce, is.contig, (unsigned long long)t.mdist, (unsigned long long)s_in[i].mdist,
+                            (unsigned long long)t.min_x, (unsigned long long)s_in[i].min_x, (unsigned long long)h.n_push,
+                            (unsigned long long)h.bmin);
+                h.final = false;
+                h.d.override_state = 1;
+                h.d.in_state = t;
+                h.d.ring_in = pv.ring_src;  // the ring the last chunk with a push left at its end
+                h.d.warm = 0;               // (ring, minimizer state and rolling k-mer all come from the chunk in front)
+                again = true;
             }
-        } else {
-            todo.swap(next);
+        }  // else: the chunk in front is not settled yet
+        if (again) next.push_back(i);
+    }
+    if (!rebuild.empty()) {
+        std::sort(rebuild.begin(), rebuild.end());
+        rebuild.erase(std::unique(rebuild.begin(), rebuild.end()), rebuild.end());
+        for (auto &h : ch)
+            if (std::binary_search(rebuild.begin(), rebuild.end(), h.island)) h.retired = true;
+        next.erase(std::remove_if(next.begin(), next.end(), [&](size_t i) { return ch[i].retired; }), next.end());
+        todo.swap(next);
+        for (size_t ii : rebuild) {
+            // merge with later islands of the same contig that the grown island now touches
+            for (size_t jj = 0; jj < islands.size(); ++jj)
+                if (jj != ii && islands[jj].contig == islands[ii].contig && islands[jj].B < islands[ii].E + tc &&
+                    islands[jj].B >= islands[ii].B && islands[jj].E > islands[ii].B && !islands[jj].whole &&
+                    islands[jj].E != 0) {
+                    islands[ii].E = std::max(islands[ii].E, islands[jj].E);
+                    islands[ii].pal = islands[ii].pal || islands[jj].pal;
+                    for (auto &h : ch)
+                        if (h.island == jj) h.retired = true;
+                    islands[jj].E = islands[jj].B = 0;  // absorbed
+                }
+            todo.erase(std::remove_if(todo.begin(), todo.end(), [&](size_t i) { return ch[i].retired; }), todo.end());
+            if ((rc = build(ii))) return rc;
         }
+    } else {
+        todo.swap(next);
+    }
+    return PGR_OK;
+}
+
+int IslandRun::begin(hipStream_t side) {
+    int rc;
+    st_chunks = side ? side : st;
+    t_isl0 = std::chrono::steady_clock::now();
+    for (size_t ii = 0; ii < islands.size(); ++ii)
+        if ((rc = build(ii))) return rc;
+    round = 0;
+    return todo.empty() ? PGR_OK : enqueue_round();
+}
+
+int IslandRun::finish() {
+    int rc;
+    for (; !todo.empty(); ++round) {
+        // Every round settles at least one seam or grows / merges an island, so the number of rounds is bounded by the number
+        // of chunks plus the growth steps; in practice it is 1-3: a state is handed through chunks that cannot change it on the
+        // host (see the verification in process_round), and only a chunk whose predecessor's state is final runs again.
+        if (round > 1024 + 4 * (int)ch.size()) return ctx->fail(PGR_ERR_INTERNAL, "exact-machine islands did not converge");
+        if (!enqueued && (rc = enqueue_round())) return rc;
+        if (st_chunks != st) {
+            PGR_HIP(ctx, hipStreamSynchronize(st_chunks));
+            st_chunks = st;  // (the rounds behind the first: in stream order)
+        }
+        PGR_HIP(ctx, hipStreamSynchronize(st));
+        isl_lap("states back on the host", round);
+        if ((rc = process_round())) return rc;
     }
     if (!zero_ranges.empty()) {  // (segment ranges of islands built in the last round: none in practice)
         Tmp_list d_zr(ctx);
@@ -416,6 +487,17 @@ static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::v
         }
     }
     isl_lap("tile lists assembled (enqueued)", -1);
+    return PGR_OK;
+}
+
+static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
+                             const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base,
+                             const std::vector<uint32_t> &empty_seg_ranges) {
+    IslandRun run(ctx, b, a, islands, tile_first, tc, region_base, empty_seg_ranges);
+    int rc;
+    if ((rc = run.begin()) || (rc = run.finish())) return rc;
+    a.out = run.a.out;
+    islands = run.islands;
     return PGR_OK;
 }
 
@@ -618,6 +700,7 @@ struct ShmmrJob {
     std::vector<Island> pre_islands;
     std::vector<uint32_t> pre_gap_segs;
     bool pre_listed = false;
+    std::unique_ptr<IslandRun> early_islands;  // round 0 of the pre-listed islands, enqueued behind the tile kernel (stage1)
     // ---- the list stage and the result
     pgr_shmmrs *res = nullptr;
     uint32_t n_blocks = 0;  // grid of the fused kernel
@@ -898,6 +981,7 @@ int ShmmrJob::stage1() {
     l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
     if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     pre_listed = false;
+    early_islands.reset();
     if (tiled && bases_tiled) {
         launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p);
         const bool pre = b->host_saw_invalid && !b->h_n_invalid.empty() && n_tiles && !ctx->opt.no_pre_islands;
@@ -920,6 +1004,25 @@ int ShmmrJob::stage1() {
             list_islands(no_flags.data(), b->h_n_invalid.data(), (uint8_t *)ctx->imail, pre_islands, pre_gap_segs);
             pre_listed = true;
             dbg_lap("islands around non-ACGT bytes listed");
+            // The synchronous driver is about to wait for the tile kernel's flags and would only then build and launch the
+            // islands' first round (a chromosome-like contig: flags on the host at 0.64 ms, chunk kernel running from 0.71).
+            // These islands do not depend on the flags: their round 0 goes behind the tile kernel NOW, and when the flags
+            // arrive the chunks' states are on their way.  A flag that adds an island (a palindromic k-mer) makes
+            // run_islands() list them again and start over: the early round's work is then wasted, not wrong -- it wrote
+            // behind serial_base and emptied segments that the longer list empties again.
+            if (early_sync && !optimistic && serial.empty() && !pre_islands.empty() && st == ctx->stream && !ctx->opt.no_early_islands) {
+                L1Args as = a;
+                as.w = sketch ? 1u : spec.w;
+                as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;  // (made cumulative in front of the tile kernel, above)
+                // (the pinned image must not move while the round's kernels are pending: room for the flags' download as well)
+                if ((r = ctx->ensure_imail(2 * (std::max<size_t>(n, 1) * sizeof(uint32_t) + 16) + n_tiles + 64))) return r;
+                early_islands.reset(new IslandRun(ctx, b, as, pre_islands, tile_first(), tc, serial_base, pre_gap_segs));
+                // (beside the tile kernel when the device runs two streams side by side; the side stream has waited for everything
+                // in front of the tile kernel: the copy of the tile flags above)
+                if ((r = early_islands->begin(ctx->opt.early_islands_in_stream ? nullptr : ctx->pre_stream))) return r;
+                a.out = early_islands->a.out;  // (the level-1 buffer may have grown -- behind the tile kernel, which has its pointer)
+                dbg_lap("islands: round 0 enqueued behind the tile kernel");
+            }
         }
     }
     PGR_HIP(ctx, hipEventRecord(ctx->ev[2], st));
@@ -937,6 +1040,9 @@ int ShmmrJob::run_islands(uint64_t need_word) {
     std::vector<uint32_t> gap_segs;  // [first, last + 1) segment ranges of tiles deep inside runs of non-ACGT bytes: emptied
     for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false, true});
     const bool use_pre = pre_listed && !(need_word & 1ull) && serial.empty();  // (no tile saw a palindromic k-mer)
+    // (a tile saw a palindromic k-mer: the early round is dropped -- which waits for it if it runs on the side stream -- BEFORE the
+    // flags come down into the pinned image its states are written to)
+    if (!use_pre) early_islands.reset();
     if (use_pre) {
         islands = pre_islands;
         gap_segs = pre_gap_segs;
@@ -975,7 +1081,15 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         }
         if (tiled && bases_tiled && n_tiles) as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;
         dbg_lap("islands: listed");
-        int r = run_exact_islands(ctx, b, as, islands, tile_first(), tc, serial_base, gap_segs);
+        int r;
+        if (use_pre && early_islands) {  // round 0 is behind the tile kernel already
+            r = early_islands->finish();
+            as.out = early_islands->a.out;
+            islands = early_islands->islands;
+        } else {
+            r = run_exact_islands(ctx, b, as, islands, tile_first(), tc, serial_base, gap_segs);
+        }
+        early_islands.reset();
         if (r) return r;
         dbg_lap("islands: exact");
         a.out = as.out;

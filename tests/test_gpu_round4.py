@@ -324,7 +324,10 @@ def test_island_options_agree_with_the_oracle(oracle, gpu_ctx):
     spec, osp = P.make_spec(*spec_t), oracle.spec(*spec_t)
     refs = [oracle.sequence_to_shmmrs(i, s, osp) for i, s in enumerate(seqs)]
     variants = [{}, {"no_pre_islands": 1}, {"island_chunk_min": 4096}, {"island_chunk_min": 1024, "no_island_relay": 1},
-                {"island_chunk_min": 32768}, {"no_short_tiles": 1, "no_small_path": 1}]
+                {"island_chunk_min": 32768}, {"no_short_tiles": 1, "no_small_path": 1},
+                # round 5: the first round of the islands around non-ACGT bytes beside the tile kernel (default) / behind it on
+                # its stream / only when the flags are in; a batch with a palindromic array drops the early round and starts over
+                {"early_islands_in_stream": 1}, {"no_early_islands": 1}]
     for opt in variants:
         with gpu_ctx.options(**dict(opt, no_small_path=1)):
             got = P.sequence_to_shmmrs_batch(seqs, spec, ctx=gpu_ctx)  # host entry point

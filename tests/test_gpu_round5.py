@@ -1,12 +1,15 @@
 """Round-5 parity tests (run with -m gpu on a MI355X): the software pipeline over resident batches (pgr_pipe_*, the loop of
 load_index_from_reader, pgr-db/src/seq_db.rs:541-571, with two batches in flight) against the synchronous calls and the CPU
 restatement."""
+import os
+
 import numpy as np
 import pytest
 
 import seqgen
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SPEC = (80, 56, 4, 64, False)
 
@@ -266,3 +269,21 @@ def test_merge_of_step_i_beside_the_tiles_of_step_i_plus_1():
     assert "error" not in ov, ov
     assert ov["content_match_vs_timed_loop"] is True
     assert line["exchange"]["rccl_ranks_in_the_librarys_communicator"] == 1
+
+
+def test_early_island_round_is_dropped_cleanly_when_the_flags_add_islands(oracle, gpu_ctx):
+    """The first round of the islands around non-ACGT bytes starts beside the tile kernel (ShmmrJob::stage1, IslandRun::begin on the
+    side stream); a tile that then reports a palindromic k-mer makes the job list the islands again and start over -- after the
+    early round has left the pinned image its states are written to (the flags come down into the same image).  Case 920174 of
+    tools/fuzz_parity.py (max_len 6 Mbp: gaps AND palindromic arrays in contigs of up to 1.6 Mbp) found that order wrong once;
+    here with its neighbours, and the chromosome-like shape's options for A/B."""
+    import sys
+    from concurrent.futures import ThreadPoolExecutor
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_parity
+    with ThreadPoolExecutor(8) as pool:
+        for opts in ({}, {"early_islands_in_stream": 1}, {"no_early_islands": 1}):
+            with gpu_ctx.options(**opts):
+                for seed in (920174, 920175, 920021):
+                    r = fuzz_parity.one_case(seed, 6_000_000, gpu_ctx, pool)
+                    assert not isinstance(r, str), (opts, r)
