@@ -439,6 +439,11 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     const uint64_t t_begin = wall_clock64();
     const uint32_t lane = threadIdx.x;
     const ChunkDesc cd = descs[blockIdx.x];
+    if (lane == 0) {  // (a chunk that never reaches its seam reports an empty state; descs / st_in / st_out / status / info: pinned host memory)
+        ChunkState z;
+        memset(&z, 0, sizeof(z));
+        st_in[blockIdx.x] = z;
+    }
     const uint32_t c = cd.contig;
     const uint32_t w = a.w, k = a.k;
     const long long L = a.b.len[c];

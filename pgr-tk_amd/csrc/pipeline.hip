@@ -192,16 +192,19 @@ int IslandRun::enqueue_round() {
     if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
     a.out = (L1Rec *)ctx->ws_l1.p;
     const hipStream_t sc = st_chunks;
-    // one block on the device and its pinned image on the host: [descriptors | states at cs | states at ce | push info | status]
+    // ONE pinned block on the host: [descriptors | states at cs | states at ce | push info | status].  The chunk kernel reads its
+    // descriptor from it and writes its states into it across PCIe (a hundred bytes per wavefront each way): a round is the
+    // chunk kernel alone -- the upload kernel, the clearing of the states and the download kernel in front of and behind it
+    // were 12-15 us of a round's 45-60 (three rounds for the repeat-rich contigs)
     desc_bytes = nq * sizeof(ChunkDesc);
     const size_t down_bytes = nq * (2 * sizeof(ChunkState) + 4 * sizeof(uint64_t) + sizeof(uint32_t));
-    if ((rc = ctx->ws_serial.ensure(ctx, desc_bytes + down_bytes)) || (rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
-    ChunkDesc *d_desc = (ChunkDesc *)ctx->ws_serial.p;
+    if ((rc = ctx->ensure_imail(desc_bytes + down_bytes))) return rc;
+    uint8_t *h_img = (uint8_t *)ctx->imail;
+    ChunkDesc *d_desc = (ChunkDesc *)h_img;
     ChunkState *d_in = (ChunkState *)(d_desc + nq);
     ChunkState *d_out = d_in + nq;
     uint64_t *d_info = (uint64_t *)(d_out + nq);
     uint32_t *d_stat = (uint32_t *)(d_info + 4 * nq);
-    uint8_t *h_img = (uint8_t *)ctx->imail;
     memcpy(h_img, descs.data(), desc_bytes);
     d_zr.reset(new Tmp_list(ctx));
     if (!zero_ranges.empty()) {
@@ -209,15 +212,10 @@ int IslandRun::enqueue_round() {
         PGR_HIP(ctx, hipMemcpyAsync(d_zr->p, zero_ranges.data(), zero_ranges.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
         launch_zero_seg_ranges(st, a, (const uint32_t *)d_zr->p, (uint32_t)(zero_ranges.size() / 2));
     }
-    // (descriptors up and states down by kernels of this stream, not by a copy engine -- which would take them in the order of
-    // its queue, behind the staging copies of a pipelined host call: pipeline.hip plan())
-    launch_copy_words(sc, (uint32_t *)d_desc, (const uint32_t *)h_img, desc_bytes / 4);
-    PGR_HIP(ctx, hipMemsetAsync(d_in, 0, nq * sizeof(ChunkState), sc));
     // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
     if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), sc))) return rc;
     isl_lap("chunks listed, buffers ready", round);
     launch_level1_chunks(sc, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
-    launch_copy_words(sc, (uint32_t *)(h_img + desc_bytes), (const uint32_t *)d_in, down_bytes / 4);
     isl_lap(sc == st ? "chunk kernel enqueued" : "chunk kernel enqueued (side stream)", round);
     enqueued = true;
     return PGR_OK;
@@ -700,6 +698,7 @@ struct ShmmrJob {
     std::vector<Island> pre_islands;
     std::vector<uint32_t> pre_gap_segs;
     bool pre_listed = false;
+    bool flags_prefetched = false;  // contig flags, tile flags and the contigs' non-ACGT counts came down with the status words
     std::unique_ptr<IslandRun> early_islands;  // round 0 of the pre-listed islands, enqueued behind the tile kernel (stage1)
     // ---- the list stage and the result
     pgr_shmmrs *res = nullptr;
@@ -981,6 +980,7 @@ int ShmmrJob::stage1() {
     l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
     if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
     pre_listed = false;
+    flags_prefetched = false;
     early_islands.reset();
     if (tiled && bases_tiled) {
         launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p);
@@ -1054,9 +1054,12 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         int r0;
         if ((r0 = ctx->ensure_imail(inv_off + nc))) return r0;
         uint8_t *img = (uint8_t *)ctx->imail;
-        PGR_HIP(ctx, hipMemcpyAsync(img, d_cflags, flag_bytes, hipMemcpyDeviceToHost, st));
-        if (n) PGR_HIP(ctx, hipMemcpyAsync(img + inv_off, b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        PGR_HIP(ctx, hipStreamSynchronize(st));
+        if (!flags_prefetched) {
+            PGR_HIP(ctx, hipMemcpyAsync(img, d_cflags, flag_bytes, hipMemcpyDeviceToHost, st));
+            if (n) PGR_HIP(ctx, hipMemcpyAsync(img + inv_off, b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            PGR_HIP(ctx, hipStreamSynchronize(st));
+        }
+        flags_prefetched = false;
         dbg_lap("islands: tile flags on the host");
         std::vector<uint8_t> tf(img + nc, img + nc + n_tiles);  // (list_islands marks tiles in its copy; run_exact_islands reuses the image)
         std::vector<uint32_t> flags((const uint32_t *)img, (const uint32_t *)img + n), n_invalid((const uint32_t *)(img + inv_off), (const uint32_t *)(img + inv_off) + n);
@@ -1253,6 +1256,19 @@ int ShmmrJob::enqueue_pass() {
     if (from <= 1) {
         if ((rc = stage1())) return rc;
         if (early_sync && !optimistic) {
+            // (a small batch that is looked at early is a batch that probably needs islands: its flags ride along with the status
+            // words instead of costing a second round trip -- 20 us of the repeat-rich contigs' 500 -- unless the pinned image
+            // belongs to the early round of the islands, which then needs no flags)
+            flags_prefetched = false;
+            const size_t nc = std::max<size_t>(n, 1) * sizeof(uint32_t);
+            const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15;
+            if (tiled && bases_tiled && !early_islands && inv_off + nc <= (256u << 10)) {
+                if ((rc = ctx->ensure_imail(inv_off + nc))) return rc;
+                uint8_t *img = (uint8_t *)ctx->imail;
+                launch_copy_words(sf, (uint32_t *)img, (const uint32_t *)d_cflags, (flag_bytes + 3) / 4);  // (64 bytes of slack behind the tile flags)
+                if (n) launch_copy_words(sf, (uint32_t *)(img + inv_off), (const uint32_t *)b->d.n_invalid, n);
+                flags_prefetched = true;
+            }
             launch_copy_words(sf, (uint32_t *)mbox, (const uint32_t *)d_cursor, 8);  // (by a kernel: see plan())
             if (hipStreamSynchronize(sf) != hipSuccess || hipGetLastError() != hipSuccess)
                 return ctx->fail(PGR_ERR_DEVICE, "level-1 kernels failed on the device");

@@ -64,8 +64,8 @@ for _ in range(3):
     sh = b.shmmrs(sp)
     ts.append(time.perf_counter() - t0)
 p = ctx.last_prof()
-print("GPU: %.1f ms (%s), %d shimmers from %d level-1 minimizers, %.1f Mbp through the exact islands" %
-      (min(ts) * 1e3, " ".join("%.1f" % (t * 1e3) for t in ts), sh.count, p.n_level1, p.exact_bases / 1e6))
+print("GPU: %.3f ms (%s), %d shimmers from %d level-1 minimizers, %.1f Mbp through the exact islands" %
+      (min(ts) * 1e3, " ".join("%.3f" % (t * 1e3) for t in ts), sh.count, p.n_level1, p.exact_bases / 1e6))
 with ctx.options(no_island_relay=1):  # A/B: the round-3 seam correction (one seam per host round)
     b.shmmrs(sp)
     ts3 = []
