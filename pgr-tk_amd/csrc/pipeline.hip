@@ -58,7 +58,7 @@ struct IslandRun {
     const std::vector<uint32_t> &tile_first;
     uint32_t tc;
     hipStream_t st;
-    uint64_t CS_SHORT = 1024;
+    uint64_t CS_SHORT = 1024, CS_PAL = 512;
     std::vector<uint32_t> zero_ranges;  // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
     struct HChunk {
         ChunkDesc d;
@@ -101,6 +101,12 @@ struct IslandRun {
         // (~2.5 wavefronts per SIMD: below that a round waits for dependent instructions, above it the SIMDs are busy -- a step is
         // ~1.5 us of issue -- and shorter chunks only add warm-up steps)
         CS_SHORT = std::min<uint64_t>(32768, std::max<uint64_t>(CS_MIN, ((island_bases / 2560 + 1023) / 1024) * 1024));
+        // Islands around palindromic k-mers come from the tile kernel's flags: their rounds are on the critical path, one after
+        // the other, and a round costs what its slowest chunk costs -- 512 positions (+ 256 of warm-up: 12 steps instead of 20;
+        // a chunk that runs again: 8 instead of 16) unless the islands are large.  The islands around non-ACGT bytes run beside
+        // the tile kernel: more, shorter chunks there only take its slots (chromosome-like 0.85 -> 0.875 ms at 768).
+        const uint64_t PAL_MIN = ctx->opt.island_chunk_min > 0 ? CS_MIN : 512;
+        CS_PAL = std::min<uint64_t>(32768, std::max<uint64_t>(PAL_MIN, ((island_bases / 2560 + 255) / 256) * 256));
     }
     // (a run that is dropped with its first round still on the side stream -- the flags added islands, or the pass starts over:
     // whoever uses the workspaces, the pinned image and the regions next must find them idle)
@@ -136,7 +142,7 @@ int IslandRun::build(size_t ii) {
     zero_ranges.push_back(rng[1]);
     // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
     // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
-    const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : CS_SHORT;
+    const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
     const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
     for (uint64_t j = 0; j < nch; ++j) {
         HChunk h;
