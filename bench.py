@@ -685,19 +685,24 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
         fresh.synchronize()
         fresh.mem_stats(reset_peak=True)
         t0 = time.perf_counter()
-        ix = P.Index(spec, ctx=fresh)
-        ix.reserve(int(n_b * n_c * L * 0.003036 * 1.01) + 4096)  # pair records per base at (80, 56, 4, 64), SURVEY 8
-        calls = [("pgr_index_reserve", time.perf_counter() - t0)]
-        pipe = P.Pipe(spec, ctx=fresh)
+        calls = []
+
+        def timed(name, f):
+            ts = time.perf_counter()
+            r = f()
+            calls.append((name, time.perf_counter() - ts))
+            return r
+        ix = timed("pgr_index_create", lambda: P.Index(spec, ctx=fresh))
+        # pair records per base at (80, 56, 4, 64), SURVEY 8
+        timed("pgr_index_reserve", lambda: ix.reserve(int(n_b * n_c * L * 0.003036 * 1.01) + 4096))
+        pipe = timed("pgr_pipe_create", lambda: P.Pipe(spec, ctx=fresh))
         kept = []
         for bi in range(n_b):
             ids = list(range(bi * n_c, (bi + 1) * n_c))
-            b = P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=fresh, contig_ids=ids)
+            b = timed("pgr_batch_synthetic of batch %d" % bi, lambda: P.Batch.synthetic([L] * n_c, seed=args.seed, ctx=fresh, contig_ids=ids))
             if pipe.in_flight == 2:
-                kept.append(pipe.collect(want_shmmrs=keep))
-            ts = time.perf_counter()
-            pipe.submit(b, sids=ids, index=ix)
-            calls.append(("pgr_pipe_submit of batch %d" % bi, time.perf_counter() - ts))
+                kept.append(timed("pgr_pipe_collect in front of batch %d" % bi, lambda: pipe.collect(want_shmmrs=keep)))
+            timed("pgr_pipe_submit of batch %d" % bi, lambda: pipe.submit(b, sids=ids, index=ix))
             del b
         slowest_call.append(max(calls, key=lambda c: c[1]))
         while pipe.in_flight:
@@ -720,8 +725,8 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
            "held_by_the_benchs_own_context_bytes": int(held_b),
            "peak_device_bytes_of_the_allocator": peak0,
            "slowest_enqueueing_call": {"call": slowest_call[0][0], "s": slowest_call[0][1],
-                                       "note": "the calls that only enqueue (and allocate): a first pass of seconds instead of 0.25 s is "
-                                               "ONE of them waiting in a 12-13 GB hipMalloc while the driver clears memory this process "
+                                       "note": "every call of the loop timed on the host: a first pass of seconds instead of 0.25 s is "
+                                               "ONE of them waiting in a multi-GB hipMalloc while the driver clears memory this process "
                                                "released earlier (every so-many-th large hipMalloc of a process that keeps allocating and "
                                                "freeing GiBs: profiles/r05_target/big_malloc_probe.txt, torch alone shows it; DESIGN 5)"},
            "repeat": {"s": r2 - r0, "Gbp_per_s": bp / (r2 - r0) / 1e9, "batches_s": r1 - r0, "sort_into_frag_map_s": r2 - r1,
