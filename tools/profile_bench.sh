@@ -28,5 +28,6 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/q_pmc_write -o q -- python 
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES GRBM_GUI_ACTIVE SQ_INSTS_LDS --output-format csv -d $O/q_pmc_sq -o q -- python $R/tools/query_leg.py --reps 5 > $O/q_pmc_sq.log 2>&1
 # the software pipeline (pgr_pipe_*): kernel trace of the pipelined leg alone -- which kernels run beside the tile kernel, and what it costs it
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pipe_trace -o p -- python $R/tools/probe/pipe_probe.py 1000 8 > $O/pipe_trace.log 2>&1
+rm -f $O/pipe_trace/*kernel_trace.csv  # (the per-dispatch trace: only the stats travel back)
 python $R/bench.py --steps 5 --warmup 1 > $O/bench.json 2> $O/bench.err
 ls -R $O | head -40
