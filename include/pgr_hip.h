@@ -100,8 +100,6 @@ const char *pgr_version(void);
  *   no_island_relay           exact islands: the round-3 seam correction (one seam per host round), for A/B timing
  *   no_short_tiles            batches of short contigs (mean length <= 2048): 4096-position tiles all the same, for A/B timing
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing
- *   no_persistent_list        the list kernel runs one workgroup per block of 1024 list elements instead of looping over its blocks with
- *                             the next block's descriptors prefetched, for A/B timing
  *   no_early_islands          ... never start their first round before the tile kernel's flags are seen, for A/B timing
  *   early_islands_in_stream   ... start it behind the tile kernel on the context's stream, not beside it on a stream of its own, for A/B
  *   island_chunk_min          > 0: shortest chunk of the exact machine in positions (default 1024; 4096 = the round-3 minimum), for A/B

@@ -474,26 +474,14 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     __shared__ FusedLds L;
     const uint32_t t = threadIdx.x;
     const uint64_t total = *a.total;
-    // PERSISTENT: the grid is what the chip holds at once and a workgroup takes the blocks blk, blk + gridDim.x, ...  A block
-    // used to cost three dependent trips to memory before its reductions could start (first segment of the block, 129 segment
-    // descriptors, the records: 0.95 of the kernel's 1.57 ms per 10 Gbp was this load phase, at 3 TB/s); now the first two trips
-    // of the NEXT block are in flight while this block's reductions run -- its first segment is asked for when the block
-    // starts, its descriptors when this block's records have arrived, and both sit in registers until the next turn.
-    uint32_t pf_seg0 = 0, pf_cid = 0;
-    uint64_t pf_dst = 0, pf_off = 0;
-    bool pf = false;
-    for (uint32_t blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {
-    const uint64_t core_lo = (uint64_t)blk * FB;
-    if (core_lo >= total) {  // the blocks are an upper bound (sized before the level-1 count is known): nothing to do here
+    const uint64_t core_lo = (uint64_t)blockIdx.x * FB;
+    if (core_lo >= total) {  // the grid is an upper bound (sized before the level-1 count is known): nothing to do here
         if (t == 0) {
-            a.blk_off[blk] = 0;
-            a.blk_cnt[blk] = 0;
+            a.blk_off[blockIdx.x] = 0;
+            a.blk_cnt[blockIdx.x] = 0;
         }
-        continue;
+        return;
     }
-    const uint32_t nblk = blk + gridDim.x;
-    const bool has_next = nblk < a.n_blocks && (uint64_t)nblk * FB < total;
-    const uint32_t nseg0 = has_next ? a.blk_first_seg[nblk] : 0u;  // (in flight: used behind this block's loads)
     uint64_t core_hi = core_lo + FB;
     if (core_hi > total) core_hi = total;
     const uint64_t lo = core_lo >= a.halo ? core_lo - a.halo : 0;
@@ -505,7 +493,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     // ---- stream [lo, hi) of the logical level-1 list into LDS.  Segment descriptors are staged 64 at a time
     // (the segment holding `lo` was located by block_first_seg_kernel); then every lane fetches its own
     // elements (k = j*256 + t) independently: ~5 outstanding 16-byte loads per lane.
-    uint32_t seg0 = pf ? pf_seg0 : a.blk_first_seg[blk];
+    uint32_t seg0 = a.blk_first_seg[blockIdx.x];
     uint64_t done = lo;  // logical elements below `done` are loaded
     uint32_t cid0 = 0;   // contig of the block's first element (the first staged segment holds it)
     bool first_batch = true;
@@ -515,20 +503,12 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     }
     while (done < hi) {
         if (t < FUSED_SEGS + 1) {
-            if (pf && first_batch) {  // asked for while the previous block's reductions ran
-                L.sdst[t] = pf_dst;
-                if (t < FUSED_SEGS) {
-                    L.soff[t] = pf_off;
-                    L.scid[t] = pf_cid;
-                }
-            } else {
-                const uint32_t sg = seg0 + t;
-                const uint64_t d = (sg <= a.n_segs) ? a.seg_dst[sg] : total;  // seg_dst[n_segs] = total
-                L.sdst[t] = d;
-                if (t < FUSED_SEGS) {
-                    L.soff[t] = (sg < a.n_segs) ? a.seg_off[sg] : 0;
-                    L.scid[t] = (sg < a.n_segs) ? a.seg_cid[sg] : 0;
-                }
+            const uint32_t sg = seg0 + t;
+            const uint64_t d = (sg <= a.n_segs) ? a.seg_dst[sg] : total;  // seg_dst[n_segs] = total
+            L.sdst[t] = d;
+            if (t < FUSED_SEGS) {
+                L.soff[t] = (sg < a.n_segs) ? a.seg_off[sg] : 0;
+                L.scid[t] = (sg < a.n_segs) ? a.seg_cid[sg] : 0;
             }
         }
         __syncthreads();
@@ -610,22 +590,10 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
         if (seg0 >= a.n_segs && done < hi) break;  // cannot happen: seg_dst[n_segs] == total >= hi
     }
 
-    // the next block's descriptors (its first staging round): in flight during this block's reductions
-    if (has_next && t < FUSED_SEGS + 1) {
-        const uint32_t sg = nseg0 + t;
-        pf_dst = (sg <= a.n_segs) ? a.seg_dst[sg] : total;
-        if (t < FUSED_SEGS) {
-            pf_off = (sg < a.n_segs) ? a.seg_off[sg] : 0;
-            pf_cid = (sg < a.n_segs) ? a.seg_cid[sg] : 0;
-        }
-    }
 #if PGR_ABLATE_L2 == 1
     if (L.x[t] != 0x1234567ull) {  // load only
-        if (t == 0) { a.blk_off[blk] = 0; a.blk_cnt[blk] = 0; }
-        pf = has_next;
-        pf_seg0 = nseg0;
-        __syncthreads();
-        continue;
+        if (t == 0) { a.blk_off[blockIdx.x] = 0; a.blk_cnt[blockIdx.x] = 0; }
+        return;
     }
 #endif
 #if PGR_L2_PACKED
@@ -739,7 +707,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     if (t == 0) {
         // fixed slot per workgroup; only blocks with more survivors than the slot use the shared cursor
         // (same-address atomics saturate at ~88/us on gfx950)
-        unsigned long long base = (unsigned long long)blk * a.slot;
+        unsigned long long base = (unsigned long long)blockIdx.x * a.slot;
         bool ok = true;
         if (tot > a.slot) {
             const unsigned long long ob = atomicAdd(a.cursor, (unsigned long long)tot);
@@ -748,8 +716,8 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
             if (!ok) atomicExch(a.cursor + 1, 1ull);
         }
         L.base_out = ok ? base : ~0ull;
-        a.blk_off[blk] = base;
-        a.blk_cnt[blk] = ok ? tot : 0u;
+        a.blk_off[blockIdx.x] = base;
+        a.blk_cnt[blockIdx.x] = ok ? tot : 0u;
     }
     __syncthreads();
     const unsigned long long base = L.base_out;
@@ -771,10 +739,6 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
             }
         }
     }
-    pf = has_next;
-    pf_seg0 = nseg0;
-    __syncthreads();  // (the next block's loads write what this block's last readers may still hold)
-    }  // blocks of this workgroup
 }
 
 // first segment of every fused workgroup: largest s with seg_dst[s] <= max(0, b*FUSED_B - halo)
@@ -839,43 +803,14 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
         if (!a.lds_match || hipFuncGetAttributes(&at, f) != hipSuccess || at.sharedSizeBytes >= a.lds_match) return 0u;
         return a.lds_match - (uint32_t)at.sharedSizeBytes;
     };
-    // grid = the workgroups the chip holds at once (a workgroup loops over its blocks: fused_select_kernel); one that had to wait
-    // for a slot would start when the others are done with all of theirs
-    auto resident = [&](const void *f, uint32_t dyn) -> uint32_t {
-        static int n_cu = 0;
-        if (!n_cu) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return n_blocks;
-            n_cu = prop.multiProcessorCount;
-        }
-        if (n_blocks <= (uint32_t)n_cu) return n_blocks;  // (a small call: no question to ask)
-        static thread_local const void *last_f = nullptr;  // (the answer for the last kernel + LDS size asked about)
-        static thread_local uint32_t last_dyn = 0;
-        static thread_local int last_per_cu = 0;
-        int per_cu = last_per_cu;
-        if (f != last_f || dyn != last_dyn || per_cu < 1) {
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, f, FUSED_T, dyn) != hipSuccess || per_cu < 1) return n_blocks;
-            last_f = f;
-            last_dyn = dyn;
-            last_per_cu = per_cu;
-        }
-        return std::min<uint32_t>(n_blocks, (uint32_t)per_cu * (uint32_t)n_cu);
-    };
-    FusedArgsPub k = a;
-    k.n_blocks = n_blocks;
-    if (a.halo <= 32 && a.block_elems == 512u) {
-        const void *f = (const void *)fused_select_kernel<512 + 2 * 32, 512>;
-        hipLaunchKernelGGL((fused_select_kernel<512 + 2 * 32, 512>), dim3(a.no_persist ? n_blocks : resident(f, 0)), dim3(FUSED_T), 0, st, k);
-    } else if (a.halo <= 32) {
-        const void *f = (const void *)fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>;
-        const uint32_t dyn = pad_for(f);
-        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>), dim3(a.no_persist ? n_blocks : resident(f, dyn)), dim3(FUSED_T), dyn, st, k);
-    } else {
-        const void *f = (const void *)fused_select_kernel<FUSED_EMAX_BIG, FUSED_B>;
-        const uint32_t dyn = pad_for(f);
-        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG, FUSED_B>), dim3(a.no_persist ? n_blocks : resident(f, dyn)), dim3(FUSED_T), dyn, st, k);
-    }
+    if (a.halo <= 32 && a.block_elems == 512u)
+        hipLaunchKernelGGL((fused_select_kernel<512 + 2 * 32, 512>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
+    else if (a.halo <= 32)
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>), dim3(n_blocks), dim3(FUSED_T),
+                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>), st, a);
+    else
+        hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_BIG, FUSED_B>), dim3(n_blocks), dim3(FUSED_T),
+                           pad_for((const void *)fused_select_kernel<FUSED_EMAX_BIG, FUSED_B>), st, a);
 }
 void launch_offsets_by_rid(hipStream_t st, const pgr_mm128 *mm, const uint64_t *n_ptr, uint64_t cap, uint32_t n_contigs,
                            uint64_t *off, const unsigned long long *cursor, const uint64_t *total1, uint64_t *status) {

@@ -80,7 +80,6 @@ struct pgr_ctx {
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t early_islands_in_stream = 0;  // ... behind the tile kernel on its stream, not beside it on a stream of their own (for A/B)
-        int64_t no_persistent_list = 0;  // the list kernel runs one workgroup per block of 1024 elements, nothing prefetched (for A/B)
         int64_t no_early_islands = 0;    // the islands around non-ACGT bytes never start their first round behind the tile kernel, before its flags are seen (for A/B)
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B

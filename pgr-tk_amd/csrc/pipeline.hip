@@ -1207,7 +1207,6 @@ int ShmmrJob::stage3() {
     fa.blk_cnt = (uint32_t *)ctx->ws_blk_cnt.p;
     fa.blk_first_seg = (uint32_t *)ctx->ws_start_rank.p;
     fa.lds_match = lds_match;
-    fa.no_persist = ctx->opt.no_persistent_list ? 1u : 0u;
     fa.block_elems = fb;
     launch_fused_select_pub(st, fa, n_blocks);
     return PGR_OK;
