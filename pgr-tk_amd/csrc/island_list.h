@@ -1,0 +1,132 @@
+// island_list.h -- from tile flags to the islands of the exact state machine (host side, plain C++: tests/island_list_harness.cpp
+// builds it with g++ against a tile-by-tile reading).
+//
+// flags[c] bit 0 = a tile of contig c saw a palindromic k-mer (skipped push, shmmrutils.rs:477-480), n_invalid[c] = its non-ACGT
+// bytes, tf[tile] = tile flags (bit 0 palindromic k-mer, bit 1 non-ACGT byte in reach, bit 2 nothing but such bytes).
+//
+// A genome-sized batch has half a million tiles of which a few thousand are flagged: the tile-by-tile form of this (four passes
+// over every tile of every flagged contig) took 0.7 ms of a 2 Gbp batch's 8 -- on the critical path, between the tile kernel's
+// flags and the first round of the islands.  Here the flags are read eight tiles at a time and everything else works on the list
+// of flagged tiles.
+#pragma once
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+namespace pgr {
+
+// A stretch [B, E) of one contig that the exact machine computes instead of the tiles: every island's
+// left edge trusts the warm-up (everything before it is regular by construction: islands keep a clean tile
+// on both sides), its right edge is verified with a probe (warm-up only) at E and the island grows when the
+// machine has not yet returned to its regular regime there.
+struct Island {
+    uint32_t contig;
+    uint64_t B, E;
+    bool whole;  // one chunk for the whole contig (last resort)
+    // a tile of the island saw a palindromic k-mer: inside a stretch of skipped pushes a chunk needs the true state of the
+    // chunk in front (one seam per round), so such islands keep long chunks; islands around non-ACGT bytes verify at the
+    // first try and are cut short for parallelism
+    bool pal = true;
+};
+
+// tf is modified: tiles deep inside a run of non-ACGT bytes end up 0 (their segment ranges go to gap_segs).
+inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, const uint32_t *h_len, uint32_t tc, bool sketch,
+                                    const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, std::vector<Island> &islands,
+                                    std::vector<uint32_t> &gap_segs) {
+    struct FT {
+        uint32_t t;
+        uint8_t f;
+    };
+    std::vector<FT> F;
+    for (uint32_t c = 0; c < n; ++c) {
+        if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
+        const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
+        const uint64_t L = h_len[c];
+        // the flagged tiles of the contig, in order
+        F.clear();
+        {
+            const uint8_t *p = tf + t0;
+            uint32_t t = 0;
+            for (; t + 8 <= nt; t += 8) {
+                uint64_t w8;
+                memcpy(&w8, p + t, 8);
+                if (!w8) continue;
+                for (uint32_t q = 0; q < 8; ++q)
+                    if (p[t + q]) F.push_back(FT{t + q, p[t + q]});
+            }
+            for (; t < nt; ++t)
+                if (p[t]) F.push_back(FT{t, p[t]});
+        }
+        if (F.empty()) continue;
+        // The inside of a long run of non-ACGT bytes (the gaps of a reference chromosome: up to 30 Mbp) needs no
+        // machine at all.  Every position there pushes the same stale k-mer (shmmrutils.rs:461-476), so the level-1
+        // list holds one element per position, all with one x -- ties keep them through both reductions
+        // (:359-415) and the min_span stencil drops every one of them for having a neighbour with its x (:545-550).
+        // What an element further than 2 r^2 list places from both ends of such a run contributes to the rest of
+        // the list is nothing: tiles whose whole extended range is invalid AND whose two neighbours on either side
+        // are too (>= 7 kbp of the run kept at each end) are left out -- their segments stay empty, the islands on
+        // both sides end inside the run, where a warmed-up machine is exact.  (Round 3 pushed 40.9 Mbp of such
+        // positions of a chromosome-like contig through the chunk kernel and the list stage: half of its 2.4 ms.)
+        // A maximal run [s, e] of tiles with bit 2 of five or more: its tiles s + 2 .. e - 2 are deep.
+        size_t n_flag = F.size();
+        for (size_t i = 0; i < F.size();) {
+            if (!(F[i].f & 4)) {
+                ++i;
+                continue;
+            }
+            size_t j = i;
+            while (j + 1 < F.size() && (F[j + 1].f & 4) && F[j + 1].t == F[j].t + 1) ++j;
+            if (j - i + 1 >= 5) {
+                const uint32_t s = F[i].t + 2, e = F[j].t - 2;
+                gap_segs.push_back(t0 + c + s);  // segment index of tile s of contig c
+                gap_segs.push_back(t0 + c + e + 1);
+                for (size_t q = i + 2; q + 2 <= j; ++q) F[q].f = 0;  // not flagged: no island over them
+                memset(tf + t0 + s, 0, (size_t)e - s + 1);
+                n_flag -= (size_t)e - s + 1;
+            }
+            i = j + 1;
+        }
+        if (n_flag == 0) continue;
+        if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
+        if (3ull * n_flag > nt) {  // mostly irregular: one island
+            bool pal = false;
+            for (const FT &x : F) pal = pal || (x.f & 1);
+            islands.push_back(Island{c, 0, L, false, pal});
+            continue;
+        }
+        if (n_flag != F.size()) F.erase(std::remove_if(F.begin(), F.end(), [](const FT &x) { return x.f == 0; }), F.end());
+        for (size_t i = 0; i < F.size();) {
+            // (no tile in front of the first flagged one: tile t - 1 is clean, so nothing irregular lies within its reach -- which
+            // ends w - 1 + 64 positions INTO tile t --, and the machine that starts 256 positions in front of tile t is regular
+            // at its first step by construction; behind tiles deep inside a gap it starts inside the run, where a warmed-up
+            // machine is exact)
+            const uint32_t ta = F[i].t;
+            uint32_t tb = ta;
+            bool any_pal = (F[i].f & 1) != 0;
+            size_t j = i;
+            while (j + 1 < F.size() && F[j + 1].t - tb <= 2) {  // bridge 1-tile gaps
+                ++j;
+                tb = F[j].t;
+                any_pal = any_pal || (F[j].f & 1);
+            }
+            // a clean neighbour on the right for the machine to find back into its regular regime -- behind skipped pushes
+            // (palindromic k-mers) it may arrive stuck; behind a non-ACGT byte it cannot: the byte lies >= w + k + 64
+            // positions in front of the first clean tile (or that tile would be flagged), every position pushes, and the
+            // ring holds only pushes from behind the byte when the island ends.  The probe at the island's end checks it.
+            if (tb + 1 < nt && any_pal) ++tb;
+            Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
+            is.pal = any_pal;
+            if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
+            if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
+                islands.back().E = std::max(islands.back().E, is.E);
+                islands.back().pal = islands.back().pal || is.pal;
+            } else {
+                islands.push_back(is);
+            }
+            i = j + 1;
+        }
+    }
+}
+
+}  // namespace pgr

@@ -14,11 +14,13 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <map>
 #include <memory>
 
 #include "pgr_ctx.h"
 #include "pgr_index.h"
 #include "pgr_small.h"
+#include "island_list.h"
 
 using namespace pgr;
 
@@ -35,15 +37,7 @@ using Tmp_list = pgr::Tmp;
 // left edge trusts the warm-up (everything before it is regular by construction: islands keep a clean tile
 // on both sides), its right edge is verified with a probe (warm-up only) at E and the island grows when the
 // machine has not yet returned to its regular regime there.
-struct Island {
-    uint32_t contig;
-    uint64_t B, E;
-    bool whole;  // one chunk for the whole contig (last resort)
-    // a tile of the island saw a palindromic k-mer: inside a stretch of skipped pushes a chunk needs the true state of the
-    // chunk in front (one seam per round), so such islands keep long chunks; islands around non-ACGT bytes verify at the
-    // first try and are cut short for parallelism
-    bool pal = true;
-};
+// (struct Island and the listing of the islands from the tile flags: island_list.h)
 
 // One run of the exact machine over a list of islands, in two halves so that the first round's chunk kernel can be enqueued
 // BEFORE the host has anything to wait for (ShmmrJob::stage1: the islands around non-ACGT bytes are known while the tile
@@ -60,6 +54,7 @@ struct IslandRun {
     hipStream_t st;
     uint64_t CS_SHORT = 1024, CS_PAL = 512;
     std::vector<uint32_t> zero_ranges;  // segment ranges of (re)built islands -- and of the tiles the caller leaves out --, cleared by ONE kernel before the next chunk launch
+    std::vector<size_t> zero_owner;     // per pair of zero_ranges: the island it was built for (SIZE_MAX: the caller's)
     struct HChunk {
         ChunkDesc d;
         size_t island;
@@ -90,7 +85,7 @@ struct IslandRun {
     IslandRun(pgr_ctx *ctx_, const pgr_batch *b_, const L1Args &a_, const std::vector<Island> &islands_, const std::vector<uint32_t> &tile_first_,
               uint32_t tc_, uint64_t region_base, const std::vector<uint32_t> &empty_seg_ranges)
         : ctx(ctx_), b(b_), a(a_), islands(islands_), tile_first(tile_first_), tc(tc_), st(ctx_->stream), zero_ranges(empty_seg_ranges),
-          next_region(region_base) {
+          zero_owner(empty_seg_ranges.size() / 2, SIZE_MAX), next_region(region_base) {
         // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
         // (one per chunk), down to 1024 positions: a round costs what its slowest chunk costs -- ~3 us per step of 64 positions,
         // 225 us for the 4096-position chunks that were the minimum while a chunk had to own the segment-table entry of the tile it
@@ -106,7 +101,7 @@ struct IslandRun {
         // a chunk that runs again: 8 instead of 16) unless the islands are large.  The islands around non-ACGT bytes run beside
         // the tile kernel: more, shorter chunks there only take its slots (chromosome-like 0.85 -> 0.875 ms at 768).
         const uint64_t PAL_MIN = ctx->opt.island_chunk_min > 0 ? CS_MIN : 512;
-        CS_PAL = std::min<uint64_t>(32768, std::max<uint64_t>(PAL_MIN, ((island_bases / 2560 + 255) / 256) * 256));
+        CS_PAL = std::min<uint64_t>(32768, std::max<uint64_t>(PAL_MIN, ((island_bases / 6144 + 255) / 256) * 256));
     }
     // (a run that is dropped with its first round still on the side stream -- the flags added islands, or the pass starts over:
     // whoever uses the workspaces, the pinned image and the regions next must find them idle)
@@ -125,6 +120,8 @@ struct IslandRun {
     int enqueue_round();
     int process_round();
     int begin(hipStream_t side = nullptr);
+    int settle_first_round();
+    int adopt(const std::vector<Island> &wanted);
     int finish();
 };
 
@@ -140,6 +137,7 @@ int IslandRun::build(size_t ii) {
     if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
     zero_ranges.push_back(rng[0]);
     zero_ranges.push_back(rng[1]);
+    zero_owner.push_back(ii);
     // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
     // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
     const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
@@ -160,7 +158,10 @@ int IslandRun::build(size_t ii) {
         // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
         // (ties, shmmrutils.rs:516-527), the sparse region estimate would overflow and the chunk run twice
         // (so is an island around non-ACGT bytes, however short: it may be one of the two ends of a long gap)
-        h.full_cap = nch >= 8 || !is.pal;
+        // (and an island around palindromic k-mers is low-complexity sequence more often than not: a genome-like batch ran a
+        // second round for a dozen chunks that had overflowed the sparse estimate -- 0.4 ms for their 225 steps.  Only a whole
+        // contig, whose region would be 12 bytes per base, starts with the estimate)
+        h.full_cap = !is.whole;
         todo.push_back(ch.size());
         ch.push_back(h);
     }
@@ -239,6 +240,7 @@ int IslandRun::process_round() {
     const uint32_t *r_stat = (const uint32_t *)(r_info + 4 * nq);
     PGR_HIP(ctx, hipGetLastError());
     zero_ranges.clear();
+    zero_owner.clear();
     d_zr.reset();
     s_in.resize(ch.size());
     s_out.resize(ch.size());
@@ -427,6 +429,101 @@ int IslandRun::begin(hipStream_t side) {
         if ((rc = build(ii))) return rc;
     round = 0;
     return todo.empty() ? PGR_OK : enqueue_round();
+}
+
+// The round that begin() enqueued is waited for and its seams are verified: afterwards nothing of this run is pending on the device
+// and nothing of it is left in the pinned image (the tile flags may come down into it).
+int IslandRun::settle_first_round() {
+    int rc;
+    if (!enqueued) return PGR_OK;
+    if (st_chunks != st) {
+        PGR_HIP(ctx, hipStreamSynchronize(st_chunks));
+        st_chunks = st;
+    }
+    PGR_HIP(ctx, hipStreamSynchronize(st));
+    isl_lap("states back on the host (early round kept)", round);
+    if ((rc = process_round())) return rc;
+    ++round;
+    return PGR_OK;
+}
+
+// The tile kernel's flags have added islands (tiles with a palindromic k-mer): `wanted` is the full list, a superset of what this
+// run was begun with.  An island of this run that `wanted` holds unchanged keeps its chunks and what they have computed; one that
+// `wanted` has merged into a longer island, or that has changed since (grown, the whole contig), is retired; every other island of
+// `wanted` is built.  The real case: a reference assembly has gaps AND (AT)n microsatellites longer than k in every batch -- the
+// islands around the gaps have run beside the tile kernel, only those around the microsatellites run behind it.
+int IslandRun::adopt(const std::vector<Island> &wanted) {
+    int rc;
+    std::vector<char> keep(islands.size(), 0), covered(wanted.size(), 0);
+    // islands the first round has rebuilt (grown: the probe at E found the machine not yet regular; the whole contig): their new
+    // segment range is waiting to be emptied.  Such an island stays when every island of `wanted` it touches lies inside it
+    std::vector<char> changed(islands.size(), 0);
+    for (size_t o : zero_owner)
+        if (o != SIZE_MAX) changed[o] = 1;
+    for (size_t i = 0; i < islands.size(); ++i) {
+        const Island &is = islands[i];
+        if (!(changed[i] || is.whole) || is.E <= is.B) continue;
+        bool inside = true;
+        for (size_t j = 0; j < wanted.size() && inside; ++j) {
+            const Island &wn = wanted[j];
+            if (wn.contig != is.contig || !(wn.B < is.E + tc && wn.E + tc > is.B)) continue;
+            inside = wn.B >= is.B && wn.E <= is.E && !covered[j];
+        }
+        if (!inside) continue;
+        keep[i] = 1;
+        for (size_t j = 0; j < wanted.size(); ++j) {
+            const Island &wn = wanted[j];
+            if (wn.contig == is.contig && wn.B < is.E + tc && wn.E + tc > is.B) {
+                covered[j] = 1;
+                islands[i].pal = islands[i].pal || wn.pal;
+            }
+        }
+    }
+    {
+        // (both lists are in (contig, B) order as list_islands makes them; islands that grew or merged are not: a map)
+        std::map<std::pair<uint32_t, uint64_t>, size_t> mine;
+        for (size_t i = 0; i < islands.size(); ++i)
+            if (!changed[i] && !islands[i].whole && islands[i].E > islands[i].B) mine.emplace(std::make_pair(islands[i].contig, islands[i].B), i);
+        for (size_t j = 0; j < wanted.size(); ++j) {
+            const Island &wn = wanted[j];
+            if (covered[j]) continue;
+            auto it = mine.find(std::make_pair(wn.contig, wn.B));
+            if (it != mine.end() && !wn.whole && islands[it->second].E == wn.E && !keep[it->second]) {
+                keep[it->second] = 1;
+                covered[j] = 1;
+                islands[it->second].pal = islands[it->second].pal || wn.pal;
+            }
+        }
+    }
+    for (auto &h : ch)
+        if (!keep[h.island]) h.retired = true;
+    todo.erase(std::remove_if(todo.begin(), todo.end(), [&](size_t i) { return ch[i].retired; }), todo.end());
+    {  // (the segment range of a rebuilt island that goes: not emptied -- the longer list may not cover all of it)
+        size_t kept = 0;
+        for (size_t q = 0; q < zero_owner.size(); ++q)
+            if (zero_owner[q] == SIZE_MAX || keep[zero_owner[q]]) {
+                zero_ranges[2 * kept] = zero_ranges[2 * q];
+                zero_ranges[2 * kept + 1] = zero_ranges[2 * q + 1];
+                zero_owner[kept++] = zero_owner[q];
+            }
+        zero_ranges.resize(2 * kept);
+        zero_owner.resize(kept);
+    }
+    for (size_t i = 0; i < keep.size(); ++i)
+        if (!keep[i]) islands[i].E = islands[i].B = 0;  // absorbed
+    // the islands the flags have added are on the critical path (nothing runs beside them): chunks short enough that the
+    // slowest one takes about a third of what the round's steps take on the whole chip (~1.5 us of issue per step of 64
+    // positions on 1024 SIMDs; a lone wavefront ~3 us per step), so that a second round -- one chunk deep -- stays cheap
+    uint64_t fresh_bases = 0;
+    for (size_t j = 0; j < wanted.size(); ++j)
+        if (!covered[j]) fresh_bases += wanted[j].E - wanted[j].B;
+    if (ctx->opt.island_chunk_min <= 0) CS_PAL = std::min<uint64_t>(32768, std::max<uint64_t>(512, ((fresh_bases / 6144 + 255) / 256) * 256));
+    for (size_t j = 0; j < wanted.size(); ++j) {
+        if (covered[j]) continue;
+        islands.push_back(wanted[j]);
+        if ((rc = build(islands.size() - 1))) return rc;
+    }
+    return PGR_OK;
 }
 
 int IslandRun::finish() {
@@ -899,73 +996,7 @@ int ShmmrJob::plan() {
 // bytes, tf[tile] = tile flags (bit 0 palindromic k-mer, bit 1 non-ACGT byte in reach, bit 2 nothing but such bytes; bit 3 is set here)
 void ShmmrJob::list_islands(const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, std::vector<Island> &islands,
                             std::vector<uint32_t> &gap_segs) {
-    const std::vector<uint32_t> &tile_first = this->tile_first();
-    for (uint32_t c = 0; c < n; ++c) {
-        if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
-        const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
-        const uint64_t L = b->h_len[c];
-        // The inside of a long run of non-ACGT bytes (the gaps of a reference chromosome: up to 30 Mbp) needs no
-        // machine at all.  Every position there pushes the same stale k-mer (shmmrutils.rs:461-476), so the level-1
-        // list holds one element per position, all with one x -- ties keep them through both reductions
-        // (:359-415) and the min_span stencil drops every one of them for having a neighbour with its x (:545-550).
-        // What an element further than 2 r^2 list places from both ends of such a run contributes to the rest of
-        // the list is nothing: tiles whose whole extended range is invalid AND whose two neighbours on either side
-        // are too (>= 7 kbp of the run kept at each end) are left out -- their segments stay empty, the islands on
-        // both sides end inside the run, where a warmed-up machine is exact.  (Round 3 pushed 40.9 Mbp of such
-        // positions of a chromosome-like contig through the chunk kernel and the list stage: half of its 2.4 ms.)
-        for (uint32_t t = 0, run = 0; t < nt; ++t) {  // tile t - 2 is deep when tiles t - 4 .. t are all inside a gap
-            run = (tf[t0 + t] & 4) ? run + 1 : 0;
-            if (run >= 5) tf[t0 + t - 2] |= 8;  // (bit 3: host only)
-        }
-        for (uint32_t t = 0; t < nt; ++t)
-            if (tf[t0 + t] & 8) {
-                uint32_t e = t;
-                while (e + 1 < nt && (tf[t0 + e + 1] & 8)) ++e;
-                gap_segs.push_back(t0 + c + t);      // segment index of tile t of contig c
-                gap_segs.push_back(t0 + c + e + 1);
-                for (uint32_t q = t; q <= e; ++q) tf[t0 + q] = 0;  // not flagged: no island over them
-                t = e;
-            }
-        uint32_t n_flag = 0;
-        for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
-        if (n_flag == 0) continue;
-        if (sketch && n_invalid[c] == 0) continue;  // sketch has no state machine: palindromes are exact
-        if (3ull * n_flag > nt) {  // mostly irregular: one island
-            bool pal = false;
-            for (uint32_t t = 0; t < nt; ++t) pal = pal || (tf[t0 + t] & 1);
-            islands.push_back(Island{c, 0, L, false, pal});
-            continue;
-        }
-        for (uint32_t t = 0; t < nt;) {
-            if (!tf[t0 + t]) {
-                ++t;
-                continue;
-            }
-            // (no tile in front of the first flagged one: tile t - 1 is clean, so nothing irregular lies within its reach -- which
-            // ends w - 1 + 64 positions INTO tile t --, and the machine that starts 256 positions in front of tile t is regular
-            // at its first step by construction; behind tiles deep inside a gap it starts inside the run, where a warmed-up
-            // machine is exact)
-            uint32_t ta = t, tb = t;
-            while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;  // bridge 1-tile gaps
-            bool any_pal = false;
-            for (uint32_t q = ta; q <= tb; ++q) any_pal = any_pal || (tf[t0 + q] & 1);
-            // a clean neighbour on the right for the machine to find back into its regular regime -- behind skipped pushes
-            // (palindromic k-mers) it may arrive stuck; behind a non-ACGT byte it cannot: the byte lies >= w + k + 64
-            // positions in front of the first clean tile (or that tile would be flagged), every position pushes, and the
-            // ring holds only pushes from behind the byte when the island ends.  The probe at the island's end checks it.
-            if (tb + 1 < nt && any_pal) ++tb;
-            Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
-            is.pal = any_pal;
-            if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
-            if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
-                islands.back().E = std::max(islands.back().E, is.E);
-                islands.back().pal = islands.back().pal || is.pal;
-            } else {
-                islands.push_back(is);
-            }
-            t = tb + 1;
-        }
-    }
+    list_islands_from_flags(n, tile_first().data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, islands, gap_segs);
 }
 
 int ShmmrJob::stage1() {
@@ -1046,9 +1077,19 @@ int ShmmrJob::run_islands(uint64_t need_word) {
     std::vector<uint32_t> gap_segs;  // [first, last + 1) segment ranges of tiles deep inside runs of non-ACGT bytes: emptied
     for (uint32_t c : serial) islands.push_back(Island{c, 0, b->h_len[c], false, true});
     const bool use_pre = pre_listed && !(need_word & 1ull) && serial.empty();  // (no tile saw a palindromic k-mer)
-    // (a tile saw a palindromic k-mer: the early round is dropped -- which waits for it if it runs on the side stream -- BEFORE the
-    // flags come down into the pinned image its states are written to)
-    if (!use_pre) early_islands.reset();
+    // A tile saw a palindromic k-mer: the islands are listed again (a superset).  The early round is kept -- its islands around
+    // non-ACGT bytes are still islands of the longer list, all but those a new neighbour is merged with -- but it is waited for and
+    // its states are taken out of the pinned image BEFORE the flags come down into that image.  (no_early_merge: the first form,
+    // the early round is dropped.)
+    bool merge_early = !use_pre && early_islands && serial.empty() && !ctx->opt.no_early_merge;
+    if (merge_early) {
+        int r0 = early_islands->settle_first_round();
+        if (r0) {
+            early_islands.reset();
+            return r0;
+        }
+    }
+    if (!use_pre && !merge_early) early_islands.reset();
     if (use_pre) {
         islands = pre_islands;
         gap_segs = pre_gap_segs;
@@ -1080,7 +1121,7 @@ int ShmmrJob::run_islands(uint64_t need_word) {
     if (!islands.empty()) {
         L1Args as = a;
         as.w = sketch ? 1u : spec.w;  // the exact machine follows the spec literally (sketch ignores w)
-        if (tiled && bases_tiled && n_tiles && !use_pre) {  // (use_pre: done in front of the tile kernel)
+        if (tiled && bases_tiled && n_tiles && !use_pre && !merge_early) {  // (use_pre, merge_early: done in front of the tile kernel)
             // per-tile "last valid position" (written by mark_invalid_tiles) -> cumulative: the chunks' k-mer look-back
             // and forward roll cross a run of N of any length in one step
             const size_t tb = scan_max_temp_bytes(n_tiles);
@@ -1093,6 +1134,10 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         int r;
         if (use_pre && early_islands) {  // round 0 is behind the tile kernel already
             r = early_islands->finish();
+            as.out = early_islands->a.out;
+            islands = early_islands->islands;
+        } else if (merge_early) {  // ... and has been looked at: the islands the flags have added join the run
+            if (!(r = early_islands->adopt(islands))) r = early_islands->finish();
             as.out = early_islands->a.out;
             islands = early_islands->islands;
         } else {

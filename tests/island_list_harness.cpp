@@ -1,0 +1,131 @@
+// CPU harness (no GPU, no HIP): csrc/island_list.h -- the islands of the exact machine listed from the FLAGGED tiles only --
+// against the tile-by-tile reading it replaced (four passes over every tile), on random flag patterns: isolated flags, clusters,
+// runs of "nothing but non-ACGT bytes" tiles of every length around the deep-gap threshold, mostly-flagged contigs, short contigs,
+// sketch specs.  Built and run by tests/test_island_list_cpu.py.   usage: island_list_harness <cases>
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "island_list.h"
+
+using pgr::Island;
+
+static void dense(uint32_t n, const uint32_t *tile_first, const uint32_t *h_len, uint32_t tc, bool sketch, const uint32_t *flags,
+                  const uint32_t *n_invalid, uint8_t *tf, std::vector<Island> &islands, std::vector<uint32_t> &gap_segs) {
+    for (uint32_t c = 0; c < n; ++c) {
+        if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
+        const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
+        const uint64_t L = h_len[c];
+        for (uint32_t t = 0, run = 0; t < nt; ++t) {
+            run = (tf[t0 + t] & 4) ? run + 1 : 0;
+            if (run >= 5) tf[t0 + t - 2] |= 8;
+        }
+        for (uint32_t t = 0; t < nt; ++t)
+            if (tf[t0 + t] & 8) {
+                uint32_t e = t;
+                while (e + 1 < nt && (tf[t0 + e + 1] & 8)) ++e;
+                gap_segs.push_back(t0 + c + t);
+                gap_segs.push_back(t0 + c + e + 1);
+                for (uint32_t q = t; q <= e; ++q) tf[t0 + q] = 0;
+                t = e;
+            }
+        uint32_t n_flag = 0;
+        for (uint32_t t = 0; t < nt; ++t) n_flag += tf[t0 + t] != 0;
+        if (n_flag == 0) continue;
+        if (sketch && n_invalid[c] == 0) continue;
+        if (3ull * n_flag > nt) {
+            bool pal = false;
+            for (uint32_t t = 0; t < nt; ++t) pal = pal || (tf[t0 + t] & 1);
+            islands.push_back(Island{c, 0, L, false, pal});
+            continue;
+        }
+        for (uint32_t t = 0; t < nt;) {
+            if (!tf[t0 + t]) {
+                ++t;
+                continue;
+            }
+            uint32_t ta = t, tb = t;
+            while (tb + 1 < nt && (tf[t0 + tb + 1] || (tb + 2 < nt && tf[t0 + tb + 2]))) ++tb;
+            bool any_pal = false;
+            for (uint32_t q = ta; q <= tb; ++q) any_pal = any_pal || (tf[t0 + q] & 1);
+            if (tb + 1 < nt && any_pal) ++tb;
+            Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
+            is.pal = any_pal;
+            if (L - is.E < 2ull * tc) is.E = L;
+            if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
+                islands.back().E = std::max(islands.back().E, is.E);
+                islands.back().pal = islands.back().pal || is.pal;
+            } else {
+                islands.push_back(is);
+            }
+            t = tb + 1;
+        }
+    }
+}
+
+int main(int argc, char **argv) {
+    const int cases = argc > 1 ? atoi(argv[1]) : 1000;
+    std::mt19937_64 rng(12345);
+    int failures = 0;
+    size_t n_islands = 0, n_gaps = 0, n_pal = 0, n_whole = 0;
+    const uint32_t tc = 3904;
+    for (int it = 0; it < cases; ++it) {
+        const uint32_t n = 1 + rng() % 6;
+        std::vector<uint32_t> tile_first(n + 1, 0), h_len(n), flags(n, 0), n_inv(n, 0);
+        for (uint32_t c = 0; c < n; ++c) {
+            const uint32_t kind = rng() % 4;
+            const uint32_t nt = kind == 0 ? 1 + rng() % 4 : kind == 1 ? 1 + rng() % 40 : 1 + rng() % 3000;
+            tile_first[c + 1] = tile_first[c] + nt;
+            h_len[c] = (nt - 1) * tc + 1 + rng() % (tc + 300);  // (a one-tile contig may exceed a core)
+        }
+        std::vector<uint8_t> tf(tile_first[n] + 8, 0);
+        for (uint32_t c = 0; c < n; ++c) {
+            const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
+            const uint32_t mode = rng() % 6;  // 0: clean
+            auto put = [&](uint32_t t, uint8_t f) {
+                if (t < nt) {
+                    tf[t0 + t] |= f;
+                    if (f & 1) flags[c] |= 1;
+                    if (f & 6) n_inv[c] += 1 + rng() % 100;
+                }
+            };
+            if (mode >= 1) {
+                const uint32_t k = mode == 5 ? nt / 2 + rng() % (nt / 2 + 1) : 1 + rng() % 12;
+                for (uint32_t i = 0; i < k; ++i) {
+                    const uint32_t t = rng() % nt;
+                    const uint32_t what = rng() % 5;
+                    if (what == 0) put(t, 1);
+                    else if (what == 1) put(t, 2);
+                    else if (what == 2) put(t, 3);
+                    else if (what == 3) {  // a cluster
+                        for (uint32_t q = 0, m = 1 + rng() % 6; q < m; ++q) put(t + rng() % 8, (uint8_t)(1 + rng() % 3));
+                    } else {  // a run of tiles with nothing but non-ACGT bytes, around the threshold of five
+                        const uint32_t len = rng() % 3 == 0 ? 1 + rng() % 400 : 1 + rng() % 9;
+                        for (uint32_t q = 0; q < len; ++q) put(t + q, 6);
+                        if (rng() % 2) put(t + len, 2);
+                        if (rng() % 3 == 0 && t) put(t - 1, (uint8_t)(rng() % 2 ? 2 : 1));
+                    }
+                }
+            }
+            if (rng() % 16 == 0) n_inv[c] = 0, flags[c] |= 0;  // (a contig whose count says "clean": skipped unless a palindrome bit is set)
+        }
+        const bool sketch = rng() % 5 == 0;
+        std::vector<uint8_t> tf_a = tf, tf_b = tf;
+        std::vector<Island> ia, ib;
+        std::vector<uint32_t> ga, gb;
+        dense(n, tile_first.data(), h_len.data(), tc, sketch, flags.data(), n_inv.data(), tf_a.data(), ia, ga);
+        pgr::list_islands_from_flags(n, tile_first.data(), h_len.data(), tc, sketch, flags.data(), n_inv.data(), tf_b.data(), ib, gb);
+        bool same = ia.size() == ib.size() && ga == gb && tf_a == tf_b;
+        n_islands += ia.size();
+        n_gaps += ga.size() / 2;
+        for (const Island &x : ia) n_pal += x.pal, n_whole += (x.B == 0 && x.E == h_len[x.contig]);
+        for (size_t i = 0; same && i < ia.size(); ++i)
+            same = ia[i].contig == ib[i].contig && ia[i].B == ib[i].B && ia[i].E == ib[i].E && ia[i].whole == ib[i].whole && ia[i].pal == ib[i].pal;
+        if (!same) {
+            if (++failures <= 5) fprintf(stderr, "case %d: %zu / %zu islands, %zu / %zu gap ranges\n", it, ia.size(), ib.size(), ga.size(), gb.size());
+        }
+    }
+    printf("%d cases, %d failures\n", cases, failures);
+    printf("%zu islands (%zu with a palindromic tile, %zu whole contigs), %zu deep-gap ranges\n", n_islands, n_pal, n_whole, n_gaps);
+    return failures ? 1 : 0;
+}

@@ -282,8 +282,32 @@ def test_early_island_round_is_dropped_cleanly_when_the_flags_add_islands(oracle
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_parity
     with ThreadPoolExecutor(8) as pool:
-        for opts in ({}, {"early_islands_in_stream": 1}, {"no_early_islands": 1}):
+        for opts in ({}, {"early_islands_in_stream": 1}, {"no_early_islands": 1}, {"no_early_merge": 1}):
             with gpu_ctx.options(**opts):
                 for seed in (920174, 920175, 920021):
                     r = fuzz_parity.one_case(seed, 6_000_000, gpu_ctx, pool)
                     assert not isinstance(r, str), (opts, r)
+
+
+def test_genome_like_batch_keeps_the_early_round_and_adds_the_flagged_islands(oracle, gpu_ctx):
+    """A batch with gaps AND (AT)n arrays longer than k (every batch of a real assembly): the islands around the non-ACGT bytes have
+    run beside the tile kernel when its flags add the islands around the palindromic k-mers -- the early round is kept, the new
+    islands join the run (IslandRun::adopt; islands the early round has grown stay when they cover what the flags ask for).
+    tools/genome_like_bench.py at 8 % of its size, every contig against the oracle, and the three orders agree."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import genome_like_bench as G
+    import pgrtk_amd as P
+    lens = [int(m * 80_000) for m in G.CHROM_MBP[:6]]
+    seqs = [G.genome_like_contig(oracle, c, L)[0] for c, L in enumerate(lens)]
+    spec = P.make_spec()
+    ref = [oracle.sequence_to_shmmrs(i, q, oracle.spec()) for i, q in enumerate(seqs)]
+    b = P.Batch.from_seqs(seqs, ctx=gpu_ctx)
+    for opts in ({}, {"no_early_merge": 1}, {"no_early_islands": 1}, {"early_islands_in_stream": 1}, {"island_chunk_min": 4096}):
+        with gpu_ctx.options(**opts):
+            sh = b.shmmrs(spec)
+            sums, off = sh.checksum(), sh.offsets()
+            for i in range(len(seqs)):
+                assert int(off[i + 1] - off[i]) == len(ref[i]), (opts, i)
+                assert np.array_equal(sums[i], oracle.shmmr_checksum(ref[i])), (opts, i)
+    assert gpu_ctx.last_prof().exact_bases > 0
