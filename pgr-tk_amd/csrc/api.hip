@@ -47,7 +47,7 @@ const std::vector<OptionName> &option_names() {
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge}, {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
-        {"back_priority", &O::back_priority}, {"pipe_staged_records", &O::pipe_staged_records},
+        {"back_priority", &O::back_priority}, {"no_fix_stream", &O::no_fix_stream}, {"no_stage1_only", &O::no_stage1_only}, {"pipe_staged_records", &O::pipe_staged_records},
         {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d},
         {"pipe_small_list", &O::pipe_small_list}, {"front_priority", &O::front_priority}};
     return v;
@@ -151,6 +151,7 @@ extern "C" int pgr_ctx_trim(pgr_ctx *ctx) {
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->back_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->back_stream));
+    if (ctx->fix_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->fix_stream));
     for (auto &kv : ctx->free_blocks) {
         (void)hipFree(kv.second.p);
         ctx->drop_events(kv.second);
@@ -200,6 +201,7 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream);
+    if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
     ctx->release_all();
     for (auto &ev : ctx->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -212,6 +214,7 @@ extern "C" void pgr_ctx_destroy(pgr_ctx *ctx) {
     for (auto &ev : ctx->pre_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (ctx->back_stream) (void)hipStreamDestroy(ctx->back_stream);
+    if (ctx->fix_stream) (void)hipStreamDestroy(ctx->fix_stream);
     if (ctx->pre_stream) (void)hipStreamDestroy(ctx->pre_stream);
     if (ctx->d2h_stream) (void)hipStreamDestroy(ctx->d2h_stream);
     if (ctx->copy_stream) (void)hipStreamDestroy(ctx->copy_stream);

@@ -91,12 +91,18 @@ void pgr_ctx::wait_and_recycle(FreeBlock &fb, hipStream_t user) {
         ev_pool.push_back(fb.ev_back);
         fb.ev_back = nullptr;
     }
+    if (fb.ev_fix) {
+        if (user != fix_stream) (void)hipStreamWaitEvent(user, fb.ev_fix, 0);
+        ev_pool.push_back(fb.ev_fix);
+        fb.ev_fix = nullptr;
+    }
 }
 
 void pgr_ctx::drop_events(FreeBlock &fb) {
     if (fb.ev_front) ev_pool.push_back(fb.ev_front);
     if (fb.ev_back) ev_pool.push_back(fb.ev_back);
-    fb.ev_front = fb.ev_back = nullptr;
+    if (fb.ev_fix) ev_pool.push_back(fb.ev_fix);
+    fb.ev_front = fb.ev_back = fb.ev_fix = nullptr;
 }
 
 namespace {
@@ -169,6 +175,22 @@ int pgr_ctx::enable_multi_stream() {
             rejected.pop_back();
         }
         for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+        rejected.clear();
+        // the stream a job's second pass runs on: beside the context's stream AND beside the back stream
+        if (!back_shares_queue && !fix_stream) {
+            for (int tries = 0; tries < 8; ++tries) {
+                hipStream_t cand = nullptr;
+                if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio) != hipSuccess) break;
+                if (streams_run_side_by_side(stream, cand, d_scratch) && streams_run_side_by_side(back_stream, cand, d_scratch)) {
+                    fix_stream = cand;
+                    break;
+                }
+                rejected.push_back(cand);
+            }
+            for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+            if (opt.debug) fprintf(stderr, "[pgr] fix stream: %s (%zu candidates shared a hardware queue with one of the two others)\n",
+                                   fix_stream ? "found" : "none", rejected.size());
+        }
         (void)hipFree(d_scratch);
         if (opt.debug) fprintf(stderr, "[pgr] back stream: priority %d, %zu candidates shared a hardware queue with the context's stream%s\n", prio,
                                rejected.size() + (back_shares_queue ? 1 : 0), back_shares_queue ? " -- none did not" : "");
@@ -260,7 +282,15 @@ void pgr_ctx::dfree(void *p) {
     FreeBlock fb;
     fb.p = p;
     fb.on_back = on_back;
-    if (multi_stream) {  // where the two streams stand now: the next user on the other stream waits for that
+    if (multi_stream && fix_stream && alloc_stream == fix_stream) {
+        // freed inside a job's second pass (pgr_pipe_collect): whatever is pending on the block is pending on the fix stream.  (The
+        // context's stream is busy with the NEXT job's tiles: an event recorded there would make this pass's next allocation, which
+        // is likely to get this very block, wait for them.)
+        if (!(fb.ev_fix = take_event()) || hipEventRecord(fb.ev_fix, fix_stream) != hipSuccess) {
+            (void)hipStreamSynchronize(fix_stream);
+            drop_events(fb);
+        }
+    } else if (multi_stream) {  // where the two streams stand now: the next user on the other stream waits for that
         if ((fb.ev_front = take_event()) && hipEventRecord(fb.ev_front, stream) != hipSuccess) drop_events(fb);
         if (on_back && (fb.ev_back = take_event()) && hipEventRecord(fb.ev_back, back_stream) != hipSuccess) {
             ev_pool.push_back(fb.ev_back);

@@ -89,6 +89,8 @@ struct pgr_ctx {
         int64_t no_direct_h2d = 0;       // packed input in pinned host memory goes through the staging windows all the same, for A/B
         int64_t lds_match = 0;           // pgr_pipe: 1 = the back stream's kernels occupy the tile kernel's LDS size or none (padded list kernel, LDS-free scans), for A/B
         int64_t pipe_staged_records = 0; // pgr_pipe: never place an index job's records through the device cursor (always stage + copy), for A/B
+        int64_t no_stage1_only = 0;      // pgr_pipe: the first pass of a job always includes its list stage, even when the last job needed islands, for A/B
+        int64_t no_fix_stream = 0;       // pgr_pipe: a job that needs a second pass is finished on the context's stream (behind the next job's tiles), for A/B
         int64_t back_priority = 0;       // pgr_pipe: priority of the back stream (list stages): 1 = the device's highest, 0 = the default, -1 = the lowest
     } opt;
     std::vector<uint32_t> h_tile_first;  // pgr_shmmrs_compute: first tile of every contig (host copy, kept between calls)
@@ -131,6 +133,8 @@ struct pgr_ctx {
     struct FreeBlock {
         void *p = nullptr;
         hipEvent_t ev_front = nullptr, ev_back = nullptr;  // recorded on stream / back_stream when the block was freed
+        hipEvent_t ev_fix = nullptr;  // a block freed while a job's second pass runs on the fix stream (alloc_stream == fix_stream): its
+                                      // pending work is there and nowhere else -- the pass that used it on the back stream has been waited for
         bool on_back = false;  // last used for work on the back stream: handed to the back stream's requests first, and to the
                                // context's stream only when nothing else fits (it would wait for a list stage: a bubble)
     };
@@ -147,6 +151,11 @@ struct pgr_ctx {
     bool back_shares_queue = false;  // no candidate for the back stream ran beside the context's stream (ctx.hip: enable_multi_stream)
     std::vector<pgr::Lane *> spare_lanes;  // lanes of destroyed pipes (their workspaces stay allocated for the next pipe)
     hipStream_t back_stream = nullptr;   // list stages of a pgr_pipe (created with the first pipe; higher priority than `stream`)
+    // A job of a pipe that cannot keep its optimistic pass (flagged tiles: every batch of a real assembly; undersized estimates) is
+    // finished on a stream of its own: the back stream holds the NEXT job's list stage, which waits for that job's tiles -- behind it
+    // the islands and the second list stage of this job would wait for them too, and the context's stream would idle meanwhile.
+    // nullptr when no stream was found that runs beside both others (then such a job is finished on the context's stream).
+    hipStream_t fix_stream = nullptr;
     hipStream_t alloc_stream = nullptr;  // the stream the NEXT dmalloc's block will be used on (nullptr: `stream`)
     std::vector<hipEvent_t> ev_pool;
     hipEvent_t take_event();

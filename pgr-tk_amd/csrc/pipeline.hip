@@ -82,9 +82,9 @@ struct IslandRun {
     // kernel touches -- its regions lie behind the tiles' part of the level-1 buffer, which must not have to grow for this
     hipStream_t st_chunks = nullptr;
 
-    IslandRun(pgr_ctx *ctx_, const pgr_batch *b_, const L1Args &a_, const std::vector<Island> &islands_, const std::vector<uint32_t> &tile_first_,
+    IslandRun(pgr_ctx *ctx_, hipStream_t st_, const pgr_batch *b_, const L1Args &a_, const std::vector<Island> &islands_, const std::vector<uint32_t> &tile_first_,
               uint32_t tc_, uint64_t region_base, const std::vector<uint32_t> &empty_seg_ranges)
-        : ctx(ctx_), b(b_), a(a_), islands(islands_), tile_first(tile_first_), tc(tc_), st(ctx_->stream), zero_ranges(empty_seg_ranges),
+        : ctx(ctx_), b(b_), a(a_), islands(islands_), tile_first(tile_first_), tc(tc_), st(st_), zero_ranges(empty_seg_ranges),
           zero_owner(empty_seg_ranges.size() / 2, SIZE_MAX), next_region(region_base) {
         // chunk length: 32 kbp for big jobs, shorter when the islands are few so that there are still thousands of wavefronts
         // (one per chunk), down to 1024 positions: a round costs what its slowest chunk costs -- ~3 us per step of 64 positions,
@@ -591,10 +591,10 @@ int IslandRun::finish() {
     return PGR_OK;
 }
 
-static int run_exact_islands(pgr_ctx *ctx, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
+static int run_exact_islands(pgr_ctx *ctx, hipStream_t st, const pgr_batch *b, L1Args &a, std::vector<Island> &islands,
                              const std::vector<uint32_t> &tile_first, uint32_t tc, uint64_t region_base,
                              const std::vector<uint32_t> &empty_seg_ranges) {
-    IslandRun run(ctx, b, a, islands, tile_first, tc, region_base, empty_seg_ranges);
+    IslandRun run(ctx, st, b, a, islands, tile_first, tc, region_base, empty_seg_ranges);
     int rc;
     if ((rc = run.begin()) || (rc = run.finish())) return rc;
     a.out = run.a.out;
@@ -757,6 +757,12 @@ struct ShmmrJob {
     hipStream_t sf = nullptr, sb = nullptr;  // front (level 1) and back (list stage) streams; the same for a synchronous call
     hipEvent_t ev_front = nullptr;           // sf != sb: stage 1 done (the back stream waits for it)
     bool optimistic = false;                 // the first pass of a pipelined job: no look at the flags between the stages
+    // ... of a job whose predecessor (same spec, same context) needed islands -- a genome comes as many similar batches, and a real
+    // assembly's are flagged every time --: stage 1 alone.  Its list stage would be thrown away at collect, and until then it runs
+    // beside the other job's tile kernel and takes its slots one for one (0.5 ms of a 2 Gbp batch's 5.6).  collect looks at the
+    // flags and enqueues the islands and THE list stage (or, for once not flagged, the list stage alone).
+    bool stage1_only = false;
+    bool list_pending = false;  // decide(): the pass that just ended had no list stage
     uint32_t lds_match = 0;                  // sf != sb: LDS per workgroup of the tile kernel; the back stream's kernels take as much or none
     // a consumer of the result that does not want to wait for the host: its kernels go behind stage 4 (stream, list, offsets,
     // capacity of the list, device address of the true count); a repeated pass calls it again
@@ -808,6 +814,7 @@ struct ShmmrJob {
     uint32_t n_blocks = 0;  // grid of the fused kernel
     uint64_t cap2 = 0;      // its overflow region
     uint64_t cap_res = 0;   // result capacity
+    uint64_t res_alloc_elems = 0;  // elements res->d_mm was allocated for
     pgr_mm128 *d_list = nullptr;  // ordered final list (before the padding artefact)
     uint64_t *d_loff = nullptr;
     uint64_t *d_total1 = nullptr;
@@ -989,6 +996,9 @@ int ShmmrJob::plan() {
     islands_done = false;
     l2_cursor_clean = false;
     pre_listed = false;
+    stage1_only = optimistic && tiled && bases_tiled && serial.empty() && ctx->est_flagged && ctx->est_l1_key == l1_key &&
+                  b->total_bases >= (4u << 20) && !ctx->opt.no_stage1_only;
+    list_pending = false;
     return PGR_OK;
 }
 
@@ -1053,7 +1063,7 @@ int ShmmrJob::stage1() {
                 as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;  // (made cumulative in front of the tile kernel, above)
                 // (the pinned image must not move while the round's kernels are pending: room for the flags' download as well)
                 if ((r = ctx->ensure_imail(2 * (std::max<size_t>(n, 1) * sizeof(uint32_t) + 16) + n_tiles + 64))) return r;
-                early_islands.reset(new IslandRun(ctx, b, as, pre_islands, tile_first(), tc, serial_base, pre_gap_segs));
+                early_islands.reset(new IslandRun(ctx, st, b, as, pre_islands, tile_first(), tc, serial_base, pre_gap_segs));
                 // (beside the tile kernel when the device runs two streams side by side; the side stream has waited for everything
                 // in front of the tile kernel: the copy of the tile flags above)
                 if ((r = early_islands->begin(ctx->opt.early_islands_in_stream ? nullptr : ctx->pre_stream))) return r;
@@ -1141,7 +1151,7 @@ int ShmmrJob::run_islands(uint64_t need_word) {
             as.out = early_islands->a.out;
             islands = early_islands->islands;
         } else {
-            r = run_exact_islands(ctx, b, as, islands, tile_first(), tc, serial_base, gap_segs);
+            r = run_exact_islands(ctx, st, b, as, islands, tile_first(), tc, serial_base, gap_segs);
         }
         early_islands.reset();
         if (r) return r;
@@ -1266,9 +1276,15 @@ int ShmmrJob::stage4() {
     }
     const uint64_t *d_nfinal = (const uint64_t *)ctx->ws_blk_base.p + n_blocks;
     if (!pad_fix) {  // common case: gather straight into the result buffer
-        ctx->dfree(res->d_mm);
-        res->d_mm = nullptr;
-        if ((r = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return r;
+        // (a second pass whose result fits the block of the first keeps it: freeing it and asking again is a round through the
+        // allocator's events for nothing)
+        if (!res->d_mm || res_alloc_elems < cap_res) {
+            ctx->dfree(res->d_mm);
+            res->d_mm = nullptr;
+            res_alloc_elems = 0;
+            if ((r = ctx->dmalloc((void **)&res->d_mm, cap_res * sizeof(pgr_mm128)))) return r;
+            res_alloc_elems = cap_res;
+        }
         d_list = res->d_mm;
         d_loff = res->d_off;
     } else {
@@ -1331,6 +1347,12 @@ int ShmmrJob::enqueue_pass() {
             if ((mbox[2] || !serial.empty()) && (rc = run_islands(mbox[2]))) return rc;
             islands_done = true;
         }
+        if (optimistic && stage1_only) {  // the status words of stage 1, and that is all for now
+            launch_copy_words(sf, (uint32_t *)mbox, (const uint32_t *)d_cursor, 8);  // (by a kernel: see plan())
+            list_pending = true;
+            dbg_lap("stage 1 enqueued (the list stage waits for the flags)");
+            return PGR_OK;
+        }
         if (sf != sb) {  // the list stage runs on the back stream, behind the level-1 kernels of THIS job only
             lds_match = (tiled && bases_tiled && ctx->opt.lds_match) ? level1_tile_lds_bytes(a) : 0;
             PGR_HIP(ctx, hipEventRecord(ev_front, sf));
@@ -1363,11 +1385,19 @@ int ShmmrJob::decide(bool &done) {
     l2_alloc_seen = l2_alloc;
     if (l1_ovf || l1_alloc > cap_par) {  // (only possible without the early look)
         cap_par = (uint64_t)((double)l1_alloc * 1.1) + 65536;
+        list_pending = false;
         from = 1;
         return PGR_OK;
     }
     if (!islands_done && (need_islands || !serial.empty())) {
         if ((rc = run_islands(need_islands))) return rc;
+        PGR_HIP(ctx, hipEventRecord(ctx->ev[3], sb));
+        list_pending = false;
+        from = 2;
+        return PGR_OK;
+    }
+    if (list_pending) {  // (a stage-1-only pass that turned out clean: the list stage, now)
+        list_pending = false;
         PGR_HIP(ctx, hipEventRecord(ctx->ev[3], sb));
         from = 2;
         return PGR_OK;
@@ -1790,7 +1820,8 @@ extern "C" int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *
     int rc;
     hipError_t e = hipSuccess;
     if (!(rc = job.plan()) && !(rc = job.begin_result())) {
-        if (ix && !ctx->opt.pipe_staged_records) {
+        if (ix && job.stage1_only) p->chain_ok = false;  // (no records before collect: staged, and so is whoever comes behind)
+        if (ix && !ctx->opt.pipe_staged_records && !job.stage1_only) {
             // direct: the chain starts here (nothing of an index in flight: the host knows the count) or continues on this index,
             // and the append buffer has room for everything the jobs in flight can produce (a job's list capacity bounds its pairs)
             const bool start = ix_jobs == 0;
@@ -1817,7 +1848,7 @@ extern "C" int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *
             e = hipMemcpyAsync(ctx->ws_rids.p, s.sids, (size_t)n * sizeof(uint32_t), hipMemcpyHostToDevice, job.sf);
         if (!rc && e == hipSuccess) e = hipEventRecord(ctx->ev[0], job.sf);
         if (!rc && e == hipSuccess) rc = job.enqueue_pass();
-        if (e == hipSuccess && !rc) e = hipEventRecord(s.ev_done, job.sb);
+        if (e == hipSuccess && !rc) e = hipEventRecord(s.ev_done, job.list_pending ? job.sf : job.sb);
     }
     if (rc || e != hipSuccess) {  // nothing of a failed submission may still be running on the lane's buffers
         (void)hipStreamSynchronize(ctx->stream);
@@ -1856,9 +1887,18 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
         LaneScope scope(ctx, *s.lane_p, nullptr);
         if (hipEventSynchronize(s.ev_done) != hipSuccess || hipGetLastError() != hipSuccess)
             rc = ctx->fail(PGR_ERR_DEVICE, "pipelined pass failed on the device");
-        job->sf = job->sb = ctx->stream;
+        // A second pass (flagged tiles -> islands + the list stage again; an undersized estimate) runs on the fix stream when there is
+        // one: beside the next job's tiles (the context's stream) and not behind that job's list stage (the back stream, which waits
+        // for those tiles).  A batch of a real assembly is flagged every time -- gaps, (AT)n microsatellites longer than k --: on the
+        // context's stream every job's islands and second list stage queued behind the next job's tile kernel, and the pipe ran at
+        // the speed of the synchronous calls.
+        hipStream_t fix = (ctx->fix_stream && !ctx->opt.no_fix_stream) ? ctx->fix_stream : ctx->stream;
+        job->sf = job->sb = fix;
+        ctx->alloc_stream = fix == ctx->stream ? nullptr : fix;
         job->optimistic = false;
         bool done = false;
+        // (a direct job whose records are about to move: the other job's pass has placed its own behind them -- waited for BEFORE
+        // the islands are enqueued only when everything shares the context's stream; otherwise behind them, see below)
         if (!rc) rc = job->decide(done);
         if (!rc && !done && s.direct) settle_others();
         while (!rc && !done) {
@@ -1867,10 +1907,11 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
                 rc = PGR_OK;
                 continue;
             }
-            if (!rc && (hipStreamSynchronize(ctx->stream) != hipSuccess || hipGetLastError() != hipSuccess))
+            if (!rc && (hipStreamSynchronize(fix) != hipSuccess || hipGetLastError() != hipSuccess))
                 rc = ctx->fail(PGR_ERR_DEVICE, "pipeline failed on the device");
             if (!rc) rc = job->decide(done);
         }
+        ctx->alloc_stream = nullptr;
         const bool want_recs = s.ix != nullptr || s.d_recs != nullptr;
         if (!rc && want_recs) np = s.pmail[0];
         if (!rc) rc = job->finish(&res);

@@ -115,6 +115,8 @@ def main():
     ap.add_argument("--no-check", action="store_true")
     ap.add_argument("--json", default=None)
     ap.add_argument("--opt", action="append", default=[], help="context option name=value for an A/B pass")
+    ap.add_argument("--pipe", type=int, default=0, help="K > 0: the same batch K times through pgr_pipe_* (two jobs in flight), lists only")
+    ap.add_argument("--pipe-index", action="store_true", help="... with the pair records into an index (staged once a job is flagged)")
     args = ap.parse_args()
     import oracle as O
     import pgrtk_amd as P
@@ -155,6 +157,40 @@ def main():
             t = time.perf_counter() - t0
         print("  with %s: %.2f ms, same count: %s" % (kv, t * 1e3, sh2.count == sh.count))
         out.setdefault("options", {})[kv] = t * 1e3
+    if args.pipe:
+        sync_sum = sh.checksum()
+
+        def pipe_pass(k, opts):
+            with ctx.options(**opts):
+                pipe = P.Pipe(sp, ctx=ctx)
+                ix = P.Index(sp, ctx=ctx) if args.pipe_index else None
+                same, got = True, []
+                t0 = time.perf_counter()
+                for i in range(k):
+                    if pipe.in_flight == 2:
+                        got.append(pipe.collect())
+                    pipe.submit(b, index=ix)
+                while pipe.in_flight:
+                    got.append(pipe.collect())
+                ctx.synchronize()
+                t = time.perf_counter() - t0
+                for r, _ in got[-2:]:
+                    same = same and r.count == sh.count and bool(np.array_equal(r.checksum(), sync_sum))
+                n_rec = None
+                if ix is not None:
+                    ix.finalize()
+                    n_rec = ix.n_records
+                pipe.close()
+            return t, same, n_rec
+        pipe_pass(3, {})
+        for name, opts in (("fix stream, stage 1 only", {}), ("fix stream, list stage twice", {"no_stage1_only": 1}),
+                           ("no_fix_stream", {"no_fix_stream": 1, "no_stage1_only": 1})):
+            t, same, n_rec = pipe_pass(args.pipe, opts)
+            print("pipe (%s): %d batches in %.2f ms = %.2f ms per batch = %.1f Gbp/s; last two jobs identical to the synchronous call: %s%s"
+                  % (name, args.pipe, t * 1e3, t * 1e3 / args.pipe, bp * args.pipe / t / 1e9, same,
+                     "" if n_rec is None else "; index records %d" % n_rec), flush=True)
+            out.setdefault("pipe", {})[name] = {"batches": args.pipe, "ms_per_batch": t * 1e3 / args.pipe, "Gbp_per_s": bp * args.pipe / t / 1e9,
+                                                "content_match_vs_synchronous_call": bool(same), "index_records": n_rec}
     if args.rounds:
         with ctx.options(debug=1, debug_times=1):
             b.shmmrs(sp)
