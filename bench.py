@@ -124,6 +124,24 @@ def synth_contig_ascii(seed, contig, length):
     return np.frombuffer(b"ACGT", dtype=np.uint8)[codes]
 
 
+def synth_contig_ascii_long(seed, contig, length, piece=1 << 24):
+    """the same for chromosome-sized contigs: `piece` bases at a time (the word-wise form above holds 8 bytes per base while it works)"""
+    import numpy as np
+    out = np.empty(length, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", dtype=np.uint8)
+    sh = (np.arange(32, dtype=np.uint64) * np.uint64(2))[None, :]
+    with np.errstate(over="ignore"):
+        for o in range(0, length, piece):
+            n = min(piece, length - o)
+            w = np.arange(o // 32, (o + n + 31) // 32, dtype=np.uint64)
+            z = (np.uint64(seed) ^ (np.uint64(contig) * np.uint64(0x9E3779B97F4A7C15)) ^ w) + np.uint64(0x9E3779B97F4A7C15)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            out[o:o + n] = acgt[((z[:, None] >> sh) & np.uint64(3)).astype(np.uint8).reshape(-1)[:n]]
+    return out
+
+
 def synth_substrings(seed, contigs, offsets, length):
     """the same generator for arbitrary (contig, offset) windows"""
     import numpy as np
@@ -641,6 +659,64 @@ def shapes_bench(P, ctx, spec, spec_t, cores, check):
         e["reads_checked"] = n_chk
         e["content_match"] = bool(same == n_chk)
     out["short_reads"] = e
+    del b, sh
+    # 4. a genome-like batch at batch size: what a reference assembly costs per base (tools/genome_like_bench.py has the generator)
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import genome_like_bench as G
+        class Base:  # (the generator's base sequence: the synthetic contigs of BASELINE.md section 4, numpy form, 16 Mbp at a time)
+            @staticmethod
+            def synth_contig(seed, c, L):
+                return synth_contig_ascii_long(seed, c, L)
+        lens = [m * 1_000_000 for m in G.CHROM_MBP]
+        with ThreadPoolExecutor(cores) as ex:
+            made = list(ex.map(lambda cl: G.genome_like_contig(Base, cl[0], cl[1]), enumerate(lens)))
+        seqs = [m[0] for m in made]
+        bp = int(sum(lens))
+        b = P.Batch.from_seqs(seqs, ctx=ctx)
+        t, sh, prof = run(b)
+        e = {"bp": bp, "contigs": len(seqs), "ms": t * 1e3, "Gbp_per_s": bp / t / 1e9, "shimmers": sh.count,
+             "Mbp_through_exact_islands": prof.exact_bases / 1e6, "level1_tile_ms": prof.level1_ms,
+             "planted": {k: int(sum(m[1][k] for m in made)) for k in made[0][1]},
+             "what": "12 chromosome-sized contigs (133 - 248 Mbp): centromere gaps beside alpha-satellite arrays, tens of shorter gaps, telomeres, "
+                     "isolated N, soft-masked repeats over half of the sequence, a microsatellite per 8 kbp (a few hundred (AT)n-like arrays "
+                     "longer than k per contig), duplications; pgr_shmmrs_compute on the resident batch"}
+        sums, off = sh.checksum(), sh.offsets()
+        # the same batch through the pipe (two jobs in flight: a flagged job's islands and list stage beside the next job's tiles)
+        pipe = P.Pipe(spec, ctx=ctx)
+        k, got = 8, []
+        for rep in range(2):
+            del got[:]
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            for i in range(k):
+                if pipe.in_flight == 2:
+                    got.append(pipe.collect()[0])
+                pipe.submit(b)
+            while pipe.in_flight:
+                got.append(pipe.collect()[0])
+            ctx.synchronize()
+            tp = time.perf_counter() - t0
+        same = all(g.count == sh.count and bool(np.array_equal(g.checksum(), sums)) for g in got[-2:])
+        pipe.close()
+        e["pipelined"] = {"batches": k, "ms_per_batch": tp * 1e3 / k, "Gbp_per_s": bp * k / tp / 1e9, "content_match_vs_synchronous_call": bool(same),
+                          "what": "pgr_pipe_submit / pgr_pipe_collect, the same resident batch %d times, lists only" % k}
+        del got
+        if check:
+            def one(i):
+                ref = O.sequence_to_shmmrs(i, seqs[i], O.spec(*spec_t))
+                return len(ref), O.shmmr_checksum(ref)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(cores) as ex:
+                refs = list(ex.map(one, range(len(seqs))))
+            e["cpu_s"] = time.perf_counter() - t0
+            e["cpu_threads"] = cores
+            e["contigs_checked"] = len(seqs)
+            e["content_match"] = bool(all(int(off[i + 1] - off[i]) == c and np.array_equal(sums[i], cs) for i, (c, cs) in enumerate(refs)))
+        out["genome_like"] = e
+    except Exception as ex:  # noqa: BLE001
+        out["genome_like"] = {"error": repr(ex)}
     return out
 
 

@@ -101,7 +101,7 @@ struct IslandRun {
         // a chunk that runs again: 8 instead of 16) unless the islands are large.  The islands around non-ACGT bytes run beside
         // the tile kernel: more, shorter chunks there only take its slots (chromosome-like 0.85 -> 0.875 ms at 768).
         const uint64_t PAL_MIN = ctx->opt.island_chunk_min > 0 ? CS_MIN : 512;
-        CS_PAL = std::min<uint64_t>(32768, std::max<uint64_t>(PAL_MIN, ((island_bases / 6144 + 255) / 256) * 256));
+        CS_PAL = pal_chunk(island_bases, PAL_MIN);
     }
     // (a run that is dropped with its first round still on the side stream -- the flags added islands, or the pass starts over:
     // whoever uses the workspaces, the pinned image and the regions next must find them idle)
@@ -110,11 +110,31 @@ struct IslandRun {
     }
     IslandRun(const IslandRun &) = delete;
     IslandRun &operator=(const IslandRun &) = delete;
+    // Chunk length of islands around palindromic k-mers: enough chunks to fill the chip (~2.5 wavefronts per SIMD), and -- once that
+    // asks for chunks of a tile or more, i.e. there are thousands of islands (a genome-sized batch: one per (AT)n microsatellite
+    // longer than k, each a flagged tile and its clean neighbour) -- ONE chunk per such island: a seam inside it costs a warm-up
+    // and, where the machine passes it stuck, a second round (a 2 Gbp genome-like batch: 148 chunks run again at 3584 positions
+    // per chunk, none at 8192; 7.06 -> 6.81 ms)
+    uint64_t pal_chunk(uint64_t bases, uint64_t floor_) const {
+        uint64_t cs = std::max<uint64_t>(floor_, ((bases / 2560 + 255) / 256) * 256);
+        if (cs >= tc) cs = std::max<uint64_t>(cs, ((2ull * tc + 512 + 255) / 256) * 256);
+        return std::min<uint64_t>(32768, cs);
+    }
     uint64_t cap_of(uint64_t len, bool full) const { return full ? len + a.w + 320 : std::min<uint64_t>(len + a.w + 320, len / 4 + 1024); }
     void isl_lap(const char *what, int r) const {
         if (ctx->opt.debug_times)
             fprintf(stderr, "[pgr]     islands round %d %-34s at %7.1f us\n", r, what,
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_isl0).count());
+    }
+    // (room for the chunks of these islands: a genome-sized batch has ten thousand, 300 bytes each, and the vector grew eight times)
+    void reserve_chunks(const std::vector<Island> &isl, size_t have) {
+        size_t nc = 0;
+        for (const Island &is : isl) {
+            const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
+            nc += is.whole ? 2 : (size_t)((is.E - is.B + CS - 1) / CS) + 1;
+        }
+        ch.reserve(have + nc + 16);
+        todo.reserve(todo.size() + nc + 16);
     }
     int build(size_t ii);
     int enqueue_round();
@@ -185,7 +205,6 @@ int IslandRun::build(size_t ii) {
 int IslandRun::enqueue_round() {
     int rc;
     nq = todo.size();
-    descs.assign(nq, ChunkDesc());
     for (size_t q = 0; q < nq; ++q) {
         HChunk &h = ch[todo[q]];
         h.d.ring_out = h.probe ? 0xFFFFFFFFu : (uint32_t)todo[q];
@@ -193,7 +212,6 @@ int IslandRun::enqueue_round() {
         h.d.region_off = next_region;
         h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
         next_region += h.d.region_cap;
-        descs[q] = h.d;
     }
     if (st_chunks != st && ctx->ws_l1.cap < (next_region + 1) * sizeof(L1Rec)) st_chunks = st;  // (the buffer grows: in stream order)
     if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st))) return rc;
@@ -212,7 +230,10 @@ int IslandRun::enqueue_round() {
     ChunkState *d_out = d_in + nq;
     uint64_t *d_info = (uint64_t *)(d_out + nq);
     uint32_t *d_stat = (uint32_t *)(d_info + 4 * nq);
-    memcpy(h_img, descs.data(), desc_bytes);
+    // (straight into the pinned image: ten thousand descriptors of a genome-sized batch are 1.6 MB -- a vector of them first, then a
+    // copy, was 0.1 ms between the tile kernel's flags and the chunk kernel)
+    for (size_t q = 0; q < nq; ++q) d_desc[q] = ch[todo[q]].d;
+    if (ctx->opt.debug) descs.assign(d_desc, d_desc + nq);
     d_zr.reset(new Tmp_list(ctx));
     if (!zero_ranges.empty()) {
         if ((rc = d_zr->alloc(zero_ranges.size() * sizeof(uint32_t)))) return rc;
@@ -254,7 +275,7 @@ int IslandRun::process_round() {
         ch[todo[q]].n_out = r_info[4 * q + 3];
         ch[todo[q]].dropped = false;
     }
-    if (ctx->opt.debug) {
+    if (ctx->opt.debug && descs.size() == nq && nq) {
         uint32_t worst = 0;
         size_t wq = 0;
         uint64_t steps = 0;
@@ -425,6 +446,7 @@ int IslandRun::begin(hipStream_t side) {
     int rc;
     st_chunks = side ? side : st;
     t_isl0 = std::chrono::steady_clock::now();
+    reserve_chunks(islands, 0);
     for (size_t ii = 0; ii < islands.size(); ++ii)
         if ((rc = build(ii))) return rc;
     round = 0;
@@ -517,7 +539,13 @@ int IslandRun::adopt(const std::vector<Island> &wanted) {
     uint64_t fresh_bases = 0;
     for (size_t j = 0; j < wanted.size(); ++j)
         if (!covered[j]) fresh_bases += wanted[j].E - wanted[j].B;
-    if (ctx->opt.island_chunk_min <= 0) CS_PAL = std::min<uint64_t>(32768, std::max<uint64_t>(512, ((fresh_bases / 6144 + 255) / 256) * 256));
+    if (ctx->opt.island_chunk_min <= 0) CS_PAL = pal_chunk(fresh_bases, 512);
+    {
+        std::vector<Island> fresh;
+        for (size_t j = 0; j < wanted.size(); ++j)
+            if (!covered[j]) fresh.push_back(wanted[j]);
+        reserve_chunks(fresh, ch.size());
+    }
     for (size_t j = 0; j < wanted.size(); ++j) {
         if (covered[j]) continue;
         islands.push_back(wanted[j]);

@@ -311,3 +311,64 @@ def test_genome_like_batch_keeps_the_early_round_and_adds_the_flagged_islands(or
                 assert int(off[i + 1] - off[i]) == len(ref[i]), (opts, i)
                 assert np.array_equal(sums[i], oracle.shmmr_checksum(ref[i])), (opts, i)
     assert gpu_ctx.last_prof().exact_bases > 0
+
+
+def test_pipe_over_flagged_batches_equals_the_synchronous_build_and_the_oracle(oracle, gpu_ctx):
+    """Every batch of a real assembly is flagged (gaps, (AT)n arrays longer than k).  In the pipe such a job's second pass -- islands
+    and the list stage -- runs on the fix stream beside the next job's tiles, and from the second job on the first pass is stage 1
+    alone (ShmmrJob::stage1_only: the predecessor needed islands).  Five batches of genome-like contigs (> 4 Mbp each, one clean one
+    in between: the prediction fails both ways), lists and the finalized index against the synchronous calls and the oracle; the
+    A/B options give the same bytes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import genome_like_bench as G
+    import pgrtk_amd as P
+    rng = np.random.default_rng(77)
+    spec = P.make_spec(*SPEC)
+    sets = []
+    for bi in range(5):
+        if bi == 2:
+            sets.append([seqgen.rnd(rng, 2_500_000), seqgen.rnd(rng, 2_000_000)])  # clean: the list stage was left out for nothing
+        else:
+            sets.append([G.genome_like_contig(oracle, 10 * bi + c, L, seed=5 + bi)[0] for c, L in enumerate((2_200_000, 1_700_000, 900_000))])
+            for q in sets[-1]:  # (AT)n / (ACGT)n arrays longer than k, a few per contig: tiles with skipped pushes in every batch
+                for pos in rng.integers(50_000, len(q) - 50_000, 6):
+                    ln = int(rng.integers(60, 1500))
+                    q[pos:pos + ln] = np.frombuffer((b"AT" if pos & 1 else b"ACGT") * (ln // 2 + 2), dtype=np.uint8)[:ln]
+    batches = [P.Batch.from_seqs(s, ctx=gpu_ctx) for s in sets]
+    refs = [[oracle.sequence_to_shmmrs(i, q, oracle.spec(*SPEC)) for i, q in enumerate(s)] for s in sets]
+    ix_s = P.Index(spec, ctx=gpu_ctx)
+    for b in batches:
+        ix_s.add_resident(b)
+    ix_s.finalize()
+    rs = ix_s.download()
+    for opts in ({}, {"no_stage1_only": 1}, {"no_fix_stream": 1}, {"no_fix_stream": 1, "no_stage1_only": 1}):
+        with gpu_ctx.options(**opts):
+            ix_p = P.Index(spec, ctx=gpu_ctx)
+            pipe = P.Pipe(spec, ctx=gpu_ctx)
+            got = []
+            for b in batches:
+                if pipe.in_flight == 2:
+                    got.append(pipe.collect()[0])
+                pipe.submit(b, index=ix_p)
+            while pipe.in_flight:
+                got.append(pipe.collect()[0])
+            pipe.close()
+            for bi, sh in enumerate(got):
+                sums, off = sh.checksum(), sh.offsets()
+                for i, ref in enumerate(refs[bi]):
+                    assert int(off[i + 1] - off[i]) == len(ref), (opts, bi, i)
+                    assert np.array_equal(sums[i], oracle.shmmr_checksum(ref)), (opts, bi, i)
+            ix_p.finalize()
+            rp = ix_p.download()
+            assert len(rp) == len(rs) > 1000 and rp.tobytes() == rs.tobytes(), opts
+    oix = oracle.Index(oracle.spec(*SPEC))
+    sid = 0
+    for s in sets:
+        for q in s:
+            oix.add_seq(sid, q)
+            sid += 1
+    oix.finalize()
+    ro = oix.records()
+    for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+        assert np.array_equal(ro[f], rs[f]), f

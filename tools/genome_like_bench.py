@@ -38,14 +38,14 @@ def genome_like_contig(O, c, L, seed=97):
     n = {"microsatellites": 0, "palindromic_arrays_over_k": 0, "gaps": 0, "satellite_bp": 0}
     # segmental duplications (10 - 200 kbp blocks copied elsewhere, 1 % divergence) and tandem duplications
     for _ in range(max(1, L // 8_000_000)):
-        ln = int(rng.integers(10_000, 200_000))
+        ln = min(int(rng.integers(10_000, 200_000)), L // 10)
         a, b = int(rng.integers(0, L - ln)), int(rng.integers(0, L - ln))
         blk = s[a:a + ln].copy()
         m = rng.random(ln) < 0.01
         blk[m] = rng.choice(ACGT, int(m.sum()))
         s[b:b + ln] = blk
     for _ in range(max(1, L // 20_000_000)):
-        u = int(rng.integers(2_000, 12_000))
+        u = min(int(rng.integers(2_000, 12_000)), L // 100)
         a = int(rng.integers(0, L - 40 * u))
         s[a:a + 20 * u] = tile_unit(s[a:a + u].copy(), 20 * u)
     # microsatellites: ~1 per 8 kbp, unit of 1-6 bases, length 12 + exponential (mean 14) with a heavy tail (2 %: up to 2 kbp)
@@ -71,9 +71,9 @@ def genome_like_contig(O, c, L, seed=97):
     n["microsatellites"] = int(n_ms)
     # centromere: satellite arrays (171-bp unit, 2 % divergence, a 12-unit higher-order repeat) on both sides of a gap
     cen = int(L * (0.35 + 0.2 * rng.random()))
-    gap = int(rng.integers(1_000_000, 6_000_000)) if c else 18_000_000
+    gap = min(int(rng.integers(1_000_000, 6_000_000)) if c else 18_000_000, L // 8)  # (the clips: scaled-down contigs of the tests)
     for side in (0, 1):
-        total = int(rng.integers(500_000, 2_500_000))
+        total = min(int(rng.integers(500_000, 2_500_000)), L // 12)
         u0 = rng.choice(ACGT, 171)
         hor = np.concatenate([np.where(rng.random(171) < 0.2, rng.choice(ACGT, 171), u0) for _ in range(12)])
         arr = tile_unit(hor, total).copy()
@@ -87,8 +87,8 @@ def genome_like_contig(O, c, L, seed=97):
     # other gaps, telomeres, isolated N
     n_gaps = int(rng.integers(15, 45))
     for _ in range(n_gaps):
-        a = int(rng.integers(0, L - 1_100_000))
-        s[a:a + int(rng.integers(1_000, 1_000_000) if rng.random() < 0.3 else rng.integers(100, 50_000))] = ord("N")
+        a = int(rng.integers(0, max(1, L - 1_100_000)))
+        s[a:a + min(int(rng.integers(1_000, 1_000_000) if rng.random() < 0.3 else rng.integers(100, 50_000)), L // 40)] = ord("N")
     n["gaps"] = n_gaps + 3
     tel = np.frombuffer(b"TTAGGG", dtype=np.uint8)
     s[:10_000] = ord("N")
