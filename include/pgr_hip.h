@@ -102,6 +102,8 @@ const char *pgr_version(void);
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing
  *   no_early_islands          ... never start their first round before the tile kernel's flags are seen, for A/B timing
  *   early_islands_in_stream   ... start it behind the tile kernel on the context's stream, not beside it on a stream of its own, for A/B
+ *   no_early_merge            ... drop that early round when the tile kernel's flags add islands (tiles with a palindromic k-mer) instead
+ *                             of keeping it and running only the added islands behind it, for A/B
  *   island_chunk_min          > 0: shortest chunk of the exact machine in positions (default 1024; 4096 = the round-3 minimum), for A/B
  *   back_priority             pgr_pipe: stream priority of the back stream (1 = highest, 0 = default, -1 = lowest), read when the
  *                             context's first pipe is created
@@ -110,6 +112,10 @@ const char *pgr_version(void);
  *   pipe_small_list           pgr_pipe: the list kernel of a pipelined job runs 512-element workgroups (14 KB of LDS), for A/B
  *   front_priority            1: the context's stream gets the device's highest priority (environment only: read at pgr_ctx_create), for A/B
  *   pipe_staged_records       pgr_pipe: index jobs always stage their records and copy them in when collected, for A/B
+ *   no_fix_stream             pgr_pipe: a job that needs a second pass (flagged tiles: every batch of a real assembly) is finished on the
+ *                             context's stream, behind the next job's tiles, instead of on a stream of its own beside them, for A/B
+ *   no_stage1_only            pgr_pipe: a job's first pass always includes its list stage, even when the job before it needed islands
+ *                             (then that list stage is thrown away at collect), for A/B
  *   direct_query_result       batches of short queries: the per-query kernel writes the host's result block itself (single pass, sections
  *                             placed from the previous batch's counts); an experiment, measured slower than two passes + download
  *   direct_query_lds_kb       ... with this much LDS per workgroup (fewer queries resident at once); -1: its block in device memory
