@@ -32,8 +32,13 @@ struct Island {
 
 // tf is modified: tiles deep inside a run of non-ACGT bytes end up 0 (their segment ranges go to gap_segs).
 inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, const uint32_t *h_len, uint32_t tc, bool sketch,
-                                    const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, std::vector<Island> &islands,
-                                    std::vector<uint32_t> &gap_segs) {
+                                    const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, const uint16_t *pal,
+                                    std::vector<Island> &islands, std::vector<uint32_t> &gap_segs) {
+    // pal (or NULL): for a tile with flag bit 0, first | last << 8 block of 64 core positions that holds a palindromic k-mer
+    // (0: in front of the core, >= tc / 64: behind it).  ISLAND_SETTLE: positions of regular sequence behind the last one
+    // within which a machine that came out of the array stuck has practically always found back (a push at or below the stuck
+    // minimum: one in ~w + 1 pushes does; the probe at the island's end checks it and the island grows if not)
+    constexpr uint32_t ISLAND_SETTLE = 1408;
     struct FT {
         uint32_t t;
         uint8_t f;
@@ -104,17 +109,27 @@ inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, cons
             const uint32_t ta = F[i].t;
             uint32_t tb = ta;
             bool any_pal = (F[i].f & 1) != 0;
-            size_t j = i;
+            size_t j = i, last_pal = i;
             while (j + 1 < F.size() && F[j + 1].t - tb <= 2) {  // bridge 1-tile gaps
                 ++j;
                 tb = F[j].t;
-                any_pal = any_pal || (F[j].f & 1);
+                if (F[j].f & 1) {
+                    any_pal = true;
+                    last_pal = j;
+                }
             }
             // a clean neighbour on the right for the machine to find back into its regular regime -- behind skipped pushes
             // (palindromic k-mers) it may arrive stuck; behind a non-ACGT byte it cannot: the byte lies >= w + k + 64
             // positions in front of the first clean tile (or that tile would be flagged), every position pushes, and the
             // ring holds only pushes from behind the byte when the island ends.  The probe at the island's end checks it.
-            if (tb + 1 < nt && any_pal) ++tb;
+            // (the clean neighbour is 3904 more positions through the machine for an array of perhaps 100: where the tile kernel has
+            // said where the last palindromic k-mer lies, and ISLAND_SETTLE positions of the flagged tiles follow it, they are the room)
+            bool neighbour = tb + 1 < nt && any_pal;
+            if (neighbour && pal) {
+                const uint32_t hi_blk = (uint32_t)(pal[t0 + F[last_pal].t] >> 8);
+                if (hi_blk < tc / 64 && (uint64_t)(tb - F[last_pal].t) * tc + (uint64_t)(tc / 64 - 1 - hi_blk) * 64 >= ISLAND_SETTLE) neighbour = false;
+            }
+            if (neighbour) ++tb;
             Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
             is.pal = any_pal;
             if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island

@@ -198,6 +198,7 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
     __shared__ uint32_t s_wsum[BLK / 64];
     __shared__ unsigned long long s_base;
     __shared__ int s_skip;
+    __shared__ uint32_t s_pal[2];  // first / last extended position of the tile with a palindromic k-mer (when s_skip)
 #ifdef PGR_LDS_PAD
     __shared__ uint32_t s_pad[PGR_LDS_PAD / 4];  // occupancy experiment only
     if (a.w == 0xdead) s_pad[threadIdx.x] = 1;
@@ -247,7 +248,11 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
         if (wi >= 0 && wi < nwords) v = planes[wi];
         s_words[t] = v;
     }
-    if (t == 0) s_skip = 0;
+    if (t == 0) {
+        s_skip = 0;
+        s_pal[0] = 0xFFFFFFFFu;
+        s_pal[1] = 0u;
+    }
     __syncthreads();
 
     // ---- per-lane masks over this lane's 16 positions (tile-extended coordinates 16t .. 16t+15)
@@ -295,10 +300,10 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
     const bool wave_full = interior || __all(valid_mask == 0xFFFFu && mwin_mask == 0xFFFFu);
     if (wave_full)
         tile_select<TW, TK, SKETCH, false, BLK>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
-                                          core_mask, x, strand_bits, emit);
+                                          core_mask, x, strand_bits, emit, s_pal);
     else
         tile_select<TW, TK, SKETCH, true, BLK>(a, w, k, t, q, wbase, s_words, s_suf, s_row, &s_skip, valid_mask, mwin_mask,
-                                         core_mask, x, strand_bits, emit);
+                                         core_mask, x, strand_bits, emit, s_pal);
 
     // ---- ordered compaction: block scan of per-lane counts, one cursor bump per tile
     const uint32_t cnt = __popc(emit);
@@ -335,6 +340,12 @@ __global__ __launch_bounds__(BLK) PGR_TILE_ATTR void level1_tile_kernel(L1Args a
             atomicOr(a.contig_flags + c, 1u);
             a.tile_flags[tile] |= 1;
             atomicOr(a.cursor + 2, 1ull);  // batch-wide "some tile needs the exact path" word (read once by the host)
+            if (a.tile_pal) {
+                // where in the tile's core, in blocks of 64 positions (in front of the core: 0; behind it: the last block)
+                const long long lo = (e0 + (long long)s_pal[0] - c0) >> 6, hi = (e0 + (long long)s_pal[1] - c0) >> 6;
+                const uint32_t lo_b = (uint32_t)(lo < 0 ? 0 : lo > 63 ? 63 : lo), hi_b = (uint32_t)(hi < 0 ? 0 : hi > 63 ? 63 : hi);
+                a.tile_pal[tile] = (uint16_t)(lo_b | (hi_b << 8));
+            }
         }
     }
     // selected keys go through LDS (s_suf is free now; each lane re-reads only its own column, so no barrier

@@ -168,7 +168,7 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
                                             long long wbase, const uint2 *s_words, double (*s_suf)[BLK],
                                             double *s_row, int *s_skip, uint32_t valid_mask, uint32_t mwin_mask,
                                             uint32_t core_mask, double (&x)[L1_G], uint32_t &strand_bits,
-                                            uint32_t &emit) {
+                                            uint32_t &emit, uint32_t *s_pal = nullptr) {
     // ---- per-lane 96-bit windows of both planes ending at this lane's last position
     const long long e = q + (L1_G - 1);
     const int jl = (int)((e >> 5) - wbase);
@@ -250,13 +250,26 @@ __device__ __forceinline__ void tile_select(const L1Args &a, uint32_t w, uint32_
     strand_bits = __brev(strand_rev) >> 16;
     uint64_t pal_any = 0;
     if (!SKETCH && pal0_any) {  // wave-uniform: some lane has f0 == r0 somewhere; now the exact test on the high planes
+        // (s_pal: the tile's first and last extended position with a palindromic k-mer -- scalar arithmetic on the lane masks, in
+        // this cold block only; the islands of the exact machine end a tile early when the last one lies well inside its tile)
+        uint32_t p_lo = 0xFFFFFFFFu, p_hi = 0u;
+        const uint32_t wave_pos0 = (t & ~63u) * (uint32_t)L1_G;
 #pragma unroll
         for (int u = 0; u < L1_G; ++u) {
             if (eq0[u] == 0) continue;
             asm volatile("s_nop 15");  // (marks the cold block for tools/isa_histogram.py: weight 0)
             const uint64_t f1 = shr_mask(u >= 8 ? fa1 : fb1, (uint32_t)((L1_G - 1 - u) & 7), kmask);
             const uint64_t r1 = TK ? shr_mask(u >= 8 ? rB1 : rA1, (uint32_t)(u & 7), kmask) : rc_plane(f1, k);
-            pal_any |= eq0[u] & cmp_eq_u64(f1, r1);
+            const uint64_t pm = eq0[u] & cmp_eq_u64(f1, r1);
+            pal_any |= pm;
+            if (s_pal && pm) {
+                p_lo = min(p_lo, wave_pos0 + (uint32_t)__builtin_ctzll(pm) * (uint32_t)L1_G + (uint32_t)u);
+                p_hi = max(p_hi, wave_pos0 + (63u - (uint32_t)__builtin_clzll(pm)) * (uint32_t)L1_G + (uint32_t)u);
+            }
+        }
+        if (s_pal && pal_any && (t & 63u) == 0) {
+            atomicMin(&s_pal[0], p_lo);
+            atomicMax(&s_pal[1], p_hi);
         }
     }
     const uint32_t pal_min = pal_any ? 0u : 1u;

@@ -156,6 +156,7 @@ struct L1Args {
     uint32_t *seg_cid;           // [n_tiles + n_contigs] contig of the records of a segment
     uint32_t *contig_flags;      // [n] bit0: palindromic skip seen (needs the exact kernel)
     uint8_t *tile_flags;         // [n_tiles] 1: the tile's extended range holds a palindromic k-mer / non-ACGT byte
+    uint16_t *tile_pal;          // [n_tiles] or NULL; of a tile with flag bit 0: first | last << 8 block of 64 core positions with a palindromic k-mer
     // [n_tiles] (contig + 1) << 32 | (last valid position <= the end of the tile's core) + 1, low word 0 when the contig has
     // no valid base up to there.  Written per tile by mark_invalid_tiles_kernel, made cumulative by an inclusive max-scan
     // before the exact-machine chunks run: their k-mer look-back crosses a multi-Mbp run of N in one step with it.
