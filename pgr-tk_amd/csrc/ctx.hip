@@ -286,8 +286,13 @@ void pgr_ctx::dfree(void *p) {
         // freed inside a job's second pass (pgr_pipe_collect): whatever is pending on the block is pending on the fix stream.  (The
         // context's stream is busy with the NEXT job's tiles: an event recorded there would make this pass's next allocation, which
         // is likely to get this very block, wait for them.)
-        if (!(fb.ev_fix = take_event()) || hipEventRecord(fb.ev_fix, fix_stream) != hipSuccess) {
+        // (a block the back stream works on too -- handed out for it, or marked: an index's records -- also remembers where that
+        // stream stands)
+        bool ok = (fb.ev_fix = take_event()) && hipEventRecord(fb.ev_fix, fix_stream) == hipSuccess;
+        if (ok && on_back) ok = (fb.ev_back = take_event()) && hipEventRecord(fb.ev_back, back_stream) == hipSuccess;
+        if (!ok) {
             (void)hipStreamSynchronize(fix_stream);
+            if (on_back && back_stream) (void)hipStreamSynchronize(back_stream);
             drop_events(fb);
         }
     } else if (multi_stream) {  // where the two streams stand now: the next user on the other stream waits for that

@@ -1734,7 +1734,10 @@ int pipe_records(pgr_pipe *p, pgr_pipe::Slot *sp, uint32_t n, hipStream_t st, co
         // a synchronous pass of a direct job: every job submitted before it has been collected, the index's count is exact, and the
         // other job in flight has been waited for (pgr_pipe_collect)
         pgr_index *ix = sp->ix;
+        hipStream_t saved_alloc = ctx->alloc_stream;
+        ctx->alloc_stream = nullptr;  // (the index's block belongs to the context's stream, whichever stream this pass runs on)
         int rc = index_grow_raw(ctx, ix, ix->n_raw + cap);
+        ctx->alloc_stream = saved_alloc;
         if (rc) return rc;
         ctx->block_on_back(ix->raw);
         sp->dst_cap = ix->cap_raw - ix->n_raw;
