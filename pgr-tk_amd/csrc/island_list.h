@@ -33,7 +33,10 @@ struct Island {
 // tf is modified: tiles deep inside a run of non-ACGT bytes end up 0 (their segment ranges go to gap_segs).
 inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, const uint32_t *h_len, uint32_t tc, bool sketch,
                                     const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, const uint16_t *pal,
-                                    std::vector<Island> &islands, std::vector<uint32_t> &gap_segs) {
+                                    std::vector<Island> &islands, std::vector<uint32_t> &gap_segs, uint32_t c_begin = 0,
+                                    uint32_t c_end = 0xFFFFFFFFu) {
+    // (contigs [c_begin, min(c_end, n)): islands never span contigs, so ranges of contigs can be listed side by side and the
+    // lists put behind one another)
     // pal (or NULL): for a tile with flag bit 0, first | last << 8 block of 64 core positions that holds a palindromic k-mer
     // (0: in front of the core, >= tc / 64: behind it).  ISLAND_SETTLE: positions of regular sequence behind the last one
     // within which a machine that came out of the array stuck has practically always found back (a push at or below the stuck
@@ -44,7 +47,7 @@ inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, cons
         uint8_t f;
     };
     std::vector<FT> F;
-    for (uint32_t c = 0; c < n; ++c) {
+    for (uint32_t c = c_begin; c < n && c < c_end; ++c) {
         if (n_invalid[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
         const uint32_t t0 = tile_first[c], nt = tile_first[c + 1] - t0;
         const uint64_t L = h_len[c];

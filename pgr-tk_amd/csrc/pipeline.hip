@@ -1038,7 +1038,30 @@ int ShmmrJob::plan() {
 // bytes, tf[tile] = tile flags (bit 0 palindromic k-mer, bit 1 non-ACGT byte in reach, bit 2 nothing but such bytes; bit 3 is set here)
 void ShmmrJob::list_islands(const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, const uint16_t *pal, std::vector<Island> &islands,
                             std::vector<uint32_t> &gap_segs) {
-    list_islands_from_flags(n, tile_first().data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, islands, gap_segs);
+    const std::vector<uint32_t> &tfi = tile_first();
+    // a genome-sized batch (half a million tiles in a dozen contigs): ranges of contigs on the pool's threads, lists in contig order
+    const unsigned par = std::min<unsigned>(std::min<unsigned>(16, HostPool::instance().workers() + 1), n);
+    if (n_tiles < (1u << 17) || par < 2) {
+        list_islands_from_flags(n, tfi.data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, islands, gap_segs);
+        return;
+    }
+    std::vector<uint32_t> cut(par + 1, n);  // contig ranges of about n_tiles / par tiles each
+    cut[0] = 0;
+    for (unsigned p = 1, c = 0; p < par; ++p) {
+        const uint64_t want = (uint64_t)n_tiles * p / par;
+        while (c < n && tfi[c] < want) ++c;
+        cut[p] = c;
+    }
+    std::vector<std::vector<Island>> isl(par);
+    std::vector<std::vector<uint32_t>> gs(par);
+    HostPool::instance().parallel_for(par, [&](size_t p) {
+        if (cut[p] < cut[p + 1])
+            list_islands_from_flags(n, tfi.data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, isl[p], gs[p], cut[p], cut[p + 1]);
+    });
+    for (unsigned p = 0; p < par; ++p) {
+        islands.insert(islands.end(), isl[p].begin(), isl[p].end());
+        gap_segs.insert(gap_segs.end(), gs[p].begin(), gs[p].end());
+    }
 }
 
 int ShmmrJob::stage1() {
@@ -1153,7 +1176,8 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         const bool have_pal = want_pal && (!flags_prefetched || pal_prefetched);
         flags_prefetched = false;
         dbg_lap("islands: tile flags on the host");
-        std::vector<uint8_t> tf(img + nc, img + nc + n_tiles);  // (list_islands marks tiles in its copy; run_exact_islands reuses the image)
+        std::vector<uint8_t> &tf = ctx->h_tf_scratch;  // (list_islands marks tiles in its copy; run_exact_islands reuses the image.  Kept: a fresh half megabyte faults in page by page)
+        tf.assign(img + nc, img + nc + n_tiles);
         std::vector<uint32_t> flags((const uint32_t *)img, (const uint32_t *)img + n), n_invalid((const uint32_t *)(img + inv_off), (const uint32_t *)(img + inv_off) + n);
         list_islands(flags.data(), n_invalid.data(), tf.data(), have_pal ? (const uint16_t *)(img + pal_off) : nullptr, islands, gap_segs);
     }

@@ -153,6 +153,18 @@ int main(int argc, char **argv) {
             n_shorter += bases_c < bases_b;
             if (!ok && ++failures <= 5) fprintf(stderr, "case %d: islands listed with palindrome positions are not a trimmed form of those without\n", it);
         }
+        {  // ranges of contigs listed one after the other give the same lists (what the product does on several threads)
+            std::vector<uint8_t> tf_d = tf;
+            std::vector<Island> id;
+            std::vector<uint32_t> gd;
+            const uint32_t cut = (uint32_t)(rng() % (n + 1));
+            pgr::list_islands_from_flags(n, tile_first.data(), h_len.data(), tc, sketch, flags.data(), n_inv.data(), tf_d.data(), nullptr, id, gd, 0, cut);
+            pgr::list_islands_from_flags(n, tile_first.data(), h_len.data(), tc, sketch, flags.data(), n_inv.data(), tf_d.data(), nullptr, id, gd, cut, n);
+            bool ok = id.size() == ib.size() && gd == gb && tf_d == tf_b;
+            for (size_t i = 0; ok && i < id.size(); ++i)
+                ok = id[i].contig == ib[i].contig && id[i].B == ib[i].B && id[i].E == ib[i].E && id[i].whole == ib[i].whole && id[i].pal == ib[i].pal;
+            if (!ok && ++failures <= 5) fprintf(stderr, "case %d: two ranges of contigs give other lists than all contigs at once\n", it);
+        }
         bool same = ia.size() == ib.size() && ga == gb && tf_a == tf_b;
         n_islands += ia.size();
         n_gaps += ga.size() / 2;
