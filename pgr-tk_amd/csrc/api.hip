@@ -124,6 +124,42 @@ extern "C" int pgr_ctx_create(int device, pgr_ctx **out) {
     return PGR_OK;
 }
 
+// A second context for work that should run BESIDE another context's: the runtime multiplexes streams onto a handful of hardware
+// queues, and two contexts whose streams share one run their batches one after the other whatever the host threads do (two query
+// batches in flight: 0.41 ms per batch side by side, 0.74 in order -- which of the two a plain pgr_ctx_create gives depends on how
+// many streams the process has created before).  Candidates for the new context's stream are tried against `other`'s until one
+// runs side by side with it (ctx.hip: streams_run_side_by_side); with none in eight the last one is kept.
+extern "C" int pgr_ctx_create_beside(pgr_ctx *other, pgr_ctx **out) {
+    if (!out) return PGR_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (!other) return PGR_ERR_INVALID_ARG;
+    pgr_ctx *ctx = nullptr;
+    int rc = pgr_ctx_create(other->device, &ctx);
+    if (rc) return rc;
+    unsigned long long *d_scratch = nullptr;
+    if (hipMalloc((void **)&d_scratch, 64) != hipSuccess) {
+        pgr_ctx_destroy(ctx);
+        g_create_error = "hipMalloc failed";
+        return PGR_ERR_NOMEM;
+    }
+    std::vector<hipStream_t> rejected;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    for (int tries = 0; tries < 8; ++tries) {
+        if (streams_run_side_by_side(other->stream, ctx->stream, d_scratch)) break;
+        hipStream_t cand = nullptr;
+        const hipError_t e = ctx->opt.front_priority > 0 ? hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, hi)
+                                                         : hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+        if (e != hipSuccess) break;
+        rejected.push_back(ctx->stream);  // (kept until the search is over: the next candidate lands on another queue)
+        ctx->stream = cand;
+    }
+    for (hipStream_t r : rejected) (void)hipStreamDestroy(r);
+    (void)hipFree(d_scratch);
+    *out = ctx;
+    return PGR_OK;
+}
+
 extern "C" int pgr_host_register(void *p, size_t bytes) {
     if (!p || !bytes) return PGR_ERR_INVALID_ARG;
     const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);

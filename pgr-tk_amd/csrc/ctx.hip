@@ -127,7 +127,7 @@ __global__ void pgr_touch_kernel(unsigned long long *out) {
 // BEHIND the next batch's tiles instead of beside them (measured: 21.5 instead of 20.6 ms per batch).  Which queue a new stream
 // gets depends on how many streams the process has created before.  So: try it.  A kernel that lingers ~0.4 ms on `a`, a trivial
 // one on `b` right after it: if `b`'s is done while `a`'s is still there, the two streams do not share a queue.
-static bool streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned long long *d_scratch) {
+bool pgr::streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned long long *d_scratch) {
     hipEvent_t ea = nullptr, eb = nullptr;
     if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) != hipSuccess) return false;
     if (hipEventCreateWithFlags(&eb, hipEventDisableTiming) != hipSuccess) {
@@ -163,7 +163,7 @@ int pgr_ctx::enable_multi_stream() {
             hipStream_t cand = nullptr;
             e = hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio);
             if (e != hipSuccess) break;
-            if (streams_run_side_by_side(stream, cand, d_scratch)) {
+            if (pgr::streams_run_side_by_side(stream, cand, d_scratch)) {
                 back_stream = cand;
                 break;
             }
@@ -181,7 +181,7 @@ int pgr_ctx::enable_multi_stream() {
             for (int tries = 0; tries < 8; ++tries) {
                 hipStream_t cand = nullptr;
                 if (hipStreamCreateWithPriority(&cand, hipStreamNonBlocking, prio) != hipSuccess) break;
-                if (streams_run_side_by_side(stream, cand, d_scratch) && streams_run_side_by_side(back_stream, cand, d_scratch)) {
+                if (pgr::streams_run_side_by_side(stream, cand, d_scratch) && pgr::streams_run_side_by_side(back_stream, cand, d_scratch)) {
                     fix_stream = cand;
                     break;
                 }

@@ -12,6 +12,8 @@
 #include "pgr_small.h"
 
 namespace pgr {
+// true when a kernel on b runs while a kernel on a is still there: the two streams do not share a hardware queue (ctx.hip)
+bool streams_run_side_by_side(hipStream_t a, hipStream_t b, unsigned long long *d_scratch);
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;

@@ -70,6 +70,7 @@ _VP = C.c_void_p
 _PVP = C.POINTER(C.c_void_p)
 _SIGS = [
     ("pgr_ctx_create", C.c_int, [C.c_int, _PVP]),
+    ("pgr_ctx_create_beside", C.c_int, [_VP, _PVP]),
     ("pgr_ctx_destroy", None, [_VP]),
     ("pgr_last_error", C.c_char_p, [_VP]),
     ("pgr_free", None, [_VP]),
@@ -302,10 +303,12 @@ def take(ptr, n, dtype):
 class Context:
     """one GPU, one stream (pgr_ctx).  Not thread safe."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, beside=None):
+        """beside: another Context -- this one's work runs side by side with that one's (pgr_ctx_create_beside: one context per
+        host thread, e.g. two query batches in flight against one index)"""
         self._h = C.c_void_p()
-        self.device = int(device)
-        rc = lib().pgr_ctx_create(device, C.byref(self._h))
+        self.device = int(device if beside is None else beside.device)
+        rc = lib().pgr_ctx_create(device, C.byref(self._h)) if beside is None else lib().pgr_ctx_create_beside(beside.handle, C.byref(self._h))
         if rc != 0:
             msg = lib().pgr_last_error(None)
             raise PgrError(rc, msg.decode() if msg else "pgr_ctx_create failed")

@@ -470,13 +470,15 @@ class Index:
         return self._unpack_raw(res, n)
 
     def query_hps_resident_raw(self, batch, penalty, max_count=128, max_count_query=128, max_count_target=128,
-                               max_aln_span=8, max_gap=None, oriented=False):
-        """pgr_query_hps_resident: the queries are a Batch already on the GPU"""
+                               max_aln_span=8, max_gap=None, oriented=False, ctx=None):
+        """pgr_query_hps_resident: the queries are a Batch already on the GPU.  ctx: the context the call runs on (the batch's;
+        default: the index's) -- a finalized index may be queried from several contexts, one per host thread"""
         res = _ffi.HpsResult()
-        self.ctx.check(lib().pgr_query_hps_resident(self.ctx.handle, self._h, batch._h, float(penalty), max_count,
-                                                    max_count_query, max_count_target, max_aln_span,
-                                                    int(max_gap is not None), int(max_gap or 0), int(bool(oriented)),
-                                                    C.byref(res)))
+        ctx = ctx or self.ctx
+        ctx.check(lib().pgr_query_hps_resident(ctx.handle, self._h, batch._h, float(penalty), max_count,
+                                               max_count_query, max_count_target, max_aln_span,
+                                               int(max_gap is not None), int(max_gap or 0), int(bool(oriented)),
+                                               C.byref(res)))
         return self._unpack_raw(res, batch.n)
 
     def time_query_resident(self, batch, penalty, max_count=128, max_count_query=128, max_count_target=128,

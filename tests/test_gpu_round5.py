@@ -372,3 +372,63 @@ def test_pipe_over_flagged_batches_equals_the_synchronous_build_and_the_oracle(o
     ro = oix.records()
     for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
         assert np.array_equal(ro[f], rs[f]), f
+
+
+def test_two_query_batches_in_flight_through_two_contexts_give_the_single_threaded_answers(oracle, gpu_ctx):
+    """pgr_ctx_create_beside: a second context whose stream runs side by side with the first one's; one host thread per context, ONE
+    finalized index (its per-batch hints are atomics): the reference's rayon loop over the queries (pgr-query.rs:135-165).  Every batch
+    of both threads equals the answer of a single-threaded call, which equals the oracle's."""
+    import threading
+    import pgrtk_amd as P
+    rng = np.random.default_rng(91)
+    spec = P.make_spec(*SPEC)
+    targets = [seqgen.rnd(rng, 300_000) for _ in range(6)]
+    ix = P.Index(spec, ctx=gpu_ctx)
+    ix.add_resident(P.Batch.from_seqs(targets, ctx=gpu_ctx))
+    ix.finalize()
+    qsets = []
+    for k in range(2):
+        qs = []
+        for _ in range(400):
+            t = int(rng.integers(0, len(targets)))
+            o = int(rng.integers(0, 290_000))
+            q = targets[t][o:o + int(rng.integers(3_000, 10_000))]
+            qs.append(seqgen.rc(q) if rng.random() < 0.5 else q)
+        qsets.append(qs)
+    ctx2 = P.Context(beside=gpu_ctx)
+    ctxs = (gpu_ctx, ctx2)
+    qbs = [P.Batch.from_seqs(qsets[k], ctx=ctxs[k]) for k in range(2)]
+    ref = [ix.query_hps_resident_raw(P.Batch.from_seqs(qsets[k], ctx=gpu_ctx), 0.025) for k in range(2)]
+    keys = ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps")
+    ref_b = [{f: np.array(ref[k][f]).tobytes() for f in keys} for k in range(2)]
+    # the oracle's chains for a sample of the queries of set 0
+    oix = oracle.Index(oracle.spec(*SPEC))
+    for i, t in enumerate(targets):
+        oix.add_seq(i, t)
+    oix.finalize()
+    for qi in range(0, 400, 37):
+        o = oix.query_fragment_to_hps(qsets[0][qi], 0.025)
+        t0, t1 = int(ref[0]["q_off"][qi]), int(ref[0]["q_off"][qi + 1])
+        assert [sid for sid, _ in o] == [int(x) for x in ref[0]["t_sid"][t0:t1]], qi
+    got = [[], []]
+    errs = []
+
+    def work(k):
+        try:
+            for _ in range(12):
+                r = ix.query_hps_resident_raw(qbs[k], 0.025, ctx=ctxs[k])
+                got[k].append({f: np.array(r[f]).tobytes() for f in keys})
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    assert not errs, errs
+    for k in range(2):
+        assert len(got[k]) == 12
+        for g in got[k]:
+            assert g == ref_b[k], k
+    del qbs
+    ctx2.close()
