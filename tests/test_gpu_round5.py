@@ -432,3 +432,49 @@ def test_two_query_batches_in_flight_through_two_contexts_give_the_single_thread
             assert g == ref_b[k], k
     del qbs
     ctx2.close()
+
+
+def test_pgr_mdb_on_a_genome_like_fasta_equals_the_oracles_frag_map(oracle, gpu_ctx, tmp_path):
+    """H1 end to end on input that looks like an assembly: contigs with gaps, satellite arrays, soft masking, microsatellites and
+    (AT)n / (ACGT)n arrays longer than k in a gzipped FASTA -> pgr-tk_amd/bin/pgr-mdb (C++ above the C ABI: host ASCII in, flagged
+    sub-batches, exact islands of both kinds) and the Python CLI write the same .mdb, whose content is the frag_map of the CPU
+    restatement of the same sequences (pgr-db/src/seq_db.rs:541-615)."""
+    import gzip
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import genome_like_bench as G
+    from pgrtk_amd import cli
+    rng = np.random.default_rng(5)
+    seqs = []
+    for c, L in enumerate((2_600_000, 1_900_000, 1_200_000, 700_000, 90_000)):
+        q = G.genome_like_contig(oracle, 40 + c, L, seed=11)[0]
+        for pos in rng.integers(20_000, L - 20_000, 5):
+            ln = int(rng.integers(60, 1200))
+            q[pos:pos + ln] = np.frombuffer((b"TA" if pos & 1 else b"GAATTC") * (ln // 2 + 3), dtype=np.uint8)[:ln]
+        seqs.append(q)
+    fa = str(tmp_path / "asm.fa.gz")
+    with gzip.open(fa, "wb", compresslevel=1) as f:
+        for i, q in enumerate(seqs):
+            f.write(b">ctg%d some description\n" % i)
+            b = q.tobytes()
+            for o in range(0, len(b), 60_000):
+                f.write(b[o:o + 60_000] + b"\n")
+    lst = tmp_path / "list.txt"
+    lst.write_text(fa + "\n")
+    p_cpp, p_py = str(tmp_path / "cpp"), str(tmp_path / "py")
+    r = subprocess.run([os.path.join(ROOT, "pgr-tk_amd", "bin", "pgr-mdb"), str(lst), p_cpp], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr
+    cli.main(["mdb", str(lst), p_py])
+    assert open(p_cpp + ".mdb", "rb").read() == open(p_py + ".mdb", "rb").read()
+    spec_t, m = oracle.read_mdb(p_cpp + ".mdb")
+    assert spec_t == (80, 56, 4, 64, 0)
+    oix = oracle.Index(oracle.spec(80, 56, 4, 64))
+    for i, q in enumerate(seqs):
+        oix.add_seq(i, q)
+    oix.finalize()
+    exp = {}
+    for rr in oix.records():
+        exp.setdefault((int(rr["h0"]), int(rr["h1"])), []).append((int(rr["frg_id"]), int(rr["sid"]), int(rr["bgn"]), int(rr["end"]), int(rr["orient"])))
+    assert m == exp and sum(len(v) for v in m.values()) > 10_000
+    assert [l.split("\t")[:3] for l in open(p_cpp + ".midx").read().splitlines()] == [[str(i), str(len(q)), "ctg%d" % i] for i, q in enumerate(seqs)]
