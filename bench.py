@@ -232,58 +232,47 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
             if offs[qi] <= tb <= offs[qi] + qlen:
                 ok += 1
     n_hps = int(len(r["hps"]))
-    # (c) two batches in flight: a second context beside this one (pgr_ctx_create_beside), one host thread each, the same index --
-    # the reference's rayon loop over the queries (pgr-query.rs:135-165).  What one batch leaves idle (a VALU-bound tile kernel, then
-    # latency-bound kernels, then 7.5 MB over PCIe) the other uses.  Every batch's result is compared with (a)'s.
-    two = None
+    # (c) two batches in flight through the context's pipe: pgr_pipe_submit_query / _collect_query -- the tiles of batch i + 1 on the
+    # context's stream beside everything behind the tiles of batch i on the pipe's back stream (which is tried against the context's
+    # stream until the two do not share a hardware queue).  The reference's rayon loop over the queries (pgr-query.rs:135-165).
+    # (Two CONTEXTS on two host threads do the same when the runtime places them well, and run one after the other -- or far worse --
+    # when it does not: tools/query_concurrency_probe.py, profiles/r05_query/two_batches_in_flight.txt; not part of this line.)
+    piped = None
     try:
-        import threading
-        ctx2 = P.Context(beside=ctx)
-        qb2 = P.Batch.from_seqs(qs, ctx=ctx2)
+        qb_b = P.Batch.from_seqs(qs, ctx=ctx)
+        pipe = P.Pipe(spec, ctx=ctx)
         ref_counts = (int(len(r["t_sid"])), int(len(r["c_score"])), n_hps)
-        lanes = ((ctx, qb), (ctx2, qb2))
+        k_batches = 32
 
-        def one(lane, keep=None):
-            res = P._ffi.HpsResult()
-            L = P._ffi.lib()
-            import ctypes as C
-            rc = L.pgr_query_hps_resident(lane[0].handle, ix._h, lane[1]._h, C.c_float(0.025), 128, 128, 128, 8, 0, 0, 0, C.byref(res))
-            got = (int(res.n_targets), int(res.n_chains), int(res.n_hps)) if rc == 0 else None
-            cs_ = None
-            if rc == 0 and keep is not None:  # content: the hit pairs' bytes
-                cs_ = bytes(np.ctypeslib.as_array(C.cast(res.hps, C.POINTER(C.c_uint8)), shape=(int(res.n_hps) * 24,)))
-            if rc == 0:
-                L.pgr_hps_result_free(C.byref(res))
-            return got, cs_
-        for lane in lanes:
-            for _ in range(3):
-                one(lane)
-        ref_bytes = r["hps"].tobytes()
-        reps_t = 24
-        results = [[], []]
-        start = threading.Barrier(3)
-
-        def work(i):
-            start.wait()
-            for k in range(reps_t):
-                results[i].append(one(lanes[i], keep=True if k == reps_t - 1 else None))
-        th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
-        for x in th:
-            x.start()
-        start.wait()
+        def run_pipe(k, raw_last):
+            outs = []
+            for i in range(k):
+                if pipe.in_flight == 2:
+                    outs.append(pipe.collect_query(raw=False))
+                pipe.submit_query(qb if i & 1 == 0 else qb_b, ix, 0.025)
+            last = None
+            while pipe.in_flight:
+                if raw_last and pipe.in_flight == 1:
+                    last = pipe.collect_query(raw=True)
+                else:
+                    outs.append(pipe.collect_query(raw=False))
+            return outs, last
+        run_pipe(4, False)
+        ctx.synchronize()
         t0 = time.perf_counter()
-        for x in th:
-            x.join()
-        dt2 = time.perf_counter() - t0
-        same_counts = all(g == ref_counts for rr in results for g, _ in rr)
-        same_bytes = all(rr[-1][1] == ref_bytes for rr in results)
-        two = {"batches": 2 * reps_t, "ms_per_batch": dt2 / (2 * reps_t) * 1e3, "queries_per_s": nq * 2 * reps_t / dt2,
-               "every_batch_same_counts": bool(same_counts), "last_batches_same_hit_pair_bytes": bool(same_bytes),
-               "what": "two contexts (pgr_ctx_create_beside), one host thread each, %d resident batches per thread against the one index; "
-                       "wall time of all batches / their number" % reps_t}
-        del qb2, ctx2
+        outs, _ = run_pipe(k_batches, False)
+        ctx.synchronize()
+        dtp = time.perf_counter() - t0
+        _, last = run_pipe(3, True)
+        same_last = all(np.array_equal(last[k], r[k]) for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps"))
+        pipe.close()
+        piped = {"batches": k_batches, "ms_per_batch": dtp / k_batches * 1e3, "queries_per_s": nq * k_batches / dtp,
+                 "every_batch_same_counts": bool(all(o == ref_counts for o in outs)), "a_batch_same_content": bool(same_last),
+                 "what": "pgr_pipe_submit_query / pgr_pipe_collect_query on one context, two batches in flight, %d batches of the same "
+                         "%d resident queries; the clock stops when the last batch's chains are in host memory and released" % (k_batches, nq)}
+        del qb_b
     except Exception as ex:  # noqa: BLE001
-        two = {"error": repr(ex)}
+        piped = {"error": repr(ex)}
     algo = 24.0 * n_hps + 0.25 * prof["query_bases"] + 17.0 * prof["n_signatures"]
     qk = committed(QUERY_PROFILE, "summary.json") or {}
     qpmc = (committed(QUERY_PROFILE, "pmc_summary.json") or {}).get("per_query_batch", {})
@@ -298,7 +287,7 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
         "inputs": "queries resident in HBM as 2-bit planes when the clock starts (pgr_query_hps_resident); the clock stops "
                   "when the chains are in host memory and the result has been released again (C entry point, no numpy copies)",
         "python_binding_s": t_py,
-        "two_batches_in_flight": two,
+        "pipelined": piped,
         "pcie_inclusive": {"query_s": t_host, "query_s_reps": reps_host, "queries_per_s": nq / t_host,
                            "hit_pairs_per_s": n_hps / t_host, "same_result_as_resident": bool(same),
                            "ascii_upload_bytes": int(prof["query_bases"]),

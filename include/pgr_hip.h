@@ -370,6 +370,17 @@ int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const pgr_batch *q
                            uint32_t max_aln_span, int has_max_gap, uint32_t max_gap, int oriented,
                            pgr_hps_result *out);
 void pgr_hps_result_free(pgr_hps_result *r);
+/* Query batches through a pgr_pipe (two in flight): the reference loops over its queries with rayon
+ * (pgr-bin/src/bin/pgr-query.rs:135-165); here the tiles of batch i + 1 run on the context's stream beside everything that is
+ * behind the tiles of batch i -- list stage, pair records, the per-query kernel, packing, the chains' way back over PCIe -- on the
+ * pipe's back stream.  submit enqueues and returns; collect hands back the oldest query job's result, which is the result of
+ * pgr_query_hps_resident on that batch (a batch the chained path cannot take -- flagged tiles, long queries, a repeat key -- is
+ * answered by that call at collect).  The pipe's spec must be the index's; `queries` and `ix` stay alive until the job is
+ * collected; jobs of pgr_pipe_submit and query jobs may be mixed, each kind collected with its own call, oldest first. */
+int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *queries, const pgr_index *ix, float penalty, uint32_t max_count,
+                          uint32_t max_count_query, uint32_t max_count_target, uint32_t max_aln_span, int has_max_gap,
+                          uint32_t max_gap, int oriented);
+int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out);
 
 /* counts and host-side stage times of the LAST pgr_query_hps_batch / _resident on the context (what bench.py prices the
  * query leg with: 24 B per hit pair emitted + 0.25 B per query base + 17 B per looked-up signature) */

@@ -123,6 +123,10 @@ struct QueryFusedRun {
     AlnParams ap;
     uint32_t P = 0, H = 0;
     bool enqueued = false, no_pinned = false, finish_called = false;
+    // a run of a pipelined query job (pgr_pipe_submit_query): its kernels and its download go to the pipe's back stream, its
+    // totals to the slot's own pinned words (NULL: the context's stream / the context's mailbox)
+    hipStream_t stream = nullptr;
+    uint64_t *mail = nullptr;
     QueryFusedRun(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries, uint64_t max_pairs, const QParams &qp, const AlnParams &ap);
     ~QueryFusedRun();
     QueryFusedRun(const QueryFusedRun &) = delete;

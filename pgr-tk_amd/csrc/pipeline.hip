@@ -18,6 +18,7 @@
 
 #include "pgr_ctx.h"
 #include "pgr_index.h"
+#include "pgr_aln.h"
 #include "pgr_small.h"
 #include "island_list.h"
 
@@ -1695,6 +1696,16 @@ struct pgr_pipe {
         uint64_t dst_cap = 0;            // capacity of the buffer the last pass wrote the records to
         uint64_t *pmail = nullptr;       // pinned: [0] = pair records the job's last pass counted, [1] = cursor value it found (direct),
                                          // [2] = the cursor's start value (source of an H2D copy)
+        // a QUERY job (pgr_pipe_submit_query): behind the queries' shimmer pass, on the back stream, pair records + the per-query
+        // kernel + packing + the download of the chains (csrc/query_fused.hip); whatever that path cannot take -- a flagged query
+        // batch, long queries, a repeat key -- is answered at collect by the synchronous call (q_fallback)
+        bool is_query = false, q_fallback = false;
+        std::unique_ptr<QueryFusedRun> qrun;
+        const pgr_index *qix = nullptr;
+        const pgr_batch *qb = nullptr;
+        QParams qqp = {};
+        AlnParams qap = {};
+        uint64_t *qmail = nullptr;       // pinned: the totals of the slot's query run
         bool has_sids = false;
         bool direct = false;             // records straight into the index's append buffer, placed by the device cursor
         bool placed_by_host = false;     // a synchronous pass wrote the records at the index's host-known count
@@ -1848,6 +1859,7 @@ extern "C" int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     pgr_pipe::Slot &s = p->slot[p->next];
     const uint32_t n = b->n;
+    s.is_query = s.q_fallback = false;
     s.ix = ix;
     s.d_recs = d_recs;
     s.recs_cap = d_recs ? recs_capacity : 0;
@@ -1951,6 +1963,7 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
     if (n_pairs) *n_pairs = 0;
     if (p->order.empty()) return ctx->fail(PGR_ERR_STATE, "no job in flight");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
+    if (p->slot[p->order.front()].is_query) return ctx->fail(PGR_ERR_STATE, "the oldest job is a query job: pgr_pipe_collect_query");
     pgr_pipe::Slot &s = p->slot[p->order.front()];
     p->order.pop_front();
     std::unique_ptr<ShmmrJob> job = std::move(s.job);
@@ -2054,6 +2067,160 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
     return PGR_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Query batches through the pipe.  One batch of queries is a chain: a VALU-bound tile kernel, a dozen latency-bound kernels, the
+// per-query kernel, and 7.5 MB of chains across PCIe (10 000 x 10 kbp: 0.69 ms, of which the tiles are 0.28 and the download
+// 0.14).  With two batches in flight the tiles of batch i + 1 (the context's stream) run beside everything behind the tiles of
+// batch i (the back stream) -- the reference loops over its queries with rayon (pgr-bin/src/bin/pgr-query.rs:135-165).  The
+// answer of every batch is the synchronous call's: what the chained path cannot take (a flagged shimmer pass, long queries, a
+// repeat key, a slot too small) is answered by that very call at collect.
+extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_index *ix, float penalty, uint32_t max_count,
+                                     uint32_t max_count_query, uint32_t max_count_target, uint32_t max_aln_span, int has_max_gap,
+                                     uint32_t max_gap, int oriented) {
+    if (!p) return PGR_ERR_INVALID_ARG;
+    pgr_ctx *ctx = p->ctx;
+    if (!b || !ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
+    if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
+    if (memcmp(&ix->spec, &p->spec, sizeof(pgr_spec)) != 0) return ctx->fail(PGR_ERR_INVALID_ARG, "the index has another spec than the pipe");
+    if (max_aln_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be at least 1");
+    if (p->order.size() >= 2) return ctx->fail(PGR_ERR_STATE, "two jobs are in flight: collect one first");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    pgr_pipe::Slot &s = p->slot[p->next];
+    const uint32_t n = b->n;
+    s.is_query = true;
+    s.q_fallback = false;
+    s.ix = nullptr;
+    s.d_recs = nullptr;
+    s.direct = s.placed_by_host = s.has_sids = false;
+    s.qix = ix;
+    s.qb = b;
+    s.qqp = QParams{max_count, max_count_query, max_count_target};
+    s.qap = AlnParams{max_aln_span, penalty, has_max_gap, max_gap, oriented};
+    s.qrun.reset();
+    s.job.reset();
+    // the same test as pgr_query_hps_resident's: the chained path takes batches of short queries on an index that has seen one
+    uint32_t pairs_hint = ix->fused_pairs.load(std::memory_order_relaxed);
+    if (!pairs_hint && n) {
+        uint32_t max_len = 0;
+        for (uint32_t c = 0; c < n; ++c) max_len = std::max(max_len, b->h_len[c]);
+        const pgr_spec &sp = ix->spec;
+        const double keep = sp.r > 1 ? 2.0 / (double)(sp.r + 1) : 1.0;
+        const double dens = sp.sketch ? 1.0 / (double)(1ull << (4 + sp.r)) : 2.0 / (double)(sp.w + 1) * keep * keep;
+        pairs_hint = (uint32_t)std::min<double>((double)max_len * dens * 1.6 + 4.0, 1e9);
+    }
+    const bool chained = n && ix->n && ix->fused_skip.load(std::memory_order_relaxed) == 0 && pairs_hint &&
+                         query_fused_eligible(ctx, n, pairs_hint, max_aln_span) && !ctx->opt.no_query_chaining;
+    if (!chained) {
+        s.q_fallback = true;
+        p->order.push_back(p->next);
+        p->next ^= 1;
+        return PGR_OK;
+    }
+    if (!s.qmail) {
+        if (hipHostMalloc((void **)&s.qmail, 256, hipHostMallocDefault) != hipSuccess) {
+            s.qmail = nullptr;
+            return ctx->fail(PGR_ERR_NOMEM, "hipHostMalloc of the query mailbox failed");
+        }
+    }
+    memset(s.qmail, 0, 256);
+    LaneScope scope(ctx, *s.lane_p, ctx->back_stream);
+    s.qrun.reset(new QueryFusedRun(ctx, ix, n, pairs_hint, s.qqp, s.qap));
+    s.qrun->stream = ctx->back_stream;
+    s.qrun->mail = s.qmail;
+    s.job.reset(new ShmmrJob());
+    ShmmrJob &job = *s.job;
+    job.ctx = ctx;
+    job.b = b;
+    job.spec = p->spec;
+    job.rids = nullptr;
+    job.padding = 0;
+    job.sf = ctx->stream;
+    job.sb = ctx->back_stream;
+    job.ev_front = s.ev_front;
+    job.optimistic = true;
+    job.dbg_t = ctx->opt.debug_times != 0;
+    job.dbg_t0 = std::chrono::steady_clock::now();
+    QueryFusedRun *run = s.qrun.get();
+    job.post = [run](hipStream_t, const pgr_mm128 *d_list, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count) -> int {
+        return run->enqueue_from_shimmers(d_list, d_off, cap, d_count);
+    };
+    int rc;
+    hipError_t e = hipSuccess;
+    if (!(rc = job.plan()) && !(rc = job.begin_result())) {
+        job.stage1_only = false;  // (the per-query kernel rides behind the list stage: always the whole pass)
+        e = hipEventRecord(ctx->ev[0], job.sf);
+        if (e == hipSuccess) rc = job.enqueue_pass();
+        if (e == hipSuccess && !rc) e = hipEventRecord(s.ev_done, job.sb);
+    }
+    if (rc || e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->back_stream);
+        s.qrun.reset();
+        s.job.reset();
+        s.is_query = false;
+        return rc ? rc : ctx->fail(PGR_ERR_DEVICE, std::string("pipe submit (query): ") + hipGetErrorString(e));
+    }
+    p->order.push_back(p->next);
+    p->next ^= 1;
+    return PGR_OK;
+}
+
+extern "C" int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out) {
+    if (!p) return PGR_ERR_INVALID_ARG;
+    pgr_ctx *ctx = p->ctx;
+    if (!out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
+    memset(out, 0, sizeof(*out));
+    if (p->order.empty()) return ctx->fail(PGR_ERR_STATE, "no job in flight");
+    if (!p->slot[p->order.front()].is_query) return ctx->fail(PGR_ERR_STATE, "the oldest job is not a query job: pgr_pipe_collect");
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    pgr_pipe::Slot &s = p->slot[p->order.front()];
+    p->order.pop_front();
+    s.is_query = false;
+    std::unique_ptr<ShmmrJob> job = std::move(s.job);
+    std::unique_ptr<QueryFusedRun> run = std::move(s.qrun);
+    bool fallback = s.q_fallback;
+    int rc = PGR_OK;
+    if (!fallback) {
+        LaneScope scope(ctx, *s.lane_p, nullptr);
+        if (hipEventSynchronize(s.ev_done) != hipSuccess || hipGetLastError() != hipSuccess)
+            rc = ctx->fail(PGR_ERR_DEVICE, "pipelined query pass failed on the device");
+        // a shimmer pass that needs anything more (flagged tiles, an undersized estimate): the synchronous call takes the batch
+        bool done = false;
+        if (!rc && (job->mbox[1] || job->mbox[2])) fallback = true;
+        if (!rc && !fallback) {
+            job->sf = job->sb = ctx->back_stream;
+            job->optimistic = false;
+            rc = job->decide(done);
+            if (!rc && !done) fallback = true;
+        }
+        if (!rc && !fallback) {
+            pgr_shmmrs *res = nullptr;
+            if (!(rc = job->finish(&res))) {
+                uint64_t max_pairs = 0;
+                for (uint32_t c = 0; c < res->n; ++c) max_pairs = std::max(max_pairs, res->h_off[c + 1] - res->h_off[c]);
+                s.qix->fused_pairs.store((uint32_t)std::min<uint64_t>(std::max<uint64_t>(max_pairs, 1), 1u << 30), std::memory_order_relaxed);
+                pgr_shmmrs_destroy(res);
+                QueryFusedCounts fc;
+                bool declined = false;
+                if (run->enqueued) rc = run->finish(out, &fc, &declined);
+                else declined = true;
+                if (!rc && declined) {
+                    memset(out, 0, sizeof(*out));
+                    fallback = true;
+                }
+            }
+        }
+        run.reset();  // (waits for its stream when its download may still be pending)
+        job.reset();
+    }
+    if (rc) return rc;
+    if (fallback)
+        return pgr_query_hps_resident(ctx, s.qix, s.qb, s.qap.penalty, s.qqp.max_count, s.qqp.max_count_query, s.qqp.max_count_target,
+                                      s.qap.max_span, s.qap.has_max_gap, s.qap.max_gap, s.qap.oriented, out);
+    return PGR_OK;
+}
+
 extern "C" void pgr_pipe_destroy(pgr_pipe *p) {
     if (!p) return;
     pgr_ctx *ctx = p->ctx;
@@ -2066,7 +2233,9 @@ extern "C" void pgr_pipe_destroy(pgr_pipe *p) {
         s.lane_p = nullptr;
         if (s.ev_front) (void)hipEventDestroy(s.ev_front);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
+        s.qrun.reset();
         if (s.pmail) (void)hipHostFree(s.pmail);
+        if (s.qmail) (void)hipHostFree(s.qmail);
         if (s.sids) (void)hipHostFree(s.sids);
     }
     if (p->d_cursor) (void)hipFree(p->d_cursor);

@@ -952,7 +952,7 @@ QueryFusedRun::QueryFusedRun(pgr_ctx *c, const pgr_index *i, uint32_t nq, uint64
 
 QueryFusedRun::~QueryFusedRun() {
     // an error between enqueue and finish: the DMA engine may still be writing the pinned block -- wait before it goes back to the pool
-    if (enqueued && !finish_called && block) (void)hipStreamSynchronize(ctx->stream);
+    if (enqueued && !finish_called && block) (void)hipStreamSynchronize(stream ? stream : ctx->stream);
     for (void *p : {d_cnt, d_offs, d_shp, d_sf, d_img, d_qrec, d_rec_off, d_desc}) ctx->dfree(p);
     if (block) result_block_release(block);
 }
@@ -977,17 +977,17 @@ int QueryFusedRun::enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *
         (rc = grow(ctx, d_rec_off, rec_off_bytes, (nq + 1) * 8)) || (rc = grow(ctx, d_cnt, cnt_bytes, nq * 24 + 16)))
         return rc;
     uint32_t *flags = (uint32_t *)d_cnt + 2 * nq + 4 * nq;  // (behind q_nsig | q_nt | q_nc | q_nh | q_nhit, as in enqueue)
-    launch_frag_recs_dev(ctx->stream, d_mm, d_off, n_queries, cap, d_count, 1, (uint64_t *)d_rec_off, (pgr_frag_rec *)d_qrec, cap, flags);
+    launch_frag_recs_dev(stream ? stream : ctx->stream, d_mm, d_off, n_queries, cap, d_count, 1, (uint64_t *)d_rec_off, (pgr_frag_rec *)d_qrec, cap, flags);
     return enqueue((const pgr_frag_rec *)d_qrec, (const uint64_t *)d_rec_off, true);
 }
 
 // the per-query kernel, the offsets, the packing and the first download, all stream ordered; finish() after a synchronization
 int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, bool flags_cleared) {
-    hipStream_t st = ctx->stream;
+    hipStream_t st = stream ? stream : ctx->stream;
     int rc;
     const size_t nq = n_queries, slots = nq * H;
-    if ((rc = ctx->ensure_qmail())) return rc;
-    uint64_t *mb = (uint64_t *)ctx->qmail;  // pinned: the kernels write the totals here
+    if (!mail && (rc = ctx->ensure_qmail())) return rc;
+    uint64_t *mb = mail ? mail : (uint64_t *)ctx->qmail;  // pinned: the kernels write the totals here
     const QfLayout lmax = qf_layout(nq, slots / 2, slots, slots);
     // EXPERIMENT (context option direct_query_result, off by default: measured SLOWER).  Single pass (query_fused_kernel<true>)
     // when an earlier batch on this index has shown how many targets, chains and hit pairs a query has: the sections of the
@@ -1100,9 +1100,9 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
         *declined = true;
         return PGR_OK;
     }
-    hipStream_t st = ctx->stream;
+    hipStream_t st = stream ? stream : ctx->stream;
     const size_t nq = n_queries;
-    uint64_t *mb = (uint64_t *)ctx->qmail;
+    uint64_t *mb = mail ? mail : (uint64_t *)ctx->qmail;
     bool grew = false;
     for (;;) {
         hipError_t e = hipGetLastError();

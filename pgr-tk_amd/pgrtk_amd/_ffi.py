@@ -154,6 +154,9 @@ _SIGS = [
     ("pgr_query_hps_resident", C.c_int, [_VP, _VP, _VP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
                                          C.c_uint32, C.c_int, C.POINTER(HpsResult)]),
     ("pgr_hps_result_free", None, [C.POINTER(HpsResult)]),
+    ("pgr_pipe_submit_query", C.c_int, [_VP, _VP, _VP, C.c_float, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int,
+                                        C.c_uint32, C.c_int]),
+    ("pgr_pipe_collect_query", C.c_int, [_VP, C.POINTER(HpsResult)]),
     ("pgr_ctx_last_query_prof", C.c_int, [_VP, C.POINTER(QueryProf)]),
     ("pgr_shmmrs_checksum", C.c_int, [_VP, _VP, _VP]),
     ("pgr_sparse_aln_batch", C.c_int, [_VP, C.c_uint32, _VP, C.POINTER(C.c_uint64), C.c_uint32, C.c_float, C.c_int,

@@ -262,6 +262,29 @@ class Pipe:
         self.ctx.check(rc)
         return (Shmmrs(self.ctx, h, n) if want_shmmrs else None), int(npairs.value)
 
+    def submit_query(self, batch, index, penalty, max_count=128, max_count_query=128, max_count_target=128, max_aln_span=8,
+                     max_gap=None, oriented=False):
+        """pgr_pipe_submit_query: a batch of queries (resident) against a finalized index; collect_query() hands back the oldest"""
+        self.ctx.check(lib().pgr_pipe_submit_query(self._h, batch._h, index._h, float(penalty), max_count, max_count_query,
+                                                   max_count_target, max_aln_span, int(max_gap is not None), int(max_gap or 0),
+                                                   int(bool(oriented))))
+        self._keep.append((batch, index))
+
+    def collect_query(self, raw=True):
+        """-> the result of pgr_query_hps_resident on the oldest query job (numpy views of the result block; raw=False: only
+        (n_targets, n_chains, n_hps), the block is released at once -- what a compiled host pays)"""
+        res = _ffi.HpsResult()
+        batch, index = self._keep[0] if self._keep else (None, None)
+        rc = lib().pgr_pipe_collect_query(self._h, C.byref(res))
+        if self._keep:
+            self._keep.pop(0)
+        self.ctx.check(rc)
+        if not raw:
+            out = (int(res.n_targets), int(res.n_chains), int(res.n_hps))
+            lib().pgr_hps_result_free(C.byref(res))
+            return out
+        return index._unpack_raw(res, batch.n)
+
     def close(self):
         if self._h:
             lib().pgr_pipe_destroy(self._h)

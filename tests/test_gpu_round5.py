@@ -478,3 +478,88 @@ def test_pgr_mdb_on_a_genome_like_fasta_equals_the_oracles_frag_map(oracle, gpu_
         exp.setdefault((int(rr["h0"]), int(rr["h1"])), []).append((int(rr["frg_id"]), int(rr["sid"]), int(rr["bgn"]), int(rr["end"]), int(rr["orient"])))
     assert m == exp and sum(len(v) for v in m.values()) > 10_000
     assert [l.split("\t")[:3] for l in open(p_cpp + ".midx").read().splitlines()] == [[str(i), str(len(q)), "ctg%d" % i] for i, q in enumerate(seqs)]
+
+
+def test_query_batches_through_the_pipe_equal_the_synchronous_calls(oracle, gpu_ctx):
+    """pgr_pipe_submit_query / pgr_pipe_collect_query: two query batches in flight (the tiles of batch i + 1 beside the list stage,
+    the per-query kernel, the packing and the download of batch i).  Every collected result is byte for byte the result of
+    pgr_query_hps_resident on that batch -- batches of short clean queries (the chained path), a batch with N in its queries and one
+    with palindromic arrays (flagged shimmer pass: answered by the synchronous call at collect), a batch of long queries (not
+    eligible), an empty-ish batch; mixed with a shimmer job of pgr_pipe_submit in between; a sample against the oracle."""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(123)
+    spec = P.make_spec(*SPEC)
+    targets = [seqgen.rnd(rng, 400_000) for _ in range(5)]
+    ix = P.Index(spec, ctx=gpu_ctx)
+    tb = P.Batch.from_seqs(targets, ctx=gpu_ctx)
+    ix.add_resident(tb)
+    ix.finalize()
+
+    def cut(n, lo, hi):
+        out = []
+        for _ in range(n):
+            t = int(rng.integers(0, len(targets)))
+            ln = int(rng.integers(lo, hi))
+            o = int(rng.integers(0, len(targets[t]) - ln))
+            q = targets[t][o:o + ln]
+            out.append(seqgen.rc(q) if rng.random() < 0.5 else q)
+        return out
+    sets = [cut(300, 3_000, 10_000), cut(500, 1_000, 9_000), cut(64, 8_000, 10_000)]
+    with_n = cut(200, 4_000, 9_000)
+    with_n[7] = with_n[7][:2000] + b"N" * 30 + with_n[7][2030:]
+    sets.append(with_n)
+    with_pal = cut(200, 4_000, 9_000)
+    with_pal[11] = with_pal[11][:1500] + b"AT" * 80 + with_pal[11][1660:]
+    sets.append(with_pal)
+    sets.append(cut(6, 150_000, 300_000))  # long queries: the stage-by-stage path
+    sets.append([b"ACGT" * 10, seqgen.rnd(rng, 90)])  # nothing to find
+    sets.append(cut(400, 2_000, 10_000))
+    batches = [P.Batch.from_seqs(s, ctx=gpu_ctx) for s in sets]
+    keys = ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps")
+    ref = []
+    for b in batches:
+        r = ix.query_hps_resident_raw(b, 0.025)
+        ref.append({f: np.array(r[f]).tobytes() for f in keys})
+    oix = oracle.Index(oracle.spec(*SPEC))
+    for i, t in enumerate(targets):
+        oix.add_seq(i, t)
+    oix.finalize()
+    r0 = ix.query_hps_resident_raw(batches[0], 0.025)
+    for qi in range(0, 300, 41):
+        o = oix.query_fragment_to_hps(sets[0][qi], 0.025)
+        t0, t1 = int(r0["q_off"][qi]), int(r0["q_off"][qi + 1])
+        assert [sid for sid, _ in o] == [int(x) for x in r0["t_sid"][t0:t1]], qi
+    for rep in range(2):  # (the second time the index's hints are those of the last batch of the first)
+        pipe = P.Pipe(spec, ctx=gpu_ctx)
+        got = []
+        order = []
+        for bi, b in enumerate(batches):
+            if pipe.in_flight == 2:
+                kind = order.pop(0)
+                if kind == "q":
+                    r = pipe.collect_query()
+                    got.append({f: np.array(r[f]).tobytes() for f in keys})
+                else:
+                    sh, _ = pipe.collect()
+                    assert sh.count > 0
+            pipe.submit_query(b, ix, 0.025)
+            order.append("q")
+            if bi == 3:  # a shimmer job between the query jobs
+                if pipe.in_flight == 2:
+                    kind = order.pop(0)
+                    r = pipe.collect_query()
+                    got.append({f: np.array(r[f]).tobytes() for f in keys})
+                pipe.submit(tb)
+                order.append("s")
+        while pipe.in_flight:
+            kind = order.pop(0)
+            if kind == "q":
+                r = pipe.collect_query()
+                got.append({f: np.array(r[f]).tobytes() for f in keys})
+            else:
+                sh, _ = pipe.collect()
+                assert sh.count > 0
+        pipe.close()
+        assert len(got) == len(batches)
+        for bi in range(len(batches)):
+            assert got[bi] == ref[bi], (rep, bi)
