@@ -127,6 +127,10 @@ struct QueryFusedRun {
     // totals to the slot's own pinned words (NULL: the context's stream / the context's mailbox)
     hipStream_t stream = nullptr;
     uint64_t *mail = nullptr;
+    // ... and the download of its chains to a third stream (behind an event), so that the back stream is free for the next job's
+    // list stage while 7.5 MB cross PCIe; ev_copied is what the collector waits for
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_packed = nullptr, ev_copied = nullptr;
     QueryFusedRun(pgr_ctx *ctx, const pgr_index *ix, uint32_t n_queries, uint64_t max_pairs, const QParams &qp, const AlnParams &ap);
     ~QueryFusedRun();
     QueryFusedRun(const QueryFusedRun &) = delete;

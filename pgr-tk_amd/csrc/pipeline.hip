@@ -1706,6 +1706,7 @@ struct pgr_pipe {
         QParams qqp = {};
         AlnParams qap = {};
         uint64_t *qmail = nullptr;       // pinned: the totals of the slot's query run
+        hipEvent_t q_ev_packed = nullptr, q_ev_copied = nullptr;  // its download runs on the fix stream behind the packing
         bool has_sids = false;
         bool direct = false;             // records straight into the index's append buffer, placed by the device cursor
         bool placed_by_host = false;     // a synchronous pass wrote the records at the index's host-known count
@@ -2084,6 +2085,9 @@ extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
     if (memcmp(&ix->spec, &p->spec, sizeof(pgr_spec)) != 0) return ctx->fail(PGR_ERR_INVALID_ARG, "the index has another spec than the pipe");
     if (max_aln_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be at least 1");
+    // (two in flight, as for shimmer jobs.  Three were tried -- with two, the tiles of batch i + 2 are enqueued only when batch i's
+    // chains are home, so the cycle is the chain behind a batch's tiles, ~0.42 ms, not the tiles' 0.3 -- and measured SLOWER: 0.54-0.62
+    // ms per batch against 0.45-0.47: three lanes' allocations and cross-stream waits cost more than the idle front stream)
     if (p->order.size() >= 2) return ctx->fail(PGR_ERR_STATE, "two jobs are in flight: collect one first");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     pgr_pipe::Slot &s = p->slot[p->next];
@@ -2128,6 +2132,15 @@ extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_
     s.qrun.reset(new QueryFusedRun(ctx, ix, n, pairs_hint, s.qqp, s.qap));
     s.qrun->stream = ctx->back_stream;
     s.qrun->mail = s.qmail;
+    if (ctx->fix_stream && !ctx->opt.no_fix_stream) {  // (a stream that runs beside both others: the chains go home while the back stream works on)
+        if (!s.q_ev_packed && hipEventCreateWithFlags(&s.q_ev_packed, hipEventDisableTiming) != hipSuccess) s.q_ev_packed = nullptr;
+        if (!s.q_ev_copied && hipEventCreateWithFlags(&s.q_ev_copied, hipEventDisableTiming) != hipSuccess) s.q_ev_copied = nullptr;
+        if (s.q_ev_packed && s.q_ev_copied) {
+            s.qrun->copy_stream = ctx->fix_stream;
+            s.qrun->ev_packed = s.q_ev_packed;
+            s.qrun->ev_copied = s.q_ev_copied;
+        }
+    }
     s.job.reset(new ShmmrJob());
     ShmmrJob &job = *s.job;
     job.ctx = ctx;
@@ -2163,6 +2176,9 @@ extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_
     }
     p->order.push_back(p->next);
     p->next ^= 1;
+    if (ctx->opt.debug_times)
+        fprintf(stderr, "[pgr] pipe submit_query took %.1f us\n",
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - s.job->dbg_t0).count());
     return PGR_OK;
 }
 
@@ -2181,10 +2197,20 @@ extern "C" int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out) {
     std::unique_ptr<QueryFusedRun> run = std::move(s.qrun);
     bool fallback = s.q_fallback;
     int rc = PGR_OK;
+    const auto tq0 = std::chrono::steady_clock::now();
+    auto qlap = [&](const char *what) {
+        if (ctx->opt.debug_times)
+            fprintf(stderr, "[pgr] pipe collect_query %-28s at %7.1f us\n", what,
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
+    };
     if (!fallback) {
         LaneScope scope(ctx, *s.lane_p, nullptr);
         if (hipEventSynchronize(s.ev_done) != hipSuccess || hipGetLastError() != hipSuccess)
             rc = ctx->fail(PGR_ERR_DEVICE, "pipelined query pass failed on the device");
+        qlap("back stream done");
+        if (!rc && run && run->enqueued && run->copy_stream && hipEventSynchronize(run->ev_copied) != hipSuccess)
+            rc = ctx->fail(PGR_ERR_DEVICE, "download of the chains failed");
+        qlap("chains home");
         // a shimmer pass that needs anything more (flagged tiles, an undersized estimate): the synchronous call takes the batch
         bool done = false;
         if (!rc && (job->mbox[1] || job->mbox[2])) fallback = true;
@@ -2211,8 +2237,10 @@ extern "C" int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out) {
                 }
             }
         }
+        qlap(fallback ? "for the synchronous call" : "result assembled");
         run.reset();  // (waits for its stream when its download may still be pending)
         job.reset();
+        qlap("run and job released");
     }
     if (rc) return rc;
     if (fallback)
@@ -2236,6 +2264,8 @@ extern "C" void pgr_pipe_destroy(pgr_pipe *p) {
         s.qrun.reset();
         if (s.pmail) (void)hipHostFree(s.pmail);
         if (s.qmail) (void)hipHostFree(s.qmail);
+        if (s.q_ev_packed) (void)hipEventDestroy(s.q_ev_packed);
+        if (s.q_ev_copied) (void)hipEventDestroy(s.q_ev_copied);
         if (s.sids) (void)hipHostFree(s.sids);
     }
     if (p->d_cursor) (void)hipFree(p->d_cursor);

@@ -952,7 +952,10 @@ QueryFusedRun::QueryFusedRun(pgr_ctx *c, const pgr_index *i, uint32_t nq, uint64
 
 QueryFusedRun::~QueryFusedRun() {
     // an error between enqueue and finish: the DMA engine may still be writing the pinned block -- wait before it goes back to the pool
-    if (enqueued && !finish_called && block) (void)hipStreamSynchronize(stream ? stream : ctx->stream);
+    if (enqueued && !finish_called && block) {
+        (void)hipStreamSynchronize(stream ? stream : ctx->stream);
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+    }
     for (void *p : {d_cnt, d_offs, d_shp, d_sf, d_img, d_qrec, d_rec_off, d_desc}) ctx->dfree(p);
     if (block) result_block_release(block);
 }
@@ -1083,7 +1086,14 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
         hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
                            n_queries, t0, c0, h0, (uint64_t *)d_img, mb);
         hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, (uint8_t *)d_img);
-        e = hipMemcpyAsync(block, d_img, first, hipMemcpyDeviceToHost, st);
+        if (copy_stream && ev_packed && ev_copied) {
+            e = hipEventRecord(ev_packed, st);
+            if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream, ev_packed, 0);
+            if (e == hipSuccess) e = hipMemcpyAsync(block, d_img, first, hipMemcpyDeviceToHost, copy_stream);
+            if (e == hipSuccess) e = hipEventRecord(ev_copied, copy_stream);
+        } else {
+            e = hipMemcpyAsync(block, d_img, first, hipMemcpyDeviceToHost, st);
+        }
     }
     if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
     qrec_used = qrec;
@@ -1134,7 +1144,8 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
                 *declined = true;
                 return PGR_OK;
             }
-            if (hipStreamSynchronize(st) != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, "query kernels failed on the device");
+            if (hipStreamSynchronize(st) != hipSuccess || (copy_stream && hipStreamSynchronize(copy_stream) != hipSuccess))
+                return ctx->fail(PGR_ERR_DEVICE, "query kernels failed on the device");
             continue;
         }
         break;

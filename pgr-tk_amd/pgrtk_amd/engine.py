@@ -256,8 +256,9 @@ class Pipe:
         h = C.c_void_p()
         npairs = C.c_uint64()
         n = self._keep[0][0].n if self._keep else 0
+        before = self.in_flight
         rc = lib().pgr_pipe_collect(self._h, C.byref(h) if want_shmmrs else None, C.byref(npairs))
-        if self._keep:
+        if self._keep and self.in_flight < before:  # (a refused call -- nothing in flight, a query job first -- takes nothing out)
             self._keep.pop(0)
         self.ctx.check(rc)
         return (Shmmrs(self.ctx, h, n) if want_shmmrs else None), int(npairs.value)
@@ -275,8 +276,9 @@ class Pipe:
         (n_targets, n_chains, n_hps), the block is released at once -- what a compiled host pays)"""
         res = _ffi.HpsResult()
         batch, index = self._keep[0] if self._keep else (None, None)
+        before = self.in_flight
         rc = lib().pgr_pipe_collect_query(self._h, C.byref(res))
-        if self._keep:
+        if self._keep and self.in_flight < before:
             self._keep.pop(0)
         self.ctx.check(rc)
         if not raw:

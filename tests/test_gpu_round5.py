@@ -529,6 +529,23 @@ def test_query_batches_through_the_pipe_equal_the_synchronous_calls(oracle, gpu_
         o = oix.query_fragment_to_hps(sets[0][qi], 0.025)
         t0, t1 = int(r0["q_off"][qi]), int(r0["q_off"][qi + 1])
         assert [sid for sid, _ in o] == [int(x) for x in r0["t_sid"][t0:t1]], qi
+    # a third job is refused, and so is the wrong kind of collect; results in submission order
+    pipe = P.Pipe(spec, ctx=gpu_ctx)
+    got = []
+    for b in batches:
+        if pipe.in_flight == 2:
+            with pytest.raises(P.PgrError):
+                pipe.submit_query(batches[0], ix, 0.025)
+            with pytest.raises(P.PgrError):
+                pipe.collect()  # the oldest job is a query job
+            r = pipe.collect_query()
+            got.append({f: np.array(r[f]).tobytes() for f in keys})
+        pipe.submit_query(b, ix, 0.025)
+    while pipe.in_flight:
+        r = pipe.collect_query()
+        got.append({f: np.array(r[f]).tobytes() for f in keys})
+    pipe.close()
+    assert got == ref
     for rep in range(2):  # (the second time the index's hints are those of the last batch of the first)
         pipe = P.Pipe(spec, ctx=gpu_ctx)
         got = []
