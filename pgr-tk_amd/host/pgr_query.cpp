@@ -73,6 +73,7 @@ int main(int argc, char **argv) {
     float gap_penalty = 0.025f;
     uint32_t merge_tol = 100000, max_count = 128, max_q = 128, max_t = 128, max_span = 8;
     bool fastx_file = false, only_summary = false, bed_summary = false;
+    size_t query_batch = 8192;  // more queries than this go to the GPU in batches of this size, two in flight (pgr_pipe_submit_query)
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -93,6 +94,7 @@ int main(int argc, char **argv) {
         else if (a == "--max-query-count") max_q = (uint32_t)atoi(val());
         else if (a == "--max-target-count") max_t = (uint32_t)atoi(val());
         else if (a == "--max-aln-chain-span") max_span = (uint32_t)atoi(val());
+        else if (a == "--query-batch") query_batch = (size_t)std::max(1ll, atoll(val()));
         else if (a == "--fastx_file") fastx_file = true;
         else if (a == "--only-summary") only_summary = true;
         else if (a == "--bed-summary") bed_summary = true;
@@ -150,16 +152,14 @@ int main(int argc, char **argv) {
         qp.push_back((const uint8_t *)q.seq.data());
         ql.push_back(q.seq.size());
     }
-    pgr_hps_result res;
-    if ((rc = pgr_query_hps_batch(ctx, ix, (uint32_t)queries.size(), qp.data(), ql.data(), gap_penalty, max_count, max_q,
-                                  max_t, max_span, 0, 0, 0, &res)))
-        die(ctx, "pgr_query_hps_batch", rc);
-
-    for (size_t qi = 0; qi < queries.size(); ++qi) {
+    // chains of the queries [q_base, q_base + res.n_queries) -> their files (the reference's loop body, rs:167-409)
+    auto emit = [&](const pgr_hps_result &res, size_t q_base) -> int {
+    for (size_t ql_ = 0; ql_ < res.n_queries; ++ql_) {
+        const size_t qi = q_base + ql_;
         // chains -> regions per target (rs:167-285): only chains with more than 2 hit pairs; the forward / reverse
         // counters are NOT reset between the chains of a target (:171-183)
         std::map<uint32_t, std::vector<Region>> regions;
-        for (uint64_t t = res.q_off[qi]; t < res.q_off[qi + 1]; ++t) {
+        for (uint64_t t = res.q_off[ql_]; t < res.q_off[ql_ + 1]; ++t) {
             const uint32_t sid = res.t_sid[t];
             uint64_t f_count = 0, r_count = 0;
             std::vector<Region> rg;
@@ -261,7 +261,45 @@ int main(int argc, char **argv) {
             fclose(f);
         }
     }
-    pgr_hps_result_free(&res);
+    return 0;
+    };
+    if (queries.size() <= query_batch) {  // one batch, one call
+        pgr_hps_result res;
+        if ((rc = pgr_query_hps_batch(ctx, ix, (uint32_t)queries.size(), qp.data(), ql.data(), gap_penalty, max_count, max_q,
+                                      max_t, max_span, 0, 0, 0, &res)))
+            die(ctx, "pgr_query_hps_batch", rc);
+        if (emit(res, 0)) return 1;
+        pgr_hps_result_free(&res);
+    } else {
+        // batches of query_batch queries, two in flight (the reference loops over its queries with rayon, rs:135-138): batch i + 1
+        // is staged and its tiles run while batch i's chains are looked up, chained and sent home
+        pgr_spec ispec;
+        if ((rc = pgr_index_spec(ix, &ispec))) die(ctx, "pgr_index_spec", rc);
+        pgr_pipe *pipe = nullptr;
+        if ((rc = pgr_pipe_create(ctx, &ispec, &pipe))) die(ctx, "pgr_pipe_create", rc);
+        std::vector<std::pair<pgr_batch *, size_t>> flying;  // (resident batch, first query), oldest first
+        auto collect_one = [&]() -> int {
+            pgr_hps_result res;
+            if ((rc = pgr_pipe_collect_query(pipe, &res))) die(ctx, "pgr_pipe_collect_query", rc);
+            const int bad = emit(res, flying.front().second);
+            pgr_hps_result_free(&res);
+            pgr_batch_destroy(flying.front().first);
+            flying.erase(flying.begin());
+            return bad;
+        };
+        for (size_t q0 = 0; q0 < queries.size(); q0 += query_batch) {
+            const size_t nb = std::min(query_batch, queries.size() - q0);
+            pgr_batch *qb = nullptr;
+            if ((rc = pgr_batch_from_ascii(ctx, (uint32_t)nb, qp.data() + q0, ql.data() + q0, &qb))) die(ctx, "pgr_batch_from_ascii", rc);
+            if (flying.size() == 2 && collect_one()) return 1;
+            if ((rc = pgr_pipe_submit_query(pipe, qb, ix, gap_penalty, max_count, max_q, max_t, max_span, 0, 0, 0)))
+                die(ctx, "pgr_pipe_submit_query", rc);
+            flying.emplace_back(qb, q0);
+        }
+        while (!flying.empty())
+            if (collect_one()) return 1;
+        pgr_pipe_destroy(pipe);
+    }
     pgr_index_destroy(ix);
     pgr_ctx_destroy(ctx);
     return 0;

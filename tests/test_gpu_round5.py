@@ -580,3 +580,34 @@ def test_query_batches_through_the_pipe_equal_the_synchronous_calls(oracle, gpu_
         assert len(got) == len(batches)
         for bi in range(len(batches)):
             assert got[bi] == ref[bi], (rep, bi)
+
+
+def test_pgr_query_in_batches_through_the_pipe_writes_the_same_files(oracle, gpu_ctx, golden_dir, tmp_path):
+    """host/pgr_query.cpp --query-batch N: more than N queries go to the GPU in batches of N, two in flight
+    (pgr_batch_from_ascii + pgr_pipe_submit_query / pgr_pipe_collect_query); every .hit / .fa file is the one the single call writes."""
+    import subprocess
+    bindir = os.path.join(ROOT, "pgr-tk_amd", "bin")
+    fa = os.path.join(golden_dir, "test_seqs.fa")
+    recs = oracle.read_fasta(fa)
+    rng = np.random.default_rng(8)
+    qfa = tmp_path / "q.fa"
+    qs = []
+    for i in range(11):
+        src = recs[int(rng.integers(0, len(recs)))][1]
+        o = int(rng.integers(0, max(1, len(src) - 4000)))
+        q = src[o:o + int(rng.integers(1500, 4000))]
+        qs.append(seqgen.rc(q) if i % 3 == 1 else q)
+    qs[4] = seqgen.rnd(rng, 2500)  # no hits
+    qs[6] = qs[6][:700] + b"N" * 5 + qs[6][705:]  # a flagged batch: answered by the synchronous call at collect
+    qfa.write_text("".join(">q%d\n%s\n" % (i, q.decode()) for i, q in enumerate(qs)))
+    outs = {}
+    for tag, extra in (("one", []), ("b1", ["--query-batch", "1"]), ("b3", ["--query-batch", "3"]), ("b4", ["--query-batch", "4"])):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([os.path.join(bindir, "pgr-query"), fa, str(qfa), str(d / "o"), "--fastx_file"] + extra,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = {f: open(d / f).read() for f in sorted(os.listdir(d))}
+    assert len(outs["one"]) == 22 and any(len(v.splitlines()) > 1 for v in outs["one"].values())
+    for tag in ("b1", "b3", "b4"):
+        assert outs[tag] == outs["one"], tag
