@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--contigs", type=int, default=1000)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--debug", action="store_true")
+    ap.add_argument("--host", action="store_true", help="also: host ASCII in (pgr_batch_from_ascii per batch) through the pipe")
     a = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
@@ -72,6 +73,40 @@ def main():
             print("   calls above 1.5 ms: %s" % slow[:12])
         print("%d in flight: %.3f ms per batch (%d batches), %.1f M queries/s; same counts every batch: %s"
               % (depth, dt / a.batches * 1e3, a.batches, a.queries * a.batches / dt / 1e6, len(set(outs)) == 1), flush=True)
+    if a.host:
+        # host ASCII in: pgr_batch_from_ascii of batch i + 1 while batch i is in flight (what host/pgr_query.cpp does)
+        import ctypes as C
+        from pgrtk_amd import _ffi
+        arrs, ptrs, lens_c, n_s = _ffi.seq_ptrs(qs)
+        L = _ffi.lib()
+
+        def stage():
+            h = C.c_void_p()
+            ctx.check(L.pgr_batch_from_ascii(ctx.handle, n_s, ptrs, lens_c, C.byref(h)))
+            return P.Batch(ctx, h, n_s)
+
+        def run_host(k):
+            held = []
+            for i in range(k):
+                b_ = stage()
+                if pipe.in_flight == 2:
+                    pipe.collect_query(raw=False)
+                    held.pop(0)
+                pipe.submit_query(b_, ix, 0.025)
+                held.append(b_)
+            while pipe.in_flight:
+                pipe.collect_query(raw=False)
+                held.pop(0)
+        ts = [ix.time_query_host(qs, 0.025)[0] for _ in range(5)]
+        print("host ASCII, synchronous call (pgr_query_hps_batch): %.3f ms per batch" % (sorted(ts)[2] * 1e3))
+        run_host(3)
+        reps = []
+        for _ in range(3):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            run_host(12)
+            reps.append((time.perf_counter() - t0) / 12 * 1e3)
+        print("host ASCII through the pipe: %s ms per batch" % " ".join("%.3f" % t for t in reps), flush=True)
     pipe.close()
 
 
