@@ -107,9 +107,6 @@ const char *pgr_version(void);
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing
  *   no_early_islands          ... never start their first round before the tile kernel's flags are seen, for A/B timing
  *   early_islands_in_stream   ... start it behind the tile kernel on the context's stream, not beside it on a stream of its own, for A/B
- *   pal_positions             1: the tile kernel reports where in a tile its palindromic k-mers lie and an island around them ends
- *                             with its last flagged tile when 1408 regular positions follow the last one (an experiment, measured
- *                             slower: one island in thousands needs longer, and growing it costs a round)
  *   no_early_merge            ... drop that early round when the tile kernel's flags add islands (tiles with a palindromic k-mer) instead
  *                             of keeping it and running only the added islands behind it, for A/B
  *   island_chunk_min          > 0: shortest chunk of the exact machine in positions (default 1024; 4096 = the round-3 minimum), for A/B

@@ -83,8 +83,6 @@ struct pgr_ctx {
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t early_islands_in_stream = 0;  // ... behind the tile kernel on its stream, not beside it on a stream of their own (for A/B)
         int64_t no_early_islands = 0;    // the islands around non-ACGT bytes never start their first round behind the tile kernel, before its flags are seen (for A/B)
-        int64_t pal_positions = 0;       // EXPERIMENT, off (measured slower: DESIGN 3.2): the tile kernel reports where in a tile its palindromic k-mers lie, and an island
-                                         // whose last one has 1408 regular positions of its own tiles behind it does not take the clean tile behind it
         int64_t no_early_merge = 0;      // a tile that reports a palindromic k-mer drops the early round of the islands around non-ACGT bytes (the first form), instead of keeping it and adding the new islands (for A/B)
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B

@@ -833,7 +833,6 @@ struct ShmmrJob {
     unsigned long long *d_cursor = nullptr;
     uint32_t *d_cflags = nullptr;
     uint8_t *d_tflags = nullptr;
-    uint16_t *d_tpal = nullptr;  // per tile with a palindromic k-mer: where in its core (L1Args::tile_pal)
     size_t zero_bytes = 0;
     uint64_t *mbox = nullptr;  // pinned: [0, N_STATUS) status, then the n + 1 result offsets
     uint32_t *d_rids = nullptr;
@@ -852,7 +851,6 @@ struct ShmmrJob {
     std::vector<Island> pre_islands;
     std::vector<uint32_t> pre_gap_segs;
     bool pre_listed = false;
-    bool pal_prefetched = false;    // ... and the tiles' palindrome positions
     bool flags_prefetched = false;  // contig flags, tile flags and the contigs' non-ACGT counts came down with the status words
     std::unique_ptr<IslandRun> early_islands;  // round 0 of the pre-listed islands, enqueued behind the tile kernel (stage1)
     // ---- the list stage and the result
@@ -975,7 +973,7 @@ int ShmmrJob::plan() {
         (rc = ctx->ws_tile_lv.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(uint64_t))) ||
         // one block that a single memset clears per call: cursors | contig flags | tile flags  (+ the status words)
         (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
-                                             std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64 + 2 * (size_t)n_tiles + 16)) ||
+                                             std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
         (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_off_b.ensure(ctx, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t))) ||
         // pinned: the pass's status words + result offsets come back into it; behind them the tile table and the rids on their way up
@@ -984,7 +982,6 @@ int ShmmrJob::plan() {
     d_cursor = (unsigned long long *)ctx->ws_cursor.p;
     d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
     d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
-    d_tpal = (uint16_t *)(((uintptr_t)(d_tflags + n_tiles + 64) + 3) & ~(uintptr_t)3);  // (not cleared: read only where this pass set flag bit 0)
     zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
     mbox = (uint64_t *)ctx->mailbox;
     // (through the pinned mailbox, read by a KERNEL of this stream: a copy engine would take these few kB in the order of its
@@ -1007,7 +1004,7 @@ int ShmmrJob::plan() {
     a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
     a.desc = (TileDesc *)ctx->ws_tile_desc.p;
     a.tile_flags = d_tflags;
-    a.tile_pal = ctx->opt.pal_positions ? d_tpal : nullptr;  // (an experiment, off: DESIGN 3.2)
+    a.tile_pal = nullptr;  // (positions of the palindromic k-mers inside a tile: an experiment that was taken out again)
     a.tile_lv = nullptr;  // set once mark_invalid_tiles has filled it and run_islands has made it cumulative
     a.w = w_eff;
     a.k = spec.k;
@@ -1133,7 +1130,7 @@ int ShmmrJob::stage1() {
                 as.w = sketch ? 1u : spec.w;
                 as.tile_lv = (uint64_t *)ctx->ws_tile_lv.p;  // (made cumulative in front of the tile kernel, above)
                 // (the pinned image must not move while the round's kernels are pending: room for the flags' download as well)
-                if ((r = ctx->ensure_imail(2 * (std::max<size_t>(n, 1) * sizeof(uint32_t) + 16) + n_tiles + 64 + 2 * (size_t)n_tiles + 16))) return r;
+                if ((r = ctx->ensure_imail(2 * (std::max<size_t>(n, 1) * sizeof(uint32_t) + 16) + n_tiles + 64))) return r;
                 early_islands.reset(new IslandRun(ctx, st, b, as, pre_islands, tile_first(), tc, serial_base, pre_gap_segs));
                 // (beside the tile kernel when the device runs two streams side by side; the side stream has waited for everything
                 // in front of the tile kernel: the copy of the tile flags above)
@@ -1178,24 +1175,21 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         // contig flags and tile flags are neighbours in the cursor block: two copies into the pinned image (three pageable ones
         // were 67 us of a 60 Mbp call's 660)
         const size_t nc = std::max<size_t>(n, 1) * sizeof(uint32_t);
-        const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15, pal_off = (inv_off + nc + 15) & ~(size_t)15;
-        const bool want_pal = a.tile_pal && (need_word & 1ull) && !sketch;  // (where in their tiles the palindromic k-mers lie: 2 bytes per tile)
+        const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15;
         int r0;
-        if ((r0 = ctx->ensure_imail(pal_off + 2 * (size_t)n_tiles + 16))) return r0;
+        if ((r0 = ctx->ensure_imail(inv_off + nc))) return r0;
         uint8_t *img = (uint8_t *)ctx->imail;
         if (!flags_prefetched) {
             PGR_HIP(ctx, hipMemcpyAsync(img, d_cflags, flag_bytes, hipMemcpyDeviceToHost, st));
             if (n) PGR_HIP(ctx, hipMemcpyAsync(img + inv_off, b->d.n_invalid, (size_t)n * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            if (want_pal) PGR_HIP(ctx, hipMemcpyAsync(img + pal_off, d_tpal, 2 * (size_t)n_tiles, hipMemcpyDeviceToHost, st));
             PGR_HIP(ctx, hipStreamSynchronize(st));
         }
-        const bool have_pal = want_pal && (!flags_prefetched || pal_prefetched);
         flags_prefetched = false;
         dbg_lap("islands: tile flags on the host");
         std::vector<uint8_t> &tf = ctx->h_tf_scratch;  // (list_islands marks tiles in its copy; run_exact_islands reuses the image.  Kept: a fresh half megabyte faults in page by page)
         tf.assign(img + nc, img + nc + n_tiles);
         std::vector<uint32_t> flags((const uint32_t *)img, (const uint32_t *)img + n), n_invalid((const uint32_t *)(img + inv_off), (const uint32_t *)(img + inv_off) + n);
-        list_islands(flags.data(), n_invalid.data(), tf.data(), have_pal ? (const uint16_t *)(img + pal_off) : nullptr, islands, gap_segs);
+        list_islands(flags.data(), n_invalid.data(), tf.data(), nullptr, islands, gap_segs);
     }
     {
         std::vector<uint32_t> cs;
@@ -1403,17 +1397,12 @@ int ShmmrJob::enqueue_pass() {
             // belongs to the early round of the islands, which then needs no flags)
             flags_prefetched = false;
             const size_t nc = std::max<size_t>(n, 1) * sizeof(uint32_t);
-            const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15, pal_off = (inv_off + nc + 15) & ~(size_t)15;
-            pal_prefetched = false;
+            const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15;
             if (tiled && bases_tiled && !early_islands && inv_off + nc <= (256u << 10)) {
-                if ((rc = ctx->ensure_imail(pal_off + 2 * (size_t)n_tiles + 16))) return rc;
+                if ((rc = ctx->ensure_imail(inv_off + nc))) return rc;
                 uint8_t *img = (uint8_t *)ctx->imail;
                 launch_copy_words(sf, (uint32_t *)img, (const uint32_t *)d_cflags, (flag_bytes + 3) / 4);  // (64 bytes of slack behind the tile flags)
                 if (n) launch_copy_words(sf, (uint32_t *)(img + inv_off), (const uint32_t *)b->d.n_invalid, n);
-                if (a.tile_pal && !sketch) {
-                    launch_copy_words(sf, (uint32_t *)(img + pal_off), (const uint32_t *)d_tpal, ((uint64_t)n_tiles + 1) / 2);  // (16 bytes of slack behind them)
-                    pal_prefetched = true;
-                }
                 flags_prefetched = true;
             }
             launch_copy_words(sf, (uint32_t *)mbox, (const uint32_t *)d_cursor, 8);  // (by a kernel: see plan())

@@ -303,7 +303,7 @@ def test_genome_like_batch_keeps_the_early_round_and_adds_the_flagged_islands(or
     spec = P.make_spec()
     ref = [oracle.sequence_to_shmmrs(i, q, oracle.spec()) for i, q in enumerate(seqs)]
     b = P.Batch.from_seqs(seqs, ctx=gpu_ctx)
-    for opts in ({}, {"no_early_merge": 1}, {"no_early_islands": 1}, {"early_islands_in_stream": 1}, {"island_chunk_min": 4096}, {"pal_positions": 1}):
+    for opts in ({}, {"no_early_merge": 1}, {"no_early_islands": 1}, {"early_islands_in_stream": 1}, {"island_chunk_min": 4096}):
         with gpu_ctx.options(**opts):
             sh = b.shmmrs(spec)
             sums, off = sh.checksum(), sh.offsets()
