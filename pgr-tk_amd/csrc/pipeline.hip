@@ -1041,8 +1041,10 @@ int ShmmrJob::plan() {
     islands_done = false;
     l2_cursor_clean = false;
     pre_listed = false;
-    stage1_only = optimistic && tiled && bases_tiled && serial.empty() && ctx->est_flagged && ctx->est_l1_key == l1_key &&
-                  b->total_bases >= (4u << 20) && !ctx->opt.no_stage1_only;
+    // (a spec without a tile path -- w < 17: every contig goes through the exact machine -- ALWAYS needs the second pass: its first
+    // pass has nothing for a list stage to work on)
+    stage1_only = optimistic && !ctx->opt.no_stage1_only &&
+                  (!serial.empty() || (tiled && bases_tiled && ctx->est_flagged && ctx->est_l1_key == l1_key && b->total_bases >= (4u << 20)));
     list_pending = false;
     return PGR_OK;
 }
@@ -1091,6 +1093,11 @@ int ShmmrJob::stage1() {
     serial_base = a.tail_base + (uint64_t)n * L1_TAIL_SLOT;  // (run_exact_islands grows the buffer behind this point)
     // cursors (both stages), contig flags, tile flags: cleared by the tile descriptor kernel when there are tiles
     if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipMemsetAsync(d_cursor, 0, zero_bytes, st));
+    // Without a tile kernel nobody writes the tile segments' entries (the tail kernel writes the contigs' tail segments, the islands
+    // write theirs later): a list stage that runs before the islands -- the optimistic pass of a pipelined job -- scanned whatever the
+    // workspace held and read level-1 records from wherever that pointed.  Found as a GPU memory fault that came and went with the
+    // SIZE of an unrelated workspace (profiles/r05_fuzz/cursor_block_size_fault.txt): the counts start at zero.
+    if (!(tiled && bases_tiled) && n_segs) PGR_HIP(ctx, hipMemsetAsync(ctx->ws_seg_cnt.p, 0, ((size_t)n_segs + 1) * sizeof(uint32_t), st));
     if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
     l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
     if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));

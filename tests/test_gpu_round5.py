@@ -611,3 +611,44 @@ def test_pgr_query_in_batches_through_the_pipe_writes_the_same_files(oracle, gpu
     assert len(outs["one"]) == 22 and any(len(v.splitlines()) > 1 for v in outs["one"].values())
     for tag in ("b1", "b3", "b4"):
         assert outs[tag] == outs["one"], tag
+
+
+def test_pipe_jobs_of_a_spec_without_a_tile_path_on_lanes_that_held_other_jobs(oracle, gpu_ctx):
+    """A spec with w < 17 has no tile kernel: nobody writes the tile segments' entries before the islands do, and the optimistic pass of
+    a pipelined job used to run its list stage over whatever the lane's workspaces held -- a GPU memory fault that came and went with
+    the size of an unrelated buffer (profiles/r05_fuzz/cursor_block_size_fault.txt; fuzz_pipe.py 2 9500 6000000).  Lanes are kept
+    between pipes: jobs of a w = 80 spec leave their segment counts behind, then jobs of w = 9 and w = 2 specs run on the same lanes
+    (first pass = stage 1 alone now; with no_stage1_only: the list stage over counts that start at zero), lists against the oracle."""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(2024)
+    big = [[seqgen.rnd(rng, 1_500_000), seqgen.rnd(rng, 900_000)] for _ in range(3)]
+    pipe = P.Pipe(P.make_spec(*SPEC), ctx=gpu_ctx)
+    bb = [P.Batch.from_seqs(s, ctx=gpu_ctx) for s in big]
+    for b in bb:
+        if pipe.in_flight == 2:
+            pipe.collect()
+        pipe.submit(b)
+    while pipe.in_flight:
+        pipe.collect()
+    pipe.close()
+    sets = [[seqgen.rnd(rng, int(L)) for L in rng.integers(20_000, 400_000, 4)] for _ in range(4)]
+    sets[1][2] = sets[1][2][:5000] + b"N" * 300 + sets[1][2][5300:]
+    batches = [P.Batch.from_seqs(s, ctx=gpu_ctx) for s in sets]
+    for spec_t in ((9, 12, 3, 8, False), (2, 5, 1, 0, False), (16, 16, 2, 4, False)):
+        spec, osp = P.make_spec(*spec_t), oracle.spec(*spec_t)
+        refs = [[oracle.sequence_to_shmmrs(i, q, osp) for i, q in enumerate(s)] for s in sets]
+        for opts in ({}, {"no_stage1_only": 1}):
+            with gpu_ctx.options(**opts):
+                pipe = P.Pipe(spec, ctx=gpu_ctx)
+                got = []
+                for b in batches:
+                    if pipe.in_flight == 2:
+                        got.append(pipe.collect()[0])
+                    pipe.submit(b)
+                while pipe.in_flight:
+                    got.append(pipe.collect()[0])
+                pipe.close()
+            for bi, sh in enumerate(got):
+                mm, off = sh.download()
+                for i, ref in enumerate(refs[bi]):
+                    _same_mm(ref, mm[int(off[i]):int(off[i + 1])], "spec %s %s batch %d seq %d" % (spec_t, opts, bi, i))
