@@ -2109,7 +2109,9 @@ extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_
         const double dens = sp.sketch ? 1.0 / (double)(1ull << (4 + sp.r)) : 2.0 / (double)(sp.w + 1) * keep * keep;
         pairs_hint = (uint32_t)std::min<double>((double)max_len * dens * 1.6 + 4.0, 1e9);
     }
-    const bool chained = n && ix->n && ix->fused_skip.load(std::memory_order_relaxed) == 0 && pairs_hint &&
+    // (a spec without a tile path needs the exact machine for every query: the synchronous call)
+    const bool chained = n && ix->n && (ix->spec.sketch || ix->spec.w >= (uint32_t)L1_MIN_W) &&
+                         ix->fused_skip.load(std::memory_order_relaxed) == 0 && pairs_hint &&
                          query_fused_eligible(ctx, n, pairs_hint, max_aln_span) && !ctx->opt.no_query_chaining;
     if (!chained) {
         s.q_fallback = true;

@@ -546,6 +546,28 @@ def test_query_batches_through_the_pipe_equal_the_synchronous_calls(oracle, gpu_
         got.append({f: np.array(r[f]).tobytes() for f in keys})
     pipe.close()
     assert got == ref
+    # an index of a spec without a tile path (w < 17): every query job is answered by the synchronous call
+    spec9 = P.make_spec(9, 12, 3, 8)
+    ix9 = P.Index(spec9, ctx=gpu_ctx)
+    ix9.add_resident(P.Batch.from_seqs([t[:60_000] for t in targets], ctx=gpu_ctx))
+    ix9.finalize()
+    q9 = [P.Batch.from_seqs([q[:2_000] for q in s[:40]], ctx=gpu_ctx) for s in sets[:3]]
+    ref9 = []
+    for b in q9:
+        r = ix9.query_hps_resident_raw(b, 0.025)
+        ref9.append({f: np.array(r[f]).tobytes() for f in keys})
+    pipe = P.Pipe(spec9, ctx=gpu_ctx)
+    got9 = []
+    for b in q9:
+        if pipe.in_flight == 2:
+            r = pipe.collect_query()
+            got9.append({f: np.array(r[f]).tobytes() for f in keys})
+        pipe.submit_query(b, ix9, 0.025)
+    while pipe.in_flight:
+        r = pipe.collect_query()
+        got9.append({f: np.array(r[f]).tobytes() for f in keys})
+    pipe.close()
+    assert got9 == ref9
     for rep in range(2):  # (the second time the index's hints are those of the last batch of the first)
         pipe = P.Pipe(spec, ctx=gpu_ctx)
         got = []
