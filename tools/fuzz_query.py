@@ -92,6 +92,47 @@ def one_case(seed, ctx):
         if got3 != got:
             return "seed %d: the chained query path differs (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
                 seed, spec_t, pen, mc, mq, mt, span, gap, ori)
+        # ... and through the pipe (pgr_pipe_submit_query / _collect_query): the queries in three resident batches, two in flight;
+        # every section of every collected result against pgr_query_hps_resident on the same batch
+        import ctypes as C
+        from pgrtk_amd import _ffi
+        L = _ffi.lib()
+        spec = P.make_spec(*spec_t)
+        third = (len(queries) + 2) // 3
+        qbs = [P.Batch.from_seqs(queries[i:i + third], ctx=ctx) for i in range(0, len(queries), third)]
+        args = (C.c_float(pen), mc, mq, mt, span, int(gap is not None), int(gap or 0), int(ori))
+
+        def sections(res, nq):
+            def raw(ptr, nbytes):
+                return C.string_at(C.cast(ptr, C.c_void_p), int(nbytes)) if nbytes else b""
+            return (raw(res.q_off, 8 * (nq + 1)), raw(res.t_sid, 4 * res.n_targets), raw(res.t_off, 8 * (res.n_targets + 1) if res.n_targets else 0),
+                    raw(res.c_score, 4 * res.n_chains), raw(res.c_off, 8 * (res.n_chains + 1) if res.n_chains else 0), raw(res.hps, 24 * res.n_hps))
+        ref_s = []
+        for b_ in qbs:
+            res = _ffi.HpsResult()
+            ctx.check(L.pgr_query_hps_resident(ctx.handle, sdb._ix, b_._h, *args, C.byref(res)))
+            ref_s.append(sections(res, b_.n))
+            L.pgr_hps_result_free(C.byref(res))
+        hp = C.c_void_p()
+        ctx.check(L.pgr_pipe_create(ctx.handle, C.byref(spec), C.byref(hp)))
+        got_s, flying = [], []
+        for b_ in qbs + qbs:
+            if len(flying) == 2:
+                res = _ffi.HpsResult()
+                ctx.check(L.pgr_pipe_collect_query(hp, C.byref(res)))
+                got_s.append(sections(res, flying.pop(0).n))
+                L.pgr_hps_result_free(C.byref(res))
+            ctx.check(L.pgr_pipe_submit_query(hp, b_._h, sdb._ix, *args))
+            flying.append(b_)
+        while flying:
+            res = _ffi.HpsResult()
+            ctx.check(L.pgr_pipe_collect_query(hp, C.byref(res)))
+            got_s.append(sections(res, flying.pop(0).n))
+            L.pgr_hps_result_free(C.byref(res))
+        L.pgr_pipe_destroy(hp)
+        if got_s != ref_s + ref_s:
+            return "seed %d: query batches through the pipe differ from the synchronous call (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
+                seed, spec_t, pen, mc, mq, mt, span, gap, ori)
         if got2 != got:
             return "seed %d: the two query paths differ (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
                 seed, spec_t, pen, mc, mq, mt, span, gap, ori)
