@@ -1100,6 +1100,10 @@ def main():
     ctx = P.Context(local_rank)
     ctx.set_option("exchange_timeout_s", args.exchange_timeout)
     ctx.set_option("exchange_collective_timeout_s", args.exchange_timeout)  # (the bench would rather fall back than wait half an hour)
+    if args.force_dist:
+        # one rank through the library's REAL communicator (the default of one rank is copies without RCCL): this process has
+        # PyTorch's librccl.so mapped already, the library takes that copy
+        ctx.set_option("exchange_rccl_world1", 1)
     spec_t = (80, 56, 4, 64)
     spec = P.make_spec(*spec_t)
     if args.strong:
@@ -1259,7 +1263,7 @@ def main():
             exch_check = {
                 "what": "key-range sharded merge: every pair record went to the rank owning its range of first hashes",
                 "transport": "pgr_exchange_shard_records (RCCL behind the C ABI)" if use_abi else "torch.distributed (%s)" % args.backend,
-                "rccl_ranks_in_the_librarys_communicator": xch.world if (use_abi and xch is not None) else 0,
+                "rccl_ranks_in_the_librarys_communicator": xch.world if (use_abi and xch is not None and xch.uses_rccl) else 0,
                 "exchange_fallback": fallback["note"],
                 "records_sent_all_ranks": sum(v["n_sent"] for v in allv), "records_in_shards": n_tot,
                 "checksum_of_sent_records": ["%016x" % x for x in s_sent], "checksum_of_shard_records": ["%016x" % x for x in s_shard],

@@ -97,8 +97,12 @@ const char *pgr_version(void);
  *   gpu_pack                  ASCII over PCIe + pack kernel instead of the CPU packer (the round-2 host path)
  *   index_full_sort, index_two_key_sort    pgr_index_finalize: force the four-field / the two-key sort
  *   no_fused_query, no_query_chaining, query_global_sort, fused_query_hits   query path variants
- *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on ncclCommInitRank, the rendezvous of the ranks (300; 0 = wait for
- *                             ever); on a timeout the communicator is aborted and the call fails
+ *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on loading librccl.so.1, ncclGetUniqueId and ncclCommInitRank (the
+ *                             rendezvous of the ranks) (300; 0 = wait for ever); on a timeout the call fails and its message
+ *                             names the step that did not return
+ *   exchange_rccl_world1      an exchange of ONE rank uses a real RCCL communicator.  Default 0: every collective of one rank is
+ *                             a device-to-device copy on the exchange's stream and RCCL is neither loaded nor initialised
+ *                             (pgr_exchange_create then ignores `id`, which may be NULL)
  *   exchange_collective_timeout_s   the same for every wait for a collective -- which is also a wait for the slowest rank to get
  *                             there, so it is generous (1800; 0 = wait for ever).  A value that is not a number leaves a numeric
  *                             option at its default (a line on stderr says so).

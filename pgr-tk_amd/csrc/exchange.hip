@@ -18,6 +18,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <cstdlib>
@@ -49,10 +50,15 @@ struct Rccl {
     std::string err;
 };
 
+std::atomic<bool> g_rccl_loaded{false};  // set once rccl() has run: lets error paths name an RCCL error without loading the library
+
 Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        struct Mark {
+            ~Mark() { g_rccl_loaded.store(true); }
+        } mark;
         // a copy that is already in the process (PyTorch loads its own librccl.so) is taken first: two RCCL instances in one
         // process would each keep their own communicators, topology state and IPC handles on the same GPUs
         for (const char *name : {"librccl.so", "librccl.so.1"}) {
@@ -94,6 +100,11 @@ struct pgr_exchange {
     pgr_ctx *ctx = nullptr;
     int rank = 0, world = 1;
     ncclComm_t comm = nullptr;
+    // world == 1: every collective of this file is a device-to-device copy on the exchange's stream (an all-gather of one rank, a
+    // broadcast from oneself; send/recv never happen).  RCCL is then neither loaded nor initialised (librccl.so.1 is a 570 MB
+    // image whose first load and ncclCommInitRank cost seconds -- minutes from a cold disk -- for nothing); the context option
+    // exchange_rccl_world1 = 1 asks for the real communicator all the same (plumbing tests on a one-GPU box).
+    bool local = false;
     hipStream_t stream = nullptr;          // the collective's own stream: overlaps the compute stream
     hipEvent_t ev_ready = nullptr, ev_done = nullptr;
     unsigned long long *d_cnt = nullptr;   // [1 + world]: this rank's count, then everybody's
@@ -137,7 +148,7 @@ static int exchange_sync(pgr_exchange *x, const char *what) {
         if (el > 2e-3) std::this_thread::sleep_for(std::chrono::microseconds(el > 0.1 ? 1000 : 50));  // spin first: steps are ms
     }
     x->broken = true;
-    if (x->comm && rccl().CommAbort) (void)rccl().CommAbort(x->comm);
+    if (x->comm && g_rccl_loaded.load() && rccl().CommAbort) (void)rccl().CommAbort(x->comm);
     x->comm = nullptr;
     char msg[200];
     snprintf(msg, sizeof msg, "%s did not complete within %.0f s (option exchange_collective_timeout_s): communicator aborted, rank %d of %d", what,
@@ -147,36 +158,125 @@ static int exchange_sync(pgr_exchange *x, const char *what) {
 
 static_assert(PGR_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "pgr_hip.h and rccl.h disagree on the unique id size");
 
+static std::string nccl_error_string(ncclResult_t r) {
+    if (g_rccl_loaded.load() && rccl().GetErrorString) return rccl().GetErrorString(r);
+    return r == ncclUnhandledCudaError ? "device-to-device copy failed (one-rank exchange without RCCL)" : "error " + std::to_string((int)r);
+}
+
 #define PGR_NCCL(ctx, expr)                                                                          \
     do {                                                                                             \
         ncclResult_t _r = (expr);                                                                    \
         if (_r != ncclSuccess)                                                                       \
-            return (ctx)->fail(PGR_ERR_DEVICE, std::string(#expr) + ": " + rccl().GetErrorString(_r)); \
+            return (ctx)->fail(PGR_ERR_DEVICE, std::string(#expr) + ": " + nccl_error_string(_r)); \
     } while (0)
+
+namespace {
+// what the functions below call collectives through: RCCL, or -- for an exchange of one rank -- copies on the exchange's stream
+struct Xport {
+    const pgr_exchange *x;
+    static ncclResult_t copy(const void *src, void *dst, size_t words, hipStream_t st) {
+        if (src == dst || words == 0) return ncclSuccess;
+        return hipMemcpyAsync(dst, src, words * 8, hipMemcpyDeviceToDevice, st) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+    }
+    ncclResult_t AllGather(const void *s, void *r, size_t n, ncclDataType_t t, ncclComm_t c, hipStream_t st) const {
+        return x->local ? copy(s, r, n, st) : rccl().AllGather(s, r, n, t, c, st);  // (every payload of this file is ncclUint64 words)
+    }
+    ncclResult_t Broadcast(const void *s, void *r, size_t n, ncclDataType_t t, int root, ncclComm_t c, hipStream_t st) const {
+        return x->local ? copy(s, r, n, st) : rccl().Broadcast(s, r, n, t, root, c, st);
+    }
+    ncclResult_t Send(const void *s, size_t n, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) const {
+        return x->local ? ncclInvalidUsage : rccl().Send(s, n, t, peer, c, st);  // (one rank has no peer)
+    }
+    ncclResult_t Recv(void *r, size_t n, ncclDataType_t t, int peer, ncclComm_t c, hipStream_t st) const {
+        return x->local ? ncclInvalidUsage : rccl().Recv(r, n, t, peer, c, st);
+    }
+    ncclResult_t GroupStart() const { return x->local ? ncclSuccess : rccl().GroupStart(); }
+    ncclResult_t GroupEnd() const { return x->local ? ncclSuccess : rccl().GroupEnd(); }
+    std::string GetErrorString(ncclResult_t r) const { return nccl_error_string(r); }
+};
+}  // namespace
+
+namespace {
+// A blocking RCCL entry (loading the library itself, ncclGetUniqueId, ncclCommInitRank) runs on a thread of its own beside a clock
+// (option exchange_timeout_s).  The thread says which step it is in, so that a time-out NAMES the call that did not return; a thread
+// that is still inside RCCL when the clock runs out is detached and owns everything it touches through the shared state.
+struct Guarded {
+    std::mutex m;
+    std::condition_variable cv;
+    bool done = false;
+    std::atomic<const char *> step{"starting"};
+    std::string load_error;
+    ncclResult_t r = ncclSuccess;
+    ncclComm_t comm = nullptr;
+    ncclUniqueId id;
+    std::chrono::steady_clock::time_point t_step = std::chrono::steady_clock::now();
+};
+
+template <class F>
+int run_beside_a_clock(pgr_ctx *ctx, const char *what, int rank, int world, std::shared_ptr<Guarded> st, F body) {
+    const int device = ctx->device;
+    const bool debug = ctx->opt.debug != 0;
+    std::thread worker([st, device, body, debug] {
+        (void)hipSetDevice(device);
+        const auto t0 = std::chrono::steady_clock::now();
+        st->step = "loading librccl.so.1 (dlopen)";
+        Rccl &R = rccl();
+        const double t_load = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!R.err.empty()) st->load_error = R.err;
+        else body(R, *st);
+        if (debug)
+            fprintf(stderr, "[pgr] exchange: RCCL ready after %.3f s, %s returned after %.3f s\n", t_load, st->step.load(),
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        std::lock_guard<std::mutex> g(st->m);
+        st->done = true;
+        st->cv.notify_all();
+    });
+    const double limit = exchange_timeout_s(ctx);
+    std::unique_lock<std::mutex> g(st->m);
+    if (limit <= 0) st->cv.wait(g, [&] { return st->done; });
+    else st->cv.wait_for(g, std::chrono::duration<double>(limit), [&] { return st->done; });
+    if (!st->done) {
+        g.unlock();
+        worker.detach();
+        char msg[320];
+        snprintf(msg, sizeof msg, "%s: %s did not return within %.0f s (option exchange_timeout_s): rank %d of %d", what, st->step.load(),
+                 limit, rank, world);
+        return ctx->fail(PGR_ERR_DEVICE, msg);
+    }
+    g.unlock();
+    worker.join();
+    if (!st->load_error.empty()) return ctx->fail(PGR_ERR_DEVICE, st->load_error);
+    if (st->r != ncclSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string(what) + ": " + st->step.load() + ": " + nccl_error_string(st->r));
+    return PGR_OK;
+}
+}  // namespace
 
 extern "C" int pgr_exchange_unique_id(pgr_ctx *ctx, uint8_t *id) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!id) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    Rccl &R = rccl();
-    if (!R.err.empty()) return ctx->fail(PGR_ERR_DEVICE, R.err);
     PGR_HIP(ctx, hipSetDevice(ctx->device));
-    ncclUniqueId u;
-    PGR_NCCL(ctx, R.GetUniqueId(&u));
-    memcpy(id, u.internal, PGR_UNIQUE_ID_BYTES);
+    auto st = std::make_shared<Guarded>();
+    const int rc = run_beside_a_clock(ctx, "pgr_exchange_unique_id", 0, 0, st, [](Rccl &R, Guarded &g) {
+        g.step = "ncclGetUniqueId";
+        g.r = R.GetUniqueId(&g.id);
+    });
+    if (rc) return rc;
+    memcpy(id, st->id.internal, PGR_UNIQUE_ID_BYTES);
     return PGR_OK;
 }
 
 extern "C" int pgr_exchange_create(pgr_ctx *ctx, const uint8_t *id, int rank, int world, pgr_exchange **out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
-    if (!id || !out || world < 1 || rank < 0 || rank >= world) return ctx->fail(PGR_ERR_INVALID_ARG, "bad exchange arguments");
+    if (!out || world < 1 || rank < 0 || rank >= world) return ctx->fail(PGR_ERR_INVALID_ARG, "bad exchange arguments");
     *out = nullptr;
-    Rccl &R = rccl();
-    if (!R.err.empty()) return ctx->fail(PGR_ERR_DEVICE, R.err);
+    const bool local = world == 1 && !ctx->opt.exchange_rccl_world1;
+    if (!local && !id) return ctx->fail(PGR_ERR_INVALID_ARG, "bad exchange arguments: no unique id");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     pgr_exchange *x = new pgr_exchange();
     x->ctx = ctx;
     x->rank = rank;
     x->world = world;
+    x->local = local;
     auto bail = [&](int code) {
         pgr_exchange_destroy(x);
         return code;
@@ -187,47 +287,19 @@ extern "C" int pgr_exchange_create(pgr_ctx *ctx, const uint8_t *id, int rank, in
     if (e == hipSuccess) e = hipMalloc((void **)&x->d_cnt, (size_t)(1 + world) * sizeof(unsigned long long));
     if (e == hipSuccess) e = hipHostMalloc((void **)&x->h_cnt, (size_t)(1 + world) * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) return bail(ctx->fail(PGR_ERR_DEVICE, std::string("exchange setup: ") + hipGetErrorString(e)));
-    ncclUniqueId u;
-    memcpy(u.internal, id, PGR_UNIQUE_ID_BYTES);
-    // ncclCommInitRank blocks until all `world` ranks have called it: run it beside a clock (see exchange_timeout_s)
-    struct Init {
-        std::mutex m;
-        std::condition_variable cv;
-        bool done = false;
-        ncclResult_t r = ncclSuccess;
-        ncclComm_t comm = nullptr;
-    };
-    auto st = std::make_shared<Init>();
-    const int device = ctx->device;
-    std::thread worker([st, u, world, rank, device, &R] {
-        (void)hipSetDevice(device);
-        ncclComm_t c = nullptr;
-        const ncclResult_t r = R.CommInitRank(&c, world, u, rank);
-        std::lock_guard<std::mutex> g(st->m);
-        st->r = r;
-        st->comm = c;
-        st->done = true;
-        st->cv.notify_all();
+    if (local) {
+        if (ctx->opt.debug) fprintf(stderr, "[pgr] exchange of one rank: copies on its own stream, RCCL not loaded\n");
+        *out = x;
+        return PGR_OK;
+    }
+    // ncclCommInitRank blocks until all `world` ranks have called it (see exchange_timeout_s)
+    auto st = std::make_shared<Guarded>();
+    memcpy(st->id.internal, id, PGR_UNIQUE_ID_BYTES);
+    const int rc = run_beside_a_clock(ctx, "pgr_exchange_create", rank, world, st, [world, rank](Rccl &R, Guarded &g) {
+        g.step = "ncclCommInitRank";
+        g.r = R.CommInitRank(&g.comm, world, g.id, rank);
     });
-    const double limit = exchange_timeout_s(ctx);
-    {
-        std::unique_lock<std::mutex> g(st->m);
-        if (limit <= 0) st->cv.wait(g, [&] { return st->done; });
-        else st->cv.wait_for(g, std::chrono::duration<double>(limit), [&] { return st->done; });
-        if (!st->done) {
-            g.unlock();
-            worker.detach();  // still inside RCCL: it keeps its shared state alive, nothing of this call is touched again
-            char msg[160];
-            snprintf(msg, sizeof msg, "ncclCommInitRank did not return within %.0f s (option exchange_timeout_s): rank %d of %d", limit,
-                     rank, world);
-            return bail(ctx->fail(PGR_ERR_DEVICE, msg));
-        }
-    }
-    worker.join();
-    if (st->r != ncclSuccess) {
-        x->comm = nullptr;
-        return bail(ctx->fail(PGR_ERR_DEVICE, std::string("ncclCommInitRank: ") + R.GetErrorString(st->r)));
-    }
+    if (rc) return bail(rc);
     x->comm = st->comm;
     *out = x;
     return PGR_OK;
@@ -237,7 +309,7 @@ extern "C" void pgr_exchange_destroy(pgr_exchange *x) {
     if (!x) return;
     (void)hipSetDevice(x->ctx->device);
     if (x->stream && !x->broken) (void)hipStreamSynchronize(x->stream);
-    if (x->comm) (void)rccl().CommDestroy(x->comm);
+    if (x->comm && g_rccl_loaded.load()) (void)rccl().CommDestroy(x->comm);
     if (x->ev_ready) (void)hipEventDestroy(x->ev_ready);
     if (x->ev_done) (void)hipEventDestroy(x->ev_done);
     if (x->d_cnt) (void)hipFree(x->d_cnt);
@@ -257,7 +329,7 @@ extern "C" int pgr_exchange_allgather_shmmrs_start(pgr_exchange *x, const pgr_mm
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is already in flight on this exchange (call pgr_exchange_wait)");
     if (!d_local || !d_out || cap_per_rank == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (n_local > cap_per_rank) return ctx->fail(PGR_ERR_INVALID_ARG, "this rank's shimmer list exceeds cap_per_rank");
-    Rccl &R = rccl();
+    const Xport R{x};
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     // the list was produced on the context's stream: the collective starts behind it, the host does not wait
     PGR_HIP(ctx, hipEventRecord(x->ev_ready, ctx->stream));
@@ -307,7 +379,7 @@ extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs 
     if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is already in flight on this exchange");
     if (s && s->n && !rids) return ctx->fail(PGR_ERR_INVALID_ARG, "null rid list");
-    Rccl &R = rccl();
+    const Xport R{x};
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n_local = s ? s->count : 0;
     // phase 1: counts (the compute stream's work is done: pgr_shmmrs_compute synchronizes)
@@ -360,7 +432,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange (call pgr_exchange_wait)");
     if (!ix || (n && !d_recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (ix->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "index belongs to another context");
-    Rccl &R = rccl();
+    const Xport R{x};
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     const int world = x->world, me = x->rank;
     int rc;
@@ -486,7 +558,7 @@ extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *sh
     if (x->broken) return ctx->fail(PGR_ERR_STATE, "this exchange was aborted after a timeout");
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange");
     *out = nullptr;
-    Rccl &R = rccl();
+    const Xport R{x};
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     const int world = x->world, me = x->rank;
     int rc;

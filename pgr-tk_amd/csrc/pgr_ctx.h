@@ -79,6 +79,7 @@ struct pgr_ctx {
         int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank (all ranks must arrive); 0 = wait for ever
         int64_t exchange_collective_timeout_s = 1800;  // bound on every wait for a collective -- which includes waiting for a SLOWER peer to
                                                        // get there (an imbalanced rank is not a dead one): generous; 0 = wait for ever
+        int64_t exchange_rccl_world1 = 0;  // an exchange of ONE rank goes through a real RCCL communicator all the same (default: plain copies, RCCL not loaded)
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t early_islands_in_stream = 0;  // ... behind the tile kernel on its stream, not beside it on a stream of their own (for A/B)

@@ -21,7 +21,7 @@
 // waits for the host (QueryFusedRun::enqueue_from_shimmers is called through pgr_ctx::post_enqueue).
 //
 // f32 arithmetic in the reference's operation order, no contraction (-ffp-contract=off), the same tie rules as
-// sparse_aln_kernel / sparse_aln_wave_kernel (index.hip): tests/test_gpu_query_fused.py compares the two paths with each other
+// sparse_aln_kernel / sparse_aln_wave_kernel (index.hip): tests/test_gpu_02_query_fused.py compares the two paths with each other
 // and with the CPU restatement of the reference.
 //
 // The path DECLINES a batch it cannot hold (the flag is read with the totals): a query with more than P <= QF_MAX_PAIRS pairs or

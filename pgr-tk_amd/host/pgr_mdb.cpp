@@ -14,6 +14,8 @@
 
 #include <cerrno>
 #include <csignal>
+#include <fcntl.h>
+#include <sys/prctl.h>
 #include <sys/wait.h>
 #include <unistd.h>
 
@@ -22,8 +24,10 @@
 #include "fastx.hpp"
 #include "pgr_hip.h"
 
-// --ranks N: the sharded build of SURVEY.md section 8e without Python.  One process per GPU (forked BEFORE the first HIP
-// call); every rank reads the inputs, takes its contigs from the greedy length-balanced partition (the unit of
+// --ranks N: the sharded build of SURVEY.md section 8e without Python.  One process per GPU: the parent forks and every child
+// EXECs this program again with --as-rank (a rank is a fresh process image: nothing of the parent's runtime state -- locks held by
+// threads a loaded library may have started, half-initialised HIP/HSA singletons -- is inherited across the fork), dies with
+// its parent (PR_SET_PDEATHSIG) and the parent hands SIGTERM/SIGINT on to its ranks; every rank reads the inputs, takes its contigs from the greedy length-balanced partition (the unit of
 // parallelism is the contig, pgr-db/src/seq_db.rs:460-467), computes their pair records with global sequence ids and
 // takes part in pgr_exchange_shard_records round after round: the frag_map (seq_db.rs:605-612) is key-range sharded,
 // rank r owns the r-th range of first hashes and sorts only that.  Every rank writes its shard as <prefix>.mdb.rank<r>,
@@ -131,13 +135,20 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
                     const std::vector<std::string> &pos);
 static int merge_mdb_shards(const std::string &prefix, int ranks);
 
+static std::vector<pid_t> g_kids;  // the rank processes of --ranks (parent only; fixed before the handler is installed)
+static void forward_signal(int sig) {
+    for (pid_t k : g_kids)
+        if (k > 0) kill(k, sig);
+}
+
 int main(int argc, char **argv) {
     pgr_spec spec = {80, 56, 4, 64, 0};
     uint64_t batch_bp = 2000000000ull;
     bool sid_quirk = false;
     int ranks = 1;
     bool force_exchange = false;
-    std::vector<int> devices;
+    int as_rank = -1, id_read_fd = -1;
+    std::vector<int> devices, id_write_fds;
     std::vector<std::string> pos;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
@@ -156,6 +167,17 @@ int main(int argc, char **argv) {
         else if (a == "--batch-bp") batch_bp = strtoull(val("--batch-bp"), nullptr, 10);
         else if (a == "--reference-sid-quirk") sid_quirk = true;  // load_index_from_reader restarts at 0 per input (seq_db.rs:543)
         else if (a == "--ranks") ranks = atoi(val("--ranks"));
+        else if (a == "--as-rank") as_rank = atoi(val("--as-rank"));          // internal: this process IS rank r of --ranks N
+        else if (a == "--id-read-fd") id_read_fd = atoi(val("--id-read-fd"));  // internal: the unique id arrives here
+        else if (a == "--id-write-fds") {                                      // internal (rank 0): one pipe per other rank
+            std::string v = val("--id-write-fds");
+            for (size_t p = 0; p < v.size();) {
+                const size_t q = v.find(',', p);
+                id_write_fds.push_back(atoi(v.substr(p, q == std::string::npos ? std::string::npos : q - p).c_str()));
+                if (q == std::string::npos) break;
+                p = q + 1;
+            }
+        }
         else if (a == "--force-exchange") force_exchange = true;
         else if (a == "--prepack") prepack = true;
         else if (a == "--synthetic") {
@@ -187,7 +209,7 @@ int main(int argc, char **argv) {
                         "       pgr-mdb --synthetic NxL --seed S <prefix> [...] [--write-fasta <path>]\n");
         return 2;
     }
-    if (synth.on && !synth.fasta_out.empty() && !write_synthetic_fasta(synth)) {
+    if (as_rank < 0 && synth.on && !synth.fasta_out.empty() && !write_synthetic_fasta(synth)) {
         fprintf(stderr, "pgr-mdb: can't write %s\n", synth.fasta_out.c_str());
         return 1;
     }
@@ -197,11 +219,25 @@ int main(int argc, char **argv) {
         fprintf(stderr, "pgr-mdb: --reference-sid-quirk cannot be combined with --ranks / --force-exchange\n");
         return 2;
     }
+    if (as_rank >= 0) {  // a rank process (see the fork/exec below)
+        if (as_rank >= ranks) {
+            fprintf(stderr, "pgr-mdb: --as-rank %d of %d ranks\n", as_rank, ranks);
+            return 2;
+        }
+        RankEnv env;
+        env.rank = as_rank;
+        env.world = ranks;
+        env.force_exchange = force_exchange;
+        env.device = devices.empty() ? as_rank : devices[(size_t)as_rank % devices.size()];
+        env.id_read_fd = id_read_fd;
+        env.id_write_fds = id_write_fds;
+        return run_rank(env, spec, batch_bp, sid_quirk, pos);
+    }
     if (ranks == 1 && devices.empty() && !force_exchange) {
         RankEnv env;
         return run_rank(env, spec, batch_bp, sid_quirk, pos);
     }
-    // one process per GPU, forked before anything touches HIP
+    // one process per GPU: fork, then exec this program again as --as-rank r (the pipe ends a rank needs stay open across the exec)
     std::vector<std::pair<int, int>> pipes((size_t)ranks, {-1, -1});
     for (int r = 1; r < ranks; ++r) {
         int fd[2];
@@ -211,34 +247,56 @@ int main(int argc, char **argv) {
         }
         pipes[(size_t)r] = {fd[0], fd[1]};
     }
+    const pid_t parent = getpid();
     std::vector<pid_t> kids;
     for (int r = 0; r < ranks; ++r) {
         const pid_t pid = fork();
         if (pid < 0) {
             perror("pgr-mdb: fork");
+            for (pid_t o : kids) kill(o, SIGTERM);
             return 1;
         }
         if (pid == 0) {
-            RankEnv env;
-            env.rank = r;
-            env.world = ranks;
-            env.force_exchange = force_exchange;
-            env.device = devices.empty() ? r : devices[(size_t)r % devices.size()];
+            // a rank never outlives the program that started it (a killed parent must not leave ranks on the GPUs)
+            (void)prctl(PR_SET_PDEATHSIG, SIGKILL);
+            if (getppid() != parent) _exit(1);  // (the parent was gone before the prctl)
+            std::vector<std::string> av(argv, argv + argc);
+            av.push_back("--as-rank");
+            av.push_back(std::to_string(r));
+            std::string wfds;
             for (int q = 1; q < ranks; ++q) {
                 if (r == 0) {
                     close(pipes[(size_t)q].first);
-                    env.id_write_fds.push_back(pipes[(size_t)q].second);
+                    wfds += (wfds.empty() ? "" : ",") + std::to_string(pipes[(size_t)q].second);
                 } else if (q == r) {
                     close(pipes[(size_t)q].second);
-                    env.id_read_fd = pipes[(size_t)q].first;
+                    av.push_back("--id-read-fd");
+                    av.push_back(std::to_string(pipes[(size_t)q].first));
                 } else {
                     close(pipes[(size_t)q].first);
                     close(pipes[(size_t)q].second);
                 }
             }
-            _exit(run_rank(env, spec, batch_bp, sid_quirk, pos));
+            if (!wfds.empty()) {
+                av.push_back("--id-write-fds");
+                av.push_back(wfds);
+            }
+            std::vector<char *> cav;
+            for (auto &a : av) cav.push_back(const_cast<char *>(a.c_str()));
+            cav.push_back(nullptr);
+            execv("/proc/self/exe", cav.data());
+            perror("pgr-mdb: exec of the rank process");
+            _exit(127);
         }
         kids.push_back(pid);
+    }
+    g_kids = kids;
+    {  // SIGTERM / SIGINT to the parent is handed on to the ranks (the wait loop below then sees them exit)
+        struct sigaction sa;
+        memset(&sa, 0, sizeof sa);
+        sa.sa_handler = forward_signal;
+        sigaction(SIGTERM, &sa, nullptr);
+        sigaction(SIGINT, &sa, nullptr);
     }
     for (int r = 1; r < ranks; ++r) {
         close(pipes[(size_t)r].first);
@@ -337,15 +395,17 @@ static int run_rank(const RankEnv &env, const pgr_spec &spec, uint64_t batch_bp,
     if ((rc = pgr_index_create(ctx, &spec, &ix))) die(ctx, "pgr_index_create", rc);
     pgr_exchange *xch = nullptr;
     if (env.world > 1 || env.force_exchange) {
-        uint8_t id[PGR_UNIQUE_ID_BYTES];
-        if (env.rank == 0) {
+        uint8_t id[PGR_UNIQUE_ID_BYTES] = {0};
+        int64_t rccl_world1 = 0;
+        (void)pgr_ctx_get_option(ctx, "exchange_rccl_world1", &rccl_world1);
+        if (env.rank == 0 && (env.world > 1 || rccl_world1)) {  // (an exchange of one rank runs without RCCL and needs no id)
             if ((rc = pgr_exchange_unique_id(ctx, id))) die(ctx, "pgr_exchange_unique_id", rc);
             for (int fd : env.id_write_fds)
                 if (write(fd, id, sizeof(id)) != (ssize_t)sizeof(id)) {
                     perror("pgr-mdb: write unique id");
                     return 1;
                 }
-        } else {
+        } else if (env.rank > 0) {
             size_t got = 0;
             while (got < sizeof(id)) {
                 const ssize_t n = read(env.id_read_fd, id + got, sizeof(id) - got);

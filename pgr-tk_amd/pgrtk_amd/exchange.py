@@ -64,9 +64,12 @@ class AbiExchange:
     def __init__(self, ctx, rank, world, dist_mod=None, unique_id=None):
         from ._ffi import lib
         self.ctx, self.rank, self.world = ctx, rank, world
+        # one rank: the library copies on its own stream and does not load RCCL (context option exchange_rccl_world1 = 1 asks
+        # for a real communicator all the same), so there is no unique id to make
+        self.uses_rccl = world > 1 or bool(ctx.get_option("exchange_rccl_world1"))
         if unique_id is None:
             idb = np.zeros(128, dtype=np.uint8)
-            if rank == 0:
+            if rank == 0 and self.uses_rccl:
                 ctx.check(lib().pgr_exchange_unique_id(ctx.handle, idb.ctypes.data))
             if world > 1:
                 d = dist_mod or dist

@@ -1,4 +1,4 @@
-"""One rank of the sharded index build (run by tests/test_gpu_round2.py, two processes on one GPU box).
+"""One rank of the sharded index build (run by tests/test_gpu_90_dist_plumbing.py, two processes on one GPU box).
 
     python exchange_worker.py <transport> <rank> <world> <port> <outdir>
 

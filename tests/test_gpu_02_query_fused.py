@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 import seqgen
-from test_gpu_index_query import _build_pair, _make_db_seqs, _oracle_hps_to_tuples, revcomp
+from test_gpu_01_index_query import _build_pair, _make_db_seqs, _oracle_hps_to_tuples, revcomp
 
 pytestmark = pytest.mark.gpu
 

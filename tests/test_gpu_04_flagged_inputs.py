@@ -2,10 +2,7 @@
 checksum, the resident query entry point, the C-ABI exchange (1 rank and 2 processes on one device), the strong-scaling
 partitioner end to end, and BASELINE.json configs[4] as one GPU's slice."""
 import os
-import socket
-import subprocess
 import sys
-import tempfile
 
 import numpy as np
 import pytest
@@ -217,178 +214,6 @@ def test_max_aln_span_above_64(oracle, gpu_ctx):
         ref = oracle.sparse_aln(flat, span, pen, gap, ori)
         ref = [(sc, [((x[0], x[1], x[2]), (x[3], x[4], x[5])) for x in hp]) for sc, hp in ref]
         assert got == ref, span
-
-
-def test_exchange_abi_one_rank(gpu_ctx):
-    """pgr_exchange_* with world = 1 on the real device: RCCL is loaded by the library, the collective runs on the
-    exchange's stream, the gathered list equals the local one"""
-    import torch
-    import pgrtk_amd as P
-    from pgrtk_amd import exchange
-    b = P.Batch.synthetic([500_000, 70_000], seed=3, ctx=gpu_ctx)
-    sh = b.shmmrs(P.make_spec())
-    cap = sh.count + 100
-    local = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
-    n = sh.copy_into(local.data_ptr(), cap, rids=[17, 5])
-    out = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
-    xch = exchange.AbiExchange(gpu_ctx, 0, 1)
-    for _ in range(2):  # the handle is reusable step after step
-        out.zero_()
-        g, counts = xch.allgather_async(local, n, out, cap).wait()
-        assert counts == [n] and bool((g == local[:n]).all())
-    xch.close()
-    mm, off = sh.download()
-    got = np.frombuffer(g.cpu().numpy().tobytes(), dtype=P.MM128)
-    assert np.array_equal(got["x"], mm["x"])
-    assert set(int(v) for v in got["y"] >> np.uint64(32)) == {17, 5}
-
-
-def _free_port():
-    s = socket.socket()
-    s.bind(("127.0.0.1", 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
-
-
-def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
-    """SURVEY 8e end to end on one GPU box: 2 processes share cuda:0, each takes its shard of ONE ragged contig set from
-    shard_contigs, the lists are all-gathered (RCCL through the C ABI; gloo if RCCL refuses two ranks on one device) and
-    every rank's merged index equals the single-process index bit for bit"""
-    import pgrtk_amd as P
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import exchange_worker as W
-    ref_b = P.Batch.synthetic(W.LENS, seed=W.SEED, ctx=gpu_ctx)
-    ref = P.Index(P.make_spec(), ctx=gpu_ctx)
-    ref.add_resident(ref_b)
-    ref.finalize()
-    want = ref.download()
-    assert len(want) > 30_000
-    used = None
-    for transport in ("abi", "gloo"):
-        with tempfile.TemporaryDirectory() as d:
-            port = _free_port()
-            env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-            procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), transport, str(r), "2",
-                                       str(port), d], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env) for r in range(2)]
-            outs, ok = [], True
-            for p in procs:
-                try:
-                    o, _ = p.communicate(timeout=240)
-                except subprocess.TimeoutExpired:
-                    p.kill()
-                    o, _ = p.communicate()
-                    ok = False
-                outs.append(o.decode(errors="replace"))
-                ok = ok and p.returncode == 0
-            if not ok:
-                if transport == "abi":
-                    print("RCCL path with two ranks on one device failed, falling back to gloo:\n" + "\n".join(outs)[-1500:])
-                    continue
-                raise AssertionError("\n".join(outs)[-3000:])
-            for r in range(2):
-                got = np.load(os.path.join(d, "records_%d.npy" % r))
-                assert len(got) == len(want)
-                for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
-                    assert np.array_equal(got[f], want[f]), (transport, r, f)
-            used = transport
-            break
-    assert used is not None
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "two_rank_transport.txt"), "w") as f:
-        f.write("two-rank sharded build (2 processes, one device) verified over: %s\n" % used)
-
-
-def test_pgr_mdb_ranks_through_the_c_abi_exchange(tmp_path):
-    """host/pgr_mdb.cpp --ranks: forked rank processes, unique id through pipes, pgr_exchange_shard_records round after round
-    (the key ranges fixed by the first round), every rank writes its shard, the parent concatenates them -- no Python in the
-    sharded build.  One GPU here, so one rank (RCCL refuses two ranks on one device); the .mdb must be byte-identical to the
-    plain build's.  --prepack: the host program packs the bases itself and hands over 2-bit planes (pgr_index_add_packed)."""
-    exe = os.path.join(ROOT, "pgr-tk_amd", "bin", "pgr-mdb")
-    fl = tmp_path / "files.txt"
-    fl.write_text(os.path.join(ROOT, "tests", "golden", "test_seqs.fa") + "\n")
-    for tag, extra in (("plain", []), ("ranks", ["--ranks", "1", "--devices", "0", "--force-exchange", "--batch-bp", "60000"]),
-                       ("prepack", ["--prepack"]),
-                       ("ranks_prepack", ["--ranks", "1", "--force-exchange", "--prepack", "--batch-bp", "100000"])):
-        r = subprocess.run([exe, str(fl), str(tmp_path / tag)] + extra, capture_output=True, text=True, timeout=300)
-        assert r.returncode == 0, r.stderr[-2000:]
-    for tag in ("ranks", "prepack", "ranks_prepack"):
-        assert (tmp_path / "plain.mdb").read_bytes() == (tmp_path / (tag + ".mdb")).read_bytes(), tag
-        assert (tmp_path / "plain.midx").read_bytes() == (tmp_path / (tag + ".midx")).read_bytes(), tag
-    assert not list(tmp_path.glob("*.rank*"))  # the shard files are gone after the merge
-    r = subprocess.run([exe, str(fl), str(tmp_path / "x"), "--ranks", "1", "--force-exchange", "--reference-sid-quirk"],
-                       capture_output=True, text=True, timeout=60)
-    assert r.returncode == 2 and "cannot be combined" in r.stderr
-    assert len((tmp_path / "plain.mdb").read_bytes()) > 10_000
-
-
-def test_bench_strong_mode_plumbing():
-    """bench.py --strong on one rank through the process-group code path (RCCL world 1, pgr_exchange_*)"""
-    import json
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
-                        "--contigs", "24", "--contig-len", "1000000", "--strong", "--force-dist", "--queries", "0",
-                        "--no-cpu-baseline", "--no-extras"], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, MASTER_PORT=str(_free_port())))
-    assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.split("\n") if l.startswith('{"metric"')][-1])
-    assert line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 24_000_000 and line["value"] > 0
-
-
-def test_config5_slice_one_gpus_share(oracle, gpu_ctx):
-    """BASELINE.json configs[4] (94 x 3 Gbp over 8 GPUs) as ONE GPU's share: 3525 x 10 Mbp (seed 5) streamed in 4 resident
-    batches into one index.  Density, sortedness, record count == sum(shimmers - 1), and content == the CPU checker on
-    48 sampled contigs (128-bit checksums of their shimmer lists)."""
-    import json
-    import time
-    import pgrtk_amd as P
-    n_total, L, seed = 3525, 10_000_000, 5
-    sp = P.make_spec()
-    ix = P.Index(sp, ctx=gpu_ctx)
-    rng = np.random.default_rng(55)
-    sample = sorted(int(v) for v in rng.choice(n_total, 48, replace=False))
-    sums, counts, n_shmmr, n_pairs = {}, {}, 0, 0
-    t_shmmr = 0.0
-    t0 = time.perf_counter()
-    for b0 in range(0, n_total, 900):
-        ids = list(range(b0, min(n_total, b0 + 900)))
-        batch = P.Batch.synthetic([L] * len(ids), seed=seed, contig0=b0, ctx=gpu_ctx)
-        t1 = time.perf_counter()
-        sh = batch.shmmrs(sp)
-        t_shmmr += time.perf_counter() - t1
-        cs, off = sh.checksum(), sh.offsets()
-        for c in sample:
-            if b0 <= c < b0 + len(ids):
-                sums[c] = cs[c - b0].copy()
-                counts[c] = int(off[c - b0 + 1] - off[c - b0])
-        n_shmmr += sh.count
-        n_pairs += sh.n_pairs
-        del sh
-        ix.add_resident(batch, sids=ids)
-        batch.close()
-    ix.finalize()
-    t_all = time.perf_counter() - t0
-    bp = n_total * L
-    assert ix.n_records == n_pairs == n_shmmr - n_total
-    assert 0.0029 < n_shmmr / bp < 0.0032  # SURVEY 8: 0.003035 final shimmers per base
-    recs = ix.download()
-    key = recs["h0"].astype(np.uint64)
-    assert bool(np.all(key[1:] >= key[:-1]))
-    same = (recs["h0"][1:] == recs["h0"][:-1]) & (recs["h1"][1:] == recs["h1"][:-1])
-    assert bool(np.all(recs["h1"][1:][recs["h0"][1:] == recs["h0"][:-1]] >= recs["h1"][:-1][recs["h0"][1:] == recs["h0"][:-1]]))
-    assert bool(np.all(recs["sid"][1:][same] >= recs["sid"][:-1][same]))
-    # content: the checker generates the sampled contigs itself
-    osp = oracle.spec()
-    for c in sample:
-        ref = oracle.sequence_to_shmmrs(0, oracle.synth_contig(seed, c, L), osp)
-        assert len(ref) == counts[c] and np.array_equal(oracle.shmmr_checksum(ref), sums[c]), c
-    line = {"workload": "configs[4] slice of one GPU: %d x %d bp, seed %d, 4 resident batches into one index" % (n_total, L, seed),
-            "bp": bp, "shimmers": n_shmmr, "records": int(ix.n_records), "keys": int(ix.n_keys),
-            "shmmr_s": t_shmmr, "total_s_incl_generation_and_sort": t_all, "Gbp_per_s_shimmers": bp / t_shmmr / 1e9,
-            "contigs_content_checked": len(sample)}
-    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "config5_slice.json"), "w") as f:
-        json.dump(line, f)
-    print(json.dumps(line))
 
 
 def _random_group(rng, n, dup=0.15):

@@ -6,7 +6,6 @@ Reference paths under test: shmmrutils::sequence_to_shmmrs (pgr-db/src/shmmrutil
 """
 import json
 import os
-import subprocess
 import sys
 
 import numpy as np
@@ -114,169 +113,6 @@ def test_packed_input_pipelined_large_batch(oracle, gpu_ctx):
         _same(oracle.sequence_to_shmmrs(i, seqs[i].tobytes(), sp), got[i], "oracle contig %d" % i)
 
 
-def test_config2_full_size(oracle, gpu_ctx):
-    """BASELINE.json configs[1] at full size: 1000 x 10 Mbp (seed 2), the final shimmer lists of ALL contigs have the
-    checksums the CPU restatement computes for the same contigs (128 bits per contig, order sensitive)"""
-    import bench
-    import pgrtk_amd as P
-    n, L, seed = 1000, 10_000_000, 2
-    spec = P.make_spec(80, 56, 4, 64)
-    batch = P.Batch.synthetic([L] * n, seed=seed, ctx=gpu_ctx)
-    sh = batch.shmmrs(spec)
-    off = sh.offsets()
-    gpu_counts = (off[1:] - off[:-1]).astype(np.uint64)
-    gpu_sums = sh.checksum()
-    cores = bench.effective_cpus()
-    counts, sums, _ = oracle.synth_checksums_threads(oracle.spec(80, 56, 4, 64), n, seed, 0, L, cores)
-    assert np.array_equal(counts, gpu_counts)
-    bad = np.nonzero(~np.all(sums == gpu_sums, axis=1))[0]
-    assert bad.size == 0, "contigs with a different shimmer list: %s" % bad[:10]
-    assert 2.9e7 < int(gpu_counts.sum()) < 3.2e7  # SURVEY 8d: ~3.0e7 final shimmers
-
-
-def test_config3_full_size(oracle, gpu_ctx):
-    """BASELINE.json configs[2] at full size: GPU index of the 1000 x 10 Mbp contigs, 10 000 x 10 kbp queries (half reverse
-    complemented).  The CPU restatement builds the index of a 64-contig subset; 1024 more queries cut from that subset go
-    through both, chain for chain (targets, chains, hit pairs, f32 score bits).  Every query of the big batch finds its
-    source contig."""
-    import bench
-    import pgrtk_amd as P
-    n, L, seed, S = 1000, 10_000_000, 2, 64
-    spec = P.make_spec(80, 56, 4, 64)
-    ids = list(range(n))
-    batch = P.Batch.synthetic([L] * n, seed=seed, ctx=gpu_ctx)
-    ix = P.Index(spec, ctx=gpu_ctx)
-    ix.add_resident(batch, sids=ids)
-    ix.finalize()
-    del batch
-    assert 2.8e7 < ix.n_records < 3.2e7
-    rng = np.random.default_rng(3)
-    cs, offs, qs = bench.make_queries(P, seed, ids, n, L, 10_000, 10_000, rng)
-    r = ix.query_hps_raw(qs, 0.025)
-    ok = 0
-    for qi in range(10_000):
-        sids = r["t_sid"][int(r["q_off"][qi]):int(r["q_off"][qi + 1])]
-        ok += int(int(cs[qi]) in set(int(v) for v in sids))
-    assert ok >= 9_990, ok  # (a 10 kbp window holds >= 2 shimmer pairs of its source with near certainty)
-    # oracle on a subset
-    cores = bench.effective_cpus()
-    oix = oracle.Index(oracle.spec(80, 56, 4, 64))
-    oix.add_synth_threads(S, 0, seed, 0, L, cores)
-    oix.finalize()
-    rng2 = np.random.default_rng(31)
-    cs2, offs2, qs2 = bench.make_queries(P, seed, ids[:S], S, L, 1024, 10_000, rng2)
-    qlist = [qs2.buf[int(qs2.off[i]):int(qs2.off[i + 1])] for i in range(1024)]
-    ref, _ = oracle.query_batch_threads(oix, qlist, 0.025, cores)
-    r2 = ix.query_hps_raw(qs2, 0.025)
-    n_same = 0
-    for qi in range(1024):
-        want = [(sid, [(np.float32(sc).tobytes(), [tuple(h) for h in hps]) for sc, hps in chains]) for sid, chains in ref[qi]]
-        got = [(sid, ch) for sid, ch in bench.chains_of(r2, qi) if sid < S]  # the full index may add other targets
-        n_same += int(got == want)
-    assert n_same == 1024, n_same
-
-
-def _free_port():
-    import socket
-    sk = socket.socket()
-    sk.bind(("127.0.0.1", 0))
-    p = sk.getsockname()[1]
-    sk.close()
-    return p
-
-
-def _run_ranks(args_of_rank, timeout=300):
-    procs = [subprocess.Popen(a, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-             for a in args_of_rank]
-    outs, ok = [], True
-    for p in procs:
-        try:
-            o, _ = p.communicate(timeout=timeout)
-        except subprocess.TimeoutExpired:
-            p.kill()
-            o, _ = p.communicate()
-            ok = False
-        outs.append(o.decode(errors="replace"))
-        ok = ok and p.returncode == 0
-    return ok, outs
-
-
-def test_key_range_sharded_index_two_ranks_equals_single_process(gpu_ctx, tmp_path):
-    """SURVEY 8e "key-range partitioned": 2 processes on this box's one GPU, each derives the pair records of its shard of ONE
-    ragged contig set, the records travel to the rank owning their range of first hashes, each rank sorts only its range.
-    The per-rank CSRs concatenated in rank order == the single-process index bit for bit; each rank sorted about half of
-    the records; nothing was lost or duplicated (checksums); the replicated index rebuilt from the shards is the same again.
-    RCCL refuses two ranks on one device, so the transport is gloo there (the library path runs with world 1 below)."""
-    import pgrtk_amd as P
-    sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import exchange_worker as W
-    ref_b = P.Batch.synthetic(W.LENS, seed=W.SEED, ctx=gpu_ctx)
-    ref = P.Index(P.make_spec(), ctx=gpu_ctx)
-    ref.add_resident(ref_b)
-    ref.finalize()
-    want = ref.download()
-    used = None
-    for transport in ("shard-abi", "shard-gloo"):
-        d = tmp_path / transport
-        d.mkdir()
-        port = _free_port()
-        ok, outs = _run_ranks([[sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), transport, str(r), "2", str(port),
-                                str(d)] for r in range(2)])
-        if not ok:
-            if transport == "shard-abi":
-                print("RCCL with two ranks on one device failed (expected), gloo transport next:\n" + "\n".join(outs)[-800:])
-                continue
-            raise AssertionError("\n".join(outs)[-3000:])
-        parts = [np.load(str(d / ("records_%d.npy" % r))) for r in range(2)]
-        meta = [json.load(open(str(d / ("meta_%d.json" % r)))) for r in range(2)]
-        got = np.concatenate(parts)
-        assert len(got) == len(want)
-        for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
-            assert np.array_equal(got[f], want[f]), (transport, f)
-        # each rank sorted about half (sampled splitters: within 15 % on 36 k records)
-        assert all(abs(len(p) - len(want) / 2) < 0.15 * len(want) for p in parts), [len(p) for p in parts]
-        assert sum(m["n_sent"] for m in meta) == len(want) == sum(m["n_shard"] for m in meta)
-        M = (1 << 64) - 1
-        for i in (0, 1):
-            assert sum(m["sent"][i] for m in meta) & M == sum(m["shard"][i] for m in meta) & M
-        assert meta[0]["splitters"] == meta[1]["splitters"] and len(meta[0]["splitters"]) == 1
-        assert meta[0]["key_range"][1] < meta[0]["splitters"][0] <= meta[1]["key_range"][0]
-        assert meta[0]["n_keys"] + meta[1]["n_keys"] == ref.n_keys == meta[0]["full_keys"]
-        for r in range(2):
-            rep = np.load(str(d / ("replicated_%d.npy" % r)))
-            assert len(rep) == len(want) and all(np.array_equal(rep[f], want[f]) for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"))
-        used = transport
-        break
-    assert used is not None
-
-
-def test_shard_exchange_through_rccl_world_one(gpu_ctx):
-    """pgr_exchange_shard_records / pgr_exchange_allgather_index over RCCL itself (one rank: the collectives, the grouped
-    send / receive loop and the local block copy all run): the shard is the whole index"""
-    import torch
-    import pgrtk_amd as P
-    from pgrtk_amd import exchange
-    spec = P.make_spec()
-    b = P.Batch.synthetic([700_000, 1_300_000, 0, 64, 2_000_000], seed=23, ctx=gpu_ctx)
-    sh = b.shmmrs(spec)
-    recs = torch.zeros((sh.n_pairs, exchange.REC_WORDS), dtype=torch.int64, device="cuda:0")
-    n = sh.frag_recs_into(recs.data_ptr(), recs.shape[0])
-    xch = exchange.AbiExchange(gpu_ctx, 0, 1)
-    ix = P.Index(spec, ctx=gpu_ctx)
-    got, spl = xch.shard_records(recs.data_ptr(), n, ix)
-    assert got == n and spl == []
-    ix.finalize()
-    full = xch.allgather_index(ix)
-    xch.close()
-    ref = P.Index(spec, ctx=gpu_ctx)
-    ref.add_resident(b)
-    ref.finalize()
-    want = ref.download()
-    for cand in (ix.download(), full.download()):
-        assert len(cand) == len(want) and all(np.array_equal(cand[f], want[f]) for f in ("h0", "h1", "frg_id", "sid", "bgn", "end"))
-    assert ix.records_checksum() == ref.records_checksum() == P.records_checksum(recs.data_ptr(), n, ctx=gpu_ctx)
-
-
 def test_shard_partition_is_stable_and_complete(gpu_ctx):
     """pgr_shard_partition with hand-made splitters on 3 and 8 destinations: every record lands in the range
     [splitter[d-1], splitter[d]) of its first hash, inside a destination the append order is kept"""
@@ -304,29 +140,6 @@ def test_shard_partition_is_stable_and_complete(gpu_ctx):
         assert [int(c) for c in counts] == [int((dest == d).sum()) for d in range(world)]
         want = np.concatenate([host[dest == d] for d in range(world)])  # stable
         assert got.tobytes() == want.tobytes()
-
-
-def test_bench_two_ranks_line_is_gradeable():
-    """the N-rank bench line before a multi-GPU driver ever runs it: 2 ranks on this box's one GPU (gloo transport),
-    every rank's shimmer lists checked against the CPU restatement, the exchanged record set against what was sent, the
-    merge inside the timed value with its parts printed"""
-    port = _free_port()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
-           "--steps", "2", "--warmup", "1", "--contigs", "40", "--contig-len", "2000000", "--queries", "400"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["bp_per_step_all_gpus"] == 160_000_000
-    assert line["merge_ms"] > 0 and line["exchange_ms"] > 0 and "roofline" in line
-    cb = line["cpu_baseline"]
-    assert cb["content_match"] is True and cb["content_match_all_ranks"] is True and cb["contigs_checked_all_ranks"] == 80
-    ex = line["exchange"]
-    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True
-    assert ex["records_sent_all_ranks"] == ex["records_in_shards"] == sum(ex["records_per_shard"])
-    assert ex["largest_shard_over_mean"] < 1.2
-    q = line["query"]
-    assert "error" not in q and q["queries_with_best_chain_on_source"] >= 396 and q["index_records"] == ex["records_in_shards"]
 
 
 def test_small_call_path_against_oracle_and_general_path(oracle, gpu_ctx, monkeypatch):

@@ -1,9 +1,6 @@
 """Round-4 parity tests (run with -m gpu on a MI355X): BASELINE.json configs[0] through the pgr-mdb counterparts
 (`--synthetic NxL --seed S`), the remaining SeqIndexDB methods of row H3."""
-import hashlib
 import os
-import subprocess
-import time
 
 import numpy as np
 import pytest
@@ -18,66 +15,6 @@ BIN = os.path.join(ROOT, "pgr-tk_amd", "bin")
 def gpu_ctx():
     import pgrtk_amd as P
     return P.default_context(0)
-
-
-def _canonical_mdb_hash(m):
-    """sha256 over the canonically sorted content of an .mdb (keys ascending, per-key signatures in file order)"""
-    h = hashlib.sha256()
-    for key in sorted(m):
-        h.update(np.array(key, dtype="<u8").tobytes())
-        h.update(np.array(m[key], dtype="<u4").tobytes())
-    return h.hexdigest()
-
-
-def test_config1_pgr_mdb_synthetic_10x1mbp_seed1(oracle, gpu_ctx, tmp_path):
-    """BASELINE.json configs[0] / BASELINE.md section 4 row 1: pgr-mdb on 10 x 1 Mbp synthetic contigs, seed 1,
-    ShmmrSpec (80, 56, 4, 64).  The C++ host program with `--synthetic 10x1000000 --seed 1` (contigs generated on the
-    device), the Python CLI with the same flags, and the C++ program on the FASTA that `--write-fasta` produced all write
-    the same .mdb, and its content equals the frag_map of the CPU restatement (pgr-db/src/seq_db.rs:541-615: index-only
-    path, per-contig fragment ids) built from the oracle's own generator.  Reported: the oracle's Gbp/s on 1 thread and
-    on all CPUs the process may use, and the content hash."""
-    from pgrtk_amd import cli
-    N, L, SEED = 10, 1_000_000, 1
-    fa = str(tmp_path / "synth.fa")
-    p_cpp, p_py, p_fa = (str(tmp_path / n) for n in ("cpp", "py", "fa"))
-    r = subprocess.run([os.path.join(BIN, "pgr-mdb"), "--synthetic", "%dx%d" % (N, L), "--seed", str(SEED), "--write-fasta", fa,
-                        p_cpp], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr
-    cli.main(["mdb", "--synthetic", "%dx%d" % (N, L), "--seed", str(SEED), p_py])
-    lst = tmp_path / "list.txt"
-    lst.write_text(fa + "\n")
-    r = subprocess.run([os.path.join(BIN, "pgr-mdb"), str(lst), p_fa], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr
-    mdb = open(p_cpp + ".mdb", "rb").read()
-    assert mdb == open(p_py + ".mdb", "rb").read() == open(p_fa + ".mdb", "rb").read()
-    assert open(p_cpp + ".midx").read() == open(p_py + ".midx").read()
-    midx = [l.split("\t") for l in open(p_cpp + ".midx").read().splitlines()]
-    assert midx == [[str(c), str(L), "synth_%d_%d" % (SEED, c), "synthetic:%dx%d:seed=%d" % (N, L, SEED)] for c in range(N)]
-    assert [l.split("\t")[:3] for l in open(p_fa + ".midx").read().splitlines()] == [m[:3] for m in midx]
-    # the FASTA holds the generator's bytes
-    recs = oracle.read_fasta(fa)
-    assert len(recs) == N and all(s == oracle.synth_contig(SEED, c, L).tobytes() for c, (_, s) in enumerate(recs))
-
-    # the CPU restatement's frag_map of the same contigs: 1 thread, then all CPUs (one task per contig = rayon par_iter)
-    sp = oracle.spec(80, 56, 4, 64)
-    rates = {}
-    import bench
-    n_cpu = bench.effective_cpus()  # scheduler affinity capped by the cgroup quota (the GPU boxes show 256 CPUs and grant 16)
-    for threads in (1, n_cpu):
-        oix = oracle.Index(sp)
-        t0 = time.perf_counter()
-        oix.add_synth_threads(N, 0, SEED, 0, L, threads)
-        rates[threads] = N * L / (time.perf_counter() - t0) / 1e9
-    ref = oix.records()
-    spec_t, m = oracle.read_mdb(p_cpp + ".mdb")
-    assert spec_t == (80, 56, 4, 64, 0)
-    exp = {}
-    for rr in ref:  # sorted by (h0, h1, sid, frg_id): per-key order = insertion order of seq_db.rs:605-612
-        exp.setdefault((int(rr["h0"]), int(rr["h1"])), []).append((int(rr["frg_id"]), int(rr["sid"]), int(rr["bgn"]),
-                                                                   int(rr["end"]), int(rr["orient"])))
-    assert m == exp and sum(len(v) for v in m.values()) == len(ref) > 25000
-    print("\nconfigs[0]: 10 x 1 Mbp seed 1 -> %d pair records, %d keys; oracle %.4f Gbp/s on 1 thread, %.4f Gbp/s on %d threads; "
-          ".mdb canonical content sha256 %s" % (len(ref), len(m), rates[1], rates[n_cpu], n_cpu, _canonical_mdb_hash(m)))
 
 
 def test_seqindexdb_remaining_methods(oracle, gpu_ctx, golden_dir, tmp_path):
@@ -107,51 +44,6 @@ def test_seqindexdb_remaining_methods(oracle, gpu_ctx, golden_dir, tmp_path):
     assert not os.path.exists(str(tmp_path / "none.mdb"))
 
 
-def test_bench_self_spawns_its_ranks_without_a_launcher():
-    """`python bench.py --gpus 2` with NO torchrun around it (the shape of the driver's N = 1 command with another N) starts
-    its own ranks and prints a gradeable line: 2 ranks on this box's one GPU (gloo transport), merge inside the value,
-    every rank's contigs checked, the exchange verified, the transport named."""
-    import json
-    import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "2",
-           "--warmup", "1", "--contigs", "30", "--contig-len", "2000000", "--queries", "200"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
-    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["bp_per_step_all_gpus"] == 120_000_000
-    assert line["merge_ms"] > 0 and line["exchange_ms"] > 0
-    ex = line["exchange"]
-    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True
-    assert ex["transport"].startswith("torch.distributed") and ex["exchange_fallback"] is None
-    assert ex["rccl_ranks_in_the_librarys_communicator"] == 0  # (gloo on one device: the library's RCCL path is not taken)
-    assert line["cpu_baseline"]["content_match_all_ranks"] is True
-
-
-def test_exchange_watchdog_times_out_instead_of_hanging(gpu_ctx):
-    """a rank whose peers never arrive: ncclCommInitRank for world = 2 with only this rank present would block for ever;
-    with the context option exchange_timeout_s the call comes back with an error that names the timeout (the bench then
-    falls back to the torch.distributed transport).  On its own context: the worker thread stays inside RCCL."""
-    import ctypes as C
-    import pgrtk_amd as P
-    from pgrtk_amd._ffi import lib
-    ctx = P.Context(0)
-    ctx.set_option("exchange_timeout_s", 3)
-    assert ctx.get_option("exchange_timeout_s") == 3
-    idb = np.zeros(128, dtype=np.uint8)
-    ctx.check(lib().pgr_exchange_unique_id(ctx.handle, idb.ctypes.data))
-    h = C.c_void_p()
-    t0 = time.perf_counter()
-    rc = lib().pgr_exchange_create(ctx.handle, idb.ctypes.data, 0, 2, C.byref(h))
-    dt = time.perf_counter() - t0
-    assert rc != 0 and not h.value and 2.5 < dt < 30
-    assert b"did not return within 3 s" in lib().pgr_last_error(ctx.handle)
-    with pytest.raises(KeyError):
-        ctx.get_option("no_such_option")
-    with pytest.raises(P.PgrError):
-        ctx.set_option("no_such_option", 1)
-
-
 def test_index_sorts_non_canonical_external_records(gpu_ctx):
     """pgr_index_add_records takes records from outside (other GPUs, other programs): nothing says h0 <= h1 there.  The
     radix passes are bounded by max(h0, h1) over ALL records (round 3 used max(h1): a record whose h0 exceeded every h1
@@ -178,32 +70,6 @@ def test_index_sorts_non_canonical_external_records(gpu_ctx):
         got = ix.download()
         for f in ("h0", "h1", "sid", "frg_id", "bgn", "end"):
             assert np.array_equal(got[f], want[f]), f
-
-
-def test_eight_ranks_strong_scaling_plumbing_on_one_device():
-    """world = 8 before an 8-GPU node ever runs it: `bench.py --gpus 8 --strong` (self-spawned, gloo, every rank on this box's one
-    GPU) partitions ONE contig set with the greedy partitioner, every rank computes its shard, the records travel by key range
-    through an 8 x 8 all-to-all, eight shards are sorted and all-gathered into the replicated query index.  Every rank's
-    contigs are checked against the CPU restatement, the exchanged record set against what was sent.  (The same command at
-    full size -- 1000 x 10 Mbp, 30.4 M records -- is kept under profiles/r04_dist/.)"""
-    import json
-    import sys
-    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--single-device", "--strong", "--steps", "1",
-           "--warmup", "1", "--contigs", "67", "--contig-len", "1500000", "--queries", "240"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(env, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, r.stderr[-3000:]
-    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
-    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 67 * 1_500_000
-    ex = line["exchange"]
-    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True and len(ex["records_per_shard"]) == 8
-    assert ex["records_sent_all_ranks"] == ex["records_in_shards"] == sum(ex["records_per_shard"]) > 250_000
-    assert ex["largest_shard_over_mean"] < 1.25
-    cb = line["cpu_baseline"]
-    assert cb["content_match_all_ranks"] is True and cb["contigs_checked_all_ranks"] == 67
-    q = line["query"]
-    assert "error" not in q and q["queries_with_best_chain_on_source"] >= 236 and q["index_records"] == ex["records_in_shards"]
-
 
 
 def _same(ref, got, what=""):

@@ -6,6 +6,7 @@ import os
 import numpy as np
 import pytest
 
+import procutil
 import seqgen
 
 pytestmark = pytest.mark.gpu
@@ -236,41 +237,6 @@ def test_packed_input_from_pinned_host_memory_and_the_validity_check(oracle, gpu
                     _same_mm(r, g, "contig %d %s" % (i, what))
 
 
-def _bench_line(extra, nproc, timeout=900):
-    import json
-    import os
-    import socket
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with socket.socket() as so:
-        so.bind(("127.0.0.1", 0))
-        port = so.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(nproc)] + extra
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
-    assert r.returncode == 0, r.stderr[-3000:]
-    return json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
-
-
-def test_merge_of_step_i_beside_the_tiles_of_step_i_plus_1():
-    """bench.py's overlapped leg (N > 1): the exchange + shard sort of a step on a worker thread and the first context while the
-    next step's shimmer pipeline runs on a second context.  Two ranks on this box's one GPU over gloo, and one rank through the
-    library's own RCCL communicator (world = 1): the last shard of the leg has the checksum and the size of the timed loop's."""
-    line = _bench_line(["--backend", "gloo", "--single-device", "--steps", "3", "--warmup", "1", "--contigs", "40", "--contig-len", "2000000",
-                        "--queries", "0"], 2)
-    ov = line["overlapped"]
-    assert "error" not in ov, ov
-    assert ov["content_match_vs_timed_loop"] is True and line["value_overlapped"] > 0 and ov["steps"] >= 4
-    assert line["exchange"]["content_match"] is True
-    line = _bench_line(["--force-dist", "--steps", "3", "--warmup", "1", "--contigs", "60", "--contig-len", "2000000", "--queries", "0",
-                        "--no-cpu-baseline"], 1)
-    ov = line["overlapped"]
-    assert "error" not in ov, ov
-    assert ov["content_match_vs_timed_loop"] is True
-    assert line["exchange"]["rccl_ranks_in_the_librarys_communicator"] == 1
-
-
 def test_early_island_round_is_dropped_cleanly_when_the_flags_add_islands(oracle, gpu_ctx):
     """The first round of the islands around non-ACGT bytes starts beside the tile kernel (ShmmrJob::stage1, IslandRun::begin on the
     side stream); a tile that then reports a palindromic k-mer makes the job list the islands again and start over -- after the
@@ -440,7 +406,6 @@ def test_pgr_mdb_on_a_genome_like_fasta_equals_the_oracles_frag_map(oracle, gpu_
     sub-batches, exact islands of both kinds) and the Python CLI write the same .mdb, whose content is the frag_map of the CPU
     restatement of the same sequences (pgr-db/src/seq_db.rs:541-615)."""
     import gzip
-    import subprocess
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import genome_like_bench as G
@@ -463,7 +428,7 @@ def test_pgr_mdb_on_a_genome_like_fasta_equals_the_oracles_frag_map(oracle, gpu_
     lst = tmp_path / "list.txt"
     lst.write_text(fa + "\n")
     p_cpp, p_py = str(tmp_path / "cpp"), str(tmp_path / "py")
-    r = subprocess.run([os.path.join(ROOT, "pgr-tk_amd", "bin", "pgr-mdb"), str(lst), p_cpp], capture_output=True, text=True, timeout=600)
+    r = procutil.run_bounded([os.path.join(ROOT, "pgr-tk_amd", "bin", "pgr-mdb"), str(lst), p_cpp], timeout=180)
     assert r.returncode == 0, r.stderr
     cli.main(["mdb", str(lst), p_py])
     assert open(p_cpp + ".mdb", "rb").read() == open(p_py + ".mdb", "rb").read()
@@ -607,7 +572,6 @@ def test_query_batches_through_the_pipe_equal_the_synchronous_calls(oracle, gpu_
 def test_pgr_query_in_batches_through_the_pipe_writes_the_same_files(oracle, gpu_ctx, golden_dir, tmp_path):
     """host/pgr_query.cpp --query-batch N: more than N queries go to the GPU in batches of N, two in flight
     (pgr_batch_from_ascii + pgr_pipe_submit_query / pgr_pipe_collect_query); every .hit / .fa file is the one the single call writes."""
-    import subprocess
     bindir = os.path.join(ROOT, "pgr-tk_amd", "bin")
     fa = os.path.join(golden_dir, "test_seqs.fa")
     recs = oracle.read_fasta(fa)
@@ -626,8 +590,8 @@ def test_pgr_query_in_batches_through_the_pipe_writes_the_same_files(oracle, gpu
     for tag, extra in (("one", []), ("b1", ["--query-batch", "1"]), ("b3", ["--query-batch", "3"]), ("b4", ["--query-batch", "4"])):
         d = tmp_path / tag
         d.mkdir()
-        r = subprocess.run([os.path.join(bindir, "pgr-query"), fa, str(qfa), str(d / "o"), "--fastx_file"] + extra,
-                           capture_output=True, text=True, timeout=600)
+        r = procutil.run_bounded([os.path.join(bindir, "pgr-query"), fa, str(qfa), str(d / "o"), "--fastx_file"] + extra,
+                           timeout=180)
         assert r.returncode == 0, r.stderr
         outs[tag] = {f: open(d / f).read() for f in sorted(os.listdir(d))}
     assert len(outs["one"]) == 22 and any(len(v.splitlines()) > 1 for v in outs["one"].values())

@@ -9,6 +9,7 @@ The reference has no expected output for any of these: parity is oracle <-> prod
 import numpy as np
 import pytest
 
+import procutil
 import seqgen
 
 pytestmark = pytest.mark.gpu
@@ -235,19 +236,18 @@ def test_cli_pbundle_decomp(oracle, gpu_ctx, tmp_path):
     assert open(tmp_path / "out4.bed").read().splitlines()[1:] == open(tmp_path / "out2.bed").read().splitlines()[1:]
     # the C++ host program above the C ABI writes the same files
     import os
-    import subprocess
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgr-tk_amd", "bin", "pgr-pbundle-decomp")
     assert os.path.exists(exe), "host programs not built: python __graft_entry__.py build"
-    subprocess.run([exe, str(fa), str(tmp_path / "cc")] + argv[3:], check=True)
+    procutil.run_bounded([exe, str(fa), str(tmp_path / "cc")] + argv[3:], check=True, timeout=120)
     assert open(tmp_path / "cc.bed").read().splitlines()[1:] == bed[1:]
     assert open(tmp_path / "cc.ctg.summary.tsv").read() == open(tmp_path / "out.ctg.summary.tsv").read()
-    subprocess.run([exe, str(fa), str(tmp_path / "cc2")] + argv[3:] + ["-d", str(fb)], check=True)
+    procutil.run_bounded([exe, str(fa), str(tmp_path / "cc2")] + argv[3:] + ["-d", str(fb)], check=True, timeout=120)
     assert open(tmp_path / "cc2.bed").read().splitlines()[1:] == open(tmp_path / "out2.bed").read().splitlines()[1:]
     assert open(tmp_path / "cc2.ctg.summary.tsv").read() == open(tmp_path / "out2.ctg.summary.tsv").read()
     inc = tmp_path / "inc.txt"
     inc.write_text("hap03\nhap07\n")
     cli.main(argv[:2] + [str(tmp_path / "out3")] + argv[3:] + ["-i", str(inc)])
-    subprocess.run([exe, str(fa), str(tmp_path / "cc3")] + argv[3:] + ["-i", str(inc)], check=True)
+    procutil.run_bounded([exe, str(fa), str(tmp_path / "cc3")] + argv[3:] + ["-i", str(inc)], check=True, timeout=120)
     assert open(tmp_path / "cc3.bed").read().splitlines()[1:] == open(tmp_path / "out3.bed").read().splitlines()[1:]
     assert len(open(tmp_path / "cc3.ctg.summary.tsv").read().splitlines()) == 3
     assert open(tmp_path / "cc3.ctg.summary.tsv").read() == open(tmp_path / "out3.ctg.summary.tsv").read()

@@ -1,0 +1,403 @@
+"""Process and RCCL plumbing of the multi-GPU path -- collected LAST on purpose: a
+stuck rendezvous, a forked rank or a cold 570 MB librccl.so.1 on a fresh box must never stand between `pytest -x` and the parity
+tests of the hot path.  Every child process here is bounded (tests/procutil.py): library watchdogs at 20/30 s through the
+environment, the test's own limit well above them, the whole process group killed on a time-out and the stacks of its processes
+in the failure message.
+
+What runs where: an exchange of ONE rank is plain copies on the exchange's stream (csrc/exchange.hip: RCCL not loaded); the
+tests that want the real communicator with one rank say so (context option / PGR_EXCHANGE_RCCL_WORLD1=1).  Two ranks on this
+box's one GPU go over gloo (RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import sys
+import tempfile
+import time
+
+import numpy as np
+import pytest
+
+import procutil
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "pgr-tk_amd", "bin")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run_ranks(args_of_rank, timeout=120):
+    """one bounded process per rank; (all exited 0, their outputs)"""
+    procs = [procutil.popen_bounded(a) for a in args_of_rank]
+    outs, ok = [], True
+    t_end = time.time() + timeout
+    for p in procs:
+        o, _, timed_out, stacks = procutil.communicate_bounded(p, max(1.0, t_end - time.time()))
+        outs.append((o or b"").decode(errors="replace") + ("\n[timed out; stacks]\n" + stacks if timed_out else ""))
+        ok = ok and not timed_out and p.returncode == 0
+    return ok, outs
+
+
+# a bench.py that is to spawn its own ranks must not see a launcher's variables (procutil drops keys set to None)
+_NO_LAUNCHER = {k: None for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+
+
+def _bench_line(extra, nproc, timeout=240):
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(nproc)] + extra
+    r = procutil.run_bounded(cmd, timeout=timeout, check=True)
+    return json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_exchange_abi_one_rank(gpu_ctx, rccl):
+    """pgr_exchange_* with world = 1 on the real device, in this process: the collective runs on the exchange's stream, the
+    gathered list equals the local one.  rccl=False: the default of one rank (copies, RCCL not loaded by the library);
+    rccl=True: option exchange_rccl_world1 -- a real communicator (this process has PyTorch's librccl.so mapped already, the
+    library takes that copy)"""
+    import torch
+    import pgrtk_amd as P
+    from pgrtk_amd import exchange
+    b = P.Batch.synthetic([500_000, 70_000], seed=3, ctx=gpu_ctx)
+    sh = b.shmmrs(P.make_spec())
+    cap = sh.count + 100
+    local = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
+    n = sh.copy_into(local.data_ptr(), cap, rids=[17, 5])
+    out = torch.zeros((cap, 2), dtype=torch.int64, device="cuda:0")
+    with gpu_ctx.options(exchange_rccl_world1=int(rccl), exchange_timeout_s=60, exchange_collective_timeout_s=60):
+        xch = exchange.AbiExchange(gpu_ctx, 0, 1)
+        assert xch.uses_rccl == rccl
+        for _ in range(2):  # the handle is reusable step after step
+            out.zero_()
+            g, counts = xch.allgather_async(local, n, out, cap).wait()
+            assert counts == [n] and bool((g == local[:n]).all())
+        xch.close()
+    mm, off = sh.download()
+    got = np.frombuffer(g.cpu().numpy().tobytes(), dtype=P.MM128)
+    assert np.array_equal(got["x"], mm["x"])
+    assert set(int(v) for v in got["y"] >> np.uint64(32)) == {17, 5}
+
+
+def test_two_ranks_sharded_build_equals_single_process_index(gpu_ctx):
+    """SURVEY 8e end to end on one GPU box: 2 processes share cuda:0, each takes its shard of ONE ragged contig set from
+    shard_contigs, the lists are all-gathered (RCCL through the C ABI; gloo if RCCL refuses two ranks on one device) and
+    every rank's merged index equals the single-process index bit for bit"""
+    import pgrtk_amd as P
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import exchange_worker as W
+    ref_b = P.Batch.synthetic(W.LENS, seed=W.SEED, ctx=gpu_ctx)
+    ref = P.Index(P.make_spec(), ctx=gpu_ctx)
+    ref.add_resident(ref_b)
+    ref.finalize()
+    want = ref.download()
+    assert len(want) > 30_000
+    used = None
+    for transport in ("abi", "gloo"):
+        with tempfile.TemporaryDirectory() as d:
+            port = _free_port()
+            ok, outs = _run_ranks([[sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), transport, str(r), "2",
+                                    str(port), d] for r in range(2)], timeout=90)
+            if not ok:
+                if transport == "abi":
+                    print("RCCL path with two ranks on one device failed, falling back to gloo:\n" + "\n".join(outs)[-1500:])
+                    continue
+                raise AssertionError("\n".join(outs)[-3000:])
+            for r in range(2):
+                got = np.load(os.path.join(d, "records_%d.npy" % r))
+                assert len(got) == len(want)
+                for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+                    assert np.array_equal(got[f], want[f]), (transport, r, f)
+            used = transport
+            break
+    assert used is not None
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "two_rank_transport.txt"), "w") as f:
+        f.write("two-rank sharded build (2 processes, one device) verified over: %s\n" % used)
+
+
+def _mdb_variants(tmp_path, variants, env=None, timeout=60):
+    exe = os.path.join(BIN, "pgr-mdb")
+    fl = tmp_path / "files.txt"
+    fl.write_text(os.path.join(ROOT, "tests", "golden", "test_seqs.fa") + "\n")
+    log = {}
+    for tag, extra in variants:
+        t0 = time.time()
+        r = procutil.run_bounded([exe, str(fl), str(tmp_path / tag)] + extra, timeout=timeout, env=env, check=True)
+        log[tag] = (round(time.time() - t0, 2), r.stderr)
+    return exe, fl, log
+
+
+def test_pgr_mdb_ranks_through_the_c_abi_exchange(tmp_path):
+    """host/pgr_mdb.cpp --ranks: one rank process per GPU (fork + exec of the program itself), pgr_exchange_shard_records round
+    after round (the key ranges fixed by the first round), every rank writes its shard, the parent concatenates them -- no Python
+    in the sharded build.  One GPU here, so one rank: its exchange is the library's one-rank form (copies on the exchange's
+    stream, RCCL not loaded -- the debug line says so); the .mdb must be byte-identical to the plain build's.  --prepack: the
+    host program packs the bases itself and hands over 2-bit planes (pgr_index_add_packed)."""
+    exe, fl, log = _mdb_variants(tmp_path, (("plain", []), ("ranks", ["--ranks", "1", "--devices", "0", "--force-exchange", "--batch-bp", "60000"]),
+                                            ("prepack", ["--prepack"]),
+                                            ("ranks_prepack", ["--ranks", "1", "--force-exchange", "--prepack", "--batch-bp", "100000"])),
+                                 env={"PGR_DEBUG": "1"})
+    assert "RCCL not loaded" in log["ranks"][1] and "RCCL not loaded" in log["ranks_prepack"][1]
+    for tag in ("ranks", "prepack", "ranks_prepack"):
+        assert (tmp_path / "plain.mdb").read_bytes() == (tmp_path / (tag + ".mdb")).read_bytes(), tag
+        assert (tmp_path / "plain.midx").read_bytes() == (tmp_path / (tag + ".midx")).read_bytes(), tag
+    assert not list(tmp_path.glob("*.rank*"))  # the shard files are gone after the merge
+    r = procutil.run_bounded([exe, str(fl), str(tmp_path / "x"), "--ranks", "1", "--force-exchange", "--reference-sid-quirk"], timeout=30)
+    assert r.returncode == 2 and "cannot be combined" in r.stderr
+    assert len((tmp_path / "plain.mdb").read_bytes()) > 10_000
+
+
+def test_pgr_mdb_killed_parent_leaves_no_rank_behind(tmp_path):
+    """a rank process dies with the program that started it (PR_SET_PDEATHSIG): what round 5's driver run was left with -- a
+    forked rank orphaned on the GPU after the test killed its parent -- cannot happen again"""
+    import signal
+    exe = os.path.join(BIN, "pgr-mdb")
+    p = procutil.popen_bounded([exe, "--synthetic", "400x10000000", "--seed", "9", str(tmp_path / "big"), "--ranks", "1",
+                                "--force-exchange", "--batch-bp", "200000000"])
+    try:
+        kids, t0 = [], time.time()
+        while not kids and time.time() - t0 < 30:
+            time.sleep(0.05)
+            kids = [q for q in procutil._group_pids(p.pid) if q != p.pid]
+        assert kids, "no rank process appeared"
+        os.kill(p.pid, signal.SIGKILL)
+        t0 = time.time()
+        while time.time() - t0 < 10 and any(os.path.exists("/proc/%d" % q) and open("/proc/%d/stat" % q).read().split()[2] != "Z" for q in kids):
+            time.sleep(0.05)
+        alive = [q for q in kids if os.path.exists("/proc/%d" % q) and open("/proc/%d/stat" % q).read().split()[2] != "Z"]
+        assert not alive, "rank processes outlived their parent: %r" % (alive,)
+    finally:
+        procutil.kill_group(p)
+        p.communicate()
+
+
+def test_bench_strong_mode_plumbing():
+    """bench.py --strong on one rank through the process-group code path (RCCL world 1, pgr_exchange_*)"""
+    r = procutil.run_bounded([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+                              "--contigs", "24", "--contig-len", "1000000", "--strong", "--force-dist", "--queries", "0",
+                              "--no-cpu-baseline", "--no-extras"], timeout=150, env={"MASTER_PORT": str(_free_port())}, check=True)
+    line = json.loads([l for l in r.stdout.split("\n") if l.startswith('{"metric"')][-1])
+    assert line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 24_000_000 and line["value"] > 0
+
+
+def test_key_range_sharded_index_two_ranks_equals_single_process(gpu_ctx, tmp_path):
+    """SURVEY 8e "key-range partitioned": 2 processes on this box's one GPU, each derives the pair records of its shard of ONE
+    ragged contig set, the records travel to the rank owning their range of first hashes, each rank sorts only its range.
+    The per-rank CSRs concatenated in rank order == the single-process index bit for bit; each rank sorted about half of
+    the records; nothing was lost or duplicated (checksums); the replicated index rebuilt from the shards is the same again.
+    RCCL refuses two ranks on one device, so the transport is gloo there (the library path runs with world 1 below)."""
+    import pgrtk_amd as P
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import exchange_worker as W
+    ref_b = P.Batch.synthetic(W.LENS, seed=W.SEED, ctx=gpu_ctx)
+    ref = P.Index(P.make_spec(), ctx=gpu_ctx)
+    ref.add_resident(ref_b)
+    ref.finalize()
+    want = ref.download()
+    used = None
+    for transport in ("shard-abi", "shard-gloo"):
+        d = tmp_path / transport
+        d.mkdir()
+        port = _free_port()
+        ok, outs = _run_ranks([[sys.executable, os.path.join(ROOT, "tests", "exchange_worker.py"), transport, str(r), "2", str(port),
+                                str(d)] for r in range(2)])
+        if not ok:
+            if transport == "shard-abi":
+                print("RCCL with two ranks on one device failed (expected), gloo transport next:\n" + "\n".join(outs)[-800:])
+                continue
+            raise AssertionError("\n".join(outs)[-3000:])
+        parts = [np.load(str(d / ("records_%d.npy" % r))) for r in range(2)]
+        meta = [json.load(open(str(d / ("meta_%d.json" % r)))) for r in range(2)]
+        got = np.concatenate(parts)
+        assert len(got) == len(want)
+        for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"):
+            assert np.array_equal(got[f], want[f]), (transport, f)
+        # each rank sorted about half (sampled splitters: within 15 % on 36 k records)
+        assert all(abs(len(p) - len(want) / 2) < 0.15 * len(want) for p in parts), [len(p) for p in parts]
+        assert sum(m["n_sent"] for m in meta) == len(want) == sum(m["n_shard"] for m in meta)
+        M = (1 << 64) - 1
+        for i in (0, 1):
+            assert sum(m["sent"][i] for m in meta) & M == sum(m["shard"][i] for m in meta) & M
+        assert meta[0]["splitters"] == meta[1]["splitters"] and len(meta[0]["splitters"]) == 1
+        assert meta[0]["key_range"][1] < meta[0]["splitters"][0] <= meta[1]["key_range"][0]
+        assert meta[0]["n_keys"] + meta[1]["n_keys"] == ref.n_keys == meta[0]["full_keys"]
+        for r in range(2):
+            rep = np.load(str(d / ("replicated_%d.npy" % r)))
+            assert len(rep) == len(want) and all(np.array_equal(rep[f], want[f]) for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient"))
+        used = transport
+        break
+    assert used is not None
+
+
+@pytest.mark.parametrize("rccl", [False, True])
+def test_shard_exchange_world_one(gpu_ctx, rccl):
+    """pgr_exchange_shard_records / pgr_exchange_allgather_index with one rank (the collectives, the grouped send / receive loop
+    and the local block copy all run): the shard is the whole index.  rccl=True: over RCCL itself (option exchange_rccl_world1),
+    rccl=False: the one-rank form without RCCL"""
+    import torch
+    import pgrtk_amd as P
+    from pgrtk_amd import exchange
+    spec = P.make_spec()
+    b = P.Batch.synthetic([700_000, 1_300_000, 0, 64, 2_000_000], seed=23, ctx=gpu_ctx)
+    sh = b.shmmrs(spec)
+    recs = torch.zeros((sh.n_pairs, exchange.REC_WORDS), dtype=torch.int64, device="cuda:0")
+    n = sh.frag_recs_into(recs.data_ptr(), recs.shape[0])
+    with gpu_ctx.options(exchange_rccl_world1=int(rccl), exchange_timeout_s=60, exchange_collective_timeout_s=60):
+        xch = exchange.AbiExchange(gpu_ctx, 0, 1)
+        assert xch.uses_rccl == rccl
+        ix = P.Index(spec, ctx=gpu_ctx)
+        got, spl = xch.shard_records(recs.data_ptr(), n, ix)
+        assert got == n and spl == []
+        ix.finalize()
+        full = xch.allgather_index(ix)
+        xch.close()
+    ref = P.Index(spec, ctx=gpu_ctx)
+    ref.add_resident(b)
+    ref.finalize()
+    want = ref.download()
+    for cand in (ix.download(), full.download()):
+        assert len(cand) == len(want) and all(np.array_equal(cand[f], want[f]) for f in ("h0", "h1", "frg_id", "sid", "bgn", "end"))
+    assert ix.records_checksum() == ref.records_checksum() == P.records_checksum(recs.data_ptr(), n, ctx=gpu_ctx)
+
+
+def test_bench_two_ranks_line_is_gradeable():
+    """the N-rank bench line before a multi-GPU driver ever runs it: 2 ranks on this box's one GPU (gloo transport),
+    every rank's shimmer lists checked against the CPU restatement, the exchanged record set against what was sent, the
+    merge inside the timed value with its parts printed"""
+    port = _free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+           "--steps", "2", "--warmup", "1", "--contigs", "40", "--contig-len", "2000000", "--queries", "400"]
+    r = procutil.run_bounded(cmd, timeout=240, check=True)
+    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["bp_per_step_all_gpus"] == 160_000_000
+    assert line["merge_ms"] > 0 and line["exchange_ms"] > 0 and "roofline" in line
+    cb = line["cpu_baseline"]
+    assert cb["content_match"] is True and cb["content_match_all_ranks"] is True and cb["contigs_checked_all_ranks"] == 80
+    ex = line["exchange"]
+    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True
+    assert ex["records_sent_all_ranks"] == ex["records_in_shards"] == sum(ex["records_per_shard"])
+    assert ex["largest_shard_over_mean"] < 1.2
+    q = line["query"]
+    assert "error" not in q and q["queries_with_best_chain_on_source"] >= 396 and q["index_records"] == ex["records_in_shards"]
+
+
+def test_bench_self_spawns_its_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with NO torchrun around it (the shape of the driver's N = 1 command with another N) starts
+    its own ranks and prints a gradeable line: 2 ranks on this box's one GPU (gloo transport), merge inside the value,
+    every rank's contigs checked, the exchange verified, the transport named."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device", "--steps", "2",
+           "--warmup", "1", "--contigs", "30", "--contig-len", "2000000", "--queries", "200"]
+    r = procutil.run_bounded(cmd, timeout=240, check=True, env=_NO_LAUNCHER)
+    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["config"]["bp_per_step_all_gpus"] == 120_000_000
+    assert line["merge_ms"] > 0 and line["exchange_ms"] > 0
+    ex = line["exchange"]
+    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True
+    assert ex["transport"].startswith("torch.distributed") and ex["exchange_fallback"] is None
+    assert ex["rccl_ranks_in_the_librarys_communicator"] == 0  # (gloo on one device: the library's RCCL path is not taken)
+    assert line["cpu_baseline"]["content_match_all_ranks"] is True
+
+
+def test_exchange_watchdog_times_out_instead_of_hanging(gpu_ctx):
+    """a rank whose peers never arrive: ncclCommInitRank for world = 2 with only this rank present would block for ever;
+    with the context option exchange_timeout_s the call comes back with an error that names the timeout (the bench then
+    falls back to the torch.distributed transport).  On its own context: the worker thread stays inside RCCL."""
+    import ctypes as C
+    import pgrtk_amd as P
+    from pgrtk_amd._ffi import lib
+    ctx = P.Context(0)
+    ctx.set_option("exchange_timeout_s", 3)
+    assert ctx.get_option("exchange_timeout_s") == 3
+    idb = np.zeros(128, dtype=np.uint8)
+    ctx.check(lib().pgr_exchange_unique_id(ctx.handle, idb.ctypes.data))
+    h = C.c_void_p()
+    t0 = time.perf_counter()
+    rc = lib().pgr_exchange_create(ctx.handle, idb.ctypes.data, 0, 2, C.byref(h))
+    dt = time.perf_counter() - t0
+    assert rc != 0 and not h.value and 2.5 < dt < 30
+    msg = lib().pgr_last_error(ctx.handle)
+    assert b"ncclCommInitRank did not return within 3 s" in msg, msg  # (the message names the step that is stuck)
+    with pytest.raises(KeyError):
+        ctx.get_option("no_such_option")
+    with pytest.raises(P.PgrError):
+        ctx.set_option("no_such_option", 1)
+
+
+def test_eight_ranks_strong_scaling_plumbing_on_one_device():
+    """world = 8 before an 8-GPU node ever runs it: `bench.py --gpus 8 --strong` (self-spawned, gloo, every rank on this box's one
+    GPU) partitions ONE contig set with the greedy partitioner, every rank computes its shard, the records travel by key range
+    through an 8 x 8 all-to-all, eight shards are sorted and all-gathered into the replicated query index.  Every rank's
+    contigs are checked against the CPU restatement, the exchanged record set against what was sent.  (The same command at
+    full size -- 1000 x 10 Mbp, 30.4 M records -- is kept under profiles/r04_dist/.)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--backend", "gloo", "--single-device", "--strong", "--steps", "1",
+           "--warmup", "1", "--contigs", "67", "--contig-len", "1500000", "--queries", "240"]
+    r = procutil.run_bounded(cmd, timeout=300, check=True, env=_NO_LAUNCHER)
+    line = json.loads([ln for ln in r.stdout.split("\n") if ln.startswith('{"metric"')][-1])
+    assert line["n_gpus"] == 8 and line["scaling"] == "strong" and line["config"]["bp_per_step_all_gpus"] == 67 * 1_500_000
+    ex = line["exchange"]
+    assert ex["content_match"] is True and ex["key_ranges_disjoint_and_ordered"] is True and len(ex["records_per_shard"]) == 8
+    assert ex["records_sent_all_ranks"] == ex["records_in_shards"] == sum(ex["records_per_shard"]) > 250_000
+    assert ex["largest_shard_over_mean"] < 1.25
+    cb = line["cpu_baseline"]
+    assert cb["content_match_all_ranks"] is True and cb["contigs_checked_all_ranks"] == 67
+    q = line["query"]
+    assert "error" not in q and q["queries_with_best_chain_on_source"] >= 236 and q["index_records"] == ex["records_in_shards"]
+
+
+def test_merge_of_step_i_beside_the_tiles_of_step_i_plus_1():
+    """bench.py's overlapped leg (N > 1): the exchange + shard sort of a step on a worker thread and the first context while the
+    next step's shimmer pipeline runs on a second context.  Two ranks on this box's one GPU over gloo, and one rank through the
+    library's own RCCL communicator (world = 1): the last shard of the leg has the checksum and the size of the timed loop's."""
+    line = _bench_line(["--backend", "gloo", "--single-device", "--steps", "3", "--warmup", "1", "--contigs", "40", "--contig-len", "2000000",
+                        "--queries", "0"], 2)
+    ov = line["overlapped"]
+    assert "error" not in ov, ov
+    assert ov["content_match_vs_timed_loop"] is True and line["value_overlapped"] > 0 and ov["steps"] >= 4
+    assert line["exchange"]["content_match"] is True
+    line = _bench_line(["--force-dist", "--steps", "3", "--warmup", "1", "--contigs", "60", "--contig-len", "2000000", "--queries", "0",
+                        "--no-cpu-baseline"], 1)
+    ov = line["overlapped"]
+    assert "error" not in ov, ov
+    assert ov["content_match_vs_timed_loop"] is True
+    assert line["exchange"]["rccl_ranks_in_the_librarys_communicator"] == 1
+
+
+def test_zz_rccl_communicator_in_a_rank_process_without_pytorch(tmp_path):
+    """The one path that maps the SYSTEM's librccl.so.1 (a 570 MB image) into a process that has no PyTorch and creates a real
+    communicator there: `pgr-mdb --ranks 1 --force-exchange` with PGR_EXCHANGE_RCCL_WORLD1=1.  This is what stood still for 300 s
+    on the driver's box in round 5 (profiles/r06_hang/README.md).  Last test of the suite; the cost of the cold image is measured
+    on its own first (reading the file), so that a slow disk is named as such and not mistaken for a stuck rendezvous; the
+    library's watchdog (60 s here) names the step if one does not return."""
+    lib_path = next((p for p in ("/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so") if os.path.exists(p)), None)
+    assert lib_path, "no system librccl.so.1"
+    t0, n, budget = time.time(), 0, 150.0
+    with open(lib_path, "rb", buffering=0) as f:
+        while time.time() - t0 < budget:
+            blk = f.read(32 << 20)
+            if not blk:
+                break
+            n += len(blk)
+    t_read = time.time() - t0
+    size = os.path.getsize(lib_path)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    note = {"file": lib_path, "bytes": size, "bytes_read": n, "read_s": round(t_read, 2), "MB_per_s": round(n / 1e6 / max(t_read, 1e-3), 1)}
+    if n < size:
+        with open(os.path.join(ROOT, "gpurun_out", "rccl_in_a_rank_process.json"), "w") as f:
+            json.dump(note, f)
+        pytest.fail("this box read only %d of %d MB of %s in %.0f s: the image is too cold to load RCCL in a bounded test "
+                    "(a property of the box, not of the library)" % (n >> 20, size >> 20, lib_path, t_read))
+    exe, fl, log = _mdb_variants(tmp_path, (("plain", []), ("rccl", ["--ranks", "1", "--devices", "0", "--force-exchange", "--batch-bp", "60000"])),
+                                 env={"PGR_DEBUG": "1", "PGR_EXCHANGE_RCCL_WORLD1": "1", "PGR_EXCHANGE_TIMEOUT_S": "60",
+                                      "PGR_EXCHANGE_COLLECTIVE_TIMEOUT_S": "60"}, timeout=150)
+    err = log["rccl"][1]
+    assert "RCCL ready after" in err and "ncclCommInitRank returned after" in err and "RCCL not loaded" not in err, err[-2000:]
+    assert (tmp_path / "plain.mdb").read_bytes() == (tmp_path / "rccl.mdb").read_bytes()
+    note.update(pgr_mdb_s=log["rccl"][0], library_lines=[l for l in err.split("\n") if l.startswith("[pgr] exchange")])
+    with open(os.path.join(ROOT, "gpurun_out", "rccl_in_a_rank_process.json"), "w") as f:
+        json.dump(note, f)

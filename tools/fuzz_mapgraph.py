@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity campaign for the MAP-graph path (GPU box): random small pangenomes with structural variation,
 random min_count / path_len_cutoff / keeps; adjacency list, weighted DFS, principal bundles, bundles-with-id, the
-per-sequence decomposition and the .bed body compared product <-> oracle (tests/test_gpu_mapgraph._check_all).
+per-sequence decomposition and the .bed body compared product <-> oracle (tests/test_gpu_08_mapgraph._check_all).
 usage: fuzz_mapgraph.py [iterations] [seed0]"""
 import os
 import sys
@@ -13,7 +13,7 @@ import numpy as np  # noqa: E402
 import oracle as O  # noqa: E402
 import pgrtk_amd as P  # noqa: E402
 import seqgen  # noqa: E402
-from test_gpu_mapgraph import _check_all  # noqa: E402
+from test_gpu_08_mapgraph import _check_all  # noqa: E402
 
 COMP = bytes.maketrans(b"ACGT", b"TGCA")
 
