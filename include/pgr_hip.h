@@ -100,6 +100,11 @@ const char *pgr_version(void);
  *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on loading librccl.so.1, ncclGetUniqueId and ncclCommInitRank (the
  *                             rendezvous of the ranks) (300; 0 = wait for ever); on a timeout the call fails and its message
  *                             names the step that did not return
+ *   debug_poison              debugging aid: every device block that is about to be used again is filled with 0xFF first (blocks leaving
+ *                             the caching allocator, grown workspaces, a job's workspaces when it is planned, the status mailbox) and a
+ *                             list stage checks the segment table it is about to read; a call that read what an earlier call left
+ *                             behind fails with PGR_ERR_INTERNAL ("debug_poison: ...") instead of faulting or not, depending on the layout
+ *   debug_inject_stale_segments   fault injection for the tests of debug_poison (re-creates the round-5 defect); never set it otherwise
  *   exchange_rccl_world1      an exchange of ONE rank uses a real RCCL communicator.  Default 0: every collective of one rank is
  *                             a device-to-device copy on the exchange's stream and RCCL is neither loaded nor initialised
  *                             (pgr_exchange_create then ignores `id`, which may be NULL)

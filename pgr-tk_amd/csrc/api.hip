@@ -45,7 +45,7 @@ const std::vector<OptionName> &option_names() {
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query}, {"direct_query_result", &O::direct_query_result}, {"direct_query_results_delivered", &O::direct_query_results_delivered}, {"direct_query_lds_kb", &O::direct_query_lds_kb},
         {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
-        {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s}, {"exchange_rccl_world1", &O::exchange_rccl_world1},
+        {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s}, {"exchange_rccl_world1", &O::exchange_rccl_world1}, {"debug_poison", &O::debug_poison}, {"debug_inject_stale_segments", &O::debug_inject_stale_segments},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
         {"back_priority", &O::back_priority}, {"no_fix_stream", &O::no_fix_stream}, {"no_stage1_only", &O::no_stage1_only}, {"pipe_staged_records", &O::pipe_staged_records},
         {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d},

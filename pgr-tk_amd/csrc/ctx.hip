@@ -36,6 +36,10 @@ int DevBuf::ensure(pgr_ctx *ctx, size_t bytes, std::string *err) {
         return ctx->fail(PGR_ERR_NOMEM, msg);
     }
     cap = want;
+    if (ctx->opt.debug_poison) {  // a fresh block is nobody's yet: fill it and wait (debugging aid, not a fast path)
+        (void)hipMemsetAsync(p, 0xFF, cap, ctx->stream);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
     return PGR_OK;
 }
 
@@ -224,8 +228,11 @@ int pgr_ctx::dmalloc(void **out, size_t bytes) {
         }
         if (hit != free_blocks.end()) {
             wait_and_recycle(hit->second, user);
+            // (on the stream the block goes to work on, behind everything that stream was made to wait for: whoever still reads the
+            // block on a stream the allocator was not told about reads 0xFF from here on)
+            if (opt.debug_poison) (void)hipMemsetAsync(hit->second.p, 0xFF, hit->first, user);
             *out = hit->second.p;
-            live_blocks[hit->second.p] = LiveBlock{hit->first, want_back};
+            live_blocks[hit->second.p] = LiveBlock{hit->first, want_back, multi_stream && fix_stream && user == fix_stream};
             cached_bytes -= hit->first;
             free_blocks.erase(hit);
             return PGR_OK;
@@ -245,9 +252,10 @@ int pgr_ctx::dmalloc(void **out, size_t bytes) {
     }
     if (e != hipSuccess)
         return fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
-    live_blocks[p] = LiveBlock{bytes, multi_stream && user == back_stream};
+    live_blocks[p] = LiveBlock{bytes, multi_stream && user == back_stream, multi_stream && fix_stream && user == fix_stream};
     live_bytes += bytes;
     peak_bytes = std::max(peak_bytes, live_bytes);
+    if (opt.debug_poison) (void)hipMemsetAsync(p, 0xFF, bytes, user);
     *out = p;
     return PGR_OK;
 }
@@ -260,7 +268,7 @@ void pgr_ctx::dfree(void *p) {
         return;
     }
     const size_t bytes = it->second.bytes;
-    const bool on_back = it->second.on_back;
+    const bool on_back = it->second.on_back, on_fix = it->second.on_fix;
     live_blocks.erase(it);
     // keep at most 160 GiB cached (288 GB of HBM3E per GPU; a failing hipMalloc drops the cache and retries).  Beyond that
     // the smallest cached blocks make room: hipFree synchronizes the device, so a full cache that frees every incoming
@@ -282,28 +290,28 @@ void pgr_ctx::dfree(void *p) {
     FreeBlock fb;
     fb.p = p;
     fb.on_back = on_back;
-    if (multi_stream && fix_stream && alloc_stream == fix_stream) {
-        // freed inside a job's second pass (pgr_pipe_collect): whatever is pending on the block is pending on the fix stream.  (The
-        // context's stream is busy with the NEXT job's tiles: an event recorded there would make this pass's next allocation, which
-        // is likely to get this very block, wait for them.)
-        // (a block the back stream works on too -- handed out for it, or marked: an index's records -- also remembers where that
-        // stream stands)
-        bool ok = (fb.ev_fix = take_event()) && hipEventRecord(fb.ev_fix, fix_stream) == hipSuccess;
-        if (ok && on_back) ok = (fb.ev_back = take_event()) && hipEventRecord(fb.ev_back, back_stream) == hipSuccess;
-        if (!ok) {
-            (void)hipStreamSynchronize(fix_stream);
-            if (on_back && back_stream) (void)hipStreamSynchronize(back_stream);
-            drop_events(fb);
-        }
-    } else if (multi_stream) {  // where the two streams stand now: the next user on the other stream waits for that
-        if ((fb.ev_front = take_event()) && hipEventRecord(fb.ev_front, stream) != hipSuccess) drop_events(fb);
-        if (on_back && (fb.ev_back = take_event()) && hipEventRecord(fb.ev_back, back_stream) != hipSuccess) {
-            ev_pool.push_back(fb.ev_back);
-            fb.ev_back = nullptr;
-        }
-        if (!fb.ev_front || (on_back && !fb.ev_back)) {  // no event to be had: the slow, safe way
+    if (multi_stream) {
+        // Where the streams that worked on the block stand now: whoever takes it for ANOTHER stream waits for that.
+        //   the context's stream: always -- except for a block freed inside a job's second pass on the fix stream (pgr_pipe_collect):
+        //     what is pending on it is pending on the fix stream (the first pass has been waited for by the host), and the context's
+        //     stream is busy with the NEXT job's tiles: an event recorded there would make this pass's next allocation, which is likely
+        //     to get this very block, wait for them;
+        //   the back stream: blocks handed out for it, or marked (an index's records);
+        //   the fix stream: blocks handed out for it or marked, and every block freed inside a second pass.
+        const bool in_fix_pass = fix_stream && alloc_stream == fix_stream;
+        bool ok = true;
+        auto mark = [&](hipEvent_t &ev, hipStream_t st) {
+            if (!ok) return;
+            ev = take_event();
+            ok = ev && hipEventRecord(ev, st) == hipSuccess;
+        };
+        if (!in_fix_pass) mark(fb.ev_front, stream);
+        if (on_back && back_stream) mark(fb.ev_back, back_stream);
+        if ((on_fix || in_fix_pass) && fix_stream) mark(fb.ev_fix, fix_stream);
+        if (!ok) {  // no event to be had: the slow, safe way
             (void)hipStreamSynchronize(stream);
             if (back_stream) (void)hipStreamSynchronize(back_stream);
+            if (fix_stream) (void)hipStreamSynchronize(fix_stream);
             drop_events(fb);
         }
     }
@@ -314,6 +322,20 @@ void pgr_ctx::dfree(void *p) {
 void pgr_ctx::block_on_back(void *p) {
     auto it = live_blocks.find(p);
     if (it != live_blocks.end()) it->second.on_back = true;
+}
+
+void pgr_ctx::block_on_fix(void *p) {
+    auto it = live_blocks.find(p);
+    if (it != live_blocks.end()) it->second.on_fix = true;
+}
+
+int pgr_ctx::poison_workspaces(hipStream_t st) {
+    pgr::DevBuf *bufs[] = {&ws_tile_first, &ws_seg_off, &ws_seg_cnt, &ws_seg_dst, &ws_cursor, &ws_flags, &ws_l1, &ws_serial, &ws_scan_tmp,
+                           &ws_list_a, &ws_list_b, &ws_off_a, &ws_off_b, &ws_blk_cnt, &ws_blk_base, &ws_start_rank, &ws_rids, &ws_rec_off,
+                           &ws_blk_off, &ws_tile_desc, &ws_tile_flags, &ws_seg_cid, &ws_tile_lv, &ws_recs};
+    for (pgr::DevBuf *b : bufs)
+        if (b->p && b->cap && hipMemsetAsync(b->p, 0xFF, b->cap, st) != hipSuccess) return fail(PGR_ERR_DEVICE, "debug_poison: memset failed");
+    return PGR_OK;
 }
 
 void pgr_ctx::swap_lane(pgr::Lane &l) {

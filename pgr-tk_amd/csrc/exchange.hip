@@ -156,6 +156,16 @@ static int exchange_sync(pgr_exchange *x, const char *what) {
     return ctx->fail(PGR_ERR_DEVICE, msg);
 }
 
+// Blocks from the context's caching allocator belong to the context's stream (work queued there may still read a recycled block, and
+// debug_poison fills it there): before the exchange's stream touches blocks that were just taken it is put behind the context's stream.
+// (The other direction is the host's: every function here waits for the exchange's stream -- exchange_sync -- before its blocks go back.)
+static int order_behind_compute(pgr_exchange *x) {
+    pgr_ctx *ctx = x->ctx;
+    PGR_HIP(ctx, hipEventRecord(x->ev_ready, ctx->stream));
+    PGR_HIP(ctx, hipStreamWaitEvent(x->stream, x->ev_ready, 0));
+    return PGR_OK;
+}
+
 static_assert(PGR_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "pgr_hip.h and rccl.h disagree on the unique id size");
 
 static std::string nccl_error_string(ncclResult_t r) {
@@ -466,7 +476,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
         local_rc = alloc_rc ? alloc_rc : pgr_shard_sample_keys(ctx, d_recs, n, SHARD_SAMPLES, mine.data() + 1, &n_s);  // synchronizes
         mine[0] = local_rc ? FAILED : n_s;
         pgr::Tmp d_smp(ctx), d_all(ctx);
-        if ((rc = d_smp.alloc(mine.size() * 8)) || (rc = d_all.alloc((size_t)world * mine.size() * 8))) return rc;
+        if ((rc = d_smp.alloc(mine.size() * 8)) || (rc = d_all.alloc((size_t)world * mine.size() * 8)) || (rc = order_behind_compute(x))) return rc;
         std::vector<uint64_t> all((size_t)world * mine.size());
         PGR_HIP(ctx, hipMemcpyAsync(d_smp.p, mine.data(), mine.size() * 8, hipMemcpyHostToDevice, x->stream));
         PGR_NCCL(ctx, R.AllGather(d_smp.p, d_all.p, mine.size(), ncclUint64, x->comm, x->stream));
@@ -494,6 +504,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     send_cnt[(size_t)world] = local_rc ? FAILED : 0;
     // ---- 3. everybody's counts: M[src][dst] (+ the error word of src)
     std::vector<uint64_t> mat((size_t)world * row);
+    if ((rc = order_behind_compute(x))) return rc;
     PGR_HIP(ctx, hipMemcpyAsync(d_cnt.p, send_cnt.data(), row * 8, hipMemcpyHostToDevice, x->stream));
     PGR_NCCL(ctx, R.AllGather(d_cnt.p, d_mat.p, row, ncclUint64, x->comm, x->stream));
     PGR_HIP(ctx, hipMemcpyAsync(mat.data(), d_mat.p, mat.size() * 8, hipMemcpyDeviceToHost, x->stream));
@@ -508,6 +519,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     else
         local_rc = pgr::index_grow_raw(ctx, ix, ix->n_raw + recv_total);
     x->h_cnt[0] = local_rc ? FAILED : 0;
+    if ((rc = order_behind_compute(x))) return rc;  // (the index's append block may have moved: its copy ran on the context's stream)
     PGR_HIP(ctx, hipMemcpyAsync(x->d_cnt, x->h_cnt, sizeof(unsigned long long), hipMemcpyHostToDevice, x->stream));
     PGR_NCCL(ctx, R.AllGather(x->d_cnt, x->d_cnt + 1, 1, ncclUint64, x->comm, x->stream));
     PGR_HIP(ctx, hipMemcpyAsync(x->h_cnt + 1, x->d_cnt + 1, (size_t)world * sizeof(unsigned long long), hipMemcpyDeviceToHost,
@@ -574,6 +586,10 @@ extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *sh
     pgr_index *full = nullptr;
     if ((rc = pgr_index_create(ctx, &shard->spec, &full))) return rc;
     if ((rc = pgr::index_grow_raw(ctx, full, total))) {
+        pgr_index_destroy(full);
+        return rc;
+    }
+    if ((rc = order_behind_compute(x))) {
         pgr_index_destroy(full);
         return rc;
     }

@@ -334,7 +334,10 @@ extern "C" uint64_t pgr_index_n_records(const pgr_index *ix) { return ix ? (ix->
 extern "C" int pgr_index_reserve(pgr_ctx *ctx, pgr_index *ix, uint64_t n_records) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
+    if (ix->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "index belongs to another context");
     if (n_records <= ix->cap_raw) return PGR_OK;
+    // (jobs of a pipe in flight write their records through the device cursor into the block that is about to move)
+    if (ix->pipe_jobs > 0) return ctx->fail(PGR_ERR_STATE, "pgr_index_reserve while jobs of a pgr_pipe on this index are in flight: collect them first");
     PGR_HIP(ctx, hipSetDevice(ctx->device));
     pgr_frag_rec *np = nullptr;
     int rc = ctx->dmalloc((void **)&np, n_records * sizeof(pgr_frag_rec));  // (exactly what was asked for: no head-room on top)

@@ -586,8 +586,13 @@ int upload_vmap(pgr_ctx *ctx, const NodeTable &nt, const VMap &vm, Tmp &dtab, ui
     *n_tab = tab.size();
     int rc;
     if ((rc = dtab.alloc(std::max<size_t>(tab.size(), 1) * sizeof(VEntry)))) return rc;
-    if (!tab.empty())
-        PGR_HIP(ctx, hipMemcpy(dtab.p, tab.data(), tab.size() * sizeof(VEntry), hipMemcpyHostToDevice));
+    // (ON the context's stream: a block from the caching allocator may still be read by work queued there -- and is filled there under
+    // debug_poison --; a plain hipMemcpy runs on the null stream, which the context's non-blocking stream is not ordered with.  Found by
+    // debug_poison: the fill landed on top of the table.)
+    if (!tab.empty()) {
+        PGR_HIP(ctx, hipMemcpyAsync(dtab.p, tab.data(), tab.size() * sizeof(VEntry), hipMemcpyHostToDevice, ctx->stream));
+        PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (`tab` goes out of scope)
+    }
     return PGR_OK;
 }
 
@@ -878,7 +883,8 @@ extern "C" int pgr_principal_bundle_projection(pgr_ctx *ctx, const pgr_index *ix
         free(hoff);
         return rc;
     }
-    hipError_t e = np ? hipMemcpy(drec.p, hrec, np * sizeof(pgr_frag_rec), hipMemcpyHostToDevice) : hipSuccess;
+    hipError_t e = np ? hipMemcpyAsync(drec.p, hrec, np * sizeof(pgr_frag_rec), hipMemcpyHostToDevice, ctx->stream) : hipSuccess;  // (see upload_vmap)
+    if (e == hipSuccess && np) e = hipStreamSynchronize(ctx->stream);
     free(hrec);
     if (e != hipSuccess) {
         free(hoff);

@@ -79,6 +79,11 @@ struct pgr_ctx {
         int64_t exchange_timeout_s = 300;  // bound on ncclCommInitRank (all ranks must arrive); 0 = wait for ever
         int64_t exchange_collective_timeout_s = 1800;  // bound on every wait for a collective -- which includes waiting for a SLOWER peer to
                                                        // get there (an imbalanced rank is not a dead one): generous; 0 = wait for ever
+        int64_t debug_poison = 0;        // every device block that is about to be used again is filled with 0xFF first (blocks leaving the caching
+                                         // allocator, grown workspaces, a job's workspaces when the job is planned), and a list stage checks the
+                                         // segment table it is about to read: reading what an earlier call left behind fails the call
+        int64_t debug_inject_stale_segments = 0;  // FAULT INJECTION for the tests of debug_poison: a pass without a tile kernel does not clear the
+                                                  // segment counts (the round-5 defect, profiles/r05_fuzz/cursor_block_size_fault.txt)
         int64_t exchange_rccl_world1 = 0;  // an exchange of ONE rank goes through a real RCCL communicator all the same (default: plain copies, RCCL not loaded)
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
@@ -145,6 +150,7 @@ struct pgr_ctx {
     struct LiveBlock {
         size_t bytes = 0;
         bool on_back = false;  // handed out for work on the back stream (or marked: block_on_back): a free records that stream too
+        bool on_fix = false;   // ... the same for the fix stream (handed out inside a second pass, or marked: block_on_fix)
     };
     std::multimap<size_t, FreeBlock> free_blocks;
     std::map<void *, LiveBlock> live_blocks;
@@ -166,8 +172,10 @@ struct pgr_ctx {
     void wait_and_recycle(FreeBlock &fb, hipStream_t user);
     void drop_events(FreeBlock &fb);
     void block_on_back(void *p);  // a block of the context's stream that the back stream works on as well (an index's records)
+    void block_on_fix(void *p);   // ... that a second pass on the fix stream works on as well
     int enable_multi_stream();  // creates back_stream; synchronizes once so that earlier frees need no events
     void swap_lane(pgr::Lane &l);
+    int poison_workspaces(hipStream_t st);  // debug_poison: 0xFF over the workspaces a job works in (whatever they hold is an earlier call's)
 
     int fail(int code, const std::string &msg) {
         err = msg;

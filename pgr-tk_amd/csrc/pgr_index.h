@@ -24,6 +24,7 @@ struct pgr_index {
     ulonglong2 *keys = nullptr;
     bool finalized = false;
     uint32_t next_sid = 0;
+    int pipe_jobs = 0;  // jobs of a pgr_pipe in flight that place records in `raw` (the block must not move under them: pgr_index_reserve)
     uint64_t sid_bound = 0;  // max(sid) + 1 over the finalized records (0: unknown)
     // query path: calls left that go straight to the stage-by-stage kernels after the one-wavefront-per-query kernel
     // (query_fused.hip) declined a batch on this index

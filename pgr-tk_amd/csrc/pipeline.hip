@@ -979,11 +979,15 @@ int ShmmrJob::plan() {
         // pinned: the pass's status words + result offsets come back into it; behind them the tile table and the rids on their way up
         (rc = ctx->ensure_mailbox((N_STATUS + (size_t)n + 1) * sizeof(uint64_t) + (2 * (size_t)n + 2) * sizeof(uint32_t))))
         return rc;
+    // debug_poison: whatever the workspaces hold now was left by an earlier call (or by the lane's previous job): nothing of this job
+    // may depend on it.  On the job's front stream, in front of everything the job enqueues.
+    if (ctx->opt.debug_poison && (rc = ctx->poison_workspaces(st))) return rc;
     d_cursor = (unsigned long long *)ctx->ws_cursor.p;
     d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
     d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
     zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
     mbox = (uint64_t *)ctx->mailbox;
+    if (ctx->opt.debug_poison) memset(mbox, 0xFF, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t));  // (status words + offsets of an earlier pass)
     // (through the pinned mailbox, read by a KERNEL of this stream: a copy engine would take these few kB in the order of its
     // queue -- behind every staging copy a pipelined host call has queued for the sub-batches to come)
     uint32_t *up = (uint32_t *)(mbox + N_STATUS + (size_t)n + 1);
@@ -1097,7 +1101,8 @@ int ShmmrJob::stage1() {
     // write theirs later): a list stage that runs before the islands -- the optimistic pass of a pipelined job -- scanned whatever the
     // workspace held and read level-1 records from wherever that pointed.  Found as a GPU memory fault that came and went with the
     // SIZE of an unrelated workspace (profiles/r05_fuzz/cursor_block_size_fault.txt): the counts start at zero.
-    if (!(tiled && bases_tiled) && n_segs) PGR_HIP(ctx, hipMemsetAsync(ctx->ws_seg_cnt.p, 0, ((size_t)n_segs + 1) * sizeof(uint32_t), st));
+    if (!(tiled && bases_tiled) && n_segs && !ctx->opt.debug_inject_stale_segments)
+        PGR_HIP(ctx, hipMemsetAsync(ctx->ws_seg_cnt.p, 0, ((size_t)n_segs + 1) * sizeof(uint32_t), st));
     if (n == 0) PGR_HIP(ctx, hipMemsetAsync((uint32_t *)ctx->ws_seg_cnt.p + n_segs, 0, sizeof(uint32_t), st));
     l2_cursor_clean = true;  // (otherwise the tail kernel writes the scan sentinel)
     if (!(tiled && bases_tiled)) PGR_HIP(ctx, hipEventRecord(ctx->ev[1], st));
@@ -1290,9 +1295,28 @@ int ShmmrJob::scan_back(const uint32_t *in, uint64_t *out, uint32_t n_plus_1) {
     return PGR_OK;
 }
 
+// debug_poison: the segment table a list stage is about to read has to describe records INSIDE the level-1 buffer (and its scan sentinel
+// has to be zero).  An entry that does not is counted in cursor word 7 (it travels to the host with the status words: decide() fails the
+// call) and cleared, so that the kernels behind this one do not follow it into unmapped memory.
+__global__ void check_segments_kernel(uint32_t *__restrict__ seg_cnt, const uint64_t *__restrict__ seg_off, uint32_t n_segs,
+                                      uint64_t l1_elems, unsigned long long *__restrict__ trip) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n_segs) return;
+    const uint32_t c = seg_cnt[i];
+    if (c == 0) return;
+    const uint64_t o = seg_off[i];
+    if (i == n_segs || o > l1_elems || o + c > l1_elems) {
+        atomicAdd(trip, 1ull);
+        seg_cnt[i] = 0;
+    }
+}
+
 int ShmmrJob::stage2() {
     hipStream_t st = sb;
     int r;
+    if (ctx->opt.debug_poison)
+        hipLaunchKernelGGL(check_segments_kernel, dim3((n_segs + 1 + 255) / 256), dim3(256), 0, st, (uint32_t *)ctx->ws_seg_cnt.p,
+                           (const uint64_t *)ctx->ws_seg_off.p, n_segs, (uint64_t)(ctx->ws_l1.cap / sizeof(L1Rec)), d_cursor + 7);
     if ((r = scan_back((const uint32_t *)ctx->ws_seg_cnt.p, (uint64_t *)ctx->ws_seg_dst.p, n_segs + 1))) return r;
     if (pad_fix)
         launch_contig_offsets(st, (const uint64_t *)ctx->ws_seg_dst.p, (const uint32_t *)ctx->ws_tile_first.p, n, n_segs,
@@ -1459,6 +1483,10 @@ int ShmmrJob::decide(bool &done) {
     n_final = mbox[9];
     l1_alloc_seen = l1_alloc;
     l2_alloc_seen = l2_alloc;
+    if (ctx->opt.debug_poison && !list_pending && mbox[7])
+        return ctx->fail(PGR_ERR_INTERNAL, "debug_poison: " + std::to_string(mbox[7]) +
+                                               " entries of the segment table a list stage read were not written by this job (they pointed "
+                                               "outside the level-1 buffer): a workspace of an earlier call was read uninitialised");
     if (l1_ovf || l1_alloc > cap_par) {  // (only possible without the early look)
         cap_par = (uint64_t)((double)l1_alloc * 1.1) + 65536;
         list_pending = false;
@@ -1711,6 +1739,8 @@ struct pgr_pipe {
     std::deque<int> order;  // slots in flight, oldest first
     int next = 0;
     bool commit_pending = false;  // copies into an index are queued on the back stream
+    hipEvent_t ev_commit = nullptr;  // ... recorded behind the last of them: a pass on another stream that rewrites the lane's record
+                                     // buffer (the copy's source) waits for it
     uint64_t *d_cursor = nullptr; // device: [0] = where the next direct job's records go in chain_ix's append buffer
     pgr_index *chain_ix = nullptr;
     bool chain_ok = false;        // every index job in flight is direct on chain_ix (the cursor is what the host would compute)
@@ -1787,6 +1817,7 @@ int pipe_records(pgr_pipe *p, pgr_pipe::Slot *sp, uint32_t n, hipStream_t st, co
         ctx->alloc_stream = saved_alloc;
         if (rc) return rc;
         ctx->block_on_back(ix->raw);
+        if (st == ctx->fix_stream) ctx->block_on_fix(ix->raw);  // (this pass writes it from the fix stream: a free remembers that stream too)
         sp->dst_cap = ix->cap_raw - ix->n_raw;
         launch_frag_recs_dev(st, d_list, d_off, n, cap, d_count, 0, rec_off, ix->raw + ix->n_raw, sp->dst_cap, nullptr, d_sids, nullptr, lds);
         sp->placed_by_host = true;
@@ -1831,6 +1862,7 @@ extern "C" int pgr_pipe_create(pgr_ctx *ctx, const pgr_spec *spec, pgr_pipe **ou
         if (e == hipSuccess) e = hipHostMalloc((void **)&s.pmail, 64, hipHostMallocDefault);
     }
     if (e == hipSuccess) e = hipMalloc((void **)&p->d_cursor, 64);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&p->ev_commit, hipEventDisableTiming);
     ++ctx->n_pipes;
     if (e != hipSuccess) {
         const std::string msg = std::string("pipe set-up: ") + hipGetErrorString(e);
@@ -1880,13 +1912,13 @@ extern "C" int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *
         else
             for (uint32_t i = 0; i < n; ++i) s.sids[i] = ix->next_sid + i;  // load_index_from_reader: running sid (seq_db.rs:543-553)
     }
-    if (ix) {
-        uint32_t mx = ix->next_sid;
-        for (uint32_t i = 0; i < n; ++i) mx = std::max(mx, s.sids[i] + 1);
-        ix->next_sid = mx;
-    }
+    uint32_t next_sid_after = ix ? ix->next_sid : 0;  // (assigned once the job is in flight: a failed submit leaves no hole in the running sids)
+    if (ix)
+        for (uint32_t i = 0; i < n; ++i) next_sid_after = std::max(next_sid_after, s.sids[i] + 1);
     const bool want_recs = ix != nullptr || d_recs != nullptr;
     const int ix_jobs = p->index_jobs_in_flight();
+    // (debug_poison fills the lane's workspaces when the job is planned: a staged copy out of its record buffer may still be queued)
+    if (ctx->opt.debug_poison && p->commit_pending) (void)hipStreamSynchronize(ctx->back_stream);
     LaneScope scope(ctx, *s.lane_p, ctx->back_stream);
     s.job.reset(new ShmmrJob());
     ShmmrJob &job = *s.job;
@@ -1948,6 +1980,10 @@ extern "C" int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *
         if (s.direct) p->chain_ok = false;
         return rc ? rc : ctx->fail(PGR_ERR_DEVICE, std::string("pipe submit: ") + hipGetErrorString(e));
     }
+    if (ix) {
+        ix->next_sid = next_sid_after;
+        ++ix->pipe_jobs;
+    }
     p->order.push_back(p->next);
     p->next ^= 1;
     return PGR_OK;
@@ -1963,6 +1999,7 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
     if (p->slot[p->order.front()].is_query) return ctx->fail(PGR_ERR_STATE, "the oldest job is a query job: pgr_pipe_collect_query");
     pgr_pipe::Slot &s = p->slot[p->order.front()];
     p->order.pop_front();
+    if (s.ix && s.ix->pipe_jobs > 0) --s.ix->pipe_jobs;
     std::unique_ptr<ShmmrJob> job = std::move(s.job);
     int rc = PGR_OK;
     pgr_shmmrs *res = nullptr;
@@ -1987,6 +2024,9 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
         hipStream_t fix = (ctx->fix_stream && !ctx->opt.no_fix_stream) ? ctx->fix_stream : ctx->stream;
         job->sf = job->sb = fix;
         ctx->alloc_stream = fix == ctx->stream ? nullptr : fix;
+        // (a staged copy out of this lane's record buffer may still be queued on the back stream -- the lane's previous job was collected
+        // without a second pass --: whatever this pass writes there comes behind it)
+        if (!rc && p->commit_pending && hipStreamWaitEvent(fix, p->ev_commit, 0) != hipSuccess) rc = ctx->fail(PGR_ERR_DEVICE, "event wait failed");
         job->optimistic = false;
         bool done = false;
         // (a direct job whose records are about to move: the other job's pass has placed its own behind them -- waited for BEFORE
@@ -2041,6 +2081,7 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
                 if (!rc && hipMemcpyAsync(ix->raw + ix->n_raw, ctx->ws_recs.p, np * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice,
                                           ctx->back_stream) != hipSuccess)
                     rc = ctx->fail(PGR_ERR_DEVICE, "copy of the pair records into the index failed");
+                if (!rc && hipEventRecord(p->ev_commit, ctx->back_stream) != hipSuccess) rc = ctx->fail(PGR_ERR_DEVICE, "event record failed");
                 if (!rc) {
                     ix->n_raw += np;
                     ix->finalized = false;
@@ -2202,7 +2243,9 @@ extern "C" int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out) {
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tq0).count());
     };
     if (!fallback) {
-        LaneScope scope(ctx, *s.lane_p, nullptr);
+        // whatever this scope still enqueues (a repeated shimmer decision, the run's redo of the per-query kernel) runs on the back
+        // stream: the blocks it takes and frees are the back stream's (round-5 advice: they were booked on the context's stream)
+        LaneScope scope(ctx, *s.lane_p, ctx->back_stream);
         if (hipEventSynchronize(s.ev_done) != hipSuccess || hipGetLastError() != hipSuccess)
             rc = ctx->fail(PGR_ERR_DEVICE, "pipelined query pass failed on the device");
         qlap("back stream done");
@@ -2253,9 +2296,21 @@ extern "C" void pgr_pipe_destroy(pgr_pipe *p) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->back_stream) (void)hipStreamSynchronize(ctx->back_stream);
+    if (ctx->fix_stream) (void)hipStreamSynchronize(ctx->fix_stream);
+    for (int i : p->order)  // jobs that were never collected
+        if (!p->slot[i].is_query && p->slot[i].ix && p->slot[i].ix->pipe_jobs > 0) --p->slot[i].ix->pipe_jobs;
     for (auto &s : p->slot) {
         s.job.reset();
-        if (s.lane_p) ctx->spare_lanes.push_back(s.lane_p);  // (pgr_ctx_destroy / pgr_ctx_trim release them)
+        if (s.lane_p) {
+            bool complete = s.lane_p->ev_end != nullptr;
+            for (auto &ev : s.lane_p->ev) complete = complete && ev != nullptr;
+            if (complete) {
+                ctx->spare_lanes.push_back(s.lane_p);  // (pgr_ctx_destroy / pgr_ctx_trim release them)
+            } else {  // a lane of a pgr_pipe_create that failed half way: not for the next pipe
+                pgr::lane_release(ctx, *s.lane_p);
+                delete s.lane_p;
+            }
+        }
         s.lane_p = nullptr;
         if (s.ev_front) (void)hipEventDestroy(s.ev_front);
         if (s.ev_done) (void)hipEventDestroy(s.ev_done);
@@ -2267,6 +2322,7 @@ extern "C" void pgr_pipe_destroy(pgr_pipe *p) {
         if (s.sids) (void)hipHostFree(s.sids);
     }
     if (p->d_cursor) (void)hipFree(p->d_cursor);
+    if (p->ev_commit) (void)hipEventDestroy(p->ev_commit);
     if (ctx->n_pipes > 0 && --ctx->n_pipes == 0) ctx->multi_stream = false;  // (both streams are idle: one-stream rule again)
     delete p;
 }
