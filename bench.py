@@ -48,6 +48,27 @@ def committed(*parts):
         return None
 
 
+def traffic_detail(tr, bp_per_launch, n_final, n_level1):
+    """roofline.traffic next to what it is made of: the read side with the MEASURED FETCH_SIZE factors of
+    this kernel's pattern (profiles/r05_calib), the write side split into the level-1 list (an intermediate, 12 B per level-1
+    minimizer: not algorithmic) and what the metric counts as output (16 B per final shimmer, written by the list stage)."""
+    if not tr or not tr.get("hbm_bytes_per_launch") or not bp_per_launch:
+        return {}
+    algo = ALGO_BYTES_PER_BP * bp_per_launch
+    d = {"traffic_low": tr.get("hbm_bytes_per_launch_low"),
+         "traffic_over_algorithmic": tr["hbm_bytes_per_launch"] / algo,
+         "traffic_low_over_algorithmic": (tr["hbm_bytes_per_launch_low"] / algo) if tr.get("hbm_bytes_per_launch_low") else None,
+         "read_side": {"algorithmic_bytes": 0.25 * bp_per_launch, "pmc_fetch_size_bytes": tr.get("fetch_size_bytes_raw"),
+                       "bytes_requested": tr.get("read_bytes_requested"), "bytes_distinct": tr.get("read_bytes_distinct"),
+                       "factors": tr.get("correction")},
+         "write_side": {"pmc_write_size_bytes": tr.get("write_size_bytes"),
+                        "level1_list_bytes": 12 * n_level1 if n_level1 else None,
+                        "algorithmic_final_output_bytes": 16 * n_final if n_final else None,
+                        "note": "the tile kernel writes the level-1 list (12 B per minimizer) and the segment tables; the final "
+                                "MM128 lists (16 B per shimmer, the algorithmic output) are written by the list stage behind it"}}
+    return d
+
+
 def valu_issue(bp_per_launch, launch_ms):
     """The bound that holds for the integer-hash kernel: VALU issue.  From tracked files only: profiles/traffic.json
     (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU2 and GRBM_GUI_ACTIVE of the committed PMC passes of this workload),
@@ -1341,6 +1362,8 @@ def main():
                 "bound": "valu", "kernel": "level1_tile_kernel",
                 "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                 "traffic": tr.get("hbm_bytes_per_launch") if tr.get("bp_per_launch") == bases_tiled else None,
+                "level1_minimizers": int(profs[-1][5]) if profs else None,
+                **(traffic_detail(tr, bases_tiled, sh.count, int(profs[-1][5]) if profs else None) if tr.get("bp_per_launch") == bases_tiled else {}),
                 "source": {"achieved, frac, avg_launch_ms": "measured in this run (HIP events around the kernel on its own stream)",
                            "traffic": "REPLAYED from profiles/traffic.json <- profiles/%s/pmc_summary.json (separate --pmc passes of "
                                       "this command), not from this run" % tr.get("profile")},

@@ -7,6 +7,7 @@
 // per-target regions -> <out>.NNN.hit[.bed] (+ <out>.NNN.fa with --fastx_file unless --only-summary) is host code
 // here as it is in the reference (rs:167-409), quirks included.
 #include <algorithm>
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,13 +96,22 @@ int main(int argc, char **argv) {
         else if (a == "--max-target-count") max_t = (uint32_t)atoi(val());
         else if (a == "--max-aln-chain-span") max_span = (uint32_t)atoi(val());
         else if (a == "--query-batch") query_batch = (size_t)std::max(1ll, atoll(val()));
-        else if (a == "--fastx_file") fastx_file = true;
-        else if (a == "--only-summary") only_summary = true;
-        else if (a == "--bed-summary") bed_summary = true;
-        else pos.push_back(a);
+        // (clap 4 derives kebab-case long names from the struct fields, pgr-query.rs:26-66: --fastx-file, --frg-file, --only-summary ...;
+        // the snake_case spellings of earlier rounds stay accepted)
+        else if (a == "--fastx-file" || a == "--fastx_file") fastx_file = true;
+        else if (a == "--frg-file" || a == "--frg_file") {
+            fprintf(stderr, "pgr-query: --frg-file (the reference's .frg sequence store, pgr-query.rs:26-27) is not supported: this program reads "
+                            "the .mdb/.midx pair (default) or, with --fastx-file, a FASTA/FASTQ(.gz) database\n");
+            return 2;
+        } else if (a == "--only-summary" || a == "--only_summary") only_summary = true;
+        else if (a == "--bed-summary" || a == "--bed_summary") bed_summary = true;
+        else if (a.size() > 1 && a[0] == '-' && !(a.size() > 1 && isdigit((unsigned char)a[1]))) {
+            fprintf(stderr, "pgr-query: unknown option %s\n", a.c_str());
+            return 2;
+        } else pos.push_back(a);
     }
     if (pos.size() != 3) {
-        fprintf(stderr, "usage: pgr-query <pgr_db_prefix | fasta> <query_fastx> <output_prefix> [--fastx_file] ...\n");
+        fprintf(stderr, "usage: pgr-query <pgr_db_prefix | fasta> <query_fastx> <output_prefix> [--fastx-file] [-w 80 -k 56 -r 4 -m 64] [-g 0.025] [--merge-range-tol 100000] [--max-count 128 --max-query-count 128 --max-target-count 128 --max-aln-chain-span 8] [--only-summary] [--bed-summary] [--query-batch N]\n");
         return 2;
     }
     pgr_ctx *ctx = nullptr;

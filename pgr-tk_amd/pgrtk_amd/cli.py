@@ -177,6 +177,10 @@ def chains_to_regions(query_result, merge_range_tol):
 
 
 def cmd_query(args):
+    if getattr(args, "frg_file", False):
+        sys.stderr.write("pgr-query: --frg-file (the reference's .frg sequence store, pgr-query.rs:26-27) is not supported: use the "
+                         ".mdb/.midx pair (default) or --fastx-file\n")
+        return 2
     sdb = SeqIndexDB()
     seqs_by_sid = None
     if args.fastx_file:
@@ -383,7 +387,10 @@ def main(argv=None):
     q.add_argument("pgr_db_prefix")
     q.add_argument("query_fastx_path")
     q.add_argument("output_prefix")
-    q.add_argument("--fastx_file", action="store_true")
+    # (clap 4 derives kebab-case long names, pgr-query.rs:26-30; the snake_case spelling of earlier rounds stays accepted)
+    q.add_argument("--fastx-file", "--fastx_file", dest="fastx_file", action="store_true")
+    q.add_argument("--frg-file", "--frg_file", dest="frg_file", action="store_true",
+                   help="the reference's .frg sequence store: not supported (use the .mdb/.midx pair or --fastx-file)")
     q.add_argument("-w", type=int, default=80)
     q.add_argument("-k", type=int, default=56)
     q.add_argument("-r", type=int, default=4)
@@ -414,8 +421,8 @@ def main(argv=None):
     b.add_argument("--bundle-merge-distance", dest="bundle_merge_distance", type=int, default=10000)
     b.set_defaults(fn=cmd_pbundle_decomp)
     args = ap.parse_args(argv)
-    args.fn(args)
+    return args.fn(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

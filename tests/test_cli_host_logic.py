@@ -139,3 +139,20 @@ def test_synthetic_generators_agree_with_the_oracle(oracle, tmp_path):
         assert r.returncode != 0 and "no CPU fallback" in r.stderr
     r = subprocess.run([exe, "--synthetic", "4by12", str(tmp_path / "p")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 2
+
+
+def test_pgr_query_accepts_claps_kebab_case_and_names_what_it_does_not_support(tmp_path):
+    """clap 4 derives `--fastx-file` / `--frg-file` from the struct fields (pgr-bin/src/bin/pgr-query.rs:26-30): the C++ program and the
+    Python CLI take the kebab-case spellings; `--frg-file` (the reference's own sequence store, not built here) is refused with a
+    message that says so, an unknown option is not mistaken for a path -- all before either asks for a GPU."""
+    import subprocess
+    from pgrtk_amd import cli
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "pgr-tk_amd", "bin", "pgr-query")
+    for flag in ("--frg-file", "--frg_file"):
+        r = subprocess.run([exe, "db", "q.fa", str(tmp_path / "o"), flag], capture_output=True, text=True, timeout=60)
+        assert r.returncode == 2 and "not supported" in r.stderr and "--fastx-file" in r.stderr, r.stderr
+        assert cli.main(["query", "db", "q.fa", str(tmp_path / "o"), flag]) == 2
+    r = subprocess.run([exe, "db", "q.fa", str(tmp_path / "o"), "--no-such-option"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "unknown option --no-such-option" in r.stderr
+    r = subprocess.run([exe, "db", "q.fa"], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 2 and "--fastx-file" in r.stderr  # (the usage line spells it clap's way)

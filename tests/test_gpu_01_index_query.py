@@ -410,7 +410,7 @@ def test_cpp_host_programs_match_python_cli(oracle, gpu_ctx, golden_dir, tmp_pat
     qfa.write_text(">q0 c\n%s\n>q1\n%s\n>q2\n%s\n>q3\n%s\n" % (
         src[200:3000].decode(), cli.reverse_complement(src[100:3300]).decode(),
         (recs[7][1][:1500] + recs[11][1][:1800]).decode(), seqgen.rnd(rng, 3000).decode()))
-    for db_py, db_cc, extra in ((py, cc, []), (py, cc, ["--bed-summary"]), (fa, fa, ["--fastx_file"]),
+    for db_py, db_cc, extra in ((py, cc, []), (py, cc, ["--bed-summary"]), (fa, fa, ["--fastx-file"]),
                                 (py, cc, ["--merge-range-tol", "10", "--max-aln-chain-span", "2", "-g", "0.5"])):
         for f in os.listdir(tmp_path):
             if f.startswith(("opy.", "occ.")):

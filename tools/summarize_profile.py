@@ -2,9 +2,10 @@
 """gpurun_out/prof_<tag> -> profiles/<name>/ (kernel_stats.csv, pmc_summary.json, bench.json) and
 profiles/traffic.json (HBM bytes per launch of the dominant kernel, read by bench.py).
 
-HBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE (KiB -> bytes): on gfx950 FETCH_SIZE reports half of the
-bytes of a wide coalesced streaming read (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is taken as is and was
-checked against the known size of the level-1 list written by the kernel."""
+HBM traffic per launch = k x FETCH_SIZE + WRITE_SIZE (KiB -> bytes).  On gfx950 FETCH_SIZE under-reports wide coalesced reads
+(MI355X_MICROARCH.md, HBM section: x 2 for a streaming read); for THIS kernel's pattern the factor was measured (profiles/r05_calib):
+1.81 (bytes requested) / 1.63 (distinct bytes) -- both are written out.  WRITE_SIZE is taken as is (calibration 1.000; it also
+matches the known size of the level-1 list written by the kernel)."""
 import collections
 import csv
 import glob
@@ -38,9 +39,19 @@ if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
     f = out[dom[0]]["FETCH_SIZE"]["mean_per_launch"] * 1024
     w = out[dom[0]]["WRITE_SIZE"]["mean_per_launch"] * 1024
     bench = json.load(open(os.path.join(dst, "bench.json"))) if os.path.exists(os.path.join(dst, "bench.json")) else {}
+    # FETCH_SIZE under-reports wide reads on gfx950 (the guide's correction: x 2).  The factor was MEASURED for this kernel's access
+    # pattern (tools/probe/fetch_calib.hip -> profiles/r05_calib/calibration.json, pattern read_tile_like: 4096-position tiles
+    # with the halos re-read): bytes REQUESTED by the loads = 1.81 x the counter, DISTINCT bytes = 1.63 x.  The halo re-reads are
+    # L2 hits or not, so HBM read traffic lies between the two; `hbm_bytes_per_launch` is the upper figure, `..._low` the lower.
+    cal = json.load(open(os.path.join(ROOT, "profiles", "r05_calib", "calibration.json")))["patterns"]["read_tile_like"]
+    k_req, k_dist = cal["requested_over_counter"], cal["distinct_over_counter"]
     t = {"kernel": "level1_tile_kernel", "profile": name, "bp_per_launch": bench.get("roofline", {}).get("bp_per_launch"),
-         "fetch_size_bytes_raw": f, "write_size_bytes": w, "hbm_bytes_per_launch": 2 * f + w,
-         "correction": "2 x FETCH_SIZE (gfx950 wide-read undercount) + WRITE_SIZE"}
+         "fetch_size_bytes_raw": f, "write_size_bytes": w,
+         "read_bytes_requested": k_req * f, "read_bytes_distinct": k_dist * f,
+         "hbm_bytes_per_launch": k_req * f + w, "hbm_bytes_per_launch_low": k_dist * f + w,
+         "hbm_bytes_per_launch_by_the_guides_factor_2": 2 * f + w,
+         "correction": "FETCH_SIZE x %.3f (requested) / x %.3f (distinct), measured for the tile pattern in profiles/r05_calib; "
+                       "WRITE_SIZE as is (calibration: 1.000)" % (k_req, k_dist)}
     if "SQ_INSTS_VALU" in out[dom[0]]:
         t["valu_wave_insts_per_launch"] = out[dom[0]]["SQ_INSTS_VALU"]["mean_per_launch"]
     if "SQ_ACTIVE_INST_VALU2" in out[dom[0]] and "GRBM_GUI_ACTIVE" in out[dom[0]]:
@@ -67,6 +78,8 @@ if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
         import bench as bench_mod
         r = bench["roofline"]
         r["traffic"] = t["hbm_bytes_per_launch"]
+        r.update(bench_mod.traffic_detail(t, r["bp_per_launch"], bench.get("config", {}).get("final_shimmers_per_gpu"),
+                                          bench.get("roofline", {}).get("level1_minimizers")))
         vi = bench_mod.valu_issue(r["bp_per_launch"], r["avg_launch_ms"])
         if vi:
             r["valu_issue"] = vi
