@@ -801,6 +801,7 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     import numpy as np
     import torch
     n_b, n_c, L = 10, 1000, 10_000_000
+    RESERVE_GIB = 56  # (the allocator's measured peak of this build is 53.8e9 bytes = 50.1 GiB)
     ctx.synchronize()
     # (NOT ctx.trim().  In a process that has allocated and released many GiB, every so-many-th large hipMalloc blocks for up to
     # seconds while the driver clears released memory (tools/probe/big_malloc_probe.py: torch alone shows it; the gaps and the
@@ -812,17 +813,24 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     fresh_process = None
     try:  # the one-shot case (pgr-mdb.rs:53-111: one process per file list): the same build in a process of its own
         import subprocess
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "t100_pipe_probe.py"), "pipe", str(n_b), "--json"],
-                           capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "t100_pipe_probe.py"), "pipe", str(n_b), "--json",
+                            "--reserve-gib", str(RESERVE_GIB)], capture_output=True, text=True, timeout=600)
         line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         fresh_process = {"first_pass": j["passes"][0], "repeat": j["passes"][-1], "context_create_s": j["context_create_s"],
+                                "pgr_ctx_reserve_s": j.get("reserve_s"), "reserved_GiB": j.get("reserve_gib"), "arena": j.get("arena"),
                                 "first_touch_of_4GiB_ms": j.get("first_touch_of_4GiB_ms"),
                                 "same_records_as_this_process": j["passes"][0]["records"],
                                 "what": "tools/t100_pipe_probe.py pipe %d --json in a new process (while this one still holds its memory)" % n_b}
     except Exception as e:  # noqa: BLE001
         fresh_process = {"error": repr(e)[:300]}
     fresh = P.Context(ctx.device)
+    # the build's device memory in ONE block, allocated and touched before the clock starts (pgr_ctx_reserve: what a one-shot host does
+    # first; round 5 measured 2.96 s for the first pass in this process, one multi-GB hipMalloc of it blocking for 2.3 s)
+    t_res = time.perf_counter()
+    fresh.reserve(int(RESERVE_GIB * (1 << 30)))
+    fresh.synchronize()
+    t_res = time.perf_counter() - t_res
     M = (1 << 64) - 1
 
     def once(keep):
@@ -868,6 +876,9 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
            "device_memory_free_before_this_leg_bytes": int(free_b), "device_memory_total_bytes": int(total_b),
            "held_by_the_benchs_own_context_bytes": int(held_b),
            "peak_device_bytes_of_the_allocator": peak0,
+           "pgr_ctx_reserve": {"GiB": RESERVE_GIB, "s": t_res, "arena_after_both_passes": fresh.arena_stats(),
+                               "note": "outside `s`: one hipMalloc + one first touch in front of the build; nothing of the build "
+                                       "then asks the runtime for device memory (fallback_calls counts what did)"},
            "slowest_enqueueing_call": {"call": slowest_call[0][0], "s": slowest_call[0][1],
                                        "note": "every call of the loop timed on the host: a first pass of seconds instead of 0.25 s is "
                                                "ONE of them waiting in a multi-GB hipMalloc while the driver clears memory this process "

@@ -142,6 +142,17 @@ const char *pgr_version(void);
  * the peak was last reset (reset_peak != 0 starts a new measurement). */
 int pgr_ctx_trim(pgr_ctx *ctx);
 int pgr_ctx_mem_stats(pgr_ctx *ctx, uint64_t *held_bytes, uint64_t *peak_bytes, int reset_peak);
+/* pgr_ctx_reserve: ONE block of device memory, allocated and touched here, that every later device allocation of the context
+ * (workspaces, batches, results, indexes, the caching allocator's blocks) is carved from and returns to.  For a host that runs
+ * one build per process (pgr-mdb: one shot per file list, pgr-bin/src/bin/pgr-mdb.rs:53-111): a multi-GB hipMalloc in the middle of
+ * a build can block for seconds, and device memory is slow at its first use (~26 ms per GiB) -- after a reserve neither happens
+ * inside the build.  Sizing: pgr_ctx_mem_stats' peak of an earlier run of the same shape, or ~5.4 bytes per base of TWO batches in
+ * flight + 40 bytes per expected pair record.  May be called again (grow-only: another block is added).  A request the arena
+ * cannot serve goes to the runtime's allocator as before and is counted (pgr_ctx_arena_stats: fallback_bytes / fallback_calls).
+ * Nothing is ever returned to the device before pgr_ctx_destroy.  Any out pointer of pgr_ctx_arena_stats may be NULL. */
+int pgr_ctx_reserve(pgr_ctx *ctx, uint64_t bytes);
+int pgr_ctx_arena_stats(pgr_ctx *ctx, uint64_t *reserved_bytes, uint64_t *used_bytes, uint64_t *peak_used_bytes,
+                        uint64_t *fallback_bytes, uint64_t *fallback_calls);
 int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value);
 int pgr_ctx_get_option(const pgr_ctx *ctx, const char *name, int64_t *value);
 

@@ -189,7 +189,7 @@ extern "C" int pgr_ctx_trim(pgr_ctx *ctx) {
     if (ctx->back_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->back_stream));
     if (ctx->fix_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->fix_stream));
     for (auto &kv : ctx->free_blocks) {
-        (void)hipFree(kv.second.p);
+        ctx->raw_free(kv.second.p);
         ctx->drop_events(kv.second);
         ctx->live_bytes -= kv.first;
     }
@@ -200,6 +200,24 @@ extern "C" int pgr_ctx_trim(pgr_ctx *ctx) {
         delete l;
     }
     ctx->spare_lanes.clear();
+    return PGR_OK;
+}
+
+// One hipMalloc, touched once, that every later device allocation of the context is carved from (csrc/pgr_ctx.h: Arena).
+extern "C" int pgr_ctx_reserve(pgr_ctx *ctx, uint64_t bytes) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    return ctx->reserve((size_t)bytes);
+}
+
+extern "C" int pgr_ctx_arena_stats(pgr_ctx *ctx, uint64_t *reserved_bytes, uint64_t *used_bytes, uint64_t *peak_used_bytes,
+                                   uint64_t *fallback_bytes, uint64_t *fallback_calls) {
+    if (!ctx) return PGR_ERR_INVALID_ARG;
+    if (reserved_bytes) *reserved_bytes = ctx->arena_bytes;
+    if (used_bytes) *used_bytes = ctx->arena_used;
+    if (peak_used_bytes) *peak_used_bytes = ctx->arena_peak;
+    if (fallback_bytes) *fallback_bytes = ctx->fallback_bytes;
+    if (fallback_calls) *fallback_calls = ctx->fallback_calls;
     return PGR_OK;
 }
 

@@ -15,16 +15,16 @@ namespace pgr {
 int DevBuf::ensure(pgr_ctx *ctx, size_t bytes, std::string *err) {
     if (bytes <= cap && p) return PGR_OK;
     if (p) {
-        (void)hipFree(p);
+        ctx->raw_free(p);
         p = nullptr;
         cap = 0;
     }
     // grow with head-room so that repeated calls with slightly different sizes do not reallocate
     size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-    hipError_t e = hipMalloc(&p, want);
+    hipError_t e = ctx->raw_alloc(&p, want);
     if (e != hipSuccess) {
         want = std::max<size_t>(bytes, 256);
-        e = hipMalloc(&p, want);
+        e = ctx->raw_alloc(&p, want);
     }
     if (e != hipSuccess) {
         p = nullptr;
@@ -47,25 +47,25 @@ int DevBuf::ensure_keep(pgr_ctx *ctx, size_t bytes, hipStream_t st) {
     if (bytes <= cap && p) return PGR_OK;
     void *np = nullptr;
     const size_t want = std::max<size_t>(bytes + bytes / 8, 256);
-    hipError_t e = hipMalloc(&np, want);
+    hipError_t e = ctx->raw_alloc(&np, want);
     if (e != hipSuccess)
         return ctx->fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(want) + "): " + hipGetErrorString(e));
     if (p && cap) {
         e = hipMemcpyAsync(np, p, cap, hipMemcpyDeviceToDevice, st);
         if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
-            (void)hipFree(np);
+            ctx->raw_free(np);
             return ctx->fail(PGR_ERR_DEVICE, std::string("workspace grow copy: ") + hipGetErrorString(e));
         }
-        (void)hipFree(p);
+        ctx->raw_free(p);
     }
     p = np;
     cap = want;
     return PGR_OK;
 }
 
-void DevBuf::release(pgr_ctx *) {
-    if (p) (void)hipFree(p);
+void DevBuf::release(pgr_ctx *ctx) {
+    if (p) ctx->raw_free(p);
     p = nullptr;
     cap = 0;
 }
@@ -208,6 +208,62 @@ int pgr_ctx::enable_multi_stream() {
     return PGR_OK;
 }
 
+// ---- the arena (pgr_ctx.h)
+int pgr_ctx::reserve(size_t bytes) {
+    if (bytes == 0) return PGR_OK;
+    bytes = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    Arena a;
+    hipError_t e = hipMalloc((void **)&a.base, bytes);
+    if (e != hipSuccess) return fail(PGR_ERR_NOMEM, std::string("pgr_ctx_reserve: hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
+    // touched once, here: the first use of untouched device memory is the other half of a cold start
+    e = hipMemsetAsync(a.base, opt.debug_poison ? 0xFF : 0, bytes, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) {
+        (void)hipFree(a.base);
+        return fail(PGR_ERR_DEVICE, std::string("pgr_ctx_reserve: first touch: ") + hipGetErrorString(e));
+    }
+    a.list.reset(bytes);
+    arenas.push_back(std::move(a));
+    arena_bytes += bytes;
+    return PGR_OK;
+}
+
+hipError_t pgr_ctx::raw_alloc(void **out, size_t bytes) {
+    *out = nullptr;
+    const size_t want = (std::max<size_t>(bytes, 1) + 4095) & ~(size_t)4095;
+    for (size_t ai = 0; ai < arenas.size(); ++ai) {
+        const size_t off = arenas[ai].list.take(want);
+        if (off == pgr::ArenaList::NONE) continue;
+        *out = arenas[ai].base + off;
+        arena_live[*out] = {(int)ai, want};
+        arena_used += want;
+        arena_peak = std::max(arena_peak, arena_used);
+        return hipSuccess;
+    }
+    const hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess && !arenas.empty()) {
+        fallback_bytes += bytes;
+        ++fallback_calls;
+        if (opt.debug) fprintf(stderr, "[pgr] arena exhausted: %zu bytes from hipMalloc (%zu of %zu arena bytes in use)\n", bytes, arena_used, arena_bytes);
+    }
+    return e;
+}
+
+void pgr_ctx::raw_free(void *p) {
+    if (!p) return;
+    auto it = arena_live.find(p);
+    if (it == arena_live.end()) {
+        (void)hipFree(p);
+        return;
+    }
+    // what hipFree guarantees, callers rely on (a grown workspace, a dropped cache): nothing of the block's past is still running
+    (void)hipDeviceSynchronize();
+    Arena &a = arenas[(size_t)it->second.first];
+    a.list.give_back((size_t)((char *)p - a.base), it->second.second);
+    arena_used -= it->second.second;
+    arena_live.erase(it);
+}
+
 int pgr_ctx::dmalloc(void **out, size_t bytes) {
     *out = nullptr;
     bytes = std::max<size_t>((bytes + 255) & ~(size_t)255, 256);
@@ -239,16 +295,16 @@ int pgr_ctx::dmalloc(void **out, size_t bytes) {
         }
     }
     void *p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = raw_alloc(&p, bytes);
     if (e != hipSuccess && !free_blocks.empty()) {  // drop the cache and retry
         for (auto &kv : free_blocks) {
-            (void)hipFree(kv.second.p);  // (synchronizes the device: nothing of a freed block's past is still running behind it)
+            raw_free(kv.second.p);  // (synchronizes the device: nothing of a freed block's past is still running behind it)
             drop_events(kv.second);
             live_bytes -= kv.first;
         }
         free_blocks.clear();
         cached_bytes = 0;
-        e = hipMalloc(&p, bytes);
+        e = raw_alloc(&p, bytes);
     }
     if (e != hipSuccess)
         return fail(PGR_ERR_NOMEM, std::string("hipMalloc(") + std::to_string(bytes) + "): " + hipGetErrorString(e));
@@ -264,7 +320,7 @@ void pgr_ctx::dfree(void *p) {
     if (!p) return;
     auto it = live_blocks.find(p);
     if (it == live_blocks.end()) {
-        (void)hipFree(p);
+        raw_free(p);
         return;
     }
     const size_t bytes = it->second.bytes;
@@ -275,13 +331,13 @@ void pgr_ctx::dfree(void *p) {
     // block (round 2) turned a streaming index build into a chain of device-wide stalls
     const size_t CAP = 160ull << 30;
     if (bytes > CAP) {
-        (void)hipFree(p);
+        raw_free(p);
         live_bytes -= bytes;
         return;
     }
     while (cached_bytes + bytes > CAP && !free_blocks.empty()) {
         auto it2 = free_blocks.begin();
-        (void)hipFree(it2->second.p);
+        raw_free(it2->second.p);
         drop_events(it2->second);
         cached_bytes -= it2->first;
         live_bytes -= it2->first;
@@ -509,14 +565,20 @@ void pgr_ctx::release_all() {
     }
     spare_lanes.clear();
     for (auto &kv : free_blocks) {
-        (void)hipFree(kv.second.p);
+        raw_free(kv.second.p);
         drop_events(kv.second);
     }
     free_blocks.clear();
-    for (auto &kv : live_blocks) (void)hipFree(kv.first);
+    for (auto &kv : live_blocks) raw_free(kv.first);
     live_blocks.clear();
     cached_bytes = 0;
     live_bytes = 0;
+    (void)hipDeviceSynchronize();
+    for (Arena &a : arenas)
+        if (a.base) (void)hipFree(a.base);
+    arenas.clear();
+    arena_live.clear();
+    arena_bytes = arena_used = 0;
     for (hipEvent_t e : ev_pool) (void)hipEventDestroy(e);
     ev_pool.clear();
     if (pinned) (void)hipHostFree(pinned);

@@ -1,6 +1,7 @@
 // pgr_ctx.h -- the context object behind the C ABI: one GPU, one stream, grow-only workspaces and a
 // small caching device allocator (so the steady state of repeated calls does no hipMalloc/hipFree).
 #pragma once
+#include "arena_list.h"
 #include <algorithm>
 #include <functional>
 #include <map>
@@ -152,6 +153,23 @@ struct pgr_ctx {
         bool on_back = false;  // handed out for work on the back stream (or marked: block_on_back): a free records that stream too
         bool on_fix = false;   // ... the same for the fix stream (handed out inside a second pass, or marked: block_on_fix)
     };
+    // ---- the arena under everything above (pgr_ctx_reserve, include/pgr_hip.h).  hipMalloc / hipFree of GiB blocks are not cheap
+    // calls on this platform: a multi-GB hipMalloc in a process that has freed as much before blocks for seconds
+    // (profiles/r05_target/big_malloc_probe.txt), and memory that has never been touched costs ~26 ms per GiB at first use.  A host
+    // that knows roughly what a build needs reserves it ONCE: one hipMalloc, touched once; from then on every workspace, result
+    // block and batch of this context is carved from it (address-ordered free list, best fit, neighbours coalesced) and goes back
+    // to it; the runtime's allocator is asked only when the arena cannot serve a request (counted: mem_fallback_bytes).
+    struct Arena {
+        char *base = nullptr;
+        pgr::ArenaList list;  // (csrc/arena_list.h: the free ranges)
+    };
+    std::vector<Arena> arenas;                 // grow-only: a later reserve adds one
+    std::map<void *, std::pair<int, size_t>> arena_live;  // block -> (arena, length)
+    size_t arena_bytes = 0, arena_used = 0, arena_peak = 0;
+    size_t fallback_bytes = 0, fallback_calls = 0;        // device memory taken from the runtime although an arena exists
+    int reserve(size_t bytes);
+    hipError_t raw_alloc(void **out, size_t bytes);  // arena first, then hipMalloc
+    void raw_free(void *p);                          // (like hipFree: nothing of the block's past is running when it returns)
     std::multimap<size_t, FreeBlock> free_blocks;
     std::map<void *, LiveBlock> live_blocks;
     size_t cached_bytes = 0;

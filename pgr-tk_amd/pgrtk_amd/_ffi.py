@@ -79,6 +79,8 @@ _SIGS = [
     ("pgr_host_unregister", C.c_int, [_VP]),
     ("pgr_ctx_trim", C.c_int, [_VP]),
     ("pgr_ctx_mem_stats", C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
+    ("pgr_ctx_reserve", C.c_int, [_VP, C.c_uint64]),
+    ("pgr_ctx_arena_stats", C.c_int, [_VP] + [C.POINTER(C.c_uint64)] * 5),
     ("pgr_ctx_set_option", C.c_int, [_VP, C.c_char_p, C.c_int64]),
     ("pgr_ctx_get_option", C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
     ("pgr_shmmr_batch", C.c_int, [_VP, C.POINTER(Spec), C.c_uint32, _PVP, C.POINTER(C.c_uint64),
@@ -353,6 +355,17 @@ class Context:
         a, b = C.c_uint64(), C.c_uint64()
         self.check(lib().pgr_ctx_mem_stats(self._h, C.byref(a), C.byref(b), int(reset_peak)))
         return int(a.value), int(b.value)
+
+    def reserve(self, n_bytes):
+        """one device block, allocated and touched now, that every later device allocation of this context is carved from
+        (include/pgr_hip.h: pgr_ctx_reserve)"""
+        self.check(lib().pgr_ctx_reserve(self._h, int(n_bytes)))
+
+    def arena_stats(self):
+        """-> dict(reserved, used, peak_used, fallback_bytes, fallback_calls) of the reserved arena (all 0 without a reserve)"""
+        v = [C.c_uint64() for _ in range(5)]
+        self.check(lib().pgr_ctx_arena_stats(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("reserved", "used", "peak_used", "fallback_bytes", "fallback_calls"), (int(x.value) for x in v)))
 
     def set_option(self, name, value=1):
         """tuning / A-B switch of this context (include/pgr_hip.h: pgr_ctx_set_option)"""

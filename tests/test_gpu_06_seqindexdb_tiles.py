@@ -204,3 +204,59 @@ def test_island_options_agree_with_the_oracle(oracle, gpu_ctx):
         sums, off = sh.checksum(), sh.offsets()
         for i in range(len(seqs)):
             assert int(off[i + 1] - off[i]) == len(refs[i]) and np.array_equal(sums[i], oracle.shmmr_checksum(refs[i])), (opt, i)
+
+
+def test_reserved_arena_serves_every_device_allocation(oracle, gpu_ctx):
+    """pgr_ctx_reserve (include/pgr_hip.h): one device block, allocated and touched up front, that workspaces, batches, results and the
+    index of a context are carved from.  A build (pipe, two batches in flight, records into one index) + queries in a context with a
+    2 GiB arena: the runtime's allocator is never asked (fallback_calls == 0), the index and the chains equal those of the shared
+    context (which has no arena) and the shimmers of sampled contigs equal the oracle's; a request the arena cannot hold is served
+    by the runtime and counted; blocks come back: after the build is destroyed the arena is as good as empty."""
+    import pgrtk_amd as P
+    sp_t = (80, 56, 4, 64, False)
+    spec, osp = P.make_spec(*sp_t), oracle.spec(*sp_t)
+    lens = [[3_000_000, 1_500_000, 70_000, 0, 999], [2_000_000, 2_500_000], [4_000_000]]
+
+    def build(ctx):
+        ix = P.Index(spec, ctx=ctx)
+        pipe = P.Pipe(spec, ctx=ctx)
+        kept, c0 = [], 0
+        for ls in lens:
+            ids = list(range(c0, c0 + len(ls)))
+            c0 += len(ls)
+            b = P.Batch.synthetic(ls, seed=21, ctx=ctx, contig_ids=ids)
+            if pipe.in_flight == 2:
+                kept.append(pipe.collect()[0])
+            pipe.submit(b, sids=ids, index=ix)
+        while pipe.in_flight:
+            kept.append(pipe.collect()[0])
+        pipe.close()
+        ix.finalize()
+        return ix, kept
+
+    ctx = P.Context(0)
+    ctx.reserve(2 << 30)
+    st0 = ctx.arena_stats()
+    assert st0["reserved"] == 2 << 30 and st0["used"] == 0
+    ix, kept = build(ctx)
+    ref_ix, _ = build(gpu_ctx)
+    assert ix.n_records == ref_ix.n_records > 30_000 and ix.records_checksum() == ref_ix.records_checksum()
+    mm, off = kept[0].download()
+    for c in (0, 2, 4):
+        ref = oracle.sequence_to_shmmrs(c, oracle.synth_contig(21, c, lens[0][c]).tobytes(), osp)
+        g = mm[int(off[c]):int(off[c + 1])]
+        assert len(ref) == len(g) and np.array_equal(ref["x"], g["x"]) and np.array_equal(ref["y"], g["y"]), c
+    qs = [oracle.synth_contig(21, 5, 2_000_000).tobytes()[100_000:112_000], oracle.synth_contig(21, 7, 4_000_000).tobytes()[3_000_000:3_009_000]]
+    ra, rb = ix.query_hps_raw(qs, 0.025), ref_ix.query_hps_raw(qs, 0.025)
+    assert all(np.array_equal(ra[k], rb[k]) for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps")) and len(ra["hps"]) > 20
+    st = ctx.arena_stats()
+    assert st["fallback_calls"] == 0 and st["fallback_bytes"] == 0, st
+    assert 0 < st["used"] <= st["peak_used"] <= st["reserved"]
+    big = P.Batch.synthetic([1_000_000_000] * 8, seed=3, ctx=ctx)  # 8 Gbp: 2-bit planes + validity = 3 GB > the arena
+    st2 = ctx.arena_stats()
+    assert st2["fallback_calls"] >= 1 and st2["fallback_bytes"] >= 900_000_000, st2  # (the planes are separate blocks: what still fits is carved, the rest comes from the runtime)
+    assert big.total_bases == 8_000_000_000
+    del big, ix, kept
+    ctx.trim()
+    st3 = ctx.arena_stats()
+    assert st3["used"] < st["used"], (st, st3)  # (workspaces of the context stay; results, batches, the index and the cache went back)

@@ -1,5 +1,6 @@
 """BASELINE.json's target on one GPU, cold: 100 Gbp of distinct synthetic contigs into ONE index in a FRESH context (first pass)
-and again (steady state), through the synchronous calls and through pgr_pipe_*.  usage: t100_pipe_probe.py [sync|pipe] [batches]"""
+and again (steady state), through the synchronous calls and through pgr_pipe_*.
+usage: t100_pipe_probe.py [sync|pipe] [batches] [--reserve-gib G] [--json]      (--reserve-gib: pgr_ctx_reserve first, timed apart)"""
 import os
 import sys
 import time
@@ -11,6 +12,11 @@ import pgrtk_amd as P  # noqa: E402
 
 as_json = "--json" in sys.argv
 argv = [a for a in sys.argv[1:] if a != "--json"]
+reserve_gib = 0.0
+if "--reserve-gib" in argv:
+    i = argv.index("--reserve-gib")
+    reserve_gib = float(argv[i + 1])
+    del argv[i:i + 2]
 mode = argv[0] if len(argv) > 0 else "pipe"
 n_b = int(argv[1]) if len(argv) > 1 else 10
 n_c, L = 1000, 10_000_000
@@ -30,6 +36,12 @@ t_ctx = time.perf_counter()
 ctx = P.Context(0)
 spec = P.make_spec()
 t_ctx = time.perf_counter() - t_ctx
+t_reserve = None
+if reserve_gib > 0:  # one block for the whole build, allocated and touched now (include/pgr_hip.h: pgr_ctx_reserve)
+    t_reserve = time.perf_counter()
+    ctx.reserve(int(reserve_gib * (1 << 30)))
+    ctx.synchronize()
+    t_reserve = time.perf_counter() - t_reserve
 
 
 rbuf = [torch.empty((33_000_000, 5), dtype=torch.int64, device="cuda:0") for _ in range(2)] if os.environ.get("T100_RECPTR") else None
@@ -80,7 +92,8 @@ def once():
 
 
 if not as_json:
-    print("%s: context created in %.3f s; first touch of 4 GiB of device memory %.1f ms" % (mode, t_ctx, first_touch_ms), flush=True)
+    print("%s: context created in %.3f s; first touch of 4 GiB of device memory %.1f ms%s" %
+          (mode, t_ctx, first_touch_ms, "; pgr_ctx_reserve(%.0f GiB) %.3f s" % (reserve_gib, t_reserve) if t_reserve is not None else ""), flush=True)
 res = []
 for what in ("fresh context", "again", "again"):
     ctx.mem_stats(reset_peak=True)
@@ -94,4 +107,5 @@ for what in ("fresh context", "again", "again"):
               % (mode, what, n_b * n_c * L // 10**9, a + b, a, b, nr, nk, cs[0], cs[1]), flush=True)
 if as_json:
     import json
-    print(json.dumps({"mode": mode, "bp": n_b * n_c * L, "context_create_s": t_ctx, "first_touch_of_4GiB_ms": first_touch_ms, "passes": res}), flush=True)
+    print(json.dumps({"mode": mode, "bp": n_b * n_c * L, "context_create_s": t_ctx, "first_touch_of_4GiB_ms": first_touch_ms,
+                      "reserve_gib": reserve_gib, "reserve_s": t_reserve, "arena": ctx.arena_stats(), "passes": res}), flush=True)
