@@ -154,6 +154,12 @@ int pgr_ctx_reserve(pgr_ctx *ctx, uint64_t bytes);
 int pgr_ctx_arena_stats(pgr_ctx *ctx, uint64_t *reserved_bytes, uint64_t *used_bytes, uint64_t *peak_used_bytes,
                         uint64_t *fallback_bytes, uint64_t *fallback_calls);
 int pgr_ctx_set_option(pgr_ctx *ctx, const char *name, int64_t value);
+/* pgr_debug_take_hip_error: the HIP runtime keeps, per host thread, the last error any of its calls returned until somebody asks
+ * for it -- and rocPRIM asks after every launch, so an error some earlier call (of this library, of PyTorch, of the host program)
+ * left behind used to surface as the failure of an unrelated scan.  The library's rocPRIM wrappers now take stale state away before
+ * they call rocPRIM; this entry point takes it (hipGetLastError) and returns it as an int (0: none) -- the GPU tests call it after
+ * every test and fail the test that left one.  No reference counterpart (debug aid). */
+int pgr_debug_take_hip_error(void);
 int pgr_ctx_get_option(const pgr_ctx *ctx, const char *name, int64_t *value);
 
 /* ------------------------------------------------------------------ B1: sequence_to_shmmrs

@@ -43,7 +43,7 @@ const std::vector<OptionName> &option_names() {
         {"debug", &O::debug}, {"debug_times", &O::debug_times}, {"gpu_pack", &O::gpu_pack}, {"no_small_path", &O::no_small_path},
         {"no_pipeline", &O::no_pipeline}, {"early_sync_bp", &O::early_sync_bp}, {"index_full_sort", &O::index_full_sort},
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query}, {"direct_query_result", &O::direct_query_result}, {"direct_query_results_delivered", &O::direct_query_results_delivered}, {"direct_query_lds_kb", &O::direct_query_lds_kb},
-        {"no_query_chaining", &O::no_query_chaining}, {"query_global_sort", &O::query_global_sort},
+        {"no_query_chaining", &O::no_query_chaining}, {"no_query_level1", &O::no_query_level1}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s}, {"exchange_rccl_world1", &O::exchange_rccl_world1}, {"debug_poison", &O::debug_poison}, {"debug_inject_stale_segments", &O::debug_inject_stale_segments},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
@@ -220,6 +220,8 @@ extern "C" int pgr_ctx_arena_stats(pgr_ctx *ctx, uint64_t *reserved_bytes, uint6
     if (fallback_calls) *fallback_calls = ctx->fallback_calls;
     return PGR_OK;
 }
+
+extern "C" int pgr_debug_take_hip_error(void) { return (int)hipGetLastError(); }
 
 extern "C" int pgr_ctx_mem_stats(pgr_ctx *ctx, uint64_t *held_bytes, uint64_t *peak_bytes, int reset_peak) {
     if (!ctx) return PGR_ERR_INVALID_ARG;

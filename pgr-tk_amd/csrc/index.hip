@@ -1758,6 +1758,43 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
         const double dens = sp.sketch ? 1.0 / (double)(1ull << (4 + sp.r)) : 2.0 / (double)(sp.w + 1) * keep * keep;
         pairs_hint = (uint32_t)std::min<double>((double)max_len * dens * 1.6 + 4.0, 1e9);
     }
+    // The level-1 form first (pgr_aln.h: QfLevel1View): the tile kernel of the queries, then the per-query kernel straight on its
+    // segments -- no list stage of the batch, one host wait.  What it declines (islands needed, a query that outgrows the LDS
+    // image) goes on below as before; an index whose batches are flagged skips the attempt for its next calls.
+    if (fused_on && pairs_hint && n_queries && !ctx->opt.no_query_level1 && ix->fused_l1_skip.load(std::memory_order_relaxed) == 0 &&
+        query_fused_eligible(ctx, n_queries, pairs_hint, max_aln_span)) {
+        uint32_t max_len = 0;
+        for (uint32_t c = 0; c < b->n; ++c) max_len = std::max(max_len, b->h_len[c]);
+        const uint32_t c1 = query_fused_level1_cap(max_len, ix->spec.w);
+        if (c1) {
+            QueryFusedRun run(ctx, ix, n_queries, pairs_hint, fqp, fap);
+            bool taken = false;
+            int rc1 = shmmr_level1_then(ctx, b, &ix->spec, [&](const QfLevel1View &v) { return run.enqueue_from_level1(v, c1); }, &taken);
+            if (rc1) return rc1;
+            if (taken) {
+                PGR_HIP(ctx, hipStreamSynchronize(st));
+                ctx->staged_unsynced = false;
+                ctx->want_host_copy = false;
+                const auto t2 = now();
+                if (run.enqueued) {
+                    QueryFusedCounts fc;
+                    bool declined = false;
+                    if ((rc1 = run.finish(out, &fc, &declined))) return rc1;
+                    if (!declined) {
+                        qp.n_query_pairs = fc.n_pairs;
+                        fused_done(fc, t2, 3);
+                        return PGR_OK;
+                    }
+                    if (run.l1_flagged) ix->fused_l1_skip.store(4, std::memory_order_relaxed);
+                    if (ctx->opt.debug)
+                        fprintf(stderr, "[pgr] query batch %u: the level-1 form declined (%s): the shimmer pipeline takes it\n", n_queries,
+                                run.l1_flagged ? "the tile kernel asked for islands" : "a query outgrows its LDS image");
+                }
+            }
+        }
+    } else if (const uint32_t left = ix->fused_l1_skip.load(std::memory_order_relaxed)) {
+        ix->fused_l1_skip.store(left - 1, std::memory_order_relaxed);
+    }
     std::unique_ptr<QueryFusedRun> chained;
     if (fused_on && pairs_hint && query_fused_eligible(ctx, n_queries, pairs_hint, max_aln_span) && !ctx->opt.no_query_chaining) {
         chained.reset(new QueryFusedRun(ctx, ix, n_queries, pairs_hint, fqp, fap));

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <functional>
+
 #include "pgr_index.h"
 
 namespace pgr {
@@ -106,9 +108,35 @@ __device__ __forceinline__ void lookup_range(uint64_t h0, uint64_t h1, const pgr
 // than HITS_HEAVY records, a (query, target) group too long for the register DP): the caller takes the general path.
 struct QueryFusedCounts {
     uint64_t n_signatures = 0, n_hits = 0;
+    uint64_t n_pairs = 0;  // (level-1 form: the queries' shimmer pairs, which only the device has counted)
 };
 constexpr uint32_t QF_MAX_PAIRS = 128;  // shimmer pairs of one query
 bool query_fused_eligible(const pgr_ctx *ctx, uint32_t n_queries, uint64_t max_pairs, uint32_t max_aln_span);
+
+// The level-1 form of the per-query kernel: no list stage of the batch at all.  The shimmer pipeline's list stage (two scans,
+// block_first_seg, fused_select, gather, offsets_by_rid, pair_offsets, frag_recs_dev: 11 dependent launches) exists to put the
+// level-1 minimizers of ALL contigs of a batch into one global order; a query's wavefront needs its own ~250 only.  It reads them
+// from the tile kernel's segments (contig q owns the segments tile_first[q] + q .. tile_first[q + 1] + q), reduces twice, applies
+// min_span and forms the pairs in LDS (shmmrutils.rs:359-415, 533-555; seq_db.rs:1205-1217), then goes on as before.  What the
+// level-1 kernels flag (islands needed: a palindromic k-mer, a non-ACGT byte; an overflow) declines the batch on the device: the
+// shimmer pipeline takes it as it always did.
+struct L1Rec;
+struct QfLevel1View {
+    const L1Rec *l1 = nullptr;            // the level-1 buffer (tile slots, overflow region, tail slots)
+    const uint64_t *seg_off = nullptr;    // [n_tiles + n]
+    const uint32_t *seg_cnt = nullptr;
+    const uint32_t *tile_first = nullptr;  // [n + 1] (device)
+    const unsigned long long *status = nullptr;  // the level-1 cursor words: [0] overflow taken [1] overflow too small [2] islands needed
+    uint64_t ovf_cap = 0;
+    uint32_t *flags = nullptr;  // six 32-bit words cleared in front of the tile kernel (the cursor words of the list stage that does not run)
+    uint32_t r = 0, min_span = 0;
+};
+constexpr uint32_t QF_C1_MAX = 2048;  // level-1 minimizers of one query (16 B of LDS each)
+// level-1 minimizers to make room for, for queries of up to max_len bases (density 2 / (w + 1) with room); 0: too long for the form
+uint32_t query_fused_level1_cap(uint32_t max_len, uint32_t w);
+// pipeline.hip: stage 1 of the shimmer pipeline alone (tile descriptors, flags, tiles + tails) and `consumer` right behind it
+int shmmr_level1_then(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const std::function<int(const QfLevel1View &)> &consumer,
+                      bool *taken);
 
 // One batch through the per-query kernel.  enqueue*() puts the kernels and the first download on the context's stream (nothing
 // waits); finish() runs behind a synchronization of that stream and hands out the result -- or says `declined`.
@@ -137,6 +165,11 @@ struct QueryFusedRun {
     QueryFusedRun &operator=(const QueryFusedRun &) = delete;
     int enqueue(const pgr_frag_rec *d_qrec, const uint64_t *d_pair_off, bool flags_cleared = false);
     int enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count);
+    // the level-1 form: behind the tile kernel of the queries (C1 from query_fused_level1_cap); finish() as for the others --
+    // `declined` with l1_flagged set means the level-1 kernels asked for the shimmer pipeline (islands, overflow)
+    int enqueue_from_level1(const QfLevel1View &v, uint32_t c1);
+    bool from_l1 = false, l1_flagged = false;
+    uint32_t C1 = 0;
     int finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *declined);
 
 private:
@@ -150,6 +183,7 @@ private:
     size_t cap = 0, first = 0;
     const pgr_frag_rec *qrec_used = nullptr;
     const uint64_t *pair_off_used = nullptr;
+    QfLevel1View l1v;
 };
 
 }  // namespace pgr

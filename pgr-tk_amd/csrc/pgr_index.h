@@ -30,6 +30,7 @@ struct pgr_index {
     // (query_fused.hip) declined a batch on this index
     // (hints only, relaxed atomics: contexts on several threads may query one index)
     mutable std::atomic<uint32_t> fused_skip{0};
+    mutable std::atomic<uint32_t> fused_l1_skip{0};  // ... that skip the level-1 form (its last batch was flagged by the tile kernel)
     mutable std::atomic<uint32_t> fused_pairs{0};  // most shimmer pairs of one query in the last batch (0: no batch yet)
     mutable std::atomic<uint32_t> fused_hits{0};  // slot size (hits per query) the last batch of short queries needed, 0: the minimum
     mutable std::atomic<float> fused_per_q[3] = {{-1.0f}, {-1.0f}, {-1.0f}};  // targets / chains / hit pairs per query of that batch (-1: none yet)

@@ -1625,6 +1625,44 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     return job.run_sync(out);  // (a failing pass releases the result and its device blocks with the job)
 }
 
+// Stage 1 ALONE of a resident batch -- tile descriptors, flags, the tile kernel with the contigs' tails -- and a consumer of the
+// level-1 segments enqueued right behind it on the context's stream: the query path's level-1 form (pgr_aln.h: QfLevel1View;
+// query_fused.hip), whose wavefronts run the list stage of their own query.  Nothing waits here.  *taken = false: the batch is
+// not for this form (no tile path for the spec, the host packer has seen non-ACGT bytes, no bases) and nothing was enqueued.
+int pgr::shmmr_level1_then(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const std::function<int(const QfLevel1View &)> &consumer,
+                           bool *taken) {
+    *taken = false;
+    if (spec->sketch || spec->w < (uint32_t)L1_MIN_W || b->host_saw_invalid || b->n == 0 || b->total_bases == 0) return PGR_OK;
+    ShmmrJob job;
+    job.ctx = ctx;
+    job.b = b;
+    job.spec = *spec;
+    job.rids = nullptr;
+    job.padding = 0;
+    job.sf = job.sb = ctx->stream;
+    job.dbg_t = ctx->opt.debug_times != 0;
+    job.dbg_t0 = std::chrono::steady_clock::now();
+    int rc;
+    if ((rc = job.plan())) return rc;
+    if (!job.serial.empty() || !job.bases_tiled) return PGR_OK;
+    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], job.sf));
+    if ((rc = job.stage1())) return rc;
+    QfLevel1View v;
+    v.l1 = job.a.out;
+    v.seg_off = job.a.seg_off;
+    v.seg_cnt = job.a.seg_cnt;
+    v.tile_first = job.a.tile_first;
+    v.status = job.d_cursor;
+    v.ovf_cap = job.cap_par;
+    v.flags = (uint32_t *)(job.d_cursor + 4);  // (the list stage's cursor words and the one behind them: cleared with the others, and no list stage runs)
+    v.r = spec->r;
+    v.min_span = spec->min_span;
+    *taken = true;
+    rc = consumer(v);
+    job.dbg_lap("stage 1 + the per-query kernel enqueued");
+    return rc;
+}
+
 // B1 + seq_to_index in ONE call and ONE wait: the index-side pair records (seq_db.rs:381-400) are derived on the device behind the
 // list stage (counts and offsets never visit the host) and land in the caller's device buffer; what pgr_shmmrs_compute followed
 // by pgr_shmmrs_to_frag_recs_device does in two calls, two waits and two pageable table copies.

@@ -37,6 +37,7 @@
 #include "pgr_device.h"
 #include "pgr_host.h"
 #include "pgr_index.h"
+#include "pgr_internal.h"
 
 namespace pgr {
 
@@ -49,6 +50,9 @@ namespace {
 constexpr uint32_t QF_P_MIN = 64, QF_H_MIN = 64, QF_H_MAX = 512;
 constexpr uint32_t QF_DECLINE = 1u, QF_MORE_HITS = 2u;  // flags[0]: the batch does not fit at all / fits with a larger H
 constexpr uint32_t QF_LOOKBACK_TIMEOUT = 4u;            // (with QF_DECLINE) the single-pass form gave up waiting for a predecessor
+// the level-1 form: (with QF_DECLINE) the level-1 kernels asked for islands / overflowed (the batch is for the shimmer pipeline);
+// a query has more pairs than P / more level-1 minimizers than C1 (flags[3] / flags[4] say how many: once more with room)
+constexpr uint32_t QF_L1_FLAGGED = 8u, QF_MORE_PAIRS = 16u, QF_MORE_L1 = 32u;
 
 struct QfArgs {
     const pgr_frag_rec *qrec;
@@ -80,13 +84,30 @@ struct QfArgs {
     uint8_t *host;         // the pinned block, laid out by qf_layout(n_queries, cap_t, cap_c, cap_h)
     uint64_t cap_t, cap_c, cap_h;
     uint64_t *words;       // the pinned mailbox (the totals, written by the last query's wavefront)
+    // the level-1 form (qf_one_query<true>): the query's level-1 minimizers come straight from the tile kernel's segments -- contig q
+    // owns the segments [tile_first[q] + q, tile_first[q + 1] + q] (its tiles, then its tail) -- and the wavefront runs the list
+    // stage itself (both reductions, min_span, the pairs) on them in LDS
+    const L1Rec *l1;
+    const uint64_t *seg_off;
+    const uint32_t *seg_cnt;
+    const uint32_t *tile_first;
+    const unsigned long long *l1_status;  // the level-1 kernels' cursor words: [0] overflow elements taken, [1] overflow region too small, [2] islands needed
+    uint64_t l1_ovf_cap;
+    uint32_t C1;  // level-1 minimizers a query may have
+    uint32_t r, min_span;
 };
 
-// dynamic LDS: h0[P] h1[P] lo[P] (u64) | nrec[P] pc[P] hoff[P] (u32) | hit[H] (24 B) | hsid[H] ssid[H] perm[H] (u32)
-//              [ | vs[H] (f32) sl[H] pv[H] (i32) | span_q[64][3] cand[4][64] (u32) ]
-inline size_t qf_lds_bytes(uint32_t P, uint32_t H, bool long_groups) {
-    return (size_t)P * 36 + (size_t)H * (sizeof(pgr_hitpair) + 12) + (long_groups ? (size_t)H * 12 + (64 * 3 + 4 * 64) * 4 : 0);
+// dynamic LDS: h0[P] h1[P] lo[P] (u64) | nrec[P] pc[P] hoff[P] (u32) [ | bgn[P] end_or[P] (u32): level-1 form ]
+//              | hit[H] (24 B) | hsid[H] ssid[H] perm[H] (u32) [ | vs[H] (f32) sl[H] pv[H] (i32) | span_q[64][3] cand[4][64] (u32) ]
+// level-1 form (C1 > 0): the level-1 list -- key1[C1] (u64) ypos1[C1] (u32), + the segment table sbase[65] soff[64] -- shares its
+// bytes with the hits (the pairs are formed before the first hit is written), its index lists idx_a[C1] idx_b[C1] (u16) with the pairs
+constexpr uint32_t QF_L1_SEGS = 64;  // segments (tiles + tail) of one query the level-1 form can take
+inline __host__ __device__ size_t qf_l1_bytes(uint32_t C1) { return C1 ? (size_t)C1 * 12 + (QF_L1_SEGS + 2) * 4 + QF_L1_SEGS * 8 + 8 : 0; }
+inline size_t qf_lds_bytes(uint32_t P, uint32_t H, bool long_groups, uint32_t C1 = 0) {
+    const size_t hits = (size_t)H * (sizeof(pgr_hitpair) + 12) + (long_groups ? (size_t)H * 12 + (64 * 3 + 4 * 64) * 4 : 0);
+    return (size_t)P * (C1 ? 44 : 36) + std::max(hits, qf_l1_bytes(C1));
 }
+// (the level-1 form keeps its two index lists, 4 B per level-1 minimizer, in the pairs' 44 P bytes: P at least C1 / 11)
 
 // sparse_aln for one group of n <= 64 hits (hit[perm[0..n)], ascending query bgn), the whole wavefront, hit j in lane j.
 // Appends the group's chains to the slot: hit pairs at o_hp[nh..], scores / first-hit offsets at [nc..]; returns true when
@@ -390,25 +411,211 @@ __device__ __forceinline__ void lookup_range_short(uint64_t h0, uint64_t h1, con
     lookup_range(h0, h1, a.recs, a.key_off, a.n_keys, a.lut, a.lut_bits, a.lut_shift, a.keys, lo_out, hi_out);
 }
 
+// ---- the list stage of ONE query on one wavefront (the level-1 form).  reduce_shmmr without padding (shmmrutils.rs:359-415): an
+// element survives iff it is an arg-min of some full r-window of its list = at least r consecutive elements including itself are
+// >= it (small.hip has the 256-lane form of the same predicate).  list: indices into key (nullptr: the identity).
+template <int TR>
+__device__ __forceinline__ bool qf_reduce_keep(const uint64_t *key, const uint16_t *list, int n, int k, uint32_t r_rt) {
+    const uint32_t r = TR ? (uint32_t)TR : r_rt;
+    const uint64_t xi = key[list ? list[k] : k];
+    uint32_t run = 1;
+    bool left = true, right = true;
+#pragma unroll
+    for (uint32_t d = 1; d < (TR ? (uint32_t)TR : 12u); ++d) {
+        if (!TR && d >= r) break;
+        const int kl = k - (int)d, kr = k + (int)d;
+        const bool in_l = kl >= 0, in_r = kr < n;
+        const uint64_t xl = key[in_l ? (list ? list[kl] : kl) : 0], xr = key[in_r ? (list ? list[kr] : kr) : 0];
+        left = left && in_l && xl >= xi;
+        right = right && in_r && xr >= xi;
+        run += (left ? 1u : 0u) + (right ? 1u : 0u);
+    }
+    return run >= r;
+}
+// ordered compaction by one wavefront: out[j] = src(k) for the k in [0, n) with pred(k), in order; returns how many
+template <class Pred, class Src>
+__device__ __forceinline__ uint32_t qf_compact(uint32_t n, int lane, uint16_t *out, Pred pred, Src src) {
+    const uint64_t lt = lane ? (U64MAX >> (64 - lane)) : 0ull;
+    uint32_t total = 0;
+    for (uint32_t b = 0; b < n; b += 64) {  // (uniform)
+        const uint32_t k = b + (uint32_t)lane;
+        const bool keep = k < n && pred(k);
+        const uint64_t bal = __ballot(keep);
+        if (keep) out[total + (uint32_t)__popcll(bal & lt)] = src(k);
+        total += (uint32_t)__popcll(bal);
+    }
+    return total;
+}
+
 // One query, the whole wavefront: chains into the query's slot; the counts come back wave-uniform (all zero for a query the
-// path cannot hold: the batch's flags say why).
+// path cannot hold: the batch's flags say why).  L1: the level-1 form (QfArgs).
+template <bool L1>
 __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, const uint32_t q, const int lane, uint32_t &nt,
-                                             uint32_t &nc, uint32_t &nh, uint32_t &n_hits_out, unsigned long long &nsig) {
+                                             uint32_t &nc, uint32_t &nh, uint32_t &n_hits_out, unsigned long long &nsig,
+                                             uint32_t &n_pairs_out) {
     const uint32_t P = a.P, H = a.H;
+    n_pairs_out = 0;
     uint64_t *L_h0 = reinterpret_cast<uint64_t *>(qf_dyn), *L_h1 = L_h0 + P, *L_lo = L_h1 + P;
     uint32_t *L_nrec = reinterpret_cast<uint32_t *>(L_lo + P), *L_pc = L_nrec + P, *L_hoff = L_pc + P;
-    pgr_hitpair *hit = reinterpret_cast<pgr_hitpair *>(L_hoff + P);
+    uint32_t *L_bgn = L_hoff + P, *L_eo = L_bgn + P;  // (level-1 form only: begin, end | orient << 31 of the pair)
+    pgr_hitpair *hit = reinterpret_cast<pgr_hitpair *>(L_hoff + (L1 ? 3 * P : P));
     uint32_t *hsid = reinterpret_cast<uint32_t *>(hit + H), *ssid = hsid + H, *perm = ssid + H;
-    const uint64_t p0 = a.pair_off[q];
-    const uint64_t np64 = a.pair_off[q + 1] - p0;
     uint32_t m = 0;
     nt = nc = nh = n_hits_out = 0;
     nsig = 0;
-    bool decline = np64 > (uint64_t)P;
-    const int np = decline ? 0 : (int)np64;
+    bool decline = false;
+    int np = 0;
+    uint64_t p0 = 0;
+    if (L1) {
+        // ---- the level-1 kernels' own verdict first: a batch that needs islands or overflowed belongs to the shimmer pipeline
+        const unsigned long long s0 = a.l1_status[0], s1 = a.l1_status[1], s2 = a.l1_status[2];
+        if (s1 || s2 || s0 > a.l1_ovf_cap) {
+            if (q == 0 && lane == 0) {
+                const uint32_t was = atomicOr(a.flags, QF_DECLINE | QF_L1_FLAGGED);
+                asm volatile("" ::"v"(was));
+            }
+            return;
+        }
+        const uint32_t C1 = a.C1;
+        uint64_t *key1 = reinterpret_cast<uint64_t *>(hit);
+        uint32_t *ypos1 = reinterpret_cast<uint32_t *>(key1 + C1);
+        uint32_t *sbase = ypos1 + C1;                                           // [QF_L1_SEGS + 1] first list place of a segment
+        uint64_t *soff = reinterpret_cast<uint64_t *>(sbase + QF_L1_SEGS + 2);  // [QF_L1_SEGS] its first record
+        // (the two index lists live where the pairs will be: nothing of a pair is written before the final list has been read)
+        uint16_t *idx_a = reinterpret_cast<uint16_t *>(qf_dyn), *idx_b = idx_a + C1;
+        // ---- the query's segments: its tiles in order, then its tail
+        const uint32_t tf0 = a.tile_first[q], tf1 = a.tile_first[q + 1];
+        const uint32_t nseg = tf1 - tf0 + 1, seg0 = tf0 + q;
+        if (nseg > QF_L1_SEGS) {
+            if (lane == 0) {
+                const uint32_t was = atomicOr(a.flags, QF_DECLINE);
+                asm volatile("" ::"v"(was));
+            }
+            return;
+        }
+        const bool sl = (uint32_t)lane < nseg;
+        const uint32_t scnt = sl ? a.seg_cnt[seg0 + lane] : 0u;
+        const uint64_t sof = sl ? a.seg_off[seg0 + lane] : 0ull;
+        const uint32_t sincl = wave_incl_sum(scnt);
+        const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
+        if (n1 > C1) {  // (low-complexity sequence: denser than the estimate)
+            if (lane == 0) {
+                const uint32_t was = atomicMax(a.flags + 4, n1) | atomicOr(a.flags, QF_MORE_L1);
+                asm volatile("" ::"v"(was));
+            }
+            return;
+        }
+        if (sl) {
+            sbase[lane] = sincl - scnt;
+            soff[lane] = sof;
+        }
+        if (lane == 0) sbase[nseg] = n1;
+        wave_sync();
+        // (six records per lane in flight at once: one trip to memory for a 10 kbp query's ~250 instead of one per 64)
+        constexpr int QF_L1_U = 6;
+        for (uint32_t e0 = 0; e0 < n1; e0 += 64 * QF_L1_U) {  // (uniform)
+            L1Rec rec[QF_L1_U];
+#pragma unroll
+            for (int u = 0; u < QF_L1_U; ++u) {
+                const uint32_t e = e0 + 64 * (uint32_t)u + (uint32_t)lane;
+                rec[u].key_lo = rec[u].key_hi = rec[u].ypos = 0;
+                if (e < n1) {
+                    uint32_t j = 0;
+                    while (sbase[j + 1] <= e) ++j;  // (a handful of segments: empty ones are stepped over)
+                    rec[u] = a.l1[soff[j] + (e - sbase[j])];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < QF_L1_U; ++u) {
+                const uint32_t e = e0 + 64 * (uint32_t)u + (uint32_t)lane;
+                if (e < n1) {
+                    key1[e] = ((uint64_t)rec[u].key_hi << 32) | rec[u].key_lo;
+                    ypos1[e] = rec[u].ypos;
+                }
+            }
+        }
+        wave_sync();
+        // ---- reduce_shmmr twice (shmmrutils.rs:533-535), then the min_span stencil on the unfiltered neighbours (:536-555: the
+        // first and the last element always stay)
+        const uint16_t *fin = nullptr;  // nullptr: the identity list
+        uint32_t n3 = n1;
+        auto ident = [](uint32_t k) { return (uint16_t)k; };
+        if (a.r > 1) {
+            const int n1i = (int)n1;
+            const uint32_t n2 = a.r == 4 ? qf_compact(n1, lane, idx_a, [&](uint32_t k) { return qf_reduce_keep<4>(key1, nullptr, n1i, (int)k, 4); }, ident)
+                                         : qf_compact(n1, lane, idx_a, [&](uint32_t k) { return qf_reduce_keep<0>(key1, nullptr, n1i, (int)k, a.r); }, ident);
+            wave_sync();
+            const int n2i = (int)n2;
+            auto from_a = [&](uint32_t k) { return idx_a[k]; };
+            n3 = a.r == 4 ? qf_compact(n2, lane, idx_b, [&](uint32_t k) { return qf_reduce_keep<4>(key1, idx_a, n2i, (int)k, 4); }, from_a)
+                          : qf_compact(n2, lane, idx_b, [&](uint32_t k) { return qf_reduce_keep<0>(key1, idx_a, n2i, (int)k, a.r); }, from_a);
+            wave_sync();
+            fin = idx_b;
+        }
+        const uint32_t ms = a.min_span;
+        const uint32_t n4 = qf_compact(
+            n3, lane, idx_a,
+            [&](uint32_t i) {
+                if (i == 0 || i + 1 == n3) return true;
+                const uint32_t e = fin ? fin[i] : i, ep = fin ? fin[i - 1] : i - 1, en = fin ? fin[i + 1] : i + 1;
+                const uint32_t p = ypos1[e] >> 1, pp = ypos1[ep] >> 1, pn = ypos1[en] >> 1;
+                const uint64_t xk = key1[e];
+                return (p - pp > ms) && (pn - p > ms) && key1[ep] != xk && key1[en] != xk;
+            },
+            [&](uint32_t i) { return fin ? fin[i] : (uint16_t)i; });
+        wave_sync();
+        // ---- the query's shimmer pairs (seq_db.rs:1205-1217: the smaller hash first, strict <)
+        const uint32_t npair = n4 ? n4 - 1 : 0u;
+        if (npair > P) {
+            if (lane == 0) {
+                const uint32_t was = atomicMax(a.flags + 3, npair) | atomicOr(a.flags, QF_MORE_PAIRS);
+                asm volatile("" ::"v"(was));
+            }
+            return;
+        }
+        np = (int)npair;
+        n_pairs_out = npair;
+        {   // (P <= 256: four pairs per lane; everything is read -- the final list lies where the pairs go -- before anything is written)
+            constexpr int QF_PU = 4;
+            static_assert(QF_MAX_PAIRS <= 64 * QF_PU && QF_C1_MAX * 4 <= 64 * QF_PU * 44, "pairs per lane");
+            uint64_t k0[QF_PU], k1[QF_PU];
+            uint32_t y0[QF_PU], y1[QF_PU];
+#pragma unroll
+            for (int u = 0; u < QF_PU; ++u) {
+                const int i = lane + 64 * u;
+                k0[u] = k1[u] = 0;
+                y0[u] = y1[u] = 0;
+                if (i < np) {
+                    const uint32_t e0 = idx_a[i], e1 = idx_a[i + 1];
+                    k0[u] = key1[e0];
+                    k1[u] = key1[e1];
+                    y0[u] = ypos1[e0];
+                    y1[u] = ypos1[e1];
+                }
+            }
+            wave_sync();
+#pragma unroll
+            for (int u = 0; u < QF_PU; ++u) {
+                const int i = lane + 64 * u;
+                if (i < np) {
+                    const bool keep = k0[u] < k1[u];
+                    L_h0[i] = keep ? k0[u] : k1[u];
+                    L_h1[i] = keep ? k1[u] : k0[u];
+                    L_bgn[i] = (y0[u] >> 1) + 1;
+                    L_eo[i] = ((y1[u] >> 1) + 1) | (keep ? 0u : 0x80000000u);
+                }
+            }
+        }
+        wave_sync();
+    } else {
+        p0 = a.pair_off[q];
+        const uint64_t np64 = a.pair_off[q + 1] - p0;
+        decline = np64 > (uint64_t)P;
+        np = decline ? 0 : (int)np64;
+    }
     // ---- lookup of every pair
     for (int i = lane; i < np; i += 64) {
-        const uint64_t h0 = a.qrec[p0 + i].h0, h1 = a.qrec[p0 + i].h1;
+        const uint64_t h0 = L1 ? L_h0[i] : a.qrec[p0 + i].h0, h1 = L1 ? L_h1[i] : a.qrec[p0 + i].h1;
         uint64_t lo, hi;
         lookup_range_short(h0, h1, a, lo, hi);
         L_h0[i] = h0;
@@ -463,7 +670,17 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
     for (int i = lane; i < np; i += 64) {
         const uint32_t c = L_pc[i];
         if (c == 0) continue;
-        const pgr_frag_rec qr = a.qrec[p0 + i];
+        uint32_t q_bgn, q_end, q_or;
+        if (L1) {
+            q_bgn = L_bgn[i];
+            q_end = L_eo[i] & 0x7FFFFFFFu;
+            q_or = L_eo[i] >> 31;
+        } else {
+            const pgr_frag_rec qr = a.qrec[p0 + i];
+            q_bgn = qr.bgn;
+            q_end = qr.end;
+            q_or = qr.orient;
+        }
         const uint64_t s0 = L_lo[i], e0 = s0 + L_nrec[i];
         uint32_t o = L_hoff[i];
         uint64_t s = s0;
@@ -475,9 +692,9 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
                 for (uint64_t u = s; u < t; ++u) {
                     const pgr_frag_rec r = a.recs[u];
                     pgr_hitpair hp;
-                    hp.qb = qr.bgn;
-                    hp.qe = qr.end;
-                    hp.qo = qr.orient;
+                    hp.qb = q_bgn;
+                    hp.qe = q_end;
+                    hp.qo = q_or;
                     hp.tb = r.bgn;
                     hp.te = r.end;
                     hp.to = r.orient;
@@ -630,20 +847,20 @@ __device__ __forceinline__ QfSums qf_wave_sums(bool take, uint64_t w0, uint64_t 
 // workgroups start in index order, so every predecessor is running or done) and copies its slot to where it belongs in the
 // HOST's block -- the writes cross PCIe while other queries still chain (tools/probe/host_write_probe.hip: 10 000 wavefronts
 // x 768 B contiguous reach the link's 50 GB/s and hide behind arithmetic; this kernel's small pieces do not: see enqueue()).
-template <bool DIRECT>
+template <bool DIRECT, bool L1 = false>
 __global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t qf_dyn[];
     const uint32_t q = blockIdx.x;
     const int lane = (int)threadIdx.x;
-    uint32_t nt, nc, nh, nhit;
+    uint32_t nt, nc, nh, nhit, npairs;
     unsigned long long nsig;
-    qf_one_query(a, qf_dyn, q, lane, nt, nc, nh, nhit, nsig);
+    qf_one_query<L1>(a, qf_dyn, q, lane, nt, nc, nh, nhit, nsig, npairs);
     if (!DIRECT) {
         if (lane == 0) {
             a.q_nt[q] = nt;
             a.q_nc[q] = nc;
             a.q_nh[q] = nh;
-            a.q_nhit[q] = nhit;
+            a.q_nhit[q] = nhit | (npairs << 16);  // (hits of a query <= QF_H_MAX; the level-1 form's pairs ride along: the host has not seen them)
             a.q_nsig[q] = nsig;
         }
         return;
@@ -782,7 +999,8 @@ __global__ __launch_bounds__(64) void query_fused_kernel(const QfArgs a) {
 // exclusive scans of the per-query counts (one workgroup: a batch has 1 .. 2^17 queries) -> where every query's targets, chains
 // and hit pairs start in the flat result; q_off of the result; the totals (straight into the host's pinned mailbox).
 // words: [0] targets [1] chains [2] hit pairs [3] signatures [4] hits [5] QF_DECLINE | QF_MORE_HITS [6] non-terminating groups
-//        [8] most hits of one query that overflowed its slot
+//        [8] most hits of one query that overflowed its slot; level-1 form: [9] most pairs, [10] most level-1 minimizers of a query
+//        that overflowed P / C1
 // Every wavefront takes one contiguous sixteenth of the queries: it adds its range up, the sixteen sums are exchanged once, then
 // it scans its range 64 queries per step with the running total in a register -- no barrier inside the loops.  The counts of
 // one query are < 2^10: 32-bit sums.
@@ -793,7 +1011,7 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
                                                                  const uint32_t *__restrict__ flags, uint32_t n,
                                                                  uint64_t *__restrict__ t0, uint64_t *__restrict__ c0,
                                                                  uint64_t *__restrict__ h0, uint64_t *__restrict__ img_q_off,
-                                                                 uint64_t *__restrict__ words) {
+                                                                 uint64_t *__restrict__ words, uint32_t l1_form) {
     constexpr uint32_t NW = QF_SCAN_T / 64;
     __shared__ uint32_t tot[3][NW];
     __shared__ unsigned long long red[2][NW];
@@ -802,7 +1020,7 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
     const uint32_t lo = w * R < n ? w * R : n, hi = lo + R < n ? lo + R : n;
     constexpr int U = 8;  // chunks of 64 queries whose loads are in flight together
     uint32_t st = 0, sc = 0, sh = 0;
-    unsigned long long sig = 0, hits = 0;
+    unsigned long long sig = 0, hits = 0;  // (hits: low 32 bits the hits, high 32 bits the pairs of the level-1 form)
     for (uint32_t q0 = lo; q0 < hi; q0 += 64 * U) {
         uint32_t a[U], b[U], c[U], d[U];
         unsigned long long e[U];
@@ -821,7 +1039,7 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
             st += a[u];
             sc += b[u];
             sh += c[u];
-            hits += d[u];
+            hits += (unsigned long long)(d[u] & 0xFFFFu) | ((unsigned long long)(d[u] >> 16) << 32);
             sig += e[u];
         }
     }
@@ -887,10 +1105,13 @@ __global__ __launch_bounds__(QF_SCAN_T) void query_offsets_kernel(const uint32_t
         words[1] = Cn;
         words[2] = Hn;
         words[3] = s;
-        words[4] = h;
+        words[4] = h & 0xFFFFFFFFull;
+        words[11] = h >> 32;  // pairs of all queries (level-1 form)
         words[5] = flags[0];
         words[6] = flags[1];
         words[8] = flags[2];
+        words[9] = l1_form ? flags[3] : 0u;   // most pairs of a query that has more than P
+        words[10] = l1_form ? flags[4] : 0u;  // most level-1 minimizers of a query that has more than C1
     }
 }
 
@@ -984,6 +1205,20 @@ int QueryFusedRun::enqueue_from_shimmers(const pgr_mm128 *d_mm, const uint64_t *
     return enqueue((const pgr_frag_rec *)d_qrec, (const uint64_t *)d_rec_off, true);
 }
 
+uint32_t query_fused_level1_cap(uint32_t max_len, uint32_t w) {
+    const double expect = 2.0 * (double)max_len / (double)(w + 1);
+    const uint64_t cap = (((uint64_t)(expect * 1.15) + 36 + 31) / 32) * 32;
+    return cap > QF_C1_MAX ? 0u : (uint32_t)cap;
+}
+
+int QueryFusedRun::enqueue_from_level1(const QfLevel1View &v, uint32_t c1) {
+    from_l1 = true;
+    l1v = v;
+    C1 = c1;
+    while ((size_t)P * 44 < (size_t)C1 * 4) P <<= 1;  // (the index lists of the level-1 stage live in the pairs' bytes)
+    return enqueue(nullptr, nullptr, true);
+}
+
 // the per-query kernel, the offsets, the packing and the first download, all stream ordered; finish() after a synchronization
 int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, bool flags_cleared) {
     hipStream_t st = stream ? stream : ctx->stream;
@@ -1002,7 +1237,7 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
     // the download.  Fewer queries resident at once (direct_query_lds_kb) only makes it longer.
     const float h_t = ix->fused_per_q[0].load(std::memory_order_relaxed), h_c = ix->fused_per_q[1].load(std::memory_order_relaxed),
                 h_h = ix->fused_per_q[2].load(std::memory_order_relaxed);
-    direct = !direct_failed && ctx->opt.direct_query_result && h_h >= 0.0f && h_t >= 0.0f && h_c >= 0.0f;
+    direct = !from_l1 && !direct_failed && ctx->opt.direct_query_result && h_h >= 0.0f && h_t >= 0.0f && h_c >= 0.0f;
     if (direct) {
         auto room = [&](float per_q, uint64_t most) { return std::min<uint64_t>(most, (uint64_t)((double)nq * per_q * 1.10) + 512); };
         cap_t = room(h_t, slots / 2);
@@ -1038,7 +1273,16 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
     a.q_nc = a.q_nt + nq;
     a.q_nh = a.q_nc + nq;
     a.q_nhit = a.q_nh + nq;
-    a.flags = a.q_nhit + nq;
+    a.flags = from_l1 ? l1v.flags : a.q_nhit + nq;
+    a.l1 = l1v.l1;
+    a.seg_off = l1v.seg_off;
+    a.seg_cnt = l1v.seg_cnt;
+    a.tile_first = l1v.tile_first;
+    a.l1_status = l1v.status;
+    a.l1_ovf_cap = l1v.ovf_cap;
+    a.C1 = from_l1 ? C1 : 0u;
+    a.r = l1v.r;
+    a.min_span = l1v.min_span;
     a.desc = nullptr;
     a.host = nullptr;
     a.cap_t = a.cap_c = a.cap_h = 0;
@@ -1064,7 +1308,7 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
         return PGR_OK;
     }
     first = std::min(est, cap);
-    hipError_t e = flags_cleared ? hipSuccess : hipMemsetAsync(a.flags, 0, 12, st);
+    hipError_t e = flags_cleared ? hipSuccess : hipMemsetAsync(a.flags, 0, from_l1 ? 24 : 12, st);
     if (e == hipSuccess && direct) {
         a.desc = (uint64_t *)d_desc;
         a.host = block;
@@ -1078,13 +1322,16 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
         a.words = mb;
         e = hipMemsetAsync(d_desc, 0, desc_need, st);
         if (e == hipSuccess)
-            hipLaunchKernelGGL(query_fused_kernel<true>, dim3(n_queries), dim3(64),
+            hipLaunchKernelGGL((query_fused_kernel<true, false>), dim3(n_queries), dim3(64),
                                std::max<size_t>(qf_lds_bytes(P, H, a.long_groups != 0), (size_t)std::max<int64_t>(0, ctx->opt.direct_query_lds_kb) << 10), st, a);
     } else if (e == hipSuccess) {
         uint64_t *t0 = (uint64_t *)d_offs, *c0 = t0 + nq, *h0 = c0 + nq;
-        hipLaunchKernelGGL(query_fused_kernel<false>, dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
+        if (from_l1)
+            hipLaunchKernelGGL((query_fused_kernel<false, true>), dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0, C1), st, a);
+        else
+            hipLaunchKernelGGL((query_fused_kernel<false, false>), dim3(n_queries), dim3(64), qf_lds_bytes(P, H, a.long_groups != 0), st, a);
         hipLaunchKernelGGL(query_offsets_kernel, dim3(1), dim3(QF_SCAN_T), 0, st, a.q_nt, a.q_nc, a.q_nh, a.q_nhit, a.q_nsig, a.flags,
-                           n_queries, t0, c0, h0, (uint64_t *)d_img, mb);
+                           n_queries, t0, c0, h0, (uint64_t *)d_img, mb, from_l1 ? 1u : 0u);
         hipLaunchKernelGGL(query_pack_kernel, dim3(n_queries), dim3(64), 0, st, a, t0, c0, h0, mb, (uint8_t *)d_img);
         if (copy_stream && ev_packed && ev_copied) {
             e = hipEventRecord(ev_packed, st);
@@ -1113,15 +1360,42 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
     hipStream_t st = stream ? stream : ctx->stream;
     const size_t nq = n_queries;
     uint64_t *mb = mail ? mail : (uint64_t *)ctx->qmail;
-    bool grew = false;
+    bool grew = false, grew_p = false, grew_c1 = false;
     for (;;) {
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return ctx->fail(PGR_ERR_DEVICE, std::string("query kernels: ") + hipGetErrorString(e));
         const bool lookback_gave_up = direct && (mb[5] & QF_LOOKBACK_TIMEOUT);
+        l1_flagged = from_l1 && (mb[5] & QF_L1_FLAGGED);
+        // the level-1 form: a query with more pairs than P / more level-1 minimizers than C1 (low-complexity sequence, a first
+        // guess that was too small) -- once more with room, when there is such a form
+        const bool more_pairs = from_l1 && (mb[5] & QF_MORE_PAIRS), more_l1 = from_l1 && (mb[5] & QF_MORE_L1);
         if (!lookback_gave_up &&
-            ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || grew)))) {
+            ((mb[5] & QF_DECLINE) || ((mb[5] & QF_MORE_HITS) && (H >= QF_H_MAX || mb[8] > QF_H_MAX || grew)) ||
+             (more_pairs && (mb[9] > QF_MAX_PAIRS || grew_p)) || (more_l1 && (mb[10] > QF_C1_MAX || grew_c1)))) {
             *declined = true;
             return PGR_OK;
+        }
+        if (more_pairs || more_l1) {
+            if (more_pairs) {
+                grew_p = true;
+                while (P < mb[9]) P <<= 1;
+                ix->fused_pairs.store(P, std::memory_order_relaxed);
+            }
+            if (more_l1) {
+                grew_c1 = true;
+                C1 = (uint32_t)((mb[10] + 31) / 32 * 32);
+                while ((size_t)P * 44 < (size_t)C1 * 4) P <<= 1;
+            }
+            // (a larger P may come with more hits than the slot holds: QF_MORE_HITS of this pass is looked at in the next one)
+            int rc = enqueue(nullptr, nullptr);
+            if (rc) return rc;
+            if (no_pinned) {
+                *declined = true;
+                return PGR_OK;
+            }
+            if (hipStreamSynchronize(st) != hipSuccess || (copy_stream && hipStreamSynchronize(copy_stream) != hipSuccess))
+                return ctx->fail(PGR_ERR_DEVICE, "query kernels failed on the device");
+            continue;
         }
         const bool more_hits = !lookback_gave_up && (mb[5] & QF_MORE_HITS);
         // the single-pass form placed the sections for fewer targets / chains / hit pairs than the batch has (or gave up
@@ -1176,6 +1450,7 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
     ix->fused_hits.store(H > QF_H_MIN ? H : 0, std::memory_order_relaxed);
     counts->n_signatures = mb[3];
     counts->n_hits = mb[4];
+    counts->n_pairs = from_l1 ? mb[11] : 0;
     out->n_queries = n_queries;
     out->q_off = (uint64_t *)block;
     out->n_targets = NT;

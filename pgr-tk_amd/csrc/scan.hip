@@ -1,6 +1,8 @@
 // scan.hip -- device-wide scan / sort primitives from rocPRIM (AMD's native primitives library).
 // These are plain library calls around the hand-written kernels (counts -> offsets, records -> CSR);
 // none of them is on the hot path's critical time.
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -10,6 +12,21 @@
 #include "pgr_internal.h"
 
 namespace pgr {
+
+// rocPRIM asks the runtime for its last error after every launch (hipGetLastError) and hands whatever it finds back as ITS result:
+// an error some earlier, unrelated call of this host thread left behind -- this library checks the return value of every call
+// it makes and never looks at that state; PyTorch and the host program share the thread -- came back as "scan_counts(...): invalid
+// argument" from a scan that had nothing wrong with it (round 6: once in a 149-test run, never in isolation).  Every wrapper
+// takes stale state away first; with PGR_DEBUG_STALE=1 it says so.
+namespace {
+inline void drop_stale_hip_error(const char *who) {
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        static const bool say = getenv("PGR_DEBUG_STALE") != nullptr;
+        if (say) fprintf(stderr, "[pgr] %s: a stale HIP error of this thread was dropped: %s\n", who, hipGetErrorString(e));
+    }
+}
+}  // namespace
 
 namespace {
 struct U32toU64 {
@@ -28,6 +45,7 @@ size_t scan_counts_temp_bytes(uint32_t n_plus_1) {
 
 hipError_t scan_counts(hipStream_t st, void *temp, size_t temp_bytes, const uint32_t *in, uint64_t *out,
                        uint32_t n_plus_1) {
+    drop_stale_hip_error("scan_counts");
     auto it = rocprim::make_transform_iterator(in, U32toU64());
     return rocprim::exclusive_scan(temp, temp_bytes, it, out, (uint64_t)0, (size_t)n_plus_1,
                                    rocprim::plus<uint64_t>(), st);
@@ -89,6 +107,7 @@ __global__ __launch_bounds__(256) void nolds_apply_kernel(const uint32_t *__rest
 size_t scan_counts_nolds_temp_bytes(uint32_t n_plus_1) { return ((size_t)(n_plus_1 + NL_CHUNK - 1) / NL_CHUNK + 1) * sizeof(unsigned long long); }
 hipError_t scan_counts_nolds(hipStream_t st, void *temp, size_t temp_bytes, const uint32_t *in, uint64_t *out, uint32_t n_plus_1) {
     if (n_plus_1 == 0) return hipSuccess;
+    drop_stale_hip_error("scan_counts_nolds");
     const uint32_t n_part = (n_plus_1 + NL_CHUNK - 1) / NL_CHUNK;
     if (temp_bytes < (size_t)n_part * sizeof(unsigned long long)) return hipErrorInvalidValue;
     unsigned long long *part = (unsigned long long *)temp;
@@ -105,6 +124,7 @@ size_t scan_max_temp_bytes(uint32_t n) {
     return bytes;
 }
 hipError_t scan_max_inplace(hipStream_t st, void *temp, size_t temp_bytes, uint64_t *v, uint32_t n) {
+    drop_stale_hip_error("scan_max_inplace");
     return rocprim::inclusive_scan(temp, temp_bytes, (const uint64_t *)v, v, (size_t)n, rocprim::maximum<uint64_t>(), st);
 }
 
@@ -118,6 +138,7 @@ size_t sort_pairs_temp_bytes(uint64_t n) {
 
 hipError_t sort_pairs(hipStream_t st, void *temp, size_t temp_bytes, const uint64_t *keys_in, uint64_t *keys_out,
                       const uint32_t *vals_in, uint32_t *vals_out, uint64_t n, unsigned end_bit) {
+    drop_stale_hip_error("sort_pairs");
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, (size_t)n, 0, end_bit, st);
 }
 

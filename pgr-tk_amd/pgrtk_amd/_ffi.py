@@ -80,6 +80,7 @@ _SIGS = [
     ("pgr_ctx_trim", C.c_int, [_VP]),
     ("pgr_ctx_mem_stats", C.c_int, [_VP, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int]),
     ("pgr_ctx_reserve", C.c_int, [_VP, C.c_uint64]),
+    ("pgr_debug_take_hip_error", C.c_int, []),
     ("pgr_ctx_arena_stats", C.c_int, [_VP] + [C.POINTER(C.c_uint64)] * 5),
     ("pgr_ctx_set_option", C.c_int, [_VP, C.c_char_p, C.c_int64]),
     ("pgr_ctx_get_option", C.c_int, [_VP, C.c_char_p, C.POINTER(C.c_int64)]),
