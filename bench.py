@@ -302,7 +302,7 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
     algo = 24.0 * n_hps + 0.25 * prof["query_bases"] + 17.0 * prof["n_signatures"]
     qk = committed(QUERY_PROFILE, "summary.json") or {}
     qpmc = (committed(QUERY_PROFILE, "pmc_summary.json") or {}).get("per_query_batch", {})
-    fused = int(prof.get("path", 0)) in (1, 2)
+    fused = int(prof.get("path", 0)) in (1, 2, 3)
     out = {
         "workload": "BASELINE.json configs[2]: %d x %d bp queries (50%% reverse complement) against the %d x %d bp index, "
                     "penalty 0.025, max counts 128, max_aln_span 8" % (nq, qlen, len(contig_ids), args.contig_len),
@@ -321,12 +321,17 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
                            "note": "pgr_query_hps_batch: host ASCII in, host chains out"},
         "counts": {k: int(prof[k]) for k in ("n_query_pairs", "n_signatures", "n_hits", "n_groups", "n_chains", "n_hps")},
         "stage_ms": {k: float(prof[k]) for k in ("shmmr_ms", "lookup_ms", "chain_ms", "result_ms", "total_ms")},
-        "path": ("one wavefront per query behind the shimmers (csrc/query_fused.hip): lookup, count filters, grouping, chaining "
+        "path": ("the level-1 form of the per-query kernel (csrc/query_fused.hip, round 6): the tile kernel of the queries, then one "
+                 "wavefront per query reads ITS level-1 minimizers from the tile segments and runs both reductions, min_span, the pairs, "
+                 "lookup, count filters, grouping and the chaining DP -- no list stage of the batch, 8 launches, the call has ONE "
+                 "synchronization (stage_ms.shmmr_ms holds the device time of all of it)" if int(prof.get("path", 0)) == 3 else
+                 "one wavefront per query behind the shimmers (csrc/query_fused.hip): lookup, count filters, grouping, chaining "
                  "DP in one kernel" + ("; enqueued behind the shimmer pipeline without a host wait in between: "
                                        "stage_ms.shmmr_ms holds the device time of both, the call has ONE "
                                        "synchronization" if int(prof.get("path", 0)) == 2 else
                                        "; stage_ms.chain_ms holds all of it, download included") if fused else
                  "one kernel per stage over the whole batch (csrc/index.hip)"),
+        "path_id": int(prof.get("path", 0)),
         "roofline": {
             "bound": "hbm", "achieved": algo / t_res / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": algo / t_res / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes": algo,

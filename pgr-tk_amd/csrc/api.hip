@@ -43,7 +43,7 @@ const std::vector<OptionName> &option_names() {
         {"debug", &O::debug}, {"debug_times", &O::debug_times}, {"gpu_pack", &O::gpu_pack}, {"no_small_path", &O::no_small_path},
         {"no_pipeline", &O::no_pipeline}, {"early_sync_bp", &O::early_sync_bp}, {"index_full_sort", &O::index_full_sort},
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query}, {"direct_query_result", &O::direct_query_result}, {"direct_query_results_delivered", &O::direct_query_results_delivered}, {"direct_query_lds_kb", &O::direct_query_lds_kb},
-        {"no_query_chaining", &O::no_query_chaining}, {"no_query_level1", &O::no_query_level1}, {"query_global_sort", &O::query_global_sort},
+        {"no_query_chaining", &O::no_query_chaining}, {"no_query_level1", &O::no_query_level1}, {"no_query_keys", &O::no_query_keys}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s}, {"exchange_rccl_world1", &O::exchange_rccl_world1}, {"debug_poison", &O::debug_poison}, {"debug_inject_stale_segments", &O::debug_inject_stale_segments},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
@@ -184,7 +184,7 @@ extern "C" int pgr_host_unregister(void *p) {
 
 extern "C" int pgr_ctx_trim(pgr_ctx *ctx) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (ctx->back_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->back_stream));
     if (ctx->fix_stream) PGR_HIP(ctx, hipStreamSynchronize(ctx->fix_stream));
@@ -206,7 +206,7 @@ extern "C" int pgr_ctx_trim(pgr_ctx *ctx) {
 // One hipMalloc, touched once, that every later device allocation of the context is carved from (csrc/pgr_ctx.h: Arena).
 extern "C" int pgr_ctx_reserve(pgr_ctx *ctx, uint64_t bytes) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     return ctx->reserve((size_t)bytes);
 }
 
@@ -658,7 +658,7 @@ static int batch_stage(pgr_ctx *ctx, pgr_batch *b, uint32_t n, const StageSrc &s
 
 static int batch_from_host(pgr_ctx *ctx, uint32_t n, const StageSrc &src, pgr_batch **out) {
     *out = nullptr;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_batch *b = nullptr;
     const bool dbg = ctx->opt.debug != 0;
     const auto t0 = std::chrono::steady_clock::now();
@@ -708,7 +708,7 @@ static int batch_synthetic(pgr_ctx *ctx, uint32_t n, const uint64_t *lens, uint6
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!out || (n && !lens)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_batch *b = nullptr;
     int rc = batch_alloc(ctx, n, lens, &b);
     if (rc) return rc;
@@ -769,7 +769,7 @@ extern "C" void pgr_shmmrs_destroy(pgr_shmmrs *s) {
 extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 **out_mm, uint64_t **out_off) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!s || !out_mm || !out_off) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     *out_mm = nullptr;
     *out_off = nullptr;
     // a list of >= 1 MiB goes into a pinned block of the pool: ONE DMA, no staging windows, no host copy (pgr_free returns
@@ -815,7 +815,7 @@ extern "C" int pgr_shmmrs_download(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_mm128 
 extern "C" int pgr_shmmrs_checksum(pgr_ctx *ctx, const pgr_shmmrs *s, uint64_t *out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!s || !out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const uint32_t n = s->n;
     if (n == 0) return PGR_OK;
     uint64_t max_cnt = 0;
@@ -836,7 +836,7 @@ extern "C" int pgr_shmmrs_copy_to_device(pgr_ctx *ctx, const pgr_shmmrs *s, pgr_
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!s || (s->count && !d_out)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (capacity < s->count) return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the shimmer list");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     if (s->count) {
         launch_copy_add_rid(ctx->stream, s->d_mm, s->count, rid_add, d_out);
         PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -851,7 +851,7 @@ extern "C" int pgr_shmmrs_copy_to_device_rids(pgr_ctx *ctx, const pgr_shmmrs *s,
     if (!s || (s->count && !d_out) || (s->n && !rids)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (capacity < s->count) return ctx->fail(PGR_ERR_INVALID_ARG, "output buffer too small for the shimmer list");
     if (!s->rid_is_index) return ctx->fail(PGR_ERR_STATE, "the result already carries caller rids (computed with rids / padding)");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     if (s->count) {
         int rc;
         if ((rc = ctx->ws_rids.ensure(ctx, (size_t)s->n * sizeof(uint32_t)))) return rc;
@@ -917,7 +917,7 @@ extern "C" int pgr_shmmrs_to_frag_recs_device(pgr_ctx *ctx, const pgr_shmmrs *s,
                                               pgr_frag_rec *d_out, uint64_t capacity, uint64_t *n_out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!s || !n_out) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     *n_out = pgr_shmmrs_n_pairs(s);
     if (*n_out == 0) return PGR_OK;
     const int rc = shmmrs_to_frag_recs_enqueue(ctx, s, sids, query_side, d_out, capacity);
@@ -943,7 +943,7 @@ bool pgr::worth_pipelining(const pgr_ctx *ctx, uint32_t n, const uint64_t *lens)
 int pgr::for_each_staged(pgr_ctx *ctx, uint32_t n, const StageSrc &src,
                          const std::function<int(pgr_batch *, uint32_t, uint32_t)> &consume) {
     const auto t_start = std::chrono::steady_clock::now();
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const uint64_t *lens = src.lens;
     for (uint32_t i = 0; i < n && !src.planes; ++i)
         if (lens[i] && !src.seqs[i]) return ctx->fail(PGR_ERR_INVALID_ARG, "null sequence pointer");
@@ -1266,7 +1266,7 @@ static int shmmr_batch_small(pgr_ctx *ctx, const pgr_spec *spec, uint32_t n, con
         total_slots += src.lens[i] / 32 + 64;
     }
     if (total_bp > SMALL_MAX_BASES) return PGR_OK;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     if (ctx->staged_unsynced) {  // the pinned windows may still be the source of an earlier staging
         PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->staged_unsynced = false;

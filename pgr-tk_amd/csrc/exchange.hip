@@ -264,7 +264,7 @@ int run_beside_a_clock(pgr_ctx *ctx, const char *what, int rank, int world, std:
 extern "C" int pgr_exchange_unique_id(pgr_ctx *ctx, uint8_t *id) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!id) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     auto st = std::make_shared<Guarded>();
     const int rc = run_beside_a_clock(ctx, "pgr_exchange_unique_id", 0, 0, st, [](Rccl &R, Guarded &g) {
         g.step = "ncclGetUniqueId";
@@ -281,7 +281,7 @@ extern "C" int pgr_exchange_create(pgr_ctx *ctx, const uint8_t *id, int rank, in
     *out = nullptr;
     const bool local = world == 1 && !ctx->opt.exchange_rccl_world1;
     if (!local && !id) return ctx->fail(PGR_ERR_INVALID_ARG, "bad exchange arguments: no unique id");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_exchange *x = new pgr_exchange();
     x->ctx = ctx;
     x->rank = rank;
@@ -340,7 +340,7 @@ extern "C" int pgr_exchange_allgather_shmmrs_start(pgr_exchange *x, const pgr_mm
     if (!d_local || !d_out || cap_per_rank == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (n_local > cap_per_rank) return ctx->fail(PGR_ERR_INVALID_ARG, "this rank's shimmer list exceeds cap_per_rank");
     const Xport R{x};
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     // the list was produced on the context's stream: the collective starts behind it, the host does not wait
     PGR_HIP(ctx, hipEventRecord(x->ev_ready, ctx->stream));
     PGR_HIP(ctx, hipStreamWaitEvent(x->stream, x->ev_ready, 0));
@@ -360,7 +360,7 @@ extern "C" int pgr_exchange_wait(pgr_exchange *x, uint64_t *counts) {
     if (!x) return PGR_ERR_INVALID_ARG;
     pgr_ctx *ctx = x->ctx;
     if (!x->in_flight) return ctx->fail(PGR_ERR_STATE, "no all-gather in flight");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     int rc = exchange_sync(x, "shimmer all-gather");  // (ev_done is the last thing on the exchange's stream)
     if (rc) {
         x->in_flight = false;
@@ -390,7 +390,7 @@ extern "C" int pgr_exchange_gather_into_index(pgr_exchange *x, const pgr_shmmrs 
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is already in flight on this exchange");
     if (s && s->n && !rids) return ctx->fail(PGR_ERR_INVALID_ARG, "null rid list");
     const Xport R{x};
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const uint64_t n_local = s ? s->count : 0;
     // phase 1: counts (the compute stream's work is done: pgr_shmmrs_compute synchronizes)
     x->h_cnt[0] = n_local;
@@ -443,7 +443,7 @@ extern "C" int pgr_exchange_shard_records(pgr_exchange *x, const pgr_frag_rec *d
     if (!ix || (n && !d_recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (ix->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "index belongs to another context");
     const Xport R{x};
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const int world = x->world, me = x->rank;
     int rc;
     if (reuse_splitters && !x->have_splitters) return ctx->fail(PGR_ERR_STATE, "no splitters yet: the first call must sample");
@@ -571,7 +571,7 @@ extern "C" int pgr_exchange_allgather_index(pgr_exchange *x, const pgr_index *sh
     if (x->in_flight) return ctx->fail(PGR_ERR_STATE, "an all-gather is in flight on this exchange");
     *out = nullptr;
     const Xport R{x};
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const int world = x->world, me = x->rank;
     int rc;
     x->h_cnt[0] = shard->n;

@@ -227,6 +227,21 @@ __global__ void gather_keys_kernel(const pgr_frag_rec *__restrict__ recs, const 
     keys[i] = make_ulonglong2(r.h0, r.h1);
 }
 
+// qkeys[i] = key i with its record when it has exactly one (pgr_index.h)
+__global__ void gather_qkeys_kernel(const pgr_frag_rec *__restrict__ recs, const uint64_t *__restrict__ key_off, uint64_t n_keys,
+                                    ulonglong4 *__restrict__ qkeys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_keys) return;
+    const uint64_t s = key_off[i], e = key_off[i + 1];
+    const pgr_frag_rec r = recs[s];
+    ulonglong4 q;
+    q.x = r.h0 | (e - s == 1 ? 1ull << 63 : 0ull);
+    q.y = r.h1 | ((uint64_t)(r.orient & 1u) << 63);
+    q.z = (uint64_t)r.sid | ((uint64_t)r.bgn << 32);
+    q.w = (uint64_t)r.end;
+    qkeys[i] = q;
+}
+
 // lut[b] = first key whose bucket is >= b (b = 2^bits: n_keys); one thread per bucket
 __global__ void build_lut_kernel(const pgr_frag_rec *__restrict__ recs, const uint64_t *__restrict__ key_off, uint64_t n_keys,
                                  uint32_t bits, uint32_t shift, uint32_t *__restrict__ lut) {
@@ -325,6 +340,7 @@ extern "C" void pgr_index_destroy(pgr_index *ix) {
     ix->ctx->dfree(ix->key_off);
     ix->ctx->dfree(ix->lut);
     ix->ctx->dfree(ix->keys);
+    ix->ctx->dfree(ix->qkeys);
     delete ix;
 }
 
@@ -338,7 +354,7 @@ extern "C" int pgr_index_reserve(pgr_ctx *ctx, pgr_index *ix, uint64_t n_records
     if (n_records <= ix->cap_raw) return PGR_OK;
     // (jobs of a pipe in flight write their records through the device cursor into the block that is about to move)
     if (ix->pipe_jobs > 0) return ctx->fail(PGR_ERR_STATE, "pgr_index_reserve while jobs of a pgr_pipe on this index are in flight: collect them first");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_frag_rec *np = nullptr;
     int rc = ctx->dmalloc((void **)&np, n_records * sizeof(pgr_frag_rec));  // (exactly what was asked for: no head-room on top)
     if (rc) return rc;
@@ -360,7 +376,7 @@ extern "C" int pgr_index_add_records(pgr_ctx *ctx, pgr_index *ix, const pgr_frag
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix || (n && !recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (n == 0) return PGR_OK;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     int rc = grow_raw(ctx, ix, ix->n_raw + n);
     if (rc) return rc;
     PGR_HIP(ctx, hipMemcpyAsync(ix->raw + ix->n_raw, recs, n * sizeof(pgr_frag_rec),
@@ -414,7 +430,7 @@ extern "C" int pgr_index_add_shmmrs(pgr_ctx *ctx, pgr_index *ix, const pgr_mm128
     if (!ix || (n && !mm)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (n < 2) return PGR_OK;
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 shimmers in one call");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     int rc;
     Tmp d_mm(ctx), flags(ctx), rank(ctx);
@@ -511,7 +527,7 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!ix) return ctx->fail(PGR_ERR_INVALID_ARG, "null index");
     if (ix->finalized) return PGR_OK;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint64_t n = ix->n_raw;
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "index holds more than 2^32-1 records per GPU");
@@ -519,10 +535,12 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
     ctx->dfree(ix->key_off);
     ctx->dfree(ix->lut);
     ctx->dfree(ix->keys);
+    ctx->dfree(ix->qkeys);
     ix->recs = nullptr;
     ix->key_off = nullptr;
     ix->lut = nullptr;
     ix->keys = nullptr;
+    ix->qkeys = nullptr;
     ix->n = n;
     ix->n_keys = 0;
     int rc;
@@ -626,6 +644,10 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
             (rc = ctx->dmalloc((void **)&ix->keys, n_keys * sizeof(ulonglong2))))
             return rc;
         hipLaunchKernelGGL(gather_keys_kernel, grid_for(n_keys), dim3(256), 0, st, ix->recs, ix->key_off, n_keys, ix->keys);
+        if (!(stats[3] >> 56) && !ctx->opt.no_query_keys) {  // (the table's flag bits sit above the library's 56-bit hashes)
+            if ((rc = ctx->dmalloc((void **)&ix->qkeys, n_keys * sizeof(ulonglong4)))) return rc;
+            hipLaunchKernelGGL(gather_qkeys_kernel, grid_for(n_keys), dim3(256), 0, st, ix->recs, ix->key_off, n_keys, ix->qkeys);
+        }
         hipLaunchKernelGGL(build_lut_kernel, grid_for((1ull << bits) + 1), dim3(256), 0, st, ix->recs, ix->key_off, n_keys, bits,
                            ix->lut_shift, ix->lut);
     }
@@ -1711,7 +1733,7 @@ extern "C" int pgr_query_hps_resident(pgr_ctx *ctx, const pgr_index *ix, const p
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized (call pgr_index_finalize)");
     if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
     if (max_aln_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_aln_span must be at least 1");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const bool dbg = ctx->opt.debug != 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -1976,7 +1998,7 @@ extern "C" int pgr_sparse_aln_batch(pgr_ctx *ctx, uint32_t n_groups, const pgr_h
     if (!out || (n_groups && (!hits || !g_off))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     memset(out, 0, sizeof(*out));
     if (max_span == 0) return ctx->fail(PGR_ERR_INVALID_ARG, "max_span must be at least 1");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const uint64_t n = n_groups ? g_off[n_groups] : 0;
     for (uint32_t g = 0; g < n_groups; ++g)
         if (g_off[g + 1] - g_off[g] < 2)  // aln.rs:24 assert!(sp_hits.len() > 1)

@@ -512,7 +512,7 @@ int adj_list_device(pgr_ctx *ctx, const pgr_index *ix, uint32_t min_count, const
     *out = nullptr;
     *n_out = 0;
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint64_t n = ix->n;
     if (n < 2) return PGR_OK;
@@ -724,7 +724,7 @@ extern "C" int pgr_index_key_counts(pgr_ctx *ctx, const pgr_index *ix, uint64_t 
     if (!ix || (n && (!keys || !counts))) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized");
     if (n == 0) return PGR_OK;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     Tmp dk(ctx), dc(ctx);
     int rc;
@@ -806,7 +806,7 @@ extern "C" int pgr_principal_bundle_decomposition(pgr_ctx *ctx, const pgr_index 
     *n_smps = 0;
     *n_seqs = 0;
     bundles_clear(bundles);
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     const uint64_t n = ix->n;
     int rc;

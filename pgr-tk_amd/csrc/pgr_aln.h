@@ -49,6 +49,24 @@ __device__ __forceinline__ float wave_max_f32(float v) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
+// The largest POSITIVE value over the wavefront, as its bit pattern (0: no lane holds a positive value).  Positive f32 values
+// order like their bit patterns, and an unsigned maximum has the identity a DPP row shift supplies for lanes without a source:
+// the compiler folds the shifts into six v_max_u32_dpp, where the f32 form above costs five instructions per step (a fill with
+// -inf, the shift, two canonicalizing maxima, a hazard nop).  What the chaining DP asks of its maximum -- is it above zero, and
+// which lanes hold it -- is answered by the bits (aln.rs:86-89, :105-131: scores are compared with > 0 and with each other).
+__device__ __forceinline__ uint32_t wave_max_pos_bits(float x) {
+    const int b = __float_as_int(x);
+    uint32_t v = (uint32_t)(b > 0 ? b : 0);
+    auto mx = [](uint32_t p, uint32_t q) { return p > q ? p : q; };
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));
+    v = mx(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 __device__ __forceinline__ void wave_sync() {  // single-wave workgroup: orders LDS and global accesses of the wave
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();

@@ -40,6 +40,10 @@ struct Lane {
 };
 }  // namespace pgr
 
+namespace pgr {
+void drop_stale_hip_error(const char *who);  // (scan.hip) takes the thread's stale HIP error away; says so under PGR_DEBUG_STALE=1
+}
+
 struct pgr_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -75,6 +79,7 @@ struct pgr_ctx {
         int64_t direct_query_results_delivered = 0;  // (a counter, read with pgr_ctx_get_option: batches whose result the single-pass kernel wrote)
         int64_t direct_query_result = 0;     // experiment: that kernel writes the host's result block itself (single pass; measured slower)
         int64_t no_query_chaining = 0;   // do not enqueue the query stage behind the shimmer pipeline
+        int64_t no_query_keys = 0;       // pgr_index_finalize builds no per-query-kernel key table (pgr_index.h: qkeys), for A/B
         int64_t no_query_level1 = 0;     // query batches never take the level-1 form of the per-query kernel (tile kernel + per-query kernel, no list stage), for A/B
         int64_t query_global_sort = 0;   // group the hits of a batch with the global radix sort
         int64_t fused_query_hits = 0;    // > 0: fixed slot size H of the per-query kernel
@@ -248,6 +253,18 @@ void *pinned_result_acquire(size_t min_bytes, size_t *cap);
 void result_block_release(void *p);
 }  // namespace pgr
 
+// Entry of an API call: the context's device, and a clean slate in the HIP runtime's per-thread "last error".  Calls below look at
+// that state after their launches (hipGetLastError: did one of MINE fail to launch?), and so does rocPRIM -- an error some earlier
+// call of this thread left there (another library's, PyTorch's, an ignored return value of this one) would be taken for theirs:
+// round 6 saw "scan_counts(...): invalid argument" once in a 149-test run from exactly that.  The stale value is dropped, not lost:
+// PGR_DEBUG_STALE=1 prints it.
+#define PGR_ENTER(ctx)                                                                                       \
+    do {                                                                                                     \
+        hipError_t _e = hipSetDevice((ctx)->device);                                                         \
+        if (_e != hipSuccess)                                                                                \
+            return (ctx)->fail(PGR_ERR_DEVICE, std::string("hipSetDevice: ") + hipGetErrorString(_e));      \
+        pgr::drop_stale_hip_error(__func__);                                                                 \
+    } while (0)
 #define PGR_HIP(ctx, expr)                                                                                   \
     do {                                                                                                     \
         hipError_t _e = (expr);                                                                              \

@@ -22,6 +22,12 @@ struct pgr_index {
     // the keys by themselves ((h0, h1) per key, 16 B each, same order as key_off): the few keys of a bucket share one or two
     // cache lines, a search step does not have to go through key_off into the 40-byte records.  nullptr: no table.
     ulonglong2 *keys = nullptr;
+    // the per-query kernel's table (query_fused.hip), 32 B per key, same order: the key AND, for a key with exactly one record (nearly
+    // all keys of a genome index), that record's sid / bgn / end / orient -- a query pair's lookup (seq_db.rs:1200-1228) is then two
+    // dependent trips to memory (bucket table, the bucket's entries) instead of six (bucket table, keys, key_off, the record's sid
+    // for the count filters, the sid again and the record for the hit).  x = h0 | single << 63, y = h1 | orient << 63,
+    // z = sid | bgn << 32, w = end.  nullptr: no table (fewer than 4096 keys, or external records with hashes of more than 56 bits).
+    ulonglong4 *qkeys = nullptr;
     bool finalized = false;
     uint32_t next_sid = 0;
     int pipe_jobs = 0;  // jobs of a pgr_pipe in flight that place records in `raw` (the block must not move under them: pgr_index_reserve)

@@ -1608,7 +1608,7 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
     if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     if (!(padding && !spec->sketch && spec->r > 1)) {  // batches of short contigs: one workgroup per contig, 4 launches
         bool handled = false;
         if ((rc = shmmrs_compute_small(ctx, b, spec, rids, out, handled)) || handled) return rc;
@@ -1629,10 +1629,35 @@ extern "C" int pgr_shmmrs_compute(pgr_ctx *ctx, const pgr_batch *b, const pgr_sp
 // level-1 segments enqueued right behind it on the context's stream: the query path's level-1 form (pgr_aln.h: QfLevel1View;
 // query_fused.hip), whose wavefronts run the list stage of their own query.  Nothing waits here.  *taken = false: the batch is
 // not for this form (no tile path for the spec, the host packer has seen non-ACGT bytes, no bases) and nothing was enqueued.
+namespace {
+// plan + stage 1 of a job that is set up (context, batch, spec, streams) and the view of what the tile kernel leaves behind;
+// *taken = false: the batch is not for the level-1 form (nothing was enqueued)
+int level1_stage_and_view(ShmmrJob &job, QfLevel1View &v, bool *taken) {
+    *taken = false;
+    const pgr_batch *b = job.b;
+    if (job.spec.sketch || job.spec.w < (uint32_t)L1_MIN_W || b->host_saw_invalid || b->n == 0 || b->total_bases == 0) return PGR_OK;
+    pgr_ctx *ctx = job.ctx;
+    int rc;
+    if ((rc = job.plan())) return rc;
+    if (!job.serial.empty() || !job.bases_tiled) return PGR_OK;
+    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], job.sf));
+    if ((rc = job.stage1())) return rc;
+    v.l1 = job.a.out;
+    v.seg_off = job.a.seg_off;
+    v.seg_cnt = job.a.seg_cnt;
+    v.tile_first = job.a.tile_first;
+    v.status = job.d_cursor;
+    v.ovf_cap = job.cap_par;
+    v.flags = (uint32_t *)(job.d_cursor + 4);  // (the list stage's cursor words and the one behind them: cleared with the others, and no list stage runs)
+    v.r = job.spec.r;
+    v.min_span = job.spec.min_span;
+    *taken = true;
+    return PGR_OK;
+}
+}  // namespace
+
 int pgr::shmmr_level1_then(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spec, const std::function<int(const QfLevel1View &)> &consumer,
                            bool *taken) {
-    *taken = false;
-    if (spec->sketch || spec->w < (uint32_t)L1_MIN_W || b->host_saw_invalid || b->n == 0 || b->total_bases == 0) return PGR_OK;
     ShmmrJob job;
     job.ctx = ctx;
     job.b = b;
@@ -1642,22 +1667,9 @@ int pgr::shmmr_level1_then(pgr_ctx *ctx, const pgr_batch *b, const pgr_spec *spe
     job.sf = job.sb = ctx->stream;
     job.dbg_t = ctx->opt.debug_times != 0;
     job.dbg_t0 = std::chrono::steady_clock::now();
-    int rc;
-    if ((rc = job.plan())) return rc;
-    if (!job.serial.empty() || !job.bases_tiled) return PGR_OK;
-    PGR_HIP(ctx, hipEventRecord(ctx->ev[0], job.sf));
-    if ((rc = job.stage1())) return rc;
     QfLevel1View v;
-    v.l1 = job.a.out;
-    v.seg_off = job.a.seg_off;
-    v.seg_cnt = job.a.seg_cnt;
-    v.tile_first = job.a.tile_first;
-    v.status = job.d_cursor;
-    v.ovf_cap = job.cap_par;
-    v.flags = (uint32_t *)(job.d_cursor + 4);  // (the list stage's cursor words and the one behind them: cleared with the others, and no list stage runs)
-    v.r = spec->r;
-    v.min_span = spec->min_span;
-    *taken = true;
+    int rc = level1_stage_and_view(job, v, taken);
+    if (rc || !*taken) return rc;
     rc = consumer(v);
     job.dbg_lap("stage 1 + the per-query kernel enqueued");
     return rc;
@@ -1675,7 +1687,7 @@ extern "C" int pgr_shmmrs_compute_recs(pgr_ctx *ctx, const pgr_batch *b, const p
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
     if (b->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "batch belongs to another context");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     {   // batches of short contigs: the one-launch kernel, then the records from its (host-known) offsets
         bool handled = false;
         if ((rc = shmmrs_compute_small(ctx, b, spec, nullptr, out, handled))) return rc;
@@ -1762,6 +1774,8 @@ struct pgr_pipe {
         // kernel + packing + the download of the chains (csrc/query_fused.hip); whatever that path cannot take -- a flagged query
         // batch, long queries, a repeat key -- is answered at collect by the synchronous call (q_fallback)
         bool is_query = false, q_fallback = false;
+        bool q_level1 = false;           // ... in its level-1 form: tiles on the context's stream, the per-query kernel (which runs the list stage of
+                                         // its own query) + packing on the back stream, no list stage of the batch (pgr_aln.h: QfLevel1View)
         std::unique_ptr<QueryFusedRun> qrun;
         const pgr_index *qix = nullptr;
         const pgr_batch *qb = nullptr;
@@ -1880,7 +1894,7 @@ extern "C" int pgr_pipe_create(pgr_ctx *ctx, const pgr_spec *spec, pgr_pipe **ou
     *out = nullptr;
     int rc = check_spec(ctx, spec);
     if (rc) return rc;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     if ((rc = ctx->enable_multi_stream())) return rc;
     pgr_pipe *p = new pgr_pipe();
     p->ctx = ctx;
@@ -1923,7 +1937,7 @@ extern "C" int pgr_pipe_submit(pgr_pipe *p, const pgr_batch *b, const uint32_t *
     if (ix && ix->ctx != ctx) return ctx->fail(PGR_ERR_STATE, "index belongs to another context");
     if (ix && memcmp(&ix->spec, &p->spec, sizeof(pgr_spec)) != 0) return ctx->fail(PGR_ERR_INVALID_ARG, "the index has another spec than the pipe");
     if (p->order.size() >= 2) return ctx->fail(PGR_ERR_STATE, "two jobs are in flight: collect one first");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_pipe::Slot &s = p->slot[p->next];
     const uint32_t n = b->n;
     s.is_query = s.q_fallback = false;
@@ -2033,7 +2047,7 @@ extern "C" int pgr_pipe_collect(pgr_pipe *p, pgr_shmmrs **out, uint64_t *n_pairs
     if (out) *out = nullptr;
     if (n_pairs) *n_pairs = 0;
     if (p->order.empty()) return ctx->fail(PGR_ERR_STATE, "no job in flight");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     if (p->slot[p->order.front()].is_query) return ctx->fail(PGR_ERR_STATE, "the oldest job is a query job: pgr_pipe_collect_query");
     pgr_pipe::Slot &s = p->slot[p->order.front()];
     p->order.pop_front();
@@ -2164,7 +2178,7 @@ extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_
     // chains are home, so the cycle is the chain behind a batch's tiles, ~0.42 ms, not the tiles' 0.3 -- and measured SLOWER: 0.54-0.62
     // ms per batch against 0.45-0.47: three lanes' allocations and cross-stream waits cost more than the idle front stream)
     if (p->order.size() >= 2) return ctx->fail(PGR_ERR_STATE, "two jobs are in flight: collect one first");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_pipe::Slot &s = p->slot[p->next];
     const uint32_t n = b->n;
     s.is_query = true;
@@ -2232,11 +2246,46 @@ extern "C" int pgr_pipe_submit_query(pgr_pipe *p, const pgr_batch *b, const pgr_
     job.dbg_t = ctx->opt.debug_times != 0;
     job.dbg_t0 = std::chrono::steady_clock::now();
     QueryFusedRun *run = s.qrun.get();
+    int rc = PGR_OK;
+    hipError_t e = hipSuccess;
+    // the level-1 form (the same test as pgr_query_hps_resident's): the tiles on the context's stream, the per-query kernel on their
+    // segments + offsets + packing on the back stream behind an event, the chains' download on the fix stream
+    s.q_level1 = false;
+    if (!ctx->opt.no_query_level1 && ix->fused_l1_skip.load(std::memory_order_relaxed) == 0) {
+        uint32_t max_len = 0;
+        for (uint32_t c = 0; c < n; ++c) max_len = std::max(max_len, b->h_len[c]);
+        const uint32_t c1 = query_fused_level1_cap(max_len, ix->spec.w);
+        if (c1) {
+            QfLevel1View v;
+            bool taken = false;
+            rc = level1_stage_and_view(job, v, &taken);
+            if (!rc && taken) {
+                e = hipEventRecord(s.ev_front, job.sf);
+                if (e == hipSuccess) e = hipStreamWaitEvent(job.sb, s.ev_front, 0);
+                if (e == hipSuccess) rc = run->enqueue_from_level1(v, c1);
+                if (e == hipSuccess && !rc) e = hipEventRecord(s.ev_done, job.sb);
+                if (e == hipSuccess && !rc) {
+                    s.q_level1 = true;
+                    p->order.push_back(p->next);
+                    p->next ^= 1;
+                    return PGR_OK;
+                }
+            }
+            if (rc || e != hipSuccess) {
+                (void)hipStreamSynchronize(ctx->stream);
+                (void)hipStreamSynchronize(ctx->back_stream);
+                s.qrun.reset();
+                s.job.reset();
+                s.is_query = false;
+                return rc ? rc : ctx->fail(PGR_ERR_DEVICE, std::string("pipe submit (query, level-1 form): ") + hipGetErrorString(e));
+            }
+        }
+    } else if (const uint32_t left = ix->fused_l1_skip.load(std::memory_order_relaxed)) {
+        if (!ctx->opt.no_query_level1) ix->fused_l1_skip.store(left - 1, std::memory_order_relaxed);
+    }
     job.post = [run](hipStream_t, const pgr_mm128 *d_list, const uint64_t *d_off, uint64_t cap, const uint64_t *d_count) -> int {
         return run->enqueue_from_shimmers(d_list, d_off, cap, d_count);
     };
-    int rc;
-    hipError_t e = hipSuccess;
     if (!(rc = job.plan()) && !(rc = job.begin_result())) {
         job.stage1_only = false;  // (the per-query kernel rides behind the list stage: always the whole pass)
         e = hipEventRecord(ctx->ev[0], job.sf);
@@ -2266,7 +2315,7 @@ extern "C" int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out) {
     memset(out, 0, sizeof(*out));
     if (p->order.empty()) return ctx->fail(PGR_ERR_STATE, "no job in flight");
     if (!p->slot[p->order.front()].is_query) return ctx->fail(PGR_ERR_STATE, "the oldest job is not a query job: pgr_pipe_collect");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     pgr_pipe::Slot &s = p->slot[p->order.front()];
     p->order.pop_front();
     s.is_query = false;
@@ -2290,16 +2339,27 @@ extern "C" int pgr_pipe_collect_query(pgr_pipe *p, pgr_hps_result *out) {
         if (!rc && run && run->enqueued && run->copy_stream && hipEventSynchronize(run->ev_copied) != hipSuccess)
             rc = ctx->fail(PGR_ERR_DEVICE, "download of the chains failed");
         qlap("chains home");
+        if (!rc && s.q_level1) {  // (no shimmer result to look at: the per-query kernel has seen the tile kernel's status words itself)
+            QueryFusedCounts fc;
+            bool declined = false;
+            if (run->enqueued) rc = run->finish(out, &fc, &declined);
+            else declined = true;
+            if (!rc && declined) {
+                memset(out, 0, sizeof(*out));
+                if (run->l1_flagged) s.qix->fused_l1_skip.store(4, std::memory_order_relaxed);
+                fallback = true;
+            }
+        }
         // a shimmer pass that needs anything more (flagged tiles, an undersized estimate): the synchronous call takes the batch
         bool done = false;
-        if (!rc && (job->mbox[1] || job->mbox[2])) fallback = true;
-        if (!rc && !fallback) {
+        if (!rc && !s.q_level1 && (job->mbox[1] || job->mbox[2])) fallback = true;
+        if (!rc && !fallback && !s.q_level1) {
             job->sf = job->sb = ctx->back_stream;
             job->optimistic = false;
             rc = job->decide(done);
             if (!rc && !done) fallback = true;
         }
-        if (!rc && !fallback) {
+        if (!rc && !fallback && !s.q_level1) {
             pgr_shmmrs *res = nullptr;
             if (!(rc = job->finish(&res))) {
                 uint64_t max_pairs = 0;

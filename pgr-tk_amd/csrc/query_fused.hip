@@ -39,13 +39,19 @@
 #include "pgr_index.h"
 #include "pgr_internal.h"
 
+#ifndef PGR_QF_ABLATE
+#define PGR_QF_ABLATE 0  // timing experiments only (tools/build_variant.sh): 1 no chaining DP, 2 nothing behind the level-1 list, 4 nothing behind the pairs,
+                         // 8 ... the lookups, 16 ... the count filters, 32 ... the hits, 64 ... the sort by target; 128 the DP's look-back loop is
+                         // empty, 256 no chain is extracted
+#endif
+
 namespace pgr {
 
 namespace {
 
 // P = pairs a query may have (64 .. QF_MAX_PAIRS), H = hits a query may have = entries of its slot (64 .. QF_H_MAX): powers of
 // two chosen per call from the longest query of the batch and the index's records per key; the kernel's LDS image is sized by
-// them (36 B per pair + 36 B per hit, + 12 B per hit and 1.8 KB for the look-back of groups of more than 64 hits, which
+// them (44 B per pair + 36 B per hit, + 12 B per hit and 1.8 KB for the look-back of groups of more than 64 hits, which
 // batches with queries of more than 64 pairs can have)
 constexpr uint32_t QF_P_MIN = 64, QF_H_MIN = 64, QF_H_MAX = 512;
 constexpr uint32_t QF_DECLINE = 1u, QF_MORE_HITS = 2u;  // flags[0]: the batch does not fit at all / fits with a larger H
@@ -64,6 +70,7 @@ struct QfArgs {
     const uint32_t *lut;
     uint32_t lut_bits, lut_shift;
     const ulonglong2 *keys;
+    const ulonglong4 *qkeys;  // pgr_index.h: the key with its record when it has exactly one (nullptr: none)
     QParams qp;
     AlnParams ap;
     uint32_t P, H;  // pairs / hits a query may have (H = entries of a slot)
@@ -97,7 +104,7 @@ struct QfArgs {
     uint32_t r, min_span;
 };
 
-// dynamic LDS: h0[P] h1[P] lo[P] (u64) | nrec[P] pc[P] hoff[P] (u32) [ | bgn[P] end_or[P] (u32): level-1 form ]
+// dynamic LDS: h0[P] h1[P] lo[P] (u64) | nrec[P] pc[P] hoff[P] sid[P] fl[P] (u32) [ | bgn[P] end_or[P] (u32): level-1 form ]
 //              | hit[H] (24 B) | hsid[H] ssid[H] perm[H] (u32) [ | vs[H] (f32) sl[H] pv[H] (i32) | span_q[64][3] cand[4][64] (u32) ]
 // level-1 form (C1 > 0): the level-1 list -- key1[C1] (u64) ypos1[C1] (u32), + the segment table sbase[65] soff[64] -- shares its
 // bytes with the hits (the pairs are formed before the first hit is written), its index lists idx_a[C1] idx_b[C1] (u16) with the pairs
@@ -105,9 +112,9 @@ constexpr uint32_t QF_L1_SEGS = 64;  // segments (tiles + tail) of one query the
 inline __host__ __device__ size_t qf_l1_bytes(uint32_t C1) { return C1 ? (size_t)C1 * 12 + (QF_L1_SEGS + 2) * 4 + QF_L1_SEGS * 8 + 8 : 0; }
 inline size_t qf_lds_bytes(uint32_t P, uint32_t H, bool long_groups, uint32_t C1 = 0) {
     const size_t hits = (size_t)H * (sizeof(pgr_hitpair) + 12) + (long_groups ? (size_t)H * 12 + (64 * 3 + 4 * 64) * 4 : 0);
-    return (size_t)P * (C1 ? 44 : 36) + std::max(hits, qf_l1_bytes(C1));
+    return (size_t)P * (C1 ? 52 : 44) + std::max(hits, qf_l1_bytes(C1));
 }
-// (the level-1 form keeps its two index lists, 4 B per level-1 minimizer, in the pairs' 44 P bytes: P at least C1 / 11)
+// (the level-1 form keeps its two index lists, 4 B per level-1 minimizer, in the pairs' 52 P bytes: P at least C1 / 13)
 
 // sparse_aln for one group of n <= 64 hits (hit[perm[0..n)], ascending query bgn), the whole wavefront, hit j in lane j.
 // Appends the group's chains to the slot: hit pairs at o_hp[nh..], scores / first-hit offsets at [nc..]; returns true when
@@ -139,27 +146,67 @@ __device__ __forceinline__ bool chain_group_regs(const pgr_hitpair *hit, const u
         if (v && same_q(x, h)) eqm |= 1ull << o;
     }
     const bool has_dup = __ballot(in && sl != lane) != 0;
+    const bool any_eq = __ballot(in && eqm != 0) != 0;  // some query interval occurs more than once in the group
     const uint64_t above = lane == 63 ? 0ull : (U64MAX << (lane + 1));
+    // The look-back of hit i is ONE step of all lanes, and the kernel is bound by instruction issue (profiles/r06_query: 5 700
+    // instructions per query, more than half of them in this loop): whatever does not depend on i is computed once per lane -- the
+    // conversions of aln.rs:31-33 / :52-84 ((float)qb, qe, tb, te of a hit, its own length: the same f32 operations on the same
+    // values, whoever performs them) --, what is the same for all lanes stays in scalar registers (the candidates of hit i as a
+    // 64-bit mask: the lanes below i, minus the filters of aln.rs:43-67 where a filter is on at all), and the span set's rule
+    // (aln.rs:70, :91) is a mask operation whenever the candidates are dense.
+    const float f_qb = (float)h.qb, f_qe = (float)h.qe, f_tb = (float)h.tb, f_te = (float)h.te;
+    const float len_f = f_qe - f_qb;
+    const int oo = (int)(h.qo | (h.to << 1));  // (orients are 0 / 1)
+    const uint32_t eq_lo = (uint32_t)eqm, eq_hi = (uint32_t)(eqm >> 32);
+    auto bcast = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
     float vs = 0.0f;
     int pv = -1;
-    if (lane == 0) vs = (float)h.qe - (float)h.qb;  // aln.rs:25-27 (sl[0] == 0)
-    for (int i = 1; i < n; ++i) {  // aln.rs:29-103
-        const uint32_t cqb = (uint32_t)__builtin_amdgcn_readlane((int)h.qb, i), cqe = (uint32_t)__builtin_amdgcn_readlane((int)h.qe, i),
-                       cqo = (uint32_t)__builtin_amdgcn_readlane((int)h.qo, i), ctb = (uint32_t)__builtin_amdgcn_readlane((int)h.tb, i),
-                       cte = (uint32_t)__builtin_amdgcn_readlane((int)h.te, i), cto = (uint32_t)__builtin_amdgcn_readlane((int)h.to, i);
-        const float cur_len = (float)cqe - (float)cqb;
-        bool cons = lane < i;
-        if (prm.oriented && ((h.qo ^ h.to) != (cqo ^ cto))) cons = false;  // :43-50
-        float a = (float)cqb - (float)h.qe;
-        float b = (cqo == cto) ? ((float)ctb - (float)h.te) : ((float)cte - (float)h.tb);
-        a = absf(a);
-        b = absf(b);
+    if (lane == 0) vs = len_f;  // aln.rs:25-27 (sl[0] == 0)
+    uint64_t lt = 1ull;         // the lanes below i
+    // the usual group -- no orientation or gap filter, no query interval twice (hence no hit pair twice) --: every lane below i is a
+    // candidate and opens an interval, the scored ones are the max_span nearest; nothing of that depends on the lanes' data
+    const bool plain = !prm.oriented && !prm.has_max_gap && !any_eq && !has_dup;
+    if (plain) {
+        for (int i = 1; i < ((PGR_QF_ABLATE & 128) ? 0 : n); ++i, lt = (lt << 1) | 1ull) {
+            const float c_fqb = bcast(f_qb, i), cur_len = bcast(len_f, i), c_ftb = bcast(f_tb, i), c_fte = bcast(f_te, i);
+            const int coo = __builtin_amdgcn_readlane(oo, i);
+            const bool c_same = ((coo ^ (coo >> 1)) & 1) == 0;
+            const float a = __builtin_fabsf(c_fqb - f_qe);
+            const float b = __builtin_fabsf(c_same ? (c_ftb - f_te) : (c_fte - f_tb));
+            const uint64_t pm = (uint32_t)i <= prm.max_span ? lt : lt & ~(lt >> prm.max_span);
+            float sc = vs + cur_len;           // :71-72
+            const float sum = a + b;           // :74-84
+            const float pen = prm.penalty * sum;
+            sc = sc - pen;
+            if (!__builtin_amdgcn_inverse_ballot_w64(pm)) sc = -INFINITY;
+            const uint32_t mb = wave_max_pos_bits(sc);
+            float nv = cur_len;  // :96-102
+            int np = -1;
+            if (mb) {  // :86-89
+                nv = __int_as_float((int)mb);
+                np = 63 - __builtin_clzll(__ballot((uint32_t)__float_as_int(sc) == mb));
+            }
+            if (lane == i) {
+                vs = nv;
+                pv = np;
+            }
+        }
+    }
+    for (int i = 1; i < ((PGR_QF_ABLATE & 128) || plain ? 0 : n); ++i, lt = (lt << 1) | 1ull) {  // aln.rs:29-103
+        const float c_fqb = bcast(f_qb, i), cur_len = bcast(len_f, i), c_ftb = bcast(f_tb, i), c_fte = bcast(f_te, i);
+        const int coo = __builtin_amdgcn_readlane(oo, i);
+        const bool c_same = ((coo ^ (coo >> 1)) & 1) == 0;  // cqo == cto
+        uint64_t cm = lt;
+        if (prm.oriented) cm &= __ballot((((oo ^ (oo >> 1)) & 1) == 0) == c_same);  // :43-50
+        float a = c_fqb - f_qe;
+        float b = c_same ? (c_ftb - f_te) : (c_fte - f_tb);
+        a = __builtin_fabsf(a);  // (a source modifier; the select of pgr_aln.h: absf differs for -0 only, which no comparison and no sum below can tell from +0)
+        b = __builtin_fabsf(b);
         if (prm.has_max_gap) {  // :52-65
             const float mg = (float)prm.max_gap;
-            if (a > mg || b > mg) cons = false;
+            cm &= ~__ballot(a > mg || b > mg);
         }
-        if (h.qb == cqb && h.qe == cqe && h.qo == cqo) cons = false;  // :67
-        const uint64_t cm = __ballot(cons);
+        if (any_eq) cm &= ~__ballot((((i < 32 ? eq_lo : eq_hi) >> (i & 31)) & 1u) != 0u);  // :67 (bit i of eqm: hit i has this lane's interval)
         float best_s = 0.0f;
         int best_v = -1;
         if (cm) {
@@ -167,23 +214,29 @@ __device__ __forceinline__ bool chain_group_regs(const pgr_hitpair *hit, const u
             // unless a considered candidate above it has the same interval; the look-back stops behind the candidate that
             // completes max_span intervals (:91), i.e. a candidate is scored iff fewer than max_span intervals were opened
             // above it.
-            const bool fresh = cons && (eqm & cm) == 0;
-            const uint64_t fm = __ballot(fresh);
-            const bool proc = cons && (uint32_t)__popcll(fm & above) < prm.max_span;
+            const bool cons = __builtin_amdgcn_inverse_ballot_w64(cm);
+            const uint64_t fm = any_eq ? __ballot(cons && (eqm & cm) == 0) : cm;
+            const uint32_t n_fresh = (uint32_t)__popcll(fm);
+            uint64_t pm;
+            if (any_eq ? n_fresh < prm.max_span : n_fresh <= prm.max_span) pm = cm;  // the span set never fills: every candidate is scored
+            else if (fm == lt) pm = lt & ~(lt >> prm.max_span);                          // all lanes below i, all fresh: the max_span nearest
+            else pm = __ballot(cons && (uint32_t)__popcll(fm & above) < prm.max_span);
+            const bool proc = __builtin_amdgcn_inverse_ballot_w64(pm);
             const float p_s = has_dup ? __shfl(vs, sl, 64) : vs;  // :71
             float s = p_s + cur_len;                              // :72
             const float sum = a + b;                              // :74-84
             const float pen = prm.penalty * sum;
             s = s - pen;
             if (!proc) s = -INFINITY;
-            const float m = wave_max_f32(s);
-            if (m > 0.0f) {  // :86-89: strict > from 0, the nearest candidate among equal maxima
-                const uint64_t mm = __ballot(proc && s == m);
-                best_s = m;
-                best_v = __builtin_amdgcn_readlane(sl, 63 - __builtin_clzll(mm));
+            const uint32_t mb = wave_max_pos_bits(s);
+            if (mb) {  // :86-89: strict > from 0, the nearest candidate among equal maxima
+                const uint64_t mm = __ballot((uint32_t)__float_as_int(s) == mb);  // (a lane that is not scored holds -inf)
+                const int top = 63 - __builtin_clzll(mm);
+                best_s = __int_as_float((int)mb);
+                best_v = has_dup ? __builtin_amdgcn_readlane(sl, top) : top;
             }
         }
-        const int si = __builtin_amdgcn_readlane(sl, i);
+        const int si = has_dup ? __builtin_amdgcn_readlane(sl, i) : i;
         if (lane == si) {  // :96-102
             vs = best_s > 0.0f ? best_s : cur_len;
             pv = best_s > 0.0f ? best_v : -1;
@@ -192,14 +245,16 @@ __device__ __forceinline__ bool chain_group_regs(const pgr_hitpair *hit, const u
     // chain extraction (aln.rs:105-140): best unvisited value slot, walk its predecessors until a visited one
     uint64_t unv = __ballot(in && sl == lane);
     bool stuck = false;
+    if (PGR_QF_ABLATE & 256) unv = 0;
     while (unv) {
-        const bool cand = (unv >> lane) & 1ull;
-        const float m = wave_max_f32(cand ? vs : -INFINITY);
-        if (!(m > 0.0f)) {  // only non-positive scores left: aln.rs:129-131 would spin forever
+        const bool cand = __builtin_amdgcn_inverse_ballot_w64(unv);
+        const uint32_t mb = wave_max_pos_bits(cand ? vs : -INFINITY);
+        if (!mb) {  // only non-positive scores left: aln.rs:129-131 would spin forever
             stuck = true;
             break;
         }
-        const int bv = __builtin_ctzll(__ballot(cand && vs == m));  // strict >: the lowest sorted index among equal maxima
+        const float m = __int_as_float((int)mb);
+        const int bv = __builtin_ctzll(__ballot(cand && (uint32_t)__float_as_int(vs) == mb));  // strict >: the lowest sorted index among equal maxima
         int len = 0, first_v = bv, v = bv, ord = -1;
         while (v >= 0 && ((unv >> v) & 1ull)) {  // :121-128
             if (lane == v) ord = len;
@@ -208,9 +263,9 @@ __device__ __forceinline__ bool chain_group_regs(const pgr_hitpair *hit, const u
             unv &= ~(1ull << v);  // :133-137
             v = __builtin_amdgcn_readlane(pv, v);
         }
-        if (ord >= 0) o_hp[nh + (uint32_t)(len - 1 - ord)] = h;  // :132 reversed
+        if (!(PGR_QF_ABLATE & 512) && ord >= 0) o_hp[nh + (uint32_t)(len - 1 - ord)] = h;  // :132 reversed
         const float first_s = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(vs), first_v));
-        if (lane == 0) {
+        if (!(PGR_QF_ABLATE & 1024) && lane == 0) {
             o_cscore[nc] = m - first_s;  // :138-139
             o_choff[nc] = nh;
         }
@@ -447,6 +502,66 @@ __device__ __forceinline__ uint32_t qf_compact(uint32_t n, int lane, uint16_t *o
     return total;
 }
 
+// The same through the per-query kernel's own table (pgr_index.h: qkeys): the bucket's entries' keys at once, then -- the same
+// cache line -- the second half of the entry that matched: a key with ONE record is answered here (single: tbte = bgn | end << 32,
+// sid, to), any other key by key_off as before.
+__device__ __forceinline__ void lookup_qkey(uint64_t h0, uint64_t h1, const QfArgs &a, uint64_t &lo_out, uint32_t &nrec, bool &single,
+                                            uint64_t &tbte, uint32_t &sid, uint32_t &to) {
+    constexpr uint64_t KM = ~(1ull << 63);
+    const uint64_t top = (1ull << a.lut_bits) - 1;
+    const uint64_t bk = (h0 >> a.lut_shift) < top ? (h0 >> a.lut_shift) : top;
+    const ulonglong2 *k2 = reinterpret_cast<const ulonglong2 *>(a.qkeys);  // entry k: k2[2 k] = (x, y), k2[2 k + 1] = (z, w)
+    uint64_t lo = a.lut[bk], hi = a.lut[bk + 1];
+    uint64_t found = U64MAX, fx = 0, fy = 0;
+    if (hi - lo <= 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint64_t k = lo + (uint64_t)j;
+            if (k < hi) {
+                const ulonglong2 kk = k2[2 * k];
+                if ((kk.x & KM) == h0 && (kk.y & KM) == h1) {
+                    found = k;
+                    fx = kk.x;
+                    fy = kk.y;
+                }
+            }
+        }
+    } else {
+        while (lo < hi) {
+            const uint64_t mid = (lo + hi) >> 1;
+            const ulonglong2 kk = k2[2 * mid];
+            const uint64_t kx = kk.x & KM, ky = kk.y & KM;
+            if (kx < h0 || (kx == h0 && ky < h1)) lo = mid + 1;
+            else hi = mid;
+        }
+        if (lo < a.n_keys) {
+            const ulonglong2 kk = k2[2 * lo];
+            if ((kk.x & KM) == h0 && (kk.y & KM) == h1) {
+                found = lo;
+                fx = kk.x;
+                fy = kk.y;
+            }
+        }
+    }
+    lo_out = 0;
+    nrec = 0;
+    single = false;
+    tbte = 0;
+    sid = to = 0;
+    if (found == U64MAX) return;
+    if (fx >> 63) {
+        const ulonglong2 zw = k2[2 * found + 1];
+        single = true;
+        nrec = 1;
+        sid = (uint32_t)zw.x;
+        tbte = (zw.x >> 32) | (zw.y << 32);
+        to = (uint32_t)(fy >> 63);
+    } else {
+        lo_out = a.key_off[found];
+        nrec = (uint32_t)(a.key_off[found + 1] - lo_out);  // (one key holds fewer than 2^32 records)
+    }
+}
+
 // One query, the whole wavefront: chains into the query's slot; the counts come back wave-uniform (all zero for a query the
 // path cannot hold: the batch's flags say why).  L1: the level-1 form (QfArgs).
 template <bool L1>
@@ -457,8 +572,9 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
     n_pairs_out = 0;
     uint64_t *L_h0 = reinterpret_cast<uint64_t *>(qf_dyn), *L_h1 = L_h0 + P, *L_lo = L_h1 + P;
     uint32_t *L_nrec = reinterpret_cast<uint32_t *>(L_lo + P), *L_pc = L_nrec + P, *L_hoff = L_pc + P;
-    uint32_t *L_bgn = L_hoff + P, *L_eo = L_bgn + P;  // (level-1 form only: begin, end | orient << 31 of the pair)
-    pgr_hitpair *hit = reinterpret_cast<pgr_hitpair *>(L_hoff + (L1 ? 3 * P : P));
+    uint32_t *L_sid = L_hoff + P, *L_fl = L_sid + P;  // a pair whose key has ONE record (qkeys): its sid; bit 0 single, bit 1 the record's orient
+    uint32_t *L_bgn = L_fl + P, *L_eo = L_bgn + P;    // (level-1 form only: begin, end | orient << 31 of the pair)
+    pgr_hitpair *hit = reinterpret_cast<pgr_hitpair *>(L_fl + (L1 ? 3 * P : P));
     uint32_t *hsid = reinterpret_cast<uint32_t *>(hit + H), *ssid = hsid + H, *perm = ssid + H;
     uint32_t m = 0;
     nt = nc = nh = n_hits_out = 0;
@@ -468,14 +584,8 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
     uint64_t p0 = 0;
     if (L1) {
         // ---- the level-1 kernels' own verdict first: a batch that needs islands or overflowed belongs to the shimmer pipeline
+        // (looked at below, when the segment table's loads are on their way: one trip to memory less in front of everything)
         const unsigned long long s0 = a.l1_status[0], s1 = a.l1_status[1], s2 = a.l1_status[2];
-        if (s1 || s2 || s0 > a.l1_ovf_cap) {
-            if (q == 0 && lane == 0) {
-                const uint32_t was = atomicOr(a.flags, QF_DECLINE | QF_L1_FLAGGED);
-                asm volatile("" ::"v"(was));
-            }
-            return;
-        }
         const uint32_t C1 = a.C1;
         uint64_t *key1 = reinterpret_cast<uint64_t *>(hit);
         uint32_t *ypos1 = reinterpret_cast<uint32_t *>(key1 + C1);
@@ -496,6 +606,13 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         const bool sl = (uint32_t)lane < nseg;
         const uint32_t scnt = sl ? a.seg_cnt[seg0 + lane] : 0u;
         const uint64_t sof = sl ? a.seg_off[seg0 + lane] : 0ull;
+        if (s1 || s2 || s0 > a.l1_ovf_cap) {
+            if (q == 0 && lane == 0) {
+                const uint32_t was = atomicOr(a.flags, QF_DECLINE | QF_L1_FLAGGED);
+                asm volatile("" ::"v"(was));
+            }
+            return;
+        }
         const uint32_t sincl = wave_incl_sum(scnt);
         const uint32_t n1 = (uint32_t)__builtin_amdgcn_readlane((int)sincl, 63);
         if (n1 > C1) {  // (low-complexity sequence: denser than the estimate)
@@ -535,6 +652,7 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
             }
         }
         wave_sync();
+        if (PGR_QF_ABLATE & 2) return;
         // ---- reduce_shmmr twice (shmmrutils.rs:533-535), then the min_span stencil on the unfiltered neighbours (:536-555: the
         // first and the last element always stay)
         const uint16_t *fin = nullptr;  // nullptr: the identity list
@@ -577,7 +695,7 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         n_pairs_out = npair;
         {   // (P <= 256: four pairs per lane; everything is read -- the final list lies where the pairs go -- before anything is written)
             constexpr int QF_PU = 4;
-            static_assert(QF_MAX_PAIRS <= 64 * QF_PU && QF_C1_MAX * 4 <= 64 * QF_PU * 44, "pairs per lane");
+            static_assert(QF_MAX_PAIRS <= 64 * QF_PU && QF_C1_MAX * 4 <= 64 * QF_PU * 52, "pairs per lane");
             uint64_t k0[QF_PU], k1[QF_PU];
             uint32_t y0[QF_PU], y1[QF_PU];
 #pragma unroll
@@ -613,18 +731,33 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         decline = np64 > (uint64_t)P;
         np = decline ? 0 : (int)np64;
     }
+    if (PGR_QF_ABLATE & 4) return;
     // ---- lookup of every pair
     for (int i = lane; i < np; i += 64) {
         const uint64_t h0 = L1 ? L_h0[i] : a.qrec[p0 + i].h0, h1 = L1 ? L_h1[i] : a.qrec[p0 + i].h1;
-        uint64_t lo, hi;
-        lookup_range_short(h0, h1, a, lo, hi);
         L_h0[i] = h0;
         L_h1[i] = h1;
-        L_lo[i] = lo;
-        L_nrec[i] = (uint32_t)(hi - lo);  // (one key holds fewer than 2^32 records)
-        nsig += hi - lo;
+        if (a.qkeys) {  // (uniform)
+            uint64_t lo, tbte;
+            uint32_t nrec, sid, to;
+            bool single;
+            lookup_qkey(h0, h1, a, lo, nrec, single, tbte, sid, to);
+            L_lo[i] = single ? tbte : lo;
+            L_nrec[i] = nrec;
+            L_sid[i] = sid;
+            L_fl[i] = (single ? 1u : 0u) | (to << 1);
+            nsig += nrec;
+        } else {
+            uint64_t lo, hi;
+            lookup_range_short(h0, h1, a, lo, hi);
+            L_lo[i] = lo;
+            L_nrec[i] = (uint32_t)(hi - lo);  // (one key holds fewer than 2^32 records)
+            L_fl[i] = 0u;
+            nsig += hi - lo;
+        }
     }
     wave_sync();
+    if (PGR_QF_ABLATE & 8) return;
     // ---- multiplicity of the pair's key inside the query (aln.rs:180-181), count filters (aln.rs:197-228), hit counts
     for (int i0 = 0; i0 < np; i0 += 64) {
         const int i = i0 + lane;
@@ -632,12 +765,22 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         uint32_t c = 0, n = 0;
         if (live) {
             const uint64_t h0 = L_h0[i], h1 = L_h1[i];
-            for (int j = 0; j < np; ++j) c += (L_h0[j] == h0 && L_h1[j] == h1) ? 1u : 0u;
+            // (four pairs per step: their LDS reads are in flight together -- the loop is a chain of LDS round trips otherwise)
+            int j = 0;
+            for (; j + 4 <= np; j += 4) {
+                const uint64_t x0 = L_h0[j], x1 = L_h0[j + 1], x2 = L_h0[j + 2], x3 = L_h0[j + 3];
+                const uint64_t y0 = L_h1[j], y1 = L_h1[j + 1], y2 = L_h1[j + 2], y3 = L_h1[j + 3];
+                c += ((x0 == h0 && y0 == h1) ? 1u : 0u) + ((x1 == h0 && y1 == h1) ? 1u : 0u) + ((x2 == h0 && y2 == h1) ? 1u : 0u) +
+                     ((x3 == h0 && y3 == h1) ? 1u : 0u);
+            }
+            for (; j < np; ++j) c += (L_h0[j] == h0 && L_h1[j] == h1) ? 1u : 0u;
         }
         const bool pass = live && c <= a.qp.max_count && c <= a.qp.max_count_query;
         const uint32_t nr = pass ? L_nrec[i] : 0u;
         if (nr > (uint32_t)HITS_HEAVY) decline = true;
-        else if (nr) {
+        else if (nr && (L_fl[i] & 1u)) {  // the key's one record: a run of length 1
+            if ((uint64_t)c <= a.qp.max_count_target) n = 1;
+        } else if (nr) {
             const uint64_t s0 = L_lo[i], e0 = s0 + nr;
             uint64_t s = s0;
             while (s < e0) {  // records of one key are sorted by sid: target_shmer_pair_count[(key, sid)] = c * run length
@@ -654,6 +797,7 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         m += (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
     }
     const uint32_t n_hits = m;
+    if (PGR_QF_ABLATE & 16) return;
     const bool any_decline = __ballot(decline) != 0;
     if (any_decline || m > H) {
         if (lane == 0) {
@@ -681,8 +825,23 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
             q_end = qr.end;
             q_or = qr.orient;
         }
-        const uint64_t s0 = L_lo[i], e0 = s0 + L_nrec[i];
         uint32_t o = L_hoff[i];
+        if (L_fl[i] & 1u) {  // the key's one record came with the lookup
+            if ((uint64_t)c <= a.qp.max_count_target) {
+                const uint64_t tbte = L_lo[i];
+                pgr_hitpair hp;
+                hp.qb = q_bgn;
+                hp.qe = q_end;
+                hp.qo = q_or;
+                hp.tb = (uint32_t)tbte;
+                hp.te = (uint32_t)(tbte >> 32);
+                hp.to = L_fl[i] >> 1;
+                hit[o] = hp;
+                hsid[o] = L_sid[i];
+            }
+            continue;
+        }
+        const uint64_t s0 = L_lo[i], e0 = s0 + L_nrec[i];
         uint64_t s = s0;
         while (s < e0) {
             const uint32_t sid = a.recs[s].sid;
@@ -706,13 +865,20 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         }
     }
     wave_sync();
+    if (PGR_QF_ABLATE & 32) return;
     // ---- stable sort by target sid: rank by counting; the hits stay where they are, perm[rank] = position
     for (uint32_t i0 = 0; i0 < m; i0 += 64) {
         const uint32_t i = i0 + (uint32_t)lane;
         if (i < m) {
             const uint32_t mine = hsid[i];
             uint32_t rank = 0;
-            for (uint32_t j = 0; j < m; ++j) {
+            uint32_t j = 0;
+            for (; j + 4 <= m; j += 4) {  // (as above: four reads in flight)
+                const uint32_t o0 = hsid[j], o1 = hsid[j + 1], o2 = hsid[j + 2], o3 = hsid[j + 3];
+                rank += ((o0 < mine || (o0 == mine && j < i)) ? 1u : 0u) + ((o1 < mine || (o1 == mine && j + 1 < i)) ? 1u : 0u) +
+                        ((o2 < mine || (o2 == mine && j + 2 < i)) ? 1u : 0u) + ((o3 < mine || (o3 == mine && j + 3 < i)) ? 1u : 0u);
+            }
+            for (; j < m; ++j) {
                 const uint32_t o = hsid[j];
                 rank += (o < mine || (o == mine && j < i)) ? 1u : 0u;
             }
@@ -721,6 +887,7 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
         }
     }
     wave_sync();
+    if (PGR_QF_ABLATE & 64) return;
     // ---- groups = runs of equal sid; targets with a single hit are dropped (aln.rs:234)
     const size_t sb = (size_t)q * H;
     pgr_hitpair *o_hp = a.s_hp + sb;
@@ -752,7 +919,9 @@ __device__ __forceinline__ void qf_one_query(const QfArgs &a, uint8_t *qf_dyn, c
             }
             ++nt;
             bool stuck;
-            if (n <= 64) {
+            if (PGR_QF_ABLATE & 1) {
+                stuck = false;
+            } else if (n <= 64) {
                 stuck = chain_group_regs(hit, perm + gs, (int)n, a.ap, lane, o_hp, o_cscore, o_choff, nc, nh);
             } else {
                 float *w_vs = reinterpret_cast<float *>(perm + H);
@@ -1215,7 +1384,7 @@ int QueryFusedRun::enqueue_from_level1(const QfLevel1View &v, uint32_t c1) {
     from_l1 = true;
     l1v = v;
     C1 = c1;
-    while ((size_t)P * 44 < (size_t)C1 * 4) P <<= 1;  // (the index lists of the level-1 stage live in the pairs' bytes)
+    while ((size_t)P * 52 < (size_t)C1 * 4) P <<= 1;  // (the index lists of the level-1 stage live in the pairs' bytes)
     return enqueue(nullptr, nullptr, true);
 }
 
@@ -1263,6 +1432,7 @@ int QueryFusedRun::enqueue(const pgr_frag_rec *qrec, const uint64_t *pair_off, b
     a.lut_bits = ix->lut_bits;
     a.lut_shift = ix->lut_shift;
     a.keys = ix->keys;
+    a.qkeys = ix->lut ? ix->qkeys : nullptr;
     a.qp = qp;
     a.ap = ap;
     a.P = P;
@@ -1384,7 +1554,7 @@ int QueryFusedRun::finish(pgr_hps_result *out, QueryFusedCounts *counts, bool *d
             if (more_l1) {
                 grew_c1 = true;
                 C1 = (uint32_t)((mb[10] + 31) / 32 * 32);
-                while ((size_t)P * 44 < (size_t)C1 * 4) P <<= 1;
+                while ((size_t)P * 52 < (size_t)C1 * 4) P <<= 1;
             }
             // (a larger P may come with more hits than the slot holds: QF_MORE_HITS of this pass is looked at in the next one)
             int rc = enqueue(nullptr, nullptr);

@@ -18,15 +18,13 @@ namespace pgr {
 // it makes and never looks at that state; PyTorch and the host program share the thread -- came back as "scan_counts(...): invalid
 // argument" from a scan that had nothing wrong with it (round 6: once in a 149-test run, never in isolation).  Every wrapper
 // takes stale state away first; with PGR_DEBUG_STALE=1 it says so.
-namespace {
-inline void drop_stale_hip_error(const char *who) {
+void drop_stale_hip_error(const char *who) {
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) {
         static const bool say = getenv("PGR_DEBUG_STALE") != nullptr;
         if (say) fprintf(stderr, "[pgr] %s: a stale HIP error of this thread was dropped: %s\n", who, hipGetErrorString(e));
     }
 }
-}  // namespace
 
 namespace {
 struct U32toU64 {

@@ -92,7 +92,7 @@ extern "C" int pgr_shard_sample_keys(pgr_ctx *ctx, const pgr_frag_rec *d_recs, u
                                      uint32_t *n_out) {
     if (!ctx) return PGR_ERR_INVALID_ARG;
     if (!out || !n_out || (n && !d_recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     const uint32_t ns = (uint32_t)std::min<uint64_t>(n, n_samples);
     *n_out = ns;
     if (ns == 0) return PGR_OK;
@@ -122,7 +122,7 @@ extern "C" int pgr_shard_partition(pgr_ctx *ctx, const pgr_frag_rec *d_recs, uin
     if (world < 1 || !counts || (world > 1 && !splitters) || (n && (!d_recs || !d_out)))
         return ctx->fail(PGR_ERR_INVALID_ARG, "bad partition arguments");
     if (n >= (1ull << 32)) return ctx->fail(PGR_ERR_INVALID_ARG, "more than 2^32-1 records in one partition call");
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     hipStream_t st = ctx->stream;
     for (int d = 0; d < world; ++d) counts[d] = 0;
     if (n == 0) return PGR_OK;
@@ -163,7 +163,7 @@ extern "C" int pgr_records_checksum(pgr_ctx *ctx, const pgr_frag_rec *d_recs, ui
     if (!out || (n && !d_recs)) return ctx->fail(PGR_ERR_INVALID_ARG, "null argument");
     out[0] = out[1] = 0;
     if (n == 0) return PGR_OK;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     Tmp d(ctx);
     int rc = d.alloc(16);
     if (rc) return rc;
@@ -194,7 +194,7 @@ extern "C" int pgr_index_key_range(pgr_ctx *ctx, const pgr_index *ix, uint64_t *
     if (!ix->finalized) return ctx->fail(PGR_ERR_STATE, "index not finalized");
     *h0_min = *h0_max = 0;
     if (ix->n == 0) return PGR_OK;
-    PGR_HIP(ctx, hipSetDevice(ctx->device));
+    PGR_ENTER(ctx);
     PGR_HIP(ctx, hipMemcpyAsync(h0_min, &ix->recs[0].h0, 8, hipMemcpyDeviceToHost, ctx->stream));
     PGR_HIP(ctx, hipMemcpyAsync(h0_max, &ix->recs[ix->n - 1].h0, 8, hipMemcpyDeviceToHost, ctx->stream));
     PGR_HIP(ctx, hipStreamSynchronize(ctx->stream));

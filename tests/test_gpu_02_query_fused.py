@@ -364,3 +364,26 @@ def test_level1_form_declines_what_the_tile_kernel_flags_and_grows_what_outgrows
     g = sdb.query_fragments_to_hps(long_q, *_args(KW))
     assert gpu_ctx.last_query_prof()["path"] == 3
     assert _check_vs_oracle(oix, long_q, g, KW) >= 8 and _general(sdb, long_q, KW) == g
+
+
+def test_per_key_table_of_the_query_kernel_changes_nothing(oracle, gpu_ctx):
+    """pgr_index.h: qkeys -- 32 B per key, the key with its record when it has exactly one: a pair's lookup (seq_db.rs:1200-1228) is two
+    dependent trips to memory instead of six.  An index built without it (context option no_query_keys at finalize) answers the
+    same: contigs that share segments (keys with several records, several of one sid), an exact duplicate, unique sequence; count
+    filters at 1, 2 and 128 (the single-record shortcut applies max_count_target itself); both forms of the kernel."""
+    rng = np.random.default_rng(63)
+    seqs, core = _make_db_seqs(rng)
+    seqs = seqs + [seqgen.rnd(rng, 200_000) for _ in range(3)]
+    sdb, oix = _build_pair(oracle, gpu_ctx, seqs)
+    with gpu_ctx.options(no_query_keys=1):
+        plain, _ = _build_pair(oracle, gpu_ctx, seqs)
+    queries = _short_queries(rng, seqs, 120) + [seqs[14][1000:9000], revcomp(seqs[15][50_000:61_000]), core[0][:9000], b""]
+    for kw in (KW, dict(KW, max_count_target=1), dict(KW, max_count=2, max_count_query=1, max_count_target=2),
+               dict(KW, max_aln_span=3, max_gap=5000, orientated=True)):
+        got = sdb.query_fragments_to_hps(queries, *_args(kw))
+        assert gpu_ctx.last_query_prof()["path"] in _paths(1, 2)
+        ref = plain.query_fragments_to_hps(queries, *_args(kw))
+        assert gpu_ctx.last_query_prof()["path"] in _paths(1, 2)
+        assert got == ref
+        assert _general(sdb, queries, kw) == got
+        assert _check_vs_oracle(oix, queries[-30:], got[-30:], kw) >= 10

@@ -20,12 +20,15 @@ def main():
     ap.add_argument("--contig-len", type=int, default=10_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
     ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--chained", action="store_true", help="the chained form (context option no_query_level1): shimmer pipeline, then the per-query kernel")
     a = ap.parse_args()
     import numpy as np
     import torch  # noqa: F401
     import bench
     import pgrtk_amd as P
     ctx = P.Context(0)
+    if a.chained:
+        ctx.set_option("no_query_level1", 1)
     spec = P.make_spec(80, 56, 4, 64)
     ids = list(range(a.contigs))
     batch = P.Batch.synthetic([a.contig_len] * a.contigs, seed=a.seed, ctx=ctx)
@@ -44,6 +47,7 @@ def main():
         ts.append(dt)
     print("query batches (C entry point): %s ms; %d hit pairs" % (" ".join("%.3f" % (t * 1e3) for t in ts), n_hps))
     p = ctx.last_query_prof()
+    print("path %d" % p["path"])
     print("stages of the last batch: " + ", ".join("%s %.3f" % (k, p[k]) for k in ("shmmr_ms", "lookup_ms", "chain_ms", "result_ms", "total_ms")))
     t0 = time.perf_counter()
     r = ix.query_hps_resident_raw(qb, 0.025)
