@@ -38,7 +38,7 @@ HBM_PEAK_GBPS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s
 N_SIMD = 256 * 4            # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32
 CLOCK_GHZ = 2.4
 PCIE_PEAK_GBPS = 63.0       # PCIe Gen5 x16, one direction
-QUERY_PROFILE = "r05_query"  # profiles/<dir> whose counters / kernel trace the query leg's replayed fields come from
+QUERY_PROFILE = "r06_query"  # profiles/<dir> whose counters / kernel trace the query leg's replayed fields come from
 
 
 def committed(*parts):

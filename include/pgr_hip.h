@@ -97,6 +97,9 @@ const char *pgr_version(void);
  *   gpu_pack                  ASCII over PCIe + pack kernel instead of the CPU packer (the round-2 host path)
  *   index_full_sort, index_two_key_sort    pgr_index_finalize: force the four-field / the two-key sort
  *   no_fused_query, no_query_chaining, query_global_sort, fused_query_hits   query path variants
+ *   no_query_level1   query batches never take the level-1 form of the per-query kernel (tile kernel + per-query kernel on the tile
+ *                     segments, no list stage of the batch: pgr_query_prof.path 3)
+ *   no_query_keys     pgr_index_finalize builds no per-key table for that kernel (32 B per key: the key with its record when it has one)
  *   exchange_timeout_s        watchdog of pgr_exchange_*: bound on loading librccl.so.1, ncclGetUniqueId and ncclCommInitRank (the
  *                             rendezvous of the ranks) (300; 0 = wait for ever); on a timeout the call fails and its message
  *                             names the step that did not return
@@ -423,7 +426,12 @@ typedef struct {
     /* 0: one kernel per stage over the whole batch (any batch).  1: one wavefront per query does every stage behind the pair
      * records (batches of short queries, csrc/query_fused.hip): lookup_ms and result_ms are 0, chain_ms holds that stage.
      * 2: the same, enqueued behind the shimmer pipeline without a host wait in between (the usual case; 1 when the guess
-     * of the queries' sizes was too small): shmmr_ms holds the device time of both, the call has ONE synchronization.      */
+     * of the queries' sizes was too small): shmmr_ms holds the device time of both, the call has ONE synchronization.
+     * 3: the level-1 form of that kernel (round 6; the usual case for batches of short clean queries): the tile kernel of the
+     * queries, then the per-query kernel on the tile segments -- it runs the list stage of its own query (reduce_shmmr twice,
+     * shmmrutils.rs:359-415; min_span, :536-555; the pairs, seq_db.rs:1205-1217) in LDS --, no list stage of the batch: 8 launches,
+     * ONE synchronization; n_query_pairs is what the device counted.  What the tile kernel flags (a palindromic k-mer, a non-ACGT
+     * byte, an overflow) declines the batch on the device and it is answered as under 2 / 1 / 0.                              */
     uint32_t path;
     uint32_t _pad;
 } pgr_query_prof;

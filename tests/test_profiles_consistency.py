@@ -7,7 +7,7 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 P = os.path.join(ROOT, "profiles")
-TILE, QUERY, UBENCH = "r05_tile", "r05_query", "r04_ubench"   # the round's evidence directories
+TILE, QUERY, UBENCH = "r06_tile", "r06_query", "r04_ubench"   # the round's evidence directories
 
 
 def _load(*parts):
@@ -79,7 +79,8 @@ def test_query_leg_evidence():
     pm = _load(QUERY, "pmc_summary.json")
     assert pm["per_query_batch"]["hbm_bytes"] > r["algorithmic_bytes"]
     assert s["kernel_ms_total"] * 1e-3 <= q["query_s"] * 1.05  # kernel time fits inside the measured batch time
-    # round 3: the per-query kernel behind the shimmer pipeline -- one host wait, at most 20 launches, under a millisecond
-    assert "one wavefront per query" in q["path"] and "ONE" in q["path"]
-    assert s["launches"] <= 20 and r["launches"] == s["launches"] and q["query_s"] < 0.9e-3
+    # round 3: the per-query kernel behind the shimmer pipeline -- one host wait, at most 20 launches, under a millisecond;
+    # round 6: its level-1 form (no list stage of the batch) -- 8 launches, under 0.65 ms
+    assert "one wavefront per query" in q["path"] and "ONE" in q["path"] and q["path_id"] == 3
+    assert s["launches"] <= 8 and r["launches"] == s["launches"] and q["query_s"] < 0.65e-3
     assert q["stage_ms"]["lookup_ms"] == 0.0 and q["stage_ms"]["chain_ms"] < 0.1  # (nothing waits between the two stages)

