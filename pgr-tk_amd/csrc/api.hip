@@ -49,7 +49,7 @@ const std::vector<OptionName> &option_names() {
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
         {"back_priority", &O::back_priority}, {"no_fix_stream", &O::no_fix_stream}, {"no_stage1_only", &O::no_stage1_only}, {"pipe_staged_records", &O::pipe_staged_records},
         {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d},
-        {"pipe_small_list", &O::pipe_small_list}, {"front_priority", &O::front_priority}};
+        {"pipe_small_list", &O::pipe_small_list}, {"pipe_persistent_list", &O::pipe_persistent_list}, {"front_priority", &O::front_priority}};
     return v;
 }
 }  // namespace

@@ -5,6 +5,8 @@
 // The level-1 list is ~2.5 % of the positions (12 B each in HBM: L1Rec).  It is read ONCE, straight from the unordered
 // per-tile segments, by fused_select_kernel (reduce x2 + min_span in LDS); only the survivors (~12 %) are
 // written, ordered by a scan + gather_segments_kernel.  Plain HBM streaming code, no MFMA.
+#include <algorithm>
+
 #include "pgr_device.h"
 #include "pgr_internal.h"
 
@@ -468,17 +470,17 @@ using FusedArgs = FusedArgsPub;
 // FB: list elements a workgroup owns (FUSED_B = 1024; 512 for the workgroups of a pipelined job: 14 KB of LDS, which fit BESIDE the
 // four tile workgroups of a CU -- 4 x 36 352 of 163 840 bytes leave 18 432)
 template <int EMAX, int FB>
-__global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
+__device__ __forceinline__ void fused_select_block(const FusedArgs &a, const uint32_t blk) {
     using FusedLds = FusedLdsT<EMAX>;
     constexpr int FUSED_CMAX = FusedLds::CMAX;
     __shared__ FusedLds L;
     const uint32_t t = threadIdx.x;
     const uint64_t total = *a.total;
-    const uint64_t core_lo = (uint64_t)blockIdx.x * FB;
+    const uint64_t core_lo = (uint64_t)blk * FB;
     if (core_lo >= total) {  // the grid is an upper bound (sized before the level-1 count is known): nothing to do here
         if (t == 0) {
-            a.blk_off[blockIdx.x] = 0;
-            a.blk_cnt[blockIdx.x] = 0;
+            a.blk_off[blk] = 0;
+            a.blk_cnt[blk] = 0;
         }
         return;
     }
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     // ---- stream [lo, hi) of the logical level-1 list into LDS.  Segment descriptors are staged 64 at a time
     // (the segment holding `lo` was located by block_first_seg_kernel); then every lane fetches its own
     // elements (k = j*256 + t) independently: ~5 outstanding 16-byte loads per lane.
-    uint32_t seg0 = a.blk_first_seg[blockIdx.x];
+    uint32_t seg0 = a.blk_first_seg[blk];
     uint64_t done = lo;  // logical elements below `done` are loaded
     uint32_t cid0 = 0;   // contig of the block's first element (the first staged segment holds it)
     bool first_batch = true;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
 
 #if PGR_ABLATE_L2 == 1
     if (L.x[t] != 0x1234567ull) {  // load only
-        if (t == 0) { a.blk_off[blockIdx.x] = 0; a.blk_cnt[blockIdx.x] = 0; }
+        if (t == 0) { a.blk_off[blk] = 0; a.blk_cnt[blk] = 0; }
         return;
     }
 #endif
@@ -707,7 +709,7 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
     if (t == 0) {
         // fixed slot per workgroup; only blocks with more survivors than the slot use the shared cursor
         // (same-address atomics saturate at ~88/us on gfx950)
-        unsigned long long base = (unsigned long long)blockIdx.x * a.slot;
+        unsigned long long base = (unsigned long long)blk * a.slot;
         bool ok = true;
         if (tot > a.slot) {
             const unsigned long long ob = atomicAdd(a.cursor, (unsigned long long)tot);
@@ -716,8 +718,8 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
             if (!ok) atomicExch(a.cursor + 1, 1ull);
         }
         L.base_out = ok ? base : ~0ull;
-        a.blk_off[blockIdx.x] = base;
-        a.blk_cnt[blockIdx.x] = ok ? tot : 0u;
+        a.blk_off[blk] = base;
+        a.blk_cnt[blk] = ok ? tot : 0u;
     }
     __syncthreads();
     const unsigned long long base = L.base_out;
@@ -738,6 +740,23 @@ __global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
                 a.out[base + cb + (uint32_t)__popcll(bal[it] & lt)] = m;
             }
         }
+    }
+}
+
+template <int EMAX, int FB>
+__global__ __launch_bounds__(FUSED_T) void fused_select_kernel(FusedArgs a) {
+    fused_select_block<EMAX, FB>(a, blockIdx.x);
+}
+// The same as a PERSISTENT grid (a pipelined job's list stage, context option pipe_persistent_list): gridDim.x workgroups of the
+// 14 KB variant loop over the blocks blk, blk + gridDim.x, ...  Launched with about one workgroup per CU it lives in the 18 KB of
+// LDS that a CU's four tile workgroups leave free and never asks the dispatcher for a tile's slot again -- a list workgroup that
+// takes a tile's 36 KB range spends most of its time waiting for memory there.  No prefetch of the next block (the
+// form of round 5 that cost 54 VGPRs): the loop is around the body as it is.
+template <int EMAX, int FB>
+__global__ __launch_bounds__(FUSED_T) void fused_select_persistent_kernel(FusedArgs a, uint32_t n_blocks) {
+    for (uint32_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        fused_select_block<EMAX, FB>(a, blk);
+        __syncthreads();  // (the next block's first writes to LDS)
     }
 }
 
@@ -803,7 +822,10 @@ void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_b
         if (!a.lds_match || hipFuncGetAttributes(&at, f) != hipSuccess || at.sharedSizeBytes >= a.lds_match) return 0u;
         return a.lds_match - (uint32_t)at.sharedSizeBytes;
     };
-    if (a.halo <= 32 && a.block_elems == 512u)
+    if (a.halo <= 32 && a.block_elems == 512u && a.persistent_grid)
+        hipLaunchKernelGGL((fused_select_persistent_kernel<512 + 2 * 32, 512>), dim3(std::min(a.persistent_grid, n_blocks)), dim3(FUSED_T), 0, st, a,
+                           n_blocks);
+    else if (a.halo <= 32 && a.block_elems == 512u)
         hipLaunchKernelGGL((fused_select_kernel<512 + 2 * 32, 512>), dim3(n_blocks), dim3(FUSED_T), 0, st, a);
     else if (a.halo <= 32)
         hipLaunchKernelGGL((fused_select_kernel<FUSED_EMAX_SMALL, FUSED_B>), dim3(n_blocks), dim3(FUSED_T),

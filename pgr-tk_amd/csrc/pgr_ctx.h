@@ -99,6 +99,7 @@ struct pgr_ctx {
         int64_t no_early_merge = 0;      // a tile that reports a palindromic k-mer drops the early round of the islands around non-ACGT bytes (the first form), instead of keeping it and adding the new islands (for A/B)
         int64_t no_pre_islands = 0;      // never list the islands around non-ACGT bytes while the tile kernel runs (for A/B)
         int64_t no_short_tiles = 0;      // batches of short contigs: the 4096-position tiles all the same, for A/B
+        int64_t pipe_persistent_list = 0;  // pgr_pipe: > 0 = the list kernel of a pipelined job is this many persistent 512-element workgroups (about one per CU: beside the tiles, never in a tile's slot), for A/B
         int64_t pipe_small_list = 0;     // pgr_pipe: 1 = the list kernel runs 512-element workgroups (14 KB of LDS: they fit beside a CU's four tile workgroups), for A/B
         int64_t front_priority = 0;      // 1: the context's stream is created with the device's highest priority (read at pgr_ctx_create only), for A/B
         int64_t no_direct_h2d = 0;       // packed input in pinned host memory goes through the staging windows all the same, for A/B

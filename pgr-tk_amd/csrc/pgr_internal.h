@@ -225,6 +225,7 @@ struct FusedArgsPub {
     uint32_t *blk_first_seg;  // [n_blocks] scratch
     uint32_t block_elems = 1024;  // list elements per workgroup: FUSED_BLOCK_ELEMS, or 512 (halo <= 32 only): small workgroups for a pipe's back stream
     uint32_t lds_match = 0;   // > 0: every workgroup occupies exactly this much LDS (the tile kernel's, when the two run side by side)
+    uint32_t persistent_grid = 0;  // > 0 (with block_elems 512): this many workgroups loop over the blocks (level2.hip: fused_select_persistent_kernel)
 };
 void launch_fused_select_pub(hipStream_t st, const FusedArgsPub &a, uint32_t n_blocks);
 // n_ptr: device, number of elements (clamped to cap)

@@ -1039,7 +1039,7 @@ int ShmmrJob::plan() {
     // (512-element workgroups for a pipelined job, measured and NOT the default: 14 KB of LDS fit beside a CU's four tile workgroups,
     // but the dispatcher gives them tile slots all the same -- the tile kernel beside them took 20.6 ms instead of 20.1 with the
     // 1024-element workgroups; with the context's stream at the highest priority they do not run beside the tiles at all)
-    fb = (sf != sb && do_reduce && halo <= 32 && ctx->opt.pipe_small_list) ? 512u : FUSED_BLOCK_ELEMS;
+    fb = (sf != sb && do_reduce && halo <= 32 && (ctx->opt.pipe_small_list || ctx->opt.pipe_persistent_list > 0)) ? 512u : FUSED_BLOCK_ELEMS;
     slot2 = do_reduce ? fb / 4 : fb;
     serial_base = 0;
     islands_done = false;
@@ -1363,6 +1363,7 @@ int ShmmrJob::stage3() {
     fa.blk_first_seg = (uint32_t *)ctx->ws_start_rank.p;
     fa.lds_match = lds_match;
     fa.block_elems = fb;
+    fa.persistent_grid = (sf != sb && fb == 512u && ctx->opt.pipe_persistent_list > 0) ? (uint32_t)ctx->opt.pipe_persistent_list : 0u;
     launch_fused_select_pub(st, fa, n_blocks);
     return PGR_OK;
 }
