@@ -806,7 +806,10 @@ def target_100gbp(P, ctx, spec, args, spec_t=(80, 56, 4, 64), cores=1, check=Tru
     import numpy as np
     import torch
     n_b, n_c, L = 10, 1000, 10_000_000
-    RESERVE_GIB = 56  # (the allocator's measured peak of this build is 53.8e9 bytes = 50.1 GiB)
+    # (what the build takes from the device: the caching allocator's peak 63.5e9 bytes + the contexts' grow-only workspaces -- level-1
+    # buffers of two lanes, segment tables -- 21e9, measured as `fallback_bytes` of a 56 GiB arena in round 6, + the per-query kernel's
+    # key table, 32 B x 304 M keys)
+    RESERVE_GIB = 96
     ctx.synchronize()
     # (NOT ctx.trim().  In a process that has allocated and released many GiB, every so-many-th large hipMalloc blocks for up to
     # seconds while the driver clears released memory (tools/probe/big_malloc_probe.py: torch alone shows it; the gaps and the
