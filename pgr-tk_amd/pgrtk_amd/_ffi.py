@@ -324,6 +324,16 @@ class Context:
             lib().pgr_ctx_destroy(self._h)
             self._h = C.c_void_p()
 
+    @property
+    def alive(self):
+        """the native context still exists.  Objects of a context (Batch, Shmmrs, Pipe, Index, SeqIndexDB, AbiExchange) hold a
+        reference to it, so by reference counting it outlives them -- but inside a garbage CYCLE (a test's frame kept by a
+        traceback, say) Python runs finalizers in arbitrary order, and pgr_*_destroy on an object of a destroyed context walks
+        freed memory (round 6: the HIP "invalid value" that surfaced in an unrelated scan began there).  Their close() looks here
+        first: a destroyed context has released every device block of its objects already (pgr_ctx_destroy), only the small host
+        structs stay behind."""
+        return bool(self._h)
+
     def __del__(self):
         try:
             self.close()

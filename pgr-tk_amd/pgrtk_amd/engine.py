@@ -148,7 +148,8 @@ class Batch:
 
     def close(self):
         if self._h:
-            lib().pgr_batch_destroy(self._h)
+            if getattr(getattr(self, "ctx", None), "alive", True):  # (_ffi.Context.alive: not on an object of a destroyed context)
+                lib().pgr_batch_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -218,7 +219,8 @@ class Shmmrs:
 
     def close(self):
         if self._h:
-            lib().pgr_shmmrs_destroy(self._h)
+            if getattr(getattr(self, "ctx", None), "alive", True):  # (_ffi.Context.alive: not on an object of a destroyed context)
+                lib().pgr_shmmrs_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -289,7 +291,8 @@ class Pipe:
 
     def close(self):
         if self._h:
-            lib().pgr_pipe_destroy(self._h)
+            if getattr(getattr(self, "ctx", None), "alive", True):  # (_ffi.Context.alive: not on an object of a destroyed context)
+                lib().pgr_pipe_destroy(self._h)
             self._h = C.c_void_p()
             self._keep = []
 
@@ -566,7 +569,8 @@ class Index:
 
     def close(self):
         if self._h:
-            lib().pgr_index_destroy(self._h)
+            if getattr(getattr(self, "ctx", None), "alive", True):  # (_ffi.Context.alive: not on an object of a destroyed context)
+                lib().pgr_index_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

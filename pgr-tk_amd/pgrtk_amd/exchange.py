@@ -113,7 +113,8 @@ class AbiExchange:
     def close(self):
         from ._ffi import lib
         if self._h:
-            lib().pgr_exchange_destroy(self._h)
+            if getattr(getattr(self, "ctx", None), "alive", True):  # (_ffi.Context.alive: not on an object of a destroyed context)
+                lib().pgr_exchange_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

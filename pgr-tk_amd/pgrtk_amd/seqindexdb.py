@@ -237,7 +237,8 @@ class SeqIndexDB:
 
     def close(self):
         if getattr(self, "_ix", None):
-            lib().pgr_index_destroy(self._ix)
+            if getattr(getattr(self, "ctx", None), "alive", True):  # (_ffi.Context.alive: not on an object of a destroyed context)
+                lib().pgr_index_destroy(self._ix)
             self._ix = C.c_void_p()
 
     def __del__(self):
