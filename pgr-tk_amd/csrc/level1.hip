@@ -1069,11 +1069,14 @@ __global__ void tile_desc_kernel(L1Args a) {
 }
 
 void launch_mark_invalid_tiles(hipStream_t st, const L1Args &a);
-void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv) {
+void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv, bool known_clean) {
     if (a.n_tiles == 0) return;
     const uint32_t n_desc = a.n_tiles > a.n_contigs ? a.n_tiles : a.n_contigs;  // (>= 8: a tile per non-empty contig ... or not)
     hipLaunchKernelGGL(tile_desc_kernel, dim3(((n_desc > 8 ? n_desc : 8) + 255) / 256), dim3(256), 0, st, a);
-    {   // flags tiles with a non-ACGT byte in reach (the tile kernel skips them), records every tile's last valid position
+    // known_clean: the host packer has counted the batch's non-ACGT bytes and found none, AND the caller never runs islands on this
+    // pass (the query path's level-1 form: what the tile kernel flags goes back to the shimmer pipeline, which plans again) -- no tile
+    // can be flagged here and nobody reads the last-valid table
+    if (!known_clean) {   // flags tiles with a non-ACGT byte in reach (the tile kernel skips them), records every tile's last valid position
         L1Args am = a;
         am.tile_lv = tile_lv;
         launch_mark_invalid_tiles(st, am);

@@ -162,7 +162,7 @@ struct L1Args {
     // before the exact-machine chunks run: their k-mer look-back crosses a multi-Mbp run of N in one step with it.
     uint64_t *tile_lv;
 };
-void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv);  // tile descriptors, flags of tiles with a non-ACGT byte in reach (tile_lv: [n_tiles] last valid positions)
+void launch_level1_pre(hipStream_t st, const L1Args &a, uint64_t *tile_lv, bool known_clean = false);  // tile descriptors, flags of tiles with a non-ACGT byte in reach (tile_lv: [n_tiles] last valid positions)
 void launch_level1_tiles(hipStream_t st, const L1Args &a);                    // the tiles (and the contigs' tails), behind launch_level1_pre
 void launch_level1_tails(hipStream_t st, const L1Args &a);
 constexpr uint32_t LDS_GRANULE = 512;  // gfx950 hands out LDS in 512-byte units

@@ -807,6 +807,8 @@ struct ShmmrJob {
     // flags and enqueues the islands and THE list stage (or, for once not flagged, the list stage alone).
     bool stage1_only = false;
     bool list_pending = false;  // decide(): the pass that just ended had no list stage
+    bool no_islands_pass = false;  // stage 1 for a consumer that declines what the tile kernel flags (the query path's level-1 form): a batch
+                                   // the host packer found clean needs no look at its validity plane
     uint32_t lds_match = 0;                  // sf != sb: LDS per workgroup of the tile kernel; the back stream's kernels take as much or none
     // a consumer of the result that does not want to wait for the host: its kernels go behind stage 4 (stream, list, offsets,
     // capacity of the list, device address of the true count); a repeated pass calls it again
@@ -1110,7 +1112,7 @@ int ShmmrJob::stage1() {
     flags_prefetched = false;
     early_islands.reset();
     if (tiled && bases_tiled) {
-        launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p);
+        launch_level1_pre(st, a, (uint64_t *)ctx->ws_tile_lv.p, no_islands_pass && !b->h_n_invalid.empty() && !b->host_saw_invalid);
         const bool pre = b->host_saw_invalid && !b->h_n_invalid.empty() && n_tiles && !ctx->opt.no_pre_islands;
         if (pre) {
             const size_t tb = scan_max_temp_bytes(n_tiles);
@@ -1642,7 +1644,10 @@ int level1_stage_and_view(ShmmrJob &job, QfLevel1View &v, bool *taken) {
     if ((rc = job.plan())) return rc;
     if (!job.serial.empty() || !job.bases_tiled) return PGR_OK;
     PGR_HIP(ctx, hipEventRecord(ctx->ev[0], job.sf));
-    if ((rc = job.stage1())) return rc;
+    job.no_islands_pass = true;
+    rc = job.stage1();
+    job.no_islands_pass = false;  // (a chained pass of the same job object -- the pipe's fall-through -- is an ordinary one)
+    if (rc) return rc;
     v.l1 = job.a.out;
     v.seg_off = job.a.seg_off;
     v.seg_cnt = job.a.seg_cnt;
