@@ -42,3 +42,37 @@ def test_synth_generator_definition(oracle):
     assert (abs(counts - 25000) < 1000).all()
     # prefix property: a shorter contig is a prefix of a longer one
     assert np.array_equal(oracle.synth_contig(2, 7, 1000), a[:1000])
+
+
+def test_run_length_form_of_the_reduction_equals_the_window_form(oracle):
+    """The list stage inside a wavefront (csrc/small.hip: reduce_keep, csrc/query_fused.hip: qf_reduce_keep -- the level-1 form of the
+    per-query kernel, round 6) decides reduce_shmmr (shmmrutils.rs:359-415, no padding) element by element: an element survives iff at
+    least r consecutive list elements including itself are >= it (the run of such neighbours to its left + the run to its right + 1).
+    That is the window form of closed_form.reduce_closed_form -- "a minimum, ties included, of some full r-window" -- restated; both
+    against the oracle's reduce_shmmr on lists with many ties, for every r the spec allows, lists shorter than r included."""
+    import closed_form as CF
+    rng = np.random.default_rng(7)
+
+    def run_length_form(x, r):
+        n = len(x)
+        keep = np.zeros(n, dtype=bool)
+        for k in range(n):
+            run, left, right = 1, True, True
+            for d in range(1, r):
+                left = left and k - d >= 0 and x[k - d] >= x[k]
+                right = right and k + d < n and x[k + d] >= x[k]
+                run += int(left) + int(right)
+            keep[k] = run >= r
+        return keep
+
+    for r in range(2, 13):
+        for n in (0, 1, r - 1, r, r + 1, 40, 333):
+            for alphabet in (3, 50, 1 << 40):
+                a = np.zeros(n, dtype=CF.MM128)
+                a["x"] = (rng.integers(0, alphabet, n).astype(np.uint64) << np.uint64(8)) | np.uint64(56)
+                a["y"] = (np.arange(n, dtype=np.uint64) * np.uint64(37)) << np.uint64(1)
+                want = CF.reduce_closed_form(a, r, False)
+                got = a[run_length_form(a["x"], r)]
+                assert np.array_equal(want["x"], got["x"]) and np.array_equal(want["y"], got["y"]), (r, n, alphabet)
+                ref = oracle.reduce_shmmr(a, r, False)
+                assert np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"]), (r, n, alphabet)
