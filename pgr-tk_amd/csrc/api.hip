@@ -43,7 +43,7 @@ const std::vector<OptionName> &option_names() {
         {"debug", &O::debug}, {"debug_times", &O::debug_times}, {"gpu_pack", &O::gpu_pack}, {"no_small_path", &O::no_small_path},
         {"no_pipeline", &O::no_pipeline}, {"early_sync_bp", &O::early_sync_bp}, {"index_full_sort", &O::index_full_sort},
         {"index_two_key_sort", &O::index_two_key_sort}, {"no_fused_query", &O::no_fused_query}, {"direct_query_result", &O::direct_query_result}, {"direct_query_results_delivered", &O::direct_query_results_delivered}, {"direct_query_lds_kb", &O::direct_query_lds_kb},
-        {"no_query_chaining", &O::no_query_chaining}, {"no_query_level1", &O::no_query_level1}, {"no_query_keys", &O::no_query_keys}, {"query_global_sort", &O::query_global_sort},
+        {"no_query_chaining", &O::no_query_chaining}, {"no_query_level1", &O::no_query_level1}, {"no_query_keys", &O::no_query_keys}, {"lut_extra_bits", &O::lut_extra_bits}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s}, {"exchange_rccl_world1", &O::exchange_rccl_world1}, {"debug_poison", &O::debug_poison}, {"debug_inject_stale_segments", &O::debug_inject_stale_segments},
         {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},

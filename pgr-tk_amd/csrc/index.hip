@@ -636,7 +636,10 @@ extern "C" int pgr_index_finalize(pgr_ctx *ctx, pgr_index *ix) {
         PGR_HIP(ctx, hipStreamSynchronize(st));
         PGR_HIP(ctx, hipMemcpyAsync(&h99, &ix->recs[k99].h0, 8, hipMemcpyDeviceToHost, st));
         PGR_HIP(ctx, hipStreamSynchronize(st));
-        const unsigned bits = std::min(22u, std::max(4u, bits_for(n_keys) - 2));
+        // (lut_extra_bits: round 6 -- window minima crowd towards small hashes, so the equal-width buckets near zero hold several
+        // times the average; profiles/r06_query/lut_bits.txt)
+        const unsigned xb = (unsigned)std::max<int64_t>(0, std::min<int64_t>(4, ctx->opt.lut_extra_bits));
+        const unsigned bits = std::min(22u + xb, std::max(4u, bits_for(n_keys) - 2 + xb));
         const unsigned hb = bits_for(h99 + 1);  // bits of the largest bucketed h0
         ix->lut_bits = bits;
         ix->lut_shift = hb > bits ? hb - bits : 0;

@@ -79,6 +79,7 @@ struct pgr_ctx {
         int64_t direct_query_results_delivered = 0;  // (a counter, read with pgr_ctx_get_option: batches whose result the single-pass kernel wrote)
         int64_t direct_query_result = 0;     // experiment: that kernel writes the host's result block itself (single pass; measured slower)
         int64_t no_query_chaining = 0;   // do not enqueue the query stage behind the shimmer pipeline
+        int64_t lut_extra_bits = 0;      // pgr_index_finalize: the bucket table over the keys gets 2^this times as many buckets (0 .. 4)
         int64_t no_query_keys = 0;       // pgr_index_finalize builds no per-query-kernel key table (pgr_index.h: qkeys), for A/B
         int64_t no_query_level1 = 0;     // query batches never take the level-1 form of the per-query kernel (tile kernel + per-query kernel, no list stage), for A/B
         int64_t query_global_sort = 0;   // group the hits of a batch with the global radix sort
