@@ -234,6 +234,20 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
     t_py, _, r = med3(lambda: ix.query_hps_resident_raw(qb, 0.025))
     t_res, reps_res, _ = med3(lambda: ix.time_query_resident(qb, 0.025)[0])
     prof = ctx.last_query_prof()
+    # the same batch through the chained form of the per-query kernel (round 5's path: the shimmer pipeline's list stage over the whole
+    # batch, then the per-query kernel; context option no_query_level1), same context, same index, result compared array for array
+    chained_form = None
+    try:
+        with ctx.options(no_query_level1=1):
+            _, _, r_ch = med3(lambda: ix.query_hps_resident_raw(qb, 0.025))
+            t_ch, reps_ch, _ = med3(lambda: ix.time_query_resident(qb, 0.025)[0])
+            p_ch = int(ctx.last_query_prof()["path"])
+        chained_form = {"query_s": t_ch, "query_s_reps": reps_ch, "path_id": p_ch,
+                        "same_result_as_the_level1_form": bool(all(np.array_equal(r[k], r_ch[k]) for k in ("q_off", "t_sid", "t_off", "c_score", "c_off", "hps"))),
+                        "what": "the same batch with context option no_query_level1: 19 launches instead of 8 (profiles/r05_query vs r06_query)"}
+        del r_ch
+    except Exception as ex:  # noqa: BLE001
+        chained_form = {"error": repr(ex)}
     # (b) the drop-in boundary: host ASCII in, host chains out
     _, _, r2 = med3(lambda: ix.query_hps_raw(qs, 0.025))
     t_host, reps_host, _ = med3(lambda: ix.time_query_host(qs, 0.025)[0])
@@ -313,6 +327,7 @@ def query_bench(P, ctx, batch, spec, args, contig_ids):
         "inputs": "queries resident in HBM as 2-bit planes when the clock starts (pgr_query_hps_resident); the clock stops "
                   "when the chains are in host memory and the result has been released again (C entry point, no numpy copies)",
         "python_binding_s": t_py,
+        "chained_form": chained_form,
         "pipelined": piped,
         "pcie_inclusive": {"query_s": t_host, "query_s_reps": reps_host, "queries_per_s": nq / t_host,
                            "hit_pairs_per_s": n_hps / t_host, "same_result_as_resident": bool(same),
