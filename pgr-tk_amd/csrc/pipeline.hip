@@ -334,9 +334,17 @@ int IslandRun::process_round() {
             if (L - is.E < 2ull * tc) is.E = L;
             rebuild.push_back(h.island);
         };
+        // A probe proves TWO things or the island grows: the exact machine's state at E is what a warm-up gives (so nothing in front
+        // of the warm-up window reaches E), AND that state is the regular regime the closed form of the tile behind E assumes --
+        // mdist within the window.  A stuck machine (mdist beyond w - 1: no rescan can fire, shmmrutils.rs:505-514) whose cause lies
+        // INSIDE the warm-up window is reproduced by the probe's warm-up exactly, the states compare equal, and the tile behind E
+        // would be computed as if a minimizer were due every w positions: found by fuzz_parity seed 7123218 (round 6) -- a palindromic
+        // (AT)n stretch in the last tile of an island around a run of N, a tile the tile kernel skips and therefore never flags for
+        // its palindromes; the machine stayed stuck for 540 positions into the next tile.
+        auto stuck = [&](const ChunkState &t) { return !a.sketch && t.mdist > (uint64_t)(a.w - 1); };
         if (!relay) {  // the round-3 scheme (A/B): every seam against whatever the chunk in front produced last
             if (h.probe) {
-                if (has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) grow();
+                if (has_prev && (memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0 || stuck(s_out[i - 1]))) grow();
             } else if (!is.whole && h.d.cs > is.B && has_prev && memcmp(&s_in[i], &s_out[i - 1], sizeof(ChunkState)) != 0) {
                 h.d.override_state = 1;
                 h.d.in_state = s_out[i - 1];
@@ -350,7 +358,7 @@ int IslandRun::process_round() {
         if (h.probe) {
             if (!has_prev) h.final = true;
             else if (ch[i - 1].final && !h.final) {
-                if (memcmp(&s_in[i], &ch[i - 1].t_out, sizeof(ChunkState)) != 0) {
+                if (memcmp(&s_in[i], &ch[i - 1].t_out, sizeof(ChunkState)) != 0 || stuck(ch[i - 1].t_out)) {
                     if (ctx->opt.debug) {
                         const ChunkState &p = s_in[i], &q = ch[i - 1].t_out;
                         fprintf(stderr, "[pgr] probe mismatch contig %u E=%llu: min_x %llx/%llx min_y %llx/%llx mdist %llu/%llu "

@@ -345,3 +345,42 @@ def test_query_through_a_repeat_heavy_keys(oracle, gpu_ctx, max_target):
         n_targets += len(ref)
     assert gpu_ctx.last_query_prof()["n_signatures"] > 300
     assert n_targets >= 100
+
+
+def test_a_probe_does_not_accept_a_stuck_machine(oracle, gpu_ctx):
+    """Round 6, found by tools/fuzz_parity.py seed 7123218 (1 of 37 300 cases; the defect dates from the islands of round 4): an island
+    around a run of N ends at the end of its last flagged tile, where a probe -- the machine warmed up over the 256 positions in front
+    -- must show the exact machine back in the regular regime the next tile's closed form assumes.  A palindromic (AT)n stretch near
+    the END of that tile (a tile the tile kernel skips, so nobody flags its palindromes) leaves the machine STUCK (mdist beyond w - 1,
+    shmmrutils.rs:505-514) beyond the tile's end; the probe's warm-up window holds the stretch as well, reproduces the stuck state
+    exactly, the states compare equal -- and the library emitted closed-form minimizers where the reference emits none for hundreds of
+    positions.  A probe now also asks for mdist <= w - 1, else the island grows.  The fuzz case itself (regenerated from its seed) and
+    a family built on purpose: a run of N that ends inside a tile, 40-80 x (AT) ending 60-400 positions in front of that tile's end."""
+    import os
+    import sys
+    import pgrtk_amd as P
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import fuzz_case
+    spec_t, padding, seqs, rids, _ = fuzz_case.gen(7123218, 2_000_000)
+    assert spec_t == (48, 56, 4, 12, False) and len(seqs[16]) == 79076
+    cases = [(spec_t[:4], seqs[16]), ((48, 56, 1, 0), seqs[16])]
+    rng = np.random.default_rng(81)
+    for w, k in ((48, 56), (80, 56), (31, 24)):
+        tc = ((4096 - 2 * (w - 1)) // 64) * 64
+        for _ in range(12):
+            t_end = int(rng.integers(4, 9)) * tc  # the end of the tile in which the run of N ends
+            n_lo = int(rng.integers(2000, t_end - tc - 500))
+            n_hi = t_end - tc + int(rng.integers(50, tc - 1200))  # the run ends inside the tile [t_end - tc, t_end)
+            at = b"AT" * int(rng.integers(40, 81))
+            at_end = t_end - int(rng.integers(60, 400))
+            body = bytearray(seqgen.rnd(rng, t_end + 3 * tc))
+            body[n_lo:n_hi] = b"N" * (n_hi - n_lo)
+            body[at_end - len(at):at_end] = at
+            cases.append(((w, k, 4, 12), bytes(body)))
+            cases.append(((w, k, 1, 0), bytes(body)))
+    for spec4, s in cases:
+        ref = oracle.sequence_to_shmmrs(0, s, oracle.spec(*spec4), False)
+        for opts in ({}, {"no_small_path": 1, "early_sync_bp": 0}):
+            with gpu_ctx.options(**opts):
+                got = P.sequence_to_shmmrs_batch([s], P.make_spec(*spec4), ctx=gpu_ctx)[0]
+            assert len(ref) == len(got) and np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"]), (spec4, len(s), opts)
