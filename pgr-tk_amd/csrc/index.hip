@@ -304,9 +304,19 @@ int pgr::index_grow_raw(pgr_ctx *ctx, pgr_index *ix, uint64_t need) {
     pgr_frag_rec *np = nullptr;
     int rc = ctx->dmalloc((void **)&np, cap * sizeof(pgr_frag_rec));
     if (rc) return rc;
-    if (ix->n_raw) {
-        hipError_t e = hipMemcpyAsync(np, ix->raw, ix->n_raw * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    {
+        // The append block is written by whatever stream the caller's jobs run on (the context's stream, a pipe's back stream for
+        // commits and direct placement, its fix stream for second passes) -- the allocator has ordered it, and under debug_poison
+        // filled it, for ONE stream: the one it was asked for.  The old records are copied on that stream and the host waits for
+        // it, ALWAYS: when this returns the block's previous life (other streams' work the allocator made this stream wait for)
+        // and the fill are over, and any stream may write it.  (Round 6, fuzz_pipe under debug_poison: the first commit into a
+        // fresh block has no old records to copy, so nothing was waited for, and the fill -- queued on the context's stream behind
+        // a tile kernel -- landed on top of the back stream's commit copy: a job's records replaced by 0xFF, 4 runs in 12.
+        // Without the fill the same gap is a block's previous life racing its first writer on another stream.)
+        hipStream_t st = ctx->alloc_stream ? ctx->alloc_stream : ctx->stream;
+        hipError_t e = hipSuccess;
+        if (ix->n_raw) e = hipMemcpyAsync(np, ix->raw, ix->n_raw * sizeof(pgr_frag_rec), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
         if (e != hipSuccess) {
             ctx->dfree(np);
             return ctx->fail(PGR_ERR_DEVICE, hipGetErrorString(e));

@@ -82,3 +82,16 @@ def test_fuzz_pipe_200_cases_with_poison_on():
                              env={"PGR_DEBUG_POISON": "1"}, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert re.search(r"\b0 failures", r.stdout) or re.search(r"failures[:=]? *0\b", r.stdout), r.stdout[-800:]
+
+
+def test_first_commit_into_a_fresh_append_block_is_ordered_behind_the_block_s_fill():
+    """Round 6, found by 6 000 fuzz_pipe cases under poison (seeds 9200023 and 9204253; timing dependent: 4 runs in 12): the first commit
+    of a pipe's records into a FRESH append block of an index (csrc/index.hip: index_grow_raw with no old records to copy) waited for
+    nothing -- the block had been ordered, and under debug_poison filled, on the context's stream, the commit copy ran on the back
+    stream, and the fill landed on top of the copy: a job's records replaced by 0xFF in the finalized index.  (Without the fill the same
+    gap lets a block's previous life race its first writer on another stream.)  index_grow_raw now copies on the stream the allocator
+    was asked for and always waits for it.  The 24 cases that led up to the first failing seed, four times over."""
+    for _ in range(4):
+        r = procutil.run_bounded([sys.executable, os.path.join(ROOT, "tools", "fuzz_pipe.py"), "24", "9200000"], timeout=200,
+                                 env={"PGR_DEBUG_POISON": "1"})
+        assert r.returncode == 0 and "0 failures" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])

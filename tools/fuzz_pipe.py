@@ -47,7 +47,9 @@ def one_case(seed, max_len, ctx, pool):
     ix = P.Index(spec, ctx=ctx) if to_index else None
     if ix is not None and rng.random() < 0.5:
         ix.reserve(int(sum(len(q) for s in sets for q in s) * 0.02) + 1024)
-    bufs = [torch.zeros((max(sum(len(q) for q in s) // 8 + 64, 64), 5), dtype=torch.int64, device="cuda:0") for s in sets] if not to_index else None
+    # (a caller's buffer that is too small is an error of the CALLER -- seed 9001412 of round 6's campaign: "output buffer too small for
+    # the pair records" from a dense spec and a buffer of a pair per 8 bases --: a pair per base + slack)
+    bufs = [torch.zeros((sum(len(q) for q in s) + 64, 5), dtype=torch.int64, device="cuda:0") for s in sets] if not to_index else None
     got = []
     sid0 = 0
     sids = []
@@ -89,7 +91,14 @@ def one_case(seed, max_len, ctx, pool):
         order = np.lexsort((exp["frg_id"], exp["sid"], exp["h1"], exp["h0"]))
         exp = exp[order]
         if len(rec) != len(exp) or any(not np.array_equal(exp[f], rec[f]) for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient")):
-            return "%s: the finalized index differs (%d vs %d records)" % (tag, len(rec), len(exp))
+            what = ""
+            if len(rec) == len(exp):  # which fields, which rows, what stands there instead
+                bad = {f: int((exp[f] != rec[f]).sum()) for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient") if (exp[f] != rec[f]).any()}
+                rows = np.where(np.any([exp[f] != rec[f] for f in ("h0", "h1", "frg_id", "sid", "bgn", "end", "orient")], axis=0))[0]
+                what = "; fields %s; rows %s; got %s expected %s; pairs per job %s" % (
+                    bad, rows[:8].tolist(), [tuple(int(rec[f][i]) for f in ("h0", "h1", "sid", "frg_id", "bgn", "end")) for i in rows[:3]],
+                    [tuple(int(exp[f][i]) for f in ("h0", "h1", "sid", "frg_id", "bgn", "end")) for i in rows[:3]], [n for _, n in got])
+            return "%s: the finalized index differs (%d vs %d records)%s" % (tag, len(rec), len(exp), what)
     return None, sum(len(q) for s in sets for q in s)
 
 
