@@ -115,6 +115,10 @@ const char *pgr_version(void);
  *                             there, so it is generous (1800; 0 = wait for ever).  A value that is not a number leaves a numeric
  *                             option at its default (a line on stderr says so).
  *   no_island_relay           exact islands: the round-3 seam correction (one seam per host round), for A/B timing
+ *   island_settle             > 0: positions behind an array of palindromic k-mers at which its island ends (default 2 w + k + 64 rounded
+ *                             up to 64; a machine that arrives there stuck moves the end on itself), for A/B
+ *   no_sub_tile_islands       exact islands made of whole tiles only (rounds 3-5), for A/B: by default an island around palindromic
+ *                             k-mers begins and ends inside the tiles the tile kernel reports them in
  *   no_short_tiles            batches of short contigs (mean length <= 2048): 4096-position tiles all the same, for A/B timing
  *   no_pre_islands            never list the islands around non-ACGT bytes while the tile kernel is still running, for A/B timing
  *   no_early_islands          ... never start their first round before the tile kernel's flags are seen, for A/B timing

@@ -46,7 +46,7 @@ const std::vector<OptionName> &option_names() {
         {"no_query_chaining", &O::no_query_chaining}, {"no_query_level1", &O::no_query_level1}, {"no_query_keys", &O::no_query_keys}, {"lut_extra_bits", &O::lut_extra_bits}, {"query_global_sort", &O::query_global_sort},
         {"fused_query_hits", &O::fused_query_hits}, {"exchange_timeout_s", &O::exchange_timeout_s},
         {"exchange_collective_timeout_s", &O::exchange_collective_timeout_s}, {"exchange_rccl_world1", &O::exchange_rccl_world1}, {"debug_poison", &O::debug_poison}, {"debug_inject_stale_segments", &O::debug_inject_stale_segments},
-        {"no_island_relay", &O::no_island_relay}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
+        {"no_island_relay", &O::no_island_relay}, {"no_sub_tile_islands", &O::no_sub_tile_islands}, {"island_settle", &O::island_settle}, {"no_short_tiles", &O::no_short_tiles}, {"no_pre_islands", &O::no_pre_islands}, {"no_early_islands", &O::no_early_islands}, {"no_early_merge", &O::no_early_merge},  {"early_islands_in_stream", &O::early_islands_in_stream}, {"island_chunk_min", &O::island_chunk_min},
         {"back_priority", &O::back_priority}, {"no_fix_stream", &O::no_fix_stream}, {"no_stage1_only", &O::no_stage1_only}, {"pipe_staged_records", &O::pipe_staged_records},
         {"lds_match", &O::lds_match}, {"no_direct_h2d", &O::no_direct_h2d},
         {"pipe_small_list", &O::pipe_small_list}, {"pipe_persistent_list", &O::pipe_persistent_list}, {"front_priority", &O::front_priority}};

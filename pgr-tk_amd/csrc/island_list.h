@@ -28,19 +28,36 @@ struct Island {
     // chunk in front (one seam per round), so such islands keep long chunks; islands around non-ACGT bytes verify at the
     // first try and are cut short for parallelism
     bool pal = true;
+    // Round 6: an island may begin and end INSIDE a tile the tile kernel has computed (a tile whose only flag is the palindromic
+    // k-mer: its elements in front of B / from E on are exact, see list_islands_from_flags).  cutB: the elements of tile B / tc below
+    // position B stay that tile's own; cutE: those of tile E / tc at or above E do (E < the contig's length).  Neither set: the island
+    // is made of whole tiles, as before.
+    bool cutB = false, cutE = false;
+    // cutE: how far the island's last chunk may move E on while its machine is stuck (ChunkDesc::ext_limit; 0: not at all) -- the end
+    // of the clean tile behind the last flagged one, where an island of whole tiles ends
+    uint64_t ext_limit = 0;
 };
 
 // tf is modified: tiles deep inside a run of non-ACGT bytes end up 0 (their segment ranges go to gap_segs).
 inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, const uint32_t *h_len, uint32_t tc, bool sketch,
                                     const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, const uint16_t *pal,
                                     std::vector<Island> &islands, std::vector<uint32_t> &gap_segs, uint32_t c_begin = 0,
-                                    uint32_t c_end = 0xFFFFFFFFu) {
+                                    uint32_t c_end = 0xFFFFFFFFu, uint32_t cut_margin = 0, uint32_t cut_settle = 0) {
     // (contigs [c_begin, min(c_end, n)): islands never span contigs, so ranges of contigs can be listed side by side and the
     // lists put behind one another)
     // pal (or NULL): for a tile with flag bit 0, first | last << 8 block of 64 core positions that holds a palindromic k-mer
     // (0: in front of the core, >= tc / 64: behind it).  ISLAND_SETTLE: positions of regular sequence behind the last one
     // within which a machine that came out of the array stuck has practically always found back (a push at or below the stuck
     // minimum: one in ~w + 1 pushes does; the probe at the island's end checks it and the island grows if not)
+    // cut_margin (0: islands of whole tiles): positions of regular sequence kept in front of the first palindromic block of an
+    // island that begins inside its first tile -- a multiple of 64, >= w + k + 64: an element the tile keeps (position < B) has every
+    // window it belongs to, and the k-mers of those windows, in front of the first skipped push; the machine that starts 256
+    // positions in front of B warms up on regular sequence (the tile in front is clean, this tile is up to its first block).
+    // cut_settle (with cut_margin; 0: ISLAND_SETTLE): positions behind the last palindromic block at which an island that ends
+    // inside a tile is to end -- a multiple of 64, >= 2 w + k + 64: the ring holds nothing from in front of the array any more,
+    // a rescan since has seen only pushes from behind it, and a machine that is NOT stuck there is the regular one; a machine that
+    // IS stuck moves the end on itself, block by block, until a push frees it (ChunkDesc::ext_limit) -- so the settling distance
+    // need not cover the stuck machines' tail (3 of 2 400 islands at 1408 positions: the tail falls off like 1 / distance).
     constexpr uint32_t ISLAND_SETTLE = 1408;
     struct FT {
         uint32_t t;
@@ -128,16 +145,56 @@ inline void list_islands_from_flags(uint32_t n, const uint32_t *tile_first, cons
             // (the clean neighbour is 3904 more positions through the machine for an array of perhaps 100: where the tile kernel has
             // said where the last palindromic k-mer lies, and ISLAND_SETTLE positions of the flagged tiles follow it, they are the room)
             bool neighbour = tb + 1 < nt && any_pal;
-            if (neighbour && pal) {
+            uint64_t cut_b = 0, cut_e = 0;  // (0: no cut)
+            if (pal && cut_margin) {
+                // Sub-tile ends.  Left: the group's first tile has no flag but the palindromic one -- the tile kernel computed it, and
+                // what it selected below (first palindromic block - cut_margin) is exact.  Right: the group's last tile is the one with
+                // the last palindromic k-mer and has no other flag -- ISLAND_SETTLE positions behind that block the machine has
+                // practically always found back (the probe at E decides), and from E on the elements of the tile E lies in -- this one
+                // or its clean neighbour, both computed -- are exact.
+                // (an array within cut_margin of its tile's start: B lies in the tile in front -- clean, or the group would begin there;
+                // a palindromic k-mer in FRONT of the core, block 0 of the report, would have flagged that tile)
+                if (F[i].f == 1) {
+                    const uint64_t first = (uint64_t)ta * tc + (uint64_t)(pal[t0 + ta] & 0xFF) * 64;
+                    if (first > cut_margin && tc > 2 * cut_margin) cut_b = first - cut_margin;
+                    if (cut_b + cut_margin >= L) cut_b = 0;  // (a block index beyond the contig's end: not from this tile kernel)
+                    if (cut_b % tc == 0) cut_b = 0;          // (exactly the tile's start: an island of whole tiles on this side)
+                }
+                if (neighbour && last_pal == j && F[j].f == 1) {
+                    const uint32_t hi_blk = (uint32_t)(pal[t0 + tb] >> 8);
+                    if (hi_blk < tc / 64) cut_e = (uint64_t)tb * tc + (uint64_t)(hi_blk + 1) * 64 + (cut_settle ? cut_settle : ISLAND_SETTLE);
+                    if (cut_e + 2ull * tc > L) cut_e = 0;  // (near the contig's end: the island takes the tail, as before)
+                    if (cut_e / tc > (uint64_t)tb + 1) cut_e = 0;    // (tiles shorter than the settling distance: E must lie in this tile or its clean neighbour)
+                }
+                if (cut_e) neighbour = false;
+            } else if (neighbour && pal) {
                 const uint32_t hi_blk = (uint32_t)(pal[t0 + F[last_pal].t] >> 8);
                 if (hi_blk < tc / 64 && (uint64_t)(tb - F[last_pal].t) * tc + (uint64_t)(tc / 64 - 1 - hi_blk) * 64 >= ISLAND_SETTLE) neighbour = false;
             }
             if (neighbour) ++tb;
             Island is{c, (uint64_t)ta * tc, tb + 1 == nt ? L : std::min<uint64_t>(L, (uint64_t)(tb + 1) * tc), false, false};
             is.pal = any_pal;
-            if (L - is.E < 2ull * tc) is.E = L;  // the contig's tail region joins the island
+            if (cut_b) {
+                is.B = cut_b;
+                is.cutB = true;
+            }
+            if (cut_e) {
+                is.E = cut_e;
+                is.cutE = true;
+                is.ext_limit = std::min<uint64_t>((uint64_t)(tb + 2) * tc, (L - 2ull * tc) / 64 * 64);
+                if (is.ext_limit <= is.E) is.ext_limit = 0;
+            }
+            if (L - is.E < 2ull * tc) {  // the contig's tail region joins the island
+                is.E = L;
+                is.cutE = false;
+                is.ext_limit = 0;
+            }
             if (!islands.empty() && islands.back().contig == c && islands.back().E + tc >= is.B) {
-                islands.back().E = std::max(islands.back().E, is.E);
+                if (is.E > islands.back().E) {
+                    islands.back().E = is.E;
+                    islands.back().cutE = is.cutE;
+                    islands.back().ext_limit = is.ext_limit;
+                }
                 islands.back().pal = islands.back().pal || is.pal;
             } else {
                 islands.push_back(is);

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                                                           ChunkState *__restrict__ st_in,
                                                           ChunkState *__restrict__ st_out,
                                                           uint32_t *__restrict__ status, uint64_t *__restrict__ rings,
-                                                          uint64_t *__restrict__ info) {
+                                                          uint64_t *__restrict__ info, const uint64_t *__restrict__ info_round) {
     __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
     const uint64_t t_begin = wall_clock64();
     const uint32_t lane = threadIdx.x;
@@ -469,7 +469,13 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     // branch 2 enabled for w+k <= pos < Lb; Rust usize arithmetic wraps in release builds
     const uint64_t Lb = (uint64_t)L - (uint64_t)w + (uint64_t)k;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
-    const long long cs = (long long)cd.cs, ce = (long long)cd.ce;
+    long long cs = (long long)cd.cs, ce = (long long)cd.ce;
+    if (cd.cs_from != 0xFFFFFFFFu && info_round) {
+        // the probe of an island that ends inside a tile: where the island's last chunk (an earlier launch of this round) has ended
+        const long long moved = (long long)(info_round[4 * (size_t)cd.cs_from + 3] >> 40) * 64;
+        cs += moved;
+        ce += moved;
+    }
 
     s_rx[lane] = U64MAX;
     s_rx[lane + 64] = U64MAX;
@@ -557,7 +563,9 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     uint64_t n_out = 0;
     uint32_t stat = 0;
 
-    const long long drain_end = (long long)cd.drain_end > ce ? (long long)cd.drain_end : ce;
+    long long drain_end = (long long)cd.drain_end > (long long)cd.ce ? (long long)cd.drain_end + (ce - (long long)cd.ce) : ce;
+    const long long ext_limit = a.sketch ? 0 : (long long)cd.ext_limit;
+    uint64_t n_ext = 0;  // blocks of 64 positions added behind cd.ce
     const uint64_t emit_lo = cd.emit_lo_pos;
     bool out_captured = false;
     bool any_push = false;  // a position of the by-step range [cs, ce) was pushed
@@ -633,6 +641,15 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     uint32_t n_steps = 0;  // loop iterations (diagnostics: status bits 8..31)
     for (long long base = pk; base < drain_end; base += 64) {
         ++n_steps;
+        if (base == ce && ce + 64 <= ext_limit && mdist > (uint64_t)(w - 1)) {
+            // The island was to end here, inside a tile, and the machine arrives STUCK: it emits nothing until a push reaches down
+            // to min_mer (shmmrutils.rs:516-520) -- the tile's closed form knows nothing of that.  The island goes on, block by
+            // block; the push that frees the machine is smaller than every push since it got stuck, i.e. the minimum of its
+            // window, and from there on the machine is the regular one again (the probe at the new end verifies it).
+            ce += 64;
+            drain_end += 64;
+            ++n_ext;
+        }
         if (base >= ce && !out_captured) {
             // end of the by-step range: this is the state the next chunk / the island-end probe must match
             leave_ring();
@@ -949,7 +966,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
             info[4 * (size_t)blockIdx.x] = n_push;
             info[4 * (size_t)blockIdx.x + 1] = bmin;
             info[4 * (size_t)blockIdx.x + 2] = ((wall_clock64() - t_begin) & 0xFFFFFFFFull) | (t_lookback << 32);  // 100 MHz ticks (diagnostics)
-            info[4 * (size_t)blockIdx.x + 3] = cd.seg != 0xFFFFFFFFu ? n_out : 0ull;  // elements in the chunk's region
+            info[4 * (size_t)blockIdx.x + 3] = (cd.seg != 0xFFFFFFFFu ? n_out : 0ull) | (n_ext << 40);  // elements in the chunk's region; blocks added
         }
     }
 }
@@ -1127,10 +1144,16 @@ void launch_level1_tails(hipStream_t st, const L1Args &a) {
     if (a.n_contigs == 0) return;
     hipLaunchKernelGGL(level1_tail_kernel, dim3((a.n_contigs + TAIL_WAVES - 1) / TAIL_WAVES), dim3(64 * TAIL_WAVES), 0, st, a);
 }
-void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
+// the round's chunks [0, n_chunks - n_late), then -- a second launch -- its last n_late (probes that take their position from what
+// a chunk of the first launch reports: ChunkDesc::cs_from)
+void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks, uint32_t n_late,
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info) {
     if (n_chunks == 0) return;
-    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings, d_info);
+    const uint32_t n0 = n_chunks - n_late;
+    if (n0) hipLaunchKernelGGL(level1_chunk_kernel, dim3(n0), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings, d_info, d_info);
+    if (n_late)
+        hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_late), dim3(64), 0, st, a, d_descs + n0, d_in + n0, d_out + n0, d_status + n0, d_rings,
+                           d_info + 4 * (size_t)n0, d_info);
 }
 // the lists of the chunks that start in one tile, put together: copy i moves list[3i + 2] records from element list[3i] to
 // element list[3i + 1] of the level-1 buffer (a fresh region: source and destination never overlap); one wavefront per copy
@@ -1146,6 +1169,42 @@ __global__ void set_segs_kernel(L1Args a, const uint64_t *__restrict__ segs, uin
     a.seg_off[sg] = segs[3 * (size_t)i + 1];
     a.seg_cnt[sg] = (uint32_t)segs[3 * (size_t)i + 2];
     a.seg_cid[sg] = (uint32_t)(segs[3 * (size_t)i] >> 32);
+}
+// A tile an island of the exact machine begins or ends inside (pipeline.hip: IslandRun::finish): e[0] = segment | contig << 32, e[1] =
+// first element of the chunks' lists put together for this tile, e[2] = their count, e[3] = lo (the tile's own elements at positions
+// below lo stay in front; ~0: none do), e[4] = hi (those at positions >= hi stay behind; ~0: none), e[5] = room behind the lists.  The
+// tile's own segment is in position order (the tile kernel's ordered compaction): the kept prefix is copied right-aligned against
+// e[1], the kept suffix behind e[1] + e[2], and the tile's entry points at the contiguous result.  One wavefront per tile.
+__global__ __launch_bounds__(64) void splice_segs_kernel(L1Args a, const uint64_t *__restrict__ ents) {
+    const uint64_t *e = ents + 6 * (size_t)blockIdx.x;
+    const uint32_t sg = (uint32_t)e[0];
+    const uint64_t mid = e[1], mid_cnt = e[2], lo = e[3], hi = e[4], room = e[5];
+    const uint64_t own = a.seg_off[sg];
+    const uint32_t cnt = a.seg_cnt[sg];
+    const L1Rec *__restrict__ src = a.out + own;
+    uint32_t n_lo = 0, n_hi = 0;  // own elements below lo / at or above hi
+    for (uint32_t i = threadIdx.x; i < cnt; i += 64) {
+        const uint64_t pos = (uint64_t)(src[i].ypos >> 1);
+        n_lo += (lo != ~0ull && pos < lo) ? 1u : 0u;
+        n_hi += (hi != ~0ull && pos >= hi) ? 1u : 0u;
+    }
+    n_lo = wave_incl_sum(n_lo);
+    n_hi = wave_incl_sum(n_hi);
+    n_lo = (uint32_t)__builtin_amdgcn_readlane((int)n_lo, 63);
+    n_hi = (uint32_t)__builtin_amdgcn_readlane((int)n_hi, 63);
+    if ((uint64_t)n_hi > room) n_hi = (uint32_t)room;  // (cannot happen: one element per position at most; never write beyond the room)
+    L1Rec *__restrict__ dst_lo = a.out + (mid - n_lo), *__restrict__ dst_hi = a.out + (mid + mid_cnt);
+    for (uint32_t i = threadIdx.x; i < n_lo; i += 64) dst_lo[i] = src[i];
+    for (uint32_t i = threadIdx.x; i < n_hi; i += 64) dst_hi[i] = src[cnt - n_hi + i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a.seg_off[sg] = mid - n_lo;
+        a.seg_cnt[sg] = (uint32_t)(n_lo + mid_cnt + n_hi);
+        a.seg_cid[sg] = (uint32_t)(e[0] >> 32);
+    }
+}
+void launch_splice_segs(hipStream_t st, const L1Args &a, const uint64_t *d_ents, uint32_t n_ents) {
+    if (n_ents) hipLaunchKernelGGL(splice_segs_kernel, dim3(n_ents), dim3(64), 0, st, a, d_ents);
 }
 void launch_assemble_chunks(hipStream_t st, const L1Args &a, const uint64_t *d_copies, uint32_t n_copies, const uint64_t *d_segs, uint32_t n_segs) {
     if (n_copies) hipLaunchKernelGGL(assemble_chunks_kernel, dim3(n_copies), dim3(64), 0, st, a.out, d_copies);

@@ -94,6 +94,8 @@ struct pgr_ctx {
                                                   // segment counts (the round-5 defect, profiles/r05_fuzz/cursor_block_size_fault.txt)
         int64_t exchange_rccl_world1 = 0;  // an exchange of ONE rank goes through a real RCCL communicator all the same (default: plain copies, RCCL not loaded)
         int64_t no_island_relay = 0;     // exact islands: correct seams one per host round (the round-3 scheme), for A/B
+        int64_t island_settle = 0;       // > 0: positions behind the last palindromic block at which a sub-tile island ends (default 2 w + k + 64, rounded up to 64)
+        int64_t no_sub_tile_islands = 0; // exact islands of whole tiles only (rounds 3-5), for A/B: round 6 begins / ends them inside tiles
         int64_t island_chunk_min = 0;    // > 0: shortest chunk of the exact machine (positions; default 1024), for A/B
         int64_t early_islands_in_stream = 0;  // ... behind the tile kernel on its stream, not beside it on a stream of their own (for A/B)
         int64_t no_early_islands = 0;    // the islands around non-ACGT bytes never start their first round behind the tile kernel, before its flags are seen (for A/B)

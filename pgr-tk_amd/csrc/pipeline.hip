@@ -59,6 +59,7 @@ struct IslandRun {
         ChunkDesc d;
         size_t island;
         bool full_cap = false, probe = false, retired = false;
+        bool late = false;      // a probe behind an island's last chunk that may move its end (ChunkDesc::ext_limit)
         bool final = false;     // the state this chunk started from is known to be the true one
         ChunkState t_out;       // final: the true state at ce
         uint32_t ring_src = 0;  // final: ring slot that holds the true ring at ce (this chunk's, or the one it passed through)
@@ -74,13 +75,17 @@ struct IslandRun {
     std::chrono::steady_clock::time_point t_isl0;
     int round = 0;
     // of the round that is enqueued
-    size_t nq = 0, desc_bytes = 0;
+    size_t nq = 0, desc_bytes = 0, n_late = 0;
+    std::vector<uint32_t> q_of;  // chunk -> its index in the round (rounds with late probes)
+    size_t n_moved = 0;          // island ends a stuck machine has moved on (diagnostics)
     std::vector<ChunkDesc> descs;
     std::unique_ptr<Tmp_list> d_zr;  // (the source vector and this block live until the synchronization at the end of the round)
     bool enqueued = false;
     // round 0 may run on a stream of its own (beside the tile kernel: begin(side)): the chunk kernel touches nothing the tile
     // kernel touches -- its regions lie behind the tiles' part of the level-1 buffer, which must not have to grow for this
     hipStream_t st_chunks = nullptr;
+    size_t n_spliced = 0;  // tiles whose own elements were kept beside an island's (diagnostics)
+    bool critical = false; // the first round has been launched: what is built from here on is waited for
 
     IslandRun(pgr_ctx *ctx_, hipStream_t st_, const pgr_batch *b_, const L1Args &a_, const std::vector<Island> &islands_, const std::vector<uint32_t> &tile_first_,
               uint32_t tc_, uint64_t region_base, const std::vector<uint32_t> &empty_seg_ranges)
@@ -130,7 +135,8 @@ struct IslandRun {
     void reserve_chunks(const std::vector<Island> &isl, size_t have) {
         size_t nc = 0;
         for (const Island &is : isl) {
-            const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
+            uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
+            if (critical && a.tile_pal) CS = std::min<uint64_t>(CS, 2816);
             nc += is.whole ? 2 : (size_t)((is.E - is.B + CS - 1) / CS) + 1;
         }
         ch.reserve(have + nc + 16);
@@ -155,12 +161,24 @@ int IslandRun::build(size_t ii) {
     // (a contig that is one tile may be longer than a tile core: clamped)
     uint32_t rng[2] = {seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, is.B / tc), seg0 + (uint32_t)std::min<uint64_t>(nt, (is.E + tc - 1) / tc)};
     if (is.E >= L) rng[1] = seg0 + nt + 1;  // including the tail segment
-    zero_ranges.push_back(rng[0]);
-    zero_ranges.push_back(rng[1]);
-    zero_owner.push_back(ii);
+    // (a tile the island begins or ends inside keeps its entry -- its own elements in front of B / from E on are spliced with the
+    // chunks' lists behind the last round, finish())
+    if (is.cutB) ++rng[0];
+    if (is.cutE) rng[1] = seg0 + (uint32_t)(is.E / tc);
+    if (rng[0] < rng[1]) {
+        zero_ranges.push_back(rng[0]);
+        zero_ranges.push_back(rng[1]);
+        zero_owner.push_back(ii);
+    }
     // (round 3 kept 32 kbp chunks for islands around palindromic k-mers: their seams were corrected one per host round.  A
     // state now passes through chunks without pushes and through chunks a stuck machine cannot emit in, on the host)
-    const uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
+    uint64_t CS = (is.pal && ctx->opt.no_island_relay) ? 32768 : is.pal ? CS_PAL : CS_SHORT;
+    // (an island that begins / ends inside its tiles is an array of palindromic k-mers and the stretch behind it in which the machine
+    // finds back: a seam between the two is passed by a stuck machine more often than not -- one chunk, 30-60 steps)
+    // (islands built behind the first round's launch -- grown, merged, added by the tile kernel's flags -- run on the critical path,
+    // where a round costs what its slowest chunk costs: the long chunks that suit a round beside the tile kernel do not suit them)
+    if (critical && a.tile_pal && !ctx->opt.no_island_relay && ctx->opt.island_chunk_min <= 0) CS = std::min<uint64_t>(CS, 2816);
+    if (is.pal && a.tile_pal && is.E - is.B <= 4096 && !ctx->opt.no_island_relay) CS = std::max<uint64_t>(CS, is.E - is.B);
     const uint64_t nch = is.whole ? 1 : (is.E - is.B + CS - 1) / CS;
     for (uint64_t j = 0; j < nch; ++j) {
         HChunk h;
@@ -173,6 +191,8 @@ int IslandRun::build(size_t ii) {
         h.d.emit_lo_pos = (j == 0) ? is.B : 0;
         h.d.drain_end = h.d.ce;
         if (j + 1 == nch && is.E < L) h.d.drain_end = std::min<uint64_t>(L, is.E + 320);
+        h.d.cs_from = 0xFFFFFFFFu;
+        if (j + 1 == nch && is.E < L && is.cutE && is.ext_limit > is.E) h.d.ext_limit = is.ext_limit;
         h.d.seg = seg0 + (uint32_t)std::min<uint64_t>(nt ? nt - 1 : 0, h.d.cs / tc);
         h.d.warm = 256;
         // a long island is a long irregular stretch (a run of N, low-complexity sequence): every position emits there
@@ -195,6 +215,8 @@ int IslandRun::build(size_t ii) {
         h.d.cs = h.d.ce = h.d.drain_end = is.E;
         h.d.seg = 0xFFFFFFFFu;
         h.d.warm = 256;
+        h.d.cs_from = 0xFFFFFFFFu;
+        h.late = is.cutE && is.ext_limit > is.E;  // (goes behind the round's chunks: its position is where the last chunk ends)
         todo.push_back(ch.size());
         ch.push_back(h);
     }
@@ -205,13 +227,26 @@ int IslandRun::build(size_t ii) {
 int IslandRun::enqueue_round() {
     int rc;
     nq = todo.size();
+    // probes that take their position from a chunk of this round go last (a second launch behind the first)
+    n_late = 0;
+    for (size_t i : todo) n_late += ch[i].late ? 1 : 0;
+    if (n_late) {
+        std::stable_partition(todo.begin(), todo.end(), [&](size_t i) { return !ch[i].late; });
+        q_of.assign(ch.size(), 0xFFFFFFFFu);
+        for (size_t q = 0; q < nq; ++q) q_of[todo[q]] = (uint32_t)q;
+    }
     for (size_t q = 0; q < nq; ++q) {
         HChunk &h = ch[todo[q]];
         h.d.ring_out = h.probe ? 0xFFFFFFFFu : (uint32_t)todo[q];
         if (!h.d.override_state) h.d.ring_in = 0xFFFFFFFFu;
         h.d.region_off = next_region;
-        h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap);
+        h.d.region_cap = h.probe ? 1 : cap_of(h.d.drain_end - h.d.cs, h.full_cap) + (h.d.ext_limit ? 128 : 0);
         next_region += h.d.region_cap;
+        h.d.cs_from = 0xFFFFFFFFu;
+        if (h.late) {  // the island's last chunk sits in front of its probe in `ch`
+            const size_t i = todo[q];
+            if (i > 0 && !ch[i - 1].retired && ch[i - 1].island == h.island && ch[i - 1].d.ext_limit) h.d.cs_from = q_of[i - 1];
+        }
     }
     isl_lap("round: regions placed", round);
     if (st_chunks != st && ctx->ws_l1.cap < (next_region + 1) * sizeof(L1Rec)) st_chunks = st;  // (the buffer grows: in stream order)
@@ -245,7 +280,7 @@ int IslandRun::enqueue_round() {
     // one ring slot per chunk ever built (ids = indices into `ch`), kept across the rounds
     if ((rc = ctx->ws_flags.ensure_keep(ctx, ch.size() * CHUNK_RING_WORDS * sizeof(uint64_t), sc))) return rc;
     isl_lap("chunks listed, buffers ready", round);
-    launch_level1_chunks(sc, a, d_desc, (uint32_t)nq, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
+    launch_level1_chunks(sc, a, d_desc, (uint32_t)nq, (uint32_t)n_late, d_in, d_out, d_stat, (uint64_t *)ctx->ws_flags.p, d_info);
     isl_lap(sc == st ? "chunk kernel enqueued" : "chunk kernel enqueued (side stream)", round);
     enqueued = true;
     return PGR_OK;
@@ -274,8 +309,20 @@ int IslandRun::process_round() {
         status[todo[q]] = r_stat[q];
         ch[todo[q]].n_push = r_info[4 * q];
         ch[todo[q]].bmin = r_info[4 * q + 1];
-        ch[todo[q]].n_out = r_info[4 * q + 3];
+        ch[todo[q]].n_out = r_info[4 * q + 3] & ((1ull << 40) - 1);
         ch[todo[q]].dropped = false;
+        const uint64_t moved = (r_info[4 * q + 3] >> 40) * 64;
+        if (moved && !ch[todo[q]].probe) {
+            // the island's end has moved on behind a stuck machine: the chunk, the island and the probe behind it say so
+            HChunk &h = ch[todo[q]];
+            h.d.ce += moved;
+            h.d.drain_end += moved;
+            islands[h.island].E = h.d.ce;
+            const size_t i = todo[q];
+            if (i + 1 < ch.size() && ch[i + 1].probe && ch[i + 1].island == h.island && !ch[i + 1].retired)
+                ch[i + 1].d.cs = ch[i + 1].d.ce = ch[i + 1].d.drain_end = h.d.ce;
+            ++n_moved;
+        }
     }
     if (ctx->opt.debug && descs.size() == nq && nq) {
         uint32_t worst = 0;
@@ -317,6 +364,8 @@ int IslandRun::process_round() {
                 is.whole = true;
                 is.B = 0;
                 is.E = b->h_len[is.contig];
+                is.cutB = is.cutE = false;
+                is.ext_limit = 0;
                 rebuild.push_back(h.island);
             }
             continue;
@@ -330,7 +379,13 @@ int IslandRun::process_round() {
         auto grow = [&]() {
             // the machine is not back in its regular regime at E: grow the island
             const uint64_t L = b->h_len[is.contig];
-            is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
+            if (is.cutE) {  // it ended inside a tile: through that tile and the next one (what an island of whole tiles starts with)
+                is.E = std::min<uint64_t>(L, (is.E / tc + 2) * (uint64_t)tc);
+                is.cutE = false;
+                is.ext_limit = 0;
+            } else {
+                is.E = std::min<uint64_t>(L, is.E + 4ull * tc);
+            }
             if (L - is.E < 2ull * tc) is.E = L;
             rebuild.push_back(h.island);
         };
@@ -423,6 +478,11 @@ int IslandRun::process_round() {
             }
         }  // else: the chunk in front is not settled yet
         if (again) next.push_back(i);
+        // (a last chunk that may move the island's end runs again: so does the probe behind it, at wherever that run ends)
+        if (again && h.d.ext_limit && i + 1 < ch.size() && ch[i + 1].probe && ch[i + 1].island == h.island && !ch[i + 1].retired) {
+            ch[i + 1].final = false;
+            next.push_back(i + 1);
+        }
     }
     if (!rebuild.empty()) {
         std::sort(rebuild.begin(), rebuild.end());
@@ -437,7 +497,11 @@ int IslandRun::process_round() {
                 if (jj != ii && islands[jj].contig == islands[ii].contig && islands[jj].B < islands[ii].E + tc &&
                     islands[jj].B >= islands[ii].B && islands[jj].E > islands[ii].B && !islands[jj].whole &&
                     islands[jj].E != 0) {
-                    islands[ii].E = std::max(islands[ii].E, islands[jj].E);
+                    if (islands[jj].E > islands[ii].E) {
+                        islands[ii].E = islands[jj].E;
+                        islands[ii].cutE = islands[jj].cutE;
+                        islands[ii].ext_limit = islands[jj].ext_limit;
+                    }
                     islands[ii].pal = islands[ii].pal || islands[jj].pal;
                     for (auto &h : ch)
                         if (h.island == jj) h.retired = true;
@@ -460,7 +524,9 @@ int IslandRun::begin(hipStream_t side) {
     for (size_t ii = 0; ii < islands.size(); ++ii)
         if ((rc = build(ii))) return rc;
     round = 0;
-    return todo.empty() ? PGR_OK : enqueue_round();
+    rc = todo.empty() ? PGR_OK : enqueue_round();
+    critical = st_chunks != st;  // (a first round beside the tile kernel; otherwise every round is waited for and the constructor's sizes hold)
+    return rc;
 }
 
 // The round that begin() enqueued is waited for and its seams are verified: afterwards nothing of this run is pending on the device
@@ -532,7 +598,7 @@ int IslandRun::adopt(const std::vector<Island> &wanted) {
             if (!wanted_sorted) p = 0;  // (never the case with list_islands' output: correct all the same)
             while (p < mine.size() && (islands[mine[p]].contig != wn.contig ? islands[mine[p]].contig < wn.contig : islands[mine[p]].B < wn.B)) ++p;
             if (p < mine.size() && islands[mine[p]].contig == wn.contig && islands[mine[p]].B == wn.B && !wn.whole &&
-                islands[mine[p]].E == wn.E && !keep[mine[p]]) {
+                islands[mine[p]].E == wn.E && islands[mine[p]].cutB == wn.cutB && islands[mine[p]].cutE == wn.cutE && !keep[mine[p]]) {
                 keep[mine[p]] = 1;
                 covered[j] = 1;
                 islands[mine[p]].pal = islands[mine[p]].pal || wn.pal;
@@ -563,6 +629,9 @@ int IslandRun::adopt(const std::vector<Island> &wanted) {
     for (size_t j = 0; j < wanted.size(); ++j)
         if (!covered[j]) fresh_bases += wanted[j].E - wanted[j].B;
     if (ctx->opt.island_chunk_min <= 0) CS_PAL = pal_chunk(fresh_bases, 512);
+    // (islands that begin and end inside their tiles are one chunk each, build(); what is longer -- groups of flagged tiles, islands
+    // merged with those around non-ACGT bytes -- is cut so that the round's slowest chunk is not three times its typical one)
+    if (ctx->opt.island_chunk_min <= 0 && a.tile_pal) CS_PAL = std::min<uint64_t>(CS_PAL, 2816);
     {
         std::vector<Island> fresh;
         for (size_t j = 0; j < wanted.size(); ++j)
@@ -603,31 +672,105 @@ int IslandRun::finish() {
     }
     isl_lap("seams verified", -1);
     // ---- the lists of the chunks that start in one tile become that tile's segment: copied back to back into a fresh region
-    // (the chunks of an island are contiguous in `ch`, in position order; their counts came back with the states)
+    // (the chunks of an island are contiguous in `ch`, in position order; their counts came back with the states).
+    // A tile an island begins or ends INSIDE (Island::cutB / cutE) keeps its own elements below B / from E on: its entry is a SPLICE
+    // -- room for that prefix in front of the chunks' lists (one element per position of [tile start, B) at most: the tile kernel
+    // selects a position once) and for the suffix behind them; splice_segs_kernel finds the two split points in the tile's own
+    // segment (in position order) and copies the prefix right-aligned against the chunks' lists, so the segment is contiguous.
     {
-        std::vector<uint64_t> img;  // copies (3 words each), then segment entries (3 words each)
-        std::vector<uint64_t> segs;
-        uint32_t cur_seg = 0xFFFFFFFFu;
+        constexpr uint64_t NONE = ~0ull;
+        std::vector<uint64_t> img;  // copies (3 words each), then segment entries (3 words each), then splices (6 words each)
+        std::vector<uint64_t> segs, splices;
+        img.reserve(3 * ch.size() + 9 * islands.size() + 64);
+        segs.reserve(3 * ch.size() + 64);
+        splices.reserve(12 * islands.size() + 64);
+        struct Open {
+            uint32_t seg = 0xFFFFFFFFu, contig = 0;
+            uint64_t off = 0, cnt = 0, lo = NONE, hi = NONE, sfx_room = 0;
+            size_t island = SIZE_MAX;
+        } cur;
+        bool cur_open = false, end_seg_done = false;
+        size_t cur_island = SIZE_MAX;
+        auto seg0_of = [&](uint32_t c) { return tile_first[c] + c; };
+        auto close_seg = [&]() {
+            if (!cur_open) return;
+            cur_open = false;
+            if (cur.lo == NONE && cur.hi == NONE) {
+                segs.push_back((uint64_t)cur.seg | ((uint64_t)cur.contig << 32));
+                segs.push_back(cur.off);
+                segs.push_back(cur.cnt);
+            } else {
+                splices.push_back((uint64_t)cur.seg | ((uint64_t)cur.contig << 32));
+                splices.push_back(cur.off);
+                splices.push_back(cur.cnt);
+                splices.push_back(cur.lo);
+                splices.push_back(cur.hi);
+                splices.push_back(cur.sfx_room);
+                next_region += cur.sfx_room;
+            }
+        };
+        auto open_seg = [&](uint32_t seg, const Island &is) {
+            close_seg();
+            cur = Open();
+            cur.seg = seg;
+            cur.contig = is.contig;
+            const uint32_t s0 = seg0_of(is.contig);
+            if (is.cutB && seg == s0 + (uint32_t)(is.B / tc)) {
+                cur.lo = is.B;
+                next_region += is.B - (uint64_t)(seg - s0) * tc + 64;  // room for the tile's own elements below B
+            }
+            if (is.cutE && seg == s0 + (uint32_t)(is.E / tc)) {
+                cur.hi = is.E;
+                cur.sfx_room = (uint64_t)(seg - s0 + 1) * tc - is.E + 64;
+                end_seg_done = true;
+            }
+            cur.off = next_region;
+            cur_open = true;
+        };
+        auto close_island = [&]() {
+            if (cur_island == SIZE_MAX) return;
+            const Island &is = islands[cur_island];
+            // (no chunk starts in the tile the island ends in: that tile's entry is its own suffix alone)
+            if (is.cutE && is.E > is.B) {
+                // tiles between the last one a chunk starts in and the one the island ends in: wholly the island's, and empty -- an end
+                // that has moved on into the next tile leaves the tile it was to end in with its own entry (build() kept it)
+                const uint32_t seg_e = seg0_of(is.contig) + (uint32_t)(is.E / tc);
+                const uint32_t last = cur_open ? cur.seg : seg_e;
+                close_seg();
+                for (uint32_t sg = last + 1; sg < seg_e; ++sg) {
+                    segs.push_back((uint64_t)sg | ((uint64_t)is.contig << 32));
+                    segs.push_back(next_region);
+                    segs.push_back(0);
+                }
+                if (!end_seg_done) open_seg(seg_e, is);
+            }
+            close_seg();
+            cur_island = SIZE_MAX;
+        };
         for (const HChunk &h : ch) {
             if (h.retired || h.probe || h.d.seg == 0xFFFFFFFFu) continue;
-            if (h.d.seg != cur_seg) {
-                cur_seg = h.d.seg;
-                segs.push_back((uint64_t)cur_seg | ((uint64_t)h.d.contig << 32));
-                segs.push_back(next_region);
-                segs.push_back(0);
+            if (h.island != cur_island) {
+                close_island();
+                cur_island = h.island;
+                end_seg_done = false;
             }
+            if (!cur_open || h.d.seg != cur.seg) open_seg(h.d.seg, islands[h.island]);
             if (h.dropped || h.n_out == 0) continue;
             img.push_back(h.d.region_off);
             img.push_back(next_region);
             img.push_back(h.n_out);
-            segs[segs.size() - 1] += h.n_out;
+            cur.cnt += h.n_out;
             next_region += h.n_out;
         }
-        const size_t n_copies = img.size() / 3, n_set = segs.size() / 3;
-        if (n_set) {
+        close_island();
+        const size_t n_copies = img.size() / 3, n_set = segs.size() / 3, n_splice = splices.size() / 6;
+        if (n_set || n_splice) {
             for (size_t i = 0; i < n_set; ++i)
                 if (segs[3 * i + 2] > 0xFFFFFFFFull) return ctx->fail(PGR_ERR_INTERNAL, "a tile's exact list exceeds 2^32 elements");
+            for (size_t i = 0; i < n_splice; ++i)
+                if (splices[6 * i + 2] > 0x7FFFFFFFull) return ctx->fail(PGR_ERR_INTERNAL, "a tile's exact list exceeds 2^31 elements");
             img.insert(img.end(), segs.begin(), segs.end());
+            img.insert(img.end(), splices.begin(), splices.end());
             const size_t bytes = img.size() * sizeof(uint64_t);
             if ((rc = ctx->ws_l1.ensure_keep(ctx, (next_region + 1) * sizeof(L1Rec), st)) || (rc = ctx->ws_serial.ensure(ctx, bytes)) ||
                 (rc = ctx->ensure_imail(bytes)))
@@ -635,10 +778,14 @@ int IslandRun::finish() {
             a.out = (L1Rec *)ctx->ws_l1.p;
             memcpy(ctx->imail, img.data(), bytes);  // (pinned, and untouched until this context's next island call: no wait here)
             PGR_HIP(ctx, hipMemcpyAsync(ctx->ws_serial.p, ctx->imail, bytes, hipMemcpyHostToDevice, st));
-            launch_assemble_chunks(st, a, (const uint64_t *)ctx->ws_serial.p, (uint32_t)n_copies,
-                                   (const uint64_t *)ctx->ws_serial.p + 3 * n_copies, (uint32_t)n_set);
+            const uint64_t *d_img = (const uint64_t *)ctx->ws_serial.p;
+            launch_assemble_chunks(st, a, d_img, (uint32_t)n_copies, d_img + 3 * n_copies, (uint32_t)n_set);
+            if (n_splice) launch_splice_segs(st, a, d_img + 3 * n_copies + 3 * n_set, (uint32_t)n_splice);
+            n_spliced = n_splice;
         }
     }
+    if (ctx->opt.debug && (n_spliced || n_moved))
+        fprintf(stderr, "[pgr] islands: %zu tiles keep elements of their own beside an island's, %zu island ends moved on behind a stuck machine\n", n_spliced, n_moved);
     isl_lap("tile lists assembled (enqueued)", -1);
     return PGR_OK;
 }
@@ -843,6 +990,9 @@ struct ShmmrJob {
     unsigned long long *d_cursor = nullptr;
     uint32_t *d_cflags = nullptr;
     uint8_t *d_tflags = nullptr;
+    uint16_t *d_tpal = nullptr;
+    size_t pal_off = 0;     // of d_tpal behind d_tflags, bytes
+    bool sub_tile = false;  // islands may begin / end inside tiles flagged for a palindromic k-mer only
     size_t zero_bytes = 0;
     uint64_t *mbox = nullptr;  // pinned: [0, N_STATUS) status, then the n + 1 result offsets
     uint32_t *d_rids = nullptr;
@@ -888,7 +1038,7 @@ struct ShmmrJob {
     }
     int plan();
     void list_islands(const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, const uint16_t *pal, std::vector<Island> &islands,
-                      std::vector<uint32_t> &gap_segs);
+                      std::vector<uint32_t> &gap_segs, uint32_t cut_margin = 0, uint32_t cut_settle = 0);
     int stage1();
     int run_islands(uint64_t need_word);
     int begin_result();
@@ -983,7 +1133,7 @@ int ShmmrJob::plan() {
         (rc = ctx->ws_tile_lv.ensure(ctx, ((size_t)n_tiles + 1) * sizeof(uint64_t))) ||
         // one block that a single memset clears per call: cursors | contig flags | tile flags  (+ the status words)
         (rc = ctx->ws_cursor.ensure(ctx, (N_CURSOR + N_STATUS) * sizeof(unsigned long long) +
-                                             std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64)) ||
+                                             std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 64 + 4 + 2 * (size_t)n_tiles + 8)) ||
         (rc = ctx->ws_off_a.ensure(ctx, ((size_t)n + 1) * sizeof(uint64_t))) ||
         (rc = ctx->ws_off_b.ensure(ctx, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t))) ||
         // pinned: the pass's status words + result offsets come back into it; behind them the tile table and the rids on their way up
@@ -995,6 +1145,11 @@ int ShmmrJob::plan() {
     d_cursor = (unsigned long long *)ctx->ws_cursor.p;
     d_cflags = (uint32_t *)(d_cursor + N_CURSOR);
     d_tflags = (uint8_t *)(d_cflags + std::max<size_t>(n, 1));
+    // behind the tile flags and their slack: first | last << 8 block of 64 core positions with a palindromic k-mer, of the tiles the
+    // tile kernel flags for one (not cleared: read only where this pass's tile kernel has set flag bit 0, i.e. has written it)
+    pal_off = (((size_t)n_tiles + 64) + 3) & ~(size_t)3;
+    d_tpal = (uint16_t *)(d_tflags + pal_off);
+    sub_tile = !sketch && !ctx->opt.no_sub_tile_islands && tiled && bases_tiled && n_tiles;
     zero_bytes = N_CURSOR * sizeof(unsigned long long) + std::max<size_t>(n, 1) * sizeof(uint32_t) + (size_t)n_tiles + 16;
     mbox = (uint64_t *)ctx->mailbox;
     if (ctx->opt.debug_poison) memset(mbox, 0xFF, (N_STATUS + (size_t)n + 1) * sizeof(uint64_t));  // (status words + offsets of an earlier pass)
@@ -1018,7 +1173,7 @@ int ShmmrJob::plan() {
     a.tile_first = (const uint32_t *)ctx->ws_tile_first.p;
     a.desc = (TileDesc *)ctx->ws_tile_desc.p;
     a.tile_flags = d_tflags;
-    a.tile_pal = nullptr;  // (positions of the palindromic k-mers inside a tile: an experiment that was taken out again)
+    a.tile_pal = sub_tile ? d_tpal : nullptr;  // (round 6: islands begin and end inside tiles, island_list.h)
     a.tile_lv = nullptr;  // set once mark_invalid_tiles has filled it and run_islands has made it cumulative
     a.w = w_eff;
     a.k = spec.k;
@@ -1066,12 +1221,12 @@ int ShmmrJob::plan() {
 // islands of exact tiles from the flags: flags[c] bit 0 = a tile of contig c saw a palindromic k-mer, n_invalid[c] = its non-ACGT
 // bytes, tf[tile] = tile flags (bit 0 palindromic k-mer, bit 1 non-ACGT byte in reach, bit 2 nothing but such bytes; bit 3 is set here)
 void ShmmrJob::list_islands(const uint32_t *flags, const uint32_t *n_invalid, uint8_t *tf, const uint16_t *pal, std::vector<Island> &islands,
-                            std::vector<uint32_t> &gap_segs) {
+                            std::vector<uint32_t> &gap_segs, uint32_t cut_margin, uint32_t cut_settle) {
     const std::vector<uint32_t> &tfi = tile_first();
     // a genome-sized batch (half a million tiles in a dozen contigs): ranges of contigs on the pool's threads, lists in contig order
     const unsigned par = std::min<unsigned>(std::min<unsigned>(16, HostPool::instance().workers() + 1), n);
     if (n_tiles < (1u << 17) || par < 2) {
-        list_islands_from_flags(n, tfi.data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, islands, gap_segs);
+        list_islands_from_flags(n, tfi.data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, islands, gap_segs, 0, 0xFFFFFFFFu, cut_margin, cut_settle);
         return;
     }
     std::vector<uint32_t> cut(par + 1, n);  // contig ranges of about n_tiles / par tiles each
@@ -1085,7 +1240,7 @@ void ShmmrJob::list_islands(const uint32_t *flags, const uint32_t *n_invalid, ui
     std::vector<std::vector<uint32_t>> gs(par);
     HostPool::instance().parallel_for(par, [&](size_t p) {
         if (cut[p] < cut[p + 1])
-            list_islands_from_flags(n, tfi.data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, isl[p], gs[p], cut[p], cut[p + 1]);
+            list_islands_from_flags(n, tfi.data(), b->h_len.data(), tc, sketch, flags, n_invalid, tf, pal, isl[p], gs[p], cut[p], cut[p + 1], cut_margin, cut_settle);
     });
     for (unsigned p = 0; p < par; ++p) {
         islands.insert(islands.end(), isl[p].begin(), isl[p].end());
@@ -1197,7 +1352,7 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         // contig flags and tile flags are neighbours in the cursor block: two copies into the pinned image (three pageable ones
         // were 67 us of a 60 Mbp call's 660)
         const size_t nc = std::max<size_t>(n, 1) * sizeof(uint32_t);
-        const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15;
+        const size_t flag_bytes = nc + (sub_tile ? pal_off + 2 * (size_t)n_tiles : (size_t)n_tiles), inv_off = (flag_bytes + 15) & ~(size_t)15;
         int r0;
         if ((r0 = ctx->ensure_imail(inv_off + nc))) return r0;
         uint8_t *img = (uint8_t *)ctx->imail;
@@ -1211,7 +1366,13 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         std::vector<uint8_t> &tf = ctx->h_tf_scratch;  // (list_islands marks tiles in its copy; run_exact_islands reuses the image.  Kept: a fresh half megabyte faults in page by page)
         tf.assign(img + nc, img + nc + n_tiles);
         std::vector<uint32_t> flags((const uint32_t *)img, (const uint32_t *)img + n), n_invalid((const uint32_t *)(img + inv_off), (const uint32_t *)(img + inv_off) + n);
-        list_islands(flags.data(), n_invalid.data(), tf.data(), nullptr, islands, gap_segs);
+        // (cut_margin: a multiple of 64 >= w + k + 64, island_list.h)
+        const uint32_t cut_margin = sub_tile ? ((spec.w + spec.k + 64 + 63) / 64) * 64 + 64 : 0;
+        // (cut_settle: a multiple of 64 >= 2 w + k + 64; option island_settle for A/B)
+        const uint32_t cut_settle = !sub_tile ? 0 : ctx->opt.island_settle > 0 ? (uint32_t)((ctx->opt.island_settle + 63) / 64 * 64)
+                                                                              : ((2 * spec.w + spec.k + 64 + 63) / 64) * 64;
+        list_islands(flags.data(), n_invalid.data(), tf.data(), sub_tile ? (const uint16_t *)(img + nc + pal_off) : nullptr, islands, gap_segs, cut_margin,
+                     cut_settle);
     }
     {
         std::vector<uint32_t> cs;
@@ -1439,7 +1600,7 @@ int ShmmrJob::enqueue_pass() {
             // belongs to the early round of the islands, which then needs no flags)
             flags_prefetched = false;
             const size_t nc = std::max<size_t>(n, 1) * sizeof(uint32_t);
-            const size_t flag_bytes = nc + n_tiles, inv_off = (flag_bytes + 15) & ~(size_t)15;
+            const size_t flag_bytes = nc + (sub_tile ? pal_off + 2 * (size_t)n_tiles : (size_t)n_tiles), inv_off = (flag_bytes + 15) & ~(size_t)15;
             if (tiled && bases_tiled && !early_islands && inv_off + nc <= (256u << 10)) {
                 if ((rc = ctx->ensure_imail(inv_off + nc))) return rc;
                 uint8_t *img = (uint8_t *)ctx->imail;

@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
     const int cases = argc > 1 ? atoi(argv[1]) : 1000;
     std::mt19937_64 rng(12345);
     int failures = 0;
-    size_t n_islands = 0, n_gaps = 0, n_pal = 0, n_whole = 0, n_shorter = 0;
+    size_t n_islands = 0, n_gaps = 0, n_pal = 0, n_whole = 0, n_shorter = 0, n_cut = 0;
     const uint32_t tc = 3904;
     for (int it = 0; it < cases; ++it) {
         const uint32_t n = 1 + rng() % 6;
@@ -153,6 +153,67 @@ int main(int argc, char **argv) {
             n_shorter += bases_c < bases_b;
             if (!ok && ++failures <= 5) fprintf(stderr, "case %d: islands listed with palindrome positions are not a trimmed form of those without\n", it);
         }
+        {
+            // round 6, cut_margin > 0: islands may begin and end INSIDE tiles whose only flag is the palindromic one.  Every island lies
+            // inside an island of the whole-tile list; tiles with a non-ACGT flag are covered whole; of a tile flagged for palindromic
+            // k-mers only, the blocks [first, last] are covered with cut_margin in front and the settling distance behind; a cut
+            // lies in a tile the tile kernel has computed (flag 1 or none); islands stay more than a tile apart.
+            const uint32_t margin = 320, settle = (it & 1) ? 1408 : 320;
+            std::vector<uint16_t> pal(tile_first[n] + 8);
+            for (auto &x : pal) {
+                const uint32_t lo = rng() % 61, hi = lo + rng() % (61 - lo);
+                x = (uint16_t)(lo | (hi << 8));
+            }
+            std::vector<uint8_t> tf_c = tf;
+            std::vector<Island> ic;
+            std::vector<uint32_t> gc;
+            pgr::list_islands_from_flags(n, tile_first.data(), h_len.data(), tc, sketch, flags.data(), n_inv.data(), tf_c.data(), pal.data(), ic, gc, 0, 0xFFFFFFFFu, margin, (it & 1) ? 0 : settle);
+            bool ok = gc == gb && tf_c == tf_b;
+            for (size_t i = 0; i < ic.size() && ok; ++i) {
+                const Island &x = ic[i];
+                const uint64_t L = h_len[x.contig];
+                bool inside = false;
+                for (const Island &y : ib) inside = inside || (y.contig == x.contig && y.B <= x.B + margin && x.E <= y.E);  // (B: up to `margin` into the clean tile in front)
+                ok = inside && x.B < x.E && x.E <= L;
+                // (islands do not share a tile, and the warm-up of one starts behind the end of the one in front -- wherever a stuck machine moves that)
+                if (i && ic[i - 1].contig == x.contig) {
+                    const uint64_t pe = std::max(ic[i - 1].E, ic[i - 1].ext_limit);
+                    ok = ok && ic[i - 1].E + tc < x.B && pe + 256 <= x.B && ((pe - 1) / tc < x.B / tc || pe % tc == 0);
+                }
+                const uint32_t t0 = tile_first[x.contig];
+                if (x.cutB) {  // in the first flagged tile, or within `margin` of it in the clean tile in front
+                    const uint64_t tb_ = x.B / tc, tf_ = tf_c[t0 + tb_] ? tb_ : tb_ + 1;
+                    ok = ok && x.B % 64 == 0 && x.B % tc != 0 && tf_c[t0 + tb_] <= 1 && tf_c[t0 + tf_] == 1 &&
+                         x.B + margin == tf_ * (uint64_t)tc + (uint64_t)(pal[t0 + tf_] & 0xFF) * 64;
+                }
+                else ok = ok && (x.B % tc == 0);
+                if (x.cutE) ok = ok && x.E + 2ull * tc <= L && tf_c[t0 + x.E / tc] <= 1 && x.E % 64 == 0;
+                else ok = ok && (x.E == L || x.E % tc == 0);
+                // how far a stuck machine may move the end on: inside the clean tile behind the last flagged one, a tile short of the next island
+                if (x.ext_limit) ok = ok && x.cutE && x.ext_limit > x.E && x.ext_limit % 64 == 0 && x.ext_limit + 2ull * tc <= L + 63 &&
+                                      tf_c[t0 + (x.ext_limit - 1) / tc] <= 1 &&
+                                      (i + 1 == ic.size() || ic[i + 1].contig != x.contig || x.ext_limit + 256 <= ic[i + 1].B);
+                n_cut += x.cutB + x.cutE;
+            }
+            for (uint32_t c = 0; c < n && ok; ++c) {
+                if (n_inv[c] == 0 && (sketch || !(flags[c] & 1u))) continue;
+                if (sketch && n_inv[c] == 0) continue;
+                for (uint32_t t = tile_first[c]; t < tile_first[c + 1] && ok; ++t) {
+                    if (!tf_c[t]) continue;
+                    const uint64_t p0 = (uint64_t)(t - tile_first[c]) * tc;
+                    uint64_t need_lo = p0, need_hi = std::min<uint64_t>(p0 + tc, h_len[c]);
+                    if (tf_c[t] == 1) {
+                        const uint64_t lo = (uint64_t)(pal[t] & 0xFF) * 64, hi = (uint64_t)(pal[t] >> 8) * 64 + 64;
+                        need_lo = p0 + (lo > margin ? lo - margin : 0);
+                        need_hi = std::min<uint64_t>(h_len[c], p0 + hi + settle);
+                    }
+                    bool cov = false;
+                    for (const Island &x : ic) cov = cov || (x.contig == c && x.B <= need_lo && need_hi <= x.E);
+                    ok = cov;
+                }
+            }
+            if (!ok && ++failures <= 5) fprintf(stderr, "case %d: islands that begin / end inside tiles break an invariant\n", it);
+        }
         {  // ranges of contigs listed one after the other give the same lists (what the product does on several threads)
             std::vector<uint8_t> tf_d = tf;
             std::vector<Island> id;
@@ -176,6 +237,6 @@ int main(int argc, char **argv) {
         }
     }
     printf("%d cases, %d failures\n", cases, failures);
-    printf("%zu islands (%zu with a palindromic tile, %zu whole contigs), %zu deep-gap ranges; %zu cases end islands earlier with palindrome positions\n", n_islands, n_pal, n_whole, n_gaps, n_shorter);
+    printf("%zu islands (%zu with a palindromic tile, %zu whole contigs), %zu deep-gap ranges; %zu cases end islands earlier with palindrome positions; %zu island ends inside tiles\n", n_islands, n_pal, n_whole, n_gaps, n_shorter, n_cut);
     return failures ? 1 : 0;
 }
