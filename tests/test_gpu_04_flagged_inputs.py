@@ -384,3 +384,64 @@ def test_a_probe_does_not_accept_a_stuck_machine(oracle, gpu_ctx):
             with gpu_ctx.options(**opts):
                 got = P.sequence_to_shmmrs_batch([s], P.make_spec(*spec4), ctx=gpu_ctx)[0]
             assert len(ref) == len(got) and np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"]), (spec4, len(s), opts)
+
+
+def test_islands_that_begin_and_end_inside_tiles(oracle, gpu_ctx):
+    """Round 6 (island_list.h, IslandRun::finish, splice_segs_kernel): an island around an array of palindromic k-mers begins
+    cut_margin in front of the first 64-position block the tile kernel reports one in and ends 2 w + k + 64 behind the last one --
+    inside the tiles, whose own elements in front of B / from E on are spliced with the exact machine's list; a machine that
+    arrives at E stuck moves the end on itself.  Arrays at every kind of place: at a tile's start (B lies in the clean tile in
+    front), in its middle, at its end (E lies in the next tile), across a boundary, two in one tile, one to three tiles apart,
+    near the contig's end; (AT)n and (ACGT)n; three specs; against the oracle, and against the islands of whole tiles
+    (no_sub_tile_islands), which must be the same list with more positions through the machine."""
+    import pgrtk_amd as P
+    rng = np.random.default_rng(606)
+    cases = []
+    for w, k in ((80, 56), (48, 56), (31, 24)):
+        tc = ((4096 - 2 * (w - 1)) // 64) * 64
+        for rep in range(10):
+            nt = int(rng.integers(40, 60))  # (a contig with more than a third of its tiles flagged is one island: arrays every 4-8 tiles)
+            body = bytearray(seqgen.rnd(rng, nt * tc + int(rng.integers(0, tc))))
+            t = 2
+            while t < nt - 1:
+                kind = int(rng.integers(0, 7))
+                unit = b"AT" if rng.random() < 0.7 else b"ACGT"
+                arr = unit * int(rng.integers(40, 220) * 2 // len(unit))
+                if kind == 0:
+                    off = int(rng.integers(0, 200))                        # at the tile's start
+                elif kind == 1:
+                    off = int(rng.integers(400, tc - 600))                 # in the middle
+                elif kind == 2:
+                    off = tc - len(arr) - int(rng.integers(0, 300))        # at its end: E in the next tile
+                elif kind == 3:
+                    off = tc - len(arr) // 2                               # across the boundary
+                elif kind == 4:
+                    off = int(rng.integers(300, 1200))                     # two in one tile
+                    o2 = off + len(arr) + int(rng.integers(200, 1800))
+                    if o2 + len(arr) < tc:
+                        body[t * tc + o2:t * tc + o2 + len(arr)] = arr
+                elif kind == 5:
+                    off = int(rng.integers(0, tc - len(arr)))
+                else:
+                    off = int(rng.integers(0, 64))
+                p0 = t * tc + off
+                if p0 + len(arr) < len(body):
+                    body[p0:p0 + len(arr)] = arr
+                t += int(rng.integers(1, 4)) if rng.random() < 0.2 else int(rng.integers(4, 9))
+            if rep % 3 == 0:  # ... and one within two tiles of the contig's end
+                p0 = len(body) - int(rng.integers(300, 2 * tc))
+                body[p0:p0 + 120] = b"AT" * 60
+            cases.append(((w, k, 4, 12) if rep % 2 else (w, k, 1, 0), bytes(body)))
+    less = 0
+    for spec4, s in cases:
+        ref = oracle.sequence_to_shmmrs(0, s, oracle.spec(*spec4), False)
+        through = {}
+        for name, opts in (("default", {"no_small_path": 1}), ("early look", {"no_small_path": 1, "early_sync_bp": 0}),
+                           ("whole tiles", {"no_small_path": 1, "no_sub_tile_islands": 1})):
+            with gpu_ctx.options(**opts):
+                got = P.sequence_to_shmmrs_batch([s], P.make_spec(*spec4), ctx=gpu_ctx)[0]
+                through[name] = gpu_ctx.last_prof().exact_bases
+            assert len(ref) == len(got) and np.array_equal(ref["x"], got["x"]) and np.array_equal(ref["y"], got["y"]), (spec4, len(s), name)
+        assert through["default"] <= through["whole tiles"], (spec4, through)
+        less += through["default"] < through["whole tiles"]
+    assert less >= len(cases) // 2  # (the sub-tile form is what runs: fewer positions through the machine in most cases)

@@ -202,6 +202,21 @@ def main():
                      "" if n_rec is None else "; index records %d" % n_rec), flush=True)
             out.setdefault("pipe", {})[name] = {"batches": args.pipe, "ms_per_batch": t * 1e3 / args.pipe, "Gbp_per_s": bp * args.pipe / t / 1e9,
                                                 "content_match_vs_synchronous_call": bool(same), "index_records": n_rec}
+    if args.pipe:
+        for kv in args.opt:  # the pipe with each A/B option, against the pipe without, in alternation
+            k, v = kv.split("=")
+            ta, tb, same = [], [], True
+            for rep in range(3):
+                t, sm, _ = pipe_pass(args.pipe, {k: int(v)})
+                tb.append(t)
+                same = same and sm
+                t, sm, _ = pipe_pass(args.pipe, {})
+                ta.append(t)
+                same = same and sm
+            print("pipe with %s: %.2f ms per batch against %.2f without (best of 3 x %d batches each, alternating); identical to the synchronous call: %s"
+                  % (kv, min(tb) * 1e3 / args.pipe, min(ta) * 1e3 / args.pipe, args.pipe, same), flush=True)
+            out["pipe"]["with " + kv] = {"ms_per_batch": min(tb) * 1e3 / args.pipe, "default_ms_per_batch": min(ta) * 1e3 / args.pipe,
+                                         "content_match_vs_synchronous_call": bool(same)}
     if args.rounds:
         with ctx.options(debug_times=1):
             b.shmmrs(sp)
