@@ -445,7 +445,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
                                                           ChunkState *__restrict__ st_in,
                                                           ChunkState *__restrict__ st_out,
                                                           uint32_t *__restrict__ status, uint64_t *__restrict__ rings,
-                                                          uint64_t *__restrict__ info, const uint64_t *__restrict__ info_round) {
+                                                          uint64_t *__restrict__ info) {
     __shared__ uint64_t s_rx[128], s_ry[128];  // ring buffer (storage order)
     const uint64_t t_begin = wall_clock64();
     const uint32_t lane = threadIdx.x;
@@ -469,13 +469,8 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     // branch 2 enabled for w+k <= pos < Lb; Rust usize arithmetic wraps in release builds
     const uint64_t Lb = (uint64_t)L - (uint64_t)w + (uint64_t)k;
     const uint64_t lt_mask = (lane == 0) ? 0ull : (U64MAX >> (64 - lane));
-    long long cs = (long long)cd.cs, ce = (long long)cd.ce;
-    if (cd.cs_from != 0xFFFFFFFFu && info_round) {
-        // the probe of an island that ends inside a tile: where the island's last chunk (an earlier launch of this round) has ended
-        const long long moved = (long long)(info_round[4 * (size_t)cd.cs_from + 3] >> 40) * 64;
-        cs += moved;
-        ce += moved;
-    }
+    const long long cs = (long long)cd.cs;
+    long long ce = (long long)cd.ce;  // (moves on behind a stuck machine: cd.ext_limit)
 
     s_rx[lane] = U64MAX;
     s_rx[lane + 64] = U64MAX;
@@ -563,7 +558,7 @@ __global__ __launch_bounds__(64) void level1_chunk_kernel(L1Args a, const ChunkD
     uint64_t n_out = 0;
     uint32_t stat = 0;
 
-    long long drain_end = (long long)cd.drain_end > (long long)cd.ce ? (long long)cd.drain_end + (ce - (long long)cd.ce) : ce;
+    long long drain_end = (long long)cd.drain_end > ce ? (long long)cd.drain_end : ce;
     const long long ext_limit = a.sketch ? 0 : (long long)cd.ext_limit;
     uint64_t n_ext = 0;  // blocks of 64 positions added behind cd.ce
     const uint64_t emit_lo = cd.emit_lo_pos;
@@ -1144,16 +1139,10 @@ void launch_level1_tails(hipStream_t st, const L1Args &a) {
     if (a.n_contigs == 0) return;
     hipLaunchKernelGGL(level1_tail_kernel, dim3((a.n_contigs + TAIL_WAVES - 1) / TAIL_WAVES), dim3(64 * TAIL_WAVES), 0, st, a);
 }
-// the round's chunks [0, n_chunks - n_late), then -- a second launch -- its last n_late (probes that take their position from what
-// a chunk of the first launch reports: ChunkDesc::cs_from)
-void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks, uint32_t n_late,
+void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info) {
     if (n_chunks == 0) return;
-    const uint32_t n0 = n_chunks - n_late;
-    if (n0) hipLaunchKernelGGL(level1_chunk_kernel, dim3(n0), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings, d_info, d_info);
-    if (n_late)
-        hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_late), dim3(64), 0, st, a, d_descs + n0, d_in + n0, d_out + n0, d_status + n0, d_rings,
-                           d_info + 4 * (size_t)n0, d_info);
+    hipLaunchKernelGGL(level1_chunk_kernel, dim3(n_chunks), dim3(64), 0, st, a, d_descs, d_in, d_out, d_status, d_rings, d_info);
 }
 // the lists of the chunks that start in one tile, put together: copy i moves list[3i + 2] records from element list[3i] to
 // element list[3i + 1] of the level-1 buffer (a fresh region: source and destination never overlap); one wavefront per copy

@@ -134,11 +134,9 @@ struct ChunkDesc {
     uint32_t ring_in, ring_out;
     // Round 6, an island that ends inside a tile (Island::cutE).  ext_limit > ce, on the island's last chunk: while the machine
     // arrives at ce STUCK (mdist > w - 1: it emits nothing until a push reaches down to min_mer, shmmrutils.rs:505-520), ce and
-    // drain_end move on by 64, up to ext_limit; the blocks added come back in bits 40.. of the chunk's 4th info word.  cs_from
-    // != 0xFFFFFFFF, on that island's probe (launched BEHIND the chunks of its round): its position is cs + 64 x the blocks the
-    // chunk with that index of the round has added.
+    // drain_end move on by 64, up to ext_limit; the blocks added come back in bits 40.. of the chunk's 4th info word (the island's
+    // probe, which ran beside the chunk at the end that was planned, then runs again at the new end in the next round).
     uint64_t ext_limit;
-    uint32_t cs_from, _pad;
 };
 constexpr uint32_t CHUNK_RING_WORDS = 2 * 128 + 1;  // x[128], y[128] in push order, fill
 constexpr uint32_t L1_TAIL_SLOT = 4;
@@ -175,7 +173,7 @@ void launch_level1_tails(hipStream_t st, const L1Args &a);
 constexpr uint32_t LDS_GRANULE = 512;  // gfx950 hands out LDS in 512-byte units
 uint32_t level1_tile_lds_bytes(const L1Args &a);  // LDS a workgroup of the tile kernel for `a` occupies (0: unknown)
 // exact state machine, one wavefront per chunk; status bit0 = region overflow, bit1 = override impossible
-void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks, uint32_t n_late,
+void launch_level1_chunks(hipStream_t st, const L1Args &a, const ChunkDesc *d_descs, uint32_t n_chunks,
                           ChunkState *d_in, ChunkState *d_out, uint32_t *d_status, uint64_t *d_rings, uint64_t *d_info);
 void launch_zero_contig_segs(hipStream_t st, const L1Args &a, const uint32_t *d_list, uint32_t n_list);
 // seg_cnt[s] = 0 for s in [ranges[2i], ranges[2i+1])

@@ -74,6 +74,26 @@ with ctx.options(no_island_relay=1):  # A/B: the round-3 seam correction (one se
         b.shmmrs(sp)
         ts3.append(time.perf_counter() - t0)
 print("     with the round-3 seam correction (option no_island_relay): %.1f ms" % (min(ts3) * 1e3))
+for a in sys.argv[1:]:  # --opt name=value: the call with a context option against without, in alternation, best of 8
+    if a.startswith("--opt="):
+        k, v = a[6:].split("=")
+        ta, tb = [], []
+        for rep in range(9):
+            with ctx.options(**{k: int(v)}):
+                t0 = time.perf_counter()
+                sh2 = b.shmmrs(sp)
+                if rep:
+                    tb.append(time.perf_counter() - t0)
+            t0 = time.perf_counter()
+            b.shmmrs(sp)
+            if rep:
+                ta.append(time.perf_counter() - t0)
+        print("     with %s: %.3f ms against %.3f without (alternating, best of 8); same count: %s" % (a[6:], min(tb) * 1e3, min(ta) * 1e3, sh2.count == sh.count))
+        if "--times" in sys.argv:
+            for o in ({k: int(v)}, {}):
+                print("--- laps with %s" % (o or "the defaults"), file=sys.stderr, flush=True)
+                with ctx.options(debug_times=1, **o):
+                    b.shmmrs(sp)
 if "--rounds" in sys.argv:  # the rounds of the island path on stderr
     sys.stderr.flush()
     with ctx.options(debug=1):
