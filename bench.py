@@ -697,7 +697,7 @@ def shapes_bench(P, ctx, spec, spec_t, cores, check):
         batch.shmmrs(spec)
         ts = []
         sh = None
-        for _ in range(3):
+        for _ in range(6):  # (a flagged batch's host-side lists take a few calls to stop growing: best of 6)
             t0 = time.perf_counter()
             sh = batch.shmmrs(spec)
             ts.append(time.perf_counter() - t0)

@@ -84,6 +84,7 @@ struct IslandRun {
     // kernel touches -- its regions lie behind the tiles' part of the level-1 buffer, which must not have to grow for this
     hipStream_t st_chunks = nullptr;
     size_t n_spliced = 0;  // tiles whose own elements were kept beside an island's (diagnostics)
+    size_t n_in_place = 0; // tiles whose segment is one chunk's region as it stands (diagnostics)
     bool critical = false; // the first round has been launched: what is built from here on is waited for
 
     IslandRun(pgr_ctx *ctx_, hipStream_t st_, const pgr_batch *b_, const L1Args &a_, const std::vector<Island> &islands_, const std::vector<uint32_t> &tile_first_,
@@ -679,7 +680,7 @@ int IslandRun::finish() {
         struct Open {
             uint32_t seg = 0xFFFFFFFFu, contig = 0;
             uint64_t off = 0, cnt = 0, lo = NONE, hi = NONE, sfx_room = 0;
-            size_t island = SIZE_MAX;
+            size_t island = SIZE_MAX, img_start = 0;  // (img_start: where this segment's copies begin in img)
         } cur;
         bool cur_open = false, end_seg_done = false;
         size_t cur_island = SIZE_MAX;
@@ -688,9 +689,18 @@ int IslandRun::finish() {
             if (!cur_open) return;
             cur_open = false;
             if (cur.lo == NONE && cur.hi == NONE) {
+                // ONE chunk's list is the whole segment (the usual case for the islands around runs of non-ACGT bytes, whose chunks are
+                // longer than a tile): the entry points at the chunk's region, nothing is copied (the copies of a genome-like batch
+                // were 160 MB through one wavefront per chunk, 65 us between the last round and the list stage)
+                uint64_t off = cur.off, cnt = cur.cnt;
+                if (img.size() - cur.img_start == 3) {
+                    off = img[cur.img_start];
+                    img.resize(cur.img_start);
+                    ++n_in_place;
+                }
                 segs.push_back((uint64_t)cur.seg | ((uint64_t)cur.contig << 32));
-                segs.push_back(cur.off);
-                segs.push_back(cur.cnt);
+                segs.push_back(off);
+                segs.push_back(cnt);
             } else {
                 splices.push_back((uint64_t)cur.seg | ((uint64_t)cur.contig << 32));
                 splices.push_back(cur.off);
@@ -717,6 +727,7 @@ int IslandRun::finish() {
                 end_seg_done = true;
             }
             cur.off = next_region;
+            cur.img_start = img.size();
             cur_open = true;
         };
         auto close_island = [&]() {
