@@ -1343,7 +1343,6 @@ __global__ __launch_bounds__(64) void sparse_aln_wave_kernel(
     // arrays are read from global memory (the ring is no longer meaningful).
     const float *xvs = in_lds ? L.vs : gvs;
     int *xsl = in_lds ? L.sl : gsl;
-    const int *xpv = in_lds ? L.pv : gpv;
     int n_unvisited = 0;
     for (int base = 0; base < n; base += 64) {
         const int i = base + lane;
