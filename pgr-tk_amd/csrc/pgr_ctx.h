@@ -113,7 +113,6 @@ struct pgr_ctx {
         int64_t back_priority = 0;       // pgr_pipe: priority of the back stream (list stages): 1 = the device's highest, 0 = the default, -1 = the lowest
     } opt;
     std::vector<uint32_t> h_tile_first;  // pgr_shmmrs_compute: first tile of every contig (host copy, kept between calls)
-    std::vector<uint8_t> h_tf_scratch;   // ... its copy of the tile flags while the islands are listed
     std::vector<uint64_t> spare_off;     // offsets block of the last destroyed big result (used again by the next one)
     bool skip_small_once = false;  // the host entry point's one-workgroup kernel handed the batch back: do not try it again
     bool want_host_copy = false;   // set by the host-buffer entry points: a small result rides along with the final round trip

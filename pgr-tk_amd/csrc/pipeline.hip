@@ -348,6 +348,9 @@ int IslandRun::process_round() {
     for (size_t i = 0; i < ch.size(); ++i) {
         HChunk &h = ch[i];
         if (h.retired) continue;
+        // (settled in an earlier round and nothing to run again: a round of a dozen chunks behind a genome-sized batch's ten thousand
+        // used to walk all of them through the rules below)
+        if (h.final && !(status[i] & 3u) && !(h.probe && h.moved)) continue;
         Island &is = islands[h.island];
         if (status[i] & 2u) {  // the true state could not be installed: the contig as one chunk
             if (!is.whole) {
@@ -1366,15 +1369,16 @@ int ShmmrJob::run_islands(uint64_t need_word) {
         }
         flags_prefetched = false;
         dbg_lap("islands: tile flags on the host");
-        std::vector<uint8_t> &tf = ctx->h_tf_scratch;  // (list_islands marks tiles in its copy; run_exact_islands reuses the image.  Kept: a fresh half megabyte faults in page by page)
-        tf.assign(img + nc, img + nc + n_tiles);
+        // (list_islands marks tiles in the flags it is given: in the pinned image itself, as stage1() does for the early list -- the image
+        // is not read again; a copy of a genome-sized batch's half megabyte was 40 us on the way to the islands' round)
+        uint8_t *tf = img + nc;
         std::vector<uint32_t> flags((const uint32_t *)img, (const uint32_t *)img + n), n_invalid((const uint32_t *)(img + inv_off), (const uint32_t *)(img + inv_off) + n);
         // (cut_margin: a multiple of 64 >= w + k + 64, island_list.h)
         const uint32_t cut_margin = sub_tile ? ((spec.w + spec.k + 64 + 63) / 64) * 64 + 64 : 0;
         // (cut_settle: a multiple of 64 >= 2 w + k + 64; option island_settle for A/B)
         const uint32_t cut_settle = !sub_tile ? 0 : ctx->opt.island_settle > 0 ? (uint32_t)((ctx->opt.island_settle + 63) / 64 * 64)
                                                                               : ((2 * spec.w + spec.k + 64 + 63) / 64) * 64;
-        list_islands(flags.data(), n_invalid.data(), tf.data(), sub_tile ? (const uint16_t *)(img + nc + pal_off) : nullptr, islands, gap_segs, cut_margin,
+        list_islands(flags.data(), n_invalid.data(), tf, sub_tile ? (const uint16_t *)(img + nc + pal_off) : nullptr, islands, gap_segs, cut_margin,
                      cut_settle);
     }
     {
