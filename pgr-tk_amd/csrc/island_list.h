@@ -8,6 +8,10 @@
 // over every tile of every flagged contig) took 0.7 ms of a 2 Gbp batch's 8 -- on the critical path, between the tile kernel's
 // flags and the first round of the islands.  Here the flags are read eight tiles at a time and everything else works on the list
 // of flagged tiles.
+//
+// Round 6: with the tile kernel's report of WHERE in a flagged tile the palindromic k-mers lie (pal: first | last << 8 block of 64
+// core positions) and cut_margin > 0, an island around such an array begins and ends inside the tiles (Island::cutB / cutE /
+// ext_limit); the harness checks the invariants of those cuts on random flag patterns.
 #pragma once
 #include <algorithm>
 #include <cstdint>

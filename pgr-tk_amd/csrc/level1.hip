@@ -17,6 +17,8 @@
 //                              seams.  Runs on islands around what the closed form does not cover: non-ACGT bytes,
 //                              reverse-complement-palindromic k-mers (skipped pushes, shmmrutils.rs:477-480); whole contigs for w < 17.
 //   assemble_chunks_kernel, set_segs_kernel   the lists of the chunks that start in one tile become that tile's segment.
+//   splice_segs_kernel         a tile an island begins or ends INSIDE (round 6): its own elements in front of the island's begin / from
+//                              its end on, spliced with the chunks' lists into one contiguous segment.
 //
 // Integer / byte work only: no MFMA.  The tile kernel is VALU bound (two 64-bit mix hashes per position).
 #include "pgr_device.h"
